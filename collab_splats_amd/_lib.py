@@ -1,0 +1,106 @@
+"""ctypes binding of libmisplat.so (the C ABI declared in include/misplat.h).
+
+There is NO fallback: if the HIP library is missing or a call fails this module raises.  The
+CPU restatements under ``oracle/`` are test infrastructure and are never imported from here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmisplat.so")
+
+MISPLAT_TILE = 16
+MISPLAT_REC = 16
+
+_ERR = {-1: "MISPLAT_EINVAL (bad size / unsupported option)",
+        -2: "MISPLAT_ELAUNCH (kernel launch failed)",
+        -3: "MISPLAT_EWORKSPACE (scratch buffer too small)"}
+
+
+class MisplatError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """Mirror of ``misplat_params`` (include/misplat.h)."""
+    _fields_ = [("n_gauss", C.c_int32), ("n_cams", C.c_int32), ("width", C.c_int32),
+                ("height", C.c_int32), ("tile_size", C.c_int32), ("tile_w", C.c_int32),
+                ("tile_h", C.c_int32), ("antialiased", C.c_int32),
+                ("opacity_aware_radius", C.c_int32), ("eps2d", C.c_float), ("near_plane", C.c_float),
+                ("far_plane", C.c_float), ("radius_clip", C.c_float), ("radius_sigma", C.c_float),
+                ("alpha_max", C.c_float), ("alpha_min", C.c_float), ("t_stop", C.c_float),
+                ("median_t", C.c_float), ("jacobian_margin", C.c_float), ("plane_eps", C.c_float)]
+
+
+def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: int = 16,
+                antialiased: bool = False, opacity_aware_radius: bool = True, eps2d: float = 0.3,
+                near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0,
+                radius_sigma: float = 3.33, alpha_max: float = 0.999, alpha_min: float = 1.0 / 255.0,
+                t_stop: float = 1e-4, median_t: float = 0.5, jacobian_margin: float = 0.3,
+                plane_eps: float = 1e-6) -> Params:
+    if tile_size != MISPLAT_TILE:
+        raise ValueError(f"tile_size must be {MISPLAT_TILE} (got {tile_size})")
+    tw = (width + tile_size - 1) // tile_size
+    th = (height + tile_size - 1) // tile_size
+    return Params(n_gauss, n_cams, width, height, tile_size, tw, th, int(antialiased),
+                  int(opacity_aware_radius), eps2d, near_plane, far_plane, radius_clip, radius_sigma,
+                  alpha_max, alpha_min, t_stop, median_t, jacobian_margin, plane_eps)
+
+
+# name -> (restype, n_args); every symbol include/misplat.h declares
+SYMBOLS = {
+    "misplat_project_fwd": (C.c_int, 16), "misplat_project_bwd": (C.c_int, 18),
+    "misplat_sh_fwd": (C.c_int, 9), "misplat_sh_bwd": (C.c_int, 11),
+    "misplat_tile_count": (C.c_int, 5), "misplat_tile_emit": (C.c_int, 9),
+    "misplat_sort_workspace_bytes": (C.c_size_t, 2), "misplat_sort_pairs": (C.c_int, 9),
+    "misplat_tile_offsets": (C.c_int, 8), "misplat_pack": (C.c_int, 11),
+    "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_bwd": (C.c_int, 19),
+    "misplat_slab_reduce": (C.c_int, 8), "misplat_depth_normal_fwd": (C.c_int, 10),
+    "misplat_depth_normal_bwd": (C.c_int, 13), "misplat_version": (C.c_char_p, 0),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libmisplat.so; raises MisplatError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MisplatError(
+            f"{LIB_PATH} not found: build it with `python -m collab_splats_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, _) in SYMBOLS.items():
+        getattr(lib, name).restype = res
+    _lib = lib
+    return lib
+
+
+def stream_ptr() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_contiguous(), "misplat: tensor must be contiguous"
+    return C.c_void_p(t.data_ptr())
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        raise MisplatError(f"{what} failed: {_ERR.get(code, code)}")
+
+
+def require_gpu(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MisplatError("misplat runs on the MI355X only: got a CPU tensor "
+                               "(there is no CPU fallback; oracle/ is test infrastructure)")

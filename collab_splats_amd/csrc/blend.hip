@@ -1,0 +1,591 @@
+// blend.hip -- per-tile front-to-back alpha compositing (colour, alpha, expected depth, median
+// depth, normal), its backward, the per-Gaussian gradient-row reduction, and the fused
+// depth->normal stencil.  gfx950 (CDNA4) only: 64-lane wavefronts.
+//
+// Replaces the rasterize-to-pixels stage inside gsplat-rade's rasterization(...,
+// return_depth_normal=True) as called at /root/reference/collab_splats/models/rade_gs_model.py:439-465
+//  and camera_utils.py:176-279 + rade_gs_model.py:212-214 (row a4).
+//
+// Design:
+//   * ONE wavefront owns ONE 16x16 tile; each lane owns 4 pixels (x = lane&15, y = lane>>4 + 4k).
+//     No inter-wave barrier exists anywhere, so tiles of very different depth complexity retire
+//     independently and the hardware scheduler does the load balancing.
+//   * Gaussians of the tile are staged 64 at a time into LDS (one 64-byte record per lane,
+//     gathered through the sorted id list, stored quad-major so the stores are conflict-free) and
+//     then broadcast-read (same address in every lane: conflict-free) once per Gaussian for 256
+//     pixels -- a quarter of the LDS traffic of a thread-per-pixel kernel.
+//   * Early termination is a 64-bit __ballot over "all four of my pixels are done".
+//   * Backward: per (tile, Gaussian) the 16 gradient components are summed over the lane's 4
+//     pixels in registers, then over the 64 lanes with a halving butterfly (17 adds instead of 96),
+//     and written as ONE 64-byte row to slab[slot].  slot = emission order, so the rows of a
+//     Gaussian are contiguous and a second kernel sums them in a fixed order: no float atomics
+//     (global atomics run at ~1.3 TB/s on MI355X and are order dependent), bitwise reproducible.
+//   * No MFMA: there is no dense contraction here; the loop is v_exp_f32 + FMA bound.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "misplat.h"
+
+namespace {
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+struct TileCtx {
+    int tile, cam, tx, ty, beg, end;
+    float fx, fy, cx, cy;
+};
+
+// XCD-aware block -> tile map: blocks are dealt round-robin over the 8 XCDs, so give every XCD a
+// contiguous run of tiles (row-major neighbours share Gaussian records in that XCD's L2).
+__device__ __forceinline__ bool tile_ctx(const misplat_params& P, const float* __restrict__ Ks,
+                                         const int32_t* __restrict__ offsets, int64_t n_isects,
+                                         TileCtx& c) {
+    const int tiles_per_cam = P.tile_w * P.tile_h;
+    const int total = tiles_per_cam * P.n_cams;
+    const int per_xcd = (total + 7) >> 3;
+    const int b = blockIdx.x;
+    c.tile = (b & 7) * per_xcd + (b >> 3);
+    if (c.tile >= total) return false;
+    c.cam = c.tile / tiles_per_cam;
+    const int t = c.tile - c.cam * tiles_per_cam;
+    c.ty = t / P.tile_w;
+    c.tx = t - c.ty * P.tile_w;
+    c.beg = offsets[c.tile];
+    c.end = (c.tile + 1 < total) ? offsets[c.tile + 1] : (int)n_isects;
+    c.fx = Ks[9 * c.cam]; c.fy = Ks[9 * c.cam + 4]; c.cx = Ks[9 * c.cam + 2]; c.cy = Ks[9 * c.cam + 5];
+    return true;
+}
+
+// Stage one record per lane, conic pre-multiplied so that vis = exp2(e) with
+// e = cA' dx^2 + cC' dy^2 + cB' dx dy  (= -sigma * log2(e)).
+__device__ __forceinline__ void stage_records(float4* sm, int lane, int i, bool valid,
+                                              const float4* __restrict__ grec,
+                                              const int32_t* __restrict__ flatten_ids) {
+    if (valid) {
+        const int g = flatten_ids[i];
+        float4 q0 = grec[4 * (size_t)g + 0], q1 = grec[4 * (size_t)g + 1];
+        float4 q2 = grec[4 * (size_t)g + 2], q3 = grec[4 * (size_t)g + 3];
+        q0.z *= -0.5f * kLog2e; q0.w *= -kLog2e; q1.x *= -0.5f * kLog2e;
+        sm[lane] = q0; sm[64 + lane] = q1; sm[128 + lane] = q2; sm[192 + lane] = q3;
+    }
+}
+
+template <int CD>
+__global__ __launch_bounds__(64) void blend_fwd_kernel(
+    misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
+    const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ offsets, int64_t n_isects,
+    float* __restrict__ render, float* __restrict__ alpha, float* __restrict__ exp_depth,
+    float* __restrict__ med_depth, float* __restrict__ normal, int32_t* __restrict__ last_ids,
+    int32_t* __restrict__ median_ids) {
+    __shared__ float4 sm[4 * 64];
+    TileCtx c;
+    if (!tile_ctx(P, Ks, offsets, n_isects, c)) return;
+    const int lane = threadIdx.x;
+    const int x = c.tx * MISPLAT_TILE + (lane & 15);
+    const int ybase = c.ty * MISPLAT_TILE + (lane >> 4);
+    const float px = (float)x + 0.5f;
+    const float rxn = (px - c.cx) / c.fx;
+    float py[4], inv_ell[4], T[4], dep[4], med[4], col[4][CD], nrm[4][3];
+    int last[4], medi[4];
+    bool done[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int y = ybase + 4 * k;
+        py[k] = (float)y + 0.5f;
+        const float ryn = (py[k] - c.cy) / c.fy;
+        inv_ell[k] = 1.0f / sqrtf(rxn * rxn + ryn * ryn + 1.0f);
+        done[k] = !(x < P.width && y < P.height);
+        T[k] = 1.0f; dep[k] = 0.f; med[k] = 0.f; last[k] = -1; medi[k] = -1;
+#pragma unroll
+        for (int ch = 0; ch < CD; ch++) col[k][ch] = 0.f;
+        nrm[k][0] = nrm[k][1] = nrm[k][2] = 0.f;
+    }
+    const float amax = P.alpha_max, amin = P.alpha_min, tstop = P.t_stop, tmed = P.median_t;
+
+    for (int bs = c.beg; bs < c.end; bs += 64) {
+        if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
+        __syncthreads();
+        stage_records(sm, lane, bs + lane, bs + lane < c.end, grec, flatten_ids);
+        __syncthreads();
+        const int n = min(64, c.end - bs);
+        for (int j = 0; j < n; j++) {
+            const float4 q0 = sm[j], q1 = sm[64 + j], q2 = sm[128 + j], q3 = sm[192 + j];
+            const int i = bs + j;
+            const float dx = q0.x - px;
+            const float ea = q0.z * dx * dx, eb = q0.w * dx;
+            const float tpx = q1.z - q1.w * dx;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const float dy = q0.y - py[k];
+                const float e = ea + (q1.x * dy + eb) * dy;
+                const float vis = __builtin_amdgcn_exp2f(e);
+                const float a = fminf(amax, q1.y * vis);
+                if (!done[k] && e <= 0.f && a >= amin) {
+                    const float Tn = T[k] * (1.0f - a);
+                    if (Tn <= tstop) {
+                        done[k] = true;
+                    } else {
+                        const float w = a * T[k];
+                        const float zp = (tpx - q2.x * dy) * inv_ell[k];
+                        col[k][0] += w * q3.x; col[k][1] += w * q3.y; col[k][2] += w * q3.z;
+                        if (CD > 3) col[k][CD > 3 ? 3 : 0] += w * q3.w;
+                        dep[k] += w * zp;
+                        nrm[k][0] += w * q2.y; nrm[k][1] += w * q2.z; nrm[k][2] += w * q2.w;
+                        if (T[k] > tmed) { med[k] = zp; medi[k] = i; }
+                        last[k] = i;
+                        T[k] = Tn;
+                    }
+                }
+            }
+            if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int y = ybase + 4 * k;
+        if (x < P.width && y < P.height) {
+            const size_t pid = ((size_t)c.cam * P.height + y) * P.width + x;
+#pragma unroll
+            for (int ch = 0; ch < CD; ch++) render[pid * CD + ch] = col[k][ch];
+            alpha[pid] = 1.0f - T[k];
+            exp_depth[pid] = dep[k];
+            med_depth[pid] = med[k];
+            normal[pid * 3 + 0] = nrm[k][0]; normal[pid * 3 + 1] = nrm[k][1]; normal[pid * 3 + 2] = nrm[k][2];
+            last_ids[pid] = last[k];
+            median_ids[pid] = medi[k];
+        }
+    }
+}
+
+// ---- wave reductions -------------------------------------------------------------------------
+// Halving butterfly over the low 4 lane bits (16 values -> 1 per lane, summed over each 16-lane
+// row), then two plain exchanges over lane bits 4 and 5.  Lane l < 16 ends with component
+// bitrev4(l) summed over all 64 lanes.
+__device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane) {
+    {
+        const bool hi = lane & 1;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float keep = hi ? v[8 + i] : v[i], send = hi ? v[i] : v[8 + i];
+            v[i] = keep + __shfl_xor(send, 1);
+        }
+    }
+    {
+        const bool hi = lane & 2;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float keep = hi ? v[4 + i] : v[i], send = hi ? v[i] : v[4 + i];
+            v[i] = keep + __shfl_xor(send, 2);
+        }
+    }
+    {
+        const bool hi = lane & 4;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const float keep = hi ? v[2 + i] : v[i], send = hi ? v[i] : v[2 + i];
+            v[i] = keep + __shfl_xor(send, 4);
+        }
+    }
+    {
+        const bool hi = lane & 8;
+        const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
+        v[0] = keep + __shfl_xor(send, 8);
+    }
+    float r = v[0];
+    r += __shfl_xor(r, 16);
+    r += __shfl_xor(r, 32);
+    return r;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m));
+    return v;
+}
+
+__device__ __forceinline__ int bitrev4(int l) {
+    return ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);
+}
+
+template <int CD, bool ABS>
+__global__ __launch_bounds__(64) void blend_bwd_kernel(
+    misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
+    const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ slots,
+    const int32_t* __restrict__ offsets, int64_t n_isects, const float* __restrict__ alpha,
+    const int32_t* __restrict__ last_ids, const int32_t* __restrict__ median_ids,
+    const float* __restrict__ v_render, const float* __restrict__ v_alpha,
+    const float* __restrict__ v_exp_depth, const float* __restrict__ v_med_depth,
+    const float* __restrict__ v_normal, float* __restrict__ slab, float* __restrict__ slab_abs) {
+    __shared__ float4 sm[4 * 64];
+    __shared__ int sm_slot[64];
+    TileCtx c;
+    if (!tile_ctx(P, Ks, offsets, n_isects, c)) return;
+    if (c.end <= c.beg) return;
+    const int lane = threadIdx.x;
+    const int x = c.tx * MISPLAT_TILE + (lane & 15);
+    const int ybase = c.ty * MISPLAT_TILE + (lane >> 4);
+    const float px = (float)x + 0.5f;
+    const float rxn = (px - c.cx) / c.fx;
+    float py[4], inv_ell[4], T[4], tfva[4], B[4], vcol[4][CD], vn[4][3], vd[4], vm[4];
+    int last[4], medi[4];
+    int mymax = -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int y = ybase + 4 * k;
+        py[k] = (float)y + 0.5f;
+        const float ryn = (py[k] - c.cy) / c.fy;
+        inv_ell[k] = 1.0f / sqrtf(rxn * rxn + ryn * ryn + 1.0f);
+        last[k] = -1; medi[k] = -1; T[k] = 1.f; tfva[k] = 0.f; B[k] = 0.f; vd[k] = 0.f; vm[k] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < CD; ch++) vcol[k][ch] = 0.f;
+        vn[k][0] = vn[k][1] = vn[k][2] = 0.f;
+        if (x < P.width && y < P.height) {
+            const size_t pid = ((size_t)c.cam * P.height + y) * P.width + x;
+            last[k] = last_ids[pid];
+            medi[k] = median_ids[pid];
+            const float Tf = 1.0f - alpha[pid];
+            T[k] = Tf;
+            tfva[k] = Tf * v_alpha[pid];
+#pragma unroll
+            for (int ch = 0; ch < CD; ch++) vcol[k][ch] = v_render[pid * CD + ch];
+            vn[k][0] = v_normal[pid * 3]; vn[k][1] = v_normal[pid * 3 + 1]; vn[k][2] = v_normal[pid * 3 + 2];
+            vd[k] = v_exp_depth[pid];
+            vm[k] = v_med_depth[pid];
+        }
+        mymax = max(mymax, last[k]);
+    }
+    const int maxlast = wave_max(mymax);
+    const int comp = bitrev4(lane & 15);
+    // rows of entries no pixel reached: zeros
+    for (int i = max(maxlast + 1, c.beg) + (lane >> 4); i < c.end; i += 4) {
+        const size_t s = (size_t)slots[i];
+        slab[s * MISPLAT_REC + (lane & 15)] = 0.f;
+        if (ABS && (lane & 15) < 2) slab_abs[s * 2 + (lane & 15)] = 0.f;
+    }
+    if (maxlast < c.beg) return;
+    // per-lane scale undoing the conic pre-multiplication (component = grec layout index)
+    const float out_scale = (comp == 2 || comp == 4) ? -0.5f * kLog2e : (comp == 3 ? -kLog2e : 1.0f);
+    const float amax = P.alpha_max, amin = P.alpha_min;
+
+    for (int b = (maxlast - c.beg) >> 6; b >= 0; b--) {
+        const int bs = c.beg + (b << 6);
+        const int n = min(64, maxlast + 1 - bs);
+        __syncthreads();
+        stage_records(sm, lane, bs + lane, bs + lane <= maxlast, grec, flatten_ids);
+        if (bs + lane <= maxlast) sm_slot[lane] = slots[bs + lane];
+        __syncthreads();
+        for (int j = n - 1; j >= 0; j--) {
+            const float4 q0 = sm[j], q1 = sm[64 + j], q2 = sm[128 + j], q3 = sm[192 + j];
+            const int i = bs + j;
+            const size_t slot = (size_t)sm_slot[j];
+            const float dx = q0.x - px;
+            const float ea = q0.z * dx * dx, eb = q0.w * dx;
+            const float tpx = q1.z - q1.w * dx;
+            float acc[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            float ab0 = 0.f, ab1 = 0.f;
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (i > last[k]) continue;
+                const float dy = q0.y - py[k];
+                const float e = ea + (q1.x * dy + eb) * dy;
+                const float vis = __builtin_amdgcn_exp2f(e);
+                const float ov = q1.y * vis;
+                const float a = fminf(amax, ov);
+                if (!(e <= 0.f && a >= amin)) continue;
+                any = true;
+                const float ra = __builtin_amdgcn_rcpf(1.0f - a);
+                T[k] *= ra;
+                const float w = a * T[k];
+                const float zp = (tpx - q2.x * dy) * inv_ell[k];
+                float dot = q3.x * vcol[k][0] + q3.y * vcol[k][1] + q3.z * vcol[k][2];
+                if (CD > 3) dot += q3.w * vcol[k][CD > 3 ? 3 : 0];
+                dot += q2.y * vn[k][0] + q2.z * vn[k][1] + q2.w * vn[k][2] + zp * vd[k];
+                const float v_a = (tfva[k] - B[k]) * ra + T[k] * dot;
+                B[k] += w * dot;
+                acc[12] += w * vcol[k][0]; acc[13] += w * vcol[k][1]; acc[14] += w * vcol[k][2];
+                if (CD > 3) acc[15] += w * vcol[k][CD > 3 ? 3 : 0];
+                acc[9] += w * vn[k][0]; acc[10] += w * vn[k][1]; acc[11] += w * vn[k][2];
+                float vz = w * vd[k];
+                if (i == medi[k]) vz += vm[k];
+                const float vzl = vz * inv_ell[k];
+                acc[6] += vzl; acc[7] -= vzl * dx; acc[8] -= vzl * dy;
+                float vmx = -vzl * q1.w, vmy = -vzl * q2.x;
+                if (ov <= amax) {
+                    const float v_e = kLn2 * ov * v_a;
+                    acc[5] += vis * v_a;
+                    acc[2] += dx * dx * v_e; acc[3] += dx * dy * v_e; acc[4] += dy * dy * v_e;
+                    vmx += (2.0f * q0.z * dx + q0.w * dy) * v_e;
+                    vmy += (2.0f * q1.x * dy + q0.w * dx) * v_e;
+                }
+                acc[0] += vmx; acc[1] += vmy;
+                if (ABS) { ab0 += fabsf(vmx); ab1 += fabsf(vmy); }
+            }
+            if (__ballot(any) != 0ull) {
+                const float r = wave_reduce16(acc, lane);
+                if (lane < 16) slab[slot * MISPLAT_REC + comp] = r * out_scale;
+                if (ABS) {
+                    ab0 = wave_sum(ab0); ab1 = wave_sum(ab1);
+                    if (lane == 0) { slab_abs[slot * 2] = ab0; slab_abs[slot * 2 + 1] = ab1; }
+                }
+            } else {
+                if (lane < 16) slab[slot * MISPLAT_REC + lane] = 0.f;
+                if (ABS && lane < 2) slab_abs[slot * 2 + lane] = 0.f;
+            }
+        }
+    }
+}
+
+// 16 lanes per row r: v_grec[r][c] = sum_j slab[cum[r] + j][c] in ascending j (fixed order).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(int64_t n_rows, const int64_t* __restrict__ cum,
+                                                          const int32_t* __restrict__ tiles_per_gauss,
+                                                          const float* __restrict__ slab,
+                                                          const float* __restrict__ slab_abs,
+                                                          float* __restrict__ v_grec,
+                                                          float* __restrict__ v_abs) {
+    const int c = threadIdx.x & 15;
+    for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; r < n_rows;
+         r += ((int64_t)gridDim.x * blockDim.x) >> 4) {
+        const int n = tiles_per_gauss[r];
+        const float* s = slab + (size_t)cum[r] * MISPLAT_REC + c;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        int j = 0;
+        for (; j + 4 <= n; j += 4) {
+            a0 += s[(size_t)(j + 0) * MISPLAT_REC]; a1 += s[(size_t)(j + 1) * MISPLAT_REC];
+            a2 += s[(size_t)(j + 2) * MISPLAT_REC]; a3 += s[(size_t)(j + 3) * MISPLAT_REC];
+        }
+        for (; j < n; j++) a0 += s[(size_t)j * MISPLAT_REC];
+        v_grec[r * MISPLAT_REC + c] = (a0 + a1) + (a2 + a3);
+        if (slab_abs != nullptr && c < 2) {
+            const float* sa = slab_abs + (size_t)cum[r] * 2 + c;
+            float b = 0.f;
+            for (int q = 0; q < n; q++) b += sa[(size_t)q * 2];
+            v_abs[r * 2 + c] = b;
+        }
+    }
+}
+
+// ---- a4: depth -> normal (camera_utils.py:191-279) + error map (rade_gs_model.py:212-214) ------
+struct DN {
+    int W, H;
+    float fx, fy;
+};
+__device__ __forceinline__ void dn_point(const DN& d, const float* __restrict__ depth, int y, int x, float* p) {
+    // rays_d = K^-1 [x+.5, y+.5, 1] with cx = W/2, cy = H/2 (camera_utils.py:211-241)
+    const float z = depth[(size_t)y * d.W + x];
+    p[0] = z * (((float)x + 0.5f) / d.fx - (float)d.W / (2.0f * d.fx));
+    p[1] = z * (((float)y + 0.5f) / d.fy - (float)d.H / (2.0f * d.fy));
+    p[2] = z;
+}
+// normal at interior pixel; returns cross-product vectors for the backward
+__device__ __forceinline__ void dn_normal(const DN& d, const float* __restrict__ depth, int y, int x,
+                                          float* a, float* b, float* cr, float& len, float* n) {
+    float p0[3], p1[3], p2[3], p3[3];
+    dn_point(d, depth, y + 1, x, p0); dn_point(d, depth, y - 1, x, p1);  // "dx": along rows (camera_utils.py:269)
+    dn_point(d, depth, y, x + 1, p2); dn_point(d, depth, y, x - 1, p3);  // "dy": along columns (:270)
+#pragma unroll
+    for (int k = 0; k < 3; k++) { a[k] = p0[k] - p1[k]; b[k] = p2[k] - p3[k]; }
+    cr[0] = a[1] * b[2] - a[2] * b[1];
+    cr[1] = a[2] * b[0] - a[0] * b[2];
+    cr[2] = a[0] * b[1] - a[1] * b[0];
+    len = sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+    const float inv = 1.0f / fmaxf(len, 1e-12f);  // F.normalize eps
+    n[0] = cr[0] * inv; n[1] = cr[1] * inv; n[2] = cr[2] * inv;
+}
+
+__global__ __launch_bounds__(256) void depth_normal_fwd_kernel(DN d, const float* __restrict__ ed,
+                                                               const float* __restrict__ md,
+                                                               const float* __restrict__ nr,
+                                                               float* __restrict__ normals2,
+                                                               float* __restrict__ err) {
+    const size_t P = (size_t)d.W * d.H;
+    for (size_t pid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pid < P; pid += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(pid / d.W), x = (int)(pid - (size_t)y * d.W);
+        const bool interior = x >= 1 && y >= 1 && x < d.W - 1 && y < d.H - 1;
+        const float r0 = nr[pid * 3], r1 = nr[pid * 3 + 1], r2 = nr[pid * 3 + 2];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            float n[3] = {0.f, 0.f, 0.f};
+            if (interior) {
+                float a[3], b[3], cr[3], len;
+                dn_normal(d, k == 0 ? ed : md, y, x, a, b, cr, len, n);
+            }
+            float* o = normals2 + ((size_t)k * P + pid) * 3;
+            o[0] = n[0]; o[1] = n[1]; o[2] = n[2];
+            err[(size_t)k * P + pid] = 1.0f - (r0 * n[0] + r1 * n[1] + r2 * n[2]);
+        }
+    }
+}
+
+// gradient of the normal at interior pixel (yn, xn) w.r.t. its own a (row diff) and b (col diff)
+__device__ __forceinline__ void dn_grad_ab(const DN& d, const float* __restrict__ depth,
+                                           const float* __restrict__ nr, const float* __restrict__ v_n2,
+                                           const float* __restrict__ v_err, int k, int yn, int xn,
+                                           float* va, float* vb) {
+    va[0] = va[1] = va[2] = 0.f; vb[0] = vb[1] = vb[2] = 0.f;
+    if (!(xn >= 1 && yn >= 1 && xn < d.W - 1 && yn < d.H - 1)) return;
+    const size_t P = (size_t)d.W * d.H, pid = (size_t)yn * d.W + xn;
+    float a[3], b[3], cr[3], len, n[3];
+    dn_normal(d, depth, yn, xn, a, b, cr, len, n);
+    float vn[3] = {0.f, 0.f, 0.f};
+    if (v_n2) { const float* s = v_n2 + ((size_t)k * P + pid) * 3; vn[0] = s[0]; vn[1] = s[1]; vn[2] = s[2]; }
+    if (v_err) {
+        const float ve = v_err[(size_t)k * P + pid];
+        vn[0] -= ve * nr[pid * 3]; vn[1] -= ve * nr[pid * 3 + 1]; vn[2] -= ve * nr[pid * 3 + 2];
+    }
+    float vc[3];
+    if (len > 1e-12f) {
+        const float dot = n[0] * vn[0] + n[1] * vn[1] + n[2] * vn[2];
+#pragma unroll
+        for (int q = 0; q < 3; q++) vc[q] = (vn[q] - n[q] * dot) / len;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 3; q++) vc[q] = vn[q] / 1e-12f;
+    }
+    // c = a x b :  v_a = b x v_c,  v_b = v_c x a
+    va[0] = b[1] * vc[2] - b[2] * vc[1]; va[1] = b[2] * vc[0] - b[0] * vc[2]; va[2] = b[0] * vc[1] - b[1] * vc[0];
+    vb[0] = vc[1] * a[2] - vc[2] * a[1]; vb[1] = vc[2] * a[0] - vc[0] * a[2]; vb[2] = vc[0] * a[1] - vc[1] * a[0];
+}
+
+__global__ __launch_bounds__(256) void depth_normal_bwd_kernel(DN d, const float* __restrict__ ed,
+                                                               const float* __restrict__ md,
+                                                               const float* __restrict__ nr,
+                                                               const float* __restrict__ v_n2,
+                                                               const float* __restrict__ v_err,
+                                                               float* __restrict__ v_ed,
+                                                               float* __restrict__ v_md,
+                                                               float* __restrict__ v_nr) {
+    const size_t P = (size_t)d.W * d.H;
+    for (size_t pid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pid < P; pid += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(pid / d.W), x = (int)(pid - (size_t)y * d.W);
+        const float rx = ((float)x + 0.5f) / d.fx - (float)d.W / (2.0f * d.fx);
+        const float ry = ((float)y + 0.5f) / d.fy - (float)d.H / (2.0f * d.fy);
+        const bool interior = x >= 1 && y >= 1 && x < d.W - 1 && y < d.H - 1;
+        float vnr[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const float* depth = k == 0 ? ed : md;
+            // P(y,x) is the +row neighbour of (y-1,x), the -row neighbour of (y+1,x),
+            // the +col neighbour of (y,x-1) and the -col neighbour of (y,x+1)
+            float va[3], vb[3], g[3] = {0.f, 0.f, 0.f};
+            if (y >= 1) { dn_grad_ab(d, depth, nr, v_n2, v_err, k, y - 1, x, va, vb); g[0] += va[0]; g[1] += va[1]; g[2] += va[2]; }
+            if (y + 1 < d.H) { dn_grad_ab(d, depth, nr, v_n2, v_err, k, y + 1, x, va, vb); g[0] -= va[0]; g[1] -= va[1]; g[2] -= va[2]; }
+            if (x >= 1) { dn_grad_ab(d, depth, nr, v_n2, v_err, k, y, x - 1, va, vb); g[0] += vb[0]; g[1] += vb[1]; g[2] += vb[2]; }
+            if (x + 1 < d.W) { dn_grad_ab(d, depth, nr, v_n2, v_err, k, y, x + 1, va, vb); g[0] -= vb[0]; g[1] -= vb[1]; g[2] -= vb[2]; }
+            (k == 0 ? v_ed : v_md)[pid] = g[0] * rx + g[1] * ry + g[2];
+            if (v_err && interior) {
+                float a[3], b[3], cr[3], len, n[3];
+                dn_normal(d, depth, y, x, a, b, cr, len, n);
+                const float ve = v_err[(size_t)k * P + pid];
+                vnr[0] -= ve * n[0]; vnr[1] -= ve * n[1]; vnr[2] -= ve * n[2];
+            }
+        }
+        v_nr[pid * 3] = vnr[0]; v_nr[pid * 3 + 1] = vnr[1]; v_nr[pid * 3 + 2] = vnr[2];
+    }
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH; }
+inline int grid_for(int64_t n, int block) {
+    int64_t b = (n + block - 1) / block;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+inline bool params_ok(const misplat_params* p) {
+    return p && p->tile_size == MISPLAT_TILE && p->n_cams >= 1 && p->width >= 1 && p->height >= 1 &&
+           p->tile_w == (p->width + MISPLAT_TILE - 1) / MISPLAT_TILE &&
+           p->tile_h == (p->height + MISPLAT_TILE - 1) / MISPLAT_TILE;
+}
+
+}  // namespace
+
+extern "C" int misplat_blend_fwd(const misplat_params* p, int32_t color_dim, const float* Ks,
+                                 const float* grec, const int32_t* flatten_ids, const int32_t* offsets,
+                                 int64_t n_isects, float* render, float* alpha, float* exp_depth,
+                                 float* med_depth, float* normal, int32_t* last_ids,
+                                 int32_t* median_ids, misplat_stream_t stream) {
+    if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL) return MISPLAT_EINVAL;
+    const int total = p->tile_w * p->tile_h * p->n_cams;
+    const int grid = ((total + 7) / 8) * 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (color_dim == 3)
+        hipLaunchKernelGGL(blend_fwd_kernel<3>, dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec,
+                           flatten_ids, offsets, n_isects, render, alpha, exp_depth, med_depth, normal,
+                           last_ids, median_ids);
+    else if (color_dim == 4)
+        hipLaunchKernelGGL(blend_fwd_kernel<4>, dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec,
+                           flatten_ids, offsets, n_isects, render, alpha, exp_depth, med_depth, normal,
+                           last_ids, median_ids);
+    else
+        return MISPLAT_EINVAL;
+    return check_launch();
+}
+
+extern "C" int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, const float* Ks,
+                                 const float* grec, const int32_t* flatten_ids,
+                                 const int32_t* slots_sorted, const int32_t* offsets, int64_t n_isects,
+                                 const float* alpha, const int32_t* last_ids, const int32_t* median_ids,
+                                 const float* v_render, const float* v_alpha, const float* v_exp_depth,
+                                 const float* v_med_depth, const float* v_normal, float* slab,
+                                 float* slab_abs, misplat_stream_t stream) {
+    if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL) return MISPLAT_EINVAL;
+    if (n_isects == 0) return MISPLAT_OK;
+    const int total = p->tile_w * p->tile_h * p->n_cams;
+    const int grid = ((total + 7) / 8) * 8;
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_BWD(CD_, ABS_)                                                                              \
+    hipLaunchKernelGGL((blend_bwd_kernel<CD_, ABS_>), dim3(grid), dim3(64), 0, s, *p, Ks,                    \
+                       (const float4*)grec, flatten_ids, slots_sorted, offsets, n_isects, alpha, last_ids, \
+                       median_ids, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, slab, slab_abs)
+    if (color_dim == 3 && slab_abs) LAUNCH_BWD(3, true);
+    else if (color_dim == 3) LAUNCH_BWD(3, false);
+    else if (color_dim == 4 && slab_abs) LAUNCH_BWD(4, true);
+    else if (color_dim == 4) LAUNCH_BWD(4, false);
+    else return MISPLAT_EINVAL;
+#undef LAUNCH_BWD
+    return check_launch();
+}
+
+extern "C" int misplat_slab_reduce(int64_t n_rows, const int64_t* cum, const int32_t* tiles_per_gauss,
+                                   const float* slab, const float* slab_abs, float* v_grec, float* v_abs,
+                                   misplat_stream_t stream) {
+    if (n_rows < 0 || (slab_abs != nullptr) != (v_abs != nullptr)) return MISPLAT_EINVAL;
+    if (n_rows == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n_rows * 16, 256)), dim3(256), 0, (hipStream_t)stream,
+                       n_rows, cum, tiles_per_gauss, slab, slab_abs, v_grec, v_abs);
+    return check_launch();
+}
+
+extern "C" int misplat_depth_normal_fwd(int32_t width, int32_t height, float fx, float fy,
+                                        const float* exp_depth, const float* med_depth,
+                                        const float* n_render, float* normals2, float* err,
+                                        misplat_stream_t stream) {
+    if (width < 1 || height < 1 || !(fx > 0.f) || !(fy > 0.f)) return MISPLAT_EINVAL;
+    DN d{width, height, fx, fy};
+    hipLaunchKernelGGL(depth_normal_fwd_kernel, dim3(grid_for((int64_t)width * height, 256)), dim3(256), 0,
+                       (hipStream_t)stream, d, exp_depth, med_depth, n_render, normals2, err);
+    return check_launch();
+}
+
+extern "C" int misplat_depth_normal_bwd(int32_t width, int32_t height, float fx, float fy,
+                                        const float* exp_depth, const float* med_depth,
+                                        const float* n_render, const float* v_normals2,
+                                        const float* v_err, float* v_exp_depth, float* v_med_depth,
+                                        float* v_n_render, misplat_stream_t stream) {
+    if (width < 1 || height < 1 || !(fx > 0.f) || !(fy > 0.f)) return MISPLAT_EINVAL;
+    DN d{width, height, fx, fy};
+    hipLaunchKernelGGL(depth_normal_bwd_kernel, dim3(grid_for((int64_t)width * height, 256)), dim3(256), 0,
+                       (hipStream_t)stream, d, exp_depth, med_depth, n_render, v_normals2, v_err, v_exp_depth,
+                       v_med_depth, v_n_render);
+    return check_launch();
+}
+
+extern "C" const char* misplat_version(void) { return "misplat 0.1.0 gfx950"; }

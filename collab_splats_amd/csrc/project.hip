@@ -1,0 +1,548 @@
+// project.hip -- per-Gaussian 3D->2D projection (+ RaDe-GS ray-distance plane and normal),
+// forward and backward, and the spherical-harmonics colour kernels.  gfx950 only.
+//
+// Replaces gsplat-rade's fully_fused_projection / spherical_harmonics as called at
+// /root/reference/collab_splats/models/rade_gs_model.py:373-394 and rade_features_model.py:430-434
+// (SURVEY.md section 8 rows a2.1, a2.2).  Math: SURVEY.md Appendix B.
+//
+// This file is compiled with -ffp-contract=off and the forward is written in one fixed IEEE
+// operation order, so radii, tile rectangles and depth bits -- everything that feeds the
+// integer binning stage -- are reproducible bit for bit by an independent fp32 implementation
+// that uses the same order.  These kernels are streaming and HBM-bound (about 44 B read + 60 B
+// written per Gaussian forward); arithmetic is irrelevant to their run time.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "misplat.h"
+
+namespace {
+
+__device__ __forceinline__ float det_log(float x) {
+    // natural log from plain mul/add/div only (deterministic): x = m * 2^e, m in (0.707, 1.414]
+    uint32_t u = __float_as_uint(x);
+    int e = (int)((u >> 23) & 0xffu) - 127;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float s2 = s * s;
+    float p = 0.11111111f;
+    p = p * s2 + 0.14285715f;
+    p = p * s2 + 0.2f;
+    p = p * s2 + 0.33333334f;
+    p = p * s2 + 1.0f;
+    return (float)e * 0.69314718f + 2.0f * s * p;
+}
+
+struct ProjState {
+    float Rc[9], qn[4], qnorm;
+    float mu[3], u, v, tx, ty, limx, limy;
+    int clampx, clampy;
+    float cov[9];
+    float J00, J02, J11, J12;
+    float a0, b0, c0, det0, a, b, c, det, comp;
+    float w[3], p[3], m[3], mnorm, nhat[3], ell, nh;
+    int plane_ok, kmin;
+};
+
+struct Cam {
+    float Rw[9], t[3], fx, fy, cx, cy;
+};
+
+__device__ __forceinline__ Cam load_cam(const float* __restrict__ V, const float* __restrict__ K) {
+    Cam c;
+    c.Rw[0] = V[0]; c.Rw[1] = V[1]; c.Rw[2] = V[2];
+    c.Rw[3] = V[4]; c.Rw[4] = V[5]; c.Rw[5] = V[6];
+    c.Rw[6] = V[8]; c.Rw[7] = V[9]; c.Rw[8] = V[10];
+    c.t[0] = V[3]; c.t[1] = V[7]; c.t[2] = V[11];
+    c.fx = K[0]; c.fy = K[4]; c.cx = K[2]; c.cy = K[5];
+    return c;
+}
+
+__device__ __forceinline__ bool project_one(const float* mean, const float* quat, const float* scale,
+                                            const Cam& cam, const misplat_params& P, ProjState& S) {
+    float n = sqrtf(quat[0] * quat[0] + quat[1] * quat[1] + quat[2] * quat[2] + quat[3] * quat[3]);
+    float r = quat[0] / n, x = quat[1] / n, y = quat[2] / n, z = quat[3] / n;
+    S.qn[0] = r; S.qn[1] = x; S.qn[2] = y; S.qn[3] = z; S.qnorm = n;
+    float Rg[9];
+    Rg[0] = 1.0f - 2.0f * (y * y + z * z); Rg[1] = 2.0f * (x * y - r * z); Rg[2] = 2.0f * (x * z + r * y);
+    Rg[3] = 2.0f * (x * y + r * z); Rg[4] = 1.0f - 2.0f * (x * x + z * z); Rg[5] = 2.0f * (y * z - r * x);
+    Rg[6] = 2.0f * (x * z - r * y); Rg[7] = 2.0f * (y * z + r * x); Rg[8] = 1.0f - 2.0f * (x * x + y * y);
+    const float* Rw = cam.Rw;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        S.mu[i] = Rw[i * 3 + 0] * mean[0] + Rw[i * 3 + 1] * mean[1] + Rw[i * 3 + 2] * mean[2] + cam.t[i];
+    float zc = S.mu[2];
+    if (!(zc >= P.near_plane) || !(zc <= P.far_plane)) return false;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            S.Rc[i * 3 + j] = Rw[i * 3 + 0] * Rg[0 * 3 + j] + Rw[i * 3 + 1] * Rg[1 * 3 + j] + Rw[i * 3 + 2] * Rg[2 * 3 + j];
+    float M[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) M[i * 3 + k] = S.Rc[i * 3 + k] * scale[k];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            S.cov[i * 3 + j] = M[i * 3 + 0] * M[j * 3 + 0] + M[i * 3 + 1] * M[j * 3 + 1] + M[i * 3 + 2] * M[j * 3 + 2];
+    float rz = 1.0f / zc;
+    S.u = S.mu[0] * rz; S.v = S.mu[1] * rz;
+    float tanx = 0.5f * (float)P.width / cam.fx, tany = 0.5f * (float)P.height / cam.fy;
+    float lxp = ((float)P.width - cam.cx) / cam.fx + P.jacobian_margin * tanx;
+    float lxn = cam.cx / cam.fx + P.jacobian_margin * tanx;
+    float lyp = ((float)P.height - cam.cy) / cam.fy + P.jacobian_margin * tany;
+    float lyn = cam.cy / cam.fy + P.jacobian_margin * tany;
+    float uc = S.u, vc = S.v;
+    S.clampx = 0; S.clampy = 0;
+    if (uc > lxp) { uc = lxp; S.clampx = 1; } else if (uc < -lxn) { uc = -lxn; S.clampx = 1; }
+    if (vc > lyp) { vc = lyp; S.clampy = 1; } else if (vc < -lyn) { vc = -lyn; S.clampy = 1; }
+    S.limx = uc; S.limy = vc;
+    S.tx = zc * uc; S.ty = zc * vc;
+    float rz2 = rz * rz;
+    S.J00 = cam.fx * rz; S.J11 = cam.fy * rz;
+    S.J02 = -cam.fx * S.tx * rz2; S.J12 = -cam.fy * S.ty * rz2;
+    const float* c3 = S.cov;
+    float t00 = S.J00 * c3[0] + S.J02 * c3[6], t01 = S.J00 * c3[1] + S.J02 * c3[7], t02 = S.J00 * c3[2] + S.J02 * c3[8];
+    float t11 = S.J11 * c3[4] + S.J12 * c3[7], t12 = S.J11 * c3[5] + S.J12 * c3[8];
+    S.a0 = t00 * S.J00 + t02 * S.J02;
+    S.b0 = t01 * S.J11 + t02 * S.J12;
+    S.c0 = t11 * S.J11 + t12 * S.J12;
+    S.det0 = S.a0 * S.c0 - S.b0 * S.b0;
+    S.a = S.a0 + P.eps2d; S.c = S.c0 + P.eps2d; S.b = S.b0;
+    S.det = S.a * S.c - S.b * S.b;
+    if (!(S.det > 0.0f)) return false;
+    float ratio = S.det0 / S.det;
+    S.comp = sqrtf(ratio > 0.0f ? ratio : 0.0f);
+    return true;
+}
+
+__device__ __forceinline__ void rade_extras(const float* scale, const Cam& cam, const misplat_params& P,
+                                            ProjState& S, float& ray_t, float* ray_plane, float* normal) {
+    int kmin = 0;
+    if (scale[1] < scale[kmin]) kmin = 1;
+    if (scale[2] < scale[kmin]) kmin = 2;
+    S.kmin = kmin;
+    float smin = kmin == 0 ? scale[0] : (kmin == 1 ? scale[1] : scale[2]);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { float q = smin / scale[k]; S.w[k] = q * q; }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        S.p[k] = S.Rc[0 * 3 + k] * S.mu[0] + S.Rc[1 * 3 + k] * S.mu[1] + S.Rc[2 * 3 + k] * S.mu[2];
+    float r0 = S.w[0] * S.p[0], r1 = S.w[1] * S.p[1], r2 = S.w[2] * S.p[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) S.m[i] = S.Rc[i * 3 + 0] * r0 + S.Rc[i * 3 + 1] * r1 + S.Rc[i * 3 + 2] * r2;
+    S.mnorm = sqrtf(S.m[0] * S.m[0] + S.m[1] * S.m[1] + S.m[2] * S.m[2]);
+    float zc = S.mu[2];
+    S.ell = sqrtf(S.u * S.u + S.v * S.v + 1.0f);
+    ray_t = zc * S.ell;
+    S.plane_ok = 0;
+    ray_plane[0] = ray_plane[1] = 0.0f;
+    normal[0] = normal[1] = normal[2] = 0.0f;
+    if (!(S.mnorm > 0.0f)) return;
+#pragma unroll
+    for (int i = 0; i < 3; i++) S.nhat[i] = S.m[i] / S.mnorm;
+    S.nh = S.nhat[0] * S.u + S.nhat[1] * S.v + S.nhat[2];
+    if (!(fabsf(S.nh) >= P.plane_eps) || !isfinite(S.nh)) return;
+    S.plane_ok = 1;
+    float A = zc * S.ell / S.nh;
+    float dtdu = -A * S.nhat[0] + zc * S.u / S.ell;
+    float dtdv = -A * S.nhat[1] + zc * S.v / S.ell;
+    ray_plane[0] = dtdu / cam.fx; ray_plane[1] = dtdv / cam.fy;
+    normal[0] = -S.nhat[0]; normal[1] = -S.nhat[1]; normal[2] = -S.nhat[2];
+}
+
+__global__ __launch_bounds__(256) void project_fwd_kernel(
+    misplat_params P, const float* __restrict__ means, const float* __restrict__ quats,
+    const float* __restrict__ scales, const float* __restrict__ opacities,
+    const float* __restrict__ viewmats, const float* __restrict__ Ks, int32_t* __restrict__ radii,
+    float* __restrict__ means2d, float* __restrict__ depths, float* __restrict__ conics,
+    float* __restrict__ comps, float* __restrict__ ray_ts, float* __restrict__ ray_planes,
+    float* __restrict__ normals) {
+    const int64_t total = (int64_t)P.n_cams * P.n_gauss;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int cam_i = (int)(idx / P.n_gauss);
+        const int g = (int)(idx - (int64_t)cam_i * P.n_gauss);
+        const Cam cam = load_cam(viewmats + 16 * cam_i, Ks + 9 * cam_i);
+        float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+        float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
+        float scale[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+        int32_t rxi = 0, ryi = 0;
+        float mx = 0.f, my = 0.f, dep = 0.f, cn0 = 0.f, cn1 = 0.f, cn2 = 0.f, comp = 0.f, rt = 0.f;
+        float rp[2] = {0.f, 0.f}, nr[3] = {0.f, 0.f, 0.f};
+        ProjState S;
+        bool ok = project_one(mean, quat, scale, cam, P, S);
+        if (ok) {
+            float extend = P.radius_sigma;
+            if (opacities != nullptr && P.opacity_aware_radius) {
+                float o = opacities[g];
+                if (P.antialiased) o = o * S.comp;
+                if (o < P.alpha_min) ok = false;
+                else {
+                    float e2 = sqrtf(2.0f * det_log(o / P.alpha_min));
+                    extend = extend < e2 ? extend : e2;
+                }
+            }
+            if (ok) {
+                float mid = 0.5f * (S.a + S.c);
+                float disc = mid * mid - S.det;
+                float v1 = mid + sqrtf(0.01f > disc ? 0.01f : disc);
+                float sv1 = extend * sqrtf(v1);
+                float ex = extend * sqrtf(S.a), ey = extend * sqrtf(S.c);
+                float rx = ceilf(ex < sv1 ? ex : sv1);
+                float ry = ceilf(ey < sv1 ? ey : sv1);
+                float mxx = cam.fx * S.u + cam.cx, myy = cam.fy * S.v + cam.cy;
+                if (rx <= P.radius_clip && ry <= P.radius_clip) ok = false;
+                else if (mxx + rx <= 0.0f || mxx - rx >= (float)P.width || myy + ry <= 0.0f ||
+                         myy - ry >= (float)P.height) ok = false;
+                if (ok) {
+                    rxi = (int32_t)rx; ryi = (int32_t)ry;
+                    mx = mxx; my = myy; dep = S.mu[2];
+                    cn0 = S.c / S.det; cn1 = -S.b / S.det; cn2 = S.a / S.det;
+                    comp = S.comp;
+                    rade_extras(scale, cam, P, S, rt, rp, nr);
+                }
+            }
+        }
+        radii[2 * idx] = rxi; radii[2 * idx + 1] = ryi;
+        means2d[2 * idx] = mx; means2d[2 * idx + 1] = my;
+        depths[idx] = dep;
+        conics[3 * idx] = cn0; conics[3 * idx + 1] = cn1; conics[3 * idx + 2] = cn2;
+        comps[idx] = comp; ray_ts[idx] = rt;
+        ray_planes[2 * idx] = rp[0]; ray_planes[2 * idx + 1] = rp[1];
+        normals[3 * idx] = nr[0]; normals[3 * idx + 1] = nr[1]; normals[3 * idx + 2] = nr[2];
+    }
+}
+
+// One thread per Gaussian, loop over cameras: gradients summed over cameras in a fixed order.
+__global__ __launch_bounds__(256) void project_bwd_kernel(
+    misplat_params P, const float* __restrict__ means, const float* __restrict__ quats,
+    const float* __restrict__ scales, const float* __restrict__ viewmats,
+    const float* __restrict__ Ks, const int32_t* __restrict__ radii,
+    const float* __restrict__ v_means2d, const float* __restrict__ v_depths,
+    const float* __restrict__ v_conics, const float* __restrict__ v_comps,
+    const float* __restrict__ v_ray_ts, const float* __restrict__ v_ray_planes,
+    const float* __restrict__ v_normals, float* __restrict__ v_means, float* __restrict__ v_quats,
+    float* __restrict__ v_scales) {
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P.n_gauss; g += gridDim.x * blockDim.x) {
+        float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+        float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
+        float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+        float o_m[3] = {0.f, 0.f, 0.f}, o_q[4] = {0.f, 0.f, 0.f, 0.f}, o_s[3] = {0.f, 0.f, 0.f};
+        for (int ci = 0; ci < P.n_cams; ci++) {
+            const int64_t idx = (int64_t)ci * P.n_gauss + g;
+            if (radii[2 * idx] <= 0 && radii[2 * idx + 1] <= 0) continue;
+            const Cam cam = load_cam(viewmats + 16 * ci, Ks + 9 * ci);
+            ProjState S;
+            if (!project_one(mean, quat, sc, cam, P, S)) continue;
+            float rt, rp[2], nr[3];
+            rade_extras(sc, cam, P, S, rt, rp, nr);
+            const float* Rw = cam.Rw;
+            float z = S.mu[2], rz = 1.0f / z, rz2 = rz * rz;
+            float v_mu[3] = {0.f, 0.f, 0.f}, v_u = 0.f, v_v = 0.f, v_s[3] = {0.f, 0.f, 0.f};
+            float v_Rc[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) v_Rc[i] = 0.f;
+            // 1. RaDe extras
+            float v_rt = v_ray_ts[idx];
+            float v_ell = v_rt * z;
+            v_mu[2] += v_rt * S.ell;
+            if (S.plane_ok) {
+                float v_dtdu = v_ray_planes[2 * idx] / cam.fx, v_dtdv = v_ray_planes[2 * idx + 1] / cam.fy;
+                float A = z * S.ell / S.nh;
+                float v_n[3] = {-v_normals[3 * idx], -v_normals[3 * idx + 1], -v_normals[3 * idx + 2]};
+                v_n[0] += -A * v_dtdu; v_n[1] += -A * v_dtdv;
+                float v_A = -(S.nhat[0] * v_dtdu + S.nhat[1] * v_dtdv);
+                v_mu[2] += v_A * S.ell / S.nh;
+                v_ell += v_A * z / S.nh;
+                float v_nh = -v_A * A / S.nh;
+                float uv = S.u * v_dtdu + S.v * v_dtdv;
+                v_mu[2] += uv / S.ell;
+                v_u += z * v_dtdu / S.ell; v_v += z * v_dtdv / S.ell;
+                v_ell += -z * uv / (S.ell * S.ell);
+                v_n[0] += v_nh * S.u; v_n[1] += v_nh * S.v; v_n[2] += v_nh;
+                v_u += v_nh * S.nhat[0]; v_v += v_nh * S.nhat[1];
+                float dotn = S.nhat[0] * v_n[0] + S.nhat[1] * v_n[1] + S.nhat[2] * v_n[2];
+                float v_m[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) v_m[i] = (v_n[i] - S.nhat[i] * dotn) / S.mnorm;
+                float r[3] = {S.w[0] * S.p[0], S.w[1] * S.p[1], S.w[2] * S.p[2]};
+                float v_w[3], v_p[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float v_r = S.Rc[0 * 3 + k] * v_m[0] + S.Rc[1 * 3 + k] * v_m[1] + S.Rc[2 * 3 + k] * v_m[2];
+                    v_w[k] = v_r * S.p[k]; v_p[k] = v_r * S.w[k];
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) v_Rc[i * 3 + k] += v_m[i] * r[k] + S.mu[i] * v_p[k];
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                    v_mu[i] += S.Rc[i * 3 + 0] * v_p[0] + S.Rc[i * 3 + 1] * v_p[1] + S.Rc[i * 3 + 2] * v_p[2];
+                float smin = S.kmin == 0 ? sc[0] : (S.kmin == 1 ? sc[1] : sc[2]);
+                float v_smin = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    v_s[k] += v_w[k] * (-2.0f * smin * smin / (sc[k] * sc[k] * sc[k]));
+                    v_smin += v_w[k] * 2.0f * smin / (sc[k] * sc[k]);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) if (k == S.kmin) v_s[k] += v_smin;
+            }
+            v_u += v_ell * S.u / S.ell; v_v += v_ell * S.v / S.ell;
+            // 2. conic / compensation -> cov2d
+            float v0 = v_conics[3 * idx], v1 = v_conics[3 * idx + 1], v2 = v_conics[3 * idx + 2];
+            float det = S.det, v_det = -(S.c * v0 - S.b * v1 + S.a * v2) / (det * det);
+            float v_det0 = 0.f;
+            if (S.det0 / det > 0.f && S.comp > 0.f) {
+                float v_ratio = v_comps[idx] / (2.0f * S.comp);
+                v_det0 = v_ratio / det;
+                v_det += -v_ratio * S.det0 / (det * det);
+            }
+            float v_a = v2 / det + v_det * S.c, v_c = v0 / det + v_det * S.a, v_b = -v1 / det - 2.0f * S.b * v_det;
+            float G00 = v_a + v_det0 * S.c0, G11 = v_c + v_det0 * S.a0, G01 = 0.5f * (v_b - 2.0f * S.b0 * v_det0);
+            // 3. cov2d = J cov J^T
+            float Jm[6] = {S.J00, 0.f, S.J02, 0.f, S.J11, S.J12};
+            float GJ[6];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { GJ[k] = G00 * Jm[k] + G01 * Jm[3 + k]; GJ[3 + k] = G01 * Jm[k] + G11 * Jm[3 + k]; }
+            float v_cov[9];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) v_cov[i * 3 + j] = Jm[i] * GJ[j] + Jm[3 + i] * GJ[3 + j];
+            float v_J[6];
+#pragma unroll
+            for (int r_ = 0; r_ < 2; r_++)
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    v_J[r_ * 3 + k] = 2.0f * (GJ[r_ * 3 + 0] * S.cov[0 * 3 + k] + GJ[r_ * 3 + 1] * S.cov[1 * 3 + k] + GJ[r_ * 3 + 2] * S.cov[2 * 3 + k]);
+            v_mu[2] += -v_J[0] * cam.fx * rz2 - v_J[4] * cam.fy * rz2;
+            float v_tx = -v_J[2] * cam.fx * rz2, v_ty = -v_J[5] * cam.fy * rz2;
+            v_mu[2] += 2.0f * v_J[2] * cam.fx * S.tx * rz2 * rz + 2.0f * v_J[5] * cam.fy * S.ty * rz2 * rz;
+            if (S.clampx) v_mu[2] += v_tx * S.limx; else v_mu[0] += v_tx;
+            if (S.clampy) v_mu[2] += v_ty * S.limy; else v_mu[1] += v_ty;
+            // 4. mean2d, depth
+            v_u += cam.fx * v_means2d[2 * idx]; v_v += cam.fy * v_means2d[2 * idx + 1];
+            v_mu[0] += v_u * rz; v_mu[1] += v_v * rz;
+            v_mu[2] += -(v_u * S.u + v_v * S.v) * rz;
+            v_mu[2] += v_depths[idx];
+            // 5. cov = M M^T, M = Rc diag(s)
+            float M[9];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) M[i * 3 + k] = S.Rc[i * 3 + k] * sc[k];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    float acc = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 3; j++) acc += (v_cov[i * 3 + j] + v_cov[j * 3 + i]) * M[j * 3 + k];
+                    v_Rc[i * 3 + k] += acc * sc[k];
+                    v_s[k] += acc * S.Rc[i * 3 + k];
+                }
+            float w_[9];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    w_[i * 3 + k] = Rw[0 * 3 + i] * v_Rc[0 * 3 + k] + Rw[1 * 3 + i] * v_Rc[1 * 3 + k] + Rw[2 * 3 + i] * v_Rc[2 * 3 + k];
+            float qr = S.qn[0], qx = S.qn[1], qy = S.qn[2], qz = S.qn[3];
+            float vq[4];
+            vq[0] = 2.0f * (-qz * w_[1] + qy * w_[2] + qz * w_[3] - qx * w_[5] - qy * w_[6] + qx * w_[7]);
+            vq[1] = 2.0f * (qy * w_[1] + qz * w_[2] + qy * w_[3] - 2.0f * qx * w_[4] - qr * w_[5] + qz * w_[6] + qr * w_[7] - 2.0f * qx * w_[8]);
+            vq[2] = 2.0f * (-2.0f * qy * w_[0] + qx * w_[1] + qr * w_[2] + qx * w_[3] + qz * w_[5] - qr * w_[6] + qz * w_[7] - 2.0f * qy * w_[8]);
+            vq[3] = 2.0f * (-2.0f * qz * w_[0] - qr * w_[1] + qx * w_[2] + qr * w_[3] - 2.0f * qz * w_[4] + qy * w_[5] + qx * w_[6] + qy * w_[7]);
+            float dq = S.qn[0] * vq[0] + S.qn[1] * vq[1] + S.qn[2] * vq[2] + S.qn[3] * vq[3];
+#pragma unroll
+            for (int k = 0; k < 4; k++) o_q[k] += (vq[k] - S.qn[k] * dq) / S.qnorm;
+#pragma unroll
+            for (int i = 0; i < 3; i++) o_m[i] += Rw[0 * 3 + i] * v_mu[0] + Rw[1 * 3 + i] * v_mu[1] + Rw[2 * 3 + i] * v_mu[2];
+#pragma unroll
+            for (int k = 0; k < 3; k++) o_s[k] += v_s[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v_means[3 * g + k] = o_m[k]; v_scales[3 * g + k] = o_s[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) v_quats[4 * g + k] = o_q[k];
+    }
+}
+
+// ------------------------------------------------------------------ spherical harmonics
+constexpr float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+__device__ constexpr float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
+__device__ constexpr float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+template <bool GRAD>
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* b, float* bx, float* by, float* bz) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) { b[k] = 0.f; if (GRAD) { bx[k] = 0.f; by[k] = 0.f; bz[k] = 0.f; } }
+    b[0] = C0;
+    if (deg > 0) {
+        b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
+        if (GRAD) { by[1] = -C1; bz[2] = C1; bx[3] = -C1; }
+    }
+    if (deg > 1) {
+        float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        b[4] = C2[0] * xy; b[5] = C2[1] * yz; b[6] = C2[2] * (2.f * zz - xx - yy); b[7] = C2[3] * xz; b[8] = C2[4] * (xx - yy);
+        if (GRAD) {
+            bx[4] = C2[0] * y; by[4] = C2[0] * x;
+            by[5] = C2[1] * z; bz[5] = C2[1] * y;
+            bx[6] = -2.f * C2[2] * x; by[6] = -2.f * C2[2] * y; bz[6] = 4.f * C2[2] * z;
+            bx[7] = C2[3] * z; bz[7] = C2[3] * x;
+            bx[8] = 2.f * C2[4] * x; by[8] = -2.f * C2[4] * y;
+        }
+        if (deg > 2) {
+            b[9] = C3[0] * y * (3.f * xx - yy); b[10] = C3[1] * xy * z; b[11] = C3[2] * y * (4.f * zz - xx - yy);
+            b[12] = C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy); b[13] = C3[4] * x * (4.f * zz - xx - yy);
+            b[14] = C3[5] * z * (xx - yy); b[15] = C3[6] * x * (xx - 3.f * yy);
+            if (GRAD) {
+                bx[9] = 6.f * C3[0] * xy; by[9] = C3[0] * (3.f * xx - 3.f * yy);
+                bx[10] = C3[1] * yz; by[10] = C3[1] * xz; bz[10] = C3[1] * xy;
+                bx[11] = -2.f * C3[2] * xy; by[11] = C3[2] * (4.f * zz - xx - 3.f * yy); bz[11] = 8.f * C3[2] * yz;
+                bx[12] = -6.f * C3[3] * xz; by[12] = -6.f * C3[3] * yz; bz[12] = C3[3] * (6.f * zz - 3.f * xx - 3.f * yy);
+                bx[13] = C3[4] * (4.f * zz - 3.f * xx - yy); by[13] = -2.f * C3[4] * xy; bz[13] = 8.f * C3[4] * xz;
+                bx[14] = 2.f * C3[5] * xz; by[14] = -2.f * C3[5] * yz; bz[14] = C3[5] * (xx - yy);
+                bx[15] = C3[6] * (3.f * xx - 3.f * yy); by[15] = -6.f * C3[6] * xy;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sh_fwd_kernel(int n_gauss, int n_cams, int K, int deg,
+                                                     const float* __restrict__ dirs,
+                                                     const float* __restrict__ coeffs,
+                                                     const int32_t* __restrict__ radii,
+                                                     float* __restrict__ colors) {
+    const int64_t total = (int64_t)n_gauss * n_cams;
+    const int nb = (deg + 1) * (deg + 1);
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        if (radii == nullptr || radii[2 * idx] > 0 || radii[2 * idx + 1] > 0) {
+            const int g = (int)(idx % n_gauss);
+            float dx = dirs[3 * idx], dy = dirs[3 * idx + 1], dz = dirs[3 * idx + 2];
+            float n = sqrtf(dx * dx + dy * dy + dz * dz);
+            float inv = n > 0.f ? 1.0f / n : 0.f;
+            float b[16];
+            sh_basis<false>(deg, dx * inv, dy * inv, dz * inv, b, nullptr, nullptr, nullptr);
+            const float* cf = coeffs + (size_t)g * K * 3;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (k < nb) { c0 += b[k] * cf[3 * k]; c1 += b[k] * cf[3 * k + 1]; c2 += b[k] * cf[3 * k + 2]; }
+        }
+        colors[3 * idx] = c0; colors[3 * idx + 1] = c1; colors[3 * idx + 2] = c2;
+    }
+}
+
+__global__ __launch_bounds__(256) void sh_bwd_kernel(int n_gauss, int n_cams, int K, int deg,
+                                                     const float* __restrict__ dirs,
+                                                     const float* __restrict__ coeffs,
+                                                     const int32_t* __restrict__ radii,
+                                                     const float* __restrict__ v_colors,
+                                                     float* __restrict__ v_coeffs,
+                                                     float* __restrict__ v_dirs) {
+    const int nb = (deg + 1) * (deg + 1);
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < n_gauss; g += gridDim.x * blockDim.x) {
+        float acc[48];
+#pragma unroll
+        for (int k = 0; k < 48; k++) acc[k] = 0.f;
+        const float* cf = coeffs + (size_t)g * K * 3;
+        for (int ci = 0; ci < n_cams; ci++) {
+            const int64_t idx = (int64_t)ci * n_gauss + g;
+            float vd0 = 0.f, vd1 = 0.f, vd2 = 0.f, x = 0.f, y = 0.f, z = 0.f, inv = 0.f;
+            if (radii == nullptr || radii[2 * idx] > 0 || radii[2 * idx + 1] > 0) {
+                float dx = dirs[3 * idx], dy = dirs[3 * idx + 1], dz = dirs[3 * idx + 2];
+                float n = sqrtf(dx * dx + dy * dy + dz * dz);
+                inv = n > 0.f ? 1.0f / n : 0.f;
+                x = dx * inv; y = dy * inv; z = dz * inv;
+                float b[16], bx[16], by[16], bz[16];
+                sh_basis<true>(deg, x, y, z, b, bx, by, bz);
+                float vc0 = v_colors[3 * idx], vc1 = v_colors[3 * idx + 1], vc2 = v_colors[3 * idx + 2];
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    if (k < nb) {
+                        acc[3 * k] += b[k] * vc0; acc[3 * k + 1] += b[k] * vc1; acc[3 * k + 2] += b[k] * vc2;
+                        float s = cf[3 * k] * vc0 + cf[3 * k + 1] * vc1 + cf[3 * k + 2] * vc2;
+                        vd0 += bx[k] * s; vd1 += by[k] * s; vd2 += bz[k] * s;
+                    }
+            }
+            float dot = x * vd0 + y * vd1 + z * vd2;
+            v_dirs[3 * idx] = (vd0 - x * dot) * inv;
+            v_dirs[3 * idx + 1] = (vd1 - y * dot) * inv;
+            v_dirs[3 * idx + 2] = (vd2 - z * dot) * inv;
+        }
+        float* o = v_coeffs + (size_t)g * K * 3;
+        for (int k = 0; k < K; k++) {
+            if (k < 16 && k < nb) { o[3 * k] = acc[3 * k]; o[3 * k + 1] = acc[3 * k + 1]; o[3 * k + 2] = acc[3 * k + 2]; }
+            else { o[3 * k] = 0.f; o[3 * k + 1] = 0.f; o[3 * k + 2] = 0.f; }
+        }
+    }
+}
+
+inline int grid_for(int64_t n, int block) {
+    int64_t b = (n + block - 1) / block;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+inline int check_launch() { return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH; }
+
+}  // namespace
+
+extern "C" int misplat_project_fwd(const misplat_params* p, const float* means, const float* quats,
+                                   const float* scales, const float* opacities, const float* viewmats,
+                                   const float* Ks, int32_t* radii, float* means2d, float* depths,
+                                   float* conics, float* compensations, float* ray_ts,
+                                   float* ray_planes, float* normals, misplat_stream_t stream) {
+    if (!p || p->n_gauss < 0 || p->n_cams < 1 || p->width < 1 || p->height < 1) return MISPLAT_EINVAL;
+    int64_t total = (int64_t)p->n_gauss * p->n_cams;
+    if (total == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(project_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *p,
+                       means, quats, scales, opacities, viewmats, Ks, radii, means2d, depths, conics,
+                       compensations, ray_ts, ray_planes, normals);
+    return check_launch();
+}
+
+extern "C" int misplat_project_bwd(const misplat_params* p, const float* means, const float* quats,
+                                   const float* scales, const float* viewmats, const float* Ks,
+                                   const int32_t* radii, const float* v_means2d, const float* v_depths,
+                                   const float* v_conics, const float* v_compensations,
+                                   const float* v_ray_ts, const float* v_ray_planes,
+                                   const float* v_normals, float* v_means, float* v_quats,
+                                   float* v_scales, misplat_stream_t stream) {
+    if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
+    if (p->n_gauss == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(project_bwd_kernel, dim3(grid_for(p->n_gauss, 256)), dim3(256), 0, (hipStream_t)stream,
+                       *p, means, quats, scales, viewmats, Ks, radii, v_means2d, v_depths, v_conics,
+                       v_compensations, v_ray_ts, v_ray_planes, v_normals, v_means, v_quats, v_scales);
+    return check_launch();
+}
+
+extern "C" int misplat_sh_fwd(int32_t n_gauss, int32_t n_cams, int32_t K, int32_t degree,
+                              const float* dirs, const float* coeffs, const int32_t* radii,
+                              float* colors, misplat_stream_t stream) {
+    if (n_gauss < 0 || n_cams < 1 || degree < 0 || degree > 3 || K < (degree + 1) * (degree + 1)) return MISPLAT_EINVAL;
+    int64_t total = (int64_t)n_gauss * n_cams;
+    if (total == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(sh_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, n_gauss,
+                       n_cams, K, degree, dirs, coeffs, radii, colors);
+    return check_launch();
+}
+
+extern "C" int misplat_sh_bwd(int32_t n_gauss, int32_t n_cams, int32_t K, int32_t degree,
+                              const float* dirs, const float* coeffs, const int32_t* radii,
+                              const float* v_colors, float* v_coeffs, float* v_dirs,
+                              misplat_stream_t stream) {
+    if (n_gauss < 0 || n_cams < 1 || degree < 0 || degree > 3 || K < (degree + 1) * (degree + 1)) return MISPLAT_EINVAL;
+    if (n_gauss == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(sh_bwd_kernel, dim3(grid_for(n_gauss, 256)), dim3(256), 0, (hipStream_t)stream, n_gauss,
+                       n_cams, K, degree, dirs, coeffs, radii, v_colors, v_coeffs, v_dirs);
+    return check_launch();
+}

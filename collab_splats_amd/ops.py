@@ -1,0 +1,278 @@
+"""Autograd-wrapped calls into libmisplat.so (HIP, gfx950).
+
+Python here is plumbing only: it allocates tensors (so PyTorch's caching allocator and current
+stream are respected), passes raw pointers through the C ABI of include/misplat.h, and raises on
+any non-zero status.  Names and tuple layouts mirror gsplat-rade's ``gsplat.cuda._wrapper`` as the
+reference calls it (/root/reference/collab_splats/models/rade_gs_model.py:373-394,
+rade_features_model.py:430-434).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from ._lib import MISPLAT_REC, Params, check, ptr, require_gpu, stream_ptr
+
+
+def _c(t: Optional[Tensor]) -> Optional[Tensor]:
+    return None if t is None else t.contiguous()
+
+
+def _f32(t: Tensor, name: str) -> Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (the reference trains in fp32, "
+                        f"rade_gs_method.py:31); got {t.dtype}")
+    return t.contiguous()
+
+
+# ----------------------------------------------------------------------------- projection
+
+class _Project(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, viewmats, Ks, P: Params):
+        lib = _lib.load()
+        require_gpu(means, quats, scales, viewmats, Ks)
+        N, Cn = P.n_gauss, P.n_cams
+        dev = means.device
+        f = dict(device=dev, dtype=torch.float32)
+        radii = torch.empty(Cn, N, 2, device=dev, dtype=torch.int32)
+        means2d = torch.empty(Cn, N, 2, **f)
+        depths = torch.empty(Cn, N, **f)
+        conics = torch.empty(Cn, N, 3, **f)
+        comps = torch.empty(Cn, N, **f)
+        ray_ts = torch.empty(Cn, N, **f)
+        ray_planes = torch.empty(Cn, N, 2, **f)
+        normals = torch.empty(Cn, N, 3, **f)
+        check(lib.misplat_project_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
+                                      ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
+                                      ptr(conics), ptr(comps), ptr(ray_ts), ptr(ray_planes), ptr(normals),
+                                      stream_ptr()), "misplat_project_fwd")
+        ctx.P = P
+        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii)
+        ctx.mark_non_differentiable(radii)
+        return radii, means2d, depths, conics, comps, ray_ts, ray_planes, normals
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, v_ray_ts, v_ray_planes, v_normals):
+        lib = _lib.load()
+        means, quats, scales, viewmats, Ks, radii = ctx.saved_tensors
+        P = ctx.P
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        g = [_c(t) for t in (v_means2d, v_depths, v_conics, v_comps, v_ray_ts, v_ray_planes, v_normals)]
+        check(lib.misplat_project_bwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
+                                      ptr(radii), *[ptr(t) for t in g], ptr(v_means), ptr(v_quats),
+                                      ptr(v_scales), stream_ptr()), "misplat_project_bwd")
+        return v_means, v_quats, v_scales, None, None, None, None
+
+
+def project(means: Tensor, quats: Tensor, scales: Tensor, opacities: Optional[Tensor], viewmats: Tensor,
+            Ks: Tensor, P: Params):
+    """8-tuple (radii, means2d, depths, conics, compensations, ray_ts, ray_planes, normals)."""
+    means, quats, scales = _f32(means, "means"), _f32(quats, "quats"), _f32(scales, "scales")
+    viewmats, Ks = _f32(viewmats, "viewmats"), _f32(Ks, "Ks")
+    op = None if opacities is None else _f32(opacities.detach(), "opacities")
+    return _Project.apply(means, quats, scales, op, viewmats, Ks, P)
+
+
+# ----------------------------------------------------------------------------- SH
+
+class _SphericalHarmonics(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dirs, coeffs, degree: int, radii):
+        lib = _lib.load()
+        require_gpu(dirs, coeffs)
+        N, K = coeffs.shape[0], coeffs.shape[1]
+        Cn = dirs.numel() // (3 * N) if N > 0 else 1
+        colors = torch.empty(dirs.shape[:-1] + (3,), device=dirs.device, dtype=torch.float32)
+        check(lib.misplat_sh_fwd(C.c_int32(N), C.c_int32(Cn), C.c_int32(K), C.c_int32(degree), ptr(dirs),
+                                 ptr(coeffs), ptr(radii), ptr(colors), stream_ptr()), "misplat_sh_fwd")
+        ctx.save_for_backward(dirs, coeffs, radii)
+        ctx.degree, ctx.Cn = degree, Cn
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        lib = _lib.load()
+        dirs, coeffs, radii = ctx.saved_tensors
+        N, K = coeffs.shape[0], coeffs.shape[1]
+        v_coeffs = torch.empty_like(coeffs)
+        v_dirs = torch.empty_like(dirs)
+        check(lib.misplat_sh_bwd(C.c_int32(N), C.c_int32(ctx.Cn), C.c_int32(K), C.c_int32(ctx.degree),
+                                 ptr(dirs), ptr(coeffs), ptr(radii), ptr(_c(v_colors)), ptr(v_coeffs),
+                                 ptr(v_dirs), stream_ptr()), "misplat_sh_bwd")
+        return v_dirs, v_coeffs, None, None
+
+
+def spherical_harmonics_raw(degree: int, dirs: Tensor, coeffs: Tensor, radii: Optional[Tensor] = None) -> Tensor:
+    """dirs [..., N, 3] (C leading cameras allowed), coeffs [N, K, 3] -> [..., N, 3]; raw SH."""
+    if coeffs.dim() != 3 or coeffs.shape[-1] != 3:
+        raise ValueError(f"coeffs must be [N, K, 3], got {tuple(coeffs.shape)}")
+    if dirs.shape[-2:] != (coeffs.shape[0], 3):
+        raise ValueError(f"dirs {tuple(dirs.shape)} does not match coeffs {tuple(coeffs.shape)}")
+    if not 0 <= degree <= 3 or (degree + 1) ** 2 > coeffs.shape[1]:
+        raise ValueError(f"degree {degree} needs {(degree + 1) ** 2} <= K={coeffs.shape[1]} and degree <= 3")
+    r = None if radii is None else radii.contiguous()
+    return _SphericalHarmonics.apply(_f32(dirs, "dirs"), _f32(coeffs, "coeffs"), int(degree), r)
+
+
+# ----------------------------------------------------------------------------- binning
+
+@torch.no_grad()
+def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor) -> Dict[str, Tensor]:
+    """Tile intersection + sort + offsets.  One host read-back: n_isects."""
+    lib = _lib.load()
+    dev = means2d.device
+    total = P.n_gauss * P.n_cams
+    n_tiles = P.tile_w * P.tile_h * P.n_cams
+    tiles_per_gauss = torch.empty(total, device=dev, dtype=torch.int32)
+    check(lib.misplat_tile_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), stream_ptr()),
+          "misplat_tile_count")
+    incl = torch.cumsum(tiles_per_gauss, dim=0, dtype=torch.int64)
+    n_isects = int(incl[-1].item()) if total > 0 else 0          # the one unavoidable sync
+    if n_isects >= 2 ** 31:
+        raise _lib.MisplatError(f"{n_isects} tile intersections exceed int32 indexing")
+    cum = (incl - tiles_per_gauss).contiguous()                    # exclusive scan, int64
+    keys = torch.empty(n_isects, device=dev, dtype=torch.int64)
+    slots = torch.empty(n_isects, device=dev, dtype=torch.int32)
+    isect_gid = torch.empty(n_isects, device=dev, dtype=torch.int32)
+    keys_s = torch.empty_like(keys)
+    slots_s = torch.empty_like(slots)
+    flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
+    offsets = torch.empty(n_tiles, device=dev, dtype=torch.int32)
+    if n_isects > 0:
+        check(lib.misplat_tile_emit(C.byref(P), ptr(means2d), ptr(radii), ptr(depths), ptr(cum), ptr(keys),
+                                    ptr(slots), ptr(isect_gid), stream_ptr()), "misplat_tile_emit")
+        end_bit = 32 + max(1, (n_tiles - 1).bit_length())
+        ws_bytes = int(lib.misplat_sort_workspace_bytes(C.c_int64(n_isects), C.c_int32(end_bit)))
+        if ws_bytes == 0:
+            raise _lib.MisplatError("misplat_sort_workspace_bytes failed")
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        check(lib.misplat_sort_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(keys), ptr(keys_s), ptr(slots),
+                                     ptr(slots_s), C.c_int64(n_isects), C.c_int32(end_bit), stream_ptr()),
+              "misplat_sort_pairs")
+    check(lib.misplat_tile_offsets(ptr(keys_s), ptr(slots_s), ptr(isect_gid), C.c_int64(n_isects),
+                                   C.c_int32(n_tiles), ptr(offsets), ptr(flatten_ids), stream_ptr()),
+          "misplat_tile_offsets")
+    return dict(tiles_per_gauss=tiles_per_gauss, cum=cum, isect_ids=keys_s, slots=slots_s,
+                flatten_ids=flatten_ids, isect_offsets=offsets, n_isects=n_isects)
+
+
+# ----------------------------------------------------------------------------- blending
+
+class _Blend(torch.autograd.Function):
+    """Compositing of <= 4 colour channels + alpha + expected/median depth + normal."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Params,
+                bins: Dict[str, Tensor], absgrad: bool):
+        lib = _lib.load()
+        require_gpu(means2d)
+        Cn, N, H, W = P.n_cams, P.n_gauss, P.height, P.width
+        cd = colors.shape[-1]
+        dev = means2d.device
+        rows = Cn * N
+        grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
+        check(lib.misplat_pack(C.c_int64(rows), C.c_int32(cd), ptr(means2d), ptr(conics), ptr(opac),
+                               ptr(ray_ts), ptr(ray_planes), ptr(normals), ptr(colors), ptr(grec),
+                               stream_ptr()), "misplat_pack")
+        f = dict(device=dev, dtype=torch.float32)
+        render = torch.empty(Cn, H, W, cd, **f)
+        alpha = torch.empty(Cn, H, W, 1, **f)
+        exp_depth = torch.empty(Cn, H, W, 1, **f)
+        med_depth = torch.empty(Cn, H, W, 1, **f)
+        normal = torch.empty(Cn, H, W, 3, **f)
+        last_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
+        median_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
+        check(lib.misplat_blend_fwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
+                                    ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(render),
+                                    ptr(alpha), ptr(exp_depth), ptr(med_depth), ptr(normal), ptr(last_ids),
+                                    ptr(median_ids), stream_ptr()), "misplat_blend_fwd")
+        ctx.P, ctx.bins, ctx.absgrad, ctx.cd = P, bins, absgrad, cd
+        ctx.means2d_ref = means2d if absgrad else None
+        ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids)
+        ctx.mark_non_differentiable(last_ids, median_ids)
+        return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
+
+    @staticmethod
+    def backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, _l, _m):
+        lib = _lib.load()
+        grec, Ks, alpha, last_ids, median_ids = ctx.saved_tensors
+        P, bins, cd = ctx.P, ctx.bins, ctx.cd
+        n_isects = bins["n_isects"]
+        rows = P.n_cams * P.n_gauss
+        dev = grec.device
+        slab = torch.empty(max(n_isects, 1), MISPLAT_REC, device=dev, dtype=torch.float32)
+        slab_abs = torch.empty(max(n_isects, 1), 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
+        check(lib.misplat_blend_bwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
+                                    ptr(bins["slots"]), ptr(bins["isect_offsets"]), C.c_int64(n_isects),
+                                    ptr(alpha), ptr(last_ids), ptr(median_ids), ptr(_c(v_render)),
+                                    ptr(_c(v_alpha)), ptr(_c(v_exp_depth)), ptr(_c(v_med_depth)),
+                                    ptr(_c(v_normal)), ptr(slab), ptr(slab_abs), stream_ptr()),
+              "misplat_blend_bwd")
+        v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
+        v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
+        check(lib.misplat_slab_reduce(C.c_int64(rows), ptr(bins["cum"]), ptr(bins["tiles_per_gauss"]),
+                                      ptr(slab), ptr(slab_abs), ptr(v_grec), ptr(v_abs), stream_ptr()),
+              "misplat_slab_reduce")
+        Cn, N = P.n_cams, P.n_gauss
+        g = v_grec.view(Cn, N, MISPLAT_REC)
+        if ctx.absgrad:
+            # gsplat convention: the 2-D |gradient| rides on the means2d tensor for the strategy
+            ctx.means2d_ref.absgrad = v_abs.view(Cn, N, 2)
+        return (g[..., 0:2], g[..., 2:5], g[..., 5], g[..., 12:12 + cd], g[..., 6], g[..., 7:9],
+                g[..., 9:12], None, None, None, None)
+
+
+def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Params, bins, absgrad=False):
+    if colors.shape[-1] < 1 or colors.shape[-1] > 4:
+        raise ValueError("blend() takes 1..4 colour channels per pass")
+    args = [_f32(t, n) for t, n in ((means2d, "means2d"), (conics, "conics"), (opac, "opacities"),
+                                    (colors, "colors"), (ray_ts, "ray_ts"), (ray_planes, "ray_planes"),
+                                    (normals, "normals"), (Ks, "Ks"))]
+    if args[0] is not means2d:
+        raise ValueError("means2d must be contiguous float32 so that its .grad/.absgrad can be retained")
+    return _Blend.apply(*args, P, bins, bool(absgrad))
+
+
+# ----------------------------------------------------------------------------- depth -> normal
+
+class _DepthNormal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, exp_depth, med_depth, n_render, fx: float, fy: float):
+        lib = _lib.load()
+        require_gpu(exp_depth, med_depth, n_render)
+        H, W = exp_depth.shape[-2], exp_depth.shape[-1]
+        dev = exp_depth.device
+        normals2 = torch.empty(2, H, W, 3, device=dev, dtype=torch.float32)
+        err = torch.empty(2, H, W, device=dev, dtype=torch.float32)
+        check(lib.misplat_depth_normal_fwd(C.c_int32(W), C.c_int32(H), C.c_float(fx), C.c_float(fy),
+                                           ptr(exp_depth), ptr(med_depth), ptr(n_render), ptr(normals2),
+                                           ptr(err), stream_ptr()), "misplat_depth_normal_fwd")
+        ctx.save_for_backward(exp_depth, med_depth, n_render)
+        ctx.fx, ctx.fy = fx, fy
+        return normals2, err
+
+    @staticmethod
+    def backward(ctx, v_normals2, v_err):
+        lib = _lib.load()
+        ed, md, nr = ctx.saved_tensors
+        H, W = ed.shape[-2], ed.shape[-1]
+        v_ed, v_md, v_nr = torch.empty_like(ed), torch.empty_like(md), torch.empty_like(nr)
+        check(lib.misplat_depth_normal_bwd(C.c_int32(W), C.c_int32(H), C.c_float(ctx.fx), C.c_float(ctx.fy),
+                                           ptr(ed), ptr(md), ptr(nr), ptr(_c(v_normals2)), ptr(_c(v_err)),
+                                           ptr(v_ed), ptr(v_md), ptr(v_nr), stream_ptr()),
+              "misplat_depth_normal_bwd")
+        return v_ed, v_md, v_nr, None, None
+
+
+def depth_normal(exp_depth: Tensor, med_depth: Tensor, n_render: Tensor, fx: float, fy: float):
+    """Fused camera_utils.depth_double_to_normal + error map.  exp/med_depth [H,W], n_render [H,W,3]
+    -> (normals2 [2,H,W,3], err [2,H,W])."""
+    return _DepthNormal.apply(_f32(exp_depth, "exp_depth"), _f32(med_depth, "med_depth"),
+                              _f32(n_render, "n_render"), float(fx), float(fy))

@@ -1,0 +1,144 @@
+"""``rasterization(...)`` -- drop-in for ``gsplat.rendering.rasterization`` of gsplat-rade as the
+reference calls it (/root/reference/collab_splats/models/rade_gs_model.py:439-465,
+rade_features_model.py:450-476), running on hand-written HIP kernels for MI355X (gfx950).
+
+Keyword surface and return arity follow SURVEY.md Appendix A.1: with
+``return_depth_normal=True`` the result is the 6-tuple
+``(render[C,H,W,D'], alpha[C,H,W,1], expected_depths[C,H,W,1], median_depths[C,H,W,1],
+expected_normals[C,H,W,3], meta)``; otherwise gsplat's 3-tuple ``(render, alpha, meta)``.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from . import ops
+from ._lib import MisplatError, make_params
+
+_RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
+
+
+def rasterization(
+    means: Tensor,                    # [N, 3]
+    quats: Tensor,                    # [N, 4] wxyz, un-normalised
+    scales: Tensor,                   # [N, 3] (already exp'd, rade_gs_model.py:443)
+    opacities: Tensor,                # [N]    (already sigmoid'ed, :444)
+    colors: Tensor,                   # [N, K, 3] SH coeffs | [N, D] | [C, N, D]
+    viewmats: Tensor,                 # [C, 4, 4] world->camera, OpenCV axes
+    Ks: Tensor,                       # [C, 3, 3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = False,
+    tile_size: int = 16,
+    backgrounds: Optional[Tensor] = None,
+    render_mode: str = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: str = "classic",
+    channel_chunk: int = 32,
+    distributed: bool = False,
+    camera_model: str = "pinhole",
+    covars: Optional[Tensor] = None,
+    return_depth_normal: bool = False,
+    # open parameters of SURVEY.md Appendix B (see DESIGN.md "Numerical choices")
+    radius_sigma: float = 3.33,
+    opacity_aware_radius: bool = True,
+    alpha_max: float = 0.999,
+    normalise_expected_depth: bool = False,
+):
+    if render_mode not in _RENDER_MODES:
+        raise ValueError(f"Unknown render_mode: {render_mode}")
+    if rasterize_mode not in ("classic", "antialiased"):
+        raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")   # cf. rade_gs_model.py:150-151
+    if packed or sparse_grad:
+        raise NotImplementedError("packed=True / sparse_grad=True are not on the reference's path "
+                                  "(it passes packed=False, sparse_grad=False: rade_gs_model.py:450, 455)")
+    if distributed or camera_model != "pinhole" or covars is not None:
+        raise NotImplementedError("only camera_model='pinhole', covars=None, distributed=False")
+    N = means.shape[0]
+    Cn = viewmats.shape[0]
+    assert means.shape == (N, 3), means.shape
+    assert quats.shape == (N, 4), quats.shape
+    assert scales.shape == (N, 3), scales.shape
+    assert opacities.shape == (N,), opacities.shape
+    assert viewmats.shape == (Cn, 4, 4), viewmats.shape
+    assert Ks.shape == (Cn, 3, 3), Ks.shape
+    if sh_degree is None:
+        assert (colors.dim() == 2 and colors.shape[0] == N) or (colors.dim() == 3 and colors.shape[:2] == (Cn, N)), colors.shape
+    else:
+        assert colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3, colors.shape
+        assert (sh_degree + 1) ** 2 <= colors.shape[1], colors.shape
+    if not means.is_cuda:
+        raise MisplatError("rasterization() runs on the MI355X only (no CPU fallback)")
+    width, height = int(width), int(height)
+    aa = rasterize_mode == "antialiased"
+    P = make_params(N, Cn, width, height, tile_size=tile_size, antialiased=aa,
+                    opacity_aware_radius=opacity_aware_radius, eps2d=eps2d, near_plane=near_plane,
+                    far_plane=far_plane, radius_clip=radius_clip, radius_sigma=radius_sigma,
+                    alpha_max=alpha_max)
+    viewmats = viewmats.contiguous().float()
+    Ks = Ks.contiguous().float()
+
+    # a2.1 projection (+ RaDe ray-distance plane and normal)
+    radii, means2d, depths, conics, comps, ray_ts, ray_planes, normals = ops.project(
+        means, quats, scales, opacities, viewmats, Ks, P)
+    opac = opacities[None, :].expand(Cn, N)
+    opac = opac * comps if aa else opac.contiguous()
+
+    # a2.2 colour
+    if sh_degree is not None:
+        cam_centers = -torch.einsum("cji,cj->ci", viewmats[:, :3, :3], viewmats[:, :3, 3])   # -R^T t
+        dirs = means[None, :, :] - cam_centers[:, None, :]
+        cols = ops.spherical_harmonics_raw(sh_degree, dirs, colors, radii)
+        cols = torch.clamp_min(cols + 0.5, 0.0)                  # rade_features_model.py:438
+    else:
+        cols = colors if colors.dim() == 3 else colors[None].expand(Cn, N, colors.shape[-1])
+    if render_mode in ("RGB+D", "RGB+ED"):
+        cols = torch.cat([cols, depths[..., None]], dim=-1)
+    elif render_mode in ("D", "ED"):
+        cols = depths[..., None]
+    cols = cols.contiguous()
+    D = cols.shape[-1]
+
+    # a2.3 binning
+    bins = ops.bin_tiles(P, means2d, radii, depths)
+
+    # a2.4 compositing, 4 colour channels per pass (the geometry outputs come from pass 0)
+    renders = []
+    first = None
+    for s in range(0, D, 4):
+        out = ops.blend(means2d, conics, opac, cols[..., s:s + 4], ray_ts, ray_planes, normals, Ks, P, bins,
+                        absgrad=absgrad and s == 0)
+        renders.append(out[0])
+        if first is None:
+            first = out
+    render = renders[0] if len(renders) == 1 else torch.cat(renders, dim=-1)
+    alpha, exp_depth, med_depth, exp_normal = first[1], first[2], first[3], first[4]
+
+    if render_mode in ("ED", "RGB+ED"):
+        render = torch.cat([render[..., :-1], render[..., -1:] / alpha.clamp(min=1e-10)], dim=-1)
+    if normalise_expected_depth:
+        exp_depth = exp_depth / alpha.clamp(min=1e-10)
+    if backgrounds is not None:
+        render = render + (1.0 - alpha) * backgrounds[:, None, None, :]
+
+    meta = {
+        "camera_ids": None, "gaussian_ids": None,
+        "radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
+        "compensations": comps, "ray_ts": ray_ts, "ray_planes": ray_planes, "normals": normals,
+        "tile_width": P.tile_w, "tile_height": P.tile_h, "tiles_per_gauss": bins["tiles_per_gauss"].view(Cn, N),
+        "isect_ids": bins["isect_ids"], "flatten_ids": bins["flatten_ids"],
+        "isect_offsets": bins["isect_offsets"].view(Cn, P.tile_h, P.tile_w),
+        "n_isects": bins["n_isects"], "last_ids": first[5], "median_ids": first[6],
+        "width": width, "height": height, "tile_size": tile_size, "n_cameras": Cn,
+    }
+    if return_depth_normal:
+        return render, alpha, exp_depth, med_depth, exp_normal, meta
+    return render, alpha, meta

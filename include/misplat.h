@@ -1,0 +1,174 @@
+/* misplat.h -- C ABI of libmisplat.so: the MI355X (gfx950) RaDe-GS splat rasterizer.
+ *
+ * This is the drop-in boundary for the one hot path BASELINE.json's north_star names.
+ * The reference (BasisResearch/collab-splats) has NO native code and no FFI of its own
+ * (SURVEY.md section 2.1): the path leaves the repo through three Python entry points of the
+ * third-party CUDA package gsplat-rade:
+ *     gsplat.rendering.rasterization(...)             collab_splats/models/rade_gs_model.py:439-465
+ *                                                     collab_splats/models/rade_features_model.py:450-476
+ *     gsplat.cuda._wrapper.fully_fused_projection(...) collab_splats/models/rade_gs_model.py:373-394
+ *     gsplat.cuda._wrapper.spherical_harmonics(...)    collab_splats/models/rade_features_model.py:430-434
+ * plus the pure-PyTorch depth->normal stage    collab_splats/utils/camera_utils.py:176-279.
+ * The functions below are what those Python entry points bind in this build (ctypes stub in
+ * collab_splats_amd/_lib.py; the reference-side binding is shown in INTEGRATION.md).  Each entry
+ * names the stage of the replaced call it implements.
+ *
+ * Rules (all entry points):
+ *   - plain device pointers and sizes only; the caller (PyTorch) owns and allocates every
+ *     buffer including scratch, so the caching allocator and stream order are respected;
+ *   - asynchronous on `stream`; no hidden synchronisation, no allocation, no host read-back;
+ *   - return 0 on success, a negative MISPLAT_E* code otherwise; never throws;
+ *   - re-entrant: no mutable global state;
+ *   - all floating point is fp32 (reference: mixed_precision=False,
+ *     collab_splats/configs/rade_gs_method.py:31); indices int32; sort keys uint64.
+ */
+#ifndef MISPLAT_H
+#define MISPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* misplat_stream_t; /* == hipStream_t */
+
+#define MISPLAT_OK 0
+#define MISPLAT_EINVAL (-1)      /* bad size / unsupported option (tile_size != 16, colour dim) */
+#define MISPLAT_ELAUNCH (-2)     /* hipGetLastError() after a launch was not hipSuccess */
+#define MISPLAT_EWORKSPACE (-3)  /* scratch buffer too small */
+
+#define MISPLAT_TILE 16          /* pixels per tile side (gsplat default tile_size)          */
+#define MISPLAT_REC 16           /* floats per packed Gaussian record / per gradient row      */
+
+/* Scalar configuration of one call (host memory, passed by pointer, copied at launch). */
+typedef struct misplat_params {
+    int32_t n_gauss;   /* N */
+    int32_t n_cams;    /* C (the reference always uses 1: rade_gs_model.py:94-95, 446-447) */
+    int32_t width, height;
+    int32_t tile_size; /* must be MISPLAT_TILE */
+    int32_t tile_w, tile_h;
+    int32_t antialiased;          /* rasterize_mode == "antialiased" (rade_gs_model.py:459) */
+    int32_t opacity_aware_radius; /* tighten the extent to the alpha_min level set */
+    float eps2d;          /* 0.3   rade_gs_model.py:382 */
+    float near_plane;     /* 0.01  rade_gs_model.py:451 */
+    float far_plane;      /* 1e10  rade_gs_model.py:452 */
+    float radius_clip;    /* 0.0   rade_gs_model.py:386 */
+    float radius_sigma;   /* 3.33 */
+    float alpha_max;      /* 0.999 */
+    float alpha_min;      /* 1/255 */
+    float t_stop;         /* 1e-4 */
+    float median_t;       /* 0.5 */
+    float jacobian_margin;/* 0.3 */
+    float plane_eps;      /* 1e-6 */
+} misplat_params;
+
+/* ---- a2.1 projection: fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, ...)
+ * (rade_gs_model.py:373-394).  Inputs: means[N,3] quats[N,4] (wxyz, un-normalised) scales[N,3]
+ * opacities[N] or NULL, viewmats[C,4,4] row-major world->camera, Ks[C,3,3].
+ * Outputs, all [C,N,...]: radii int32[.,2], means2d[.,2], depths[.], conics[.,3],
+ * compensations[.], ray_ts[.], ray_planes[.,2], normals[.,3]; rows with radii==0 are zero. */
+int misplat_project_fwd(const misplat_params* p, const float* means, const float* quats,
+                        const float* scales, const float* opacities, const float* viewmats,
+                        const float* Ks, int32_t* radii, float* means2d, float* depths,
+                        float* conics, float* compensations, float* ray_ts, float* ray_planes,
+                        float* normals, misplat_stream_t stream);
+
+/* Backward of the above.  v_* inputs are [C,N,...] gradients of the eight outputs (radii has
+ * none); outputs v_means[N,3], v_quats[N,4], v_scales[N,3] are summed over cameras and fully
+ * overwritten. */
+int misplat_project_bwd(const misplat_params* p, const float* means, const float* quats,
+                        const float* scales, const float* viewmats, const float* Ks,
+                        const int32_t* radii, const float* v_means2d, const float* v_depths,
+                        const float* v_conics, const float* v_compensations,
+                        const float* v_ray_ts, const float* v_ray_planes, const float* v_normals,
+                        float* v_means, float* v_quats, float* v_scales, misplat_stream_t stream);
+
+/* ---- a2.2 SH: spherical_harmonics(degrees_to_use, dirs, coeffs) (rade_features_model.py:430-434).
+ * dirs[C*N,3] (normalised inside), coeffs[N,K,3] shared by the C cameras, radii[C*N,2] or NULL
+ * (rows with radii==0 are skipped and get colour 0), colors[C*N,3] = raw SH (no +0.5). */
+int misplat_sh_fwd(int32_t n_gauss, int32_t n_cams, int32_t K, int32_t degree, const float* dirs,
+                   const float* coeffs, const int32_t* radii, float* colors,
+                   misplat_stream_t stream);
+int misplat_sh_bwd(int32_t n_gauss, int32_t n_cams, int32_t K, int32_t degree, const float* dirs,
+                   const float* coeffs, const int32_t* radii, const float* v_colors,
+                   float* v_coeffs /*[N,K,3]*/, float* v_dirs /*[C*N,3]*/,
+                   misplat_stream_t stream);
+
+/* ---- a2.3 binning.  tiles_per_gauss[C*N] = number of 16x16 tiles the rect mean2d +- radii
+ * touches (0 if culled). */
+int misplat_tile_count(const misplat_params* p, const float* means2d, const int32_t* radii,
+                       int32_t* tiles_per_gauss, misplat_stream_t stream);
+/* cum[C*N] = EXCLUSIVE prefix sum of tiles_per_gauss (int64).  Writes, for every intersection j
+ * in emission order (ascending camera, Gaussian id, then row-major tiles):
+ * keys[j] = ((cam*tile_w*tile_h + tile) << 32) | bits(depth), slot_ids[j] = j,
+ * isect_gid[j] = cam*N + gid. */
+int misplat_tile_emit(const misplat_params* p, const float* means2d, const int32_t* radii,
+                      const float* depths, const int64_t* cum, uint64_t* keys, int32_t* slot_ids,
+                      int32_t* isect_gid, misplat_stream_t stream);
+/* Stable ascending radix sort of (key, value) pairs on bits [0, end_bit). */
+size_t misplat_sort_workspace_bytes(int64_t n_isects, int32_t end_bit);
+int misplat_sort_pairs(void* workspace, size_t workspace_bytes, const uint64_t* keys_in,
+                       uint64_t* keys_out, const int32_t* vals_in, int32_t* vals_out,
+                       int64_t n_isects, int32_t end_bit, misplat_stream_t stream);
+/* offsets[t] = first sorted position whose tile is >= t (t over C*tile_w*tile_h);
+ * flatten_ids[i] = isect_gid[slots_sorted[i]]. */
+int misplat_tile_offsets(const uint64_t* keys_sorted, const int32_t* slots_sorted,
+                         const int32_t* isect_gid, int64_t n_isects, int32_t n_tiles_total,
+                         int32_t* offsets, int32_t* flatten_ids, misplat_stream_t stream);
+
+/* ---- a2.4 / a2.5 compositing.  Packed record per (camera, Gaussian), MISPLAT_REC floats:
+ *   [0:2] mean2d  [2:5] conic  [5] opacity_eff  [6] ray_t  [7:9] ray_plane  [9:12] normal
+ *   [12:16] colour channels 0..3 (unused channels zero).                         */
+int misplat_pack(int64_t n_rows, int32_t color_dim, const float* means2d, const float* conics,
+                 const float* opacities_eff, const float* ray_ts, const float* ray_planes,
+                 const float* normals, const float* colors, float* grec, misplat_stream_t stream);
+
+/* Forward: one wavefront per 16x16 tile, 4 pixels per lane.  Outputs [C,H,W,...]:
+ * render[.,color_dim], alpha[.], exp_depth[.] (sum w*z, un-normalised), med_depth[.],
+ * normal[.,3], last_ids[.], median_ids[.] (sorted positions; -1 = none).  color_dim in {3,4}. */
+int misplat_blend_fwd(const misplat_params* p, int32_t color_dim, const float* Ks,
+                      const float* grec, const int32_t* flatten_ids, const int32_t* offsets,
+                      int64_t n_isects, float* render, float* alpha, float* exp_depth,
+                      float* med_depth, float* normal, int32_t* last_ids, int32_t* median_ids,
+                      misplat_stream_t stream);
+
+/* Backward: re-traverses each tile back to front and writes ONE gradient row (same layout as
+ * the record) per intersection to slab[slot] (slot = position in emission order, so the rows of
+ * one Gaussian are contiguous); every slot of every tile range is written (zeros where nothing
+ * contributed), no atomics.  slab_abs[n_isects,2] (or NULL) receives sum |dL/dmean2d|. */
+int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, const float* Ks,
+                      const float* grec, const int32_t* flatten_ids, const int32_t* slots_sorted,
+                      const int32_t* offsets, int64_t n_isects, const float* alpha,
+                      const int32_t* last_ids, const int32_t* median_ids, const float* v_render,
+                      const float* v_alpha, const float* v_exp_depth, const float* v_med_depth,
+                      const float* v_normal, float* slab, float* slab_abs,
+                      misplat_stream_t stream);
+/* v_grec[r] = sum of slab rows [cum[r], cum[r]+tiles_per_gauss[r]); fixed order => bitwise
+ * reproducible.  v_abs[n_rows,2] likewise from slab_abs (both may be NULL together). */
+int misplat_slab_reduce(int64_t n_rows, const int64_t* cum, const int32_t* tiles_per_gauss,
+                        const float* slab, const float* slab_abs, float* v_grec, float* v_abs,
+                        misplat_stream_t stream);
+
+/* ---- a4 depth->normal (camera_utils.py:176-279) fused with the error map of
+ * rade_gs_model.py:212-214: n_d = normalize(cross(dP/drow, dP/dcol)) of the back-projected
+ * expected / median z-depth maps (interior pixels; border 0), err[k] = 1 - <n_render, n_d[k]>.
+ * depths: exp_depth[H,W], med_depth[H,W]; n_render[H,W,3]; outputs normals2[2,H,W,3], err[2,H,W]. */
+int misplat_depth_normal_fwd(int32_t width, int32_t height, float fx, float fy,
+                             const float* exp_depth, const float* med_depth,
+                             const float* n_render, float* normals2, float* err,
+                             misplat_stream_t stream);
+int misplat_depth_normal_bwd(int32_t width, int32_t height, float fx, float fy,
+                             const float* exp_depth, const float* med_depth,
+                             const float* n_render, const float* v_normals2 /*or NULL*/,
+                             const float* v_err /*or NULL*/, float* v_exp_depth,
+                             float* v_med_depth, float* v_n_render, misplat_stream_t stream);
+
+/* Library identification ("misplat <version> gfx950"). */
+const char* misplat_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISPLAT_H */

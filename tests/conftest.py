@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def built_lib():
+    """libmisplat.so, built once (hipcc cross-compiles without a GPU)."""
+    from collab_splats_amd.build import build
+    return build()
+
+
+@pytest.fixture(scope="session")
+def craster():
+    from oracle import craster as cr
+    cr.build()
+    return cr
