@@ -18,6 +18,29 @@ from . import _lib
 from ._lib import MISPLAT_REC, Params, check, ptr, require_gpu, stream_ptr
 
 
+# Optional per-kernel timing (bench.py): name -> list of (start_event, end_event) recorded on the
+# current stream, i.e. the stream the kernels are launched on.  None = off (no events recorded).
+KERNEL_EVENTS: Optional[Dict[str, list]] = None
+
+
+class _timed:
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if KERNEL_EVENTS is not None:
+            self.e1.record()
+            KERNEL_EVENTS.setdefault(self.name, []).append((self.e0, self.e1))
+        return False
+
+
 def _c(t: Optional[Tensor]) -> Optional[Tensor]:
     return None if t is None else t.contiguous()
 
@@ -189,10 +212,11 @@ class _Blend(torch.autograd.Function):
         normal = torch.empty(Cn, H, W, 3, **f)
         last_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
         median_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
-        check(lib.misplat_blend_fwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
-                                    ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(render),
-                                    ptr(alpha), ptr(exp_depth), ptr(med_depth), ptr(normal), ptr(last_ids),
-                                    ptr(median_ids), stream_ptr()), "misplat_blend_fwd")
+        with _timed("blend_fwd"):
+            check(lib.misplat_blend_fwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
+                                        ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(render),
+                                        ptr(alpha), ptr(exp_depth), ptr(med_depth), ptr(normal), ptr(last_ids),
+                                        ptr(median_ids), stream_ptr()), "misplat_blend_fwd")
         ctx.P, ctx.bins, ctx.absgrad, ctx.cd = P, bins, absgrad, cd
         ctx.means2d_ref = means2d if absgrad else None
         ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids)
@@ -209,12 +233,12 @@ class _Blend(torch.autograd.Function):
         dev = grec.device
         slab = torch.empty(max(n_isects, 1), MISPLAT_REC, device=dev, dtype=torch.float32)
         slab_abs = torch.empty(max(n_isects, 1), 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
-        check(lib.misplat_blend_bwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
-                                    ptr(bins["slots"]), ptr(bins["isect_offsets"]), C.c_int64(n_isects),
-                                    ptr(alpha), ptr(last_ids), ptr(median_ids), ptr(_c(v_render)),
-                                    ptr(_c(v_alpha)), ptr(_c(v_exp_depth)), ptr(_c(v_med_depth)),
-                                    ptr(_c(v_normal)), ptr(slab), ptr(slab_abs), stream_ptr()),
-              "misplat_blend_bwd")
+        ups = [_c(t) for t in (v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)]
+        with _timed("blend_bwd"):
+            check(lib.misplat_blend_bwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
+                                        ptr(bins["slots"]), ptr(bins["isect_offsets"]), C.c_int64(n_isects),
+                                        ptr(alpha), ptr(last_ids), ptr(median_ids), *[ptr(t) for t in ups],
+                                        ptr(slab), ptr(slab_abs), stream_ptr()), "misplat_blend_bwd")
         v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
         v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
         check(lib.misplat_slab_reduce(C.c_int64(rows), ptr(bins["cum"]), ptr(bins["tiles_per_gauss"]),

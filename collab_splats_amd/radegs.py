@@ -1,0 +1,296 @@
+"""Host-side mirror of the reference's RaDe-GS model path around the rasterizer.
+
+Reproduces, with the reference's names, argument meaning and error behaviour:
+  a1  ``RadegsModel._get_camera_parameters`` + ``convert_to_colmap_camera``
+      (/root/reference/collab_splats/models/rade_gs_model.py:311-346, utils/camera_utils.py:74-135)
+  a3  ``RadegsModel.get_outputs`` post-processing (rade_gs_model.py:200-272)
+  a4  ``depth_double_to_normal`` (camera_utils.py:176-279) -- one fused HIP stencil kernel
+  a5  ``RadegsModel.get_loss_dict`` depth-normal term (rade_gs_model.py:289-307)
+  a6  ``RadegsModel.normals`` / ``build_rotation`` (rade_gs_model.py:65-78, camera_utils.py:138-168)
+  a7  ``RadegsModel._prefilter_voxel`` (rade_gs_model.py:348-399)
+The reference's Python does not travel to the GPU box and depends on nerfstudio (absent), so this
+module is the build's own counterpart; nerfstudio's ``Cameras`` is duck-typed (only
+``camera_to_worlds``, ``width``, ``height``, ``get_intrinsics_matrices()``, ``shape`` are touched by
+the reference: camera_utils.py:76-88, rade_gs_model.py:94-95, 135).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Union
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from . import ops
+from ._lib import make_params
+from .rendering import rasterization
+from .strategy import DefaultStrategy
+
+
+# ----------------------------------------------------------------------------- cameras (a1)
+
+@dataclass
+class PinholeCamera:
+    """Duck-type of the nerfstudio ``Cameras`` attributes the reference touches."""
+    camera_to_worlds: Tensor          # [1, 3, 4], OpenGL axes (nerfstudio convention)
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    width: Tensor                     # [[W]]
+    height: Tensor                    # [[H]]
+    metadata: Optional[dict] = None
+
+    @classmethod
+    def make(cls, camera_to_worlds: Tensor, fx: float, fy: float, width: int, height: int,
+             cx: Optional[float] = None, cy: Optional[float] = None) -> "PinholeCamera":
+        c2w = camera_to_worlds.reshape(1, 3, 4)
+        return cls(c2w, float(fx), float(fy), width / 2.0 if cx is None else float(cx),
+                   height / 2.0 if cy is None else float(cy), torch.tensor([[int(width)]]),
+                   torch.tensor([[int(height)]]))
+
+    @property
+    def shape(self):
+        return (self.camera_to_worlds.shape[0],)
+
+    def get_intrinsics_matrices(self) -> Tensor:
+        K = torch.tensor([[self.fx, 0.0, self.cx], [0.0, self.fy, self.cy], [0.0, 0.0, 1.0]])
+        return K[None].to(self.camera_to_worlds.device)
+
+    def rescale_output_resolution(self, scale: float) -> None:
+        if scale == 1 or scale == 1.0:
+            return
+        self.fx *= scale; self.fy *= scale; self.cx *= scale; self.cy *= scale
+        self.width = (self.width * scale).to(torch.int64)
+        self.height = (self.height * scale).to(torch.int64)
+
+
+def focal2fov(focal: float, pixels: float) -> float:
+    """camera_utils.py:134-135."""
+    return 2 * math.atan(pixels / (2 * focal))
+
+
+def camera_parameters(camera, device: Optional[torch.device] = None) -> Dict[str, Union[Tensor, int, float]]:
+    """``_get_camera_parameters`` (rade_gs_model.py:311-346) without the reference's host syncs.
+
+    nerfstudio c2w (OpenGL) -> OpenCV world->camera: flip the y/z camera axes (camera_utils.py:79),
+    invert (for the rigid c2w the inverse is [R^T | -R^T t], which is what ``torch.linalg.inv``
+    returns up to rounding; :82-84, 94-105), rebuild ``Ks`` from the field of view with the
+    principal point FORCED to the image centre (rade_gs_model.py:322-334).
+    """
+    c2w = camera.camera_to_worlds[0].to(torch.float32)                  # [3,4]
+    device = device or c2w.device
+    W, H = int(camera.width.item()), int(camera.height.item())
+    K = camera.get_intrinsics_matrices()
+    fovx = focal2fov(float(K[0, 0, 0]), W)
+    fovy = focal2fov(float(K[0, 1, 1]), H)
+    fx = W / (2 * math.tan(fovx * 0.5))
+    fy = H / (2 * math.tan(fovy * 0.5))
+    flip = torch.tensor([1.0, -1.0, -1.0], dtype=torch.float32, device=c2w.device)
+    Rc = c2w[:3, :3] * flip[None, :]                                      # c2w[:3, 1:3] *= -1
+    Rw = Rc.transpose(0, 1)
+    t = -(Rw @ c2w[:3, 3])
+    viewmat = torch.eye(4, dtype=torch.float32, device=c2w.device)
+    viewmat[:3, :3] = Rw
+    viewmat[:3, 3] = t
+    Ks = torch.tensor([[fx, 0.0, W / 2.0], [0.0, fy, H / 2.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    return {"Ks": Ks[None].to(device), "viewmats": viewmat[None].to(device), "image_width": W,
+            "image_height": H, "camera_center": c2w[:3, 3].to(device), "fx": fx, "fy": fy}
+
+
+def build_rotation(quats: Tensor) -> Tensor:
+    """wxyz -> [N,3,3]; normalised inside (camera_utils.py:138-168)."""
+    q = quats / torch.sqrt((quats * quats).sum(dim=-1, keepdim=True))
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], dim=-1)
+    return R.reshape(-1, 3, 3)
+
+
+def depth_double_to_normal(camera_or_params, depth1: Tensor, depth2: Tensor) -> Tensor:
+    """camera_utils.py:176-188: two z-depth maps [1,H,W,1] -> normals [2,H,W,3] (HIP stencil)."""
+    cp = camera_or_params if isinstance(camera_or_params, dict) else camera_parameters(camera_or_params)
+    H, W = cp["image_height"], cp["image_width"]
+    zeros = torch.zeros(H, W, 3, device=depth1.device, dtype=torch.float32)
+    normals2, _ = ops.depth_normal(depth1.reshape(H, W), depth2.reshape(H, W), zeros, cp["fx"], cp["fy"])
+    return normals2
+
+
+# ----------------------------------------------------------------------------- model
+
+@dataclass
+class RadegsModelConfig:
+    """The hot-path fields of the reference's config (rade_gs_model.py:29-55 + the Splatfacto
+    fields ``get_outputs`` reads)."""
+    regularization_from_iter: int = 15000
+    use_depth_normal_loss: bool = True
+    depth_normal_lambda: float = 0.05
+    depth_ratio: float = 0.6
+    render_mode: str = "RGB"
+    prefilter_voxel: bool = False
+    sh_degree: int = 3
+    sh_degree_interval: int = 1000
+    rasterize_mode: str = "classic"
+    output_depth_during_training: bool = False
+    background_color: str = "black"
+    absgrad: bool = False
+
+
+class RadegsModel(nn.Module):
+    """Gaussian parameters + the reference's ``get_outputs`` / ``get_loss_dict`` for the hot path.
+
+    Parameter names match the reference's ``gauss_params`` (rade_gs_model.py:110-122) so a
+    ``state_dict`` of those six tensors loads unchanged.
+    """
+
+    def __init__(self, config: RadegsModelConfig, means: Tensor, scales: Tensor, quats: Tensor,
+                 opacities: Tensor, features_dc: Tensor, features_rest: Tensor):
+        super().__init__()
+        self.config = config
+        self.gauss_params = nn.ParameterDict({
+            "means": nn.Parameter(means), "scales": nn.Parameter(scales), "quats": nn.Parameter(quats),
+            "opacities": nn.Parameter(opacities.reshape(-1, 1)), "features_dc": nn.Parameter(features_dc),
+            "features_rest": nn.Parameter(features_rest)})
+        self.step = 0
+        self.strategy = DefaultStrategy(absgrad=config.absgrad)
+        self.strategy_state = self.strategy.initialize_state()
+        self.optimizers: Dict = {}
+        self.info: Dict = {}
+        self.crop_box = None
+
+    means = property(lambda self: self.gauss_params["means"])
+    scales = property(lambda self: self.gauss_params["scales"])
+    quats = property(lambda self: self.gauss_params["quats"])
+    opacities = property(lambda self: self.gauss_params["opacities"])
+    features_dc = property(lambda self: self.gauss_params["features_dc"])
+    features_rest = property(lambda self: self.gauss_params["features_rest"])
+
+    @property
+    def device(self):
+        return self.means.device
+
+    @property
+    def normals(self) -> Tensor:
+        """rade_gs_model.py:65-78: world normal = rotation column of the smallest scale axis."""
+        scales = torch.exp(self.scales)
+        axis = F.one_hot(torch.argmin(scales, dim=-1), num_classes=3).float()
+        rots = build_rotation(self.quats)
+        return F.normalize(torch.bmm(rots, axis[:, :, None]).squeeze(-1), dim=1)
+
+    def _get_background_color(self) -> Tensor:
+        c = {"black": [0.0, 0.0, 0.0], "white": [1.0, 1.0, 1.0]}.get(self.config.background_color)
+        if c is None:
+            raise ValueError(f"Unknown background_color: {self.config.background_color}")
+        return torch.tensor(c, device=self.device)
+
+    def _get_camera_parameters(self, camera) -> Dict:
+        return camera_parameters(camera, self.device)
+
+    def _prefilter_voxel(self, camera_params: Dict) -> Tensor:
+        """rade_gs_model.py:348-399: visibility mask from projection radii."""
+        from .wrapper import fully_fused_projection
+        means, scales, quats = self.means, torch.exp(self.scales), self.quats
+        N, Cn = means.shape[0], camera_params["viewmats"].shape[0]
+        assert means.shape == (N, 3), means.shape
+        assert quats.shape == (N, 4), quats.shape
+        assert scales.shape == (N, 3), scales.shape
+        assert camera_params["viewmats"].shape == (Cn, 4, 4), camera_params["viewmats"].shape
+        assert camera_params["Ks"].shape == (Cn, 3, 3), camera_params["Ks"].shape
+        radii = fully_fused_projection(means, None, quats, scales, camera_params["viewmats"],
+                                       camera_params["Ks"], int(camera_params["image_width"]),
+                                       int(camera_params["image_height"]), eps2d=0.3, packed=False,
+                                       near_plane=0.01, far_plane=1e10, radius_clip=0.0,
+                                       sparse_grad=False, calc_compensations=False)[0]
+        return torch.sum(radii, dim=-1).squeeze() > 0
+
+    def _render(self, means, quats, scales, opacities, colors, render_mode, sh_degree_to_use,
+                camera_params, visible_mask=None):
+        """rade_gs_model.py:401-467."""
+        if visible_mask is not None:
+            means, quats, scales = means[visible_mask], quats[visible_mask], scales[visible_mask]
+            opacities, colors = opacities[visible_mask], colors[visible_mask]
+        return rasterization(
+            means=means, quats=quats, scales=torch.exp(scales),
+            opacities=torch.sigmoid(opacities.squeeze(-1)), colors=colors,
+            viewmats=camera_params["viewmats"], Ks=camera_params["Ks"],
+            width=int(camera_params["image_width"]), height=int(camera_params["image_height"]),
+            packed=False, near_plane=0.01, far_plane=1e10, render_mode=render_mode,
+            sh_degree=sh_degree_to_use, sparse_grad=False,
+            absgrad=self.strategy.absgrad if isinstance(self.strategy, DefaultStrategy) else False,
+            rasterize_mode=self.config.rasterize_mode, return_depth_normal=True)
+
+    def get_outputs(self, camera) -> Dict[str, Union[Tensor, List, None]]:
+        """rade_gs_model.py:80-272."""
+        if not hasattr(camera, "camera_to_worlds"):
+            print("Called get_outputs with not a camera")
+            return {}
+        if self.training:
+            assert camera.shape[0] == 1, "Only one camera at a time"
+        colors_crop = torch.cat((self.features_dc[:, None, :], self.features_rest), dim=1)
+        W, H = int(camera.width.item()), int(camera.height.item())
+        self.last_size = (H, W)
+        camera_params = self._get_camera_parameters(camera)
+        voxel_visible_mask = self._prefilter_voxel(camera_params) if self.config.prefilter_voxel else None
+        if self.config.rasterize_mode not in ["antialiased", "classic"]:
+            raise ValueError("Unknown rasterize_mode: %s", self.config.rasterize_mode)
+        render_mode = "RGB+ED" if (self.config.output_depth_during_training or not self.training) else "RGB"
+        if self.config.sh_degree > 0:
+            sh_degree_to_use = min(self.step // self.config.sh_degree_interval, self.config.sh_degree)
+        else:
+            colors_crop = torch.sigmoid(colors_crop).squeeze(1)
+            sh_degree_to_use = None
+
+        render, alpha, expected_depths, median_depths, expected_normals, self.info = self._render(
+            means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities,
+            colors=colors_crop, render_mode=render_mode, sh_degree_to_use=sh_degree_to_use,
+            visible_mask=voxel_visible_mask, camera_params=camera_params)
+
+        if self.training:
+            self.strategy.step_pre_backward(self.gauss_params, self.optimizers, self.strategy_state,
+                                            self.step, self.info)
+
+        if self.config.use_depth_normal_loss and self.step >= self.config.regularization_from_iter:
+            # depth_double_to_normal + "1 - <n, n_depth>" (rade_gs_model.py:206-214), one fused kernel
+            _, normal_error_map = ops.depth_normal(expected_depths.reshape(H, W), median_depths.reshape(H, W),
+                                                   expected_normals.reshape(H, W, 3), camera_params["fx"],
+                                                   camera_params["fy"])
+        else:
+            # the reference builds zeros(2, 1, H) here (rade_gs_model.py:217-219); the
+            # entries are unused under the same condition -- emit the intended [2, H, W]
+            normal_error_map = torch.zeros(2, H, W, device=expected_normals.device)
+
+        normals = (expected_normals + 1) / 2
+        background = self._get_background_color()
+        rgb = torch.clamp(render[:, ..., :3] + (1 - alpha) * background, 0.0, 1.0)
+        if render_mode == "RGB+ED":
+            depth_im = render[:, ..., 3:4]
+            depth_im = torch.where(alpha > 0, depth_im, depth_im.detach().max()).squeeze(0)
+        else:
+            depth_im = None
+        if background.shape[0] == 3 and not self.training:
+            background = background.expand(H, W, 3)
+        expected_depths = torch.where(alpha > 0, expected_depths, expected_depths.detach().max())
+        median_depths = torch.where(alpha > 0, median_depths, median_depths.detach().max())
+        normals = torch.where(alpha > 0, normals, normals.detach().max())
+        return {
+            "rgb": rgb.squeeze(0), "depth": expected_depths.squeeze(0), "median_depth": median_depths.squeeze(0),
+            "depth_im": depth_im, "accumulation": alpha.squeeze(0), "normals": normals.squeeze(0),
+            "depth_normal_error_map": normal_error_map[0, ...].unsqueeze(-1),
+            "middepth_normal_error_map": normal_error_map[1, ...].unsqueeze(-1),
+            "background": background,
+        }
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
+        """rade_gs_model.py:274-309.  The Splatfacto base loss (L1 + SSIM, third-party, absent) is
+        represented by its L1 term only."""
+        loss_dict: Dict[str, Tensor] = {}
+        if batch is not None and "image" in batch:
+            loss_dict["rgb_loss"] = torch.abs(batch["image"].to(outputs["rgb"].device) - outputs["rgb"]).mean()
+        if self.config.use_depth_normal_loss and self.step >= self.config.regularization_from_iter:
+            depth_normal_loss = ((1 - self.config.depth_ratio) * outputs["depth_normal_error_map"].mean()
+                                 + self.config.depth_ratio * outputs["middepth_normal_error_map"].mean())
+            loss_dict["depth_normal_loss"] = self.config.depth_normal_lambda * depth_normal_loss
+        return loss_dict
