@@ -1,0 +1,80 @@
+"""CPU restatement (torch, fp32/fp64, autograd) of the reference's camera / depth->normal stage.
+
+TEST INFRASTRUCTURE ONLY (never imported by collab_splats_amd).  PINNED: unlike the rasterizer
+oracle this one is checked against outputs of the reference itself -- tests/golden/
+camera_goldens.npz, produced by tests/golden/make_camera_goldens.py, which imports
+/root/reference/collab_splats/utils/camera_utils.py in the build container.
+
+Follows:
+  convert_to_colmap_camera / ColmapCamera / get_world2view_transform / focal2fov
+      /root/reference/collab_splats/utils/camera_utils.py:28-135
+  RadegsModel._get_camera_parameters   /root/reference/collab_splats/models/rade_gs_model.py:311-346
+  depth_double_to_normal (+ helpers)   camera_utils.py:176-279
+  normal error map / depth-normal loss rade_gs_model.py:212-214, 297-304
+  build_rotation                       camera_utils.py:138-168
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+
+def focal2fov(focal, pixels):
+    return 2 * math.atan(pixels / (2 * focal))                     # camera_utils.py:134-135
+
+
+def camera_params(c2w_3x4: torch.Tensor, K: torch.Tensor, W: int, H: int):
+    """viewmat [4,4], Ks [3,3], camera_center [3], fov (x,y) as the reference derives them."""
+    dt = c2w_3x4.dtype
+    c2w = torch.eye(4, dtype=dt)
+    c2w[:3, :] = c2w_3x4
+    c2w[:3, 1:3] *= -1                                             # :79 OpenGL -> OpenCV axes
+    w2c = torch.linalg.inv(c2w)                                    # :82
+    R = w2c[:3, :3].T                                              # :83 (stored transposed)
+    T = w2c[:3, 3]
+    Rt = torch.zeros(4, 4, dtype=dt)                               # get_world2view_transform :94-105
+    Rt[:3, :3] = R.T
+    Rt[:3, 3] = T
+    Rt[3, 3] = 1.0
+    Rt = torch.linalg.inv(torch.linalg.inv(Rt))                    # translate = 0, scale = 1
+    world_view_transform = Rt.T                                    # :54-58
+    viewmat = world_view_transform.T                               # rade_gs_model.py:336
+    fovx, fovy = focal2fov(float(K[0, 0]), W), focal2fov(float(K[1, 1]), H)
+    fx = W / (2 * math.tan(fovx * 0.5))                            # rade_gs_model.py:322-325
+    fy = H / (2 * math.tan(fovy * 0.5))
+    Ks = torch.tensor([[fx, 0, W / 2.0], [0, fy, H / 2.0], [0, 0, 1]], dtype=dt)
+    center = torch.linalg.inv(world_view_transform)[3, :3]         # :71
+    return viewmat, Ks, center, (fovx, fovy)
+
+
+def depth_double_to_normal(d1: torch.Tensor, d2: torch.Tensor, fx: float, fy: float) -> torch.Tensor:
+    """d1, d2 [H,W] z-depth -> [2,H,W,3]; pixel centres +0.5, principal point at the image centre."""
+    H, W = d1.shape
+    dt = d1.dtype
+    xs = (torch.arange(W, dtype=dt) + 0.5) / fx - W / (2 * fx)     # K^-1 [x+.5, y+.5, 1]  :211-241
+    ys = (torch.arange(H, dtype=dt) + 0.5) / fy - H / (2 * fy)
+    rays = torch.stack([xs[None, :].expand(H, W), ys[:, None].expand(H, W), torch.ones(H, W, dtype=dt)], 0)
+    pts = torch.stack([d1[None] * rays, d2[None] * rays], 0)       # [2,3,H,W]
+    out = torch.zeros_like(pts)
+    drow = pts[..., 2:, 1:-1] - pts[..., :-2, 1:-1]                # "dx" :269 -- along rows
+    dcol = pts[..., 1:-1, 2:] - pts[..., 1:-1, :-2]                # "dy" :270 -- along columns
+    out[..., 1:-1, 1:-1] = torch.nn.functional.normalize(torch.cross(drow, dcol, dim=1), dim=1)
+    return out.permute(0, 2, 3, 1)
+
+
+def normal_error_map(expected_normals: torch.Tensor, normals2: torch.Tensor) -> torch.Tensor:
+    """expected_normals [H,W,3], normals2 [2,H,W,3] -> [2,H,W]  (rade_gs_model.py:212-214)."""
+    return 1 - (expected_normals[None] * normals2).sum(-1)
+
+
+def depth_normal_loss(err: torch.Tensor, lam: float = 0.05, ratio: float = 0.6) -> torch.Tensor:
+    return lam * ((1 - ratio) * err[0].mean() + ratio * err[1].mean())   # rade_gs_model.py:297-304
+
+
+def build_rotation(q: torch.Tensor) -> torch.Tensor:
+    q = q / torch.sqrt((q * q).sum(-1, keepdim=True))
+    r, x, y, z = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                        2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                        2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)

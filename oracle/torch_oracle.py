@@ -391,6 +391,7 @@ def rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width: 
                                     for ci, m in enumerate(metas)]),
         isect_offsets=np.stack([m["isect_offsets"] + base for m, base in zip(
             metas, np.concatenate([[0], np.cumsum([m["n_isects"] for m in metas])[:-1]]).astype(np.int32))]),
+        order_ids=[m["order"].numpy() for m in metas],
         last_ids=torch.stack([m["last_ids"] for m in metas]),
         median_ids=torch.stack([m["median_ids"] for m in metas]),
         width=width, height=height, tile_size=tile_size, n_cameras=C,

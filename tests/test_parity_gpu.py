@@ -1,0 +1,353 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against the oracles.
+
+Bars (BASELINE.json north_star): integer / index outputs bit-exact vs the fp32 CPU restatement;
+colour / depth / normal and all gradients within 1e-4 relative (tensor-inf-norm, SURVEY.md
+section 8(d)); at BASELINE's full size, size-independent properties (sortedness, determinism,
+linearity of the backward, permutation invariance).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_close_flips, rel_err, small_scene, upstream
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "camera_goldens.npz")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    from collab_splats_amd import load_library
+    load_library()
+    return torch.device("cuda:0")
+
+
+def _scene_np(sc):
+    return (sc["means"].numpy(), sc["quats"].numpy(), torch.exp(sc["log_scales"]).numpy(),
+            torch.sigmoid(sc["opacity_logits"]).numpy(), sc["sh"].numpy(), sc["viewmats"][0].numpy(), sc["Ks"][0].numpy())
+
+
+def _run_gpu(sc, dev, W, H, sh_degree=3, **kw):
+    from collab_splats_amd import rasterization
+    leaves = [sc["means"].to(dev).requires_grad_(True), sc["quats"].to(dev).requires_grad_(True),
+              torch.exp(sc["log_scales"]).to(dev).requires_grad_(True),
+              torch.sigmoid(sc["opacity_logits"]).to(dev).requires_grad_(True), sc["sh"].to(dev).requires_grad_(True)]
+    out = rasterization(*leaves, sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H, sh_degree=sh_degree,
+                        return_depth_normal=True, **kw)
+    return leaves, out
+
+
+@pytest.mark.parametrize("N,W,H,mode,rm,deg", [
+    (3000, 256, 256, "antialiased", "RGB+ED", 3),      # BASELINE configs[0] shape (256x256)
+    (20000, 640, 360, "classic", "RGB", 3),
+    (5000, 333, 197, "antialiased", "RGB", 1),         # ragged: W, H not multiples of 16
+    (100000, 1920, 1080, "antialiased", "RGB+ED", 3),  # BASELINE configs[1]
+])
+def test_full_pipeline_vs_c_port(dev, craster, N, W, H, mode, rm, deg):
+    from collab_splats_amd.synthetic import random_scene
+    sc = random_scene(N, W, H, seed=42, sh_degree=3)
+    leaves, out = _run_gpu(sc, dev, W, H, sh_degree=deg, render_mode=rm, rasterize_mode=mode, absgrad=True)
+    r, a, ed, md, n, meta = out
+    cr = craster.CRaster(np.float32)
+    st = cr.forward(*_scene_np(sc), W, H, sh_degree=deg, render_mode=rm, rasterize_mode=mode)
+    # ---- integer / index stages: bit-exact
+    assert np.array_equal(st["proj"]["radii"], meta["radii"][0].cpu().numpy())
+    assert np.array_equal(st["proj"]["depths"].view(np.uint32), meta["depths"][0].detach().cpu().numpy().view(np.uint32))
+    assert np.array_equal(st["proj"]["means2d"].view(np.uint32), meta["means2d"][0].detach().cpu().numpy().view(np.uint32))
+    assert np.array_equal(st["bins"]["tiles_per_gauss"], meta["tiles_per_gauss"][0].cpu().numpy())
+    assert st["bins"]["n_isects"] == meta["n_isects"]
+    assert np.array_equal(st["bins"]["isect_ids"], meta["isect_ids"].cpu().numpy().view(np.uint64))
+    assert np.array_equal(st["bins"]["flatten_ids"], meta["flatten_ids"].cpu().numpy())
+    assert np.array_equal(st["bins"]["isect_offsets"], meta["isect_offsets"][0].cpu().numpy())
+    # ---- images
+    fw = st["fwd"]
+    for name, got, ref in (("render", r, st["render"]), ("alpha", a, fw["alpha"]), ("exp_depth", ed, fw["exp_depth"]),
+                           ("med_depth", md, fw["med_depth"]), ("normal", n, fw["normal"])):
+        assert_close_flips(got[0], ref, name)
+    # contributor indices agree except at fp32 threshold flips (alpha ~ 1/255, T ~ 1e-4)
+    assert (meta["last_ids"][0].cpu().numpy() == fw["last_ids"]).mean() > 0.9999
+    assert (meta["median_ids"][0].cpu().numpy() == fw["median_ids"]).mean() > 0.9999
+    # ---- gradients of every output to every parameter
+    ups = upstream([t.shape for t in (r, a, ed, md, n)], dtype=torch.float32)
+    meta["means2d"].retain_grad()
+    torch.autograd.backward([r, a, ed, md, n], [u.to(dev) for u in ups])
+    gr = cr.backward(st, *[u[0].numpy() for u in ups])
+    for name, leaf in zip(("v_means", "v_quats", "v_scales", "v_opacities", "v_colors"), leaves):
+        assert_close_flips(leaf.grad, gr[name], name)
+    assert_close_flips(meta["means2d"].grad[0], gr["v_means2d"], "v_means2d")
+    assert_close_flips(meta["means2d"].absgrad[0], gr["v_means2d_abs"], "v_means2d_abs")
+
+
+def test_vs_fp64_autograd_oracle(dev):
+    """Independent check against the dense fp64 autograd restatement (small scene)."""
+    from oracle import torch_oracle as O
+    from collab_splats_amd import rasterization
+    sc = small_scene(n=400, W=70, H=52, seed=1)
+    ins64 = [sc[k].clone().requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "sh")]
+    ref = O.rasterization(*ins64, sc["viewmat"][None], sc["K"][None], 70, 52, sh_degree=3, render_mode="RGB+ED",
+                          rasterize_mode="antialiased")
+    ins = [sc[k].float().to(dev).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "sh")]
+    out = rasterization(*ins, sc["viewmat"][None].float().to(dev), sc["K"][None].float().to(dev), 70, 52, sh_degree=3,
+                        render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True)
+    ups = upstream([t.shape for t in ref[:5]])
+    torch.autograd.backward(list(ref[:5]), ups)
+    torch.autograd.backward(list(out[:5]), [u.float().to(dev) for u in ups])
+    for got, want in zip(out[:5], ref[:5]):
+        assert rel_err(got, want) < TOL
+    for got, want in zip(ins, ins64):
+        assert rel_err(got.grad, want.grad) < TOL
+    assert np.array_equal(out[5]["radii"][0].cpu().numpy(), ref[5]["radii"][0].numpy())
+
+
+def test_kat_single_gaussian_on_gpu(dev):
+    from collab_splats_amd import rasterization
+    t = lambda x: torch.tensor(x, dtype=torch.float32, device=dev)
+    z0, s, o, f = 4.0, 0.2, 0.8, 20.0
+    K = t([[f, 0, 8.5], [0, f, 8.5], [0, 0, 1]])[None]
+    r, a, ed, md, n, _ = rasterization(t([[0, 0, z0]]), t([[1, 0, 0, 0]]), t([[s, s, s]]), t([o]), t([[0.2, 0.5, 0.9]]),
+                                       torch.eye(4, device=dev)[None], K, 17, 17, render_mode="RGB+ED",
+                                       return_depth_normal=True)
+    assert a[0, 8, 8, 0].item() == pytest.approx(o, rel=1e-6)
+    assert r[0, 8, 8].tolist() == pytest.approx([o * 0.2, o * 0.5, o * 0.9, z0], rel=1e-5)
+    assert md[0, 8, 8, 0].item() == pytest.approx(z0, rel=1e-6)
+    assert n[0, 8, 8].tolist() == pytest.approx([0, 0, -o], abs=1e-6)
+    var = (f * s / z0) ** 2 + 0.3
+    assert a[0, 8, 10, 0].item() == pytest.approx(o * np.exp(-2.0 / var), rel=1e-5)
+
+
+def test_edge_cases_empty_culled_and_two_cameras(dev, craster):
+    from collab_splats_amd import rasterization
+    from collab_splats_amd.synthetic import random_scene, view_matrix
+    z = lambda *s: torch.zeros(*s, device=dev)
+    eye, K = torch.eye(4, device=dev)[None], torch.tensor([[[20.0, 0, 8.5], [0, 20.0, 5.5], [0, 0, 1]]], device=dev)
+    # empty scene and everything culled (behind the camera): zeros, last_ids == -1
+    for means in (z(0, 3), torch.tensor([[0.0, 0, -2.0]] * 5, device=dev)):
+        m = means.shape[0]
+        quats = torch.ones(m, 4, device=dev)
+        r, a, ed, md, n, meta = rasterization(means, quats, torch.ones(m, 3, device=dev) * 0.1, torch.ones(m, device=dev) * 0.5,
+                                              z(m, 16, 3), eye, K, 17, 11, sh_degree=3, return_depth_normal=True)
+        assert meta["n_isects"] == 0 and not a.any() and not r.any() and (meta["last_ids"] == -1).all()
+        assert r.shape == (1, 11, 17, 3) and a.shape == (1, 11, 17, 1) and n.shape == (1, 11, 17, 3)
+    # two cameras in one call == two single-camera calls (keys carry the camera index)
+    W, H, N = 160, 96, 3000
+    sc = random_scene(N, W, H, seed=7)
+    V2 = torch.cat([sc["viewmats"], view_matrix(1)], 0).to(dev)
+    K2 = sc["Ks"].expand(2, 3, 3).contiguous().to(dev)
+    args = [sc["means"].to(dev), sc["quats"].to(dev), torch.exp(sc["log_scales"]).to(dev),
+            torch.sigmoid(sc["opacity_logits"]).to(dev), sc["sh"].to(dev)]
+    both = rasterization(*args, V2, K2, W, H, sh_degree=3, render_mode="RGB+ED", return_depth_normal=True)
+    for ci in range(2):
+        one = rasterization(*args, V2[ci:ci + 1], K2[ci:ci + 1], W, H, sh_degree=3, render_mode="RGB+ED",
+                            return_depth_normal=True)
+        for t2, t1 in zip(both[:5], one[:5]):
+            assert torch.equal(t2[ci], t1[0])
+    assert both[5]["radii"].shape == (2, N, 2) and both[5]["isect_offsets"].shape[0] == 2
+    keys = both[5]["isect_ids"].cpu().numpy()
+    assert np.all(np.diff(keys) >= 0)
+
+
+def test_feature_channels_backgrounds_and_render_modes(dev, craster):
+    """sh_degree=None with D=7 'fused features' (rade_features_model.py:441-476 shape: D>4 goes through
+    4-channel passes), backgrounds, and the 3-tuple return."""
+    from collab_splats_amd import rasterization
+    from collab_splats_amd.synthetic import random_scene
+    W, H, N, D = 200, 120, 4000, 7
+    sc = random_scene(N, W, H, seed=9)
+    g = torch.Generator().manual_seed(4)
+    feats = torch.rand(N, D, generator=g)
+    scales, op = torch.exp(sc["log_scales"]), torch.sigmoid(sc["opacity_logits"])
+    leaves = [t.to(dev).requires_grad_(True) for t in (sc["means"], sc["quats"], scales, op, feats)]
+    bg = torch.rand(1, D + 1, generator=g).to(dev)
+    out = rasterization(*leaves, sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H, sh_degree=None, render_mode="RGB+ED",
+                        rasterize_mode="classic", backgrounds=bg, return_depth_normal=True)
+    assert out[0].shape == (1, H, W, D + 1)
+    cr = craster.CRaster(np.float32)
+    st = cr.forward(sc["means"].numpy(), sc["quats"].numpy(), scales.numpy(), op.numpy(), feats.numpy(),
+                    sc["viewmats"][0].numpy(), sc["Ks"][0].numpy(), W, H, sh_degree=None, render_mode="RGB+ED")
+    want = st["render"] + (1 - st["fwd"]["alpha"]) * bg[0].cpu().numpy()
+    assert rel_err(out[0][0], want) < TOL
+    ups = upstream([t.shape for t in out[:5]], dtype=torch.float32)
+    torch.autograd.backward(list(out[:5]), [u.to(dev) for u in ups])
+    v_alpha = ups[1][0].numpy() - (ups[0][0].numpy() * bg[0].cpu().numpy()).sum(-1, keepdims=True)
+    gr = cr.backward(st, ups[0][0].numpy(), v_alpha, ups[2][0].numpy(), ups[3][0].numpy(), ups[4][0].numpy())
+    for name, leaf in zip(("v_means", "v_quats", "v_scales", "v_opacities", "v_colors"), leaves):
+        assert rel_err(leaf.grad, gr[name]) < TOL, name
+    r3 = rasterization(*[l.detach() for l in leaves[:4]], feats[:, :3].to(dev), sc["viewmats"].to(dev),
+                       sc["Ks"].to(dev), W, H)
+    assert len(r3) == 3 and r3[0].shape == (1, H, W, 3)
+
+
+def test_projection_and_sh_wrappers(dev, craster):
+    """fully_fused_projection 8-tuple (rade_gs_model.py:373-394) and spherical_harmonics
+    (rade_features_model.py:430-438)."""
+    from collab_splats_amd import fully_fused_projection, spherical_harmonics
+    from collab_splats_amd.synthetic import random_scene
+    W, H, N = 320, 200, 5000
+    sc = random_scene(N, W, H, seed=5)
+    scales = torch.exp(sc["log_scales"])
+    res = fully_fused_projection(sc["means"].to(dev), None, sc["quats"].to(dev), scales.to(dev), sc["viewmats"].to(dev),
+                                 sc["Ks"].to(dev), W, H, eps2d=0.3, packed=False, near_plane=0.01, far_plane=1e10,
+                                 radius_clip=0.0, sparse_grad=False, calc_compensations=False)
+    radii, means2d, depths, conics, comps, ray_ts, ray_planes, normals = res
+    assert comps is None and radii.shape == (1, N, 2) and normals.shape == (1, N, 3)
+    cr = craster.CRaster(np.float32)
+    P = cr.params(sc["Ks"][0].numpy(), W, H)
+    ref = cr.project_fwd(sc["means"].numpy(), sc["quats"].numpy(), scales.numpy(), None, sc["viewmats"][0].numpy(), P)
+    assert np.array_equal(radii[0].cpu().numpy(), ref["radii"])
+    mask = torch.sum(radii, dim=-1).squeeze() > 0                       # rade_gs_model.py:397
+    assert 0.5 * N < int(mask.sum()) < N
+    for got, key in ((conics, "conics"), (ray_ts, "ray_ts"), (ray_planes, "ray_planes"), (normals, "normals")):
+        assert rel_err(got[0], ref[key]) < 1e-5, key
+    vis = mask.cpu().numpy()
+    view_dir = sc["means"].numpy()[vis]                                  # camera at the origin (identity viewmat)
+    assert np.all((normals[0].cpu().numpy()[vis] * view_dir).sum(-1) < 0)             # normals face the camera
+    dirs = (sc["means"] - torch.tensor([0.0, 0.0, 0.0]))
+    cols = spherical_harmonics(degrees_to_use=2, dirs=dirs.to(dev), coeffs=sc["sh"].to(dev))
+    want = cr.sh_fwd(2, dirs.numpy(), sc["sh"].numpy())
+    assert rel_err(cols, want) < 1e-5
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_depth_normal_kernel_vs_reference_goldens(dev, i):
+    """The fused a4 stencil against vectors produced by the reference's own camera_utils.py."""
+    from collab_splats_amd import ops
+    g = np.load(GOLD)
+    W, H = [int(v) for v in g[f"cam{i}_WH"]]
+    fovx, fovy = g[f"cam{i}_fov"]
+    fx, fy = W / (2 * np.tan(fovx / 2)), H / (2 * np.tan(fovy / 2))
+    d1 = torch.from_numpy(g[f"dn{i}_d1"]).to(dev).requires_grad_(True)
+    d2 = torch.from_numpy(g[f"dn{i}_d2"]).to(dev).requires_grad_(True)
+    nr = torch.from_numpy(g[f"dn{i}_nrm"]).to(dev).requires_grad_(True)
+    n2, err = ops.depth_normal(d1, d2, nr, fx, fy)
+    assert np.abs(n2.detach().cpu().numpy() - g[f"dn{i}_normals2"]).max() < 2e-5
+    assert np.abs(err.detach().cpu().numpy() - g[f"dn{i}_err"]).max() < 2e-5
+    loss = 0.05 * ((1 - 0.6) * err[0].mean() + 0.6 * err[1].mean())
+    assert abs(loss.item() - float(g[f"dn{i}_loss"])) < 1e-6
+    loss.backward()
+    assert rel_err(d1.grad, g[f"dn{i}_v_d1"]) < TOL
+    assert rel_err(d2.grad, g[f"dn{i}_v_d2"]) < TOL
+    assert rel_err(nr.grad, g[f"dn{i}_v_nrm"]) < TOL
+
+
+def test_model_get_outputs_and_loss(dev):
+    """Host mirror of RadegsModel.get_outputs / get_loss_dict (rade_gs_model.py:80-309): keys, shapes,
+    masking conventions and the depth-normal loss, end to end with backward."""
+    from collab_splats_amd import radegs
+    from collab_splats_amd.synthetic import random_scene
+    W, H, N = 240, 136, 6000
+    sc = random_scene(N, W, H, seed=2)
+    cfg = radegs.RadegsModelConfig(rasterize_mode="antialiased", regularization_from_iter=0, absgrad=True)
+    model = radegs.RadegsModel(cfg, sc["means"], sc["log_scales"], sc["quats"], sc["opacity_logits"], sc["sh"][:, 0],
+                               sc["sh"][:, 1:]).to(dev)
+    model.train()
+    c2w = torch.tensor([[1.0, 0, 0, 0], [0, -1.0, 0, 0], [0, 0, -1.0, 0]])         # OpenGL camera looking down +z (OpenCV)
+    cam = radegs.PinholeCamera.make(c2w, 0.9 * W, 0.9 * W, W, H)
+    model.step = 5000
+    out = model.get_outputs(cam)
+    assert set(out) == {"rgb", "depth", "median_depth", "depth_im", "accumulation", "normals",
+                        "depth_normal_error_map", "middepth_normal_error_map", "background"}
+    assert out["rgb"].shape == (H, W, 3) and out["depth"].shape == (H, W, 1) and out["normals"].shape == (H, W, 3)
+    assert out["depth_im"] is None and out["depth_normal_error_map"].shape == (H, W, 1)
+    assert 0 <= out["rgb"].min() and out["rgb"].max() <= 1
+    acc = out["accumulation"]
+    empty = acc[..., 0] == 0
+    assert empty.any() and torch.all(out["depth"][..., 0][empty] == out["depth"].max())   # where(alpha>0, x, max)
+    loss = model.get_loss_dict(out, {"image": torch.rand(H, W, 3)})
+    assert set(loss) == {"rgb_loss", "depth_normal_loss"}
+    sum(loss.values()).backward()
+    for k, p in model.gauss_params.items():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    assert model.info["means2d"].grad is not None and model.info["means2d"].absgrad is not None
+    model.strategy.step_post_backward(model.gauss_params, {}, model.strategy_state, model.step, model.info)
+    assert model.strategy_state["count"].sum() > 0
+    model.eval()
+    with torch.no_grad():
+        ev = model.get_outputs(cam)
+    assert ev["depth_im"].shape == (H, W, 1) and ev["background"].shape == (H, W, 3)
+    mask = model._prefilter_voxel(model._get_camera_parameters(cam))
+    assert mask.shape == (N,) and mask.dtype == torch.bool and 0 < int(mask.sum()) < N
+
+
+# ---------------------------------------------------------------- BASELINE full size: properties
+@pytest.fixture(scope="module")
+def full(dev):
+    from collab_splats_amd.synthetic import random_scene
+    W, H, N = 1920, 1080, 1_000_000
+    sc = random_scene(N, W, H, seed=42)
+    return sc, W, H, N
+
+
+def test_full_size_properties(dev, full):
+    """1 M Gaussians, 1080p (BASELINE configs[2]): sortedness, tile ranges, invariants, bitwise
+    determinism (no float atomics anywhere) and linearity of the backward."""
+    sc, W, H, N = full
+    leaves, out = _run_gpu(sc, dev, W, H, render_mode="RGB+ED", rasterize_mode="antialiased")
+    r, a, ed, md, n, meta = out
+    keys = meta["isect_ids"]
+    I = meta["n_isects"]
+    assert I == int(meta["tiles_per_gauss"].sum()) and I > 4_000_000
+    assert bool((keys[1:] >= keys[:-1]).all())                                        # sorted
+    offs = meta["isect_offsets"].reshape(-1).long()
+    assert bool((offs[1:] >= offs[:-1]).all()) and int(offs[0]) == 0 and int(offs[-1]) <= I
+    tiles = (keys >> 32)
+    probe = torch.randint(0, offs.numel() - 1, (2000,), device=dev)
+    nonempty = offs[probe + 1] > offs[probe]
+    p = probe[nonempty]
+    assert bool((tiles[offs[p]] == p).all()) and bool((tiles[offs[p + 1] - 1] == p).all())
+    fl = meta["flatten_ids"].long()
+    assert int(fl.min()) >= 0 and int(fl.max()) < N
+    vis = (meta["radii"][0] > 0).any(-1)
+    assert bool(vis[fl].all())                                                        # only visible Gaussians are binned
+    assert float(a.detach().min()) >= 0 and float(a.detach().max()) < 1.0                              # alpha = 1 - T, T > t_stop
+    assert bool((n.norm(dim=-1, keepdim=True) <= a + 1e-5).all())                    # |sum w n| <= sum w
+    assert bool(torch.isfinite(r).all() and torch.isfinite(ed).all() and torch.isfinite(md).all())
+    zmin, zmax = float(meta["depths"][0][vis].detach().min()), float(meta["depths"][0][vis].detach().max())
+    has = a[..., 0] > 0.5
+    assert float(md[..., 0][has].min()) > 0.5 * zmin and float(md[..., 0][has].max()) < 2.0 * zmax
+    ups1 = [u.to(dev) for u in upstream([t.shape for t in (r, a, ed, md, n)], seed=1, dtype=torch.float32)]
+    ups2 = [u.to(dev) for u in upstream([t.shape for t in (r, a, ed, md, n)], seed=2, dtype=torch.float32)]
+
+    def grads(ups):
+        for l in leaves:
+            l.grad = None
+        torch.autograd.backward([r, a, ed, md, n], ups, retain_graph=True)
+        return [l.grad.clone() for l in leaves]
+
+    g1, g1b, g2 = grads(ups1), grads(ups1), grads(ups2)
+    g12 = grads([x + y for x, y in zip(ups1, ups2)])
+    for x, y in zip(g1, g1b):
+        assert torch.equal(x, y)                                                      # bitwise reproducible backward
+    for x, y, s in zip(g1, g2, g12):
+        assert rel_err(x + y, s) < 1e-4                                               # backward is linear in the upstream
+    _, out2 = _run_gpu(sc, dev, W, H, render_mode="RGB+ED", rasterize_mode="antialiased")
+    for t1, t2 in zip(out[:5], out2[:5]):
+        assert torch.equal(t1, t2)                                                    # bitwise reproducible forward
+
+
+def test_full_size_permutation_invariance(dev, full):
+    """Re-ordering the Gaussians (distinct depths) must not change any image: per pixel the
+    compositing order is by depth, so the fp32 operation sequence is identical."""
+    from collab_splats_amd import rasterization
+    sc, W, H, N = full
+    n = 200_000
+    g = torch.Generator().manual_seed(3)
+    perm = torch.randperm(n, generator=g)
+    means = sc["means"][:n].clone()
+    zs = 2.0 + 10.0 * (torch.randperm(n, generator=g).float() + 0.5) / n          # distinct depths by construction
+    means[:, :2] *= (zs / means[:, 2])[:, None]
+    means[:, 2] = zs
+    base = [means, sc["quats"][:n], torch.exp(sc["log_scales"][:n]), torch.sigmoid(sc["opacity_logits"][:n]), sc["sh"][:n]]
+    o1 = rasterization(*[t.to(dev) for t in base], sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H, sh_degree=3,
+                       render_mode="RGB+ED", return_depth_normal=True)
+    o2 = rasterization(*[t[perm].to(dev) for t in base], sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H, sh_degree=3,
+                       render_mode="RGB+ED", return_depth_normal=True)
+    d = o1[5]["depths"][0][(o1[5]["radii"][0] > 0).any(-1)]
+    assert d.unique().numel() == d.numel()
+    for t1, t2 in zip(o1[:5], o2[:5]):
+        assert torch.equal(t1, t2)
+    assert torch.equal(o1[5]["radii"][0][perm], o2[5]["radii"][0])
