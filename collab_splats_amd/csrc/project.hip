@@ -217,6 +217,146 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
     }
 }
 
+struct ProjGrads {
+    float v_m2d[2], v_depth, v_conic[3], v_comp, v_rt, v_rp[2], v_nr[3];
+};
+
+// Backward of project_one + rade_extras for ONE (camera, Gaussian); ACCUMULATES into o_m/o_q/o_s.
+__device__ __forceinline__ void project_bwd_one(const float* mean, const float* quat, const float* sc,
+                                                const Cam& cam, const misplat_params& P, const ProjGrads& G,
+                                                float* o_m, float* o_q, float* o_s) {
+    ProjState S;
+    if (!project_one(mean, quat, sc, cam, P, S)) return;
+    float rt, rp[2], nr[3];
+    rade_extras(sc, cam, P, S, rt, rp, nr);
+    const float* Rw = cam.Rw;
+    float z = S.mu[2], rz = 1.0f / z, rz2 = rz * rz;
+    float v_mu[3] = {0.f, 0.f, 0.f}, v_u = 0.f, v_v = 0.f, v_s[3] = {0.f, 0.f, 0.f};
+    float v_Rc[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) v_Rc[i] = 0.f;
+    // 1. RaDe extras
+    float v_rt = G.v_rt;
+    float v_ell = v_rt * z;
+    v_mu[2] += v_rt * S.ell;
+    if (S.plane_ok) {
+        float v_dtdu = G.v_rp[0] / cam.fx, v_dtdv = G.v_rp[1] / cam.fy;
+        float A = z * S.ell / S.nh;
+        float v_n[3] = {-G.v_nr[0], -G.v_nr[1], -G.v_nr[2]};
+        v_n[0] += -A * v_dtdu; v_n[1] += -A * v_dtdv;
+        float v_A = -(S.nhat[0] * v_dtdu + S.nhat[1] * v_dtdv);
+        v_mu[2] += v_A * S.ell / S.nh;
+        v_ell += v_A * z / S.nh;
+        float v_nh = -v_A * A / S.nh;
+        float uv = S.u * v_dtdu + S.v * v_dtdv;
+        v_mu[2] += uv / S.ell;
+        v_u += z * v_dtdu / S.ell; v_v += z * v_dtdv / S.ell;
+        v_ell += -z * uv / (S.ell * S.ell);
+        v_n[0] += v_nh * S.u; v_n[1] += v_nh * S.v; v_n[2] += v_nh;
+        v_u += v_nh * S.nhat[0]; v_v += v_nh * S.nhat[1];
+        float dotn = S.nhat[0] * v_n[0] + S.nhat[1] * v_n[1] + S.nhat[2] * v_n[2];
+        float v_m[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) v_m[i] = (v_n[i] - S.nhat[i] * dotn) / S.mnorm;
+        float r[3] = {S.w[0] * S.p[0], S.w[1] * S.p[1], S.w[2] * S.p[2]};
+        float v_w[3], v_p[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float v_r = S.Rc[0 * 3 + k] * v_m[0] + S.Rc[1 * 3 + k] * v_m[1] + S.Rc[2 * 3 + k] * v_m[2];
+            v_w[k] = v_r * S.p[k]; v_p[k] = v_r * S.w[k];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) v_Rc[i * 3 + k] += v_m[i] * r[k] + S.mu[i] * v_p[k];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            v_mu[i] += S.Rc[i * 3 + 0] * v_p[0] + S.Rc[i * 3 + 1] * v_p[1] + S.Rc[i * 3 + 2] * v_p[2];
+        float smin = S.kmin == 0 ? sc[0] : (S.kmin == 1 ? sc[1] : sc[2]);
+        float v_smin = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            v_s[k] += v_w[k] * (-2.0f * smin * smin / (sc[k] * sc[k] * sc[k]));
+            v_smin += v_w[k] * 2.0f * smin / (sc[k] * sc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) if (k == S.kmin) v_s[k] += v_smin;
+    }
+    v_u += v_ell * S.u / S.ell; v_v += v_ell * S.v / S.ell;
+    // 2. conic / compensation -> cov2d
+    float v0 = G.v_conic[0], v1 = G.v_conic[1], v2 = G.v_conic[2];
+    float det = S.det, v_det = -(S.c * v0 - S.b * v1 + S.a * v2) / (det * det);
+    float v_det0 = 0.f;
+    if (S.det0 / det > 0.f && S.comp > 0.f) {
+        float v_ratio = G.v_comp / (2.0f * S.comp);
+        v_det0 = v_ratio / det;
+        v_det += -v_ratio * S.det0 / (det * det);
+    }
+    float v_a = v2 / det + v_det * S.c, v_c = v0 / det + v_det * S.a, v_b = -v1 / det - 2.0f * S.b * v_det;
+    float G00 = v_a + v_det0 * S.c0, G11 = v_c + v_det0 * S.a0, G01 = 0.5f * (v_b - 2.0f * S.b0 * v_det0);
+    // 3. cov2d = J cov J^T
+    float Jm[6] = {S.J00, 0.f, S.J02, 0.f, S.J11, S.J12};
+    float GJ[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { GJ[k] = G00 * Jm[k] + G01 * Jm[3 + k]; GJ[3 + k] = G01 * Jm[k] + G11 * Jm[3 + k]; }
+    float v_cov[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) v_cov[i * 3 + j] = Jm[i] * GJ[j] + Jm[3 + i] * GJ[3 + j];
+    float v_J[6];
+#pragma unroll
+    for (int r_ = 0; r_ < 2; r_++)
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            v_J[r_ * 3 + k] = 2.0f * (GJ[r_ * 3 + 0] * S.cov[0 * 3 + k] + GJ[r_ * 3 + 1] * S.cov[1 * 3 + k] + GJ[r_ * 3 + 2] * S.cov[2 * 3 + k]);
+    v_mu[2] += -v_J[0] * cam.fx * rz2 - v_J[4] * cam.fy * rz2;
+    float v_tx = -v_J[2] * cam.fx * rz2, v_ty = -v_J[5] * cam.fy * rz2;
+    v_mu[2] += 2.0f * v_J[2] * cam.fx * S.tx * rz2 * rz + 2.0f * v_J[5] * cam.fy * S.ty * rz2 * rz;
+    if (S.clampx) v_mu[2] += v_tx * S.limx; else v_mu[0] += v_tx;
+    if (S.clampy) v_mu[2] += v_ty * S.limy; else v_mu[1] += v_ty;
+    // 4. mean2d, depth
+    v_u += cam.fx * G.v_m2d[0]; v_v += cam.fy * G.v_m2d[1];
+    v_mu[0] += v_u * rz; v_mu[1] += v_v * rz;
+    v_mu[2] += -(v_u * S.u + v_v * S.v) * rz;
+    v_mu[2] += G.v_depth;
+    // 5. cov = M M^T, M = Rc diag(s)
+    float M[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) M[i * 3 + k] = S.Rc[i * 3 + k] * sc[k];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; j++) acc += (v_cov[i * 3 + j] + v_cov[j * 3 + i]) * M[j * 3 + k];
+            v_Rc[i * 3 + k] += acc * sc[k];
+            v_s[k] += acc * S.Rc[i * 3 + k];
+        }
+    float w_[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            w_[i * 3 + k] = Rw[0 * 3 + i] * v_Rc[0 * 3 + k] + Rw[1 * 3 + i] * v_Rc[1 * 3 + k] + Rw[2 * 3 + i] * v_Rc[2 * 3 + k];
+    float qr = S.qn[0], qx = S.qn[1], qy = S.qn[2], qz = S.qn[3];
+    float vq[4];
+    vq[0] = 2.0f * (-qz * w_[1] + qy * w_[2] + qz * w_[3] - qx * w_[5] - qy * w_[6] + qx * w_[7]);
+    vq[1] = 2.0f * (qy * w_[1] + qz * w_[2] + qy * w_[3] - 2.0f * qx * w_[4] - qr * w_[5] + qz * w_[6] + qr * w_[7] - 2.0f * qx * w_[8]);
+    vq[2] = 2.0f * (-2.0f * qy * w_[0] + qx * w_[1] + qr * w_[2] + qx * w_[3] + qz * w_[5] - qr * w_[6] + qz * w_[7] - 2.0f * qy * w_[8]);
+    vq[3] = 2.0f * (-2.0f * qz * w_[0] - qr * w_[1] + qx * w_[2] + qr * w_[3] - 2.0f * qz * w_[4] + qy * w_[5] + qx * w_[6] + qy * w_[7]);
+    float dq = S.qn[0] * vq[0] + S.qn[1] * vq[1] + S.qn[2] * vq[2] + S.qn[3] * vq[3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o_q[k] += (vq[k] - S.qn[k] * dq) / S.qnorm;
+#pragma unroll
+    for (int i = 0; i < 3; i++) o_m[i] += Rw[0 * 3 + i] * v_mu[0] + Rw[1 * 3 + i] * v_mu[1] + Rw[2 * 3 + i] * v_mu[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) o_s[k] += v_s[k];
+}
+
 // One thread per Gaussian, loop over cameras: gradients summed over cameras in a fixed order.
 __global__ __launch_bounds__(256) void project_bwd_kernel(
     misplat_params P, const float* __restrict__ means, const float* __restrict__ quats,
@@ -236,136 +376,14 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
             const int64_t idx = (int64_t)ci * P.n_gauss + g;
             if (radii[2 * idx] <= 0 && radii[2 * idx + 1] <= 0) continue;
             const Cam cam = load_cam(viewmats + 16 * ci, Ks + 9 * ci);
-            ProjState S;
-            if (!project_one(mean, quat, sc, cam, P, S)) continue;
-            float rt, rp[2], nr[3];
-            rade_extras(sc, cam, P, S, rt, rp, nr);
-            const float* Rw = cam.Rw;
-            float z = S.mu[2], rz = 1.0f / z, rz2 = rz * rz;
-            float v_mu[3] = {0.f, 0.f, 0.f}, v_u = 0.f, v_v = 0.f, v_s[3] = {0.f, 0.f, 0.f};
-            float v_Rc[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) v_Rc[i] = 0.f;
-            // 1. RaDe extras
-            float v_rt = v_ray_ts[idx];
-            float v_ell = v_rt * z;
-            v_mu[2] += v_rt * S.ell;
-            if (S.plane_ok) {
-                float v_dtdu = v_ray_planes[2 * idx] / cam.fx, v_dtdv = v_ray_planes[2 * idx + 1] / cam.fy;
-                float A = z * S.ell / S.nh;
-                float v_n[3] = {-v_normals[3 * idx], -v_normals[3 * idx + 1], -v_normals[3 * idx + 2]};
-                v_n[0] += -A * v_dtdu; v_n[1] += -A * v_dtdv;
-                float v_A = -(S.nhat[0] * v_dtdu + S.nhat[1] * v_dtdv);
-                v_mu[2] += v_A * S.ell / S.nh;
-                v_ell += v_A * z / S.nh;
-                float v_nh = -v_A * A / S.nh;
-                float uv = S.u * v_dtdu + S.v * v_dtdv;
-                v_mu[2] += uv / S.ell;
-                v_u += z * v_dtdu / S.ell; v_v += z * v_dtdv / S.ell;
-                v_ell += -z * uv / (S.ell * S.ell);
-                v_n[0] += v_nh * S.u; v_n[1] += v_nh * S.v; v_n[2] += v_nh;
-                v_u += v_nh * S.nhat[0]; v_v += v_nh * S.nhat[1];
-                float dotn = S.nhat[0] * v_n[0] + S.nhat[1] * v_n[1] + S.nhat[2] * v_n[2];
-                float v_m[3];
-#pragma unroll
-                for (int i = 0; i < 3; i++) v_m[i] = (v_n[i] - S.nhat[i] * dotn) / S.mnorm;
-                float r[3] = {S.w[0] * S.p[0], S.w[1] * S.p[1], S.w[2] * S.p[2]};
-                float v_w[3], v_p[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    float v_r = S.Rc[0 * 3 + k] * v_m[0] + S.Rc[1 * 3 + k] * v_m[1] + S.Rc[2 * 3 + k] * v_m[2];
-                    v_w[k] = v_r * S.p[k]; v_p[k] = v_r * S.w[k];
-                }
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-#pragma unroll
-                    for (int k = 0; k < 3; k++) v_Rc[i * 3 + k] += v_m[i] * r[k] + S.mu[i] * v_p[k];
-#pragma unroll
-                for (int i = 0; i < 3; i++)
-                    v_mu[i] += S.Rc[i * 3 + 0] * v_p[0] + S.Rc[i * 3 + 1] * v_p[1] + S.Rc[i * 3 + 2] * v_p[2];
-                float smin = S.kmin == 0 ? sc[0] : (S.kmin == 1 ? sc[1] : sc[2]);
-                float v_smin = 0.f;
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    v_s[k] += v_w[k] * (-2.0f * smin * smin / (sc[k] * sc[k] * sc[k]));
-                    v_smin += v_w[k] * 2.0f * smin / (sc[k] * sc[k]);
-                }
-#pragma unroll
-                for (int k = 0; k < 3; k++) if (k == S.kmin) v_s[k] += v_smin;
-            }
-            v_u += v_ell * S.u / S.ell; v_v += v_ell * S.v / S.ell;
-            // 2. conic / compensation -> cov2d
-            float v0 = v_conics[3 * idx], v1 = v_conics[3 * idx + 1], v2 = v_conics[3 * idx + 2];
-            float det = S.det, v_det = -(S.c * v0 - S.b * v1 + S.a * v2) / (det * det);
-            float v_det0 = 0.f;
-            if (S.det0 / det > 0.f && S.comp > 0.f) {
-                float v_ratio = v_comps[idx] / (2.0f * S.comp);
-                v_det0 = v_ratio / det;
-                v_det += -v_ratio * S.det0 / (det * det);
-            }
-            float v_a = v2 / det + v_det * S.c, v_c = v0 / det + v_det * S.a, v_b = -v1 / det - 2.0f * S.b * v_det;
-            float G00 = v_a + v_det0 * S.c0, G11 = v_c + v_det0 * S.a0, G01 = 0.5f * (v_b - 2.0f * S.b0 * v_det0);
-            // 3. cov2d = J cov J^T
-            float Jm[6] = {S.J00, 0.f, S.J02, 0.f, S.J11, S.J12};
-            float GJ[6];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { GJ[k] = G00 * Jm[k] + G01 * Jm[3 + k]; GJ[3 + k] = G01 * Jm[k] + G11 * Jm[3 + k]; }
-            float v_cov[9];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) v_cov[i * 3 + j] = Jm[i] * GJ[j] + Jm[3 + i] * GJ[3 + j];
-            float v_J[6];
-#pragma unroll
-            for (int r_ = 0; r_ < 2; r_++)
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    v_J[r_ * 3 + k] = 2.0f * (GJ[r_ * 3 + 0] * S.cov[0 * 3 + k] + GJ[r_ * 3 + 1] * S.cov[1 * 3 + k] + GJ[r_ * 3 + 2] * S.cov[2 * 3 + k]);
-            v_mu[2] += -v_J[0] * cam.fx * rz2 - v_J[4] * cam.fy * rz2;
-            float v_tx = -v_J[2] * cam.fx * rz2, v_ty = -v_J[5] * cam.fy * rz2;
-            v_mu[2] += 2.0f * v_J[2] * cam.fx * S.tx * rz2 * rz + 2.0f * v_J[5] * cam.fy * S.ty * rz2 * rz;
-            if (S.clampx) v_mu[2] += v_tx * S.limx; else v_mu[0] += v_tx;
-            if (S.clampy) v_mu[2] += v_ty * S.limy; else v_mu[1] += v_ty;
-            // 4. mean2d, depth
-            v_u += cam.fx * v_means2d[2 * idx]; v_v += cam.fy * v_means2d[2 * idx + 1];
-            v_mu[0] += v_u * rz; v_mu[1] += v_v * rz;
-            v_mu[2] += -(v_u * S.u + v_v * S.v) * rz;
-            v_mu[2] += v_depths[idx];
-            // 5. cov = M M^T, M = Rc diag(s)
-            float M[9];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int k = 0; k < 3; k++) M[i * 3 + k] = S.Rc[i * 3 + k] * sc[k];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 3; j++) acc += (v_cov[i * 3 + j] + v_cov[j * 3 + i]) * M[j * 3 + k];
-                    v_Rc[i * 3 + k] += acc * sc[k];
-                    v_s[k] += acc * S.Rc[i * 3 + k];
-                }
-            float w_[9];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int k = 0; k < 3; k++)
-                    w_[i * 3 + k] = Rw[0 * 3 + i] * v_Rc[0 * 3 + k] + Rw[1 * 3 + i] * v_Rc[1 * 3 + k] + Rw[2 * 3 + i] * v_Rc[2 * 3 + k];
-            float qr = S.qn[0], qx = S.qn[1], qy = S.qn[2], qz = S.qn[3];
-            float vq[4];
-            vq[0] = 2.0f * (-qz * w_[1] + qy * w_[2] + qz * w_[3] - qx * w_[5] - qy * w_[6] + qx * w_[7]);
-            vq[1] = 2.0f * (qy * w_[1] + qz * w_[2] + qy * w_[3] - 2.0f * qx * w_[4] - qr * w_[5] + qz * w_[6] + qr * w_[7] - 2.0f * qx * w_[8]);
-            vq[2] = 2.0f * (-2.0f * qy * w_[0] + qx * w_[1] + qr * w_[2] + qx * w_[3] + qz * w_[5] - qr * w_[6] + qz * w_[7] - 2.0f * qy * w_[8]);
-            vq[3] = 2.0f * (-2.0f * qz * w_[0] - qr * w_[1] + qx * w_[2] + qr * w_[3] - 2.0f * qz * w_[4] + qy * w_[5] + qx * w_[6] + qy * w_[7]);
-            float dq = S.qn[0] * vq[0] + S.qn[1] * vq[1] + S.qn[2] * vq[2] + S.qn[3] * vq[3];
-#pragma unroll
-            for (int k = 0; k < 4; k++) o_q[k] += (vq[k] - S.qn[k] * dq) / S.qnorm;
-#pragma unroll
-            for (int i = 0; i < 3; i++) o_m[i] += Rw[0 * 3 + i] * v_mu[0] + Rw[1 * 3 + i] * v_mu[1] + Rw[2 * 3 + i] * v_mu[2];
-#pragma unroll
-            for (int k = 0; k < 3; k++) o_s[k] += v_s[k];
+            ProjGrads G;
+            G.v_m2d[0] = v_means2d[2 * idx]; G.v_m2d[1] = v_means2d[2 * idx + 1];
+            G.v_depth = v_depths[idx];
+            G.v_conic[0] = v_conics[3 * idx]; G.v_conic[1] = v_conics[3 * idx + 1]; G.v_conic[2] = v_conics[3 * idx + 2];
+            G.v_comp = v_comps[idx]; G.v_rt = v_ray_ts[idx];
+            G.v_rp[0] = v_ray_planes[2 * idx]; G.v_rp[1] = v_ray_planes[2 * idx + 1];
+            G.v_nr[0] = v_normals[3 * idx]; G.v_nr[1] = v_normals[3 * idx + 1]; G.v_nr[2] = v_normals[3 * idx + 2];
+            project_bwd_one(mean, quat, sc, cam, P, G, o_m, o_q, o_s);
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) { v_means[3 * g + k] = o_m[k]; v_scales[3 * g + k] = o_s[k]; }
@@ -486,6 +504,258 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int n_gauss, int n_cams, in
     }
 }
 
+
+// ================================================================================================
+// Fused per-Gaussian stages (the path rasterization() takes): projection writes the packed blend
+// record directly, the colour kernel (SH + 0.5 clamp, or pass-through) fills its colour slots, and
+// the two backward kernels consume the packed gradient rows -- no intermediate SoA round trips.
+// Record layout (MISPLAT_REC floats): [0:2] mean2d [2:5] conic [5] opacity_eff [6] ray_t
+// [7:9] ray_plane [9:12] normal [12:16] colour channels.
+// ================================================================================================
+__global__ __launch_bounds__(256) void project_pack_fwd_kernel(
+    misplat_params P, const float* __restrict__ means, const float* __restrict__ quats,
+    const float* __restrict__ scales, const float* __restrict__ opacities,
+    const float* __restrict__ viewmats, const float* __restrict__ Ks, int32_t* __restrict__ radii,
+    float* __restrict__ means2d, float* __restrict__ depths, float* __restrict__ comps,
+    float4* __restrict__ grec) {
+    const int64_t total = (int64_t)P.n_cams * P.n_gauss;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int cam_i = (int)(idx / P.n_gauss);
+        const int g = (int)(idx - (int64_t)cam_i * P.n_gauss);
+        const Cam cam = load_cam(viewmats + 16 * cam_i, Ks + 9 * cam_i);
+        float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+        float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
+        float scale[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+        const float opac = opacities[g];
+        int32_t rxi = 0, ryi = 0;
+        float mx = 0.f, my = 0.f, dep = 0.f, cn0 = 0.f, cn1 = 0.f, cn2 = 0.f, comp = 0.f, rt = 0.f, oeff = 0.f;
+        float rp[2] = {0.f, 0.f}, nr[3] = {0.f, 0.f, 0.f};
+        ProjState S;
+        bool ok = project_one(mean, quat, scale, cam, P, S);
+        if (ok) {
+            float extend = P.radius_sigma;
+            float o = opac;
+            if (P.antialiased) o = o * S.comp;
+            if (P.opacity_aware_radius) {
+                if (o < P.alpha_min) ok = false;
+                else {
+                    float e2 = sqrtf(2.0f * det_log(o / P.alpha_min));
+                    extend = extend < e2 ? extend : e2;
+                }
+            }
+            if (ok) {
+                float mid = 0.5f * (S.a + S.c);
+                float disc = mid * mid - S.det;
+                float v1 = mid + sqrtf(0.01f > disc ? 0.01f : disc);
+                float sv1 = extend * sqrtf(v1);
+                float ex = extend * sqrtf(S.a), ey = extend * sqrtf(S.c);
+                float rx = ceilf(ex < sv1 ? ex : sv1);
+                float ry = ceilf(ey < sv1 ? ey : sv1);
+                float mxx = cam.fx * S.u + cam.cx, myy = cam.fy * S.v + cam.cy;
+                if (rx <= P.radius_clip && ry <= P.radius_clip) ok = false;
+                else if (mxx + rx <= 0.0f || mxx - rx >= (float)P.width || myy + ry <= 0.0f ||
+                         myy - ry >= (float)P.height) ok = false;
+                if (ok) {
+                    rxi = (int32_t)rx; ryi = (int32_t)ry;
+                    mx = mxx; my = myy; dep = S.mu[2];
+                    cn0 = S.c / S.det; cn1 = -S.b / S.det; cn2 = S.a / S.det;
+                    comp = S.comp; oeff = o;
+                    rade_extras(scale, cam, P, S, rt, rp, nr);
+                }
+            }
+        }
+        radii[2 * idx] = rxi; radii[2 * idx + 1] = ryi;
+        means2d[2 * idx] = mx; means2d[2 * idx + 1] = my;
+        depths[idx] = dep; comps[idx] = comp;
+        grec[4 * idx + 0] = make_float4(mx, my, cn0, cn1);
+        grec[4 * idx + 1] = make_float4(cn2, oeff, rt, rp[0]);
+        grec[4 * idx + 2] = make_float4(rp[1], nr[0], nr[1], nr[2]);
+    }
+}
+
+// Colour slots of the record.  sh_degree >= 0: colour = max(SH(dir) + 0.5, 0) with
+// dir = mean - camera_centre (rade_features_model.py:428-438); sh_degree < 0: the first
+// min(D, 4) entries of colors[(cam,) g, D] are copied.  depth_channel: channel n_color = depth.
+// SH coefficients ([N, K, 3], 12 K bytes per Gaussian) are staged through LDS in whole
+// coalesced lines and read back at a stride of 3K+1 floats (conflict-free).
+template <bool BWD>
+__global__ __launch_bounds__(256) void color_sh_kernel(
+    misplat_params P, int K, int deg, int depth_channel, const float* __restrict__ means,
+    const float* __restrict__ viewmats, const float* __restrict__ coeffs,
+    const int32_t* __restrict__ radii, const float* __restrict__ depths, float* __restrict__ grec,
+    const float* __restrict__ v_grec, float* __restrict__ v_coeffs, float* __restrict__ v_means_dir) {
+    extern __shared__ float lds[];
+    const int row = 3 * K, stride = row + 1;
+    const int nb = (deg + 1) * (deg + 1);
+    const int n_blocks = (P.n_gauss + 255) / 256;
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const int g0 = blk * 256;
+        const int cnt = min(256, P.n_gauss - g0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * row; e += 256) {
+            const int t = e / row, k = e - t * row;
+            lds[t * stride + k] = coeffs[(size_t)g0 * row + e];
+        }
+        __syncthreads();
+        const int t = threadIdx.x;
+        const int g = g0 + t;
+        float acc[48];
+        float vmd[3] = {0.f, 0.f, 0.f};
+        if (BWD) {
+#pragma unroll
+            for (int k = 0; k < 48; k++) acc[k] = 0.f;
+        }
+        if (t < cnt) {
+            const float* cf = lds + t * stride;
+            for (int ci = 0; ci < P.n_cams; ci++) {
+                const int64_t idx = (int64_t)ci * P.n_gauss + g;
+                const bool vis = radii[2 * idx] > 0 || radii[2 * idx + 1] > 0;
+                float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+                if (vis) {
+                    const float* V = viewmats + 16 * ci;
+                    // camera centre = -R^T t
+                    const float ccx = -(V[0] * V[3] + V[4] * V[7] + V[8] * V[11]);
+                    const float ccy = -(V[1] * V[3] + V[5] * V[7] + V[9] * V[11]);
+                    const float ccz = -(V[2] * V[3] + V[6] * V[7] + V[10] * V[11]);
+                    const float dx = means[3 * g] - ccx, dy = means[3 * g + 1] - ccy, dz = means[3 * g + 2] - ccz;
+                    const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+                    const float inv = n > 0.f ? 1.0f / n : 0.f;
+                    const float x = dx * inv, y = dy * inv, z = dz * inv;
+                    float b[16], bx[16], by[16], bz[16];
+                    sh_basis<BWD>(deg, x, y, z, b, bx, by, bz);
+#pragma unroll
+                    for (int k = 0; k < 16; k++)
+                        if (k < nb) { c0 += b[k] * cf[3 * k]; c1 += b[k] * cf[3 * k + 1]; c2 += b[k] * cf[3 * k + 2]; }
+                    if (BWD) {
+                        const float* vg = v_grec + (size_t)idx * MISPLAT_REC + 12;
+                        const float vc0 = (c0 + 0.5f > 0.f) ? vg[0] : 0.f;
+                        const float vc1 = (c1 + 0.5f > 0.f) ? vg[1] : 0.f;
+                        const float vc2 = (c2 + 0.5f > 0.f) ? vg[2] : 0.f;
+                        float vd0 = 0.f, vd1 = 0.f, vd2 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                            if (k < nb) {
+                                acc[3 * k] += b[k] * vc0; acc[3 * k + 1] += b[k] * vc1; acc[3 * k + 2] += b[k] * vc2;
+                                const float s = cf[3 * k] * vc0 + cf[3 * k + 1] * vc1 + cf[3 * k + 2] * vc2;
+                                vd0 += bx[k] * s; vd1 += by[k] * s; vd2 += bz[k] * s;
+                            }
+                        const float dot = x * vd0 + y * vd1 + z * vd2;
+                        vmd[0] += (vd0 - x * dot) * inv; vmd[1] += (vd1 - y * dot) * inv; vmd[2] += (vd2 - z * dot) * inv;
+                    }
+                }
+                if (!BWD) {
+                    float* o = grec + (size_t)idx * MISPLAT_REC + 12;
+                    float4 c = make_float4(fmaxf(c0 + 0.5f, 0.f), fmaxf(c1 + 0.5f, 0.f), fmaxf(c2 + 0.5f, 0.f),
+                                           depth_channel ? depths[idx] : 0.f);
+                    if (!vis) c = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(o) = c;
+                }
+            }
+        }
+        if (BWD) {
+            // gradient rows back through LDS so the global stores are whole coalesced lines
+            __syncthreads();
+            if (t < cnt) {
+                float* cf = lds + t * stride;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (k < K) {
+                        const bool on = k < nb;
+                        cf[3 * k] = on ? acc[3 * k] : 0.f; cf[3 * k + 1] = on ? acc[3 * k + 1] : 0.f; cf[3 * k + 2] = on ? acc[3 * k + 2] : 0.f;
+                    }
+                }
+                for (int k = 16; k < K; k++) { cf[3 * k] = 0.f; cf[3 * k + 1] = 0.f; cf[3 * k + 2] = 0.f; }
+                v_means_dir[3 * g] = vmd[0]; v_means_dir[3 * g + 1] = vmd[1]; v_means_dir[3 * g + 2] = vmd[2];
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < cnt * row; e += 256) {
+                const int tt = e / row, k = e - tt * row;
+                v_coeffs[(size_t)g0 * row + e] = lds[tt * stride + k];
+            }
+        }
+    }
+}
+
+// pass-through colours: colors [N, D] (per_cam = 0) or [C, N, D] (per_cam = 1), D <= 4 channels used
+__global__ __launch_bounds__(256) void color_copy_kernel(misplat_params P, int D, int n_color, int per_cam,
+                                                         int depth_channel, const float* __restrict__ colors,
+                                                         const int32_t* __restrict__ radii,
+                                                         const float* __restrict__ depths, float* __restrict__ grec) {
+    const int64_t total = (int64_t)P.n_cams * P.n_gauss;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = per_cam ? idx : idx % P.n_gauss;
+        float c[4] = {0.f, 0.f, 0.f, 0.f};
+        if (radii[2 * idx] > 0 || radii[2 * idx + 1] > 0) {
+            for (int k = 0; k < n_color; k++) c[k] = colors[(size_t)src * D + k];
+            if (depth_channel) c[n_color] = depths[idx];
+        }
+        *reinterpret_cast<float4*>(grec + (size_t)idx * MISPLAT_REC + 12) = make_float4(c[0], c[1], c[2], c[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void color_copy_bwd_kernel(misplat_params P, int D, int n_color, int per_cam,
+                                                             const int32_t* __restrict__ radii,
+                                                             const float* __restrict__ v_grec,
+                                                             float* __restrict__ v_colors) {
+    const int64_t rows = per_cam ? (int64_t)P.n_cams * P.n_gauss : P.n_gauss;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        float c[4] = {0.f, 0.f, 0.f, 0.f};
+        const int c_lo = per_cam ? (int)(r / P.n_gauss) : 0, c_hi = per_cam ? c_lo + 1 : P.n_cams;
+        const int g = (int)(r % P.n_gauss);
+        for (int ci = c_lo; ci < c_hi; ci++) {
+            const int64_t idx = (int64_t)ci * P.n_gauss + g;
+            if (radii[2 * idx] > 0 || radii[2 * idx + 1] > 0)
+                for (int k = 0; k < n_color; k++) c[k] += v_grec[(size_t)idx * MISPLAT_REC + 12 + k];
+        }
+        for (int k = 0; k < D; k++) v_colors[(size_t)r * D + k] = k < n_color ? c[k] : 0.f;
+    }
+}
+
+// Backward of project_pack_fwd from packed gradient rows.  depth_slot: index (12..15) of the
+// colour channel that carries the depth (RGB+ED / ED), or -1.  v_means_dir (or NULL) is the
+// gradient that reached the means through the SH view direction; it is added here.
+__global__ __launch_bounds__(256) void project_pack_bwd_kernel(
+    misplat_params P, int depth_slot, const float* __restrict__ means, const float* __restrict__ quats,
+    const float* __restrict__ scales, const float* __restrict__ opacities,
+    const float* __restrict__ viewmats, const float* __restrict__ Ks, const int32_t* __restrict__ radii,
+    const float* __restrict__ comps, const float* __restrict__ v_means2d, const float* __restrict__ v_grec,
+    const float* __restrict__ v_means_dir, float* __restrict__ v_means, float* __restrict__ v_quats,
+    float* __restrict__ v_scales, float* __restrict__ v_opacities) {
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P.n_gauss; g += gridDim.x * blockDim.x) {
+        float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+        float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
+        float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+        const float opac = opacities[g];
+        float o_m[3] = {0.f, 0.f, 0.f}, o_q[4] = {0.f, 0.f, 0.f, 0.f}, o_s[3] = {0.f, 0.f, 0.f};
+        float o_op = 0.f;
+        if (v_means_dir) { o_m[0] = v_means_dir[3 * g]; o_m[1] = v_means_dir[3 * g + 1]; o_m[2] = v_means_dir[3 * g + 2]; }
+        for (int ci = 0; ci < P.n_cams; ci++) {
+            const int64_t idx = (int64_t)ci * P.n_gauss + g;
+            if (radii[2 * idx] <= 0 && radii[2 * idx + 1] <= 0) continue;
+            const Cam cam = load_cam(viewmats + 16 * ci, Ks + 9 * ci);
+            const float4* vg = reinterpret_cast<const float4*>(v_grec + (size_t)idx * MISPLAT_REC);
+            const float4 g0 = vg[0], g1 = vg[1], g2 = vg[2], g3 = vg[3];
+            ProjGrads G;
+            G.v_m2d[0] = v_means2d[2 * idx]; G.v_m2d[1] = v_means2d[2 * idx + 1];   // (not g0.x/g0.y: see ops.py)
+            G.v_conic[0] = g0.z; G.v_conic[1] = g0.w; G.v_conic[2] = g1.x;
+            const float v_oeff = g1.y;
+            G.v_rt = g1.z; G.v_rp[0] = g1.w; G.v_rp[1] = g2.x;
+            G.v_nr[0] = g2.y; G.v_nr[1] = g2.z; G.v_nr[2] = g2.w;
+            G.v_depth = depth_slot == 12 ? g3.x : (depth_slot == 13 ? g3.y : (depth_slot == 14 ? g3.z : (depth_slot == 15 ? g3.w : 0.f)));
+            if (P.antialiased) { o_op += v_oeff * comps[idx]; G.v_comp = v_oeff * opac; }
+            else { o_op += v_oeff; G.v_comp = 0.f; }
+            project_bwd_one(mean, quat, sc, cam, P, G, o_m, o_q, o_s);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v_means[3 * g + k] = o_m[k]; v_scales[3 * g + k] = o_s[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) v_quats[4 * g + k] = o_q[k];
+        v_opacities[g] = o_op;
+    }
+}
+
 inline int grid_for(int64_t n, int block) {
     int64_t b = (n + block - 1) / block;
     if (b > 8192) b = 8192;
@@ -544,5 +814,81 @@ extern "C" int misplat_sh_bwd(int32_t n_gauss, int32_t n_cams, int32_t K, int32_
     if (n_gauss == 0) return MISPLAT_OK;
     hipLaunchKernelGGL(sh_bwd_kernel, dim3(grid_for(n_gauss, 256)), dim3(256), 0, (hipStream_t)stream, n_gauss,
                        n_cams, K, degree, dirs, coeffs, radii, v_colors, v_coeffs, v_dirs);
+    return check_launch();
+}
+
+// ------------------------------------------------------------------ fused path entry points
+extern "C" int misplat_project_pack_fwd(const misplat_params* p, const float* means, const float* quats,
+                                        const float* scales, const float* opacities, const float* viewmats,
+                                        const float* Ks, int32_t* radii, float* means2d, float* depths,
+                                        float* compensations, float* grec, misplat_stream_t stream) {
+    if (!p || p->n_gauss < 0 || p->n_cams < 1 || p->width < 1 || p->height < 1) return MISPLAT_EINVAL;
+    int64_t total = (int64_t)p->n_gauss * p->n_cams;
+    if (total == 0) return MISPLAT_OK;
+    if (!opacities) return MISPLAT_EINVAL;
+    hipLaunchKernelGGL(project_pack_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *p,
+                       means, quats, scales, opacities, viewmats, Ks, radii, means2d, depths, compensations,
+                       (float4*)grec);
+    return check_launch();
+}
+
+extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
+                                 int32_t per_cam, int32_t depth_channel, const float* means,
+                                 const float* viewmats, const float* coeffs_or_colors, const int32_t* radii,
+                                 const float* depths, float* grec, misplat_stream_t stream) {
+    if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
+    if (n_color < 0 || n_color + (depth_channel ? 1 : 0) > 4) return MISPLAT_EINVAL;
+    if (p->n_gauss == 0) return MISPLAT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (sh_degree >= 0) {
+        if (sh_degree > 3 || K_or_D < (sh_degree + 1) * (sh_degree + 1) || K_or_D > 16 || n_color != 3) return MISPLAT_EINVAL;
+        const int n_blocks = (p->n_gauss + 255) / 256;
+        const size_t lds = (size_t)256 * (3 * K_or_D + 1) * sizeof(float);
+        hipLaunchKernelGGL((color_sh_kernel<false>), dim3(n_blocks < 4096 ? n_blocks : 4096), dim3(256), lds, s, *p,
+                           K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, radii, depths, grec,
+                           (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+    } else {
+        if (K_or_D < n_color) return MISPLAT_EINVAL;
+        int64_t total = (int64_t)p->n_gauss * p->n_cams;
+        hipLaunchKernelGGL(color_copy_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, *p, K_or_D, n_color,
+                           per_cam, depth_channel, coeffs_or_colors, radii, depths, grec);
+    }
+    return check_launch();
+}
+
+extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
+                                 int32_t per_cam, const float* means, const float* viewmats,
+                                 const float* coeffs_or_colors, const int32_t* radii, const float* v_grec,
+                                 float* v_coeffs_or_colors, float* v_means_dir, misplat_stream_t stream) {
+    if (!p || p->n_gauss < 0 || p->n_cams < 1 || n_color < 0 || n_color > 4) return MISPLAT_EINVAL;
+    if (p->n_gauss == 0) return MISPLAT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (sh_degree >= 0) {
+        if (sh_degree > 3 || K_or_D < (sh_degree + 1) * (sh_degree + 1) || K_or_D > 16 || !v_means_dir) return MISPLAT_EINVAL;
+        const int n_blocks = (p->n_gauss + 255) / 256;
+        const size_t lds = (size_t)256 * (3 * K_or_D + 1) * sizeof(float);
+        hipLaunchKernelGGL((color_sh_kernel<true>), dim3(n_blocks < 4096 ? n_blocks : 4096), dim3(256), lds, s, *p,
+                           K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, radii, (const float*)nullptr,
+                           (float*)nullptr, v_grec, v_coeffs_or_colors, v_means_dir);
+    } else {
+        int64_t rows = per_cam ? (int64_t)p->n_gauss * p->n_cams : p->n_gauss;
+        hipLaunchKernelGGL(color_copy_bwd_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, s, *p, K_or_D, n_color,
+                           per_cam, radii, v_grec, v_coeffs_or_colors);
+    }
+    return check_launch();
+}
+
+extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_slot, const float* means,
+                                        const float* quats, const float* scales, const float* opacities,
+                                        const float* viewmats, const float* Ks, const int32_t* radii,
+                                        const float* compensations, const float* v_means2d, const float* v_grec,
+                                        const float* v_means_dir, float* v_means, float* v_quats,
+                                        float* v_scales, float* v_opacities, misplat_stream_t stream) {
+    if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
+    if (depth_slot != -1 && (depth_slot < 12 || depth_slot > 15)) return MISPLAT_EINVAL;
+    if (p->n_gauss == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(project_pack_bwd_kernel, dim3(grid_for(p->n_gauss, 256)), dim3(256), 0, (hipStream_t)stream,
+                       *p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii, compensations, v_means2d,
+                       v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities);
     return check_launch();
 }

@@ -225,25 +225,8 @@ class _Blend(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, _l, _m):
-        lib = _lib.load()
-        grec, Ks, alpha, last_ids, median_ids = ctx.saved_tensors
-        P, bins, cd = ctx.P, ctx.bins, ctx.cd
-        n_isects = bins["n_isects"]
-        rows = P.n_cams * P.n_gauss
-        dev = grec.device
-        slab = torch.empty(max(n_isects, 1), MISPLAT_REC, device=dev, dtype=torch.float32)
-        slab_abs = torch.empty(max(n_isects, 1), 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
-        ups = [_c(t) for t in (v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)]
-        with _timed("blend_bwd"):
-            check(lib.misplat_blend_bwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
-                                        ptr(bins["slots"]), ptr(bins["isect_offsets"]), C.c_int64(n_isects),
-                                        ptr(alpha), ptr(last_ids), ptr(median_ids), *[ptr(t) for t in ups],
-                                        ptr(slab), ptr(slab_abs), stream_ptr()), "misplat_blend_bwd")
-        v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
-        v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
-        check(lib.misplat_slab_reduce(C.c_int64(rows), ptr(bins["cum"]), ptr(bins["tiles_per_gauss"]),
-                                      ptr(slab), ptr(slab_abs), ptr(v_grec), ptr(v_abs), stream_ptr()),
-              "misplat_slab_reduce")
+        v_grec, v_abs = _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
+        P, cd = ctx.P, ctx.cd
         Cn, N = P.n_cams, P.n_gauss
         g = v_grec.view(Cn, N, MISPLAT_REC)
         if ctx.absgrad:
@@ -262,6 +245,140 @@ def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Par
     if args[0] is not means2d:
         raise ValueError("means2d must be contiguous float32 so that its .grad/.absgrad can be retained")
     return _Blend.apply(*args, P, bins, bool(absgrad))
+
+
+# ----------------------------------------------------------------------------- fused path
+
+class _ProjectPack(torch.autograd.Function):
+    """projection + colour (SH or pass-through) -> packed blend records, one autograd node.
+
+    Outputs (radii, means2d, depths, compensations, grec).  ``means2d`` is a separate
+    differentiable output so that ``meta["means2d"].retain_grad()`` works (rade_gs_model.py:191-198);
+    every other gradient travels in the packed rows ``v_grec`` (columns 0:2 of which are ignored
+    here -- the mean2d gradient arrives through ``v_means2d``)."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, P: Params, sh_degree,
+                depth_channel: bool):
+        lib = _lib.load()
+        require_gpu(means, quats, scales, opacities, colors, viewmats, Ks)
+        N, Cn = P.n_gauss, P.n_cams
+        dev = means.device
+        radii = torch.empty(Cn, N, 2, device=dev, dtype=torch.int32)
+        means2d = torch.empty(Cn, N, 2, device=dev, dtype=torch.float32)
+        depths = torch.empty(Cn, N, device=dev, dtype=torch.float32)
+        comps = torch.empty(Cn, N, device=dev, dtype=torch.float32)
+        grec = torch.empty(Cn * N, MISPLAT_REC, device=dev, dtype=torch.float32)
+        check(lib.misplat_project_pack_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
+                                           ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
+                                           ptr(comps), ptr(grec), stream_ptr()), "misplat_project_pack_fwd")
+        if sh_degree is not None:
+            deg, kd, n_color, per_cam = int(sh_degree), colors.shape[1], 3, 0
+        else:
+            deg, kd, per_cam = -1, colors.shape[-1], int(colors.dim() == 3)
+            n_color = kd
+        check(lib.misplat_color_fwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
+                                    C.c_int32(per_cam), C.c_int32(int(depth_channel)), ptr(means), ptr(viewmats),
+                                    ptr(colors), ptr(radii), ptr(depths), ptr(grec), stream_ptr()),
+              "misplat_color_fwd")
+        ctx.P, ctx.color_args = P, (deg, kd, n_color, per_cam)
+        ctx.depth_slot = 12 + n_color if depth_channel else -1
+        ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps)
+        ctx.mark_non_differentiable(radii, depths, comps)
+        return radii, means2d, depths, comps, grec
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, _v_depths, _v_comps, v_grec):
+        lib = _lib.load()
+        means, quats, scales, opacities, colors, viewmats, Ks, radii, comps = ctx.saved_tensors
+        P = ctx.P
+        deg, kd, n_color, per_cam = ctx.color_args
+        v_means2d, v_grec = _c(v_means2d), _c(v_grec)
+        v_colors = torch.empty_like(colors)
+        v_means_dir = torch.empty_like(means) if deg >= 0 else None
+        check(lib.misplat_color_bwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
+                                    C.c_int32(per_cam), ptr(means), ptr(viewmats), ptr(colors), ptr(radii),
+                                    ptr(v_grec), ptr(v_colors), ptr(v_means_dir), stream_ptr()), "misplat_color_bwd")
+        v_means, v_quats = torch.empty_like(means), torch.empty_like(quats)
+        v_scales, v_opac = torch.empty_like(scales), torch.empty_like(opacities)
+        check(lib.misplat_project_pack_bwd(C.byref(P), C.c_int32(ctx.depth_slot), ptr(means), ptr(quats),
+                                           ptr(scales), ptr(opacities), ptr(viewmats), ptr(Ks), ptr(radii),
+                                           ptr(comps), ptr(v_means2d), ptr(v_grec), ptr(v_means_dir), ptr(v_means),
+                                           ptr(v_quats), ptr(v_scales), ptr(v_opac), stream_ptr()),
+              "misplat_project_pack_bwd")
+        return v_means, v_quats, v_scales, v_opac, v_colors, None, None, None, None, None
+
+
+def project_pack(means, quats, scales, opacities, colors, viewmats, Ks, P: Params, sh_degree, depth_channel):
+    args = [_f32(t, n) for t, n in ((means, "means"), (quats, "quats"), (scales, "scales"),
+                                    (opacities, "opacities"), (colors, "colors"), (viewmats, "viewmats"), (Ks, "Ks"))]
+    return _ProjectPack.apply(*args, P, sh_degree, bool(depth_channel))
+
+
+class _BlendPacked(torch.autograd.Function):
+    """Compositing straight from the packed records (<= 4 colour slots)."""
+
+    @staticmethod
+    def forward(ctx, means2d, grec, Ks, P: Params, bins: Dict[str, Tensor], absgrad: bool, cd: int):
+        lib = _lib.load()
+        Cn, H, W = P.n_cams, P.height, P.width
+        dev = grec.device
+        f = dict(device=dev, dtype=torch.float32)
+        render = torch.empty(Cn, H, W, cd, **f)
+        alpha = torch.empty(Cn, H, W, 1, **f)
+        exp_depth = torch.empty(Cn, H, W, 1, **f)
+        med_depth = torch.empty(Cn, H, W, 1, **f)
+        normal = torch.empty(Cn, H, W, 3, **f)
+        last_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
+        median_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
+        with _timed("blend_fwd"):
+            check(lib.misplat_blend_fwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
+                                        ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(render),
+                                        ptr(alpha), ptr(exp_depth), ptr(med_depth), ptr(normal), ptr(last_ids),
+                                        ptr(median_ids), stream_ptr()), "misplat_blend_fwd")
+        ctx.P, ctx.bins, ctx.absgrad, ctx.cd = P, bins, absgrad, cd
+        ctx.means2d_ref = means2d if absgrad else None
+        ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids)
+        ctx.mark_non_differentiable(last_ids, median_ids)
+        return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
+
+    @staticmethod
+    def backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, _l, _m):
+        v_grec, v_abs = _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
+        P = ctx.P
+        if ctx.absgrad:
+            ctx.means2d_ref.absgrad = v_abs.view(P.n_cams, P.n_gauss, 2)
+        return v_grec.view(P.n_cams, P.n_gauss, MISPLAT_REC)[..., 0:2], v_grec, None, None, None, None, None
+
+
+def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
+    """blend_bwd -> per-intersection rows -> fixed-order per-Gaussian sum.  Returns (v_grec, v_abs)."""
+    lib = _lib.load()
+    grec, Ks, alpha, last_ids, median_ids = ctx.saved_tensors
+    P, bins, cd = ctx.P, ctx.bins, ctx.cd
+    n_isects = bins["n_isects"]
+    rows = P.n_cams * P.n_gauss
+    dev = grec.device
+    slab = torch.empty(max(n_isects, 1), MISPLAT_REC, device=dev, dtype=torch.float32)
+    slab_abs = torch.empty(max(n_isects, 1), 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
+    ups = [_c(t) for t in (v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)]
+    with _timed("blend_bwd"):
+        check(lib.misplat_blend_bwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
+                                    ptr(bins["slots"]), ptr(bins["isect_offsets"]), C.c_int64(n_isects),
+                                    ptr(alpha), ptr(last_ids), ptr(median_ids), *[ptr(t) for t in ups],
+                                    ptr(slab), ptr(slab_abs), stream_ptr()), "misplat_blend_bwd")
+    v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
+    v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
+    check(lib.misplat_slab_reduce(C.c_int64(rows), ptr(bins["cum"]), ptr(bins["tiles_per_gauss"]),
+                                  ptr(slab), ptr(slab_abs), ptr(v_grec), ptr(v_abs), stream_ptr()),
+          "misplat_slab_reduce")
+    return v_grec, v_abs
+
+
+def blend_packed(means2d, grec, Ks, P: Params, bins, absgrad: bool, cd: int):
+    if not 1 <= cd <= 4:
+        raise ValueError("blend_packed() takes 1..4 colour channels")
+    return _BlendPacked.apply(means2d, grec, _f32(Ks, "Ks"), P, bins, bool(absgrad), int(cd))
 
 
 # ----------------------------------------------------------------------------- depth -> normal

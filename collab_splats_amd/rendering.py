@@ -86,40 +86,51 @@ def rasterization(
     viewmats = viewmats.contiguous().float()
     Ks = Ks.contiguous().float()
 
-    # a2.1 projection (+ RaDe ray-distance plane and normal)
-    radii, means2d, depths, conics, comps, ray_ts, ray_planes, normals = ops.project(
-        means, quats, scales, opacities, viewmats, Ks, P)
-    opac = opacities[None, :].expand(Cn, N)
-    opac = opac * comps if aa else opac.contiguous()
-
-    # a2.2 colour
-    if sh_degree is not None:
-        cam_centers = -torch.einsum("cji,cj->ci", viewmats[:, :3, :3], viewmats[:, :3, 3])   # -R^T t
-        dirs = means[None, :, :] - cam_centers[:, None, :]
-        cols = ops.spherical_harmonics_raw(sh_degree, dirs, colors, radii)
-        cols = torch.clamp_min(cols + 0.5, 0.0)                  # rade_features_model.py:438
+    depth_channel = render_mode in ("RGB+D", "RGB+ED", "D", "ED")
+    n_user = 0 if render_mode in ("D", "ED") else (3 if sh_degree is not None else colors.shape[-1])
+    fused = n_user + int(depth_channel) <= 4 and (sh_degree is None or colors.shape[1] <= 16)
+    if fused:
+        # ---- the reference's path (RGB / RGB+ED, SH or RGB colours): two autograd nodes, no glue kernels
+        cin = colors if n_user > 0 else means.new_zeros(N, 1)
+        radii, means2d, depths, comps, grec = ops.project_pack(
+            means, quats, scales, opacities, cin if n_user > 0 else cin[:, :0].contiguous(), viewmats, Ks, P,
+            sh_degree if n_user > 0 else None, depth_channel)
+        bins = ops.bin_tiles(P, means2d, radii, depths)
+        D = n_user + int(depth_channel)
+        first = ops.blend_packed(means2d, grec, Ks, P, bins, absgrad, D)
+        render = first[0]
+        gv = grec.view(Cn, N, 16)
+        conics, opac, ray_ts, ray_planes, normals = gv[..., 2:5], gv[..., 5], gv[..., 6], gv[..., 7:9], gv[..., 9:12]
     else:
-        cols = colors if colors.dim() == 3 else colors[None].expand(Cn, N, colors.shape[-1])
-    if render_mode in ("RGB+D", "RGB+ED"):
-        cols = torch.cat([cols, depths[..., None]], dim=-1)
-    elif render_mode in ("D", "ED"):
-        cols = depths[..., None]
-    cols = cols.contiguous()
-    D = cols.shape[-1]
-
-    # a2.3 binning
-    bins = ops.bin_tiles(P, means2d, radii, depths)
-
-    # a2.4 compositing, 4 colour channels per pass (the geometry outputs come from pass 0)
-    renders = []
-    first = None
-    for s in range(0, D, 4):
-        out = ops.blend(means2d, conics, opac, cols[..., s:s + 4], ray_ts, ray_planes, normals, Ks, P, bins,
-                        absgrad=absgrad and s == 0)
-        renders.append(out[0])
-        if first is None:
-            first = out
-    render = renders[0] if len(renders) == 1 else torch.cat(renders, dim=-1)
+        # ---- generic path: any number of colour channels (rade_features_model.py:441-476, D = 16 / 17),
+        # composited 4 channels per pass; the geometry outputs come from pass 0
+        radii, means2d, depths, conics, comps, ray_ts, ray_planes, normals = ops.project(
+            means, quats, scales, opacities, viewmats, Ks, P)
+        opac = opacities[None, :].expand(Cn, N)
+        opac = opac * comps if aa else opac.contiguous()
+        if sh_degree is not None:
+            cam_centers = -torch.einsum("cji,cj->ci", viewmats[:, :3, :3], viewmats[:, :3, 3])   # -R^T t
+            dirs = means[None, :, :] - cam_centers[:, None, :]
+            cols = ops.spherical_harmonics_raw(sh_degree, dirs, colors, radii)
+            cols = torch.clamp_min(cols + 0.5, 0.0)                  # rade_features_model.py:438
+        else:
+            cols = colors if colors.dim() == 3 else colors[None].expand(Cn, N, colors.shape[-1])
+        if render_mode in ("RGB+D", "RGB+ED"):
+            cols = torch.cat([cols, depths[..., None]], dim=-1)
+        elif render_mode in ("D", "ED"):
+            cols = depths[..., None]
+        cols = cols.contiguous()
+        D = cols.shape[-1]
+        bins = ops.bin_tiles(P, means2d, radii, depths)
+        renders = []
+        first = None
+        for s in range(0, D, 4):
+            out = ops.blend(means2d, conics, opac, cols[..., s:s + 4], ray_ts, ray_planes, normals, Ks, P, bins,
+                            absgrad=absgrad and s == 0)
+            renders.append(out[0])
+            if first is None:
+                first = out
+        render = renders[0] if len(renders) == 1 else torch.cat(renders, dim=-1)
     alpha, exp_depth, med_depth, exp_normal = first[1], first[2], first[3], first[4]
 
     if render_mode in ("ED", "RGB+ED"):

@@ -96,6 +96,38 @@ int misplat_sh_bwd(int32_t n_gauss, int32_t n_cams, int32_t K, int32_t degree, c
                    float* v_coeffs /*[N,K,3]*/, float* v_dirs /*[C*N,3]*/,
                    misplat_stream_t stream);
 
+/* ---- fused per-Gaussian stages (what rasterization() runs; same math as the entry points above,
+ * without the SoA round trips).  project_pack_fwd writes the geometry part of the packed blend
+ * record (layout: see misplat_pack) straight away; color_fwd fills the record's colour slots:
+ *   sh_degree >= 0: colour = max(SH_deg(mean - camera_centre) . coeffs[N,K,3] + 0.5, 0), K <= 16
+ *                   (rade_features_model.py:428-438; coefficients staged through LDS, coalesced);
+ *   sh_degree <  0: the first n_color (<= 4) of the D colour channels are copied
+ *                   (colors [N,D], or [C,N,D] when per_cam).
+ * depth_channel != 0 puts the z-depth into colour slot n_color (RGB+ED / ED render modes).
+ * The backward kernels consume the packed gradient rows v_grec[C*N,16] produced by
+ * misplat_slab_reduce; v_means2d is passed separately (it is a retained autograd node). */
+int misplat_project_pack_fwd(const misplat_params* p, const float* means, const float* quats,
+                             const float* scales, const float* opacities, const float* viewmats,
+                             const float* Ks, int32_t* radii, float* means2d, float* depths,
+                             float* compensations, float* grec, misplat_stream_t stream);
+int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
+                      int32_t per_cam, int32_t depth_channel, const float* means,
+                      const float* viewmats, const float* coeffs_or_colors, const int32_t* radii,
+                      const float* depths, float* grec, misplat_stream_t stream);
+int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
+                      int32_t per_cam, const float* means, const float* viewmats,
+                      const float* coeffs_or_colors, const int32_t* radii, const float* v_grec,
+                      float* v_coeffs_or_colors, float* v_means_dir /*[N,3], SH only*/,
+                      misplat_stream_t stream);
+/* depth_slot: 12..15 = record slot carrying the depth channel, -1 = none.  v_means_dir may be
+ * NULL.  Outputs v_means[N,3] v_quats[N,4] v_scales[N,3] v_opacities[N], summed over cameras. */
+int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_slot, const float* means,
+                             const float* quats, const float* scales, const float* opacities,
+                             const float* viewmats, const float* Ks, const int32_t* radii,
+                             const float* compensations, const float* v_means2d, const float* v_grec,
+                             const float* v_means_dir, float* v_means, float* v_quats,
+                             float* v_scales, float* v_opacities, misplat_stream_t stream);
+
 /* ---- a2.3 binning.  tiles_per_gauss[C*N] = number of 16x16 tiles the rect mean2d +- radii
  * touches (0 if culled). */
 int misplat_tile_count(const misplat_params* p, const float* means2d, const int32_t* radii,

@@ -1,0 +1,15 @@
+"""Summarise rocprofv3 --pmc CSVs: per kernel, per counter, mean over dispatches."""
+import csv, glob, sys, collections, json
+root = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        for key in ("blend_fwd", "blend_bwd", "slab_reduce", "sh_fwd", "sh_bwd", "project_fwd", "project_bwd", "tile_emit", "tile_offsets", "pack_kernel", "rocprim"):
+            if key in k:
+                agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                break
+out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in agg.items()}
+for k, d in out.items():
+    print(k, {c: f"{v:.4g}" for c, v in sorted(d.items())})
+json.dump(out, open(root + "/summary.json", "w"), indent=1)
