@@ -56,6 +56,8 @@ def algorithmic_bytes(kernel: str, N: int, I: int, P: int) -> float:
         return 88.0 * P + 64.0 * I + 60.0 * N     # saved outputs + upstream grads, re-gather, 2-D grads
     if kernel == "blend_fwd":
         return 64.0 * I + 48.0 * P                 # record gather, pixel outputs incl. saved indices
+    if kernel == "slab_reduce":
+        return 64.0 * I + 64.0 * N                 # one gradient row per intersection in, one per Gaussian out
     raise KeyError(kernel)
 
 

@@ -9,6 +9,7 @@ from ._lib import MisplatError, load as load_library  # noqa: F401
 from .rendering import rasterization  # noqa: F401
 from .wrapper import fully_fused_projection, spherical_harmonics  # noqa: F401
 from .strategy import DefaultStrategy  # noqa: F401
+from .ops import set_deterministic  # noqa: F401
 
 __version__ = "0.1.0"
 

@@ -34,7 +34,8 @@ class Params(C.Structure):
                 ("opacity_aware_radius", C.c_int32), ("eps2d", C.c_float), ("near_plane", C.c_float),
                 ("far_plane", C.c_float), ("radius_clip", C.c_float), ("radius_sigma", C.c_float),
                 ("alpha_max", C.c_float), ("alpha_min", C.c_float), ("t_stop", C.c_float),
-                ("median_t", C.c_float), ("jacobian_margin", C.c_float), ("plane_eps", C.c_float)]
+                ("median_t", C.c_float), ("jacobian_margin", C.c_float), ("plane_eps", C.c_float),
+                ("ppl_fwd", C.c_int32), ("ppl_bwd", C.c_int32)]
 
 
 def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: int = 16,
@@ -42,14 +43,15 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
                 near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0,
                 radius_sigma: float = 3.33, alpha_max: float = 0.999, alpha_min: float = 1.0 / 255.0,
                 t_stop: float = 1e-4, median_t: float = 0.5, jacobian_margin: float = 0.3,
-                plane_eps: float = 1e-6) -> Params:
+                plane_eps: float = 1e-6, ppl_fwd: int = 0, ppl_bwd: int = 0) -> Params:
     if tile_size != MISPLAT_TILE:
         raise ValueError(f"tile_size must be {MISPLAT_TILE} (got {tile_size})")
     tw = (width + tile_size - 1) // tile_size
     th = (height + tile_size - 1) // tile_size
     return Params(n_gauss, n_cams, width, height, tile_size, tw, th, int(antialiased),
                   int(opacity_aware_radius), eps2d, near_plane, far_plane, radius_clip, radius_sigma,
-                  alpha_max, alpha_min, t_stop, median_t, jacobian_margin, plane_eps)
+                  alpha_max, alpha_min, t_stop, median_t, jacobian_margin, plane_eps,
+                  int(os.environ.get("MISPLAT_PPL_FWD", ppl_fwd)), int(os.environ.get("MISPLAT_PPL_BWD", ppl_bwd)))
 
 
 # name -> (restype, n_args); every symbol include/misplat.h declares
@@ -61,8 +63,8 @@ SYMBOLS = {
     "misplat_tile_count": (C.c_int, 5), "misplat_tile_emit": (C.c_int, 9),
     "misplat_sort_workspace_bytes": (C.c_size_t, 2), "misplat_sort_pairs": (C.c_int, 9),
     "misplat_tile_offsets": (C.c_int, 8), "misplat_pack": (C.c_int, 11),
-    "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_bwd": (C.c_int, 19),
-    "misplat_slab_reduce": (C.c_int, 8), "misplat_depth_normal_fwd": (C.c_int, 10),
+    "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_bwd": (C.c_int, 20),
+    "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 18), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),
     "misplat_depth_normal_bwd": (C.c_int, 13), "misplat_version": (C.c_char_p, 0),
 }
 

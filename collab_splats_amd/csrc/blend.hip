@@ -30,47 +30,87 @@ namespace {
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 
-struct TileCtx {
-    int tile, cam, tx, ty, beg, end;
+// One wavefront owns a band of 16 x (4*PPL) pixels of a tile: lane -> x = lane & 15,
+// y = band_y0 + (lane >> 4) + 4k, k < PPL.  PPL = 4: one wave per tile; PPL = 2 / 1: two / four
+// independent waves per tile (more waves in flight, finer early termination and culling, at the
+// price of re-staging the tile's list per wave).
+struct BandCtx {
+    int tile, cam, band, tx, ty, y0, beg, end;
     float fx, fy, cx, cy;
 };
 
-// XCD-aware block -> tile map: blocks are dealt round-robin over the 8 XCDs, so give every XCD a
-// contiguous run of tiles (row-major neighbours share Gaussian records in that XCD's L2).
-__device__ __forceinline__ bool tile_ctx(const misplat_params& P, const float* __restrict__ Ks,
+// XCD-aware block -> work map: blocks are dealt round-robin over the 8 XCDs, so every XCD gets a
+// contiguous run of (tile, band) units (row-major neighbours share Gaussian records in its L2).
+template <int PPL>
+__device__ __forceinline__ bool band_ctx(const misplat_params& P, const float* __restrict__ Ks,
                                          const int32_t* __restrict__ offsets, int64_t n_isects,
-                                         TileCtx& c) {
+                                         BandCtx& c) {
+    constexpr int WPT = 4 / PPL;
     const int tiles_per_cam = P.tile_w * P.tile_h;
-    const int total = tiles_per_cam * P.n_cams;
+    const int total_tiles = tiles_per_cam * P.n_cams;
+    const int total = total_tiles * WPT;
     const int per_xcd = (total + 7) >> 3;
     const int b = blockIdx.x;
-    c.tile = (b & 7) * per_xcd + (b >> 3);
-    if (c.tile >= total) return false;
+    const int unit = (b & 7) * per_xcd + (b >> 3);
+    if (unit >= total) return false;
+    c.tile = unit / WPT;
+    c.band = unit - c.tile * WPT;
     c.cam = c.tile / tiles_per_cam;
     const int t = c.tile - c.cam * tiles_per_cam;
     c.ty = t / P.tile_w;
     c.tx = t - c.ty * P.tile_w;
+    c.y0 = c.ty * MISPLAT_TILE + c.band * 4 * PPL;
+    if (c.y0 >= P.height) return false;
     c.beg = offsets[c.tile];
-    c.end = (c.tile + 1 < total) ? offsets[c.tile + 1] : (int)n_isects;
+    c.end = (c.tile + 1 < total_tiles) ? offsets[c.tile + 1] : (int)n_isects;
     c.fx = Ks[9 * c.cam]; c.fy = Ks[9 * c.cam + 4]; c.cx = Ks[9 * c.cam + 2]; c.cy = Ks[9 * c.cam + 5];
     return true;
 }
 
-// Stage one record per lane, conic pre-multiplied so that vis = exp2(e) with
-// e = cA' dx^2 + cC' dy^2 + cB' dx dy  (= -sigma * log2(e)).
-__device__ __forceinline__ void stage_records(float4* sm, int lane, int i, bool valid,
-                                              const float4* __restrict__ grec,
-                                              const int32_t* __restrict__ flatten_ids) {
-    if (valid) {
-        const int g = flatten_ids[i];
-        float4 q0 = grec[4 * (size_t)g + 0], q1 = grec[4 * (size_t)g + 1];
-        float4 q2 = grec[4 * (size_t)g + 2], q3 = grec[4 * (size_t)g + 3];
-        q0.z *= -0.5f * kLog2e; q0.w *= -kLog2e; q1.x *= -0.5f * kLog2e;
-        sm[lane] = q0; sm[64 + lane] = q1; sm[128 + lane] = q2; sm[192 + lane] = q3;
-    }
+// Exact minimum of sigma(d) = 0.5 (a dx^2 + c dy^2) + b dx dy over the box d in [dxl,dxh] x [dyl,dyh]
+// (d = mean2d - pixel centre): 0 if the mean is inside, else the minimum lies on one of the two box
+// faces nearest to the mean (convexity).
+__device__ __forceinline__ float sigma_min_box(float a, float b, float c, float dxl, float dxh, float dyl, float dyh) {
+    const float dxc = fminf(fmaxf(0.f, dxl), dxh), dyc = fminf(fmaxf(0.f, dyl), dyh);
+    const float dys = fminf(fmaxf(-b * dxc / c, dyl), dyh);
+    const float dxs = fminf(fmaxf(-b * dyc / a, dxl), dxh);
+    const float s1 = 0.5f * (a * dxc * dxc + c * dys * dys) + b * dxc * dys;
+    const float s2 = 0.5f * (a * dxs * dxs + c * dyc * dyc) + b * dxs * dyc;
+    return fminf(s1, s2);
 }
 
-template <int CD>
+// Stage up to 64 records: each lane fetches one Gaussian of the tile list, tests it against the
+// wave's pixel band (conservatively: kept unless max alpha over the band is provably < alpha_min),
+// and the survivors are compacted with a ballot prefix into LDS, conic pre-multiplied so that
+// vis = exp2(e), e = cA' dx^2 + cC' dy^2 + cB' dx dy (= -sigma log2 e).  Returns the survivor count.
+__device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_slot, int lane, int i, bool valid,
+                                             const float4* __restrict__ grec,
+                                             const int32_t* __restrict__ flatten_ids,
+                                             const int32_t* __restrict__ slots, float xlo, float xhi,
+                                             float ylo, float yhi, float alpha_min) {
+    float4 q0, q1, q2, q3;
+    bool keep = false;
+    int slot = 0;
+    if (valid) {
+        const int g = flatten_ids[i];
+        q0 = grec[4 * (size_t)g + 0]; q1 = grec[4 * (size_t)g + 1];
+        q2 = grec[4 * (size_t)g + 2]; q3 = grec[4 * (size_t)g + 3];
+        if (slots) slot = slots[i]; else slot = g;
+        const float smin = sigma_min_box(q0.z, q0.w, q1.x, q0.x - xhi, q0.x - xlo, q0.y - yhi, q0.y - ylo);
+        keep = q1.y * __builtin_amdgcn_exp2f(-smin * kLog2e) * 1.002f >= alpha_min;
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (keep) {
+        const int pos = __popcll(mask & ((1ull << lane) - 1ull));
+        q0.z *= -0.5f * kLog2e; q0.w *= -kLog2e; q1.x *= -0.5f * kLog2e;
+        sm[pos] = q0; sm[64 + pos] = q1; sm[128 + pos] = q2; sm[192 + pos] = q3;
+        sm_idx[pos] = i;
+        if (sm_slot) sm_slot[pos] = slot;      // emission slot (slab mode) or Gaussian row (atomic mode)
+    }
+    return __popcll(mask);
+}
+
+template <int CD, int PPL>
 __global__ __launch_bounds__(64) void blend_fwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ offsets, int64_t n_isects,
@@ -78,18 +118,19 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     float* __restrict__ med_depth, float* __restrict__ normal, int32_t* __restrict__ last_ids,
     int32_t* __restrict__ median_ids) {
     __shared__ float4 sm[4 * 64];
-    TileCtx c;
-    if (!tile_ctx(P, Ks, offsets, n_isects, c)) return;
+    __shared__ int sm_idx[64];
+    BandCtx c;
+    if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c)) return;
     const int lane = threadIdx.x;
     const int x = c.tx * MISPLAT_TILE + (lane & 15);
-    const int ybase = c.ty * MISPLAT_TILE + (lane >> 4);
+    const int ybase = c.y0 + (lane >> 4);
     const float px = (float)x + 0.5f;
     const float rxn = (px - c.cx) / c.fx;
-    float py[4], inv_ell[4], T[4], dep[4], med[4], col[4][CD], nrm[4][3];
-    int last[4], medi[4];
-    bool done[4];
+    float py[PPL], inv_ell[PPL], T[PPL], dep[PPL], med[PPL], col[PPL][CD], nrm[PPL][3];
+    int last[PPL], medi[PPL];
+    bool done[PPL];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < PPL; k++) {
         const int y = ybase + 4 * k;
         py[k] = (float)y + 0.5f;
         const float ryn = (py[k] - c.cy) / c.fy;
@@ -101,21 +142,27 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
         nrm[k][0] = nrm[k][1] = nrm[k][2] = 0.f;
     }
     const float amax = P.alpha_max, amin = P.alpha_min, tstop = P.t_stop, tmed = P.median_t;
+    const float xlo = (float)(c.tx * MISPLAT_TILE) + 0.5f, xhi = xlo + 15.0f;
+    const float ylo = (float)c.y0 + 0.5f, yhi = ylo + (float)(4 * PPL - 1);
 
     for (int bs = c.beg; bs < c.end; bs += 64) {
-        if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < PPL; k++) all = all && done[k];
+        if (__ballot(!all) == 0ull) break;
         __syncthreads();
-        stage_records(sm, lane, bs + lane, bs + lane < c.end, grec, flatten_ids);
+        const int n = stage_records(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
+                                    nullptr, xlo, xhi, ylo, yhi, amin);
         __syncthreads();
-        const int n = min(64, c.end - bs);
         for (int j = 0; j < n; j++) {
             const float4 q0 = sm[j], q1 = sm[64 + j], q2 = sm[128 + j], q3 = sm[192 + j];
-            const int i = bs + j;
+            const int i = sm_idx[j];
             const float dx = q0.x - px;
             const float ea = q0.z * dx * dx, eb = q0.w * dx;
             const float tpx = q1.z - q1.w * dx;
+            bool alld = true;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < PPL; k++) {
                 const float dy = q0.y - py[k];
                 const float e = ea + (q1.x * dy + eb) * dy;
                 const float vis = __builtin_amdgcn_exp2f(e);
@@ -127,7 +174,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
                     } else {
                         const float w = a * T[k];
                         const float zp = (tpx - q2.x * dy) * inv_ell[k];
-                        col[k][0] += w * q3.x; col[k][1] += w * q3.y; col[k][2] += w * q3.z;
+                        col[k][0] += w * q3.x;
+                        if (CD > 1) col[k][CD > 1 ? 1 : 0] += w * q3.y;
+                        if (CD > 2) col[k][CD > 2 ? 2 : 0] += w * q3.z;
                         if (CD > 3) col[k][CD > 3 ? 3 : 0] += w * q3.w;
                         dep[k] += w * zp;
                         nrm[k][0] += w * q2.y; nrm[k][1] += w * q2.z; nrm[k][2] += w * q2.w;
@@ -136,12 +185,13 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
                         T[k] = Tn;
                     }
                 }
+                alld = alld && done[k];
             }
-            if (__ballot(!(done[0] && done[1] && done[2] && done[3])) == 0ull) break;
+            if (__ballot(!alld) == 0ull) break;
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < PPL; k++) {
         const int y = ybase + 4 * k;
         if (x < P.width && y < P.height) {
             const size_t pid = ((size_t)c.cam * P.height + y) * P.width + x;
@@ -213,7 +263,10 @@ __device__ __forceinline__ int bitrev4(int l) {
     return ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);
 }
 
-template <int CD, bool ABS>
+// Backward.  Each wave writes one gradient row per Gaussian that contributed to its band, to
+// slab[band][slot], and marks it in valid[band][slot] (zeroed by the launcher); rows never marked
+// are never read.
+template <int CD, int PPL, bool ABS, bool ATOMIC>
 __global__ __launch_bounds__(64) void blend_bwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ slots,
@@ -221,22 +274,24 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
     const int32_t* __restrict__ last_ids, const int32_t* __restrict__ median_ids,
     const float* __restrict__ v_render, const float* __restrict__ v_alpha,
     const float* __restrict__ v_exp_depth, const float* __restrict__ v_med_depth,
-    const float* __restrict__ v_normal, float* __restrict__ slab, float* __restrict__ slab_abs) {
+    const float* __restrict__ v_normal, float* __restrict__ slab, float* __restrict__ slab_abs,
+    uint8_t* __restrict__ valid) {
     __shared__ float4 sm[4 * 64];
+    __shared__ int sm_idx[64];
     __shared__ int sm_slot[64];
-    TileCtx c;
-    if (!tile_ctx(P, Ks, offsets, n_isects, c)) return;
+    BandCtx c;
+    if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c)) return;
     if (c.end <= c.beg) return;
     const int lane = threadIdx.x;
     const int x = c.tx * MISPLAT_TILE + (lane & 15);
-    const int ybase = c.ty * MISPLAT_TILE + (lane >> 4);
+    const int ybase = c.y0 + (lane >> 4);
     const float px = (float)x + 0.5f;
     const float rxn = (px - c.cx) / c.fx;
-    float py[4], inv_ell[4], T[4], tfva[4], B[4], vcol[4][CD], vn[4][3], vd[4], vm[4];
-    int last[4], medi[4];
+    float py[PPL], inv_ell[PPL], T[PPL], tfva[PPL], B[PPL], vcol[PPL][CD], vn[PPL][3], vd[PPL], vm[PPL];
+    int last[PPL], medi[PPL];
     int mymax = -1;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < PPL; k++) {
         const int y = ybase + 4 * k;
         py[k] = (float)y + 0.5f;
         const float ryn = (py[k] - c.cy) / c.fy;
@@ -261,29 +316,27 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
         mymax = max(mymax, last[k]);
     }
     const int maxlast = wave_max(mymax);
-    const int comp = bitrev4(lane & 15);
-    // rows of entries no pixel reached: zeros
-    for (int i = max(maxlast + 1, c.beg) + (lane >> 4); i < c.end; i += 4) {
-        const size_t s = (size_t)slots[i];
-        slab[s * MISPLAT_REC + (lane & 15)] = 0.f;
-        if (ABS && (lane & 15) < 2) slab_abs[s * 2 + (lane & 15)] = 0.f;
-    }
     if (maxlast < c.beg) return;
-    // per-lane scale undoing the conic pre-multiplication (component = grec layout index)
+    const int comp = bitrev4(lane & 15);
+    // per-lane scale undoing the conic pre-multiplication (component = record layout index)
     const float out_scale = (comp == 2 || comp == 4) ? -0.5f * kLog2e : (comp == 3 ? -kLog2e : 1.0f);
     const float amax = P.alpha_max, amin = P.alpha_min;
+    const float xlo = (float)(c.tx * MISPLAT_TILE) + 0.5f, xhi = xlo + 15.0f;
+    const float ylo = (float)c.y0 + 0.5f, yhi = ylo + (float)(4 * PPL - 1);
+    // slab mode: one plane per band; atomic mode: slab IS v_grec[C*N,16] (zeroed by the launcher)
+    float* slab_b = ATOMIC ? slab : slab + (size_t)c.band * (size_t)n_isects * MISPLAT_REC;
+    float* abs_b = ABS ? (ATOMIC ? slab_abs : slab_abs + (size_t)c.band * (size_t)n_isects * 2) : nullptr;
+    uint8_t* valid_b = ATOMIC ? nullptr : valid + (size_t)c.band * (size_t)n_isects;
 
     for (int b = (maxlast - c.beg) >> 6; b >= 0; b--) {
         const int bs = c.beg + (b << 6);
-        const int n = min(64, maxlast + 1 - bs);
         __syncthreads();
-        stage_records(sm, lane, bs + lane, bs + lane <= maxlast, grec, flatten_ids);
-        if (bs + lane <= maxlast) sm_slot[lane] = slots[bs + lane];
+        const int n = stage_records(sm, sm_idx, sm_slot, lane, bs + lane, bs + lane <= maxlast, grec, flatten_ids,
+                                    ATOMIC ? nullptr : slots, xlo, xhi, ylo, yhi, amin);
         __syncthreads();
         for (int j = n - 1; j >= 0; j--) {
             const float4 q0 = sm[j], q1 = sm[64 + j], q2 = sm[128 + j], q3 = sm[192 + j];
-            const int i = bs + j;
-            const size_t slot = (size_t)sm_slot[j];
+            const int i = sm_idx[j];
             const float dx = q0.x - px;
             const float ea = q0.z * dx * dx, eb = q0.w * dx;
             const float tpx = q1.z - q1.w * dx;
@@ -293,7 +346,7 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
             float ab0 = 0.f, ab1 = 0.f;
             bool any = false;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < PPL; k++) {
                 if (i > last[k]) continue;
                 const float dy = q0.y - py[k];
                 const float e = ea + (q1.x * dy + eb) * dy;
@@ -306,12 +359,16 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
                 T[k] *= ra;
                 const float w = a * T[k];
                 const float zp = (tpx - q2.x * dy) * inv_ell[k];
-                float dot = q3.x * vcol[k][0] + q3.y * vcol[k][1] + q3.z * vcol[k][2];
+                float dot = q3.x * vcol[k][0];
+                if (CD > 1) dot += q3.y * vcol[k][CD > 1 ? 1 : 0];
+                if (CD > 2) dot += q3.z * vcol[k][CD > 2 ? 2 : 0];
                 if (CD > 3) dot += q3.w * vcol[k][CD > 3 ? 3 : 0];
                 dot += q2.y * vn[k][0] + q2.z * vn[k][1] + q2.w * vn[k][2] + zp * vd[k];
                 const float v_a = (tfva[k] - B[k]) * ra + T[k] * dot;
                 B[k] += w * dot;
-                acc[12] += w * vcol[k][0]; acc[13] += w * vcol[k][1]; acc[14] += w * vcol[k][2];
+                acc[12] += w * vcol[k][0];
+                if (CD > 1) acc[13] += w * vcol[k][CD > 1 ? 1 : 0];
+                if (CD > 2) acc[14] += w * vcol[k][CD > 2 ? 2 : 0];
                 if (CD > 3) acc[15] += w * vcol[k][CD > 3 ? 3 : 0];
                 acc[9] += w * vn[k][0]; acc[10] += w * vn[k][1]; acc[11] += w * vn[k][2];
                 float vz = w * vd[k];
@@ -330,46 +387,78 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
                 if (ABS) { ab0 += fabsf(vmx); ab1 += fabsf(vmy); }
             }
             if (__ballot(any) != 0ull) {
+                const size_t slot = (size_t)sm_slot[j];
                 const float r = wave_reduce16(acc, lane);
-                if (lane < 16) slab[slot * MISPLAT_REC + comp] = r * out_scale;
+                if (ATOMIC) {
+                    // one 64-byte contiguous no-return fp32 atomic per (band, Gaussian)
+                    if (lane < 16) atomicAdd(&slab_b[slot * MISPLAT_REC + comp], r * out_scale);
+                } else {
+                    if (lane < 16) slab_b[slot * MISPLAT_REC + comp] = r * out_scale;
+                    if (lane == 16) valid_b[slot] = 1;
+                }
                 if (ABS) {
                     ab0 = wave_sum(ab0); ab1 = wave_sum(ab1);
-                    if (lane == 0) { slab_abs[slot * 2] = ab0; slab_abs[slot * 2 + 1] = ab1; }
+                    if (ATOMIC) {
+                        if (lane < 2) atomicAdd(&abs_b[slot * 2 + lane], lane == 0 ? ab0 : ab1);
+                    } else if (lane == 0) { abs_b[slot * 2] = ab0; abs_b[slot * 2 + 1] = ab1; }
                 }
-            } else {
-                if (lane < 16) slab[slot * MISPLAT_REC + lane] = 0.f;
-                if (ABS && lane < 2) slab_abs[slot * 2 + lane] = 0.f;
             }
         }
     }
 }
 
-// 16 lanes per row r: v_grec[r][c] = sum_j slab[cum[r] + j][c] in ascending j (fixed order).
-__global__ __launch_bounds__(256) void slab_reduce_kernel(int64_t n_rows, const int64_t* __restrict__ cum,
+// 16 lanes per Gaussian row r: v_grec[r][c] = sum over its intersections (ascending slot) and over
+// the bands (ascending) of the VALID slab rows: a fixed order, so the result is bitwise
+// reproducible.  Rows are fetched four slots at a time with unconditional loads (invalid rows are
+// redirected to a zero row) so that the flag and row loads of a chunk are all in flight together.
+__device__ const float kZeroRow[MISPLAT_REC] = {0.f};
+
+template <int PLANES>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(int64_t n_rows, int64_t n_isects,
+                                                          const int64_t* __restrict__ cum,
                                                           const int32_t* __restrict__ tiles_per_gauss,
                                                           const float* __restrict__ slab,
                                                           const float* __restrict__ slab_abs,
+                                                          const uint8_t* __restrict__ valid,
                                                           float* __restrict__ v_grec,
                                                           float* __restrict__ v_abs) {
     const int c = threadIdx.x & 15;
+    constexpr int U = 4;
     for (int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; r < n_rows;
          r += ((int64_t)gridDim.x * blockDim.x) >> 4) {
         const int n = tiles_per_gauss[r];
-        const float* s = slab + (size_t)cum[r] * MISPLAT_REC + c;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int j = 0;
-        for (; j + 4 <= n; j += 4) {
-            a0 += s[(size_t)(j + 0) * MISPLAT_REC]; a1 += s[(size_t)(j + 1) * MISPLAT_REC];
-            a2 += s[(size_t)(j + 2) * MISPLAT_REC]; a3 += s[(size_t)(j + 3) * MISPLAT_REC];
+        const int64_t base = cum[r];
+        float acc = 0.f, acc_abs = 0.f;
+        for (int j0 = 0; j0 < n; j0 += U) {
+            bool f[U][PLANES];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int w = 0; w < PLANES; w++)
+                    f[u][w] = (j0 + u < n) && valid[(size_t)w * (size_t)n_isects + (size_t)(base + j0 + u)] != 0;
+            float v[U][PLANES], va[U][PLANES];
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int w = 0; w < PLANES; w++) {
+                    const size_t row = (size_t)w * (size_t)n_isects + (size_t)(base + j0 + u);
+                    const float* src = f[u][w] ? slab + row * MISPLAT_REC : kZeroRow;
+                    v[u][w] = src[c];
+                    if (slab_abs != nullptr) {
+                        const float* sa = f[u][w] ? slab_abs + row * 2 : kZeroRow;
+                        va[u][w] = sa[c & 1];
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+#pragma unroll
+                for (int w = 0; w < PLANES; w++) {
+                    acc += v[u][w];
+                    if (slab_abs != nullptr) acc_abs += va[u][w];
+                }
         }
-        for (; j < n; j++) a0 += s[(size_t)j * MISPLAT_REC];
-        v_grec[r * MISPLAT_REC + c] = (a0 + a1) + (a2 + a3);
-        if (slab_abs != nullptr && c < 2) {
-            const float* sa = slab_abs + (size_t)cum[r] * 2 + c;
-            float b = 0.f;
-            for (int q = 0; q < n; q++) b += sa[(size_t)q * 2];
-            v_abs[r * 2 + c] = b;
-        }
+        v_grec[r * MISPLAT_REC + c] = acc;
+        if (slab_abs != nullptr && c < 2) v_abs[r * 2 + c] = acc_abs;
     }
 }
 
@@ -507,25 +596,39 @@ inline bool params_ok(const misplat_params* p) {
 
 }  // namespace
 
+// pixels-per-lane selection: params field (0 = default)
+inline int pick_ppl(int requested, int dflt) { return (requested == 1 || requested == 2 || requested == 4) ? requested : dflt; }
+constexpr int kDefaultPplFwd = 2, kDefaultPplBwd = 2;
+
+extern "C" int misplat_blend_planes(const misplat_params* p) { return p ? 4 / pick_ppl(p->ppl_bwd, kDefaultPplBwd) : 0; }
+
 extern "C" int misplat_blend_fwd(const misplat_params* p, int32_t color_dim, const float* Ks,
                                  const float* grec, const int32_t* flatten_ids, const int32_t* offsets,
                                  int64_t n_isects, float* render, float* alpha, float* exp_depth,
                                  float* med_depth, float* normal, int32_t* last_ids,
                                  int32_t* median_ids, misplat_stream_t stream) {
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL) return MISPLAT_EINVAL;
-    const int total = p->tile_w * p->tile_h * p->n_cams;
+    const int ppl = pick_ppl(p->ppl_fwd, kDefaultPplFwd);
+    const int total = p->tile_w * p->tile_h * p->n_cams * (4 / ppl);
     const int grid = ((total + 7) / 8) * 8;
     hipStream_t s = (hipStream_t)stream;
-    if (color_dim == 3)
-        hipLaunchKernelGGL(blend_fwd_kernel<3>, dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec,
-                           flatten_ids, offsets, n_isects, render, alpha, exp_depth, med_depth, normal,
-                           last_ids, median_ids);
-    else if (color_dim == 4)
-        hipLaunchKernelGGL(blend_fwd_kernel<4>, dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec,
-                           flatten_ids, offsets, n_isects, render, alpha, exp_depth, med_depth, normal,
-                           last_ids, median_ids);
-    else
-        return MISPLAT_EINVAL;
+#define LAUNCH_FWD(CD_, PPL_)                                                                              \
+    hipLaunchKernelGGL((blend_fwd_kernel<CD_, PPL_>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec, \
+                       flatten_ids, offsets, n_isects, render, alpha, exp_depth, med_depth, normal, last_ids,  \
+                       median_ids)
+#define DISPATCH_FWD(CD_)                                  \
+    do {                                                   \
+        if (ppl == 1) LAUNCH_FWD(CD_, 1);                  \
+        else if (ppl == 2) LAUNCH_FWD(CD_, 2);             \
+        else LAUNCH_FWD(CD_, 4);                           \
+    } while (0)
+    if (color_dim == 1) DISPATCH_FWD(1);
+    else if (color_dim == 2) DISPATCH_FWD(2);
+    else if (color_dim == 3) DISPATCH_FWD(3);
+    else if (color_dim == 4) DISPATCH_FWD(4);
+    else return MISPLAT_EINVAL;
+#undef DISPATCH_FWD
+#undef LAUNCH_FWD
     return check_launch();
 }
 
@@ -535,32 +638,108 @@ extern "C" int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, con
                                  const float* alpha, const int32_t* last_ids, const int32_t* median_ids,
                                  const float* v_render, const float* v_alpha, const float* v_exp_depth,
                                  const float* v_med_depth, const float* v_normal, float* slab,
-                                 float* slab_abs, misplat_stream_t stream) {
-    if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL) return MISPLAT_EINVAL;
+                                 float* slab_abs, uint8_t* slab_valid, misplat_stream_t stream) {
+    if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !slab_valid) return MISPLAT_EINVAL;
     if (n_isects == 0) return MISPLAT_OK;
-    const int total = p->tile_w * p->tile_h * p->n_cams;
+    const int ppl = pick_ppl(p->ppl_bwd, kDefaultPplBwd);
+    const int planes = 4 / ppl;
+    const int total = p->tile_w * p->tile_h * p->n_cams * planes;
     const int grid = ((total + 7) / 8) * 8;
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_BWD(CD_, ABS_)                                                                              \
-    hipLaunchKernelGGL((blend_bwd_kernel<CD_, ABS_>), dim3(grid), dim3(64), 0, s, *p, Ks,                    \
-                       (const float4*)grec, flatten_ids, slots_sorted, offsets, n_isects, alpha, last_ids, \
-                       median_ids, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, slab, slab_abs)
-    if (color_dim == 3 && slab_abs) LAUNCH_BWD(3, true);
-    else if (color_dim == 3) LAUNCH_BWD(3, false);
-    else if (color_dim == 4 && slab_abs) LAUNCH_BWD(4, true);
-    else if (color_dim == 4) LAUNCH_BWD(4, false);
+    if (hipMemsetAsync(slab_valid, 0, (size_t)n_isects * planes, s) != hipSuccess) return MISPLAT_ELAUNCH;
+#define LAUNCH_BWD(CD_, PPL_, ABS_)                                                                          \
+    hipLaunchKernelGGL((blend_bwd_kernel<CD_, PPL_, ABS_, false>), dim3(grid), dim3(64), 0, s, *p, Ks,         \
+                       (const float4*)grec, flatten_ids, slots_sorted, offsets, n_isects, alpha, last_ids,     \
+                       median_ids, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, slab, slab_abs,      \
+                       slab_valid)
+#define DISPATCH_BWD(CD_)                                                        \
+    do {                                                                         \
+        if (slab_abs) {                                                          \
+            if (ppl == 1) LAUNCH_BWD(CD_, 1, true);                              \
+            else if (ppl == 2) LAUNCH_BWD(CD_, 2, true);                         \
+            else LAUNCH_BWD(CD_, 4, true);                                       \
+        } else {                                                                 \
+            if (ppl == 1) LAUNCH_BWD(CD_, 1, false);                             \
+            else if (ppl == 2) LAUNCH_BWD(CD_, 2, false);                        \
+            else LAUNCH_BWD(CD_, 4, false);                                      \
+        }                                                                        \
+    } while (0)
+    if (color_dim == 1) DISPATCH_BWD(1);
+    else if (color_dim == 2) DISPATCH_BWD(2);
+    else if (color_dim == 3) DISPATCH_BWD(3);
+    else if (color_dim == 4) DISPATCH_BWD(4);
     else return MISPLAT_EINVAL;
+#undef DISPATCH_BWD
 #undef LAUNCH_BWD
     return check_launch();
 }
 
-extern "C" int misplat_slab_reduce(int64_t n_rows, const int64_t* cum, const int32_t* tiles_per_gauss,
-                                   const float* slab, const float* slab_abs, float* v_grec, float* v_abs,
-                                   misplat_stream_t stream) {
-    if (n_rows < 0 || (slab_abs != nullptr) != (v_abs != nullptr)) return MISPLAT_EINVAL;
+// Same backward, but every (band, Gaussian) row is added straight into v_grec[C*N,16] (and
+// v_abs[C*N,2]) with no-return fp32 atomics -- no slab, no second kernel; the sums then depend on
+// arrival order (not bitwise reproducible).  v_grec / v_abs are zeroed here on `stream`.
+extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks,
+                                        const float* grec, const int32_t* flatten_ids,
+                                        const int32_t* offsets, int64_t n_isects, const float* alpha,
+                                        const int32_t* last_ids, const int32_t* median_ids,
+                                        const float* v_render, const float* v_alpha,
+                                        const float* v_exp_depth, const float* v_med_depth,
+                                        const float* v_normal, float* v_grec, float* v_abs,
+                                        misplat_stream_t stream) {
+    if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !v_grec) return MISPLAT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rows = (size_t)p->n_gauss * p->n_cams;
+    if (rows == 0) return MISPLAT_OK;
+    if (hipMemsetAsync(v_grec, 0, rows * MISPLAT_REC * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (v_abs && hipMemsetAsync(v_abs, 0, rows * 2 * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (n_isects == 0) return MISPLAT_OK;
+    const int ppl = pick_ppl(p->ppl_bwd, kDefaultPplBwd);
+    const int total = p->tile_w * p->tile_h * p->n_cams * (4 / ppl);
+    const int grid = ((total + 7) / 8) * 8;
+#define LAUNCH_BWDA(CD_, PPL_, ABS_)                                                                         \
+    hipLaunchKernelGGL((blend_bwd_kernel<CD_, PPL_, ABS_, true>), dim3(grid), dim3(64), 0, s, *p, Ks,          \
+                       (const float4*)grec, flatten_ids, (const int32_t*)nullptr, offsets, n_isects, alpha,    \
+                       last_ids, median_ids, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, v_grec,    \
+                       v_abs, (uint8_t*)nullptr)
+#define DISPATCH_BWDA(CD_)                                                       \
+    do {                                                                         \
+        if (v_abs) {                                                             \
+            if (ppl == 1) LAUNCH_BWDA(CD_, 1, true);                             \
+            else if (ppl == 2) LAUNCH_BWDA(CD_, 2, true);                        \
+            else LAUNCH_BWDA(CD_, 4, true);                                      \
+        } else {                                                                 \
+            if (ppl == 1) LAUNCH_BWDA(CD_, 1, false);                            \
+            else if (ppl == 2) LAUNCH_BWDA(CD_, 2, false);                       \
+            else LAUNCH_BWDA(CD_, 4, false);                                     \
+        }                                                                        \
+    } while (0)
+    if (color_dim == 1) DISPATCH_BWDA(1);
+    else if (color_dim == 2) DISPATCH_BWDA(2);
+    else if (color_dim == 3) DISPATCH_BWDA(3);
+    else if (color_dim == 4) DISPATCH_BWDA(4);
+    else return MISPLAT_EINVAL;
+#undef DISPATCH_BWDA
+#undef LAUNCH_BWDA
+    return check_launch();
+}
+
+extern "C" int misplat_slab_reduce(const misplat_params* p, int64_t n_rows, int64_t n_isects,
+                                   const int64_t* cum, const int32_t* tiles_per_gauss, const float* slab,
+                                   const float* slab_abs, const uint8_t* slab_valid, float* v_grec,
+                                   float* v_abs, misplat_stream_t stream) {
+    if (!p || n_rows < 0 || n_isects < 0 || (slab_abs != nullptr) != (v_abs != nullptr)) return MISPLAT_EINVAL;
     if (n_rows == 0) return MISPLAT_OK;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n_rows * 16, 256)), dim3(256), 0, (hipStream_t)stream,
-                       n_rows, cum, tiles_per_gauss, slab, slab_abs, v_grec, v_abs);
+    const int planes = 4 / pick_ppl(p->ppl_bwd, kDefaultPplBwd);
+    const dim3 grid(grid_for(n_rows * 16, 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (planes == 1)
+        hipLaunchKernelGGL(slab_reduce_kernel<1>, grid, block, 0, s, n_rows, n_isects, cum, tiles_per_gauss, slab,
+                           slab_abs, slab_valid, v_grec, v_abs);
+    else if (planes == 2)
+        hipLaunchKernelGGL(slab_reduce_kernel<2>, grid, block, 0, s, n_rows, n_isects, cum, tiles_per_gauss, slab,
+                           slab_abs, slab_valid, v_grec, v_abs);
+    else
+        hipLaunchKernelGGL(slab_reduce_kernel<4>, grid, block, 0, s, n_rows, n_isects, cum, tiles_per_gauss, slab,
+                           slab_abs, slab_valid, v_grec, v_abs);
     return check_launch();
 }
 

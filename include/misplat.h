@@ -62,6 +62,8 @@ typedef struct misplat_params {
     float median_t;       /* 0.5 */
     float jacobian_margin;/* 0.3 */
     float plane_eps;      /* 1e-6 */
+    int32_t ppl_fwd;      /* pixels per lane of the compositing kernels: 1, 2 or 4 (0 = default); */
+    int32_t ppl_bwd;      /* a tile is covered by 4/ppl independent wavefronts ("bands")          */
 } misplat_params;
 
 /* ---- a2.1 projection: fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, ...)
@@ -157,30 +159,47 @@ int misplat_pack(int64_t n_rows, int32_t color_dim, const float* means2d, const 
                  const float* opacities_eff, const float* ray_ts, const float* ray_planes,
                  const float* normals, const float* colors, float* grec, misplat_stream_t stream);
 
-/* Forward: one wavefront per 16x16 tile, 4 pixels per lane.  Outputs [C,H,W,...]:
- * render[.,color_dim], alpha[.], exp_depth[.] (sum w*z, un-normalised), med_depth[.],
- * normal[.,3], last_ids[.], median_ids[.] (sorted positions; -1 = none).  color_dim in {3,4}. */
+/* Forward: one wavefront per band of 16 x (4*ppl) pixels of a tile (ppl pixels per lane).
+ * Outputs [C,H,W,...]: render[.,color_dim], alpha[.], exp_depth[.] (sum w*z, un-normalised),
+ * med_depth[.], normal[.,3], last_ids[.], median_ids[.] (sorted positions; -1 = none).
+ * color_dim in 1..4. */
 int misplat_blend_fwd(const misplat_params* p, int32_t color_dim, const float* Ks,
                       const float* grec, const int32_t* flatten_ids, const int32_t* offsets,
                       int64_t n_isects, float* render, float* alpha, float* exp_depth,
                       float* med_depth, float* normal, int32_t* last_ids, int32_t* median_ids,
                       misplat_stream_t stream);
 
-/* Backward: re-traverses each tile back to front and writes ONE gradient row (same layout as
- * the record) per intersection to slab[slot] (slot = position in emission order, so the rows of
- * one Gaussian are contiguous); every slot of every tile range is written (zeros where nothing
- * contributed), no atomics.  slab_abs[n_isects,2] (or NULL) receives sum |dL/dmean2d|. */
+/* Number of gradient planes (= bands per tile) the backward of this configuration writes. */
+int misplat_blend_planes(const misplat_params* p);
+
+/* Backward: every band re-traverses its tile list back to front and writes ONE gradient row
+ * (record layout) per Gaussian that contributed to the band, to slab[band][slot] (slot = position in
+ * emission order, so the rows of one Gaussian are contiguous), and sets slab_valid[band][slot] = 1.
+ * slab: [planes, n_isects, 16] floats; slab_abs: [planes, n_isects, 2] or NULL (sum |dL/dmean2d|);
+ * slab_valid: [planes, n_isects] bytes, zeroed here on `stream`.  No float atomics anywhere. */
 int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, const float* Ks,
                       const float* grec, const int32_t* flatten_ids, const int32_t* slots_sorted,
                       const int32_t* offsets, int64_t n_isects, const float* alpha,
                       const int32_t* last_ids, const int32_t* median_ids, const float* v_render,
                       const float* v_alpha, const float* v_exp_depth, const float* v_med_depth,
-                      const float* v_normal, float* slab, float* slab_abs,
+                      const float* v_normal, float* slab, float* slab_abs, uint8_t* slab_valid,
                       misplat_stream_t stream);
-/* v_grec[r] = sum of slab rows [cum[r], cum[r]+tiles_per_gauss[r]); fixed order => bitwise
- * reproducible.  v_abs[n_rows,2] likewise from slab_abs (both may be NULL together). */
-int misplat_slab_reduce(int64_t n_rows, const int64_t* cum, const int32_t* tiles_per_gauss,
-                        const float* slab, const float* slab_abs, float* v_grec, float* v_abs,
+/* Same backward with the rows added straight into v_grec[C*N,16] / v_abs[C*N,2] (or NULL) by
+ * no-return fp32 atomics of 64 contiguous bytes: no slab and no reduce pass, but the sums depend on
+ * arrival order.  v_grec / v_abs are zeroed here on `stream`. */
+int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks,
+                             const float* grec, const int32_t* flatten_ids, const int32_t* offsets,
+                             int64_t n_isects, const float* alpha, const int32_t* last_ids,
+                             const int32_t* median_ids, const float* v_render, const float* v_alpha,
+                             const float* v_exp_depth, const float* v_med_depth,
+                             const float* v_normal, float* v_grec, float* v_abs,
+                             misplat_stream_t stream);
+/* v_grec[r] = sum of the VALID slab rows of Gaussian row r (slots cum[r] .. cum[r]+tiles_per_gauss[r],
+ * all planes) in a fixed order => bitwise reproducible.  v_abs[n_rows,2] likewise from slab_abs
+ * (both may be NULL together). */
+int misplat_slab_reduce(const misplat_params* p, int64_t n_rows, int64_t n_isects, const int64_t* cum,
+                        const int32_t* tiles_per_gauss, const float* slab, const float* slab_abs,
+                        const uint8_t* slab_valid, float* v_grec, float* v_abs,
                         misplat_stream_t stream);
 
 /* ---- a4 depth->normal (camera_utils.py:176-279) fused with the error map of

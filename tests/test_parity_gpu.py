@@ -42,13 +42,23 @@ def _run_gpu(sc, dev, W, H, sh_degree=3, **kw):
     return leaves, out
 
 
+@pytest.fixture(params=[False, True], ids=["atomic", "deterministic"])
+def grad_mode(request):
+    """Both gradient-accumulation modes of the backward (ops.DETERMINISTIC_BACKWARD)."""
+    from collab_splats_amd import ops
+    old = ops.DETERMINISTIC_BACKWARD
+    ops.set_deterministic(request.param)
+    yield request.param
+    ops.set_deterministic(old)
+
+
 @pytest.mark.parametrize("N,W,H,mode,rm,deg", [
     (3000, 256, 256, "antialiased", "RGB+ED", 3),      # BASELINE configs[0] shape (256x256)
     (20000, 640, 360, "classic", "RGB", 3),
     (5000, 333, 197, "antialiased", "RGB", 1),         # ragged: W, H not multiples of 16
     (100000, 1920, 1080, "antialiased", "RGB+ED", 3),  # BASELINE configs[1]
 ])
-def test_full_pipeline_vs_c_port(dev, craster, N, W, H, mode, rm, deg):
+def test_full_pipeline_vs_c_port(dev, craster, grad_mode, N, W, H, mode, rm, deg):
     from collab_splats_amd.synthetic import random_scene
     sc = random_scene(N, W, H, seed=42, sh_degree=3)
     leaves, out = _run_gpu(sc, dev, W, H, sh_degree=deg, render_mode=rm, rasterize_mode=mode, absgrad=True)
@@ -282,9 +292,9 @@ def full(dev):
     return sc, W, H, N
 
 
-def test_full_size_properties(dev, full):
+def test_full_size_properties(dev, full, grad_mode):
     """1 M Gaussians, 1080p (BASELINE configs[2]): sortedness, tile ranges, invariants, bitwise
-    determinism (no float atomics anywhere) and linearity of the backward."""
+    determinism (forward always; backward in deterministic mode) and linearity of the backward."""
     sc, W, H, N = full
     leaves, out = _run_gpu(sc, dev, W, H, render_mode="RGB+ED", rasterize_mode="antialiased")
     r, a, ed, md, n, meta = out
@@ -321,7 +331,10 @@ def test_full_size_properties(dev, full):
     g1, g1b, g2 = grads(ups1), grads(ups1), grads(ups2)
     g12 = grads([x + y for x, y in zip(ups1, ups2)])
     for x, y in zip(g1, g1b):
-        assert torch.equal(x, y)                                                      # bitwise reproducible backward
+        if grad_mode:
+            assert torch.equal(x, y)                                                  # bitwise reproducible backward
+        else:
+            assert rel_err(x, y) < 1e-4, rel_err(x, y)                                # atomics: order-dependent rounding
     for x, y, s in zip(g1, g2, g12):
         assert rel_err(x + y, s) < 1e-4                                               # backward is linear in the upstream
     _, out2 = _run_gpu(sc, dev, W, H, render_mode="RGB+ED", rasterize_mode="antialiased")
