@@ -62,7 +62,10 @@ SYMBOLS = {
     "misplat_sh_fwd": (C.c_int, 9), "misplat_sh_bwd": (C.c_int, 11),
     "misplat_tile_count": (C.c_int, 5), "misplat_tile_emit": (C.c_int, 9),
     "misplat_sort_workspace_bytes": (C.c_size_t, 2), "misplat_sort_pairs": (C.c_int, 9),
-    "misplat_tile_offsets": (C.c_int, 8), "misplat_pack": (C.c_int, 11),
+    "misplat_tile_offsets": (C.c_int, 8), "misplat_depth_keys": (C.c_int, 6),
+    "misplat_tile_emit_ordered": (C.c_int, 9), "misplat_sort32_workspace_bytes": (C.c_size_t, 2),
+    "misplat_sort32_pairs": (C.c_int, 9), "misplat_tile_offsets32": (C.c_int, 5),
+    "misplat_isect_ids": (C.c_int, 6), "misplat_depth_keys32": (C.c_int, 6), "misplat_pack": (C.c_int, 11),
     "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_bwd": (C.c_int, 20),
     "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 18), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),
     "misplat_depth_normal_bwd": (C.c_int, 13), "misplat_version": (C.c_char_p, 0),

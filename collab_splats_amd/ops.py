@@ -159,44 +159,111 @@ def spherical_harmonics_raw(degree: int, dirs: Tensor, coeffs: Tensor, radii: Op
 
 # ----------------------------------------------------------------------------- binning
 
+_WS_CACHE: Dict[tuple, int] = {}
+
+
+def _sort_ws_bytes(lib, kind: str, n: int, end_bit: int) -> int:
+    """rocPRIM temp-storage size; depends only on (n, end_bit), so cache it (host-side query)."""
+    key = (kind, n, end_bit)
+    if key not in _WS_CACHE:
+        fn = lib.misplat_sort_workspace_bytes if kind == "u64" else lib.misplat_sort32_workspace_bytes
+        b = int(fn(C.c_int64(n), C.c_int32(end_bit)))
+        if b == 0:
+            raise _lib.MisplatError("sort workspace query failed")
+        _WS_CACHE[key] = b
+    return _WS_CACHE[key]
+
+
 @torch.no_grad()
 def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor) -> Dict[str, Tensor]:
-    """Tile intersection + sort + offsets.  One host read-back: n_isects."""
+    """Tile intersection + ordering + offsets.  One host read-back: n_isects.
+
+    Two-stage ordering (see include/misplat.h): depth-sort the rows once, emit in that order, then a
+    stable sort on the tile bits only -- bit-identical to the (tile << 32 | depth) key sort.  In the
+    default (atomic) backward mode the sort payload is the Gaussian row itself; the deterministic mode
+    carries the emission slot instead (the slab is indexed by it) and gathers the rows afterwards."""
     lib = _lib.load()
     dev = means2d.device
     total = P.n_gauss * P.n_cams
     n_tiles = P.tile_w * P.tile_h * P.n_cams
-    tiles_per_gauss = torch.empty(total, device=dev, dtype=torch.int32)
+    deterministic = DETERMINISTIC_BACKWARD
+    i32 = dict(device=dev, dtype=torch.int32)
+    tiles_per_gauss = torch.empty(total, **i32)
     check(lib.misplat_tile_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), stream_ptr()),
           "misplat_tile_count")
-    incl = torch.cumsum(tiles_per_gauss, dim=0, dtype=torch.int64)
+    # (1) rows in (camera, depth) order
+    ids, order = torch.empty(total, **i32), torch.empty(total, **i32)
+    if total > 0 and P.n_cams == 1:
+        dkeys = torch.empty(total, **i32)
+        dkeys_s = torch.empty_like(dkeys)
+        check(lib.misplat_depth_keys32(C.byref(P), ptr(radii), ptr(depths), ptr(dkeys), ptr(ids), stream_ptr()),
+              "misplat_depth_keys32")
+        ws_bytes = _sort_ws_bytes(lib, "u32", total, 32)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        check(lib.misplat_sort32_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(dkeys), ptr(dkeys_s), ptr(ids), ptr(order),
+                                       C.c_int64(total), C.c_int32(32), stream_ptr()), "misplat_sort32_pairs")
+    elif total > 0:
+        dkeys = torch.empty(total, device=dev, dtype=torch.int64)
+        dkeys_s = torch.empty_like(dkeys)
+        check(lib.misplat_depth_keys(C.byref(P), ptr(radii), ptr(depths), ptr(dkeys), ptr(ids), stream_ptr()),
+              "misplat_depth_keys")
+        end_bit = 32 + max(1, P.n_cams.bit_length())
+        ws_bytes = _sort_ws_bytes(lib, "u64", total, end_bit)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        check(lib.misplat_sort_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(dkeys), ptr(dkeys_s), ptr(ids), ptr(order),
+                                     C.c_int64(total), C.c_int32(end_bit), stream_ptr()), "misplat_sort_pairs")
+    tpg_ordered = tiles_per_gauss[order.long()]
+    incl = torch.cumsum(tpg_ordered, dim=0, dtype=torch.int64)
     n_isects = int(incl[-1].item()) if total > 0 else 0          # the one unavoidable sync
     if n_isects >= 2 ** 31:
         raise _lib.MisplatError(f"{n_isects} tile intersections exceed int32 indexing")
-    cum = (incl - tiles_per_gauss).contiguous()                    # exclusive scan, int64
-    keys = torch.empty(n_isects, device=dev, dtype=torch.int64)
-    slots = torch.empty(n_isects, device=dev, dtype=torch.int32)
-    isect_gid = torch.empty(n_isects, device=dev, dtype=torch.int32)
-    keys_s = torch.empty_like(keys)
-    slots_s = torch.empty_like(slots)
-    flatten_ids = torch.empty(n_isects, device=dev, dtype=torch.int32)
-    offsets = torch.empty(n_tiles, device=dev, dtype=torch.int32)
+    cum_ordered = (incl - tpg_ordered).contiguous()               # exclusive scan in depth order, int64
+    # (2) emit in depth order, (3) stable sort on the tile bits
+    tile_ids = torch.empty(n_isects, **i32)
+    isect_gid = torch.empty(n_isects, **i32)
+    slots = torch.empty(n_isects, **i32) if deterministic else None
+    tile_ids_s, payload_s = torch.empty_like(tile_ids), torch.empty(n_isects, **i32)
+    offsets = torch.empty(n_tiles, **i32)
     if n_isects > 0:
-        check(lib.misplat_tile_emit(C.byref(P), ptr(means2d), ptr(radii), ptr(depths), ptr(cum), ptr(keys),
-                                    ptr(slots), ptr(isect_gid), stream_ptr()), "misplat_tile_emit")
-        end_bit = 32 + max(1, (n_tiles - 1).bit_length())
-        ws_bytes = int(lib.misplat_sort_workspace_bytes(C.c_int64(n_isects), C.c_int32(end_bit)))
-        if ws_bytes == 0:
-            raise _lib.MisplatError("misplat_sort_workspace_bytes failed")
+        check(lib.misplat_tile_emit_ordered(C.byref(P), ptr(order), ptr(means2d), ptr(radii), ptr(cum_ordered),
+                                            ptr(tile_ids), ptr(slots), ptr(isect_gid), stream_ptr()),
+              "misplat_tile_emit_ordered")
+        tile_bits = max(1, (n_tiles - 1).bit_length())
+        ws_bytes = _sort_ws_bytes(lib, "u32", n_isects, tile_bits)
         ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        check(lib.misplat_sort_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(keys), ptr(keys_s), ptr(slots),
-                                     ptr(slots_s), C.c_int64(n_isects), C.c_int32(end_bit), stream_ptr()),
-              "misplat_sort_pairs")
-    check(lib.misplat_tile_offsets(ptr(keys_s), ptr(slots_s), ptr(isect_gid), C.c_int64(n_isects),
-                                   C.c_int32(n_tiles), ptr(offsets), ptr(flatten_ids), stream_ptr()),
-          "misplat_tile_offsets")
-    return dict(tiles_per_gauss=tiles_per_gauss, cum=cum, isect_ids=keys_s, slots=slots_s,
-                flatten_ids=flatten_ids, isect_offsets=offsets, n_isects=n_isects)
+        check(lib.misplat_sort32_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(tile_ids), ptr(tile_ids_s),
+                                       ptr(slots if deterministic else isect_gid), ptr(payload_s),
+                                       C.c_int64(n_isects), C.c_int32(tile_bits), stream_ptr()),
+              "misplat_sort32_pairs")
+    check(lib.misplat_tile_offsets32(ptr(tile_ids_s), C.c_int64(n_isects), C.c_int32(n_tiles), ptr(offsets),
+                                     stream_ptr()), "misplat_tile_offsets32")
+    if deterministic:
+        slots_s = payload_s
+        flatten_ids = isect_gid[slots_s.long()] if n_isects > 0 else payload_s
+    else:
+        slots_s, flatten_ids = None, payload_s
+    return dict(tiles_per_gauss=tiles_per_gauss, tile_ids=tile_ids_s, slots=slots_s, flatten_ids=flatten_ids,
+                isect_offsets=offsets, n_isects=n_isects, order=order, cum_ordered=cum_ordered, depths=depths)
+
+
+@torch.no_grad()
+def isect_ids(bins: Dict[str, Tensor]) -> Tensor:
+    """gsplat's ``meta["isect_ids"]``: the sorted 64-bit keys (tile << 32 | depth bits), on demand."""
+    lib = _lib.load()
+    n = bins["n_isects"]
+    out = torch.empty(n, device=bins["flatten_ids"].device, dtype=torch.int64)
+    check(lib.misplat_isect_ids(ptr(bins["tile_ids"]), ptr(bins["flatten_ids"]), ptr(bins["depths"].contiguous()),
+                                C.c_int64(n), ptr(out), stream_ptr()), "misplat_isect_ids")
+    return out
+
+
+def _cum_by_row(bins: Dict[str, Tensor]) -> Tensor:
+    """First emission slot of every Gaussian row (deterministic backward only; built lazily)."""
+    if "cum" not in bins:
+        cum = torch.empty_like(bins["cum_ordered"])
+        cum[bins["order"].long()] = bins["cum_ordered"]
+        bins["cum"] = cum
+    return bins["cum"]
 
 
 # ----------------------------------------------------------------------------- blending
@@ -373,7 +440,7 @@ def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
     rows = P.n_cams * P.n_gauss
     dev = grec.device
     ups = [_c(t) for t in (v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)]
-    if not DETERMINISTIC_BACKWARD:
+    if bins["slots"] is None:                      # binned in atomic mode (ops.DETERMINISTIC_BACKWARD was False)
         v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
         v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
         with _timed("blend_bwd"):
@@ -396,7 +463,7 @@ def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
     v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
     v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
     with _timed("slab_reduce"):
-        check(lib.misplat_slab_reduce(C.byref(P), C.c_int64(rows), C.c_int64(n_isects), ptr(bins["cum"]),
+        check(lib.misplat_slab_reduce(C.byref(P), C.c_int64(rows), C.c_int64(n_isects), ptr(_cum_by_row(bins)),
                                       ptr(bins["tiles_per_gauss"]), ptr(slab), ptr(slab_abs), ptr(slab_valid),
                                       ptr(v_grec), ptr(v_abs), stream_ptr()), "misplat_slab_reduce")
     return v_grec, v_abs

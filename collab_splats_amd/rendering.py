@@ -20,6 +20,17 @@ from ._lib import MisplatError, make_params
 _RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
 
 
+class _Meta(dict):
+    """``meta`` dict; ``meta["isect_ids"]`` (gsplat's sorted 64-bit keys, which nothing on the
+    reference's path reads) is rebuilt from the tile ids and depths on first access."""
+
+    def __missing__(self, key):
+        if key == "isect_ids":
+            self[key] = ops.isect_ids(self["_bins"])
+            return self[key]
+        raise KeyError(key)
+
+
 def rasterization(
     means: Tensor,                    # [N, 3]
     quats: Tensor,                    # [N, 4] wxyz, un-normalised
@@ -140,16 +151,16 @@ def rasterization(
     if backgrounds is not None:
         render = render + (1.0 - alpha) * backgrounds[:, None, None, :]
 
-    meta = {
-        "camera_ids": None, "gaussian_ids": None,
+    meta = _Meta({
+        "_bins": bins, "camera_ids": None, "gaussian_ids": None,
         "radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
         "compensations": comps, "ray_ts": ray_ts, "ray_planes": ray_planes, "normals": normals,
         "tile_width": P.tile_w, "tile_height": P.tile_h, "tiles_per_gauss": bins["tiles_per_gauss"].view(Cn, N),
-        "isect_ids": bins["isect_ids"], "flatten_ids": bins["flatten_ids"],
+        "flatten_ids": bins["flatten_ids"],
         "isect_offsets": bins["isect_offsets"].view(Cn, P.tile_h, P.tile_w),
         "n_isects": bins["n_isects"], "last_ids": first[5], "median_ids": first[6],
         "width": width, "height": height, "tile_size": tile_size, "n_cameras": Cn,
-    }
+    })
     if return_depth_normal:
         return render, alpha, exp_depth, med_depth, exp_normal, meta
     return render, alpha, meta

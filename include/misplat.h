@@ -152,6 +152,31 @@ int misplat_tile_offsets(const uint64_t* keys_sorted, const int32_t* slots_sorte
                          const int32_t* isect_gid, int64_t n_isects, int32_t n_tiles_total,
                          int32_t* offsets, int32_t* flatten_ids, misplat_stream_t stream);
 
+/* Two-stage ordering (used by the shipped path; same final (tile, depth, Gaussian id) order as the
+ * 64-bit sort above): (1) depth_keys (+ sort_pairs) or, for one camera, depth_keys32 (+ sort32_pairs)
+ * order the C*N rows by (camera, depth bits), culled rows last; (2) tile_emit_ordered walks that
+ * order (order[r] = row, cum_ordered = exclusive scan of tiles_per_gauss[order[r]]) and writes the
+ * 32-bit tile id and the row of every intersection (isect_gid), plus its emission slot if slot_ids
+ * != NULL; (3) sort32_pairs is a STABLE radix sort on the ceil(log2(C*tiles)) tile bits only, the
+ * payload being the row (=> flatten_ids directly) or the slot; (4) tile_offsets32 builds the per-tile
+ * offsets; isect_ids rebuilds the 64-bit keys (tile << 32 | depth bits) on demand. */
+int misplat_depth_keys(const misplat_params* p, const int32_t* radii, const float* depths,
+                       uint64_t* keys, int32_t* ids, misplat_stream_t stream);
+int misplat_depth_keys32(const misplat_params* p, const int32_t* radii, const float* depths,
+                         uint32_t* keys, int32_t* ids, misplat_stream_t stream);
+int misplat_tile_emit_ordered(const misplat_params* p, const int32_t* order, const float* means2d,
+                              const int32_t* radii, const int64_t* cum_ordered, uint32_t* tile_ids,
+                              int32_t* slot_ids /* or NULL */, int32_t* isect_gid,
+                              misplat_stream_t stream);
+size_t misplat_sort32_workspace_bytes(int64_t n, int32_t end_bit);
+int misplat_sort32_pairs(void* workspace, size_t workspace_bytes, const uint32_t* keys_in,
+                         uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
+                         int32_t end_bit, misplat_stream_t stream);
+int misplat_tile_offsets32(const uint32_t* tiles_sorted, int64_t n_isects, int32_t n_tiles_total,
+                           int32_t* offsets, misplat_stream_t stream);
+int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, const float* depths,
+                      int64_t n_isects, uint64_t* isect_ids, misplat_stream_t stream);
+
 /* ---- a2.4 / a2.5 compositing.  Packed record per (camera, Gaussian), MISPLAT_REC floats:
  *   [0:2] mean2d  [2:5] conic  [5] opacity_eff  [6] ray_t  [7:9] ray_plane  [9:12] normal
  *   [12:16] colour channels 0..3 (unused channels zero).                         */
