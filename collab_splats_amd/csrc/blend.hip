@@ -6,20 +6,20 @@
 // return_depth_normal=True) as called at /root/reference/collab_splats/models/rade_gs_model.py:439-465
 //  and camera_utils.py:176-279 + rade_gs_model.py:212-214 (row a4).
 //
-// Design (see DESIGN.md):
-//   * ONE wavefront owns ONE 16x16 tile; each lane owns 4 pixels (x = lane&15, y = lane>>4 + 4k).
-//     No inter-wave barrier exists anywhere, so tiles of very different depth complexity retire
-//     independently and the hardware scheduler does the load balancing.
-//   * Gaussians of the tile are staged 64 at a time into LDS (one 64-byte record per lane,
-//     gathered through the sorted id list, stored quad-major so the stores are conflict-free) and
-//     then broadcast-read (same address in every lane: conflict-free) once per Gaussian for 256
-//     pixels -- a quarter of the LDS traffic of a thread-per-pixel kernel.
-//   * Early termination is a 64-bit __ballot over "all four of my pixels are done".
-//   * Backward: per (tile, Gaussian) the 16 gradient components are summed over the lane's 4
-//     pixels in registers, then over the 64 lanes with a halving butterfly (17 adds instead of 96),
-//     and written as ONE 64-byte row to slab[slot].  slot = emission order, so the rows of a
-//     Gaussian are contiguous and a second kernel sums them in a fixed order: no float atomics
-//     (global atomics run at ~1.3 TB/s on MI355X and are order dependent), bitwise reproducible.
+// Design (DESIGN.md section 6):
+//   * ONE wavefront owns a band of 16 x (4*PPL) pixels of a tile, PPL pixels per lane; a block is a
+//     single wave, so no inter-wave barrier exists anywhere and bands of very different depth
+//     complexity retire independently (the hardware scheduler does the load balancing).
+//   * Gaussians of the tile are staged 64 at a time: one 64-byte record per lane, gathered through
+//     the sorted id list, tested against the band's pixel box (exact minimum of the quadratic),
+//     survivors compacted with a ballot prefix into LDS (quad-major: conflict-free stores) and then
+//     broadcast-read (same address in every lane: conflict-free) once per Gaussian.
+//   * Early termination is a 64-bit __ballot over "all my pixels are done".
+//   * Backward: per (band, Gaussian) the 16 gradient components are summed over the lane's pixels
+//     in registers, then over the 64 lanes with a halving butterfly (17 adds instead of 96), and
+//     leave as ONE 64-byte row: a contiguous no-return fp32 atomic into the per-Gaussian gradient
+//     (default; hidden under the VALU-bound kernel) or a store into a per-intersection slab that a
+//     second kernel sums in a fixed order (bitwise reproducible).
 //   * No MFMA: there is no dense contraction here; the loop is v_exp_f32 + FMA bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
