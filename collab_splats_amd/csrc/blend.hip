@@ -110,6 +110,9 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
     return __popcll(mask);
 }
 
+// Forward.  The per-pixel loop is branch-free: a pixel that has terminated carries T = 0 (its
+// transmittance at termination is parked in Tfin), so every later weight w = a*T vanishes by itself;
+// "skip" is a = 0.  The next record is prefetched from LDS while the current one is consumed.
 template <int CD, int PPL>
 __global__ __launch_bounds__(64) void blend_fwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
@@ -117,8 +120,8 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     float* __restrict__ render, float* __restrict__ alpha, float* __restrict__ exp_depth,
     float* __restrict__ med_depth, float* __restrict__ normal, int32_t* __restrict__ last_ids,
     int32_t* __restrict__ median_ids) {
-    __shared__ float4 sm[4 * 64];
-    __shared__ int sm_idx[64];
+    __shared__ float4 sm[4 * 64 + 4];
+    __shared__ int sm_idx[64 + 4];
     BandCtx c;
     if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c)) return;
     const int lane = threadIdx.x;
@@ -126,17 +129,17 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     const int ybase = c.y0 + (lane >> 4);
     const float px = (float)x + 0.5f;
     const float rxn = (px - c.cx) / c.fx;
-    float py[PPL], inv_ell[PPL], T[PPL], dep[PPL], med[PPL], col[PPL][CD], nrm[PPL][3];
+    float py[PPL], inv_ell[PPL], T[PPL], Tfin[PPL], dep[PPL], med[PPL], col[PPL][CD], nrm[PPL][3];
     int last[PPL], medi[PPL];
-    bool done[PPL];
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
         const int y = ybase + 4 * k;
         py[k] = (float)y + 0.5f;
         const float ryn = (py[k] - c.cy) / c.fy;
         inv_ell[k] = 1.0f / sqrtf(rxn * rxn + ryn * ryn + 1.0f);
-        done[k] = !(x < P.width && y < P.height);
-        T[k] = 1.0f; dep[k] = 0.f; med[k] = 0.f; last[k] = -1; medi[k] = -1;
+        const bool inside = x < P.width && y < P.height;
+        T[k] = inside ? 1.0f : 0.0f;           // T == 0  <=>  pixel finished
+        Tfin[k] = 1.0f; dep[k] = 0.f; med[k] = 0.f; last[k] = -1; medi[k] = -1;
 #pragma unroll
         for (int ch = 0; ch < CD; ch++) col[k][ch] = 0.f;
         nrm[k][0] = nrm[k][1] = nrm[k][2] = 0.f;
@@ -146,48 +149,54 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     const float ylo = (float)c.y0 + 0.5f, yhi = ylo + (float)(4 * PPL - 1);
 
     for (int bs = c.beg; bs < c.end; bs += 64) {
-        bool all = true;
+        float tmax = T[0];
 #pragma unroll
-        for (int k = 0; k < PPL; k++) all = all && done[k];
-        if (__ballot(!all) == 0ull) break;
+        for (int k = 1; k < PPL; k++) tmax = fmaxf(tmax, T[k]);
+        if (__ballot(tmax > 0.f) == 0ull) break;
         __syncthreads();
         const int n = stage_records(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
                                     nullptr, xlo, xhi, ylo, yhi, amin);
         __syncthreads();
+        if (n == 0) continue;
+        float4 n0 = sm[0], n1 = sm[64], n2 = sm[128], n3 = sm[192];
+        int ni = sm_idx[0];
         for (int j = 0; j < n; j++) {
-            const float4 q0 = sm[j], q1 = sm[64 + j], q2 = sm[128 + j], q3 = sm[192 + j];
-            const int i = sm_idx[j];
+            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+            const int i = ni;
+            n0 = sm[j + 1]; n1 = sm[64 + j + 1]; n2 = sm[128 + j + 1]; n3 = sm[192 + j + 1];   // prefetch (padded)
+            ni = sm_idx[j + 1];
             const float dx = q0.x - px;
             const float ea = q0.z * dx * dx, eb = q0.w * dx;
             const float tpx = q1.z - q1.w * dx;
-            bool alld = true;
+            float tm = 0.f;
 #pragma unroll
             for (int k = 0; k < PPL; k++) {
                 const float dy = q0.y - py[k];
                 const float e = ea + (q1.x * dy + eb) * dy;
                 const float vis = __builtin_amdgcn_exp2f(e);
-                const float a = fminf(amax, q1.y * vis);
-                if (!done[k] && e <= 0.f && a >= amin) {
-                    const float Tn = T[k] * (1.0f - a);
-                    if (Tn <= tstop) {
-                        done[k] = true;
-                    } else {
-                        const float w = a * T[k];
-                        const float zp = (tpx - q2.x * dy) * inv_ell[k];
-                        col[k][0] += w * q3.x;
-                        if (CD > 1) col[k][CD > 1 ? 1 : 0] += w * q3.y;
-                        if (CD > 2) col[k][CD > 2 ? 2 : 0] += w * q3.z;
-                        if (CD > 3) col[k][CD > 3 ? 3 : 0] += w * q3.w;
-                        dep[k] += w * zp;
-                        nrm[k][0] += w * q2.y; nrm[k][1] += w * q2.z; nrm[k][2] += w * q2.w;
-                        if (T[k] > tmed) { med[k] = zp; medi[k] = i; }
-                        last[k] = i;
-                        T[k] = Tn;
-                    }
-                }
-                alld = alld && done[k];
+                float a = fminf(amax, q1.y * vis);
+                a = (e <= 0.f && a >= amin) ? a : 0.f;
+                float w = a * T[k];
+                const float Tn = T[k] - w;
+                const bool stop = (w > 0.f) && (Tn <= tstop);       // this Gaussian is excluded
+                const bool use = (w > 0.f) && !stop;
+                Tfin[k] = stop ? T[k] : Tfin[k];
+                const bool is_med = use && (T[k] > tmed);
+                T[k] = stop ? 0.f : Tn;
+                w = stop ? 0.f : w;
+                const float zp = (tpx - q2.x * dy) * inv_ell[k];
+                col[k][0] += w * q3.x;
+                if (CD > 1) col[k][CD > 1 ? 1 : 0] += w * q3.y;
+                if (CD > 2) col[k][CD > 2 ? 2 : 0] += w * q3.z;
+                if (CD > 3) col[k][CD > 3 ? 3 : 0] += w * q3.w;
+                dep[k] += w * zp;
+                nrm[k][0] += w * q2.y; nrm[k][1] += w * q2.z; nrm[k][2] += w * q2.w;
+                med[k] = is_med ? zp : med[k];
+                medi[k] = is_med ? i : medi[k];
+                last[k] = use ? i : last[k];
+                tm = fmaxf(tm, T[k]);
             }
-            if (__ballot(!alld) == 0ull) break;
+            if (__ballot(tm > 0.f) == 0ull) break;
         }
     }
 #pragma unroll
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
             const size_t pid = ((size_t)c.cam * P.height + y) * P.width + x;
 #pragma unroll
             for (int ch = 0; ch < CD; ch++) render[pid * CD + ch] = col[k][ch];
-            alpha[pid] = 1.0f - T[k];
+            alpha[pid] = 1.0f - (T[k] > 0.f ? T[k] : Tfin[k]);
             exp_depth[pid] = dep[k];
             med_depth[pid] = med[k];
             normal[pid * 3 + 0] = nrm[k][0]; normal[pid * 3 + 1] = nrm[k][1]; normal[pid * 3 + 2] = nrm[k][2];
@@ -207,50 +216,71 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     }
 }
 
-// ---- wave reductions -------------------------------------------------------------------------
-// Halving butterfly over the low 4 lane bits (16 values -> 1 per lane, summed over each 16-lane
-// row), then two plain exchanges over lane bits 4 and 5.  Lane l < 16 ends with component
-// bitrev4(l) summed over all 64 lanes.
+// ---- wave reductions (DPP / permlane: no LDS traffic) ------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+constexpr int kDppHalfMirror = 0x141;  // lane l <-> l ^ 7   (within 8)
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppRor8 = 0x128;        // row_ror:8 == l ^ 8 (within 16)
+
+__device__ __forceinline__ float cross_row_sum(float r) {      // + lanes l^16, l^32 (v_permlane*_swap)
+    typedef int v2i __attribute__((ext_vector_type(2)));
+    int ri = __float_as_int(r);
+    v2i s16 = __builtin_amdgcn_permlane16_swap(ri, ri, false, false);
+    r = __int_as_float(s16.x) + __int_as_float(s16.y);
+    ri = __float_as_int(r);
+    v2i s32 = __builtin_amdgcn_permlane32_swap(ri, ri, false, false);
+    return __int_as_float(s32.x) + __int_as_float(s32.y);
+}
+
+// Halving butterfly: 16 values per lane -> 1 per lane, summed over all 64 lanes.  Partners:
+// l^7 (split on lane bit 2), l^1 (bit 0), l^2 (bit 1), l^8 (bit 3), then the two cross-row adds.
+// 8 + 4 + 2 + 1 + 2 = 17 adds instead of 16 * 6.  Lane l ends with component butterfly_comp(l).
 __device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane) {
     {
-        const bool hi = lane & 1;
+        const bool hi = lane & 4;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const float keep = hi ? v[8 + i] : v[i], send = hi ? v[i] : v[8 + i];
-            v[i] = keep + __shfl_xor(send, 1);
+            v[i] = keep + dpp_mov<kDppHalfMirror>(send);
+        }
+    }
+    {
+        const bool hi = lane & 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float keep = hi ? v[4 + i] : v[i], send = hi ? v[i] : v[4 + i];
+            v[i] = keep + dpp_mov<kDppXor1>(send);
         }
     }
     {
         const bool hi = lane & 2;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float keep = hi ? v[4 + i] : v[i], send = hi ? v[i] : v[4 + i];
-            v[i] = keep + __shfl_xor(send, 2);
-        }
-    }
-    {
-        const bool hi = lane & 4;
-#pragma unroll
         for (int i = 0; i < 2; i++) {
             const float keep = hi ? v[2 + i] : v[i], send = hi ? v[i] : v[2 + i];
-            v[i] = keep + __shfl_xor(send, 4);
+            v[i] = keep + dpp_mov<kDppXor2>(send);
         }
     }
     {
         const bool hi = lane & 8;
         const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
-        v[0] = keep + __shfl_xor(send, 8);
+        v[0] = keep + dpp_mov<kDppRor8>(send);
     }
-    float r = v[0];
-    r += __shfl_xor(r, 16);
-    r += __shfl_xor(r, 32);
-    return r;
+    return cross_row_sum(v[0]);
+}
+__device__ __forceinline__ int butterfly_comp(int l) {
+    return (((l >> 2) & 1) << 3) | ((l & 1) << 2) | (((l >> 1) & 1) << 1) | ((l >> 3) & 1);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-    return v;
+    v += dpp_mov<kDppHalfMirror>(v);
+    v += dpp_mov<kDppXor1>(v);
+    v += dpp_mov<kDppXor2>(v);
+    v += dpp_mov<kDppRor8>(v);
+    return cross_row_sum(v);
 }
 
 __device__ __forceinline__ int wave_max(int v) {
@@ -259,13 +289,9 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
-__device__ __forceinline__ int bitrev4(int l) {
-    return ((l & 1) << 3) | ((l & 2) << 1) | ((l & 4) >> 1) | ((l & 8) >> 3);
-}
-
-// Backward.  Each wave writes one gradient row per Gaussian that contributed to its band, to
-// slab[band][slot], and marks it in valid[band][slot] (zeroed by the launcher); rows never marked
-// are never read.
+// Backward.  Branch-free per-pixel body (a == 0 makes a pair a no-op), next record prefetched from
+// LDS.  ATOMIC: the reduced 64-byte row is added into v_grec[row]; otherwise it is stored to
+// slab[band][slot] and marked in valid[band][slot] (zeroed by the launcher).
 template <int CD, int PPL, bool ABS, bool ATOMIC>
 __global__ __launch_bounds__(64) void blend_bwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
@@ -276,9 +302,9 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
     const float* __restrict__ v_exp_depth, const float* __restrict__ v_med_depth,
     const float* __restrict__ v_normal, float* __restrict__ slab, float* __restrict__ slab_abs,
     uint8_t* __restrict__ valid) {
-    __shared__ float4 sm[4 * 64];
-    __shared__ int sm_idx[64];
-    __shared__ int sm_slot[64];
+    __shared__ float4 sm[4 * 64 + 4];
+    __shared__ int sm_idx[64 + 4];
+    __shared__ int sm_slot[64 + 4];
     BandCtx c;
     if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c)) return;
     if (c.end <= c.beg) return;
@@ -317,7 +343,7 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
     }
     const int maxlast = wave_max(mymax);
     if (maxlast < c.beg) return;
-    const int comp = bitrev4(lane & 15);
+    const int comp = butterfly_comp(lane & 15);
     // per-lane scale undoing the conic pre-multiplication (component = record layout index)
     const float out_scale = (comp == 2 || comp == 4) ? -0.5f * kLog2e : (comp == 3 ? -kLog2e : 1.0f);
     const float amax = P.alpha_max, amin = P.alpha_min;
@@ -334,9 +360,16 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
         const int n = stage_records(sm, sm_idx, sm_slot, lane, bs + lane, bs + lane <= maxlast, grec, flatten_ids,
                                     ATOMIC ? nullptr : slots, xlo, xhi, ylo, yhi, amin);
         __syncthreads();
+        if (n == 0) continue;
+        float4 n0 = sm[n - 1], n1 = sm[64 + n - 1], n2 = sm[128 + n - 1], n3 = sm[192 + n - 1];
+        int ni = sm_idx[n - 1], nslot = sm_slot[n - 1];
         for (int j = n - 1; j >= 0; j--) {
-            const float4 q0 = sm[j], q1 = sm[64 + j], q2 = sm[128 + j], q3 = sm[192 + j];
-            const int i = sm_idx[j];
+            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
+            const int i = ni;
+            const size_t slot = (size_t)nslot;
+            const int jn = j > 0 ? j - 1 : 0;                                  // prefetch
+            n0 = sm[jn]; n1 = sm[64 + jn]; n2 = sm[128 + jn]; n3 = sm[192 + jn];
+            ni = sm_idx[jn]; nslot = sm_slot[jn];
             const float dx = q0.x - px;
             const float ea = q0.z * dx * dx, eb = q0.w * dx;
             const float tpx = q1.z - q1.w * dx;
@@ -344,17 +377,17 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
             float ab0 = 0.f, ab1 = 0.f;
-            bool any = false;
+            float amx = 0.f;
 #pragma unroll
             for (int k = 0; k < PPL; k++) {
-                if (i > last[k]) continue;
                 const float dy = q0.y - py[k];
                 const float e = ea + (q1.x * dy + eb) * dy;
                 const float vis = __builtin_amdgcn_exp2f(e);
                 const float ov = q1.y * vis;
-                const float a = fminf(amax, ov);
-                if (!(e <= 0.f && a >= amin)) continue;
-                any = true;
+                float a = fminf(amax, ov);
+                const bool ok = (i <= last[k]) && (e <= 0.f) && (a >= amin);
+                a = ok ? a : 0.f;
+                amx = fmaxf(amx, a);
                 const float ra = __builtin_amdgcn_rcpf(1.0f - a);
                 T[k] *= ra;
                 const float w = a * T[k];
@@ -364,7 +397,8 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
                 if (CD > 2) dot += q3.z * vcol[k][CD > 2 ? 2 : 0];
                 if (CD > 3) dot += q3.w * vcol[k][CD > 3 ? 3 : 0];
                 dot += q2.y * vn[k][0] + q2.z * vn[k][1] + q2.w * vn[k][2] + zp * vd[k];
-                const float v_a = (tfva[k] - B[k]) * ra + T[k] * dot;
+                float v_a = (tfva[k] - B[k]) * ra + T[k] * dot;
+                v_a = ok ? v_a : 0.f;
                 B[k] += w * dot;
                 acc[12] += w * vcol[k][0];
                 if (CD > 1) acc[13] += w * vcol[k][CD > 1 ? 1 : 0];
@@ -372,22 +406,18 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
                 if (CD > 3) acc[15] += w * vcol[k][CD > 3 ? 3 : 0];
                 acc[9] += w * vn[k][0]; acc[10] += w * vn[k][1]; acc[11] += w * vn[k][2];
                 float vz = w * vd[k];
-                if (i == medi[k]) vz += vm[k];
+                vz += (ok && i == medi[k]) ? vm[k] : 0.f;
                 const float vzl = vz * inv_ell[k];
                 acc[6] += vzl; acc[7] -= vzl * dx; acc[8] -= vzl * dy;
-                float vmx = -vzl * q1.w, vmy = -vzl * q2.x;
-                if (ov <= amax) {
-                    const float v_e = kLn2 * ov * v_a;
-                    acc[5] += vis * v_a;
-                    acc[2] += dx * dx * v_e; acc[3] += dx * dy * v_e; acc[4] += dy * dy * v_e;
-                    vmx += (2.0f * q0.z * dx + q0.w * dy) * v_e;
-                    vmy += (2.0f * q1.x * dy + q0.w * dx) * v_e;
-                }
+                const float v_e = (ov <= amax) ? kLn2 * ov * v_a : 0.f;
+                acc[5] += vis * ((ov <= amax) ? v_a : 0.f);
+                acc[2] += dx * dx * v_e; acc[3] += dx * dy * v_e; acc[4] += dy * dy * v_e;
+                const float vmx = (2.0f * q0.z * dx + q0.w * dy) * v_e - vzl * q1.w;
+                const float vmy = (2.0f * q1.x * dy + q0.w * dx) * v_e - vzl * q2.x;
                 acc[0] += vmx; acc[1] += vmy;
                 if (ABS) { ab0 += fabsf(vmx); ab1 += fabsf(vmy); }
             }
-            if (__ballot(any) != 0ull) {
-                const size_t slot = (size_t)sm_slot[j];
+            if (__ballot(amx > 0.f) != 0ull) {
                 const float r = wave_reduce16(acc, lane);
                 if (ATOMIC) {
                     // one 64-byte contiguous no-return fp32 atomic per (band, Gaussian)
