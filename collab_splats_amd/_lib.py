@@ -35,7 +35,7 @@ class Params(C.Structure):
                 ("far_plane", C.c_float), ("radius_clip", C.c_float), ("radius_sigma", C.c_float),
                 ("alpha_max", C.c_float), ("alpha_min", C.c_float), ("t_stop", C.c_float),
                 ("median_t", C.c_float), ("jacobian_margin", C.c_float), ("plane_eps", C.c_float),
-                ("ppl_fwd", C.c_int32), ("ppl_bwd", C.c_int32)]
+                ("ppl_fwd", C.c_int32), ("ppl_bwd", C.c_int32), ("ed_slot", C.c_int32)]
 
 
 def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: int = 16,
@@ -43,7 +43,7 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
                 near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0,
                 radius_sigma: float = 3.33, alpha_max: float = 0.999, alpha_min: float = 1.0 / 255.0,
                 t_stop: float = 1e-4, median_t: float = 0.5, jacobian_margin: float = 0.3,
-                plane_eps: float = 1e-6, ppl_fwd: int = 0, ppl_bwd: int = 0) -> Params:
+                plane_eps: float = 1e-6, ppl_fwd: int = 0, ppl_bwd: int = 0, ed_slot: int = -1) -> Params:
     if tile_size != MISPLAT_TILE:
         raise ValueError(f"tile_size must be {MISPLAT_TILE} (got {tile_size})")
     tw = (width + tile_size - 1) // tile_size
@@ -51,7 +51,7 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
     return Params(n_gauss, n_cams, width, height, tile_size, tw, th, int(antialiased),
                   int(opacity_aware_radius), eps2d, near_plane, far_plane, radius_clip, radius_sigma,
                   alpha_max, alpha_min, t_stop, median_t, jacobian_margin, plane_eps,
-                  int(os.environ.get("MISPLAT_PPL_FWD", ppl_fwd)), int(os.environ.get("MISPLAT_PPL_BWD", ppl_bwd)))
+                  int(os.environ.get("MISPLAT_PPL_FWD", ppl_fwd)), int(os.environ.get("MISPLAT_PPL_BWD", ppl_bwd)), int(ed_slot))
 
 
 # name -> (restype, n_args); every symbol include/misplat.h declares
@@ -66,8 +66,8 @@ SYMBOLS = {
     "misplat_tile_emit_ordered": (C.c_int, 9), "misplat_sort32_workspace_bytes": (C.c_size_t, 2),
     "misplat_sort32_pairs": (C.c_int, 9), "misplat_tile_offsets32": (C.c_int, 5),
     "misplat_isect_ids": (C.c_int, 6), "misplat_depth_keys32": (C.c_int, 6), "misplat_pack": (C.c_int, 11),
-    "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_bwd": (C.c_int, 20),
-    "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 18), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),
+    "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_bwd": (C.c_int, 21),
+    "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 19), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),
     "misplat_depth_normal_bwd": (C.c_int, 13), "misplat_version": (C.c_char_p, 0),
 }
 

@@ -204,9 +204,11 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
         const int y = ybase + 4 * k;
         if (x < P.width && y < P.height) {
             const size_t pid = ((size_t)c.cam * P.height + y) * P.width + x;
+            const float al = 1.0f - (T[k] > 0.f ? T[k] : Tfin[k]);
+            const float inv_al = 1.0f / fmaxf(al, 1e-10f);
 #pragma unroll
-            for (int ch = 0; ch < CD; ch++) render[pid * CD + ch] = col[k][ch];
-            alpha[pid] = 1.0f - (T[k] > 0.f ? T[k] : Tfin[k]);
+            for (int ch = 0; ch < CD; ch++) render[pid * CD + ch] = (ch == P.ed_slot) ? col[k][ch] * inv_al : col[k][ch];
+            alpha[pid] = al;
             exp_depth[pid] = dep[k];
             med_depth[pid] = med[k];
             normal[pid * 3 + 0] = nrm[k][0]; normal[pid * 3 + 1] = nrm[k][1]; normal[pid * 3 + 2] = nrm[k][2];
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ slots,
     const int32_t* __restrict__ offsets, int64_t n_isects, const float* __restrict__ alpha,
     const int32_t* __restrict__ last_ids, const int32_t* __restrict__ median_ids,
-    const float* __restrict__ v_render, const float* __restrict__ v_alpha,
+    const float* __restrict__ render, const float* __restrict__ v_render, const float* __restrict__ v_alpha,
     const float* __restrict__ v_exp_depth, const float* __restrict__ v_med_depth,
     const float* __restrict__ v_normal, float* __restrict__ slab, float* __restrict__ slab_abs,
     uint8_t* __restrict__ valid) {
@@ -330,11 +332,21 @@ __global__ __launch_bounds__(64) void blend_bwd_kernel(
             const size_t pid = ((size_t)c.cam * P.height + y) * P.width + x;
             last[k] = last_ids[pid];
             medi[k] = median_ids[pid];
-            const float Tf = 1.0f - alpha[pid];
+            const float al = alpha[pid];
+            const float Tf = 1.0f - al;
             T[k] = Tf;
-            tfva[k] = Tf * v_alpha[pid];
+            float va = v_alpha[pid];
 #pragma unroll
-            for (int ch = 0; ch < CD; ch++) vcol[k][ch] = v_render[pid * CD + ch];
+            for (int ch = 0; ch < CD; ch++) {
+                float g = v_render[pid * CD + ch];
+                if (ch == P.ed_slot) {         // out = raw / max(alpha, 1e-10)
+                    const float inv_al = 1.0f / fmaxf(al, 1e-10f);
+                    g *= inv_al;
+                    if (al > 1e-10f) va -= g * render[pid * CD + ch];
+                }
+                vcol[k][ch] = g;
+            }
+            tfva[k] = Tf * va;
             vn[k][0] = v_normal[pid * 3]; vn[k][1] = v_normal[pid * 3 + 1]; vn[k][2] = v_normal[pid * 3 + 2];
             vd[k] = v_exp_depth[pid];
             vm[k] = v_med_depth[pid];
@@ -620,6 +632,7 @@ inline int grid_for(int64_t n, int block) {
 }
 inline bool params_ok(const misplat_params* p) {
     return p && p->tile_size == MISPLAT_TILE && p->n_cams >= 1 && p->width >= 1 && p->height >= 1 &&
+           p->ed_slot >= -1 && p->ed_slot <= 3 &&
            p->tile_w == (p->width + MISPLAT_TILE - 1) / MISPLAT_TILE &&
            p->tile_h == (p->height + MISPLAT_TILE - 1) / MISPLAT_TILE;
 }
@@ -666,7 +679,8 @@ extern "C" int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, con
                                  const float* grec, const int32_t* flatten_ids,
                                  const int32_t* slots_sorted, const int32_t* offsets, int64_t n_isects,
                                  const float* alpha, const int32_t* last_ids, const int32_t* median_ids,
-                                 const float* v_render, const float* v_alpha, const float* v_exp_depth,
+                                 const float* render, const float* v_render, const float* v_alpha,
+                                 const float* v_exp_depth,
                                  const float* v_med_depth, const float* v_normal, float* slab,
                                  float* slab_abs, uint8_t* slab_valid, misplat_stream_t stream) {
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !slab_valid) return MISPLAT_EINVAL;
@@ -680,8 +694,8 @@ extern "C" int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, con
 #define LAUNCH_BWD(CD_, PPL_, ABS_)                                                                          \
     hipLaunchKernelGGL((blend_bwd_kernel<CD_, PPL_, ABS_, false>), dim3(grid), dim3(64), 0, s, *p, Ks,         \
                        (const float4*)grec, flatten_ids, slots_sorted, offsets, n_isects, alpha, last_ids,     \
-                       median_ids, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, slab, slab_abs,      \
-                       slab_valid)
+                       median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, slab,        \
+                       slab_abs, slab_valid)
 #define DISPATCH_BWD(CD_)                                                        \
     do {                                                                         \
         if (slab_abs) {                                                          \
@@ -711,7 +725,7 @@ extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_d
                                         const float* grec, const int32_t* flatten_ids,
                                         const int32_t* offsets, int64_t n_isects, const float* alpha,
                                         const int32_t* last_ids, const int32_t* median_ids,
-                                        const float* v_render, const float* v_alpha,
+                                        const float* render, const float* v_render, const float* v_alpha,
                                         const float* v_exp_depth, const float* v_med_depth,
                                         const float* v_normal, float* v_grec, float* v_abs,
                                         misplat_stream_t stream) {
@@ -728,8 +742,8 @@ extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_d
 #define LAUNCH_BWDA(CD_, PPL_, ABS_)                                                                         \
     hipLaunchKernelGGL((blend_bwd_kernel<CD_, PPL_, ABS_, true>), dim3(grid), dim3(64), 0, s, *p, Ks,          \
                        (const float4*)grec, flatten_ids, (const int32_t*)nullptr, offsets, n_isects, alpha,    \
-                       last_ids, median_ids, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, v_grec,    \
-                       v_abs, (uint8_t*)nullptr)
+                       last_ids, median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal,    \
+                       v_grec, v_abs, (uint8_t*)nullptr)
 #define DISPATCH_BWDA(CD_)                                                       \
     do {                                                                         \
         if (v_abs) {                                                             \

@@ -299,7 +299,7 @@ class _Blend(torch.autograd.Function):
                                         ptr(median_ids), stream_ptr()), "misplat_blend_fwd")
         ctx.P, ctx.bins, ctx.absgrad, ctx.cd = P, bins, absgrad, cd
         ctx.means2d_ref = means2d if absgrad else None
-        ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids)
+        ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids, render)
         ctx.mark_non_differentiable(last_ids, median_ids)
         return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
 
@@ -418,7 +418,7 @@ class _BlendPacked(torch.autograd.Function):
                                         ptr(median_ids), stream_ptr()), "misplat_blend_fwd")
         ctx.P, ctx.bins, ctx.absgrad, ctx.cd = P, bins, absgrad, cd
         ctx.means2d_ref = means2d if absgrad else None
-        ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids)
+        ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids, render)
         ctx.mark_non_differentiable(last_ids, median_ids)
         return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
 
@@ -434,7 +434,7 @@ class _BlendPacked(torch.autograd.Function):
 def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
     """blend_bwd -> per-intersection rows -> fixed-order per-Gaussian sum.  Returns (v_grec, v_abs)."""
     lib = _lib.load()
-    grec, Ks, alpha, last_ids, median_ids = ctx.saved_tensors
+    grec, Ks, alpha, last_ids, median_ids, render = ctx.saved_tensors
     P, bins, cd = ctx.P, ctx.bins, ctx.cd
     n_isects = bins["n_isects"]
     rows = P.n_cams * P.n_gauss
@@ -446,8 +446,8 @@ def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
         with _timed("blend_bwd"):
             check(lib.misplat_blend_bwd_atomic(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
                                                ptr(bins["isect_offsets"]), C.c_int64(n_isects), ptr(alpha),
-                                               ptr(last_ids), ptr(median_ids), *[ptr(t) for t in ups], ptr(v_grec),
-                                               ptr(v_abs), stream_ptr()), "misplat_blend_bwd_atomic")
+                                               ptr(last_ids), ptr(median_ids), ptr(render), *[ptr(t) for t in ups],
+                                               ptr(v_grec), ptr(v_abs), stream_ptr()), "misplat_blend_bwd_atomic")
         return v_grec, v_abs
     planes = int(lib.misplat_blend_planes(C.byref(P)))
     rows_s = max(n_isects, 1) * planes
@@ -458,7 +458,7 @@ def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
     with _timed("blend_bwd"):
         check(lib.misplat_blend_bwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
                                     ptr(bins["slots"]), ptr(bins["isect_offsets"]), C.c_int64(n_isects),
-                                    ptr(alpha), ptr(last_ids), ptr(median_ids), *[ptr(t) for t in ups],
+                                    ptr(alpha), ptr(last_ids), ptr(median_ids), ptr(render), *[ptr(t) for t in ups],
                                     ptr(slab), ptr(slab_abs), ptr(slab_valid), stream_ptr()), "misplat_blend_bwd")
     v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
     v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None

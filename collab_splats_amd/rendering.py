@@ -90,16 +90,18 @@ def rasterization(
         raise MisplatError("rasterization() runs on the MI355X only (no CPU fallback)")
     width, height = int(width), int(height)
     aa = rasterize_mode == "antialiased"
-    P = make_params(N, Cn, width, height, tile_size=tile_size, antialiased=aa,
-                    opacity_aware_radius=opacity_aware_radius, eps2d=eps2d, near_plane=near_plane,
-                    far_plane=far_plane, radius_clip=radius_clip, radius_sigma=radius_sigma,
-                    alpha_max=alpha_max)
     viewmats = viewmats.contiguous().float()
     Ks = Ks.contiguous().float()
 
     depth_channel = render_mode in ("RGB+D", "RGB+ED", "D", "ED")
     n_user = 0 if render_mode in ("D", "ED") else (3 if sh_degree is not None else colors.shape[-1])
     fused = n_user + int(depth_channel) <= 4 and (sh_degree is None or colors.shape[1] <= 16)
+    # fused path: the kernels divide the depth channel by max(alpha, 1e-10) themselves ("ED")
+    ed_fused = fused and render_mode in ("ED", "RGB+ED")
+    P = make_params(N, Cn, width, height, tile_size=tile_size, antialiased=aa,
+                    opacity_aware_radius=opacity_aware_radius, eps2d=eps2d, near_plane=near_plane,
+                    far_plane=far_plane, radius_clip=radius_clip, radius_sigma=radius_sigma,
+                    alpha_max=alpha_max, ed_slot=n_user if ed_fused else -1)
     if fused:
         # ---- the reference's path (RGB / RGB+ED, SH or RGB colours): two autograd nodes, no glue kernels
         cin = colors if n_user > 0 else means.new_zeros(N, 1)
@@ -144,7 +146,7 @@ def rasterization(
         render = renders[0] if len(renders) == 1 else torch.cat(renders, dim=-1)
     alpha, exp_depth, med_depth, exp_normal = first[1], first[2], first[3], first[4]
 
-    if render_mode in ("ED", "RGB+ED"):
+    if render_mode in ("ED", "RGB+ED") and not ed_fused:
         render = torch.cat([render[..., :-1], render[..., -1:] / alpha.clamp(min=1e-10)], dim=-1)
     if normalise_expected_depth:
         exp_depth = exp_depth / alpha.clamp(min=1e-10)

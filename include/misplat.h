@@ -64,6 +64,8 @@ typedef struct misplat_params {
     float plane_eps;      /* 1e-6 */
     int32_t ppl_fwd;      /* pixels per lane of the compositing kernels: 1, 2 or 4 (0 = default); */
     int32_t ppl_bwd;      /* a tile is covered by 4/ppl independent wavefronts ("bands")          */
+    int32_t ed_slot;      /* colour channel (0..3) the compositing kernels divide by max(alpha,1e-10)
+                             (the "ED" of render_mode RGB+ED / ED, rade_gs_model.py:237), or -1     */
 } misplat_params;
 
 /* ---- a2.1 projection: fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, ...)
@@ -205,9 +207,11 @@ int misplat_blend_planes(const misplat_params* p);
 int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, const float* Ks,
                       const float* grec, const int32_t* flatten_ids, const int32_t* slots_sorted,
                       const int32_t* offsets, int64_t n_isects, const float* alpha,
-                      const int32_t* last_ids, const int32_t* median_ids, const float* v_render,
-                      const float* v_alpha, const float* v_exp_depth, const float* v_med_depth,
-                      const float* v_normal, float* slab, float* slab_abs, uint8_t* slab_valid,
+                      const int32_t* last_ids, const int32_t* median_ids,
+                      const float* render /* forward output, read only if ed_slot >= 0 */,
+                      const float* v_render, const float* v_alpha, const float* v_exp_depth,
+                      const float* v_med_depth, const float* v_normal, float* slab, float* slab_abs,
+                      uint8_t* slab_valid,
                       misplat_stream_t stream);
 /* Same backward with the rows added straight into v_grec[C*N,16] / v_abs[C*N,2] (or NULL) by
  * no-return fp32 atomics of 64 contiguous bytes: no slab and no reduce pass, but the sums depend on
@@ -215,8 +219,8 @@ int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, const float* K
 int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks,
                              const float* grec, const int32_t* flatten_ids, const int32_t* offsets,
                              int64_t n_isects, const float* alpha, const int32_t* last_ids,
-                             const int32_t* median_ids, const float* v_render, const float* v_alpha,
-                             const float* v_exp_depth, const float* v_med_depth,
+                             const int32_t* median_ids, const float* render, const float* v_render,
+                             const float* v_alpha, const float* v_exp_depth, const float* v_med_depth,
                              const float* v_normal, float* v_grec, float* v_abs,
                              misplat_stream_t stream);
 /* v_grec[r] = sum of the VALID slab rows of Gaussian row r (slots cum[r] .. cum[r]+tiles_per_gauss[r],
