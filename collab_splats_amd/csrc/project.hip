@@ -579,8 +579,8 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
 // min(D, 4) entries of colors[(cam,) g, D] are copied.  depth_channel: channel n_color = depth.
 // SH coefficients ([N, K, 3], 12 K bytes per Gaussian) are staged through LDS in whole
 // coalesced lines and read back at a stride of 3K+1 floats (conflict-free).
-template <bool BWD>
-__global__ __launch_bounds__(256) void color_sh_kernel(
+template <bool BWD, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void color_sh_kernel(
     misplat_params P, int K, int deg, int depth_channel, const float* __restrict__ means,
     const float* __restrict__ viewmats, const float* __restrict__ coeffs,
     const int32_t* __restrict__ radii, const float* __restrict__ depths, float* __restrict__ grec,
@@ -588,12 +588,12 @@ __global__ __launch_bounds__(256) void color_sh_kernel(
     extern __shared__ float lds[];
     const int row = 3 * K, stride = row + 1;
     const int nb = (deg + 1) * (deg + 1);
-    const int n_blocks = (P.n_gauss + 255) / 256;
+    const int n_blocks = (P.n_gauss + BLOCK - 1) / BLOCK;
     for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
-        const int g0 = blk * 256;
-        const int cnt = min(256, P.n_gauss - g0);
+        const int g0 = blk * BLOCK;
+        const int cnt = min(BLOCK, P.n_gauss - g0);
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt * row; e += 256) {
+        for (int e = threadIdx.x; e < cnt * row; e += BLOCK) {
             const int t = e / row, k = e - t * row;
             lds[t * stride + k] = coeffs[(size_t)g0 * row + e];
         }
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(256) void color_sh_kernel(
                 v_means_dir[3 * g] = vmd[0]; v_means_dir[3 * g + 1] = vmd[1]; v_means_dir[3 * g + 2] = vmd[2];
             }
             __syncthreads();
-            for (int e = threadIdx.x; e < cnt * row; e += 256) {
+            for (int e = threadIdx.x; e < cnt * row; e += BLOCK) {
                 const int tt = e / row, k = e - tt * row;
                 v_coeffs[(size_t)g0 * row + e] = lds[tt * stride + k];
             }
@@ -842,9 +842,10 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
     hipStream_t s = (hipStream_t)stream;
     if (sh_degree >= 0) {
         if (sh_degree > 3 || K_or_D < (sh_degree + 1) * (sh_degree + 1) || K_or_D > 16 || n_color != 3) return MISPLAT_EINVAL;
-        const int n_blocks = (p->n_gauss + 255) / 256;
-        const size_t lds = (size_t)256 * (3 * K_or_D + 1) * sizeof(float);
-        hipLaunchKernelGGL((color_sh_kernel<false>), dim3(n_blocks < 4096 ? n_blocks : 4096), dim3(256), lds, s, *p,
+        constexpr int BLK = 64;
+        const int n_blocks = (p->n_gauss + BLK - 1) / BLK;
+        const size_t lds = (size_t)BLK * (3 * K_or_D + 1) * sizeof(float);
+        hipLaunchKernelGGL((color_sh_kernel<false, BLK>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK), lds, s, *p,
                            K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, radii, depths, grec,
                            (const float*)nullptr, (float*)nullptr, (float*)nullptr);
     } else {
@@ -865,9 +866,10 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
     hipStream_t s = (hipStream_t)stream;
     if (sh_degree >= 0) {
         if (sh_degree > 3 || K_or_D < (sh_degree + 1) * (sh_degree + 1) || K_or_D > 16 || !v_means_dir) return MISPLAT_EINVAL;
-        const int n_blocks = (p->n_gauss + 255) / 256;
-        const size_t lds = (size_t)256 * (3 * K_or_D + 1) * sizeof(float);
-        hipLaunchKernelGGL((color_sh_kernel<true>), dim3(n_blocks < 4096 ? n_blocks : 4096), dim3(256), lds, s, *p,
+        constexpr int BLK = 64;
+        const int n_blocks = (p->n_gauss + BLK - 1) / BLK;
+        const size_t lds = (size_t)BLK * (3 * K_or_D + 1) * sizeof(float);
+        hipLaunchKernelGGL((color_sh_kernel<true, BLK>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK), lds, s, *p,
                            K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, radii, (const float*)nullptr,
                            (float*)nullptr, v_grec, v_coeffs_or_colors, v_means_dir);
     } else {

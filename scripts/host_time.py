@@ -1,0 +1,26 @@
+import sys, time; sys.path.insert(0, '.')
+import torch
+from collab_splats_amd.rendering import rasterization
+from collab_splats_amd.synthetic import random_scene
+N, W, H = 1_000_000, 1920, 1080
+sc = random_scene(N, W, H, seed=42); dev = 'cuda'
+params = {k: sc[k].to(dev).requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+V, K = sc["viewmats"].to(dev), sc["Ks"].to(dev)
+g = torch.Generator().manual_seed(7)
+ups = [torch.rand(s, generator=g).to(dev) for s in ((1, H, W, 4), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3))]
+def step():
+    for p in params.values(): p.grad = None
+    out = rasterization(params["means"], params["quats"], torch.exp(params["log_scales"]), torch.sigmoid(params["opacity_logits"]), params["sh"], V, K, W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True)
+    t1 = time.perf_counter()
+    torch.autograd.backward(list(out[:5]), ups)
+    return t1
+for _ in range(5): step()
+torch.cuda.synchronize()
+K_ = 20
+t0 = time.perf_counter(); tf = 0
+for _ in range(K_):
+    ts = time.perf_counter(); t1 = step(); tf += t1 - ts
+t_enq = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print(f"host enqueue {t_enq/K_*1e3:.3f} ms/step (fwd part {tf/K_*1e3:.3f}), total {t_all/K_*1e3:.3f} ms/step")
