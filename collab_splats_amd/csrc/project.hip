@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
 // min(D, 4) entries of colors[(cam,) g, D] are copied.  depth_channel: channel n_color = depth.
 // SH coefficients ([N, K, 3], 12 K bytes per Gaussian) are staged through LDS in whole
 // coalesced lines and read back at a stride of 3K+1 floats (conflict-free).
-template <bool BWD, int BLOCK>
+template <bool BWD, int BLOCK, bool MULTI>
 __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
     misplat_params P, int K, int deg, int depth_channel, const float* __restrict__ means,
     const float* __restrict__ viewmats, const float* __restrict__ coeffs,
@@ -600,14 +600,15 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
         __syncthreads();
         const int t = threadIdx.x;
         const int g = g0 + t;
-        float acc[48];
+        float acc[MULTI ? 48 : 1];           // cross-camera accumulators (one camera: written in place)
         float vmd[3] = {0.f, 0.f, 0.f};
-        if (BWD) {
+        if (BWD && MULTI) {
 #pragma unroll
             for (int k = 0; k < 48; k++) acc[k] = 0.f;
         }
+        bool wrote = false;
         if (t < cnt) {
-            const float* cf = lds + t * stride;
+            float* cf = lds + t * stride;
             for (int ci = 0; ci < P.n_cams; ci++) {
                 const int64_t idx = (int64_t)ci * P.n_gauss + g;
                 const bool vis = radii[2 * idx] > 0 || radii[2 * idx + 1] > 0;
@@ -636,10 +637,15 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
 #pragma unroll
                         for (int k = 0; k < 16; k++)
                             if (k < nb) {
-                                acc[3 * k] += b[k] * vc0; acc[3 * k + 1] += b[k] * vc1; acc[3 * k + 2] += b[k] * vc2;
                                 const float s = cf[3 * k] * vc0 + cf[3 * k + 1] * vc1 + cf[3 * k + 2] * vc2;
                                 vd0 += bx[k] * s; vd1 += by[k] * s; vd2 += bz[k] * s;
+                                if (MULTI) {
+                                    acc[3 * k] += b[k] * vc0; acc[3 * k + 1] += b[k] * vc1; acc[3 * k + 2] += b[k] * vc2;
+                                } else {      // the coefficient is dead now: its slot takes the gradient
+                                    cf[3 * k] = b[k] * vc0; cf[3 * k + 1] = b[k] * vc1; cf[3 * k + 2] = b[k] * vc2;
+                                }
                             }
+                        wrote = true;
                         const float dot = x * vd0 + y * vd1 + z * vd2;
                         vmd[0] += (vd0 - x * dot) * inv; vmd[1] += (vd1 - y * dot) * inv; vmd[2] += (vd2 - z * dot) * inv;
                     }
@@ -655,17 +661,21 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
         }
         if (BWD) {
             // gradient rows back through LDS so the global stores are whole coalesced lines
-            __syncthreads();
             if (t < cnt) {
-                float* cf = lds + t * stride;
+                float* cf = lds + t * stride;     // own row only: no barrier needed before writing it
+                if (MULTI) {
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    if (k < K) {
-                        const bool on = k < nb;
-                        cf[3 * k] = on ? acc[3 * k] : 0.f; cf[3 * k + 1] = on ? acc[3 * k + 1] : 0.f; cf[3 * k + 2] = on ? acc[3 * k + 2] : 0.f;
+                    for (int k = 0; k < 16; k++) {
+                        if (k < K) {
+                            const bool on = k < nb;
+                            cf[3 * k] = on ? acc[3 * k] : 0.f; cf[3 * k + 1] = on ? acc[3 * k + 1] : 0.f; cf[3 * k + 2] = on ? acc[3 * k + 2] : 0.f;
+                        }
                     }
+                    for (int k = 16; k < K; k++) { cf[3 * k] = 0.f; cf[3 * k + 1] = 0.f; cf[3 * k + 2] = 0.f; }
+                } else {
+                    // rows of culled Gaussians and the coefficients above the active degree get zeros
+                    for (int k = wrote ? nb : 0; k < K; k++) { cf[3 * k] = 0.f; cf[3 * k + 1] = 0.f; cf[3 * k + 2] = 0.f; }
                 }
-                for (int k = 16; k < K; k++) { cf[3 * k] = 0.f; cf[3 * k + 1] = 0.f; cf[3 * k + 2] = 0.f; }
                 v_means_dir[3 * g] = vmd[0]; v_means_dir[3 * g + 1] = vmd[1]; v_means_dir[3 * g + 2] = vmd[2];
             }
             __syncthreads();
@@ -845,7 +855,7 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
         constexpr int BLK = 64;
         const int n_blocks = (p->n_gauss + BLK - 1) / BLK;
         const size_t lds = (size_t)BLK * (3 * K_or_D + 1) * sizeof(float);
-        hipLaunchKernelGGL((color_sh_kernel<false, BLK>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK), lds, s, *p,
+        hipLaunchKernelGGL((color_sh_kernel<false, BLK, false>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK), lds, s, *p,
                            K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, radii, depths, grec,
                            (const float*)nullptr, (float*)nullptr, (float*)nullptr);
     } else {
@@ -869,9 +879,14 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
         constexpr int BLK = 64;
         const int n_blocks = (p->n_gauss + BLK - 1) / BLK;
         const size_t lds = (size_t)BLK * (3 * K_or_D + 1) * sizeof(float);
-        hipLaunchKernelGGL((color_sh_kernel<true, BLK>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK), lds, s, *p,
-                           K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, radii, (const float*)nullptr,
-                           (float*)nullptr, v_grec, v_coeffs_or_colors, v_means_dir);
+        if (p->n_cams > 1)
+            hipLaunchKernelGGL((color_sh_kernel<true, BLK, true>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK),
+                               lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, radii,
+                               (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_means_dir);
+        else
+            hipLaunchKernelGGL((color_sh_kernel<true, BLK, false>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK),
+                               lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, radii,
+                               (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_means_dir);
     } else {
         int64_t rows = per_cam ? (int64_t)p->n_gauss * p->n_cams : p->n_gauss;
         hipLaunchKernelGGL(color_copy_bwd_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, s, *p, K_or_D, n_color,
