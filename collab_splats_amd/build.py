@@ -27,6 +27,7 @@ SOURCES = {
     "project.hip": ["-ffp-contract=off"],
     "binning.hip": [],
     "blend.hip": [],
+    "epilogue.hip": [],
 }
 
 

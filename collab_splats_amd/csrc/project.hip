@@ -582,9 +582,13 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
 template <bool BWD, int BLOCK, bool MULTI>
 __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
     misplat_params P, int K, int deg, int depth_channel, const float* __restrict__ means,
-    const float* __restrict__ viewmats, const float* __restrict__ coeffs,
+    const float* __restrict__ viewmats, const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest,
     const int32_t* __restrict__ radii, const float* __restrict__ depths, float* __restrict__ grec,
-    const float* __restrict__ v_grec, float* __restrict__ v_coeffs, float* __restrict__ v_means_dir) {
+    const float* __restrict__ v_grec, float* __restrict__ v_coeffs, float* __restrict__ v_coeffs_rest,
+    float* __restrict__ v_means_dir) {
+    // coeffs_rest == NULL: coeffs is [N,K,3]; else coeffs is features_dc [N,3] and coeffs_rest is
+    // features_rest [N,K-1,3] (the two parameter tensors of rade_gs_model.py:119-120, read in place
+    // instead of through the per-step torch.cat of :128-130)
     extern __shared__ float lds[];
     const int row = 3 * K, stride = row + 1;
     const int nb = (deg + 1) * (deg + 1);
@@ -593,9 +597,21 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
         const int g0 = blk * BLOCK;
         const int cnt = min(BLOCK, P.n_gauss - g0);
         __syncthreads();
-        for (int e = threadIdx.x; e < cnt * row; e += BLOCK) {
-            const int t = e / row, k = e - t * row;
-            lds[t * stride + k] = coeffs[(size_t)g0 * row + e];
+        if (coeffs_rest == nullptr) {
+            const float* src = coeffs + (size_t)g0 * row;
+            for (int e = threadIdx.x; e < cnt * row; e += BLOCK) {
+                const int t = e / row, k = e - t * row;
+                lds[t * stride + k] = src[e];
+            }
+        } else {
+            const float* src_dc = coeffs + (size_t)g0 * 3;
+            const float* src_rest = coeffs_rest + (size_t)g0 * (row - 3);
+            for (int e = threadIdx.x; e < cnt * 3; e += BLOCK) lds[(e / 3) * stride + (e % 3)] = src_dc[e];
+            const int rrow = row - 3;
+            for (int e = threadIdx.x; e < cnt * rrow; e += BLOCK) {
+                const int t = e / rrow, k = e - t * rrow;
+                lds[t * stride + 3 + k] = src_rest[e];
+            }
         }
         __syncthreads();
         const int t = threadIdx.x;
@@ -679,9 +695,21 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
                 v_means_dir[3 * g] = vmd[0]; v_means_dir[3 * g + 1] = vmd[1]; v_means_dir[3 * g + 2] = vmd[2];
             }
             __syncthreads();
-            for (int e = threadIdx.x; e < cnt * row; e += BLOCK) {
-                const int tt = e / row, k = e - tt * row;
-                v_coeffs[(size_t)g0 * row + e] = lds[tt * stride + k];
+            if (v_coeffs_rest == nullptr) {
+                float* dst = v_coeffs + (size_t)g0 * row;
+                for (int e = threadIdx.x; e < cnt * row; e += BLOCK) {
+                    const int tt = e / row, k = e - tt * row;
+                    dst[e] = lds[tt * stride + k];
+                }
+            } else {
+                float* dst_dc = v_coeffs + (size_t)g0 * 3;
+                float* dst_rest = v_coeffs_rest + (size_t)g0 * (row - 3);
+                for (int e = threadIdx.x; e < cnt * 3; e += BLOCK) dst_dc[e] = lds[(e / 3) * stride + (e % 3)];
+                const int rrow = row - 3;
+                for (int e = threadIdx.x; e < cnt * rrow; e += BLOCK) {
+                    const int tt = e / rrow, k = e - tt * rrow;
+                    dst_rest[e] = lds[tt * stride + 3 + k];
+                }
             }
         }
     }
@@ -844,8 +872,9 @@ extern "C" int misplat_project_pack_fwd(const misplat_params* p, const float* me
 
 extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
                                  int32_t per_cam, int32_t depth_channel, const float* means,
-                                 const float* viewmats, const float* coeffs_or_colors, const int32_t* radii,
-                                 const float* depths, float* grec, misplat_stream_t stream) {
+                                 const float* viewmats, const float* coeffs_or_colors, const float* coeffs_rest,
+                                 const int32_t* radii, const float* depths, float* grec,
+                                 misplat_stream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
     if (n_color < 0 || n_color + (depth_channel ? 1 : 0) > 4) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
@@ -856,8 +885,8 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
         const int n_blocks = (p->n_gauss + BLK - 1) / BLK;
         const size_t lds = (size_t)BLK * (3 * K_or_D + 1) * sizeof(float);
         hipLaunchKernelGGL((color_sh_kernel<false, BLK, false>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK), lds, s, *p,
-                           K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, radii, depths, grec,
-                           (const float*)nullptr, (float*)nullptr, (float*)nullptr);
+                           K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, coeffs_rest, radii, depths,
+                           grec, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
     } else {
         if (K_or_D < n_color) return MISPLAT_EINVAL;
         int64_t total = (int64_t)p->n_gauss * p->n_cams;
@@ -869,8 +898,9 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
 
 extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
                                  int32_t per_cam, const float* means, const float* viewmats,
-                                 const float* coeffs_or_colors, const int32_t* radii, const float* v_grec,
-                                 float* v_coeffs_or_colors, float* v_means_dir, misplat_stream_t stream) {
+                                 const float* coeffs_or_colors, const float* coeffs_rest, const int32_t* radii,
+                                 const float* v_grec, float* v_coeffs_or_colors, float* v_coeffs_rest,
+                                 float* v_means_dir, misplat_stream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1 || n_color < 0 || n_color > 4) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -881,12 +911,14 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
         const size_t lds = (size_t)BLK * (3 * K_or_D + 1) * sizeof(float);
         if (p->n_cams > 1)
             hipLaunchKernelGGL((color_sh_kernel<true, BLK, true>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK),
-                               lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, radii,
-                               (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_means_dir);
+                               lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, coeffs_rest, radii,
+                               (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_coeffs_rest,
+                               v_means_dir);
         else
             hipLaunchKernelGGL((color_sh_kernel<true, BLK, false>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK),
-                               lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, radii,
-                               (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_means_dir);
+                               lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, coeffs_rest, radii,
+                               (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_coeffs_rest,
+                               v_means_dir);
     } else {
         int64_t rows = per_cam ? (int64_t)p->n_gauss * p->n_cams : p->n_gauss;
         hipLaunchKernelGGL(color_copy_bwd_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, s, *p, K_or_D, n_color,

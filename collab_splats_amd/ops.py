@@ -352,7 +352,7 @@ class _ProjectPack(torch.autograd.Function):
     here -- the mean2d gradient arrives through ``v_means2d``)."""
 
     @staticmethod
-    def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, P: Params, sh_degree,
+    def forward(ctx, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, P: Params, sh_degree,
                 depth_channel: bool):
         lib = _lib.load()
         require_gpu(means, quats, scales, opacities, colors, viewmats, Ks)
@@ -367,7 +367,8 @@ class _ProjectPack(torch.autograd.Function):
                                            ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
                                            ptr(comps), ptr(grec), stream_ptr()), "misplat_project_pack_fwd")
         if sh_degree is not None:
-            deg, kd, n_color, per_cam = int(sh_degree), colors.shape[1], 3, 0
+            kd = colors.shape[1] if colors_rest is None else 1 + colors_rest.shape[1]
+            deg, n_color, per_cam = int(sh_degree), 3, 0
         else:
             deg, kd, per_cam = -1, colors.shape[-1], int(colors.dim() == 3)
             n_color = kd
@@ -382,35 +383,40 @@ class _ProjectPack(torch.autograd.Function):
         with torch.cuda.stream(side):
             check(lib.misplat_color_fwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
                                         C.c_int32(per_cam), C.c_int32(int(depth_channel)), ptr(means), ptr(viewmats),
-                                        ptr(colors), ptr(radii), ptr(depths), ptr(grec), stream_ptr()),
-                  "misplat_color_fwd")
+                                        ptr(colors), ptr(colors_rest), ptr(radii), ptr(depths), ptr(grec),
+                                        stream_ptr()), "misplat_color_fwd")
         ctx.P, ctx.color_args = P, (deg, kd, n_color, per_cam)
         ctx.depth_slot = 12 + n_color if depth_channel else -1
-        ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps)
+        ctx.has_rest = colors_rest is not None
+        ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps,
+                              colors_rest if colors_rest is not None else colors)
         ctx.mark_non_differentiable(radii, depths, comps)
         return radii, means2d, depths, comps, grec
 
     @staticmethod
     def backward(ctx, _v_radii, v_means2d, _v_depths, _v_comps, v_grec):
         lib = _lib.load()
-        means, quats, scales, opacities, colors, viewmats, Ks, radii, comps = ctx.saved_tensors
+        means, quats, scales, opacities, colors, viewmats, Ks, radii, comps, colors_rest = ctx.saved_tensors
+        if not ctx.has_rest:
+            colors_rest = None
         P = ctx.P
         deg, kd, n_color, per_cam = ctx.color_args
         v_means2d, v_grec = _c(v_means2d), _c(v_grec)
         v_colors = torch.empty_like(colors)
+        v_colors_rest = torch.empty_like(colors_rest) if colors_rest is not None else None
         v_means_dir = torch.empty_like(means) if deg >= 0 else None
         cur = torch.cuda.current_stream()
         side = _side_stream(means.device) if OVERLAP else cur
         if side is not cur:
             side.wait_stream(cur)
-            for t in (v_grec, v_colors, v_means_dir, means, viewmats, colors, radii):
+            for t in (v_grec, v_colors, v_colors_rest, v_means_dir, means, viewmats, colors, colors_rest, radii):
                 if t is not None:
                     t.record_stream(side)
         with torch.cuda.stream(side):
             check(lib.misplat_color_bwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
-                                        C.c_int32(per_cam), ptr(means), ptr(viewmats), ptr(colors), ptr(radii),
-                                        ptr(v_grec), ptr(v_colors), ptr(v_means_dir), stream_ptr()),
-                  "misplat_color_bwd")
+                                        C.c_int32(per_cam), ptr(means), ptr(viewmats), ptr(colors), ptr(colors_rest),
+                                        ptr(radii), ptr(v_grec), ptr(v_colors), ptr(v_colors_rest), ptr(v_means_dir),
+                                        stream_ptr()), "misplat_color_bwd")
         v_means, v_quats = torch.empty_like(means), torch.empty_like(quats)
         v_scales, v_opac = torch.empty_like(scales), torch.empty_like(opacities)
         fused_dir = v_means_dir if side is cur else None        # overlapped: add the SH direction term afterwards
@@ -423,13 +429,19 @@ class _ProjectPack(torch.autograd.Function):
             cur.wait_stream(side)
             if v_means_dir is not None:
                 v_means.add_(v_means_dir)
-        return v_means, v_quats, v_scales, v_opac, v_colors, None, None, None, None, None
+        return v_means, v_quats, v_scales, v_opac, v_colors, v_colors_rest, None, None, None, None, None
 
 
 def project_pack(means, quats, scales, opacities, colors, viewmats, Ks, P: Params, sh_degree, depth_channel):
+    """``colors`` may be a pair (features_dc [N,3], features_rest [N,K-1,3]) when ``sh_degree`` is given."""
+    rest = None
+    if isinstance(colors, (tuple, list)):
+        colors, rest = colors
+        rest = _f32(rest, "features_rest")
     args = [_f32(t, n) for t, n in ((means, "means"), (quats, "quats"), (scales, "scales"),
-                                    (opacities, "opacities"), (colors, "colors"), (viewmats, "viewmats"), (Ks, "Ks"))]
-    return _ProjectPack.apply(*args, P, sh_degree, bool(depth_channel))
+                                    (opacities, "opacities"), (colors, "colors"))]
+    return _ProjectPack.apply(*args, rest, _f32(viewmats, "viewmats"), _f32(Ks, "Ks"), P, sh_degree,
+                              bool(depth_channel))
 
 
 class _BlendPacked(torch.autograd.Function):
@@ -550,3 +562,53 @@ def depth_normal(exp_depth: Tensor, med_depth: Tensor, n_render: Tensor, fx: flo
     -> (normals2 [2,H,W,3], err [2,H,W])."""
     return _DepthNormal.apply(_f32(exp_depth, "exp_depth"), _f32(med_depth, "med_depth"),
                               _f32(n_render, "n_render"), float(fx), float(fy))
+
+
+# ----------------------------------------------------------------------------- get_outputs epilogue (a3)
+
+class _Outputs(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, render, alpha, exp_depth, med_depth, exp_normal, bg, want_depth_im: bool):
+        lib = _lib.load()
+        require_gpu(render, alpha, exp_depth, med_depth, exp_normal)
+        cd = render.shape[-1]
+        n_pix = alpha.numel()
+        dev = render.device
+        f = dict(device=dev, dtype=torch.float32)
+        rgb = torch.empty(alpha.shape[:-1] + (3,), **f)
+        depth, median = torch.empty_like(alpha), torch.empty_like(alpha)
+        normals = torch.empty_like(exp_normal)
+        depth_im = torch.empty_like(alpha) if want_depth_im else None
+        maxes = torch.empty(4, **f)
+        bg_c = (C.c_float * 3)(*[float(b) for b in bg])
+        check(lib.misplat_outputs_fwd(C.c_int64(n_pix), C.c_int32(cd), bg_c, ptr(render), ptr(alpha), ptr(exp_depth),
+                                      ptr(med_depth), ptr(exp_normal), ptr(maxes), ptr(rgb), ptr(depth), ptr(median),
+                                      ptr(normals), ptr(depth_im), stream_ptr()), "misplat_outputs_fwd")
+        ctx.save_for_backward(render, alpha)
+        ctx.bg, ctx.cd, ctx.want_depth_im = bg_c, cd, want_depth_im
+        if want_depth_im:
+            return rgb, depth, median, normals, depth_im
+        return rgb, depth, median, normals
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_depth, v_median, v_normals, v_depth_im=None):
+        lib = _lib.load()
+        render, alpha = ctx.saved_tensors
+        v_render = torch.empty_like(render)
+        v_alpha, v_ed, v_md = torch.empty_like(alpha), torch.empty_like(alpha), torch.empty_like(alpha)
+        v_nr = torch.empty_like(v_normals)
+        ups = [_c(t) for t in (v_rgb, v_depth, v_median, v_normals)]
+        vdi = _c(v_depth_im) if ctx.want_depth_im else None
+        check(lib.misplat_outputs_bwd(C.c_int64(alpha.numel()), C.c_int32(ctx.cd), ctx.bg, ptr(render), ptr(alpha),
+                                      *[ptr(t) for t in ups], ptr(vdi), ptr(v_render), ptr(v_alpha), ptr(v_ed),
+                                      ptr(v_md), ptr(v_nr), stream_ptr()), "misplat_outputs_bwd")
+        return v_render, v_alpha, v_ed, v_md, v_nr, None, None
+
+
+def outputs_epilogue(render, alpha, exp_depth, med_depth, exp_normal, background, want_depth_im: bool):
+    """rade_gs_model.py:221-254 in three kernels.  ``background``: 3 Python floats."""
+    if render.shape[-1] not in (3, 4) or (want_depth_im and render.shape[-1] != 4):
+        raise ValueError("outputs_epilogue needs render[..., 3] (RGB) or [..., 4] (RGB+ED)")
+    args = [_f32(t, n) for t, n in ((render, "render"), (alpha, "alpha"), (exp_depth, "expected_depths"),
+                                    (med_depth, "median_depths"), (exp_normal, "expected_normals"))]
+    return _Outputs.apply(*args, tuple(float(b) for b in background), bool(want_depth_im))

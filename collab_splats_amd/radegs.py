@@ -180,11 +180,14 @@ class RadegsModel(nn.Module):
         rots = build_rotation(self.quats)
         return F.normalize(torch.bmm(rots, axis[:, :, None]).squeeze(-1), dim=1)
 
-    def _get_background_color(self) -> Tensor:
+    def _background_list(self) -> List[float]:
         c = {"black": [0.0, 0.0, 0.0], "white": [1.0, 1.0, 1.0]}.get(self.config.background_color)
         if c is None:
             raise ValueError(f"Unknown background_color: {self.config.background_color}")
-        return torch.tensor(c, device=self.device)
+        return c
+
+    def _get_background_color(self) -> Tensor:
+        return torch.tensor(self._background_list(), device=self.device)
 
     def _get_camera_parameters(self, camera) -> Dict:
         return camera_parameters(camera, self.device)
@@ -211,7 +214,8 @@ class RadegsModel(nn.Module):
         """rade_gs_model.py:401-467."""
         if visible_mask is not None:
             means, quats, scales = means[visible_mask], quats[visible_mask], scales[visible_mask]
-            opacities, colors = opacities[visible_mask], colors[visible_mask]
+            opacities = opacities[visible_mask]
+            colors = tuple(c[visible_mask] for c in colors) if isinstance(colors, tuple) else colors[visible_mask]
         return rasterization(
             means=means, quats=quats, scales=torch.exp(scales),
             opacities=torch.sigmoid(opacities.squeeze(-1)), colors=colors,
@@ -229,7 +233,9 @@ class RadegsModel(nn.Module):
             return {}
         if self.training:
             assert camera.shape[0] == 1, "Only one camera at a time"
-        colors_crop = torch.cat((self.features_dc[:, None, :], self.features_rest), dim=1)
+        # the reference concatenates the two colour parameters every step (rade_gs_model.py:128-130:
+        # a 192 B/Gaussian copy + its backward split); the colour kernels read them in place instead
+        colors_crop = (self.features_dc, self.features_rest)
         W, H = int(camera.width.item()), int(camera.height.item())
         self.last_size = (H, W)
         camera_params = self._get_camera_parameters(camera)
@@ -240,7 +246,7 @@ class RadegsModel(nn.Module):
         if self.config.sh_degree > 0:
             sh_degree_to_use = min(self.step // self.config.sh_degree_interval, self.config.sh_degree)
         else:
-            colors_crop = torch.sigmoid(colors_crop).squeeze(1)
+            colors_crop = torch.sigmoid(self.features_dc)               # [N, 1, 3] -> [N, 3]  (:163)
             sh_degree_to_use = None
 
         render, alpha, expected_depths, median_depths, expected_normals, self.info = self._render(
@@ -262,19 +268,16 @@ class RadegsModel(nn.Module):
             # entries are unused under the same condition -- emit the intended [2, H, W]
             normal_error_map = torch.zeros(2, H, W, device=expected_normals.device)
 
-        normals = (expected_normals + 1) / 2
+        # a3: clamp / background / (n+1)/2 / where(alpha > 0, x, x.detach().max()) -- rade_gs_model.py:221-254,
+        # fused into one reduction + one elementwise kernel (and one kernel backward)
+        bg_list = self._background_list()
         background = self._get_background_color()
-        rgb = torch.clamp(render[:, ..., :3] + (1 - alpha) * background, 0.0, 1.0)
-        if render_mode == "RGB+ED":
-            depth_im = render[:, ..., 3:4]
-            depth_im = torch.where(alpha > 0, depth_im, depth_im.detach().max()).squeeze(0)
-        else:
-            depth_im = None
+        want_depth_im = render_mode == "RGB+ED"
+        ep = ops.outputs_epilogue(render, alpha, expected_depths, median_depths, expected_normals, bg_list, want_depth_im)
+        rgb, expected_depths, median_depths, normals = ep[0], ep[1], ep[2], ep[3]
+        depth_im = ep[4].squeeze(0) if want_depth_im else None
         if background.shape[0] == 3 and not self.training:
             background = background.expand(H, W, 3)
-        expected_depths = torch.where(alpha > 0, expected_depths, expected_depths.detach().max())
-        median_depths = torch.where(alpha > 0, median_depths, median_depths.detach().max())
-        normals = torch.where(alpha > 0, normals, normals.detach().max())
         return {
             "rgb": rgb.squeeze(0), "depth": expected_depths.squeeze(0), "median_depth": median_depths.squeeze(0),
             "depth_im": depth_im, "accumulation": alpha.squeeze(0), "normals": normals.squeeze(0),

@@ -81,7 +81,15 @@ def rasterization(
     assert opacities.shape == (N,), opacities.shape
     assert viewmats.shape == (Cn, 4, 4), viewmats.shape
     assert Ks.shape == (Cn, 3, 3), Ks.shape
-    if sh_degree is None:
+    split_sh = isinstance(colors, (tuple, list))
+    if split_sh:
+        # extension: (features_dc [N,3], features_rest [N,K-1,3]) -- the reference's two colour parameters
+        # (rade_gs_model.py:119-120) consumed in place, without its per-step torch.cat (:128-130)
+        assert sh_degree is not None and len(colors) == 2, "a (features_dc, features_rest) pair needs sh_degree"
+        dc, rest = colors
+        assert dc.shape == (N, 3) and rest.dim() == 3 and rest.shape[0] == N and rest.shape[2] == 3, (dc.shape, rest.shape)
+        assert (sh_degree + 1) ** 2 <= 1 + rest.shape[1], rest.shape
+    elif sh_degree is None:
         assert (colors.dim() == 2 and colors.shape[0] == N) or (colors.dim() == 3 and colors.shape[:2] == (Cn, N)), colors.shape
     else:
         assert colors.dim() == 3 and colors.shape[0] == N and colors.shape[2] == 3, colors.shape
@@ -95,7 +103,10 @@ def rasterization(
 
     depth_channel = render_mode in ("RGB+D", "RGB+ED", "D", "ED")
     n_user = 0 if render_mode in ("D", "ED") else (3 if sh_degree is not None else colors.shape[-1])
-    fused = n_user + int(depth_channel) <= 4 and (sh_degree is None or colors.shape[1] <= 16)
+    n_sh = (1 + colors[1].shape[1]) if split_sh else (colors.shape[1] if sh_degree is not None else 0)
+    fused = n_user + int(depth_channel) <= 4 and n_sh <= 16
+    if split_sh and not fused:
+        colors = torch.cat((colors[0][:, None, :], colors[1]), dim=1)
     # fused path: the kernels divide the depth channel by max(alpha, 1e-10) themselves ("ED")
     ed_fused = fused and render_mode in ("ED", "RGB+ED")
     P = make_params(N, Cn, width, height, tile_size=tile_size, antialiased=aa,

@@ -114,15 +114,19 @@ int misplat_project_pack_fwd(const misplat_params* p, const float* means, const 
                              const float* scales, const float* opacities, const float* viewmats,
                              const float* Ks, int32_t* radii, float* means2d, float* depths,
                              float* compensations, float* grec, misplat_stream_t stream);
+/* coeffs_rest (SH only, may be NULL): when given, coeffs_or_colors is features_dc[N,3] and
+ * coeffs_rest is features_rest[N,K-1,3] -- the reference's two parameter tensors
+ * (rade_gs_model.py:119-120) read in place instead of through its per-step torch.cat (:128-130);
+ * v_coeffs_rest is the matching gradient output. */
 int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
                       int32_t per_cam, int32_t depth_channel, const float* means,
-                      const float* viewmats, const float* coeffs_or_colors, const int32_t* radii,
-                      const float* depths, float* grec, misplat_stream_t stream);
+                      const float* viewmats, const float* coeffs_or_colors, const float* coeffs_rest,
+                      const int32_t* radii, const float* depths, float* grec, misplat_stream_t stream);
 int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
                       int32_t per_cam, const float* means, const float* viewmats,
-                      const float* coeffs_or_colors, const int32_t* radii, const float* v_grec,
-                      float* v_coeffs_or_colors, float* v_means_dir /*[N,3], SH only*/,
-                      misplat_stream_t stream);
+                      const float* coeffs_or_colors, const float* coeffs_rest, const int32_t* radii,
+                      const float* v_grec, float* v_coeffs_or_colors, float* v_coeffs_rest,
+                      float* v_means_dir /*[N,3], SH only*/, misplat_stream_t stream);
 /* depth_slot: 12..15 = record slot carrying the depth channel, -1 = none.  v_means_dir may be
  * NULL.  Outputs v_means[N,3] v_quats[N,4] v_scales[N,3] v_opacities[N], summed over cameras. */
 int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_slot, const float* means,
@@ -244,6 +248,24 @@ int misplat_depth_normal_bwd(int32_t width, int32_t height, float fx, float fy,
                              const float* n_render, const float* v_normals2 /*or NULL*/,
                              const float* v_err /*or NULL*/, float* v_exp_depth,
                              float* v_med_depth, float* v_n_render, misplat_stream_t stream);
+
+/* ---- a3 get_outputs post-processing (rade_gs_model.py:221-254), one pixel = one image element
+ * (C = 1).  background3_host: 3 floats in HOST memory.  maxes4: 4-float device scratch receiving
+ * the un-masked maxima of expected depth, median depth, (normal+1)/2 and render[...,3].
+ *   rgb = clamp(render[:3] + (1-alpha)*bg, 0, 1); depth/median_depth/normals/depth_im =
+ *   where(alpha > 0, x, max(x)) with normals = (expected_normals+1)/2; depth_im (or NULL) needs
+ *   color_dim == 4.  The maxima carry no gradient (the reference detaches them). */
+int misplat_outputs_fwd(int64_t n_pix, int32_t color_dim, const float* background3_host,
+                        const float* render, const float* alpha, const float* exp_depth,
+                        const float* med_depth, const float* exp_normal, float* maxes4, float* rgb,
+                        float* depth, float* median_depth, float* normals, float* depth_im,
+                        misplat_stream_t stream);
+int misplat_outputs_bwd(int64_t n_pix, int32_t color_dim, const float* background3_host,
+                        const float* render, const float* alpha, const float* v_rgb,
+                        const float* v_depth, const float* v_median_depth, const float* v_normals,
+                        const float* v_depth_im /* or NULL */, float* v_render, float* v_alpha,
+                        float* v_exp_depth, float* v_med_depth, float* v_exp_normal,
+                        misplat_stream_t stream);
 
 /* Library identification ("misplat <version> gfx950"). */
 const char* misplat_version(void);

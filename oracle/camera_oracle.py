@@ -78,3 +78,18 @@ def build_rotation(q: torch.Tensor) -> torch.Tensor:
     return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).reshape(-1, 3, 3)
+
+
+def outputs_post(render, alpha, expected_depths, median_depths, expected_normals, background):
+    """get_outputs post-processing, restated from rade_gs_model.py:221-254 (torch, autograd).
+    render [1,H,W,3|4]; returns rgb, depth, median_depth, normals, depth_im (or None)."""
+    normals = (expected_normals + 1) / 2                                               # :221
+    rgb = torch.clamp(render[:, ..., :3] + (1 - alpha) * background, 0.0, 1.0)          # :228-229
+    depth_im = None
+    if render.shape[-1] == 4:                                                          # :236-240
+        depth_im = render[:, ..., 3:4]
+        depth_im = torch.where(alpha > 0, depth_im, depth_im.detach().max())
+    expected_depths = torch.where(alpha > 0, expected_depths, expected_depths.detach().max())   # :248-250
+    median_depths = torch.where(alpha > 0, median_depths, median_depths.detach().max())         # :251-253
+    normals = torch.where(alpha > 0, normals, normals.detach().max())                           # :254
+    return rgb, expected_depths, median_depths, normals, depth_im

@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0, '.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from collab_splats_amd.rendering import rasterization
 from collab_splats_amd.synthetic import random_scene

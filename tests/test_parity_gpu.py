@@ -192,6 +192,28 @@ def test_feature_channels_backgrounds_and_render_modes(dev, craster):
     assert len(r3) == 3 and r3[0].shape == (1, H, W, 3)
 
 
+def test_split_sh_parameters_match_concatenated(dev):
+    """colors=(features_dc, features_rest) (extension) == the reference's torch.cat path, values and gradients."""
+    from collab_splats_amd import rasterization
+    from collab_splats_amd.synthetic import random_scene
+    W, H, N = 320, 200, 6000
+    sc = random_scene(N, W, H, seed=8)
+    base = [sc["means"].to(dev), sc["quats"].to(dev), torch.exp(sc["log_scales"]).to(dev), torch.sigmoid(sc["opacity_logits"]).to(dev)]
+    dc = sc["sh"][:, 0].contiguous().to(dev).requires_grad_(True)
+    rest = sc["sh"][:, 1:].contiguous().to(dev).requires_grad_(True)
+    cat = sc["sh"].to(dev).requires_grad_(True)
+    kw = dict(sh_degree=2, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True)
+    o1 = rasterization(*base, (dc, rest), sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H, **kw)
+    o2 = rasterization(*base, cat, sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H, **kw)
+    for a, b in zip(o1[:5], o2[:5]):
+        assert torch.equal(a, b)
+    ups = [u.to(dev) for u in upstream([t.shape for t in o1[:5]], dtype=torch.float32)]
+    torch.autograd.backward(list(o1[:5]), ups)
+    torch.autograd.backward(list(o2[:5]), ups)
+    assert rel_err(dc.grad, cat.grad[:, 0]) < 1e-5 and rel_err(rest.grad, cat.grad[:, 1:]) < 1e-5
+    assert not rest.grad[:, 8:].any()                                   # coefficients above the active degree
+
+
 def test_projection_and_sh_wrappers(dev, craster):
     """fully_fused_projection 8-tuple (rade_gs_model.py:373-394) and spherical_harmonics
     (rade_features_model.py:430-438)."""
@@ -242,6 +264,33 @@ def test_depth_normal_kernel_vs_reference_goldens(dev, i):
     assert rel_err(d1.grad, g[f"dn{i}_v_d1"]) < TOL
     assert rel_err(d2.grad, g[f"dn{i}_v_d2"]) < TOL
     assert rel_err(nr.grad, g[f"dn{i}_v_nrm"]) < TOL
+
+
+@pytest.mark.parametrize("cd", [3, 4])
+def test_outputs_epilogue_vs_reference_formulas(dev, cd):
+    """Fused a3 kernels against the torch restatement of rade_gs_model.py:221-254, forward and backward."""
+    from collab_splats_amd import ops
+    from oracle import camera_oracle as co
+    H, W = 37, 53
+    g = torch.Generator().manual_seed(11)
+    alpha = torch.rand(1, H, W, 1, generator=g)
+    alpha[alpha < 0.3] = 0.0                                           # empty pixels exercise the where() branches
+    render = torch.rand(1, H, W, cd, generator=g) * 1.4 - 0.2          # some values clamp at 0 and at 1
+    ed, md = torch.rand(1, H, W, 1, generator=g) * 5, torch.rand(1, H, W, 1, generator=g) * 5
+    nr = torch.randn(1, H, W, 3, generator=g) * 0.5
+    bg = [0.2, 0.5, 0.9]
+    ref_in = [t.clone().double().requires_grad_(True) for t in (render, alpha, ed, md, nr)]
+    ref = co.outputs_post(*ref_in, torch.tensor(bg, dtype=torch.float64))
+    got_in = [t.clone().to(dev).requires_grad_(True) for t in (render, alpha, ed, md, nr)]
+    got = ops.outputs_epilogue(*got_in, bg, cd == 4)
+    n_out = 5 if cd == 4 else 4
+    ups = [torch.rand(t.shape, generator=g) for t in got[:n_out]]
+    for a, b in zip(got[:n_out], ref[:n_out]):
+        assert rel_err(a, b) < 1e-6
+    torch.autograd.backward(list(ref[:n_out]), [u.double() for u in ups])
+    torch.autograd.backward(list(got[:n_out]), [u.to(dev) for u in ups])
+    for a, b, name in zip(got_in, ref_in, ("render", "alpha", "expected_depths", "median_depths", "expected_normals")):
+        assert rel_err(a.grad, b.grad) < 1e-6, name
 
 
 def test_model_get_outputs_and_loss(dev):
