@@ -103,6 +103,7 @@ def main():
     rank, world, local = parallel.init_distributed()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    local = local % torch.cuda.device_count()      # (a 1-GPU rehearsal of N > 1 puts every rank on cuda:0)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -151,10 +152,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = parallel.max_over_ranks(dt, dev)
 
     if rank == 0:
         I = int(info["n_isects"])

@@ -26,9 +26,9 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("MISPLAT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
@@ -54,12 +54,31 @@ def unflatten_into_grads(flat: torch.Tensor, params: Sequence[torch.Tensor]) -> 
         o += n
 
 
+def _reduce_device(t: torch.Tensor) -> torch.Tensor:
+    """gloo (CPU rehearsal of the multi-rank path) cannot reduce device tensors: stage through host."""
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        return t.cpu()
+    return t
+
+
 def allreduce_gradients(params: Sequence[torch.Tensor], average: bool = False) -> torch.Tensor:
     """Sum (or mean) the gradients of the shared Gaussians over all ranks, in place."""
     flat = flatten_grads(params)
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        buf = _reduce_device(flat)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        if buf is not flat:
+            flat.copy_(buf)
         if average:
             flat /= dist.get_world_size()
     unflatten_into_grads(flat, params)
     return flat
+
+
+def max_over_ranks(value: float, device: torch.device) -> float:
+    """bench.py's max-over-ranks of the timed region."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() != "gloo" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
