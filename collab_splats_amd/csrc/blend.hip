@@ -296,8 +296,9 @@ __device__ __forceinline__ int wave_max(int v) {
 // slab[band][slot] and marked in valid[band][slot] (zeroed by the launcher).
 // Measured (1 M / 1080p, PPL 2): 4 waves/SIMD (111 VGPRs) 0.663 ms, 5 waves (96 VGPRs + 48 B
 // scratch) 0.616 ms, 6 waves (80 VGPRs + 88 B scratch) 0.711 ms.
+// PPL 4: 2 waves (172 VGPRs) 0.73 ms, 3 waves 0.655 ms, 4 waves (spills) 1.28 ms.
 template <int CD, int PPL, bool ABS, bool ATOMIC>
-__global__ __launch_bounds__(64, PPL == 2 ? 5 : 1) void blend_bwd_kernel(
+__global__ __launch_bounds__(64, PPL == 2 ? 5 : (PPL == 4 ? 3 : 1)) void blend_bwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ slots,
     const int32_t* __restrict__ offsets, int64_t n_isects, const float* __restrict__ alpha,
