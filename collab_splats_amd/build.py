@@ -28,6 +28,7 @@ SOURCES = {
     "binning.hip": [],
     "blend.hip": [],
     "epilogue.hip": [],
+    "sort.hip": [],
 }
 
 

@@ -173,7 +173,35 @@ def spherical_harmonics_raw(degree: int, dirs: Tensor, coeffs: Tensor, radii: Op
 
 # ----------------------------------------------------------------------------- binning
 
+# Ordering backend: "rocprim" = rocPRIM's radix_sort_pairs (default: 0.28 ms for both sorts at
+# 1 M / 1080p), "misplat" = the hand-written, spin-free radix sort of csrc/sort.hip (bit-identical
+# results, tests/test_parity_gpu.py; measured 0.43 ms, i.e. +0.15 ms per step -- launch/latency bound
+# at these sizes; kept as the library-free path and as the base for a onesweep-style version).
+SORT_BACKEND = os.environ.get("MISPLAT_SORT", "rocprim")
+SORT_BITS_DEPTH = int(os.environ.get("MISPLAT_SORT_BITS_DEPTH", "8"))
+SORT_BITS_TILE = int(os.environ.get("MISPLAT_SORT_BITS_TILE", "5"))
+
 _WS_CACHE: Dict[tuple, int] = {}
+
+
+def _sort32(lib, keys_in, keys_out, vals_in, vals_out, n: int, end_bit: int, bits_per_pass: int) -> None:
+    """Stable sort of (u32 key, i32 value) pairs on key bits [0, end_bit)."""
+    dev = keys_in.device
+    if SORT_BACKEND == "rocprim":
+        ws_bytes = _sort_ws_bytes(lib, "u32", n, end_bit)
+        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+        check(lib.misplat_sort32_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(keys_in), ptr(keys_out), ptr(vals_in),
+                                       ptr(vals_out), C.c_int64(n), C.c_int32(end_bit), stream_ptr()),
+              "misplat_sort32_pairs")
+        return
+    bpp = min(bits_per_pass, end_bit)
+    ws_bytes = int(lib.misplat_radix_workspace_bytes(C.c_int64(n), C.c_int32(0), C.c_int32(end_bit), C.c_int32(bpp)))
+    if ws_bytes == 0:
+        raise _lib.MisplatError("misplat_radix_workspace_bytes failed")
+    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+    check(lib.misplat_radix_sort_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(keys_in), ptr(keys_out), ptr(vals_in),
+                                       ptr(vals_out), C.c_int64(n), C.c_int32(0), C.c_int32(end_bit), C.c_int32(bpp),
+                                       stream_ptr()), "misplat_radix_sort_pairs")
 
 
 def _sort_ws_bytes(lib, kind: str, n: int, end_bit: int) -> int:
@@ -212,10 +240,7 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor) -> Dict
         dkeys_s = torch.empty_like(dkeys)
         check(lib.misplat_depth_keys32(C.byref(P), ptr(radii), ptr(depths), ptr(dkeys), ptr(ids), stream_ptr()),
               "misplat_depth_keys32")
-        ws_bytes = _sort_ws_bytes(lib, "u32", total, 32)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        check(lib.misplat_sort32_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(dkeys), ptr(dkeys_s), ptr(ids), ptr(order),
-                                       C.c_int64(total), C.c_int32(32), stream_ptr()), "misplat_sort32_pairs")
+        _sort32(lib, dkeys, dkeys_s, ids, order, total, 32, SORT_BITS_DEPTH)
     elif total > 0:
         dkeys = torch.empty(total, device=dev, dtype=torch.int64)
         dkeys_s = torch.empty_like(dkeys)
@@ -243,12 +268,8 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor) -> Dict
                                             ptr(tile_ids), ptr(slots), ptr(isect_gid), stream_ptr()),
               "misplat_tile_emit_ordered")
         tile_bits = max(1, (n_tiles - 1).bit_length())
-        ws_bytes = _sort_ws_bytes(lib, "u32", n_isects, tile_bits)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        check(lib.misplat_sort32_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(tile_ids), ptr(tile_ids_s),
-                                       ptr(slots if deterministic else isect_gid), ptr(payload_s),
-                                       C.c_int64(n_isects), C.c_int32(tile_bits), stream_ptr()),
-              "misplat_sort32_pairs")
+        _sort32(lib, tile_ids, tile_ids_s, slots if deterministic else isect_gid, payload_s, n_isects, tile_bits,
+                SORT_BITS_TILE)
     check(lib.misplat_tile_offsets32(ptr(tile_ids_s), C.c_int64(n_isects), C.c_int32(n_tiles), ptr(offsets),
                                      stream_ptr()), "misplat_tile_offsets32")
     if deterministic:

@@ -183,6 +183,16 @@ int misplat_tile_offsets32(const uint32_t* tiles_sorted, int64_t n_isects, int32
 int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, const float* depths,
                       int64_t n_isects, uint64_t* isect_ids, misplat_stream_t stream);
 
+/* Hand-written stable LSD radix sort of (uint32 key, int32 value) pairs on key bits
+ * [begin_bit, end_bit), bits_per_pass (1..11) bits per pass, three launches per pass, no
+ * inter-workgroup waiting (csrc/sort.hip).  keys_in / vals_in are not modified; the result is in
+ * keys_out / vals_out; workspace holds one ping-pong pair and the per-chunk digit counts. */
+size_t misplat_radix_workspace_bytes(int64_t n, int32_t begin_bit, int32_t end_bit, int32_t bits_per_pass);
+int misplat_radix_sort_pairs(void* workspace, size_t workspace_bytes, const uint32_t* keys_in,
+                             uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
+                             int32_t begin_bit, int32_t end_bit, int32_t bits_per_pass,
+                             misplat_stream_t stream);
+
 /* ---- a2.4 / a2.5 compositing.  Packed record per (camera, Gaussian), MISPLAT_REC floats:
  *   [0:2] mean2d  [2:5] conic  [5] opacity_eff  [6] ray_t  [7:9] ray_plane  [9:12] normal
  *   [12:16] colour channels 0..3 (unused channels zero).                         */

@@ -192,6 +192,58 @@ def test_feature_channels_backgrounds_and_render_modes(dev, craster):
     assert len(r3) == 3 and r3[0].shape == (1, H, W, 3)
 
 
+@pytest.mark.parametrize("n,end_bit,bpp", [(1, 32, 11), (63, 13, 7), (64, 8, 8), (5000, 32, 11), (100_003, 13, 7),
+                                           (1_000_000, 32, 8), (3_000_001, 13, 5), (2_500_000, 32, 11)])
+def test_hand_written_radix_sort_is_stable_and_exact(dev, n, end_bit, bpp):
+    """csrc/sort.hip against numpy's stable argsort: sorted keys AND the order of equal keys (stability)."""
+    from collab_splats_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(n)
+    hi = (1 << end_bit) if end_bit < 32 else (1 << 31)
+    keys = torch.randint(0, min(hi, 1 << 31), (n,), generator=g, dtype=torch.int64)
+    if end_bit == 32:
+        keys = keys * 2 + torch.randint(0, 2, (n,), generator=g)           # use the top bit too
+        keys[::7] = 0xFFFFFFFF                                             # the "culled" depth key
+    if n > 1000:
+        keys[: n // 3] = keys[n // 3: 2 * (n // 3)]                        # many duplicates: stability matters
+    k32 = keys.to(torch.int64).numpy().astype(np.uint32)
+    kin = torch.from_numpy(k32.view(np.int32)).to(dev)
+    vin = torch.arange(n, dtype=torch.int32, device=dev)
+    kout, vout = torch.empty_like(kin), torch.empty_like(vin)
+    ws_bytes = int(lib.misplat_radix_workspace_bytes(C.c_int64(n), C.c_int32(0), C.c_int32(end_bit), C.c_int32(bpp)))
+    assert ws_bytes > 0
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    rc = lib.misplat_radix_sort_pairs(_lib.ptr(ws), C.c_size_t(ws_bytes), _lib.ptr(kin), _lib.ptr(kout), _lib.ptr(vin),
+                                      _lib.ptr(vout), C.c_int64(n), C.c_int32(0), C.c_int32(end_bit), C.c_int32(bpp),
+                                      _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    mask = np.uint32((1 << end_bit) - 1) if end_bit < 32 else np.uint32(0xFFFFFFFF)
+    order = np.argsort(k32 & mask, kind="stable")
+    assert np.array_equal(vout.cpu().numpy(), order.astype(np.int32))
+    assert np.array_equal(kout.cpu().numpy().view(np.uint32), k32[order])
+    assert np.array_equal(kin.cpu().numpy().view(np.uint32), k32)           # input untouched
+
+
+def test_sort_backends_give_identical_bins(dev, monkeypatch):
+    """rocPRIM and the hand-written sort must produce the same tile lists (bit for bit)."""
+    from collab_splats_amd import ops, rasterization
+    from collab_splats_amd.synthetic import random_scene
+    W, H, N = 640, 360, 50_000
+    sc = random_scene(N, W, H, seed=12)
+    args = [sc["means"].to(dev), sc["quats"].to(dev), torch.exp(sc["log_scales"]).to(dev),
+            torch.sigmoid(sc["opacity_logits"]).to(dev), sc["sh"].to(dev), sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H]
+    outs = {}
+    for backend in ("rocprim", "misplat"):
+        monkeypatch.setattr(ops, "SORT_BACKEND", backend)
+        outs[backend] = rasterization(*args, sh_degree=3, render_mode="RGB+ED", return_depth_normal=True)
+    a, b = outs["rocprim"], outs["misplat"]
+    assert torch.equal(a[5]["flatten_ids"], b[5]["flatten_ids"]) and torch.equal(a[5]["isect_offsets"], b[5]["isect_offsets"])
+    assert torch.equal(a[5]["isect_ids"], b[5]["isect_ids"])
+    for x, y in zip(a[:5], b[:5]):
+        assert torch.equal(x, y)
+
+
 def test_split_sh_parameters_match_concatenated(dev):
     """colors=(features_dc, features_rest) (extension) == the reference's torch.cat path, values and gradients."""
     from collab_splats_amd import rasterization
