@@ -225,6 +225,83 @@ def test_hand_written_radix_sort_is_stable_and_exact(dev, n, end_bit, bpp):
     assert np.array_equal(kin.cpu().numpy().view(np.uint32), k32)           # input untouched
 
 
+def _compare_with_c_port(dev, craster, means, quats, scales, opac, cols, V, K, W, H, sh_degree=None, rm="RGB+ED",
+                         mode="antialiased", tol=TOL):
+    from collab_splats_amd import rasterization
+    leaves = [t.clone().to(dev).requires_grad_(True) for t in (means, quats, scales, opac, cols)]
+    out = rasterization(*leaves, V[None].to(dev), K[None].to(dev), W, H, sh_degree=sh_degree, render_mode=rm,
+                        rasterize_mode=mode, return_depth_normal=True)
+    cr = craster.CRaster(np.float32)
+    st = cr.forward(means.numpy(), quats.numpy(), scales.numpy(), opac.numpy(), cols.numpy(), V.numpy(), K.numpy(), W, H,
+                    sh_degree=sh_degree, render_mode=rm, rasterize_mode=mode)
+    assert np.array_equal(st["proj"]["radii"], out[5]["radii"][0].cpu().numpy())
+    assert np.array_equal(st["bins"]["flatten_ids"], out[5]["flatten_ids"].cpu().numpy())
+    assert np.array_equal(st["bins"]["isect_offsets"], out[5]["isect_offsets"][0].cpu().numpy())
+    fw = st["fwd"]
+    for name, got, ref in (("render", out[0], st["render"]), ("alpha", out[1], fw["alpha"]), ("exp_depth", out[2], fw["exp_depth"]),
+                           ("med_depth", out[3], fw["med_depth"]), ("normal", out[4], fw["normal"])):
+        assert_close_flips(got[0], ref, name, tol=tol)
+    ups = upstream([t.shape for t in out[:5]], dtype=torch.float32)
+    torch.autograd.backward(list(out[:5]), [u.to(dev) for u in ups])
+    gr = cr.backward(st, *[u[0].numpy() for u in ups])
+    for name, leaf in zip(("v_means", "v_quats", "v_scales", "v_opacities", "v_colors"), leaves):
+        assert torch.isfinite(leaf.grad).all(), name
+        assert_close_flips(leaf.grad, gr[name], name, tol=tol)
+    return out, st
+
+
+@pytest.mark.parametrize("W,H", [(1, 1), (5, 3), (16, 16), (17, 33), (130, 7)])
+def test_tiny_and_odd_image_sizes(dev, craster, W, H):
+    g = torch.Generator().manual_seed(W * 100 + H)
+    n = 200
+    means = torch.stack([(torch.rand(n, generator=g) - 0.5) * 2, (torch.rand(n, generator=g) - 0.5) * 2,
+                         torch.rand(n, generator=g) * 3 + 1.5], -1)
+    quats, scales = torch.randn(n, 4, generator=g), torch.exp(torch.rand(n, 3, generator=g) * 2 - 3.5)
+    opac, cols = torch.rand(n, generator=g) * 0.9 + 0.05, torch.rand(n, 3, generator=g)
+    K = torch.tensor([[1.2 * max(W, H), 0, W / 2], [0, 1.2 * max(W, H), H / 2], [0, 0, 1.0]])
+    out, _ = _compare_with_c_port(dev, craster, means, quats, scales, opac, cols, torch.eye(4), K, W, H)
+    assert out[0].shape == (1, H, W, 4)
+
+
+def test_deep_stack_multi_batch_and_early_termination(dev, craster):
+    """5000 Gaussians piled on the same few pixels: 70+ staging batches per tile, transmittance stop,
+    median switch and the back-to-front re-traversal from the saved last index."""
+    g = torch.Generator().manual_seed(77)
+    n, W, H = 5000, 48, 32
+    means = torch.stack([(torch.rand(n, generator=g) - 0.5) * 0.3, (torch.rand(n, generator=g) - 0.5) * 0.2,
+                         2.0 + torch.arange(n).float() * 1e-3], -1)
+    quats = torch.randn(n, 4, generator=g)
+    scales = torch.exp(torch.rand(n, 3, generator=g) * 1.0 - 3.0)
+    opac = torch.rand(n, generator=g) * 0.05 + 0.01                      # faint: hundreds contribute before T < 1e-4
+    cols = torch.rand(n, 3, generator=g)
+    K = torch.tensor([[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1.0]])
+    out, st = _compare_with_c_port(dev, craster, means, quats, scales, opac, cols, torch.eye(4), K, W, H, mode="classic", tol=2e-4)
+    per_tile = np.diff(np.append(st["bins"]["isect_offsets"].reshape(-1), st["bins"]["n_isects"]))
+    assert per_tile.max() > 2000                                          # >> 64: many batches
+    assert float(out[1].detach().max()) > 0.99                            # pixels that saturate and stop early
+    last = out[5]["last_ids"][0].cpu().numpy()
+    assert (last >= 0).any() and last.max() < st["bins"]["n_isects"]
+
+
+def test_screen_filling_and_degenerate_gaussians(dev, craster):
+    """One Gaussian covering every tile, needle-like and pancake-like shapes, a Gaussian exactly on a tile corner,
+    and a zero-opacity one; all gradients stay finite."""
+    W, H = 96, 64
+    means = torch.tensor([[0.0, 0.0, 1.0], [0.3, 0.1, 3.0], [-0.4, -0.2, 4.0], [0.0, 0.0, 5.0], [0.2, 0.2, 2.5], [0.1, -0.3, 6.0]])
+    quats = torch.tensor([[1.0, 0, 0, 0], [0.3, 0.8, -0.2, 0.4], [0.0, 0.0, 1e-3, 0.0], [1, 1, 1, 1.0], [0.5, -0.5, 0.5, 0.5], [2.0, 0, 0, 0]])
+    scales = torch.tensor([[5.0, 5.0, 5.0], [1.0, 1e-3, 1e-3], [1e-3, 0.7, 0.7], [0.05, 0.05, 0.05], [1e-4, 1e-4, 1e-4], [0.4, 0.2, 0.1]])
+    opac = torch.tensor([0.3, 0.9, 0.8, 0.999, 0.5, 0.0])
+    cols = torch.rand(6, 3, generator=torch.Generator().manual_seed(1))
+    K = torch.tensor([[80.0, 0, 48.0], [0, 80.0, 32.0], [0, 0, 1.0]])           # mean 3 projects exactly onto a tile corner
+    out, st = _compare_with_c_port(dev, craster, means, quats, scales, opac, cols, torch.eye(4), K, W, H)
+    assert st["bins"]["tiles_per_gauss"][0] == (W // 16) * (H // 16)              # the big one hits every tile
+    assert st["bins"]["tiles_per_gauss"][5] == 0                                  # zero opacity is culled
+    # the sub-pixel Gaussian: antialiasing scales its opacity by sqrt(det0/det) ~ 0 -> below 1/255 -> culled ...
+    assert out[5]["radii"][0, 4].max() == 0
+    out_c, _ = _compare_with_c_port(dev, craster, means, quats, scales, opac, cols, torch.eye(4), K, W, H, mode="classic")
+    assert out_c[5]["radii"][0, 4].min() > 0                                      # ... but survives in classic mode (eps2d)
+
+
 def test_sort_backends_give_identical_bins(dev, monkeypatch):
     """rocPRIM and the hand-written sort must produce the same tile lists (bit for bit)."""
     from collab_splats_amd import ops, rasterization
