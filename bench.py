@@ -89,7 +89,7 @@ def cpu_baseline(args, seed: int):
     while True:
         isects = one()
         reps += 1
-        if time.perf_counter() - t0 > 10.0 or reps >= 5:
+        if time.perf_counter() - t0 > 10.0 or reps >= 20:
             break
     dt = (time.perf_counter() - t0) / reps
     return {"value": round(n / dt / 1e6, 4), "unit": "Msplats/s", "cores": cr.threads, "kind": "port",
