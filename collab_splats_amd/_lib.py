@@ -68,6 +68,8 @@ SYMBOLS = {
     "misplat_isect_ids": (C.c_int, 6),
     "misplat_radix_workspace_bytes": (C.c_size_t, 4), "misplat_radix_sort_pairs": (C.c_int, 11), "misplat_depth_keys32": (C.c_int, 6), "misplat_pack": (C.c_int, 11),
     "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_bwd": (C.c_int, 21),
+    "misplat_color_fwd_x": (C.c_int, 11), "misplat_color_bwd_x": (C.c_int, 9),
+    "misplat_blend_fwd_x": (C.c_int, 17), "misplat_blend_bwd_x_atomic": (C.c_int, 22),
     "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 19), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),
     "misplat_depth_normal_bwd": (C.c_int, 13), "misplat_outputs_fwd": (C.c_int, 15), "misplat_outputs_bwd": (C.c_int, 16),
     "misplat_version": (C.c_char_p, 0),

@@ -83,16 +83,19 @@ __device__ __forceinline__ float sigma_min_box(float a, float b, float c, float 
 // wave's pixel band (conservatively: kept unless max alpha over the band is provably < alpha_min),
 // and the survivors are compacted with a ballot prefix into LDS, conic pre-multiplied so that
 // vis = exp2(e), e = cA' dx^2 + cC' dy^2 + cB' dx dy (= -sigma log2 e).  Returns the survivor count.
+template <int NXQ = 0>
 __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_slot, int lane, int i, bool valid,
                                              const float4* __restrict__ grec,
                                              const int32_t* __restrict__ flatten_ids,
                                              const int32_t* __restrict__ slots, float xlo, float xhi,
-                                             float ylo, float yhi, float alpha_min) {
+                                             float ylo, float yhi, float alpha_min,
+                                             float4* smx = nullptr, const float4* __restrict__ featx = nullptr) {
     float4 q0, q1, q2, q3;
     bool keep = false;
     int slot = 0;
+    int g = 0;
     if (valid) {
-        const int g = flatten_ids[i];
+        g = flatten_ids[i];
         q0 = grec[4 * (size_t)g + 0]; q1 = grec[4 * (size_t)g + 1];
         q2 = grec[4 * (size_t)g + 2]; q3 = grec[4 * (size_t)g + 3];
         if (slots) slot = slots[i]; else slot = g;
@@ -106,6 +109,8 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
         sm[pos] = q0; sm[64 + pos] = q1; sm[128 + pos] = q2; sm[192 + pos] = q3;
         sm_idx[pos] = i;
         if (sm_slot) sm_slot[pos] = slot;      // emission slot (slab mode) or Gaussian row (atomic mode)
+#pragma unroll
+        for (int q = 0; q < NXQ; q++) smx[q * 64 + pos] = featx[(size_t)g * NXQ + q];   // channels 4 .. 4+4*NXQ
     }
     return __popcll(mask);
 }
@@ -113,15 +118,23 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
 // Forward.  The per-pixel loop is branch-free: a pixel that has terminated carries T = 0 (its
 // transmittance at termination is parked in Tfin), so every later weight w = a*T vanishes by itself;
 // "skip" is a = 0.  The next record is prefetched from LDS while the current one is consumed.
-template <int CD, int PPL>
+// NXQ > 0: N-D colours (rade_features_model.py:441-476, D = 16 / 17): channels 0..3 ride in the record,
+// channels 4.. in featx[row][NXQ] (float4s, zero padded); n_channels = D' is the render width.
+template <int CD, int PPL, int NXQ = 0>
 __global__ __launch_bounds__(64) void blend_fwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ offsets, int64_t n_isects,
     float* __restrict__ render, float* __restrict__ alpha, float* __restrict__ exp_depth,
     float* __restrict__ med_depth, float* __restrict__ normal, int32_t* __restrict__ last_ids,
-    int32_t* __restrict__ median_ids) {
+    int32_t* __restrict__ median_ids, const float4* __restrict__ featx = nullptr, int n_channels = CD) {
     __shared__ float4 sm[4 * 64 + 4];
     __shared__ int sm_idx[64 + 4];
+    __shared__ float4 smx[NXQ > 0 ? NXQ * 64 + 4 : 1];
+    float colx[PPL][NXQ > 0 ? 4 * NXQ : 1];
+#pragma unroll
+    for (int k = 0; k < PPL; k++)
+#pragma unroll
+        for (int ch = 0; ch < (NXQ > 0 ? 4 * NXQ : 1); ch++) colx[k][ch] = 0.f;
     BandCtx c;
     if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c)) return;
     const int lane = threadIdx.x;
@@ -154,8 +167,8 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
         for (int k = 1; k < PPL; k++) tmax = fmaxf(tmax, T[k]);
         if (__ballot(tmax > 0.f) == 0ull) break;
         __syncthreads();
-        const int n = stage_records(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
-                                    nullptr, xlo, xhi, ylo, yhi, amin);
+        const int n = stage_records<NXQ>(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
+                                         nullptr, xlo, xhi, ylo, yhi, amin, smx, featx);
         __syncthreads();
         if (n == 0) continue;
         float4 n0 = sm[0], n1 = sm[64], n2 = sm[128], n3 = sm[192];
@@ -165,6 +178,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
             const int i = ni;
             n0 = sm[j + 1]; n1 = sm[64 + j + 1]; n2 = sm[128 + j + 1]; n3 = sm[192 + j + 1];   // prefetch (padded)
             ni = sm_idx[j + 1];
+            float4 xq[NXQ > 0 ? NXQ : 1];
+#pragma unroll
+            for (int q = 0; q < NXQ; q++) xq[q] = smx[q * 64 + j];
             const float dx = q0.x - px;
             const float ea = q0.z * dx * dx, eb = q0.w * dx;
             const float tpx = q1.z - q1.w * dx;
@@ -189,6 +205,11 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
                 if (CD > 1) col[k][CD > 1 ? 1 : 0] += w * q3.y;
                 if (CD > 2) col[k][CD > 2 ? 2 : 0] += w * q3.z;
                 if (CD > 3) col[k][CD > 3 ? 3 : 0] += w * q3.w;
+#pragma unroll
+                for (int q = 0; q < NXQ; q++) {
+                    colx[k][4 * q + 0] += w * xq[q].x; colx[k][4 * q + 1] += w * xq[q].y;
+                    colx[k][4 * q + 2] += w * xq[q].z; colx[k][4 * q + 3] += w * xq[q].w;
+                }
                 dep[k] += w * zp;
                 nrm[k][0] += w * q2.y; nrm[k][1] += w * q2.z; nrm[k][2] += w * q2.w;
                 med[k] = is_med ? zp : med[k];
@@ -206,8 +227,17 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
             const size_t pid = ((size_t)c.cam * P.height + y) * P.width + x;
             const float al = 1.0f - (T[k] > 0.f ? T[k] : Tfin[k]);
             const float inv_al = 1.0f / fmaxf(al, 1e-10f);
+            if (NXQ == 0) {
 #pragma unroll
-            for (int ch = 0; ch < CD; ch++) render[pid * CD + ch] = (ch == P.ed_slot) ? col[k][ch] * inv_al : col[k][ch];
+                for (int ch = 0; ch < CD; ch++) render[pid * CD + ch] = (ch == P.ed_slot) ? col[k][ch] * inv_al : col[k][ch];
+            } else {
+                float* o = render + pid * (size_t)n_channels;
+#pragma unroll
+                for (int ch = 0; ch < CD; ch++) o[ch] = (ch == P.ed_slot) ? col[k][ch] * inv_al : col[k][ch];
+#pragma unroll
+                for (int ch = 0; ch < 4 * NXQ; ch++)
+                    if (CD + ch < n_channels) o[CD + ch] = (CD + ch == P.ed_slot) ? colx[k][ch] * inv_al : colx[k][ch];
+            }
             alpha[pid] = al;
             exp_depth[pid] = dep[k];
             med_depth[pid] = med[k];
@@ -297,8 +327,8 @@ __device__ __forceinline__ int wave_max(int v) {
 // Measured (1 M / 1080p, PPL 2): 4 waves/SIMD (111 VGPRs) 0.663 ms, 5 waves (96 VGPRs + 48 B
 // scratch) 0.616 ms, 6 waves (80 VGPRs + 88 B scratch) 0.711 ms.
 // PPL 4: 2 waves (172 VGPRs) 0.73 ms, 3 waves 0.655 ms, 4 waves (spills) 1.28 ms.
-template <int CD, int PPL, bool ABS, bool ATOMIC>
-__global__ __launch_bounds__(64, PPL == 2 ? 5 : (PPL == 4 ? 3 : 1)) void blend_bwd_kernel(
+template <int CD, int PPL, bool ABS, bool ATOMIC, int NXQ = 0>
+__global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? 5 : (PPL == 4 ? 3 : 1)) void blend_bwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ slots,
     const int32_t* __restrict__ offsets, int64_t n_isects, const float* __restrict__ alpha,
@@ -306,10 +336,20 @@ __global__ __launch_bounds__(64, PPL == 2 ? 5 : (PPL == 4 ? 3 : 1)) void blend_b
     const float* __restrict__ render, const float* __restrict__ v_render, const float* __restrict__ v_alpha,
     const float* __restrict__ v_exp_depth, const float* __restrict__ v_med_depth,
     const float* __restrict__ v_normal, float* __restrict__ slab, float* __restrict__ slab_abs,
-    uint8_t* __restrict__ valid) {
+    uint8_t* __restrict__ valid, const float4* __restrict__ featx = nullptr, float* __restrict__ v_featx = nullptr,
+    int n_channels = CD) {
+    static_assert(NXQ == 0 || ATOMIC, "N-D colours: atomic gradient mode only");
     __shared__ float4 sm[4 * 64 + 4];
     __shared__ int sm_idx[64 + 4];
     __shared__ int sm_slot[64 + 4];
+    __shared__ float4 smx[NXQ > 0 ? NXQ * 64 + 4 : 1];
+    constexpr int NX = NXQ > 0 ? 4 * NXQ : 1;
+    float vcolx[PPL][NX];
+#pragma unroll
+    for (int k = 0; k < PPL; k++)
+#pragma unroll
+        for (int ch = 0; ch < NX; ch++) vcolx[k][ch] = 0.f;
+    const size_t rstride = NXQ > 0 ? (size_t)n_channels : (size_t)CD;
     BandCtx c;
     if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c)) return;
     if (c.end <= c.beg) return;
@@ -341,13 +381,25 @@ __global__ __launch_bounds__(64, PPL == 2 ? 5 : (PPL == 4 ? 3 : 1)) void blend_b
             float va = v_alpha[pid];
 #pragma unroll
             for (int ch = 0; ch < CD; ch++) {
-                float g = v_render[pid * CD + ch];
+                float g = v_render[pid * rstride + ch];
                 if (ch == P.ed_slot) {         // out = raw / max(alpha, 1e-10)
                     const float inv_al = 1.0f / fmaxf(al, 1e-10f);
                     g *= inv_al;
-                    if (al > 1e-10f) va -= g * render[pid * CD + ch];
+                    if (al > 1e-10f) va -= g * render[pid * rstride + ch];
                 }
                 vcol[k][ch] = g;
+            }
+#pragma unroll
+            for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) {
+                if (CD + ch < n_channels) {
+                    float g = v_render[pid * rstride + CD + ch];
+                    if (CD + ch == P.ed_slot) {
+                        const float inv_al = 1.0f / fmaxf(al, 1e-10f);
+                        g *= inv_al;
+                        if (al > 1e-10f) va -= g * render[pid * rstride + CD + ch];
+                    }
+                    vcolx[k][ch] = g;
+                }
             }
             tfva[k] = Tf * va;
             vn[k][0] = v_normal[pid * 3]; vn[k][1] = v_normal[pid * 3 + 1]; vn[k][2] = v_normal[pid * 3 + 2];
@@ -372,8 +424,8 @@ __global__ __launch_bounds__(64, PPL == 2 ? 5 : (PPL == 4 ? 3 : 1)) void blend_b
     for (int b = (maxlast - c.beg) >> 6; b >= 0; b--) {
         const int bs = c.beg + (b << 6);
         __syncthreads();
-        const int n = stage_records(sm, sm_idx, sm_slot, lane, bs + lane, bs + lane <= maxlast, grec, flatten_ids,
-                                    ATOMIC ? nullptr : slots, xlo, xhi, ylo, yhi, amin);
+        const int n = stage_records<NXQ>(sm, sm_idx, sm_slot, lane, bs + lane, bs + lane <= maxlast, grec, flatten_ids,
+                                         ATOMIC ? nullptr : slots, xlo, xhi, ylo, yhi, amin, smx, featx);
         __syncthreads();
         if (n == 0) continue;
         float4 n0 = sm[n - 1], n1 = sm[64 + n - 1], n2 = sm[128 + n - 1], n3 = sm[192 + n - 1];
@@ -385,12 +437,18 @@ __global__ __launch_bounds__(64, PPL == 2 ? 5 : (PPL == 4 ? 3 : 1)) void blend_b
             const int jn = j > 0 ? j - 1 : 0;                                  // prefetch
             n0 = sm[jn]; n1 = sm[64 + jn]; n2 = sm[128 + jn]; n3 = sm[192 + jn];
             ni = sm_idx[jn]; nslot = sm_slot[jn];
+            float4 xq[NXQ > 0 ? NXQ : 1];
+#pragma unroll
+            for (int q = 0; q < NXQ; q++) xq[q] = smx[q * 64 + j];
             const float dx = q0.x - px;
             const float ea = q0.z * dx * dx, eb = q0.w * dx;
             const float tpx = q1.z - q1.w * dx;
             float acc[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[r] = 0.f;
+            float accx[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) accx[r] = 0.f;
             float ab0 = 0.f, ab1 = 0.f;
             float amx = 0.f;
 #pragma unroll
@@ -411,6 +469,10 @@ __global__ __launch_bounds__(64, PPL == 2 ? 5 : (PPL == 4 ? 3 : 1)) void blend_b
                 if (CD > 1) dot += q3.y * vcol[k][CD > 1 ? 1 : 0];
                 if (CD > 2) dot += q3.z * vcol[k][CD > 2 ? 2 : 0];
                 if (CD > 3) dot += q3.w * vcol[k][CD > 3 ? 3 : 0];
+#pragma unroll
+                for (int q = 0; q < NXQ; q++)
+                    dot += xq[q].x * vcolx[k][4 * q] + xq[q].y * vcolx[k][4 * q + 1] + xq[q].z * vcolx[k][4 * q + 2] +
+                           xq[q].w * vcolx[k][4 * q + 3];
                 dot += q2.y * vn[k][0] + q2.z * vn[k][1] + q2.w * vn[k][2] + zp * vd[k];
                 float v_a = (tfva[k] - B[k]) * ra + T[k] * dot;
                 v_a = ok ? v_a : 0.f;
@@ -419,6 +481,8 @@ __global__ __launch_bounds__(64, PPL == 2 ? 5 : (PPL == 4 ? 3 : 1)) void blend_b
                 if (CD > 1) acc[13] += w * vcol[k][CD > 1 ? 1 : 0];
                 if (CD > 2) acc[14] += w * vcol[k][CD > 2 ? 2 : 0];
                 if (CD > 3) acc[15] += w * vcol[k][CD > 3 ? 3 : 0];
+#pragma unroll
+                for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) accx[ch] += w * vcolx[k][ch];
                 acc[9] += w * vn[k][0]; acc[10] += w * vn[k][1]; acc[11] += w * vn[k][2];
                 float vz = w * vd[k];
                 vz += (ok && i == medi[k]) ? vm[k] : 0.f;
@@ -437,6 +501,10 @@ __global__ __launch_bounds__(64, PPL == 2 ? 5 : (PPL == 4 ? 3 : 1)) void blend_b
                 if (ATOMIC) {
                     // one 64-byte contiguous no-return fp32 atomic per (band, Gaussian)
                     if (lane < 16) atomicAdd(&slab_b[slot * MISPLAT_REC + comp], r * out_scale);
+                    if (NXQ > 0) {
+                        const float rx = wave_reduce16(accx, lane);
+                        if (lane < 16 && comp < NX) atomicAdd(&v_featx[slot * NX + comp], rx);
+                    }
                 } else {
                     if (lane < 16) slab_b[slot * MISPLAT_REC + comp] = r * out_scale;
                     if (lane == 16) valid_b[slot] = 1;
@@ -635,7 +703,7 @@ inline int grid_for(int64_t n, int block) {
 }
 inline bool params_ok(const misplat_params* p) {
     return p && p->tile_size == MISPLAT_TILE && p->n_cams >= 1 && p->width >= 1 && p->height >= 1 &&
-           p->ed_slot >= -1 && p->ed_slot <= 3 &&
+           p->ed_slot >= -1 && p->ed_slot <= 19 &&
            p->tile_w == (p->width + MISPLAT_TILE - 1) / MISPLAT_TILE &&
            p->tile_h == (p->height + MISPLAT_TILE - 1) / MISPLAT_TILE;
 }
@@ -766,6 +834,69 @@ extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_d
     else return MISPLAT_EINVAL;
 #undef DISPATCH_BWDA
 #undef LAUNCH_BWDA
+    return check_launch();
+}
+
+// ---- N-D colours: D' = n_channels in 5..20 composited in ONE pass.
+// Channels 0..3 ride in the record's colour slots, channels 4.. in featx[C*N, 4*nxq] (zero padded).
+extern "C" int misplat_blend_fwd_x(const misplat_params* p, int32_t n_channels, int32_t nxq, const float* Ks,
+                                   const float* grec, const float* featx, const int32_t* flatten_ids,
+                                   const int32_t* offsets, int64_t n_isects, float* render, float* alpha,
+                                   float* exp_depth, float* med_depth, float* normal, int32_t* last_ids,
+                                   int32_t* median_ids, misplat_stream_t stream) {
+    if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || nxq < 1 || nxq > 4 || n_channels < 5 ||
+        n_channels > 4 + 4 * nxq || !featx)
+        return MISPLAT_EINVAL;
+    const int total = p->tile_w * p->tile_h * p->n_cams * 2;
+    const int grid = ((total + 7) / 8) * 8;
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_FWDX(NXQ_)                                                                                   \
+    hipLaunchKernelGGL((blend_fwd_kernel<4, 2, NXQ_>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec, \
+                       flatten_ids, offsets, n_isects, render, alpha, exp_depth, med_depth, normal, last_ids,  \
+                       median_ids, (const float4*)featx, n_channels)
+    if (nxq == 1) LAUNCH_FWDX(1);
+    else if (nxq == 2) LAUNCH_FWDX(2);
+    else if (nxq == 3) LAUNCH_FWDX(3);
+    else LAUNCH_FWDX(4);
+#undef LAUNCH_FWDX
+    return check_launch();
+}
+
+extern "C" int misplat_blend_bwd_x_atomic(const misplat_params* p, int32_t n_channels, int32_t nxq, const float* Ks,
+                                          const float* grec, const float* featx, const int32_t* flatten_ids,
+                                          const int32_t* offsets, int64_t n_isects, const float* alpha,
+                                          const int32_t* last_ids, const int32_t* median_ids, const float* render,
+                                          const float* v_render, const float* v_alpha, const float* v_exp_depth,
+                                          const float* v_med_depth, const float* v_normal, float* v_grec,
+                                          float* v_featx, float* v_abs, misplat_stream_t stream) {
+    if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || nxq < 1 || nxq > 4 || n_channels < 5 ||
+        n_channels > 4 + 4 * nxq || !featx || !v_grec || !v_featx)
+        return MISPLAT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t rows = (size_t)p->n_gauss * p->n_cams;
+    if (rows == 0) return MISPLAT_OK;
+    if (hipMemsetAsync(v_grec, 0, rows * MISPLAT_REC * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (hipMemsetAsync(v_featx, 0, rows * 4 * nxq * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (v_abs && hipMemsetAsync(v_abs, 0, rows * 2 * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (n_isects == 0) return MISPLAT_OK;
+    const int total = p->tile_w * p->tile_h * p->n_cams * 2;
+    const int grid = ((total + 7) / 8) * 8;
+#define LAUNCH_BWDX(NXQ_, ABS_)                                                                              \
+    hipLaunchKernelGGL((blend_bwd_kernel<4, 2, ABS_, true, NXQ_>), dim3(grid), dim3(64), 0, s, *p, Ks,          \
+                       (const float4*)grec, flatten_ids, (const int32_t*)nullptr, offsets, n_isects, alpha,    \
+                       last_ids, median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal,    \
+                       v_grec, v_abs, (uint8_t*)nullptr, (const float4*)featx, v_featx, n_channels)
+#define DISPATCH_BWDX(NXQ_)                     \
+    do {                                        \
+        if (v_abs) LAUNCH_BWDX(NXQ_, true);     \
+        else LAUNCH_BWDX(NXQ_, false);          \
+    } while (0)
+    if (nxq == 1) DISPATCH_BWDX(1);
+    else if (nxq == 2) DISPATCH_BWDX(2);
+    else if (nxq == 3) DISPATCH_BWDX(3);
+    else DISPATCH_BWDX(4);
+#undef DISPATCH_BWDX
+#undef LAUNCH_BWDX
     return check_launch();
 }
 

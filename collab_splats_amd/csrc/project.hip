@@ -751,6 +751,52 @@ __global__ __launch_bounds__(256) void color_copy_bwd_kernel(misplat_params P, i
     }
 }
 
+// N-D pass-through colours: channel c of [user colours ..., depth] goes to record slot 12+c for c < 4 and
+// to featx[row][c-4] beyond (zero padded up to 4*nxq).
+__global__ __launch_bounds__(256) void color_copy_x_kernel(misplat_params P, int D, int per_cam, int depth_channel,
+                                                           int nxq, const float* __restrict__ colors,
+                                                           const int32_t* __restrict__ radii,
+                                                           const float* __restrict__ depths, float* __restrict__ grec,
+                                                           float* __restrict__ featx) {
+    const int64_t total = (int64_t)P.n_cams * P.n_gauss;
+    const int nx = 4 * nxq;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t src = per_cam ? idx : idx % P.n_gauss;
+        const bool vis = radii[2 * idx] > 0 || radii[2 * idx + 1] > 0;
+        const int n_ch = D + (depth_channel ? 1 : 0);
+        float* rec = grec + (size_t)idx * MISPLAT_REC + 12;
+        float* fx = featx + (size_t)idx * nx;
+        for (int c = 0; c < 4 + nx; c++) {
+            float v = 0.f;
+            if (vis && c < n_ch) v = c < D ? colors[(size_t)src * D + c] : depths[idx];
+            if (c < 4) rec[c] = v; else fx[c - 4] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void color_copy_x_bwd_kernel(misplat_params P, int D, int per_cam, int nxq,
+                                                               const int32_t* __restrict__ radii,
+                                                               const float* __restrict__ v_grec,
+                                                               const float* __restrict__ v_featx,
+                                                               float* __restrict__ v_colors) {
+    const int64_t rows = per_cam ? (int64_t)P.n_cams * P.n_gauss : P.n_gauss;
+    const int nx = 4 * nxq;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const int c_lo = per_cam ? (int)(r / P.n_gauss) : 0, c_hi = per_cam ? c_lo + 1 : P.n_cams;
+        const int g = (int)(r % P.n_gauss);
+        for (int c = 0; c < D; c++) {
+            float acc = 0.f;
+            for (int ci = c_lo; ci < c_hi; ci++) {
+                const int64_t idx = (int64_t)ci * P.n_gauss + g;
+                if (radii[2 * idx] > 0 || radii[2 * idx + 1] > 0)
+                    acc += c < 4 ? v_grec[(size_t)idx * MISPLAT_REC + 12 + c] : v_featx[(size_t)idx * nx + (c - 4)];
+            }
+            v_colors[(size_t)r * D + c] = acc;
+        }
+    }
+}
+
 // Backward of project_pack_fwd from packed gradient rows.  depth_slot: index (12..15) of the
 // colour channel that carries the depth (RGB+ED / ED), or -1.  v_means_dir (or NULL) is the
 // gradient that reached the means through the SH view direction; it is added here.
@@ -939,5 +985,28 @@ extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_s
     hipLaunchKernelGGL(project_pack_bwd_kernel, dim3(grid_for(p->n_gauss, 256)), dim3(256), 0, (hipStream_t)stream,
                        *p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii, compensations, v_means2d,
                        v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities);
+    return check_launch();
+}
+
+extern "C" int misplat_color_fwd_x(const misplat_params* p, int32_t D, int32_t per_cam, int32_t depth_channel,
+                                   int32_t nxq, const float* colors, const int32_t* radii, const float* depths,
+                                   float* grec, float* featx, misplat_stream_t stream) {
+    if (!p || p->n_gauss < 0 || p->n_cams < 1 || nxq < 1 || nxq > 4 || D < 1 || D + (depth_channel ? 1 : 0) > 4 + 4 * nxq)
+        return MISPLAT_EINVAL;
+    int64_t total = (int64_t)p->n_gauss * p->n_cams;
+    if (total == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(color_copy_x_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *p, D,
+                       per_cam, depth_channel, nxq, colors, radii, depths, grec, featx);
+    return check_launch();
+}
+
+extern "C" int misplat_color_bwd_x(const misplat_params* p, int32_t D, int32_t per_cam, int32_t nxq,
+                                   const int32_t* radii, const float* v_grec, const float* v_featx,
+                                   float* v_colors, misplat_stream_t stream) {
+    if (!p || p->n_gauss < 0 || p->n_cams < 1 || nxq < 1 || nxq > 4 || D < 1) return MISPLAT_EINVAL;
+    int64_t rows = per_cam ? (int64_t)p->n_gauss * p->n_cams : p->n_gauss;
+    if (rows == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(color_copy_x_bwd_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, (hipStream_t)stream, *p, D,
+                       per_cam, nxq, radii, v_grec, v_featx, v_colors);
     return check_launch();
 }

@@ -547,6 +547,125 @@ def blend_packed(means2d, grec, Ks, P: Params, bins, absgrad: bool, cd: int):
     return _BlendPacked.apply(means2d, grec, _f32(Ks, "Ks"), P, bins, bool(absgrad), int(cd))
 
 
+# ----------------------------------------------------------------------------- N-D colours (a8)
+
+class _ProjectPackX(torch.autograd.Function):
+    """projection + pass-through colours with D' = D (+ depth) in 5..20 channels: channels 0..3 go to the record,
+    the rest to ``featx[C*N, 4*nxq]`` (rade_features_model.py:441-476 renders 16 fused channels, 17 with ED)."""
+
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, P: Params, depth_channel: bool, nxq: int):
+        lib = _lib.load()
+        require_gpu(means, quats, scales, opacities, colors, viewmats, Ks)
+        N, Cn = P.n_gauss, P.n_cams
+        dev = means.device
+        radii = torch.empty(Cn, N, 2, device=dev, dtype=torch.int32)
+        means2d = torch.empty(Cn, N, 2, device=dev, dtype=torch.float32)
+        depths = torch.empty(Cn, N, device=dev, dtype=torch.float32)
+        comps = torch.empty(Cn, N, device=dev, dtype=torch.float32)
+        grec = torch.empty(Cn * N, MISPLAT_REC, device=dev, dtype=torch.float32)
+        featx = torch.empty(Cn * N, 4 * nxq, device=dev, dtype=torch.float32)
+        check(lib.misplat_project_pack_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
+                                           ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
+                                           ptr(comps), ptr(grec), stream_ptr()), "misplat_project_pack_fwd")
+        D, per_cam = colors.shape[-1], int(colors.dim() == 3)
+        check(lib.misplat_color_fwd_x(C.byref(P), C.c_int32(D), C.c_int32(per_cam), C.c_int32(int(depth_channel)),
+                                      C.c_int32(nxq), ptr(colors), ptr(radii), ptr(depths), ptr(grec), ptr(featx),
+                                      stream_ptr()), "misplat_color_fwd_x")
+        ctx.P, ctx.D, ctx.per_cam, ctx.nxq, ctx.depth_channel = P, D, per_cam, nxq, depth_channel
+        ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps)
+        ctx.mark_non_differentiable(radii, depths, comps)
+        return radii, means2d, depths, comps, grec, featx
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, _v_depths, _v_comps, v_grec, v_featx):
+        lib = _lib.load()
+        means, quats, scales, opacities, colors, viewmats, Ks, radii, comps = ctx.saved_tensors
+        P, D, nxq = ctx.P, ctx.D, ctx.nxq
+        v_means2d, v_grec, v_featx = _c(v_means2d), _c(v_grec), _c(v_featx)
+        v_colors = torch.empty_like(colors)
+        check(lib.misplat_color_bwd_x(C.byref(P), C.c_int32(D), C.c_int32(ctx.per_cam), C.c_int32(nxq), ptr(radii),
+                                      ptr(v_grec), ptr(v_featx), ptr(v_colors), stream_ptr()), "misplat_color_bwd_x")
+        depth_slot = -1
+        if ctx.depth_channel:                       # channel D carries the depth
+            if D < 4:
+                depth_slot = 12 + D
+            else:                                   # it lives in featx: park its gradient in the (consumed) slot 15
+                v_grec = v_grec.clone()
+                v_grec[:, 15] = v_featx[:, D - 4]
+                depth_slot = 15
+        v_means, v_quats = torch.empty_like(means), torch.empty_like(quats)
+        v_scales, v_opac = torch.empty_like(scales), torch.empty_like(opacities)
+        check(lib.misplat_project_pack_bwd(C.byref(P), C.c_int32(depth_slot), ptr(means), ptr(quats), ptr(scales),
+                                           ptr(opacities), ptr(viewmats), ptr(Ks), ptr(radii), ptr(comps),
+                                           ptr(v_means2d), ptr(v_grec), ptr(None), ptr(v_means), ptr(v_quats),
+                                           ptr(v_scales), ptr(v_opac), stream_ptr()), "misplat_project_pack_bwd")
+        return v_means, v_quats, v_scales, v_opac, v_colors, None, None, None, None, None
+
+
+def project_pack_x(means, quats, scales, opacities, colors, viewmats, Ks, P: Params, depth_channel: bool, nxq: int):
+    args = [_f32(t, n) for t, n in ((means, "means"), (quats, "quats"), (scales, "scales"),
+                                    (opacities, "opacities"), (colors, "colors"), (viewmats, "viewmats"), (Ks, "Ks"))]
+    return _ProjectPackX.apply(*args, P, bool(depth_channel), int(nxq))
+
+
+class _BlendPackedX(torch.autograd.Function):
+    """One-pass compositing of 5..20 colour channels (atomic gradient mode)."""
+
+    @staticmethod
+    def forward(ctx, means2d, grec, featx, Ks, P: Params, bins: Dict[str, Tensor], absgrad: bool, n_channels: int,
+                nxq: int):
+        lib = _lib.load()
+        Cn, H, W = P.n_cams, P.height, P.width
+        dev = grec.device
+        f = dict(device=dev, dtype=torch.float32)
+        render = torch.empty(Cn, H, W, n_channels, **f)
+        alpha = torch.empty(Cn, H, W, 1, **f)
+        exp_depth = torch.empty(Cn, H, W, 1, **f)
+        med_depth = torch.empty(Cn, H, W, 1, **f)
+        normal = torch.empty(Cn, H, W, 3, **f)
+        last_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
+        median_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
+        with _timed("blend_fwd"):
+            check(lib.misplat_blend_fwd_x(C.byref(P), C.c_int32(n_channels), C.c_int32(nxq), ptr(Ks), ptr(grec),
+                                          ptr(featx), ptr(bins["flatten_ids"]), ptr(bins["isect_offsets"]),
+                                          C.c_int64(bins["n_isects"]), ptr(render), ptr(alpha), ptr(exp_depth),
+                                          ptr(med_depth), ptr(normal), ptr(last_ids), ptr(median_ids), stream_ptr()),
+                  "misplat_blend_fwd_x")
+        ctx.P, ctx.bins, ctx.absgrad, ctx.n_channels, ctx.nxq = P, bins, absgrad, n_channels, nxq
+        ctx.means2d_ref = means2d if absgrad else None
+        ctx.save_for_backward(grec, featx, Ks, alpha, last_ids, median_ids, render)
+        ctx.mark_non_differentiable(last_ids, median_ids)
+        return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
+
+    @staticmethod
+    def backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, _l, _m):
+        lib = _lib.load()
+        grec, featx, Ks, alpha, last_ids, median_ids, render = ctx.saved_tensors
+        P, bins = ctx.P, ctx.bins
+        rows = P.n_cams * P.n_gauss
+        dev = grec.device
+        v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
+        v_featx = torch.empty(rows, 4 * ctx.nxq, device=dev, dtype=torch.float32)
+        v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
+        ups = [_c(t) for t in (v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)]
+        with _timed("blend_bwd"):
+            check(lib.misplat_blend_bwd_x_atomic(C.byref(P), C.c_int32(ctx.n_channels), C.c_int32(ctx.nxq), ptr(Ks),
+                                                 ptr(grec), ptr(featx), ptr(bins["flatten_ids"]),
+                                                 ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(alpha),
+                                                 ptr(last_ids), ptr(median_ids), ptr(render), *[ptr(t) for t in ups],
+                                                 ptr(v_grec), ptr(v_featx), ptr(v_abs), stream_ptr()),
+                  "misplat_blend_bwd_x_atomic")
+        if ctx.absgrad:
+            ctx.means2d_ref.absgrad = v_abs.view(P.n_cams, P.n_gauss, 2)
+        return (v_grec.view(P.n_cams, P.n_gauss, MISPLAT_REC)[..., 0:2], v_grec, v_featx, None, None, None, None, None,
+                None)
+
+
+def blend_packed_x(means2d, grec, featx, Ks, P: Params, bins, absgrad: bool, n_channels: int, nxq: int):
+    return _BlendPackedX.apply(means2d, grec, featx, _f32(Ks, "Ks"), P, bins, bool(absgrad), int(n_channels), int(nxq))
+
+
 # ----------------------------------------------------------------------------- depth -> normal
 
 class _DepthNormal(torch.autograd.Function):

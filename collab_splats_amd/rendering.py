@@ -18,6 +18,7 @@ from . import ops
 from ._lib import MisplatError, make_params
 
 _RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
+ENABLE_ND_ONE_PASS = True        # a8: 5..20 channels in one compositing pass (False: 4-channel passes; for A/B)
 
 
 class _Meta(dict):
@@ -107,8 +108,12 @@ def rasterization(
     fused = n_user + int(depth_channel) <= 4 and n_sh <= 16
     if split_sh and not fused:
         colors = torch.cat((colors[0][:, None, :], colors[1]), dim=1)
-    # fused path: the kernels divide the depth channel by max(alpha, 1e-10) themselves ("ED")
-    ed_fused = fused and render_mode in ("ED", "RGB+ED")
+    # N-D colours in one pass (a8): 5..20 channels, pass-through colours, atomic gradient mode
+    n_total = n_user + int(depth_channel)
+    fused_x = (ENABLE_ND_ONE_PASS and (not fused) and sh_degree is None and 5 <= n_total <= 20
+               and not ops.DETERMINISTIC_BACKWARD)
+    # fused paths: the kernels divide the depth channel by max(alpha, 1e-10) themselves ("ED")
+    ed_fused = (fused or fused_x) and render_mode in ("ED", "RGB+ED")
     P = make_params(N, Cn, width, height, tile_size=tile_size, antialiased=aa,
                     opacity_aware_radius=opacity_aware_radius, eps2d=eps2d, near_plane=near_plane,
                     far_plane=far_plane, radius_clip=radius_clip, radius_sigma=radius_sigma,
@@ -122,6 +127,16 @@ def rasterization(
         bins = ops.bin_tiles(P, means2d, radii, depths)
         D = n_user + int(depth_channel)
         first = ops.blend_packed(means2d, grec, Ks, P, bins, absgrad, D)
+        render = first[0]
+        gv = grec.view(Cn, N, 16)
+        conics, opac, ray_ts, ray_planes, normals = gv[..., 2:5], gv[..., 5], gv[..., 6], gv[..., 7:9], gv[..., 9:12]
+    elif fused_x:
+        # ---- rade_features_model.py:441-476 (16 fused channels, 17 with ED): one compositing pass
+        nxq = (n_total - 4 + 3) // 4
+        radii, means2d, depths, comps, grec, featx = ops.project_pack_x(
+            means, quats, scales, opacities, colors, viewmats, Ks, P, depth_channel, nxq)
+        bins = ops.bin_tiles(P, means2d, radii, depths)
+        first = ops.blend_packed_x(means2d, grec, featx, Ks, P, bins, absgrad, n_total, nxq)
         render = first[0]
         gv = grec.view(Cn, N, 16)
         conics, opac, ray_ts, ray_planes, normals = gv[..., 2:5], gv[..., 5], gv[..., 6], gv[..., 7:9], gv[..., 9:12]

@@ -237,6 +237,30 @@ int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const f
                              const float* v_alpha, const float* v_exp_depth, const float* v_med_depth,
                              const float* v_normal, float* v_grec, float* v_abs,
                              misplat_stream_t stream);
+/* ---- a8: N-D colours in one pass (rade_features_model.py:441-476: D = 16 fused channels, 17 with
+ * RGB+ED).  n_channels = D' in 5..20; channels 0..3 live in the record's colour slots, channels 4..
+ * in featx[C*N, 4*nxq] (nxq = ceil((D'-4)/4) float4s per row, zero padded); color_fwd_x writes both
+ * from colors[(C,)N,D] (+ the depth channel); render is [C,H,W,n_channels].  Gradients: atomic mode
+ * only (v_grec, v_featx, v_abs zeroed here on `stream`). */
+int misplat_color_fwd_x(const misplat_params* p, int32_t D, int32_t per_cam, int32_t depth_channel,
+                        int32_t nxq, const float* colors, const int32_t* radii, const float* depths,
+                        float* grec, float* featx, misplat_stream_t stream);
+int misplat_color_bwd_x(const misplat_params* p, int32_t D, int32_t per_cam, int32_t nxq,
+                        const int32_t* radii, const float* v_grec, const float* v_featx,
+                        float* v_colors, misplat_stream_t stream);
+int misplat_blend_fwd_x(const misplat_params* p, int32_t n_channels, int32_t nxq, const float* Ks,
+                        const float* grec, const float* featx, const int32_t* flatten_ids,
+                        const int32_t* offsets, int64_t n_isects, float* render, float* alpha,
+                        float* exp_depth, float* med_depth, float* normal, int32_t* last_ids,
+                        int32_t* median_ids, misplat_stream_t stream);
+int misplat_blend_bwd_x_atomic(const misplat_params* p, int32_t n_channels, int32_t nxq, const float* Ks,
+                               const float* grec, const float* featx, const int32_t* flatten_ids,
+                               const int32_t* offsets, int64_t n_isects, const float* alpha,
+                               const int32_t* last_ids, const int32_t* median_ids, const float* render,
+                               const float* v_render, const float* v_alpha, const float* v_exp_depth,
+                               const float* v_med_depth, const float* v_normal, float* v_grec,
+                               float* v_featx, float* v_abs, misplat_stream_t stream);
+
 /* v_grec[r] = sum of the VALID slab rows of Gaussian row r (slots cum[r] .. cum[r]+tiles_per_gauss[r],
  * all planes) in a fixed order => bitwise reproducible.  v_abs[n_rows,2] likewise from slab_abs
  * (both may be NULL together). */

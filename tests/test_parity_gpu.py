@@ -161,24 +161,39 @@ def test_edge_cases_empty_culled_and_two_cameras(dev, craster):
     assert np.all(np.diff(keys) >= 0)
 
 
-def test_feature_channels_backgrounds_and_render_modes(dev, craster):
-    """sh_degree=None with D=7 'fused features' (rade_features_model.py:441-476 shape: D>4 goes through
-    4-channel passes), backgrounds, and the 3-tuple return."""
+@pytest.mark.parametrize("D,rm,det", [(7, "RGB+ED", False), (16, "RGB+ED", False), (16, "RGB", False), (5, "RGB", False),
+                                      (19, "RGB+ED", False), (16, "RGB+ED", True), (23, "RGB", False)])
+def test_feature_channels_backgrounds_and_render_modes(dev, craster, D, rm, det):
+    """sh_degree=None with D 'fused feature' channels (rade_features_model.py:441-476: D = 16, 17 with ED):
+    5..20 channels take the one-pass N-D kernels, anything else (or deterministic mode) the 4-channel passes;
+    plus backgrounds and the 3-tuple return."""
+    from collab_splats_amd import ops, rasterization
+    from collab_splats_amd.synthetic import random_scene
+    old = ops.DETERMINISTIC_BACKWARD
+    ops.set_deterministic(det)
+    try:
+        _feature_case(dev, craster, D, rm)
+    finally:
+        ops.set_deterministic(old)
+
+
+def _feature_case(dev, craster, D, rm):
     from collab_splats_amd import rasterization
     from collab_splats_amd.synthetic import random_scene
-    W, H, N, D = 200, 120, 4000, 7
+    W, H, N = 200, 120, 4000
     sc = random_scene(N, W, H, seed=9)
     g = torch.Generator().manual_seed(4)
     feats = torch.rand(N, D, generator=g)
     scales, op = torch.exp(sc["log_scales"]), torch.sigmoid(sc["opacity_logits"])
     leaves = [t.to(dev).requires_grad_(True) for t in (sc["means"], sc["quats"], scales, op, feats)]
-    bg = torch.rand(1, D + 1, generator=g).to(dev)
-    out = rasterization(*leaves, sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H, sh_degree=None, render_mode="RGB+ED",
+    Dp = D + (1 if rm == "RGB+ED" else 0)
+    bg = torch.rand(1, Dp, generator=g).to(dev)
+    out = rasterization(*leaves, sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H, sh_degree=None, render_mode=rm,
                         rasterize_mode="classic", backgrounds=bg, return_depth_normal=True)
-    assert out[0].shape == (1, H, W, D + 1)
+    assert out[0].shape == (1, H, W, Dp)
     cr = craster.CRaster(np.float32)
     st = cr.forward(sc["means"].numpy(), sc["quats"].numpy(), scales.numpy(), op.numpy(), feats.numpy(),
-                    sc["viewmats"][0].numpy(), sc["Ks"][0].numpy(), W, H, sh_degree=None, render_mode="RGB+ED")
+                    sc["viewmats"][0].numpy(), sc["Ks"][0].numpy(), W, H, sh_degree=None, render_mode=rm)
     want = st["render"] + (1 - st["fwd"]["alpha"]) * bg[0].cpu().numpy()
     assert rel_err(out[0][0], want) < TOL
     ups = upstream([t.shape for t in out[:5]], dtype=torch.float32)
@@ -300,6 +315,36 @@ def test_screen_filling_and_degenerate_gaussians(dev, craster):
     assert out[5]["radii"][0, 4].max() == 0
     out_c, _ = _compare_with_c_port(dev, craster, means, quats, scales, opac, cols, torch.eye(4), K, W, H, mode="classic")
     assert out_c[5]["radii"][0, 4].min() > 0                                      # ... but survives in classic mode (eps2d)
+
+
+def test_meta_serves_the_reference_consumers(dev):
+    """`meta` must carry what the reference's consumers read: project_gaussians (utils/utils.py:13-40:
+    radii, means2d, depths, width, height) and the prefilter mask (rade_gs_model.py:397)."""
+    from collab_splats_amd import rasterization
+    from collab_splats_amd.synthetic import random_scene
+    W, H, N = 320, 200, 4000
+    sc = random_scene(N, W, H, seed=21)
+    out = rasterization(sc["means"].to(dev), sc["quats"].to(dev), torch.exp(sc["log_scales"]).to(dev),
+                        torch.sigmoid(sc["opacity_logits"]).to(dev), sc["sh"].to(dev), sc["viewmats"].to(dev),
+                        sc["Ks"].to(dev), W, H, sh_degree=3, packed=False, return_depth_normal=True)
+    meta = out[5]
+    # --- the consumer's own steps (utils.py:19-37), on this build's meta
+    Wm, Hm = meta["width"], meta["height"]
+    radii = meta["radii"].squeeze()
+    assert radii.shape == (N, 2)
+    valid_mask = (radii > 1.0).sum(dim=1) > 0
+    gaussian_ids = valid_mask.nonzero(as_tuple=False).squeeze()
+    xy = torch.round(meta["means2d"]).squeeze().long()
+    x, y = torch.clamp(xy[:, 0], 0, Wm - 1), torch.clamp(xy[:, 1], 0, Hm - 1)
+    flat = x + y * Wm
+    depths = meta["depths"].squeeze().detach().cpu()
+    assert (Wm, Hm) == (W, H) and flat.shape == (N,) and depths.shape == (N,)
+    assert 0 < gaussian_ids.numel() < N and int(flat.max()) < W * H
+    assert torch.all(depths[valid_mask.cpu()] > 0)
+    for key in ("conics", "opacities", "tile_width", "tile_height", "tiles_per_gauss", "isect_ids", "flatten_ids",
+                "isect_offsets", "tile_size", "n_cameras", "ray_ts", "ray_planes", "normals"):
+        assert meta[key] is not None, key
+    assert meta["isect_offsets"].shape == (1, meta["tile_height"], meta["tile_width"])
 
 
 def test_sort_backends_give_identical_bins(dev, monkeypatch):
