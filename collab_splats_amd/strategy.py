@@ -1,54 +1,238 @@
-"""``gsplat.strategy.DefaultStrategy`` surface used by the reference
-(/root/reference/collab_splats/models/rade_gs_model.py:19, 191-198, 456-458): an ``isinstance``
-check, the ``absgrad`` flag and ``step_pre_backward(params, optimizers, state, step, info)``.
+"""``gsplat.strategy.DefaultStrategy`` for the reference's training loop.
 
-The densification controller itself (split / clone / prune / opacity reset) is the step on the
-other side of the rasterizer and is NOT part of this round: only the
-statistics it would consume are gathered here, from the rasterizer's ``meta``.
+Surface the reference touches (/root/reference/collab_splats/models/rade_gs_model.py:19, 191-198,
+456-458): an ``isinstance`` check, the ``absgrad`` flag and
+``step_pre_backward(params, optimizers, state, step, info)``; nerfstudio's Splatfacto (third-party,
+absent) additionally calls ``step_post_backward(params, optimizers, state, step, info, packed)`` after
+``backward()``.
+
+The controller itself -- the 3D Gaussian Splatting adaptive density control: accumulate the
+screen-space gradient norm of every visible Gaussian, every ``refine_every`` steps duplicate the
+small high-gradient Gaussians, split the large ones in two, prune the transparent / oversized ones,
+and periodically reset the opacities -- is restated here from the published algorithm (Kerbl et al.
+2023, section 5) with gsplat's parameter names and defaults **[UNVERIFIED-UPSTREAM: gsplat is absent
+from the build container; SURVEY.md section 8(f) rank 3]**.  It is plain tensor surgery on the
+parameter dict and the optimizer states (no kernel of its own) and runs wherever the tensors live.
 """
 from __future__ import annotations
 
+import math
 from dataclasses import dataclass
-from typing import Any, Dict
+from typing import Any, Callable, Dict, Optional, Tuple, Union
 
 import torch
+from torch import Tensor
+
+
+def _quat_to_rotmat(quats: Tensor) -> Tensor:
+    q = torch.nn.functional.normalize(quats, dim=-1)
+    w, x, y, z = q.unbind(-1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], dim=-1)
+    return R.reshape(quats.shape[:-1] + (3, 3))
+
+
+@torch.no_grad()
+def _update_param_with_optimizer(param_fn: Callable[[str, Tensor], Tensor],
+                                 optimizer_fn: Callable[[str, Tensor], Tensor],
+                                 params, optimizers: Dict[str, torch.optim.Optimizer], names=None) -> None:
+    """Replace every parameter by ``param_fn(name, p)`` and map each per-parameter optimizer-state tensor
+    through ``optimizer_fn`` (one optimizer per parameter name, as nerfstudio / gsplat hand them in)."""
+    names = list(params.keys()) if names is None else names
+    for name in names:
+        param = params[name]
+        new_param = torch.nn.Parameter(param_fn(name, param), requires_grad=param.requires_grad)
+        if name in optimizers:
+            opt = optimizers[name]
+            for group in opt.param_groups:
+                for i, p in enumerate(group["params"]):
+                    if p is param:
+                        st = opt.state.pop(p, {})
+                        for key, val in list(st.items()):
+                            if isinstance(val, Tensor) and val.dim() > 0 and val.shape[0] == param.shape[0]:
+                                st[key] = optimizer_fn(key, val)
+                        group["params"][i] = new_param
+                        if st:
+                            opt.state[new_param] = st
+        params[name] = new_param
+
+
+@torch.no_grad()
+def duplicate(params, optimizers, state: Dict[str, Any], mask: Tensor) -> None:
+    sel = torch.where(mask)[0]
+    _update_param_with_optimizer(lambda n, p: torch.cat([p, p[sel]]),
+                                 lambda k, v: torch.cat([v, torch.zeros((len(sel), *v.shape[1:]), device=v.device, dtype=v.dtype)]),
+                                 params, optimizers)
+    for k, v in state.items():
+        if isinstance(v, Tensor) and v.dim() > 0:
+            state[k] = torch.cat([v, v[sel]])
+
+
+@torch.no_grad()
+def split(params, optimizers, state: Dict[str, Any], mask: Tensor, revised_opacity: bool = False,
+          generator: Optional[torch.Generator] = None) -> None:
+    """Each selected Gaussian is replaced by two samples of itself with scales / 1.6."""
+    sel, rest = torch.where(mask)[0], torch.where(~mask)[0]
+    scales = torch.exp(params["scales"][sel])
+    rot = _quat_to_rotmat(params["quats"][sel])
+    noise = torch.randn(2, len(sel), 3, device=scales.device, dtype=scales.dtype, generator=generator)
+    samples = torch.einsum("nij,nj,bnj->bni", rot, scales, noise)
+
+    def param_fn(name: str, p: Tensor) -> Tensor:
+        reps = [2] + [1] * (p.dim() - 1)
+        if name == "means":
+            p_split = (p[sel] + samples).reshape(-1, 3)
+        elif name == "scales":
+            p_split = torch.log(scales / 1.6).repeat(2, 1)
+        elif name == "opacities" and revised_opacity:
+            p_split = torch.logit(1.0 - torch.sqrt(1.0 - torch.sigmoid(p[sel]))).repeat(reps)
+        else:
+            p_split = p[sel].repeat(reps)
+        return torch.cat([p[rest], p_split])
+
+    def optimizer_fn(key: str, v: Tensor) -> Tensor:
+        return torch.cat([v[rest], torch.zeros((2 * len(sel), *v.shape[1:]), device=v.device, dtype=v.dtype)])
+
+    _update_param_with_optimizer(param_fn, optimizer_fn, params, optimizers)
+    for k, v in state.items():
+        if isinstance(v, Tensor) and v.dim() > 0:
+            state[k] = torch.cat([v[rest], v[sel].repeat([2] + [1] * (v.dim() - 1))])
+
+
+@torch.no_grad()
+def remove(params, optimizers, state: Dict[str, Any], mask: Tensor) -> None:
+    keep = torch.where(~mask)[0]
+    _update_param_with_optimizer(lambda n, p: p[keep], lambda k, v: v[keep], params, optimizers)
+    for k, v in state.items():
+        if isinstance(v, Tensor) and v.dim() > 0:
+            state[k] = v[keep]
+
+
+@torch.no_grad()
+def reset_opa(params, optimizers, state: Dict[str, Any], value: float) -> None:
+    """Clamp the opacity logits to logit(value) and forget their optimizer moments."""
+    cap = math.log(value / (1.0 - value))
+    _update_param_with_optimizer(lambda n, p: torch.clamp(p, max=cap), lambda k, v: torch.zeros_like(v),
+                                 params, optimizers, names=["opacities"])
 
 
 @dataclass
 class DefaultStrategy:
-    absgrad: bool = False
-    key_for_gradient: str = "means2d"
+    """gsplat's parameter names and defaults [UNVERIFIED-UPSTREAM]; all thresholds as in 3DGS."""
+    prune_opa: float = 0.005
+    grow_grad2d: float = 0.0002
+    grow_scale3d: float = 0.01
+    grow_scale2d: float = 0.05
+    prune_scale3d: float = 0.1
+    prune_scale2d: float = 0.15
+    refine_scale2d_stop_iter: int = 0
     refine_start_iter: int = 500
     refine_stop_iter: int = 15_000
+    reset_every: int = 3000
+    refine_every: int = 100
+    pause_refine_after_reset: int = 0
+    absgrad: bool = False
+    revised_opacity: bool = False
     verbose: bool = False
+    key_for_gradient: str = "means2d"
 
     def initialize_state(self, scene_scale: float = 1.0) -> Dict[str, Any]:
-        return {"grad2d": None, "count": None, "radii": None, "scene_scale": scene_scale}
+        state: Dict[str, Any] = {"grad2d": None, "count": None, "scene_scale": scene_scale}
+        if self.refine_scale2d_stop_iter > 0:
+            state["radii"] = None
+        return state
 
     def check_sanity(self, params, optimizers) -> None:
         for key in ("means", "scales", "quats", "opacities"):
             assert key in params, f"{key} is required in params but missing."
+        for key in optimizers:
+            assert key in params, f"optimizer {key} has no parameter"
 
     def step_pre_backward(self, params, optimizers, state: Dict[str, Any], step: int, info: Dict[str, Any]) -> None:
         """Keep the 2-D mean gradient: ``info["means2d"]`` is a non-leaf of the autograd graph."""
         assert self.key_for_gradient in info, "The 2D means of the Gaussians is required but missing."
         info[self.key_for_gradient].retain_grad()
 
-    @torch.no_grad()
     def step_post_backward(self, params, optimizers, state: Dict[str, Any], step: int, info: Dict[str, Any],
-                           packed: bool = False) -> None:
-        """Accumulate the per-Gaussian screen-space gradient norm (the densification statistic)."""
+                           packed: bool = False) -> Tuple[int, int, int]:
+        """Returns (n_duplicated, n_split, n_pruned) of this call."""
+        if packed:
+            raise NotImplementedError("packed=True is not on the reference's path (rade_gs_model.py:450)")
         if step >= self.refine_stop_iter:
-            return
+            return 0, 0, 0
+        self._update_state(params, state, info)
+        counts = (0, 0, 0)
+        if (step > self.refine_start_iter and step % self.refine_every == 0
+                and step % self.reset_every >= self.pause_refine_after_reset):
+            n_dupli, n_split = self._grow_gs(params, optimizers, state, step)
+            n_prune = self._prune_gs(params, optimizers, state, step)
+            if self.verbose:
+                print(f"Step {step}: {n_dupli} duplicated, {n_split} split, {n_prune} pruned; "
+                      f"now {len(params['means'])} Gaussians")
+            state["grad2d"].zero_()
+            state["count"].zero_()
+            if state.get("radii") is not None:
+                state["radii"].zero_()
+            counts = (n_dupli, n_split, n_prune)
+        if step % self.reset_every == 0 and step > 0:
+            reset_opa(params, optimizers, state, value=self.prune_opa * 2.0)
+        return counts
+
+    # ------------------------------------------------------------------ internals
+    @torch.no_grad()
+    def _update_state(self, params, state: Dict[str, Any], info: Dict[str, Any]) -> None:
+        for key in ("width", "height", "n_cameras", "radii", self.key_for_gradient):
+            assert key in info, f"{key} is required but missing."
         m2d = info[self.key_for_gradient]
-        grads = (m2d.absgrad if self.absgrad else m2d.grad).clone()
-        grads[..., 0] *= info["width"] / 2.0 * info["n_cameras"]
+        grads = (m2d.absgrad if self.absgrad else m2d.grad).clone()           # [C, N, 2]
+        grads[..., 0] *= info["width"] / 2.0 * info["n_cameras"]             # to normalised-device units
         grads[..., 1] *= info["height"] / 2.0 * info["n_cameras"]
-        sel = (info["radii"] > 0).any(dim=-1)                      # [C, N]
-        n = m2d.shape[1]
+        n = len(params["means"])
+        dev = grads.device
         if state["grad2d"] is None:
-            state["grad2d"] = torch.zeros(n, device=grads.device)
-            state["count"] = torch.zeros(n, device=grads.device)
-        norm = grads.norm(dim=-1) * sel
-        state["grad2d"] += norm.sum(0)
-        state["count"] += sel.sum(0).to(state["count"].dtype)
+            state["grad2d"] = torch.zeros(n, device=dev)
+            state["count"] = torch.zeros(n, device=dev)
+        if "radii" in state and state["radii"] is None:
+            state["radii"] = torch.zeros(n, device=dev)
+        radii = info["radii"]
+        sel = (radii > 0).all(dim=-1) if radii.dim() == 3 else radii > 0      # [C, N]
+        gs_ids = torch.where(sel)[1]
+        state["grad2d"].index_add_(0, gs_ids, grads[sel].norm(dim=-1))
+        state["count"].index_add_(0, gs_ids, torch.ones_like(gs_ids, dtype=torch.float32))
+        if state.get("radii") is not None:
+            r = radii.max(dim=-1).values if radii.dim() == 3 else radii
+            norm_r = r[sel].float() / float(max(info["width"], info["height"]))
+            state["radii"][gs_ids] = torch.maximum(state["radii"][gs_ids], norm_r)
+
+    @torch.no_grad()
+    def _grow_gs(self, params, optimizers, state: Dict[str, Any], step: int) -> Tuple[int, int]:
+        count = state["count"]
+        grads = state["grad2d"] / count.clamp_min(1)
+        is_grad_high = grads > self.grow_grad2d
+        is_small = torch.exp(params["scales"]).max(dim=-1).values <= self.grow_scale3d * state["scene_scale"]
+        is_dupli = is_grad_high & is_small
+        n_dupli = int(is_dupli.sum().item())
+        is_split = is_grad_high & ~is_small
+        if step < self.refine_scale2d_stop_iter and state.get("radii") is not None:
+            is_split |= state["radii"] > self.grow_scale2d
+        n_split = int(is_split.sum().item())
+        if n_dupli > 0:
+            duplicate(params, optimizers, state, is_dupli)
+        is_split = torch.cat([is_split, torch.zeros(n_dupli, dtype=torch.bool, device=is_split.device)])
+        if n_split > 0:
+            split(params, optimizers, state, is_split, revised_opacity=self.revised_opacity)
+        return n_dupli, n_split
+
+    @torch.no_grad()
+    def _prune_gs(self, params, optimizers, state: Dict[str, Any], step: int) -> int:
+        is_prune = torch.sigmoid(params["opacities"].flatten()) < self.prune_opa
+        if step > self.reset_every:
+            is_too_big = torch.exp(params["scales"]).max(dim=-1).values > self.prune_scale3d * state["scene_scale"]
+            if step < self.refine_scale2d_stop_iter and state.get("radii") is not None:
+                is_too_big |= state["radii"] > self.prune_scale2d
+            is_prune = is_prune | is_too_big
+        n_prune = int(is_prune.sum().item())
+        if n_prune > 0:
+            remove(params, optimizers, state, is_prune)
+        return n_prune

@@ -48,20 +48,94 @@ def test_get_outputs_rejects_non_camera(capsys):
     assert "not a camera" in capsys.readouterr().out
 
 
-def test_strategy_surface():
+def _toy_training_state(n=12, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    params = torch.nn.ParameterDict({
+        "means": torch.nn.Parameter(torch.randn(n, 3, generator=g)),
+        "scales": torch.nn.Parameter(torch.log(torch.full((n, 3), 0.005))),
+        "quats": torch.nn.Parameter(torch.randn(n, 4, generator=g)),
+        "opacities": torch.nn.Parameter(torch.full((n, 1), 2.0)),
+        "features_dc": torch.nn.Parameter(torch.rand(n, 3, generator=g)),
+        "features_rest": torch.nn.Parameter(torch.rand(n, 15, 3, generator=g)),
+    })
+    optimizers = {k: torch.optim.Adam([v], lr=1e-3) for k, v in params.items()}
+    for k, v in params.items():                       # one step so that every optimizer has moments
+        v.grad = torch.ones_like(v)
+        optimizers[k].step()
+    return params, optimizers
+
+
+def test_strategy_surface_and_statistics():
     s = DefaultStrategy(absgrad=True)
     st = s.initialize_state()
+    params, _ = _toy_training_state(4)
     x = torch.zeros(1, 4, 2, requires_grad=True)
     m2d = x * 2.0
-    info = {"means2d": m2d, "radii": torch.ones(1, 4, 2, dtype=torch.int32), "width": 8, "height": 4, "n_cameras": 1}
-    s.step_pre_backward({}, {}, st, 0, info)
+    radii = torch.ones(1, 4, 2, dtype=torch.int32)
+    radii[0, 3] = 0                                    # culled Gaussian: no statistics
+    info = {"means2d": m2d, "radii": radii, "width": 8, "height": 4, "n_cameras": 1}
+    s.step_pre_backward(params, {}, st, 0, info)
     m2d.sum().backward()
-    assert m2d.grad is not None                                       # retained on the non-leaf
+    assert m2d.grad is not None                        # retained on the non-leaf (rade_gs_model.py:191-198)
     m2d.absgrad = torch.ones(1, 4, 2)
-    s.step_post_backward({}, {}, st, 0, info)
-    assert torch.allclose(st["grad2d"], torch.full((4,), float(np.hypot(4.0, 2.0))))
+    assert s.step_post_backward(params, {}, st, 1, info) == (0, 0, 0)
+    expect = float(np.hypot(8 / 2.0, 4 / 2.0))         # |grad| in normalised-device units
+    assert torch.allclose(st["grad2d"], torch.tensor([expect, expect, expect, 0.0]))
+    assert st["count"].tolist() == [1, 1, 1, 0]
     with pytest.raises(AssertionError):
-        s.step_pre_backward({}, {}, st, 0, {})
+        s.step_pre_backward(params, {}, st, 0, {})
+    with pytest.raises(NotImplementedError):
+        s.step_post_backward(params, {}, st, 1, info, packed=True)
+    assert s.step_post_backward(params, {}, st, s.refine_stop_iter, info) == (0, 0, 0)
+
+
+def test_strategy_densification_duplicate_split_prune_reset():
+    """Adaptive density control (3DGS section 5) on a toy state: who is duplicated / split / pruned, and that
+    parameters, optimizer moments and statistics stay aligned."""
+    n = 12
+    params, optimizers = _toy_training_state(n)
+    s = DefaultStrategy(refine_start_iter=0, refine_every=10, reset_every=3000, grow_grad2d=0.5, grow_scale3d=0.01,
+                        prune_opa=0.005)
+    st = s.initialize_state(scene_scale=1.0)
+    with torch.no_grad():
+        params["scales"][4:8] = float(np.log(0.05))           # 4..7 are "large"
+        params["opacities"][10:12] = -9.0                     # 10, 11 are transparent
+    grad = torch.zeros(1, n, 2)
+    grad[0, [0, 1, 4, 5], 0] = 1.0                            # 0,1 (small) and 4,5 (large) have high 2-D gradients
+    m2d = torch.zeros(1, n, 2, requires_grad=True)
+    m2d.grad = grad
+    info = {"means2d": m2d, "radii": torch.ones(1, n, 2, dtype=torch.int32), "width": 2, "height": 2, "n_cameras": 1}
+    old_means = params["means"].detach().clone()
+    n_dup, n_split, n_prune = s.step_post_backward(params, optimizers, st, 10, info)
+    assert (n_dup, n_split, n_prune) == (2, 2, 2)
+    n_new = n + 2 + 2 - 2                                     # +2 copies, +2 (split: 2 in, 4 out), -2 pruned
+    for k, v in params.items():
+        assert v.shape[0] == n_new, k
+        opt = optimizers[k]
+        assert opt.param_groups[0]["params"][0] is v          # the optimizer follows the new tensor
+        assert opt.state[v]["exp_avg"].shape == v.shape and opt.state[v]["exp_avg_sq"].shape == v.shape
+    assert st["grad2d"].shape == (n_new,) and not st["grad2d"].any() and not st["count"].any()
+    # survivors keep their moments, new Gaussians start from zero moments
+    ea = optimizers["means"].state[params["means"]]["exp_avg"]
+    assert ea[:6].abs().min() > 0 and not ea[-4:].any()
+    # the split children: scales / 1.6, means scattered around the parent within a few sigma
+    assert torch.allclose(torch.exp(params["scales"][-4:]), torch.full((4, 3), 0.05 / 1.6))
+    parents = old_means[[4, 5]].repeat(2, 1)
+    assert (params["means"][-4:] - parents).abs().max() < 0.05 * 6
+    assert torch.sigmoid(params["opacities"]).min() > 0.005   # transparent ones are gone
+    # opacity reset at reset_every: logits clamped to logit(2 * prune_opa), moments forgotten
+    s2 = DefaultStrategy(refine_start_iter=10 ** 6, reset_every=20, prune_opa=0.005)
+    m2d2 = torch.zeros(1, n_new, 2, requires_grad=True)
+    m2d2.grad = torch.zeros(1, n_new, 2)
+    info2 = {"means2d": m2d2, "radii": torch.ones(1, n_new, 2, dtype=torch.int32), "width": 2, "height": 2, "n_cameras": 1}
+    s2.step_post_backward(params, optimizers, s2.initialize_state(), 20, info2)
+    cap = np.log(0.01 / 0.99)
+    assert params["opacities"].max().item() <= cap + 1e-6
+    assert not optimizers["opacities"].state[params["opacities"]]["exp_avg"].any()
+    # a training step still works after the surgery
+    for k, v in params.items():
+        v.grad = torch.ones_like(v)
+        optimizers[k].step()
 
 
 def test_synthetic_scene_is_deterministic_and_in_spec():
