@@ -550,6 +550,23 @@ def test_end_to_end_optimisation_recovers_a_scene(dev):
     assert all(torch.isfinite(p).all() for p in params.values())
 
 
+def test_training_loop_with_densification(dev):
+    """Model mirror + one Adam per parameter group + DefaultStrategy refinement every 25 steps, multi-view: the loss
+    falls, the scene is resized, and parameters / optimizer moments stay aligned throughout."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "train_synthetic", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "train_synthetic.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    log = mod.train(steps=120, n=3000, W=160, H=96, n_views=4, refine_every=25, verbose=False)
+    losses = [l for l, _, _ in log]
+    assert all(np.isfinite(losses))
+    assert np.mean(losses[-8:]) < 0.75 * np.mean(losses[:8]), (losses[:8], losses[-8:])     # L1 colour loss
+    sizes = {n for _, n, _ in log}
+    assert len(sizes) > 1                                                 # densification resized the scene
+    assert sum(sum(c) for _, _, c in log) > 0
+
+
 # ---------------------------------------------------------------- BASELINE full size: properties
 @pytest.fixture(scope="module")
 def full(dev):
