@@ -76,11 +76,14 @@ def cpu_baseline(args, seed: int):
     cd = 4 if args.render_mode == "RGB+ED" else 3
     ups = [torch.rand(s, generator=g).numpy() for s in ((H, W, cd), (H, W, 1), (H, W, 1), (H, W, 1), (H, W, 3))]
 
+    ref = {}
+
     def one():
         st = cr.forward(sc["means"].numpy(), sc["quats"].numpy(), scales, op, sc["sh"].numpy(),
                         sc["viewmats"][0].numpy(), sc["Ks"][0].numpy(), W, H, sh_degree=3,
                         render_mode=args.render_mode, rasterize_mode=args.rasterize_mode)
-        cr.backward(st, *ups)
+        ref["grads"] = cr.backward(st, *ups)
+        ref["render"] = st["render"]
         return st["bins"]["n_isects"]
 
     one()  # warm-up (page-in, thread pool)
@@ -92,9 +95,35 @@ def cpu_baseline(args, seed: int):
         if time.perf_counter() - t0 > 10.0 or reps >= 20:
             break
     dt = (time.perf_counter() - t0) / reps
-    return {"value": round(n / dt / 1e6, 4), "unit": "Msplats/s", "cores": cr.threads, "kind": "port",
+    base = {"value": round(n / dt / 1e6, 4), "unit": "Msplats/s", "cores": cr.threads, "kind": "port",
             "sample": f"{n} Gaussians (same generator, seed {seed}), {W}x{H}, {args.render_mode} fwd+bwd, "
                       f"{reps} timed iteration(s) after 1 warm-up, {isects} intersections, C/OpenMP fp32"}
+    return base, parity_on_sample(args, sc, scales, op, ups, ref)
+
+
+def parity_on_sample(args, sc, scales, op, ups, ref):
+    """The second half of the metric ("grad max-rel-err vs reference"): HIP gradients against the C port
+    (the checker; the upstream CUDA reference is absent -- parity unpinned) on the
+    cpu_baseline sample.  tensor-inf-norm relative error  max|g - g_ref| / max|g_ref|  per parameter."""
+    import numpy as np
+    from collab_splats_amd.rendering import rasterization
+    dev = torch.device("cuda", torch.cuda.current_device())
+    leaves = [sc["means"].to(dev).requires_grad_(True), sc["quats"].to(dev).requires_grad_(True),
+              torch.from_numpy(scales).to(dev).requires_grad_(True), torch.from_numpy(op).to(dev).requires_grad_(True),
+              sc["sh"].to(dev).requires_grad_(True)]
+    out = rasterization(*leaves, sc["viewmats"].to(dev), sc["Ks"].to(dev), args.width, args.height, sh_degree=3,
+                        render_mode=args.render_mode, rasterize_mode=args.rasterize_mode, return_depth_normal=True)
+    torch.autograd.backward(list(out[:5]), [torch.from_numpy(u)[None].to(dev) for u in ups])
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+    names = ("v_means", "v_quats", "v_scales", "v_opacities", "v_colors")
+    errs = {k[2:]: rel(l.grad.cpu().numpy(), ref["grads"][k]) for k, l in zip(names, leaves)}
+    return {"value": max(errs.values()), "per_tensor": {k: float(f"{v:.3e}") for k, v in errs.items()},
+            "against": "oracle/craster.c (fp32 C port; upstream gsplat-rade absent: parity unpinned)",
+            "target": 1e-4}
 
 
 def main():
@@ -188,7 +217,8 @@ def main():
                          "note": "blend kernels are VALU (v_exp/FMA) bound, not HBM bound: see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, seed)
+            line["cpu_baseline"], line["grad_max_rel_err"] = cpu_baseline(args, seed)
+            line["grad_max_rel_err"]["value"] = float(f"{line['grad_max_rel_err']['value']:.3e}")
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
