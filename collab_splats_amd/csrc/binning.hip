@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void tile_emit_ordered_kernel(int64_t total, i
     // slot_ids == NULL: only the Gaussian row is emitted (it is then the sort payload)
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < total;
          r += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t idx = order[r];
+        const int64_t idx = order ? (int64_t)order[r] : r;       // order == NULL: rows in their own order
         int rx = radii[2 * idx], ry = radii[2 * idx + 1];
         if (!(rx > 0 || ry > 0)) continue;
         int x0, x1, y0, y1;
@@ -199,6 +199,292 @@ __global__ __launch_bounds__(256) void depth_keys32_kernel(int64_t total, const 
         const bool vis = radii[2 * idx] > 0 || radii[2 * idx + 1] > 0;
         keys[idx] = vis ? __float_as_uint(depths[idx]) : 0xffffffffu;
         ids[idx] = (int32_t)idx;
+    }
+}
+
+// ---- per-tile ordering: after the intersections have been bucketed by tile with a STABLE sort of
+// pairs emitted in row order (so every bucket is in ascending row order), ONE workgroup per tile sorts
+// its bucket by the 32 depth bits with a stable LSD radix sort (4 passes x 8 bits) -- which yields
+// exactly the (tile, depth, Gaussian id) order of the global key sort.  Tile lists are short (hundreds
+// to a few thousand entries): they live in LDS, and 8 000+ independent workgroups replace the ~20
+// launch-latency-bound kernels of a global 32-bit depth sort of the rows.
+// Per pass: per-wave digit histograms (LDS atomics) -> exclusive scan over (digit, wave) -> every wave
+// walks its contiguous chunk 64 entries at a time in order, peers found with one __ballot per digit
+// bit, rank = popcount of the lower peers (the scheme of csrc/sort.hip at workgroup scope).
+// GLOBAL = true: the ping-pong buffers live in global scratch (lists longer than the largest LDS class).
+// Register-resident classes: a bucket of n <= 64*WAVES*R entries; wave w owns the contiguous entries
+// [w*64R, (w+1)*64R) and lane l holds entries w*64R + r*64 + l (r < R) in registers for the whole sort.
+// Keys are the depth bits minus the bucket's minimum, so only bits = 32 - clz(max - min) of them can
+// differ: the sort runs ceil(bits / 9) passes of equal width (<= 9 bits, typically 3 passes instead of
+// 4 fixed 8-bit ones, 0 for a bucket of equal depths).  LDS holds the exchange buffer (8 B per entry) and
+// two [512 digits][WAVES] histograms used alternately (the idle one is cleared during the scan, saving a
+// barrier).  The histogram is digit-major, so the exclusive scan over (digit, wave) is a flat scan in
+// which every thread owns 8 consecutive counters; wave-level scans and reductions are DPP (row_shr /
+// row_bcast), not LDS permutes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_take(uint32_t ident, uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+// inclusive wave scan: lane i ends with op(x_0 .. x_i); lane 63 holds the wave total
+template <class Op>
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x, uint32_t ident, Op op) {
+    x = op(x, dpp_take<0x111, 0xF>(ident, x));      // row_shr:1
+    x = op(x, dpp_take<0x112, 0xF>(ident, x));      // row_shr:2
+    x = op(x, dpp_take<0x114, 0xF>(ident, x));      // row_shr:4
+    x = op(x, dpp_take<0x118, 0xF>(ident, x));      // row_shr:8
+    x = op(x, dpp_take<0x142, 0xA>(ident, x));      // row_bcast:15 -> rows 1, 3
+    x = op(x, dpp_take<0x143, 0xC>(ident, x));      // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+template <int WAVES, int R, bool HAS_VALS>
+__global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t* __restrict__ offsets, int n_tiles,
+                                                                   int64_t n_isects, int lo, int hi,
+                                                                   const float* __restrict__ depths,
+                                                                   const int32_t* __restrict__ isect_gid,
+                                                                   int32_t* __restrict__ payload,
+                                                                   int32_t* __restrict__ flatten_ids) {
+    constexpr int THREADS = 64 * WAVES, CAP = THREADS * R, DIG = 512;
+    __shared__ uint32_t xk[CAP], xv[CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t hist2[2][DIG * WAVES];
+    __shared__ uint32_t wsum[WAVES];
+    __shared__ uint32_t kmin_s, kmax_s;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xffffffffu;
+    const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int beg = offsets[t];
+        const int end = (t + 1 < n_tiles) ? offsets[t + 1] : (int)n_isects;
+        const int n = end - beg;
+        if (n <= lo || n > hi) continue;               // uniform over the block (n >= 1 from here)
+        uint32_t key[R], val[R];
+        int32_t row[R];
+        // all loads of one level are issued before the first use (index clamped instead of predicated)
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = wave * 64 * R + r * 64 + lane;
+            val[r] = (uint32_t)payload[beg + (i < n ? i : 0)];
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) row[r] = HAS_VALS ? isect_gid[val[r]] : (int32_t)val[r];
+#pragma unroll
+        for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[row[r]]);
+        uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = wave * 64 * R + r * 64 + lane;
+            if (i < n) { mn = min(mn, key[r]); mx = max(mx, key[r]); }
+        }
+        if (threadIdx.x == 0) { kmin_s = 0xffffffffu; kmax_s = 0u; }
+        reinterpret_cast<uint4*>(hist2[0])[2 * threadIdx.x] = zero4;
+        reinterpret_cast<uint4*>(hist2[0])[2 * threadIdx.x + 1] = zero4;
+        mn = wave_scan_incl(mn, 0xffffffffu, [](uint32_t a, uint32_t b) { return min(a, b); });
+        mx = wave_scan_incl(mx, 0u, [](uint32_t a, uint32_t b) { return max(a, b); });
+        __syncthreads();
+        if (lane == 63 && wave * 64 * R < n) { atomicMin(&kmin_s, mn); atomicMax(&kmax_s, mx); }
+        __syncthreads();
+        const uint32_t kmin = kmin_s;
+        const uint32_t range = kmax_s - kmin;
+        const int bits = range ? 32 - __builtin_clz(range) : 0;
+        const int passes = (bits + 8) / 9;                            // 0 when every depth is equal
+        const int dbits = passes ? (bits + passes - 1) / passes : 0;  // <= 9
+#pragma unroll
+        for (int r = 0; r < R; r++) key[r] -= kmin;                   // idle lanes: never used
+        int hb = 0;
+        for (int pass = 0; pass < passes; pass++) {
+            const int shift = pass * dbits;
+            const uint32_t dmask = (1u << dbits) - 1u;
+            uint32_t* hist = hist2[hb];
+            uint32_t* hnext = hist2[hb ^ 1];
+            hb ^= 1;
+            uint32_t plo[R], phi[R];
+            // 1. peers of every entry inside its 64-entry round: one ballot per digit bit
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i = wave * 64 * R + r * 64 + lane;
+                const unsigned long long v = __ballot(i < n);
+                plo[r] = (uint32_t)v; phi[r] = (uint32_t)(v >> 32);
+            }
+            for (int bit = 0; bit < dbits; bit++) {
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    const uint32_t m = 0u - ((key[r] >> (shift + bit)) & 1u);      // 0 or ~0
+                    const unsigned long long bb = __ballot(m != 0u);
+                    plo[r] &= ~((uint32_t)bb ^ m);
+                    phi[r] &= ~((uint32_t)(bb >> 32) ^ m);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i = wave * 64 * R + r * 64 + lane;
+                const uint32_t dg = (key[r] >> shift) & dmask;
+                if (i < n && ((plo[r] & lt_lo) | (phi[r] & lt_hi)) == 0u) {
+                    const uint32_t cnt = (uint32_t)(__popc(plo[r]) + __popc(phi[r]));
+                    if (R == 1) hist[dg * WAVES + wave] = cnt;
+                    else atomicAdd(&hist[dg * WAVES + wave], cnt);
+                }
+            }
+            __syncthreads();
+            // 2. flat exclusive scan of hist[512*WAVES]: 8 consecutive counters per thread
+            const uint4 h0 = reinterpret_cast<uint4*>(hist)[2 * threadIdx.x];
+            const uint4 h1 = reinterpret_cast<uint4*>(hist)[2 * threadIdx.x + 1];
+            const uint32_t tot = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
+            const uint32_t incl = wave_scan_incl(tot, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+            if (lane == 63) wsum[wave] = incl;
+            reinterpret_cast<uint4*>(hnext)[2 * threadIdx.x] = zero4;
+            reinterpret_cast<uint4*>(hnext)[2 * threadIdx.x + 1] = zero4;
+            __syncthreads();
+            uint32_t e = incl - tot;
+#pragma unroll
+            for (int w = 0; w < WAVES; w++) e += (w < wave) ? wsum[w] : 0u;
+            uint4 e0, e1;
+            e0.x = e; e += h0.x; e0.y = e; e += h0.y; e0.z = e; e += h0.z; e0.w = e; e += h0.w;
+            e1.x = e; e += h1.x; e1.y = e; e += h1.y; e1.z = e; e += h1.z; e1.w = e;
+            reinterpret_cast<uint4*>(hist)[2 * threadIdx.x] = e0;
+            reinterpret_cast<uint4*>(hist)[2 * threadIdx.x + 1] = e1;
+            __syncthreads();
+            // 3. scatter through LDS in order: the rounds of one wave share and advance its digit cursors
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i = wave * 64 * R + r * 64 + lane;
+                const uint32_t dg = (key[r] >> shift) & dmask;
+                const uint32_t rank = (uint32_t)(__popc(plo[r] & lt_lo) + __popc(phi[r] & lt_hi));
+                if (i < n) {
+                    const uint32_t base = hist[dg * WAVES + wave];
+                    if (R > 1 && rank == 0u) hist[dg * WAVES + wave] = base + (uint32_t)(__popc(plo[r]) + __popc(phi[r]));
+                    xk[base + rank] = key[r];
+                    xv[base + rank] = val[r];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i = wave * 64 * R + r * 64 + lane;
+                if (i < n) { key[r] = xk[i]; val[r] = xv[i]; }
+            }
+            // the next pass accumulates into hnext (cleared above, a barrier has passed); xk/xv are next
+            // written only after two more barriers
+        }
+        if (HAS_VALS) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int i = wave * 64 * R + r * 64 + lane;
+                row[r] = isect_gid[i < n ? val[r] : 0u];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = wave * 64 * R + r * 64 + lane;
+            if (i < n) {
+                payload[beg + i] = (int32_t)val[r];
+                flatten_ids[beg + i] = HAS_VALS ? row[r] : (int32_t)val[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// Fallback for buckets longer than the largest register class: same algorithm, entries walked 64 at a
+// time per wave, ping-pong buffers in global scratch (GLOBAL) or dynamic LDS.
+template <int CAP, int WAVES, bool HAS_VALS, bool GLOBAL>
+__global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __restrict__ offsets, int n_tiles,
+                                                               int64_t n_isects, int lo, int hi,
+                                                               const float* __restrict__ depths,
+                                                               const int32_t* __restrict__ isect_gid,
+                                                               int32_t* __restrict__ payload,
+                                                               int32_t* __restrict__ flatten_ids,
+                                                               uint32_t* __restrict__ scratch) {
+    extern __shared__ uint32_t lds32[];
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    const int beg = offsets[t];
+    const int end = (t + 1 < n_tiles) ? offsets[t + 1] : (int)n_isects;
+    const int n = end - beg;
+    if (n <= lo || n > hi) continue;                 // another size class (uniform over the block)
+    constexpr int THREADS = 64 * WAVES;
+    // buffers: keys / values, ping and pong; hist[WAVES][256] always in LDS
+    uint32_t* hist = lds32;
+    uint32_t* buf = GLOBAL ? scratch + (size_t)beg * 4 : lds32 + WAVES * 256;
+    const int cap = GLOBAL ? n : CAP;
+    uint32_t* k0 = buf;
+    uint32_t* k1 = buf + cap;
+    uint32_t* v0 = buf + 2 * cap;
+    uint32_t* v1 = buf + 3 * cap;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < n; i += THREADS) {
+        const int32_t v = payload[beg + i];
+        const int32_t row = isect_gid ? isect_gid[v] : v;
+        k0[i] = __float_as_uint(depths[row]);
+        v0[i] = (uint32_t)v;
+    }
+    const int per = ((n + WAVES - 1) / WAVES + 63) & ~63;     // entries per wave, whole rounds
+    const int cbeg = min(wave * per, n), cend = min(cbeg + per, n);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t* kin = k0; uint32_t* vin = v0; uint32_t* kout = k1; uint32_t* vout = v1;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 8 * pass;
+        for (int b = threadIdx.x; b < WAVES * 256; b += THREADS) hist[b] = 0u;
+        if (GLOBAL) __threadfence_block();
+        __syncthreads();
+        for (int i = cbeg + lane; i < cend; i += 64) atomicAdd(&hist[wave * 256 + ((kin[i] >> shift) & 255u)], 1u);
+        __syncthreads();
+        // exclusive scan over (digit major, wave minor): thread d < 256 owns digit d
+        uint32_t tot = 0;
+        if (threadIdx.x < 256) {
+            for (int w = 0; w < WAVES; w++) { const uint32_t h = hist[w * 256 + threadIdx.x]; hist[w * 256 + threadIdx.x] = tot; tot += h; }
+        }
+        // block-exclusive scan of the 256 digit totals (4 waves of 64: wave scan + carry through LDS slot reuse)
+        __shared__ uint32_t wsum[4];
+        uint32_t incl = tot;
+        if (threadIdx.x < 256) {
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off);
+                if (lane >= off) incl += o;
+            }
+            if (lane == 63) wsum[wave] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            uint32_t carry = 0;
+            for (int w = 0; w < wave; w++) carry += wsum[w];
+            const uint32_t base = carry + incl - tot;
+            for (int w = 0; w < WAVES; w++) hist[w * 256 + threadIdx.x] += base;
+        }
+        __syncthreads();
+        for (int r = cbeg; r < cend; r += 64) {
+            const int i = r + lane;
+            const bool valid = i < cend;
+            const uint32_t key = valid ? kin[i] : 0u;
+            const uint32_t val = valid ? vin[i] : 0u;
+            const uint32_t dg = (key >> shift) & 255u;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) {
+                const bool on = (dg >> bit) & 1u;
+                const unsigned long long bb = __ballot(on);
+                peers &= on ? bb : ~bb;
+            }
+            const int rank = __popcll(peers & lt);
+            uint32_t pos = 0;
+            if (valid) pos = hist[wave * 256 + dg] + (uint32_t)rank;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) hist[wave * 256 + dg] += (uint32_t)__popcll(peers);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if (valid) { kout[pos] = key; vout[pos] = val; }
+        }
+        if (GLOBAL) __threadfence_block();
+        __syncthreads();
+        uint32_t* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    for (int i = threadIdx.x; i < n; i += THREADS) {
+        const int32_t v = (int32_t)vin[i];
+        payload[beg + i] = v;
+        flatten_ids[beg + i] = HAS_VALS ? isect_gid[v] : v;
+    }
+    __syncthreads();
     }
 }
 
@@ -351,4 +637,42 @@ extern "C" int misplat_depth_keys32(const misplat_params* p, const int32_t* radi
     hipLaunchKernelGGL(depth_keys32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
                        radii, depths, keys, ids);
     return check_launch();
+}
+
+// Sort every tile's bucket (ascending row order on entry) by the depth bits, stably.  payload: in/out
+// (rows, or emission slots when isect_gid != NULL); flatten_ids: out (rows in final order);
+// scratch: 4 * n_isects uint32, only touched by tiles longer than the largest LDS class (8192 entries).
+template <bool HAS_VALS>
+static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
+                            const int32_t* isect_gid, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,
+                            hipStream_t s) {
+    // size classes (entries per bucket): <=256 | <=1024 | <=2048 | <=8192 | longer (global scratch).
+    // Every class walks all tiles with a grid-stride loop and skips buckets of the other classes, so the
+    // rarely used classes cost a few hundred (not n_tiles) workgroups.
+    const int g0 = n_tiles < 8192 ? n_tiles : 8192;
+    const int g1 = n_tiles < 1024 ? n_tiles : 1024;
+    const int g2 = n_tiles < 256 ? n_tiles : 256;
+    hipLaunchKernelGGL((tile_sort_reg_kernel<4, 1, HAS_VALS>), dim3(g0), dim3(256), 0, s, offsets, n_tiles, n_isects, 0,
+                       256, depths, isect_gid, payload, flatten_ids);
+    hipLaunchKernelGGL((tile_sort_reg_kernel<4, 4, HAS_VALS>), dim3(g0), dim3(256), 0, s, offsets, n_tiles, n_isects,
+                       256, 1024, depths, isect_gid, payload, flatten_ids);
+    hipLaunchKernelGGL((tile_sort_reg_kernel<8, 4, HAS_VALS>), dim3(g1), dim3(512), 0, s, offsets, n_tiles, n_isects,
+                       1024, 2048, depths, isect_gid, payload, flatten_ids);
+    hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS>), dim3(g2), dim3(1024), 0, s, offsets, n_tiles, n_isects,
+                       2048, 8192, depths, isect_gid, payload, flatten_ids);
+    hipLaunchKernelGGL((tile_sort_kernel<0, 16, HAS_VALS, true>), dim3(g2), dim3(1024), (size_t)16 * 256 * 4, s,
+                       offsets, n_tiles, n_isects, 8192, 0x7fffffff, depths, isect_gid, payload, flatten_ids, scratch);
+    return check_launch();
+}
+
+extern "C" int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
+                                 const float* depths, const int32_t* isect_gid, int32_t* payload,
+                                 int32_t* flatten_ids, uint32_t* scratch, misplat_stream_t stream) {
+    if (n_isects < 0 || n_tiles_total < 1 || n_isects > 0x7fffffffLL || !scratch) return MISPLAT_EINVAL;
+    if (n_isects == 0) return MISPLAT_OK;
+    if (isect_gid)
+        return launch_tile_sort<true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids,
+                                      scratch, (hipStream_t)stream);
+    return launch_tile_sort<false>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
+                                   (hipStream_t)stream);
 }

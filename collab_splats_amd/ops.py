@@ -216,48 +216,57 @@ def _sort_ws_bytes(lib, kind: str, n: int, end_bit: int) -> int:
     return _WS_CACHE[key]
 
 
+# Ordering scheme: "pertile" = bucket by tile, then one workgroup per tile sorts its list by
+# (depth, row) in LDS; "twostage" = depth-sort the rows, emit in that order, stable sort on the tile bits.
+# Both give exactly the (tile, depth, Gaussian id) order of a one-shot 64-bit key sort.
+ORDERING = os.environ.get("MISPLAT_ORDERING", "pertile")
+
+
 @torch.no_grad()
 def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor) -> Dict[str, Tensor]:
     """Tile intersection + ordering + offsets.  One host read-back: n_isects.
 
-    Two-stage ordering (see include/misplat.h): depth-sort the rows once, emit in that order, then a
-    stable sort on the tile bits only -- bit-identical to the (tile << 32 | depth) key sort.  In the
-    default (atomic) backward mode the sort payload is the Gaussian row itself; the deterministic mode
-    carries the emission slot instead (the slab is indexed by it) and gathers the rows afterwards."""
+    In the default (atomic) backward mode the sort payload is the Gaussian row itself; the deterministic mode
+    carries the emission slot instead (the gradient slab is indexed by it)."""
     lib = _lib.load()
     dev = means2d.device
     total = P.n_gauss * P.n_cams
     n_tiles = P.tile_w * P.tile_h * P.n_cams
     deterministic = DETERMINISTIC_BACKWARD
+    pertile = ORDERING == "pertile"
     i32 = dict(device=dev, dtype=torch.int32)
     tiles_per_gauss = torch.empty(total, **i32)
     check(lib.misplat_tile_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), stream_ptr()),
           "misplat_tile_count")
-    # (1) rows in (camera, depth) order
-    ids, order = torch.empty(total, **i32), torch.empty(total, **i32)
-    if total > 0 and P.n_cams == 1:
-        dkeys = torch.empty(total, **i32)
-        dkeys_s = torch.empty_like(dkeys)
-        check(lib.misplat_depth_keys32(C.byref(P), ptr(radii), ptr(depths), ptr(dkeys), ptr(ids), stream_ptr()),
-              "misplat_depth_keys32")
-        _sort32(lib, dkeys, dkeys_s, ids, order, total, 32, SORT_BITS_DEPTH)
-    elif total > 0:
-        dkeys = torch.empty(total, device=dev, dtype=torch.int64)
-        dkeys_s = torch.empty_like(dkeys)
-        check(lib.misplat_depth_keys(C.byref(P), ptr(radii), ptr(depths), ptr(dkeys), ptr(ids), stream_ptr()),
-              "misplat_depth_keys")
-        end_bit = 32 + max(1, P.n_cams.bit_length())
-        ws_bytes = _sort_ws_bytes(lib, "u64", total, end_bit)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        check(lib.misplat_sort_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(dkeys), ptr(dkeys_s), ptr(ids), ptr(order),
-                                     C.c_int64(total), C.c_int32(end_bit), stream_ptr()), "misplat_sort_pairs")
-    tpg_ordered = tiles_per_gauss[order.long()]
+    order = None
+    if not pertile:
+        # rows in (camera, depth) order
+        ids, order = torch.empty(total, **i32), torch.empty(total, **i32)
+        if total > 0 and P.n_cams == 1:
+            dkeys = torch.empty(total, **i32)
+            dkeys_s = torch.empty_like(dkeys)
+            check(lib.misplat_depth_keys32(C.byref(P), ptr(radii), ptr(depths), ptr(dkeys), ptr(ids), stream_ptr()),
+                  "misplat_depth_keys32")
+            _sort32(lib, dkeys, dkeys_s, ids, order, total, 32, SORT_BITS_DEPTH)
+        elif total > 0:
+            dkeys = torch.empty(total, device=dev, dtype=torch.int64)
+            dkeys_s = torch.empty_like(dkeys)
+            check(lib.misplat_depth_keys(C.byref(P), ptr(radii), ptr(depths), ptr(dkeys), ptr(ids), stream_ptr()),
+                  "misplat_depth_keys")
+            end_bit = 32 + max(1, P.n_cams.bit_length())
+            ws_bytes = _sort_ws_bytes(lib, "u64", total, end_bit)
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+            check(lib.misplat_sort_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(dkeys), ptr(dkeys_s), ptr(ids), ptr(order),
+                                         C.c_int64(total), C.c_int32(end_bit), stream_ptr()), "misplat_sort_pairs")
+        tpg_ordered = tiles_per_gauss[order.long()]
+    else:
+        tpg_ordered = tiles_per_gauss
     incl = torch.cumsum(tpg_ordered, dim=0, dtype=torch.int64)
     n_isects = int(incl[-1].item()) if total > 0 else 0          # the one unavoidable sync
     if n_isects >= 2 ** 31:
         raise _lib.MisplatError(f"{n_isects} tile intersections exceed int32 indexing")
-    cum_ordered = (incl - tpg_ordered).contiguous()               # exclusive scan in depth order, int64
-    # (2) emit in depth order, (3) stable sort on the tile bits
+    cum_ordered = (incl - tpg_ordered).contiguous()               # exclusive scan in emission order, int64
+    # emit in that order, bucket by tile (stable radix on the tile bits)
     tile_ids = torch.empty(n_isects, **i32)
     isect_gid = torch.empty(n_isects, **i32)
     slots = torch.empty(n_isects, **i32) if deterministic else None
@@ -272,7 +281,15 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor) -> Dict
                 SORT_BITS_TILE)
     check(lib.misplat_tile_offsets32(ptr(tile_ids_s), C.c_int64(n_isects), C.c_int32(n_tiles), ptr(offsets),
                                      stream_ptr()), "misplat_tile_offsets32")
-    if deterministic:
+    if pertile and n_isects > 0:
+        # every tile's bucket -> (depth, row) order, one workgroup per tile, in LDS
+        flatten_ids = torch.empty(n_isects, **i32)
+        scratch = torch.empty(4 * n_isects, **i32)               # only touched by tiles longer than 8192 entries
+        check(lib.misplat_tile_sort(ptr(offsets), C.c_int32(n_tiles), C.c_int64(n_isects), ptr(depths.contiguous()),
+                                    ptr(isect_gid if deterministic else None), ptr(payload_s), ptr(flatten_ids),
+                                    ptr(scratch), stream_ptr()), "misplat_tile_sort")
+        slots_s = payload_s if deterministic else None
+    elif deterministic:
         slots_s = payload_s
         flatten_ids = isect_gid[slots_s.long()] if n_isects > 0 else payload_s
     else:
@@ -295,9 +312,12 @@ def isect_ids(bins: Dict[str, Tensor]) -> Tensor:
 def _cum_by_row(bins: Dict[str, Tensor]) -> Tensor:
     """First emission slot of every Gaussian row (deterministic backward only; built lazily)."""
     if "cum" not in bins:
-        cum = torch.empty_like(bins["cum_ordered"])
-        cum[bins["order"].long()] = bins["cum_ordered"]
-        bins["cum"] = cum
+        if bins["order"] is None:                      # emission was in row order already
+            bins["cum"] = bins["cum_ordered"]
+        else:
+            cum = torch.empty_like(bins["cum_ordered"])
+            cum[bins["order"].long()] = bins["cum_ordered"]
+            bins["cum"] = cum
     return bins["cum"]
 
 

@@ -183,6 +183,16 @@ int misplat_tile_offsets32(const uint32_t* tiles_sorted, int64_t n_isects, int32
 int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, const float* depths,
                       int64_t n_isects, uint64_t* isect_ids, misplat_stream_t stream);
 
+/* Per-tile ordering (the shipped path): after the intersections have been bucketed by tile with a
+ * STABLE sort of pairs emitted in ROW order (sort32_pairs on the tile bits -- no depth sort of the rows
+ * at all), one workgroup per tile sorts its bucket stably by the 32 depth bits (LSD radix in LDS),
+ * which is exactly the (tile, depth, id) order.  payload (in/out): rows, or emission slots when
+ * isect_gid != NULL (row = isect_gid[slot]); flatten_ids (out): rows in final order;
+ * scratch[4 * n_isects] backs the rare tiles longer than 8192 entries. */
+int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
+                      const float* depths, const int32_t* isect_gid, int32_t* payload,
+                      int32_t* flatten_ids, uint32_t* scratch, misplat_stream_t stream);
+
 /* Hand-written stable LSD radix sort of (uint32 key, int32 value) pairs on key bits
  * [begin_bit, end_bit), bits_per_pass (1..11) bits per pass, three launches per pass, no
  * inter-workgroup waiting (csrc/sort.hip).  keys_in / vals_in are not modified; the result is in

@@ -356,14 +356,21 @@ def test_sort_backends_give_identical_bins(dev, monkeypatch):
     args = [sc["means"].to(dev), sc["quats"].to(dev), torch.exp(sc["log_scales"]).to(dev),
             torch.sigmoid(sc["opacity_logits"]).to(dev), sc["sh"].to(dev), sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H]
     outs = {}
-    for backend in ("rocprim", "misplat"):
-        monkeypatch.setattr(ops, "SORT_BACKEND", backend)
-        outs[backend] = rasterization(*args, sh_degree=3, render_mode="RGB+ED", return_depth_normal=True)
-    a, b = outs["rocprim"], outs["misplat"]
-    assert torch.equal(a[5]["flatten_ids"], b[5]["flatten_ids"]) and torch.equal(a[5]["isect_offsets"], b[5]["isect_offsets"])
-    assert torch.equal(a[5]["isect_ids"], b[5]["isect_ids"])
-    for x, y in zip(a[:5], b[:5]):
-        assert torch.equal(x, y)
+    for ordering in ("pertile", "twostage"):
+        for backend in ("rocprim", "misplat"):
+            for det in (False, True):
+                monkeypatch.setattr(ops, "ORDERING", ordering)
+                monkeypatch.setattr(ops, "SORT_BACKEND", backend)
+                monkeypatch.setattr(ops, "DETERMINISTIC_BACKWARD", det)
+                outs[(ordering, backend, det)] = rasterization(*args, sh_degree=3, render_mode="RGB+ED",
+                                                               return_depth_normal=True)
+    a = outs[("twostage", "rocprim", False)]
+    for key, b in outs.items():
+        assert torch.equal(a[5]["flatten_ids"], b[5]["flatten_ids"]), key
+        assert torch.equal(a[5]["isect_offsets"], b[5]["isect_offsets"]), key
+        assert torch.equal(a[5]["isect_ids"], b[5]["isect_ids"]), key
+        for x, y in zip(a[:5], b[:5]):
+            assert torch.equal(x, y), key
 
 
 def test_split_sh_parameters_match_concatenated(dev):
