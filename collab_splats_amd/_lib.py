@@ -65,7 +65,10 @@ SYMBOLS = {
     "misplat_tile_offsets": (C.c_int, 8), "misplat_depth_keys": (C.c_int, 6),
     "misplat_tile_emit_ordered": (C.c_int, 9), "misplat_sort32_workspace_bytes": (C.c_size_t, 2),
     "misplat_sort32_pairs": (C.c_int, 9), "misplat_tile_offsets32": (C.c_int, 5),
-    "misplat_isect_ids": (C.c_int, 6), "misplat_tile_sort": (C.c_int, 9),
+    "misplat_isect_ids": (C.c_int, 6), "misplat_tile_sort": (C.c_int, 10),
+    "misplat_tile_hist": (C.c_int, 6),
+    "misplat_tile_scan": (C.c_int, 5),
+    "misplat_tile_scatter": (C.c_int, 9),
     "misplat_radix_workspace_bytes": (C.c_size_t, 4), "misplat_radix_sort_pairs": (C.c_int, 11), "misplat_depth_keys32": (C.c_int, 6), "misplat_pack": (C.c_int, 11),
     "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_bwd": (C.c_int, 21),
     "misplat_color_fwd_x": (C.c_int, 11), "misplat_color_bwd_x": (C.c_int, 9),

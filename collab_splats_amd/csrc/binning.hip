@@ -237,22 +237,141 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x, uint32_t ident, O
     return x;
 }
 
-template <int WAVES, int R, bool HAS_VALS>
+template <int WAVES, int R>
+struct tile_sort_lds {
+    static constexpr int CAP = 64 * WAVES * R, DIG = 512;
+    uint32_t xk[CAP], xv[CAP];
+    __attribute__((aligned(16))) uint32_t hist2[2][DIG * WAVES];
+    uint32_t wsum[WAVES];
+    uint32_t kmin, kmax;
+};
+
+// Stable ascending sort of the block's n (key, val) pairs held in registers (entry i = wave*64R + r*64 +
+// lane).  Every thread of the block calls it; returns the number of radix passes that ran (0: all keys
+// equal).  On return the registers hold the sorted pairs and, if a pass ran, L.xk holds the sorted keys
+// minus their minimum (what the tie check of the unordered mode compares).
+template <int WAVES, int R>
+__device__ __forceinline__ int tile_radix_regs(uint32_t (&key)[R], uint32_t (&val)[R], int n,
+                                               tile_sort_lds<WAVES, R>& L) {
+    constexpr int DIG = 512;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xffffffffu;
+    const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    (void)DIG;
+    uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = wave * 64 * R + r * 64 + lane;
+        if (i < n) { mn = min(mn, key[r]); mx = max(mx, key[r]); }
+    }
+    if (threadIdx.x == 0) { L.kmin = 0xffffffffu; L.kmax = 0u; }
+    reinterpret_cast<uint4*>(L.hist2[0])[2 * threadIdx.x] = zero4;
+    reinterpret_cast<uint4*>(L.hist2[0])[2 * threadIdx.x + 1] = zero4;
+    mn = wave_scan_incl(mn, 0xffffffffu, [](uint32_t a, uint32_t b) { return min(a, b); });
+    mx = wave_scan_incl(mx, 0u, [](uint32_t a, uint32_t b) { return max(a, b); });
+    __syncthreads();
+    if (lane == 63 && wave * 64 * R < n) { atomicMin(&L.kmin, mn); atomicMax(&L.kmax, mx); }
+    __syncthreads();
+    const uint32_t kmin = L.kmin;
+    const uint32_t range = L.kmax - kmin;
+    const int bits = range ? 32 - __builtin_clz(range) : 0;
+    const int passes = (bits + 8) / 9;                            // 0 when every key is equal
+    const int dbits = passes ? (bits + passes - 1) / passes : 0;  // <= 9
+#pragma unroll
+    for (int r = 0; r < R; r++) key[r] -= kmin;                   // idle lanes: never used
+    int hb = 0;
+    for (int pass = 0; pass < passes; pass++) {
+        const int shift = pass * dbits;
+        const uint32_t dmask = (1u << dbits) - 1u;
+        uint32_t* hist = L.hist2[hb];
+        uint32_t* hnext = L.hist2[hb ^ 1];
+        hb ^= 1;
+        uint32_t plo[R], phi[R];
+        // 1. peers of every entry inside its 64-entry round: one ballot per digit bit
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = wave * 64 * R + r * 64 + lane;
+            const unsigned long long v = __ballot(i < n);
+            plo[r] = (uint32_t)v; phi[r] = (uint32_t)(v >> 32);
+        }
+        for (int bit = 0; bit < dbits; bit++) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t m = 0u - ((key[r] >> (shift + bit)) & 1u);      // 0 or ~0
+                const unsigned long long bb = __ballot(m != 0u);
+                plo[r] &= ~((uint32_t)bb ^ m);
+                phi[r] &= ~((uint32_t)(bb >> 32) ^ m);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = wave * 64 * R + r * 64 + lane;
+            const uint32_t dg = (key[r] >> shift) & dmask;
+            if (i < n && ((plo[r] & lt_lo) | (phi[r] & lt_hi)) == 0u) {
+                const uint32_t cnt = (uint32_t)(__popc(plo[r]) + __popc(phi[r]));
+                if (R == 1) hist[dg * WAVES + wave] = cnt;
+                else atomicAdd(&hist[dg * WAVES + wave], cnt);
+            }
+        }
+        __syncthreads();
+        // 2. flat exclusive scan of hist[512*WAVES]: 8 consecutive counters per thread
+        const uint4 h0 = reinterpret_cast<uint4*>(hist)[2 * threadIdx.x];
+        const uint4 h1 = reinterpret_cast<uint4*>(hist)[2 * threadIdx.x + 1];
+        const uint32_t tot = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
+        const uint32_t incl = wave_scan_incl(tot, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+        if (lane == 63) L.wsum[wave] = incl;
+        reinterpret_cast<uint4*>(hnext)[2 * threadIdx.x] = zero4;
+        reinterpret_cast<uint4*>(hnext)[2 * threadIdx.x + 1] = zero4;
+        __syncthreads();
+        uint32_t e = incl - tot;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) e += (w < wave) ? L.wsum[w] : 0u;
+        uint4 e0, e1;
+        e0.x = e; e += h0.x; e0.y = e; e += h0.y; e0.z = e; e += h0.z; e0.w = e; e += h0.w;
+        e1.x = e; e += h1.x; e1.y = e; e += h1.y; e1.z = e; e += h1.z; e1.w = e;
+        reinterpret_cast<uint4*>(hist)[2 * threadIdx.x] = e0;
+        reinterpret_cast<uint4*>(hist)[2 * threadIdx.x + 1] = e1;
+        __syncthreads();
+        // 3. scatter through LDS in order: the rounds of one wave share and advance its digit cursors
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = wave * 64 * R + r * 64 + lane;
+            const uint32_t dg = (key[r] >> shift) & dmask;
+            const uint32_t rank = (uint32_t)(__popc(plo[r] & lt_lo) + __popc(phi[r] & lt_hi));
+            if (i < n) {
+                const uint32_t base = hist[dg * WAVES + wave];
+                if (R > 1 && rank == 0u) hist[dg * WAVES + wave] = base + (uint32_t)(__popc(plo[r]) + __popc(phi[r]));
+                L.xk[base + rank] = key[r];
+                L.xv[base + rank] = val[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = wave * 64 * R + r * 64 + lane;
+            if (i < n) { key[r] = L.xk[i]; val[r] = L.xv[i]; }
+        }
+        // the next pass accumulates into hnext (cleared above, a barrier has passed); xk/xv are next
+        // written only after two more barriers
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) key[r] += kmin;
+    return passes;
+}
+
+// UNORDERED: the bucket arrives in arbitrary order (filled with atomic cursors, misplat_tile_scatter).  The
+// depth sort alone is then only deterministic when all depths differ, so after it neighbours are compared
+// and a bucket with ties (rare in a real scene) is re-sorted by row and then, stably, by depth again.
+template <int WAVES, int R, bool HAS_VALS, bool UNORDERED>
 __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t* __restrict__ offsets, int n_tiles,
                                                                    int64_t n_isects, int lo, int hi,
                                                                    const float* __restrict__ depths,
                                                                    const int32_t* __restrict__ isect_gid,
                                                                    int32_t* __restrict__ payload,
                                                                    int32_t* __restrict__ flatten_ids) {
-    constexpr int THREADS = 64 * WAVES, CAP = THREADS * R, DIG = 512;
-    __shared__ uint32_t xk[CAP], xv[CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t hist2[2][DIG * WAVES];
-    __shared__ uint32_t wsum[WAVES];
-    __shared__ uint32_t kmin_s, kmax_s;
+    __shared__ tile_sort_lds<WAVES, R> L;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t lt_lo = lane < 32 ? ((1u << lane) - 1u) : 0xffffffffu;
-    const uint32_t lt_hi = lane < 32 ? 0u : ((1u << (lane - 32)) - 1u);
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int beg = offsets[t];
         const int end = (t + 1 < n_tiles) ? offsets[t + 1] : (int)n_isects;
@@ -270,108 +389,30 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
         for (int r = 0; r < R; r++) row[r] = HAS_VALS ? isect_gid[val[r]] : (int32_t)val[r];
 #pragma unroll
         for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[row[r]]);
-        uint32_t mn = 0xffffffffu, mx = 0u;
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int i = wave * 64 * R + r * 64 + lane;
-            if (i < n) { mn = min(mn, key[r]); mx = max(mx, key[r]); }
-        }
-        if (threadIdx.x == 0) { kmin_s = 0xffffffffu; kmax_s = 0u; }
-        reinterpret_cast<uint4*>(hist2[0])[2 * threadIdx.x] = zero4;
-        reinterpret_cast<uint4*>(hist2[0])[2 * threadIdx.x + 1] = zero4;
-        mn = wave_scan_incl(mn, 0xffffffffu, [](uint32_t a, uint32_t b) { return min(a, b); });
-        mx = wave_scan_incl(mx, 0u, [](uint32_t a, uint32_t b) { return max(a, b); });
-        __syncthreads();
-        if (lane == 63 && wave * 64 * R < n) { atomicMin(&kmin_s, mn); atomicMax(&kmax_s, mx); }
-        __syncthreads();
-        const uint32_t kmin = kmin_s;
-        const uint32_t range = kmax_s - kmin;
-        const int bits = range ? 32 - __builtin_clz(range) : 0;
-        const int passes = (bits + 8) / 9;                            // 0 when every depth is equal
-        const int dbits = passes ? (bits + passes - 1) / passes : 0;  // <= 9
-#pragma unroll
-        for (int r = 0; r < R; r++) key[r] -= kmin;                   // idle lanes: never used
-        int hb = 0;
-        for (int pass = 0; pass < passes; pass++) {
-            const int shift = pass * dbits;
-            const uint32_t dmask = (1u << dbits) - 1u;
-            uint32_t* hist = hist2[hb];
-            uint32_t* hnext = hist2[hb ^ 1];
-            hb ^= 1;
-            uint32_t plo[R], phi[R];
-            // 1. peers of every entry inside its 64-entry round: one ballot per digit bit
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int i = wave * 64 * R + r * 64 + lane;
-                const unsigned long long v = __ballot(i < n);
-                plo[r] = (uint32_t)v; phi[r] = (uint32_t)(v >> 32);
-            }
-            for (int bit = 0; bit < dbits; bit++) {
+        const int passes = tile_radix_regs<WAVES, R>(key, val, n, L);
+        if (UNORDERED) {
+            bool tie = false;
+            if (passes == 0) tie = n > 1;
+            else {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    const uint32_t m = 0u - ((key[r] >> (shift + bit)) & 1u);      // 0 or ~0
-                    const unsigned long long bb = __ballot(m != 0u);
-                    plo[r] &= ~((uint32_t)bb ^ m);
-                    phi[r] &= ~((uint32_t)(bb >> 32) ^ m);
+                    const int i = wave * 64 * R + r * 64 + lane;
+                    if (i + 1 < n && L.xk[i] == L.xk[i + 1]) tie = true;
                 }
             }
+            if (__syncthreads_or(tie)) {
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int i = wave * 64 * R + r * 64 + lane;
-                const uint32_t dg = (key[r] >> shift) & dmask;
-                if (i < n && ((plo[r] & lt_lo) | (phi[r] & lt_hi)) == 0u) {
-                    const uint32_t cnt = (uint32_t)(__popc(plo[r]) + __popc(phi[r]));
-                    if (R == 1) hist[dg * WAVES + wave] = cnt;
-                    else atomicAdd(&hist[dg * WAVES + wave], cnt);
-                }
+                for (int r = 0; r < R; r++) key[r] = HAS_VALS ? (uint32_t)isect_gid[val[r]] : val[r];
+                tile_radix_regs<WAVES, R>(key, val, n, L);            // by row
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[key[r]]);
+                tile_radix_regs<WAVES, R>(key, val, n, L);            // stably by depth
             }
-            __syncthreads();
-            // 2. flat exclusive scan of hist[512*WAVES]: 8 consecutive counters per thread
-            const uint4 h0 = reinterpret_cast<uint4*>(hist)[2 * threadIdx.x];
-            const uint4 h1 = reinterpret_cast<uint4*>(hist)[2 * threadIdx.x + 1];
-            const uint32_t tot = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
-            const uint32_t incl = wave_scan_incl(tot, 0u, [](uint32_t a, uint32_t b) { return a + b; });
-            if (lane == 63) wsum[wave] = incl;
-            reinterpret_cast<uint4*>(hnext)[2 * threadIdx.x] = zero4;
-            reinterpret_cast<uint4*>(hnext)[2 * threadIdx.x + 1] = zero4;
-            __syncthreads();
-            uint32_t e = incl - tot;
-#pragma unroll
-            for (int w = 0; w < WAVES; w++) e += (w < wave) ? wsum[w] : 0u;
-            uint4 e0, e1;
-            e0.x = e; e += h0.x; e0.y = e; e += h0.y; e0.z = e; e += h0.z; e0.w = e; e += h0.w;
-            e1.x = e; e += h1.x; e1.y = e; e += h1.y; e1.z = e; e += h1.z; e1.w = e;
-            reinterpret_cast<uint4*>(hist)[2 * threadIdx.x] = e0;
-            reinterpret_cast<uint4*>(hist)[2 * threadIdx.x + 1] = e1;
-            __syncthreads();
-            // 3. scatter through LDS in order: the rounds of one wave share and advance its digit cursors
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int i = wave * 64 * R + r * 64 + lane;
-                const uint32_t dg = (key[r] >> shift) & dmask;
-                const uint32_t rank = (uint32_t)(__popc(plo[r] & lt_lo) + __popc(phi[r] & lt_hi));
-                if (i < n) {
-                    const uint32_t base = hist[dg * WAVES + wave];
-                    if (R > 1 && rank == 0u) hist[dg * WAVES + wave] = base + (uint32_t)(__popc(plo[r]) + __popc(phi[r]));
-                    xk[base + rank] = key[r];
-                    xv[base + rank] = val[r];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int i = wave * 64 * R + r * 64 + lane;
-                if (i < n) { key[r] = xk[i]; val[r] = xv[i]; }
-            }
-            // the next pass accumulates into hnext (cleared above, a barrier has passed); xk/xv are next
-            // written only after two more barriers
         }
         if (HAS_VALS) {
 #pragma unroll
-            for (int r = 0; r < R; r++) {
-                const int i = wave * 64 * R + r * 64 + lane;
-                row[r] = isect_gid[i < n ? val[r] : 0u];
-            }
+            for (int r = 0; r < R; r++) row[r] = isect_gid[val[r]];
         }
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -385,9 +426,11 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
     }
 }
 
-// Fallback for buckets longer than the largest register class: same algorithm, entries walked 64 at a
-// time per wave, ping-pong buffers in global scratch (GLOBAL) or dynamic LDS.
-template <int CAP, int WAVES, bool HAS_VALS, bool GLOBAL>
+// Fallback for buckets longer than the largest register class: same algorithm with fixed 8-bit digits,
+// entries walked 64 at a time per wave, ping-pong buffers in global scratch (GLOBAL) or dynamic LDS.
+// UNORDERED: four passes over the row bits come first, so the result is the (depth, row) order whatever
+// the order of arrival.
+template <int CAP, int WAVES, bool HAS_VALS, bool GLOBAL, bool UNORDERED>
 __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __restrict__ offsets, int n_tiles,
                                                                int64_t n_isects, int lo, int hi,
                                                                const float* __restrict__ depths,
@@ -421,12 +464,17 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __
     const int cbeg = min(wave * per, n), cend = min(cbeg + per, n);
     const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t* kin = k0; uint32_t* vin = v0; uint32_t* kout = k1; uint32_t* vout = v1;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 8 * pass;
+    for (int pass = 0; pass < (UNORDERED ? 8 : 4); pass++) {
+        const bool by_row = UNORDERED && pass < 4;
+        const int shift = 8 * (pass & 3);
+        auto digit_of = [&](uint32_t k, uint32_t v) -> uint32_t {
+            const uint32_t src = by_row ? (HAS_VALS ? (uint32_t)isect_gid[v] : v) : k;
+            return (src >> shift) & 255u;
+        };
         for (int b = threadIdx.x; b < WAVES * 256; b += THREADS) hist[b] = 0u;
         if (GLOBAL) __threadfence_block();
         __syncthreads();
-        for (int i = cbeg + lane; i < cend; i += 64) atomicAdd(&hist[wave * 256 + ((kin[i] >> shift) & 255u)], 1u);
+        for (int i = cbeg + lane; i < cend; i += 64) atomicAdd(&hist[wave * 256 + digit_of(kin[i], vin[i])], 1u);
         __syncthreads();
         // exclusive scan over (digit major, wave minor): thread d < 256 owns digit d
         uint32_t tot = 0;
@@ -457,7 +505,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __
             const bool valid = i < cend;
             const uint32_t key = valid ? kin[i] : 0u;
             const uint32_t val = valid ? vin[i] : 0u;
-            const uint32_t dg = (key >> shift) & 255u;
+            const uint32_t dg = valid ? digit_of(key, val) : 0u;
             unsigned long long peers = __ballot(valid);
 #pragma unroll
             for (int bit = 0; bit < 8; bit++) {
@@ -485,6 +533,91 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __
         flatten_ids[beg + i] = HAS_VALS ? isect_gid[v] : v;
     }
     __syncthreads();
+    }
+}
+
+// ---- bucketing without a sort ("scatter" ordering): count the intersections of every tile with atomics,
+// scan the counts into offsets, then every intersection takes the next free slot of its tile's bucket
+// (atomic cursor).  The buckets come out in arbitrary order; misplat_tile_sort(unordered = 1) then
+// establishes the (depth, row) order inside each, so the result is deterministic all the same.
+__global__ __launch_bounds__(256) void tile_hist_kernel(int64_t total, int n_gauss, int tw, int th,
+                                                        const float* __restrict__ means2d,
+                                                        const int32_t* __restrict__ radii,
+                                                        int32_t* __restrict__ tiles_per_gauss,
+                                                        int32_t* __restrict__ tile_counts) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int rx = radii[2 * idx], ry = radii[2 * idx + 1];
+        int n = 0;
+        if (rx > 0 || ry > 0) {
+            int x0, x1, y0, y1;
+            tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rx, ry, tw, th, x0, x1, y0, y1);
+            n = (x1 - x0) * (y1 - y0);
+            int32_t* base = tile_counts + (int64_t)(idx / n_gauss) * (tw * th);
+            for (int ty = y0; ty < y1; ty++)
+                for (int tx = x0; tx < x1; tx++) atomicAdd(&base[ty * tw + tx], 1);
+        }
+        tiles_per_gauss[idx] = n;
+    }
+}
+
+// one workgroup: offsets = exclusive scan of the counts, total -> *n_isects; the counts are cleared so
+// the same buffer serves as the cursors of tile_scatter_kernel
+__global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, int32_t* __restrict__ counts,
+                                                         int32_t* __restrict__ offsets,
+                                                         int64_t* __restrict__ n_isects) {
+    __shared__ unsigned long long wsum[16];
+    const int per = (n_tiles + 1023) / 1024;
+    const int b = threadIdx.x * per, e = min(b + per, n_tiles);
+    unsigned long long tot = 0;
+    for (int i = b; i < e; i++) tot += (unsigned long long)counts[i];
+    // wave inclusive scan of 64-bit totals (shuffles: this kernel is launch-latency bound anyway)
+    unsigned long long incl = tot;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned long long carry = 0;
+    for (int w = 0; w < wave; w++) carry += wsum[w];
+    unsigned long long run = carry + incl - tot;
+    for (int i = b; i < e; i++) {
+        const int32_t c = counts[i];
+        offsets[i] = (int32_t)run;                 // meaningless beyond 2^31: the host checks *n_isects first
+        counts[i] = 0;
+        run += (unsigned long long)c;
+    }
+    if (threadIdx.x == 1023) *n_isects = (int64_t)(carry + incl);
+}
+
+// slot_base (deterministic backward): first emission slot of every row; the payload is then the emission
+// slot and isect_gid[slot] = row.  Otherwise the payload is the row itself.
+__global__ __launch_bounds__(256) void tile_scatter_kernel(int64_t total, int n_gauss, int tw, int th,
+                                                           const float* __restrict__ means2d,
+                                                           const int32_t* __restrict__ radii,
+                                                           const int32_t* __restrict__ offsets,
+                                                           int32_t* __restrict__ cursors,
+                                                           const int64_t* __restrict__ slot_base,
+                                                           int32_t* __restrict__ payload,
+                                                           int32_t* __restrict__ isect_gid) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int rx = radii[2 * idx], ry = radii[2 * idx + 1];
+        if (!(rx > 0 || ry > 0)) continue;
+        int x0, x1, y0, y1;
+        tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rx, ry, tw, th, x0, x1, y0, y1);
+        const int64_t tbase = (int64_t)(idx / n_gauss) * (tw * th);
+        int64_t j = slot_base ? slot_base[idx] : 0;
+        for (int ty = y0; ty < y1; ty++)
+            for (int tx = x0; tx < x1; tx++) {
+                const int64_t tile = tbase + ty * tw + tx;
+                const int pos = offsets[tile] + atomicAdd(&cursors[tile], 1);
+                if (slot_base) { payload[pos] = (int32_t)j; isect_gid[j] = (int32_t)idx; j++; }
+                else payload[pos] = (int32_t)idx;
+            }
     }
 }
 
@@ -642,7 +775,7 @@ extern "C" int misplat_depth_keys32(const misplat_params* p, const int32_t* radi
 // Sort every tile's bucket (ascending row order on entry) by the depth bits, stably.  payload: in/out
 // (rows, or emission slots when isect_gid != NULL); flatten_ids: out (rows in final order);
 // scratch: 4 * n_isects uint32, only touched by tiles longer than the largest LDS class (8192 entries).
-template <bool HAS_VALS>
+template <bool HAS_VALS, bool UNORDERED>
 static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
                             const int32_t* isect_gid, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,
                             hipStream_t s) {
@@ -652,27 +785,64 @@ static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_i
     const int g0 = n_tiles < 8192 ? n_tiles : 8192;
     const int g1 = n_tiles < 1024 ? n_tiles : 1024;
     const int g2 = n_tiles < 256 ? n_tiles : 256;
-    hipLaunchKernelGGL((tile_sort_reg_kernel<4, 1, HAS_VALS>), dim3(g0), dim3(256), 0, s, offsets, n_tiles, n_isects, 0,
-                       256, depths, isect_gid, payload, flatten_ids);
-    hipLaunchKernelGGL((tile_sort_reg_kernel<4, 4, HAS_VALS>), dim3(g0), dim3(256), 0, s, offsets, n_tiles, n_isects,
-                       256, 1024, depths, isect_gid, payload, flatten_ids);
-    hipLaunchKernelGGL((tile_sort_reg_kernel<8, 4, HAS_VALS>), dim3(g1), dim3(512), 0, s, offsets, n_tiles, n_isects,
-                       1024, 2048, depths, isect_gid, payload, flatten_ids);
-    hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS>), dim3(g2), dim3(1024), 0, s, offsets, n_tiles, n_isects,
-                       2048, 8192, depths, isect_gid, payload, flatten_ids);
-    hipLaunchKernelGGL((tile_sort_kernel<0, 16, HAS_VALS, true>), dim3(g2), dim3(1024), (size_t)16 * 256 * 4, s,
-                       offsets, n_tiles, n_isects, 8192, 0x7fffffff, depths, isect_gid, payload, flatten_ids, scratch);
+    hipLaunchKernelGGL((tile_sort_reg_kernel<4, 1, HAS_VALS, UNORDERED>), dim3(g0), dim3(256), 0, s, offsets, n_tiles,
+                       n_isects, 0, 256, depths, isect_gid, payload, flatten_ids);
+    hipLaunchKernelGGL((tile_sort_reg_kernel<4, 4, HAS_VALS, UNORDERED>), dim3(g0), dim3(256), 0, s, offsets, n_tiles,
+                       n_isects, 256, 1024, depths, isect_gid, payload, flatten_ids);
+    hipLaunchKernelGGL((tile_sort_reg_kernel<8, 4, HAS_VALS, UNORDERED>), dim3(g1), dim3(512), 0, s, offsets, n_tiles,
+                       n_isects, 1024, 2048, depths, isect_gid, payload, flatten_ids);
+    hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS, UNORDERED>), dim3(g2), dim3(1024), 0, s, offsets,
+                       n_tiles, n_isects, 2048, 8192, depths, isect_gid, payload, flatten_ids);
+    hipLaunchKernelGGL((tile_sort_kernel<0, 16, HAS_VALS, true, UNORDERED>), dim3(g2), dim3(1024),
+                       (size_t)16 * 256 * 4, s, offsets, n_tiles, n_isects, 8192, 0x7fffffff, depths, isect_gid,
+                       payload, flatten_ids, scratch);
     return check_launch();
 }
 
 extern "C" int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
                                  const float* depths, const int32_t* isect_gid, int32_t* payload,
-                                 int32_t* flatten_ids, uint32_t* scratch, misplat_stream_t stream) {
+                                 int32_t* flatten_ids, uint32_t* scratch, int32_t unordered,
+                                 misplat_stream_t stream) {
     if (n_isects < 0 || n_tiles_total < 1 || n_isects > 0x7fffffffLL || !scratch) return MISPLAT_EINVAL;
     if (n_isects == 0) return MISPLAT_OK;
+    hipStream_t s = (hipStream_t)stream;
     if (isect_gid)
-        return launch_tile_sort<true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids,
-                                      scratch, (hipStream_t)stream);
-    return launch_tile_sort<false>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
-                                   (hipStream_t)stream);
+        return unordered ? launch_tile_sort<true, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
+                                                        flatten_ids, scratch, s)
+                         : launch_tile_sort<true, false>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
+                                                         flatten_ids, scratch, s);
+    return unordered ? launch_tile_sort<false, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
+                                                     flatten_ids, scratch, s)
+                     : launch_tile_sort<false, false>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
+                                                      flatten_ids, scratch, s);
+}
+
+extern "C" int misplat_tile_hist(const misplat_params* p, const float* means2d, const int32_t* radii,
+                                 int32_t* tiles_per_gauss, int32_t* tile_counts, misplat_stream_t stream) {
+    if (!p || p->tile_size != MISPLAT_TILE) return MISPLAT_EINVAL;
+    int64_t total = (int64_t)p->n_gauss * p->n_cams;
+    if (total == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(tile_hist_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
+                       p->n_gauss, p->tile_w, p->tile_h, means2d, radii, tiles_per_gauss, tile_counts);
+    return check_launch();
+}
+
+extern "C" int misplat_tile_scan(int32_t n_tiles_total, int32_t* tile_counts, int32_t* offsets, int64_t* n_isects,
+                                 misplat_stream_t stream) {
+    if (n_tiles_total < 1 || !tile_counts || !offsets || !n_isects) return MISPLAT_EINVAL;
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles_total, tile_counts,
+                       offsets, n_isects);
+    return check_launch();
+}
+
+extern "C" int misplat_tile_scatter(const misplat_params* p, const float* means2d, const int32_t* radii,
+                                    const int32_t* offsets, int32_t* cursors, const int64_t* slot_base,
+                                    int32_t* payload, int32_t* isect_gid, misplat_stream_t stream) {
+    if (!p || p->tile_size != MISPLAT_TILE || (slot_base && !isect_gid)) return MISPLAT_EINVAL;
+    int64_t total = (int64_t)p->n_gauss * p->n_cams;
+    if (total == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
+                       p->n_gauss, p->tile_w, p->tile_h, means2d, radii, offsets, cursors, slot_base, payload,
+                       isect_gid);
+    return check_launch();
 }

@@ -183,15 +183,33 @@ int misplat_tile_offsets32(const uint32_t* tiles_sorted, int64_t n_isects, int32
 int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, const float* depths,
                       int64_t n_isects, uint64_t* isect_ids, misplat_stream_t stream);
 
-/* Per-tile ordering (the shipped path): after the intersections have been bucketed by tile with a
- * STABLE sort of pairs emitted in ROW order (sort32_pairs on the tile bits -- no depth sort of the rows
- * at all), one workgroup per tile sorts its bucket stably by the 32 depth bits (LSD radix in LDS),
- * which is exactly the (tile, depth, id) order.  payload (in/out): rows, or emission slots when
- * isect_gid != NULL (row = isect_gid[slot]); flatten_ids (out): rows in final order;
- * scratch[4 * n_isects] backs the rare tiles longer than 8192 entries. */
+/* Per-tile ordering: once the intersections have been bucketed by tile, one workgroup per tile sorts
+ * its bucket by the 32 depth bits with a stable LSD radix sort whose entries stay in registers (exchange
+ * through LDS), which is exactly the (tile, depth, id) order -- no global depth sort at all.
+ *   unordered = 0: every bucket arrives in ascending row order (stable sort32_pairs on the tile bits of
+ *                  pairs emitted in row order, ordering "pertile");
+ *   unordered = 1: buckets arrive in arbitrary order (misplat_tile_scatter, ordering "scatter", the
+ *                  shipped path); buckets with equal depths are re-sorted by (row, then depth).
+ * payload (in/out): rows, or emission slots when isect_gid != NULL (row = isect_gid[slot]);
+ * flatten_ids (out): rows in final order; scratch[4 * n_isects] backs the rare tiles longer than 8192. */
 int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
                       const float* depths, const int32_t* isect_gid, int32_t* payload,
-                      int32_t* flatten_ids, uint32_t* scratch, misplat_stream_t stream);
+                      int32_t* flatten_ids, uint32_t* scratch, int32_t unordered, misplat_stream_t stream);
+
+/* Bucketing without a sort ("scatter" ordering; replaces tile_count + tile_emit + the tile-id sort +
+ * tile_offsets of gsplat's isect_tiles / isect_offset_encode):
+ *   tile_hist    tiles_per_gauss[C*N] and, with atomics, tile_counts[C*tiles] (+=; caller zeroes it);
+ *   tile_scan    offsets = exclusive scan of tile_counts, *n_isects = total (device int64), and
+ *                tile_counts cleared again so that the same buffer is the cursor array of
+ *   tile_scatter payload[offsets[tile] + cursor[tile]++] = row (or the emission slot slot_base[row] + j,
+ *                with isect_gid[slot] = row, when slot_base != NULL: deterministic backward). */
+int misplat_tile_hist(const misplat_params* p, const float* means2d, const int32_t* radii,
+                      int32_t* tiles_per_gauss, int32_t* tile_counts, misplat_stream_t stream);
+int misplat_tile_scan(int32_t n_tiles_total, int32_t* tile_counts, int32_t* offsets, int64_t* n_isects,
+                      misplat_stream_t stream);
+int misplat_tile_scatter(const misplat_params* p, const float* means2d, const int32_t* radii,
+                         const int32_t* offsets, int32_t* cursors, const int64_t* slot_base,
+                         int32_t* payload, int32_t* isect_gid, misplat_stream_t stream);
 
 /* Hand-written stable LSD radix sort of (uint32 key, int32 value) pairs on key bits
  * [begin_bit, end_bit), bits_per_pass (1..11) bits per pass, three launches per pass, no

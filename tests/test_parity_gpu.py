@@ -356,7 +356,7 @@ def test_sort_backends_give_identical_bins(dev, monkeypatch):
     args = [sc["means"].to(dev), sc["quats"].to(dev), torch.exp(sc["log_scales"]).to(dev),
             torch.sigmoid(sc["opacity_logits"]).to(dev), sc["sh"].to(dev), sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H]
     outs = {}
-    for ordering in ("pertile", "twostage"):
+    for ordering in ("scatter", "pertile", "twostage"):
         for backend in ("rocprim", "misplat"):
             for det in (False, True):
                 monkeypatch.setattr(ops, "ORDERING", ordering)
@@ -369,6 +369,39 @@ def test_sort_backends_give_identical_bins(dev, monkeypatch):
         assert torch.equal(a[5]["flatten_ids"], b[5]["flatten_ids"]), key
         assert torch.equal(a[5]["isect_offsets"], b[5]["isect_offsets"]), key
         assert torch.equal(a[5]["isect_ids"], b[5]["isect_ids"]), key
+        for x, y in zip(a[:5], b[:5]):
+            assert torch.equal(x, y), key
+
+
+@pytest.mark.parametrize("n,size", [(40_000, (320, 200)), (30_000, (48, 32))])
+def test_orderings_agree_with_depth_ties_and_long_buckets(dev, monkeypatch, n, size):
+    """Buckets filled through atomic cursors arrive in arbitrary order: equal depths must still come out in
+    Gaussian-id order (the tie path of the per-tile sort), for short buckets and for buckets longer than
+    every LDS class (48x32 image: 6 tiles share 30k Gaussians)."""
+    from collab_splats_amd import ops, rasterization
+    from collab_splats_amd.synthetic import random_scene
+    W, H = size
+    sc = random_scene(n, W, H, seed=21)
+    means = sc["means"].clone()
+    vm = sc["viewmats"][:1]
+    # camera-space depth quantised to a handful of exactly equal values
+    cam = means @ vm[0, :3, :3].T + vm[0, :3, 3]
+    cam[:, 2] = torch.round(cam[:, 2] * 2.0) / 2.0
+    means = (cam - vm[0, :3, 3]) @ vm[0, :3, :3]
+    args = [means.to(dev), sc["quats"].to(dev), torch.exp(sc["log_scales"]).to(dev),
+            torch.sigmoid(sc["opacity_logits"]).to(dev), sc["sh"].to(dev), vm.to(dev), sc["Ks"][:1].to(dev), W, H]
+    outs = {}
+    for ordering in ("scatter", "pertile", "twostage"):
+        for det in (False, True):
+            monkeypatch.setattr(ops, "ORDERING", ordering)
+            monkeypatch.setattr(ops, "DETERMINISTIC_BACKWARD", det)
+            outs[(ordering, det)] = rasterization(*args, sh_degree=3, render_mode="RGB+ED", return_depth_normal=True)
+    a = outs[("twostage", False)]
+    d = a[5]["depths"].flatten()[a[5]["flatten_ids"].long()]
+    assert (d[1:] == d[:-1]).float().mean() > 0.5                      # the scene really is full of ties
+    for key, b in outs.items():
+        assert torch.equal(a[5]["flatten_ids"], b[5]["flatten_ids"]), key
+        assert torch.equal(a[5]["isect_offsets"], b[5]["isect_offsets"]), key
         for x, y in zip(a[:5], b[:5]):
             assert torch.equal(x, y), key
 
