@@ -27,6 +27,22 @@ __device__ __forceinline__ void tile_rect(float mx, float my, int rxi, int ryi, 
     y0 = (int)(fy0 < fth ? fy0 : fth); y1 = (int)(fy1 < fth ? fy1 : fth);
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_take(uint32_t ident, uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+// inclusive wave scan: lane i ends with op(x_0 .. x_i); lane 63 holds the wave total
+template <class Op>
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x, uint32_t ident, Op op) {
+    x = op(x, dpp_take<0x111, 0xF>(ident, x));      // row_shr:1
+    x = op(x, dpp_take<0x112, 0xF>(ident, x));      // row_shr:2
+    x = op(x, dpp_take<0x114, 0xF>(ident, x));      // row_shr:4
+    x = op(x, dpp_take<0x118, 0xF>(ident, x));      // row_shr:8
+    x = op(x, dpp_take<0x142, 0xA>(ident, x));      // row_bcast:15 -> rows 1, 3
+    x = op(x, dpp_take<0x143, 0xC>(ident, x));      // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
 __global__ __launch_bounds__(256) void tile_count_kernel(int64_t total, int tw, int th,
                                                          const float* __restrict__ means2d,
                                                          const int32_t* __restrict__ radii,
@@ -221,22 +237,6 @@ __global__ __launch_bounds__(256) void depth_keys32_kernel(int64_t total, const 
 // barrier).  The histogram is digit-major, so the exclusive scan over (digit, wave) is a flat scan in
 // which every thread owns 8 consecutive counters; wave-level scans and reductions are DPP (row_shr /
 // row_bcast), not LDS permutes.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_take(uint32_t ident, uint32_t x) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)x, CTRL, ROW_MASK, 0xF, false);
-}
-// inclusive wave scan: lane i ends with op(x_0 .. x_i); lane 63 holds the wave total
-template <class Op>
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x, uint32_t ident, Op op) {
-    x = op(x, dpp_take<0x111, 0xF>(ident, x));      // row_shr:1
-    x = op(x, dpp_take<0x112, 0xF>(ident, x));      // row_shr:2
-    x = op(x, dpp_take<0x114, 0xF>(ident, x));      // row_shr:4
-    x = op(x, dpp_take<0x118, 0xF>(ident, x));      // row_shr:8
-    x = op(x, dpp_take<0x142, 0xA>(ident, x));      // row_bcast:15 -> rows 1, 3
-    x = op(x, dpp_take<0x143, 0xC>(ident, x));      // row_bcast:31 -> rows 2, 3
-    return x;
-}
-
 template <int WAVES, int R>
 struct tile_sort_lds {
     static constexpr int CAP = 64 * WAVES * R, DIG = 512;
@@ -536,6 +536,99 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __
     }
 }
 
+// ---- row-order emission without a global scan array ("pertile" ordering): rows are cut into blocks of
+// MISPLAT_COUNT_BLOCK; tile_count_blocks writes the per-row counts and one sum per block, a single
+// workgroup scans the block sums (and produces the grand total the host needs), and the emission kernel
+// redoes the cheap in-block scan itself.  Replaces count + int64 cast + device scan + subtraction.
+__global__ __launch_bounds__(MISPLAT_COUNT_BLOCK) void tile_count_blocks_kernel(int64_t total, int tw, int th,
+                                                                                const float* __restrict__ means2d,
+                                                                                const int32_t* __restrict__ radii,
+                                                                                int32_t* __restrict__ tiles_per_gauss,
+                                                                                int32_t* __restrict__ block_sums) {
+    __shared__ uint32_t wsum[MISPLAT_COUNT_BLOCK / 64];
+    const int64_t idx = (int64_t)blockIdx.x * MISPLAT_COUNT_BLOCK + threadIdx.x;
+    int n = 0;
+    if (idx < total) {
+        const int rx = radii[2 * idx], ry = radii[2 * idx + 1];
+        if (rx > 0 || ry > 0) {
+            int x0, x1, y0, y1;
+            tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rx, ry, tw, th, x0, x1, y0, y1);
+            n = (x1 - x0) * (y1 - y0);
+        }
+        tiles_per_gauss[idx] = n;
+    }
+    const uint32_t incl = wave_scan_incl((uint32_t)n, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < MISPLAT_COUNT_BLOCK / 64; w++) t += wsum[w];
+        block_sums[blockIdx.x] = (int32_t)t;
+    }
+}
+
+// one workgroup: block_offs = exclusive scan (int64) of block_sums, *n_isects = grand total
+__global__ __launch_bounds__(1024) void tile_block_scan_kernel(int n_blocks, const int32_t* __restrict__ block_sums,
+                                                               int64_t* __restrict__ block_offs,
+                                                               int64_t* __restrict__ n_isects) {
+    __shared__ unsigned long long wsum[16];
+    const int per = (n_blocks + 1023) / 1024;
+    const int b = min(threadIdx.x * per, n_blocks), e = min(b + per, n_blocks);
+    unsigned long long tot = 0;
+    for (int i = b; i < e; i++) tot += (unsigned long long)(uint32_t)block_sums[i];
+    unsigned long long incl = tot;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned long long carry = 0;
+    for (int w = 0; w < wave; w++) carry += wsum[w];
+    unsigned long long run = carry + incl - tot;
+    for (int i = b; i < e; i++) {
+        block_offs[i] = (int64_t)run;
+        run += (unsigned long long)(uint32_t)block_sums[i];
+    }
+    if (threadIdx.x == 1023) *n_isects = (int64_t)(carry + incl);
+}
+
+__global__ __launch_bounds__(MISPLAT_COUNT_BLOCK) void tile_emit_blocks_kernel(int64_t total, int n_gauss, int tw, int th,
+                                                                               const float* __restrict__ means2d,
+                                                                               const int32_t* __restrict__ radii,
+                                                                               const int32_t* __restrict__ tiles_per_gauss,
+                                                                               const int64_t* __restrict__ block_offs,
+                                                                               uint32_t* __restrict__ tile_ids,
+                                                                               int32_t* __restrict__ slot_ids,
+                                                                               int32_t* __restrict__ isect_gid) {
+    // slot_ids == NULL: only the Gaussian row is emitted (it is then the sort payload)
+    __shared__ uint32_t wsum[MISPLAT_COUNT_BLOCK / 64];
+    const int64_t idx = (int64_t)blockIdx.x * MISPLAT_COUNT_BLOCK + threadIdx.x;
+    const uint32_t n = idx < total ? (uint32_t)tiles_per_gauss[idx] : 0u;
+    const uint32_t incl = wave_scan_incl(n, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (n == 0u) return;
+    uint32_t before = incl - n;
+#pragma unroll
+    for (int w = 0; w < MISPLAT_COUNT_BLOCK / 64; w++) before += (w < wave) ? wsum[w] : 0u;
+    int64_t j = block_offs[blockIdx.x] + (int64_t)before;
+    int x0, x1, y0, y1;
+    tile_rect(means2d[2 * idx], means2d[2 * idx + 1], radii[2 * idx], radii[2 * idx + 1], tw, th, x0, x1, y0, y1);
+    const uint32_t base = (uint32_t)(idx / n_gauss) * (uint32_t)(tw * th);
+    for (int ty = y0; ty < y1; ty++)
+        for (int tx = x0; tx < x1; tx++) {
+            tile_ids[j] = base + (uint32_t)(ty * tw + tx);
+            if (slot_ids) slot_ids[j] = (int32_t)j;
+            isect_gid[j] = (int32_t)idx;
+            j++;
+        }
+}
+
 // ---- bucketing without a sort ("scatter" ordering): count the intersections of every tile with atomics,
 // scan the counts into offsets, then every intersection takes the next free slot of its tile's bucket
 // (atomic cursor).  The buckets come out in arbitrary order; misplat_tile_sort(unordered = 1) then
@@ -779,21 +872,16 @@ template <bool HAS_VALS, bool UNORDERED>
 static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
                             const int32_t* isect_gid, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,
                             hipStream_t s) {
-    // size classes (entries per bucket): <=256 | <=1024 | <=2048 | <=8192 | longer (global scratch).
-    // Every class walks all tiles with a grid-stride loop and skips buckets of the other classes, so the
-    // rarely used classes cost a few hundred (not n_tiles) workgroups.
-    const int g0 = n_tiles < 8192 ? n_tiles : 8192;
-    const int g1 = n_tiles < 1024 ? n_tiles : 1024;
+    // size classes (entries per bucket): <=1024 | <=8192 | longer (global scratch).  Every class walks all
+    // tiles with a grid-stride loop and skips buckets of the other classes, so the rarely used classes
+    // cost a few hundred (not n_tiles) workgroups.
+    const int g0 = n_tiles < 16384 ? n_tiles : 16384;
     const int g2 = n_tiles < 256 ? n_tiles : 256;
-    hipLaunchKernelGGL((tile_sort_reg_kernel<4, 1, HAS_VALS, UNORDERED>), dim3(g0), dim3(256), 0, s, offsets, n_tiles,
-                       n_isects, 0, 256, depths, isect_gid, payload, flatten_ids);
     hipLaunchKernelGGL((tile_sort_reg_kernel<4, 4, HAS_VALS, UNORDERED>), dim3(g0), dim3(256), 0, s, offsets, n_tiles,
-                       n_isects, 256, 1024, depths, isect_gid, payload, flatten_ids);
-    hipLaunchKernelGGL((tile_sort_reg_kernel<8, 4, HAS_VALS, UNORDERED>), dim3(g1), dim3(512), 0, s, offsets, n_tiles,
-                       n_isects, 1024, 2048, depths, isect_gid, payload, flatten_ids);
+                       n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids);
     hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS, UNORDERED>), dim3(g2), dim3(1024), 0, s, offsets,
-                       n_tiles, n_isects, 2048, 8192, depths, isect_gid, payload, flatten_ids);
-    hipLaunchKernelGGL((tile_sort_kernel<0, 16, HAS_VALS, true, UNORDERED>), dim3(g2), dim3(1024),
+                       n_tiles, n_isects, 1024, 8192, depths, isect_gid, payload, flatten_ids);
+    hipLaunchKernelGGL((tile_sort_kernel<0, 16, HAS_VALS, true, UNORDERED>), dim3(g2 < 64 ? g2 : 64), dim3(1024),
                        (size_t)16 * 256 * 4, s, offsets, n_tiles, n_isects, 8192, 0x7fffffff, depths, isect_gid,
                        payload, flatten_ids, scratch);
     return check_launch();
@@ -844,5 +932,34 @@ extern "C" int misplat_tile_scatter(const misplat_params* p, const float* means2
     hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
                        p->n_gauss, p->tile_w, p->tile_h, means2d, radii, offsets, cursors, slot_base, payload,
                        isect_gid);
+    return check_launch();
+}
+
+extern "C" int misplat_tile_count_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
+                                         int32_t* tiles_per_gauss, int32_t* block_sums, int64_t* block_offs,
+                                         int64_t* n_isects, misplat_stream_t stream) {
+    if (!p || p->tile_size != MISPLAT_TILE || !block_sums || !block_offs || !n_isects) return MISPLAT_EINVAL;
+    const int64_t total = (int64_t)p->n_gauss * p->n_cams;
+    const int64_t n_blocks = (total + MISPLAT_COUNT_BLOCK - 1) / MISPLAT_COUNT_BLOCK;
+    if (n_blocks > 0x7fffffffLL) return MISPLAT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (total > 0)
+        hipLaunchKernelGGL(tile_count_blocks_kernel, dim3((unsigned)n_blocks), dim3(MISPLAT_COUNT_BLOCK), 0, s, total,
+                           p->tile_w, p->tile_h, means2d, radii, tiles_per_gauss, block_sums);
+    hipLaunchKernelGGL(tile_block_scan_kernel, dim3(1), dim3(1024), 0, s, (int)n_blocks, block_sums, block_offs,
+                       n_isects);
+    return check_launch();
+}
+
+extern "C" int misplat_tile_emit_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
+                                        const int32_t* tiles_per_gauss, const int64_t* block_offs, uint32_t* tile_ids,
+                                        int32_t* slot_ids, int32_t* isect_gid, misplat_stream_t stream) {
+    if (!p || p->tile_size != MISPLAT_TILE) return MISPLAT_EINVAL;
+    const int64_t total = (int64_t)p->n_gauss * p->n_cams;
+    if (total == 0) return MISPLAT_OK;
+    const int64_t n_blocks = (total + MISPLAT_COUNT_BLOCK - 1) / MISPLAT_COUNT_BLOCK;
+    hipLaunchKernelGGL(tile_emit_blocks_kernel, dim3((unsigned)n_blocks), dim3(MISPLAT_COUNT_BLOCK), 0,
+                       (hipStream_t)stream, total, p->n_gauss, p->tile_w, p->tile_h, means2d, radii, tiles_per_gauss,
+                       block_offs, tile_ids, slot_ids, isect_gid);
     return check_launch();
 }

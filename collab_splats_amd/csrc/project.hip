@@ -822,7 +822,10 @@ __global__ __launch_bounds__(256) void project_pack_bwd_kernel(
             const float4* vg = reinterpret_cast<const float4*>(v_grec + (size_t)idx * MISPLAT_REC);
             const float4 g0 = vg[0], g1 = vg[1], g2 = vg[2], g3 = vg[3];
             ProjGrads G;
-            G.v_m2d[0] = v_means2d[2 * idx]; G.v_m2d[1] = v_means2d[2 * idx + 1];   // (not g0.x/g0.y: see ops.py)
+            // v_means2d == NULL: the 2-D mean gradient is columns 0:2 of the packed row (nothing else
+            // was accumulated into means2d by autograd; ops.py checks the aliasing)
+            G.v_m2d[0] = v_means2d ? v_means2d[2 * idx] : g0.x;
+            G.v_m2d[1] = v_means2d ? v_means2d[2 * idx + 1] : g0.y;
             G.v_conic[0] = g0.z; G.v_conic[1] = g0.w; G.v_conic[2] = g1.x;
             const float v_oeff = g1.y;
             G.v_rt = g1.z; G.v_rp[0] = g1.w; G.v_rp[1] = g2.x;

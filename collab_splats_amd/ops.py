@@ -263,8 +263,38 @@ def _bin_tiles_scatter(lib, P: Params, means2d: Tensor, radii: Tensor, depths: T
                 depths=depths, n_tiles=n_tiles)
 
 
+COUNT_BLOCK = 256                                     # MISPLAT_COUNT_BLOCK (include/misplat.h)
+
+
 @torch.no_grad()
-def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor) -> Dict[str, Tensor]:
+def start_binning(P: Params, means2d: Tensor, radii: Tensor) -> Optional[Dict[str, Tensor]]:
+    """First half of ``bin_tiles`` for the "pertile" ordering: tile counts, block scan, and an ASYNCHRONOUS
+    read-back of n_isects (pinned buffer + event).  Called right after the projection kernel, before the colour
+    kernel is launched, so that the host's wait for n_isects -- the one unavoidable sync of the step -- and the
+    launches that follow it are hidden behind the colour kernel instead of idling the GPU."""
+    if ORDERING != "pertile":
+        return None
+    lib = _lib.load()
+    dev = means2d.device
+    total = P.n_gauss * P.n_cams
+    n_blocks = (total + COUNT_BLOCK - 1) // COUNT_BLOCK
+    i32 = dict(device=dev, dtype=torch.int32)
+    tiles_per_gauss = torch.empty(total, **i32)
+    block_sums = torch.empty(max(n_blocks, 1), **i32)
+    block_offs = torch.empty(max(n_blocks, 1), device=dev, dtype=torch.int64)
+    n_dev = torch.empty(1, device=dev, dtype=torch.int64)
+    check(lib.misplat_tile_count_blocks(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(block_sums),
+                                        ptr(block_offs), ptr(n_dev), stream_ptr()), "misplat_tile_count_blocks")
+    host = torch.empty(1, dtype=torch.int64, pin_memory=True)
+    host.copy_(n_dev, non_blocking=True)
+    event = torch.cuda.Event()
+    event.record()
+    return dict(tiles_per_gauss=tiles_per_gauss, block_offs=block_offs, host=host, event=event, n_dev=n_dev)
+
+
+@torch.no_grad()
+def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor,
+              pending: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
     """Tile intersection + ordering + offsets.  One host read-back: n_isects.
 
     In the default (atomic) backward mode the sort payload is the Gaussian row itself; the deterministic mode
@@ -280,11 +310,16 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor) -> Dict
     deterministic = DETERMINISTIC_BACKWARD
     pertile = ORDERING == "pertile"
     i32 = dict(device=dev, dtype=torch.int32)
-    tiles_per_gauss = torch.empty(total, **i32)
-    check(lib.misplat_tile_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), stream_ptr()),
-          "misplat_tile_count")
-    order = None
-    if not pertile:
+    order = cum_ordered = block_offs = None
+    if pertile:
+        pend = pending if pending is not None else start_binning(P, means2d, radii)
+        tiles_per_gauss, block_offs = pend["tiles_per_gauss"], pend["block_offs"]
+        pend["event"].synchronize()                               # the one unavoidable sync (usually long past)
+        n_isects = int(pend["host"][0])
+    else:
+        tiles_per_gauss = torch.empty(total, **i32)
+        check(lib.misplat_tile_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), stream_ptr()),
+              "misplat_tile_count")
         # rows in (camera, depth) order
         ids, order = torch.empty(total, **i32), torch.empty(total, **i32)
         if total > 0 and P.n_cams == 1:
@@ -304,13 +339,11 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor) -> Dict
             check(lib.misplat_sort_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(dkeys), ptr(dkeys_s), ptr(ids), ptr(order),
                                          C.c_int64(total), C.c_int32(end_bit), stream_ptr()), "misplat_sort_pairs")
         tpg_ordered = tiles_per_gauss[order.long()]
-    else:
-        tpg_ordered = tiles_per_gauss
-    incl = torch.cumsum(tpg_ordered, dim=0, dtype=torch.int64)
-    n_isects = int(incl[-1].item()) if total > 0 else 0          # the one unavoidable sync
+        incl = torch.cumsum(tpg_ordered, dim=0, dtype=torch.int64)
+        n_isects = int(incl[-1].item()) if total > 0 else 0      # the one unavoidable sync
+        cum_ordered = (incl - tpg_ordered).contiguous()           # exclusive scan in emission order, int64
     if n_isects >= 2 ** 31:
         raise _lib.MisplatError(f"{n_isects} tile intersections exceed int32 indexing")
-    cum_ordered = (incl - tpg_ordered).contiguous()               # exclusive scan in emission order, int64
     # emit in that order, bucket by tile (stable radix on the tile bits)
     tile_ids = torch.empty(n_isects, **i32)
     isect_gid = torch.empty(n_isects, **i32)
@@ -318,9 +351,14 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor) -> Dict
     tile_ids_s, payload_s = torch.empty_like(tile_ids), torch.empty(n_isects, **i32)
     offsets = torch.empty(n_tiles, **i32)
     if n_isects > 0:
-        check(lib.misplat_tile_emit_ordered(C.byref(P), ptr(order), ptr(means2d), ptr(radii), ptr(cum_ordered),
-                                            ptr(tile_ids), ptr(slots), ptr(isect_gid), stream_ptr()),
-              "misplat_tile_emit_ordered")
+        if pertile:
+            check(lib.misplat_tile_emit_blocks(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss),
+                                               ptr(block_offs), ptr(tile_ids), ptr(slots), ptr(isect_gid),
+                                               stream_ptr()), "misplat_tile_emit_blocks")
+        else:
+            check(lib.misplat_tile_emit_ordered(C.byref(P), ptr(order), ptr(means2d), ptr(radii), ptr(cum_ordered),
+                                                ptr(tile_ids), ptr(slots), ptr(isect_gid), stream_ptr()),
+                  "misplat_tile_emit_ordered")
         tile_bits = max(1, (n_tiles - 1).bit_length())
         _sort32(lib, tile_ids, tile_ids_s, slots if deterministic else isect_gid, payload_s, n_isects, tile_bits,
                 SORT_BITS_TILE)
@@ -362,7 +400,10 @@ def isect_ids(bins: Dict[str, Tensor]) -> Tensor:
 def _cum_by_row(bins: Dict[str, Tensor]) -> Tensor:
     """First emission slot of every Gaussian row (deterministic backward only; built lazily)."""
     if "cum" not in bins:
-        if bins["order"] is None:                      # emission was in row order already
+        if bins["order"] is None and bins["cum_ordered"] is None:     # "pertile": row order, no scan array kept
+            tpg = bins["tiles_per_gauss"]
+            bins["cum"] = (torch.cumsum(tpg, dim=0, dtype=torch.int64) - tpg).contiguous()
+        elif bins["order"] is None:                    # emission was in row order already
             bins["cum"] = bins["cum_ordered"]
         else:
             cum = torch.empty_like(bins["cum_ordered"])
@@ -406,6 +447,7 @@ class _Blend(torch.autograd.Function):
         ctx.means2d_ref = means2d if absgrad else None
         ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids, render)
         ctx.mark_non_differentiable(last_ids, median_ids)
+        ctx.set_materialize_grads(False)               # absent upstream gradients arrive as None
         return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
 
     @staticmethod
@@ -434,6 +476,25 @@ def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Par
 
 # ----------------------------------------------------------------------------- fused path
 
+def _grads_of_pack(P: Params, v_means2d, v_grec):
+    """Incoming gradients of (means2d, grec).  When the mean gradient is exactly the view of columns 0:2 of
+    the packed rows that _BlendPacked returned (nothing else was accumulated into means2d), the kernel
+    reads it from the rows and the strided copy is skipped (v_means2d -> None)."""
+    rows = P.n_cams * P.n_gauss
+    if v_grec is None:
+        ref = v_means2d
+        v_grec = torch.zeros(rows, MISPLAT_REC, device=ref.device, dtype=torch.float32)
+    v_grec = _c(v_grec)
+    if v_means2d is None:
+        v_means2d = torch.zeros(rows, 2, device=v_grec.device, dtype=torch.float32)
+    elif (v_means2d.data_ptr() == v_grec.data_ptr() and v_means2d.dtype == torch.float32
+          and v_means2d.stride() == (P.n_gauss * MISPLAT_REC, MISPLAT_REC, 1)):
+        v_means2d = None
+    else:
+        v_means2d = _c(v_means2d)
+    return v_means2d, v_grec
+
+
 class _ProjectPack(torch.autograd.Function):
     """projection + colour (SH or pass-through) -> packed blend records, one autograd node.
 
@@ -444,7 +505,7 @@ class _ProjectPack(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, P: Params, sh_degree,
-                depth_channel: bool):
+                depth_channel: bool, prebin: Optional[dict] = None):
         lib = _lib.load()
         require_gpu(means, quats, scales, opacities, colors, viewmats, Ks)
         N, Cn = P.n_gauss, P.n_cams
@@ -457,6 +518,8 @@ class _ProjectPack(torch.autograd.Function):
         check(lib.misplat_project_pack_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
                                            ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
                                            ptr(comps), ptr(grec), stream_ptr()), "misplat_project_pack_fwd")
+        if prebin is not None:                         # count tiles + start the n_isects read-back before the colours
+            prebin["pending"] = start_binning(P, means2d, radii)
         if sh_degree is not None:
             kd = colors.shape[1] if colors_rest is None else 1 + colors_rest.shape[1]
             deg, n_color, per_cam = int(sh_degree), 3, 0
@@ -482,6 +545,7 @@ class _ProjectPack(torch.autograd.Function):
         ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps,
                               colors_rest if colors_rest is not None else colors)
         ctx.mark_non_differentiable(radii, depths, comps)
+        ctx.set_materialize_grads(False)               # no zero tensors for the non-differentiable outputs
         return radii, means2d, depths, comps, grec
 
     @staticmethod
@@ -492,7 +556,7 @@ class _ProjectPack(torch.autograd.Function):
             colors_rest = None
         P = ctx.P
         deg, kd, n_color, per_cam = ctx.color_args
-        v_means2d, v_grec = _c(v_means2d), _c(v_grec)
+        v_means2d, v_grec = _grads_of_pack(P, v_means2d, v_grec)
         v_colors = torch.empty_like(colors)
         v_colors_rest = torch.empty_like(colors_rest) if colors_rest is not None else None
         v_means_dir = torch.empty_like(means) if deg >= 0 else None
@@ -520,11 +584,13 @@ class _ProjectPack(torch.autograd.Function):
             cur.wait_stream(side)
             if v_means_dir is not None:
                 v_means.add_(v_means_dir)
-        return v_means, v_quats, v_scales, v_opac, v_colors, v_colors_rest, None, None, None, None, None
+        return v_means, v_quats, v_scales, v_opac, v_colors, v_colors_rest, None, None, None, None, None, None
 
 
-def project_pack(means, quats, scales, opacities, colors, viewmats, Ks, P: Params, sh_degree, depth_channel):
-    """``colors`` may be a pair (features_dc [N,3], features_rest [N,K-1,3]) when ``sh_degree`` is given."""
+def project_pack(means, quats, scales, opacities, colors, viewmats, Ks, P: Params, sh_degree, depth_channel,
+                 prebin: Optional[dict] = None):
+    """``colors`` may be a pair (features_dc [N,3], features_rest [N,K-1,3]) when ``sh_degree`` is given.
+    ``prebin``: a dict that receives ``["pending"]`` = ``start_binning(...)`` for ``bin_tiles(pending=...)``."""
     rest = None
     if isinstance(colors, (tuple, list)):
         colors, rest = colors
@@ -532,7 +598,7 @@ def project_pack(means, quats, scales, opacities, colors, viewmats, Ks, P: Param
     args = [_f32(t, n) for t, n in ((means, "means"), (quats, "quats"), (scales, "scales"),
                                     (opacities, "opacities"), (colors, "colors"))]
     return _ProjectPack.apply(*args, rest, _f32(viewmats, "viewmats"), _f32(Ks, "Ks"), P, sh_degree,
-                              bool(depth_channel))
+                              bool(depth_channel), prebin)
 
 
 class _BlendPacked(torch.autograd.Function):
@@ -560,6 +626,7 @@ class _BlendPacked(torch.autograd.Function):
         ctx.means2d_ref = means2d if absgrad else None
         ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids, render)
         ctx.mark_non_differentiable(last_ids, median_ids)
+        ctx.set_materialize_grads(False)               # absent upstream gradients arrive as None
         return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
 
     @staticmethod
@@ -571,6 +638,14 @@ class _BlendPacked(torch.autograd.Function):
         return v_grec.view(P.n_cams, P.n_gauss, MISPLAT_REC)[..., 0:2], v_grec, None, None, None, None, None
 
 
+def _upstream(P: Params, cd: int, dev, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
+    """Contiguous upstream gradients of the five images; an output that took no part in the loss (None: the
+    nodes do not materialise gradients) contributes zeros."""
+    widths = (cd, 1, 1, 1, 3)
+    return [_c(t) if t is not None else torch.zeros(P.n_cams, P.height, P.width, w, device=dev, dtype=torch.float32)
+            for t, w in zip((v_render, v_alpha, v_exp_depth, v_med_depth, v_normal), widths)]
+
+
 def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
     """blend_bwd -> per-intersection rows -> fixed-order per-Gaussian sum.  Returns (v_grec, v_abs)."""
     lib = _lib.load()
@@ -579,7 +654,7 @@ def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
     n_isects = bins["n_isects"]
     rows = P.n_cams * P.n_gauss
     dev = grec.device
-    ups = [_c(t) for t in (v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)]
+    ups = _upstream(P, cd, dev, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
     if bins["slots"] is None:                      # binned in atomic mode (ops.DETERMINISTIC_BACKWARD was False)
         v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
         v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
@@ -594,7 +669,6 @@ def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
     slab = torch.empty(rows_s, MISPLAT_REC, device=dev, dtype=torch.float32)
     slab_abs = torch.empty(rows_s, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
     slab_valid = torch.empty(rows_s, device=dev, dtype=torch.uint8)
-    ups = [_c(t) for t in (v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)]
     with _timed("blend_bwd"):
         check(lib.misplat_blend_bwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
                                     ptr(bins["slots"]), ptr(bins["isect_offsets"]), C.c_int64(n_isects),
@@ -645,6 +719,7 @@ class _ProjectPackX(torch.autograd.Function):
         ctx.P, ctx.D, ctx.per_cam, ctx.nxq, ctx.depth_channel = P, D, per_cam, nxq, depth_channel
         ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps)
         ctx.mark_non_differentiable(radii, depths, comps)
+        ctx.set_materialize_grads(False)
         return radii, means2d, depths, comps, grec, featx
 
     @staticmethod
@@ -652,7 +727,8 @@ class _ProjectPackX(torch.autograd.Function):
         lib = _lib.load()
         means, quats, scales, opacities, colors, viewmats, Ks, radii, comps = ctx.saved_tensors
         P, D, nxq = ctx.P, ctx.D, ctx.nxq
-        v_means2d, v_grec, v_featx = _c(v_means2d), _c(v_grec), _c(v_featx)
+        v_means2d, v_grec = _grads_of_pack(P, v_means2d, v_grec)
+        v_featx = _c(v_featx) if v_featx is not None else torch.zeros(v_grec.shape[0], 4 * nxq, device=v_grec.device)
         v_colors = torch.empty_like(colors)
         check(lib.misplat_color_bwd_x(C.byref(P), C.c_int32(D), C.c_int32(ctx.per_cam), C.c_int32(nxq), ptr(radii),
                                       ptr(v_grec), ptr(v_featx), ptr(v_colors), stream_ptr()), "misplat_color_bwd_x")
@@ -706,6 +782,7 @@ class _BlendPackedX(torch.autograd.Function):
         ctx.means2d_ref = means2d if absgrad else None
         ctx.save_for_backward(grec, featx, Ks, alpha, last_ids, median_ids, render)
         ctx.mark_non_differentiable(last_ids, median_ids)
+        ctx.set_materialize_grads(False)               # absent upstream gradients arrive as None
         return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
 
     @staticmethod
@@ -718,7 +795,7 @@ class _BlendPackedX(torch.autograd.Function):
         v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
         v_featx = torch.empty(rows, 4 * ctx.nxq, device=dev, dtype=torch.float32)
         v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
-        ups = [_c(t) for t in (v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)]
+        ups = _upstream(P, ctx.n_channels, dev, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
         with _timed("blend_bwd"):
             check(lib.misplat_blend_bwd_x_atomic(C.byref(P), C.c_int32(ctx.n_channels), C.c_int32(ctx.nxq), ptr(Ks),
                                                  ptr(grec), ptr(featx), ptr(bins["flatten_ids"]),

@@ -121,10 +121,11 @@ def rasterization(
     if fused:
         # ---- the reference's path (RGB / RGB+ED, SH or RGB colours): two autograd nodes, no glue kernels
         cin = colors if n_user > 0 else means.new_zeros(N, 1)
+        prebin = {}                                   # tile counting starts inside the node, before the colour kernel
         radii, means2d, depths, comps, grec = ops.project_pack(
             means, quats, scales, opacities, cin if n_user > 0 else cin[:, :0].contiguous(), viewmats, Ks, P,
-            sh_degree if n_user > 0 else None, depth_channel)
-        bins = ops.bin_tiles(P, means2d, radii, depths)
+            sh_degree if n_user > 0 else None, depth_channel, prebin)
+        bins = ops.bin_tiles(P, means2d, radii, depths, pending=prebin.get("pending"))
         D = n_user + int(depth_channel)
         first = ops.blend_packed(means2d, grec, Ks, P, bins, absgrad, D)
         render = first[0]

@@ -196,6 +196,21 @@ int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_i
                       const float* depths, const int32_t* isect_gid, int32_t* payload,
                       int32_t* flatten_ids, uint32_t* scratch, int32_t unordered, misplat_stream_t stream);
 
+/* Row-order emission without a global scan array (ordering "pertile"; replaces gsplat's cumsum between
+ * its projection and isect_tiles): rows are cut into blocks of MISPLAT_COUNT_BLOCK.
+ *   tile_count_blocks  tiles_per_gauss[C*N], block_sums[n_blocks] (scratch), block_offs[n_blocks] = exclusive
+ *                      int64 scan of the block sums, *n_isects = grand total (device; the host reads it);
+ *   tile_emit_blocks   (tile id, row) pairs in row order: row r of block b starts at
+ *                      block_offs[b] + (sum of tiles_per_gauss over the rows of b before r).
+ * n_blocks = ceil(C*N / MISPLAT_COUNT_BLOCK). */
+#define MISPLAT_COUNT_BLOCK 256
+int misplat_tile_count_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
+                              int32_t* tiles_per_gauss, int32_t* block_sums, int64_t* block_offs,
+                              int64_t* n_isects, misplat_stream_t stream);
+int misplat_tile_emit_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
+                             const int32_t* tiles_per_gauss, const int64_t* block_offs, uint32_t* tile_ids,
+                             int32_t* slot_ids, int32_t* isect_gid, misplat_stream_t stream);
+
 /* Bucketing without a sort ("scatter" ordering; replaces tile_count + tile_emit + the tile-id sort +
  * tile_offsets of gsplat's isect_tiles / isect_offset_encode):
  *   tile_hist    tiles_per_gauss[C*N] and, with atomics, tile_counts[C*tiles] (+=; caller zeroes it);
