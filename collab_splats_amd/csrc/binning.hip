@@ -237,6 +237,27 @@ __global__ __launch_bounds__(256) void depth_keys32_kernel(int64_t total, const 
 // barrier).  The histogram is digit-major, so the exclusive scan over (digit, wave) is a flat scan in
 // which every thread owns 8 consecutive counters; wave-level scans and reductions are DPP (row_shr /
 // row_bcast), not LDS permutes.
+// Tiles a workgroup of a size class walks.  A grid as large as n_tiles: one tile each.  A smaller grid (the
+// rare classes): a contiguous chunk per workgroup, first tested in parallel (one tile per thread) so that
+// workgroups without a bucket of the class leave after one round of loads instead of a serial walk.
+__device__ __forceinline__ bool tile_range(const int32_t* __restrict__ offsets, int n_tiles, int64_t n_isects, int lo,
+                                           int hi, int& t_first, int& t_last, int& t_step) {
+    if ((int)gridDim.x >= n_tiles) {
+        t_first = blockIdx.x; t_last = n_tiles; t_step = gridDim.x;
+        return true;
+    }
+    const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    t_first = blockIdx.x * per;
+    t_last = min(t_first + per, n_tiles);
+    t_step = 1;
+    bool mine = false;
+    for (int t = t_first + threadIdx.x; t < t_last; t += blockDim.x) {
+        const int n = ((t + 1 < n_tiles) ? offsets[t + 1] : (int)n_isects) - offsets[t];
+        mine |= (n > lo && n <= hi);
+    }
+    return __syncthreads_or(mine) != 0;
+}
+
 template <int WAVES, int R>
 struct tile_sort_lds {
     static constexpr int CAP = 64 * WAVES * R, DIG = 512;
@@ -372,7 +393,9 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
                                                                    int32_t* __restrict__ flatten_ids) {
     __shared__ tile_sort_lds<WAVES, R> L;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    int t_first, t_last, t_step;
+    if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step)) return;
+    for (int t = t_first; t < t_last; t += t_step) {
         const int beg = offsets[t];
         const int end = (t + 1 < n_tiles) ? offsets[t + 1] : (int)n_isects;
         const int n = end - beg;
@@ -439,7 +462,9 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __
                                                                int32_t* __restrict__ flatten_ids,
                                                                uint32_t* __restrict__ scratch) {
     extern __shared__ uint32_t lds32[];
-    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+    int t_first, t_last, t_step;
+    if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step)) return;
+    for (int t = t_first; t < t_last; t += t_step) {
     const int beg = offsets[t];
     const int end = (t + 1 < n_tiles) ? offsets[t + 1] : (int)n_isects;
     const int n = end - beg;

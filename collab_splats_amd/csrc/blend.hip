@@ -268,44 +268,54 @@ __device__ __forceinline__ float cross_row_sum(float r) {      // + lanes l^16, 
     return __int_as_float(s32.x) + __int_as_float(s32.y);
 }
 
-// Halving butterfly: 16 values per lane -> 1 per lane, summed over all 64 lanes.  Partners:
-// l^7 (split on lane bit 2), l^1 (bit 0), l^2 (bit 1), l^8 (bit 3), then the two cross-row adds.
-// 8 + 4 + 2 + 1 + 2 = 17 adds instead of 16 * 6.  Lane l ends with component butterfly_comp(l).
+// Halving butterfly: 16 values per lane -> 1 per lane, summed over all 64 lanes; lane l ends with
+// component butterfly_comp(l) = (l >> 2) & 15 (replicated over the 4 lanes of its quad).
+// An exchange unit takes two values (a, b) and a lane bit s and leaves a_self + a_partner in the lanes
+// with s = 0, b_self + b_partner in those with s = 1.  Measured on gfx950 (scripts/ubench/valu_rates.hip):
+// the select-select-add form (2 v_cndmask + v_add_dpp) costs ~22 cycles per unit in a dependent chain,
+// two BANK-MASKED DPP adds ~7 (bank_mask enables groups of 4 lanes of a row, i.e. lane bits 2 and 3), a
+// v_permlane{16,32}_swap + add ~12 (lane bits 4 and 5).  So the two big stages run on the bank bits, the
+// two small ones on the row bits, and the quad bits (0, 1) are a plain 2-step sum of the single survivor:
+//   bit 2: 8 units, row_half_mirror, banks 1|3 vs 0|2      bit 3: 4 units, row_ror:8, banks 2|3 vs 0|1
+//   bit 4: 2 units, v_permlane16_swap                      bit 5: 1 unit,  v_permlane32_swap
+// The compiler cannot see inside the asm, so each block opens with the 2 wait states a DPP / permlane
+// read of a freshly written VGPR needs on gfx9.
+#define MISPLAT_XU(k, n, ctrl, m_hi, m_lo)                                                            \
+    "v_add_f32_dpp %" #k ", %" #k ", %" #k " " ctrl " row_mask:0xf bank_mask:" m_hi "\n\t"            \
+    "v_add_f32_dpp %" #k ", %" #n ", %" #n " " ctrl " row_mask:0xf bank_mask:" m_lo "\n\t"
 __device__ __forceinline__ float wave_reduce16(float (&v)[16], int lane) {
-    {
-        const bool hi = lane & 4;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float keep = hi ? v[8 + i] : v[i], send = hi ? v[i] : v[8 + i];
-            v[i] = keep + dpp_mov<kDppHalfMirror>(send);
-        }
-    }
-    {
-        const bool hi = lane & 1;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const float keep = hi ? v[4 + i] : v[i], send = hi ? v[i] : v[4 + i];
-            v[i] = keep + dpp_mov<kDppXor1>(send);
-        }
-    }
-    {
-        const bool hi = lane & 2;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const float keep = hi ? v[2 + i] : v[i], send = hi ? v[i] : v[2 + i];
-            v[i] = keep + dpp_mov<kDppXor2>(send);
-        }
-    }
-    {
-        const bool hi = lane & 8;
-        const float keep = hi ? v[1] : v[0], send = hi ? v[0] : v[1];
-        v[0] = keep + dpp_mov<kDppRor8>(send);
-    }
-    return cross_row_sum(v[0]);
+    (void)lane;
+    // bit 2: (v[2i], v[2i+1]) -> v[2i+1]
+    asm("s_nop 1\n\t"
+        MISPLAT_XU(0, 8, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(1, 9, "row_half_mirror", "0xa", "0x5")
+        MISPLAT_XU(2, 10, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(3, 11, "row_half_mirror", "0xa", "0x5")
+        MISPLAT_XU(4, 12, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(5, 13, "row_half_mirror", "0xa", "0x5")
+        MISPLAT_XU(6, 14, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(7, 15, "row_half_mirror", "0xa", "0x5")
+        : "+v"(v[1]), "+v"(v[3]), "+v"(v[5]), "+v"(v[7]), "+v"(v[9]), "+v"(v[11]), "+v"(v[13]), "+v"(v[15])
+        : "v"(v[0]), "v"(v[2]), "v"(v[4]), "v"(v[6]), "v"(v[8]), "v"(v[10]), "v"(v[12]), "v"(v[14]));
+    // bit 3: (v[1], v[3]) -> v[3], (v[5], v[7]) -> v[7], (v[9], v[11]) -> v[11], (v[13], v[15]) -> v[15]
+    asm("s_nop 1\n\t"
+        MISPLAT_XU(0, 4, "row_ror:8", "0xc", "0x3") MISPLAT_XU(1, 5, "row_ror:8", "0xc", "0x3")
+        MISPLAT_XU(2, 6, "row_ror:8", "0xc", "0x3") MISPLAT_XU(3, 7, "row_ror:8", "0xc", "0x3")
+        : "+v"(v[3]), "+v"(v[7]), "+v"(v[11]), "+v"(v[15])
+        : "v"(v[1]), "v"(v[5]), "v"(v[9]), "v"(v[13]));
+    // bit 4: rows 0|2 keep the first value, rows 1|3 the second
+    asm("s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\t"
+        "v_permlane16_swap_b32 %2, %3"
+        : "+v"(v[3]), "+v"(v[7]), "+v"(v[11]), "+v"(v[15]));
+    float lo = v[3] + v[7], hi = v[11] + v[15];
+    // bit 5: lanes 0..31 keep lo, lanes 32..63 keep hi
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %1"
+        : "+v"(lo), "+v"(hi));
+    float r = lo + hi;
+    r += dpp_mov<kDppXor1>(r);
+    r += dpp_mov<kDppXor2>(r);
+    return r;
 }
-__device__ __forceinline__ int butterfly_comp(int l) {
-    return (((l >> 2) & 1) << 3) | ((l & 1) << 2) | (((l >> 1) & 1) << 1) | ((l >> 3) & 1);
-}
+#undef MISPLAT_XU
+__device__ __forceinline__ int butterfly_comp(int l) { return (l >> 2) & 15; }
 
 __device__ __forceinline__ float wave_sum(float v) {
     v += dpp_mov<kDppHalfMirror>(v);
@@ -410,7 +420,8 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? 5 : (PPL == 4 ? 3 : 1)
     }
     const int maxlast = wave_max(mymax);
     if (maxlast < c.beg) return;
-    const int comp = butterfly_comp(lane & 15);
+    const int comp = butterfly_comp(lane);
+    const bool writer = (lane & 3) == 0;          // one lane per quad holds (and writes) component `comp`
     // per-lane scale undoing the conic pre-multiplication (component = record layout index)
     const float out_scale = (comp == 2 || comp == 4) ? -0.5f * kLog2e : (comp == 3 ? -kLog2e : 1.0f);
     const float amax = P.alpha_max, amin = P.alpha_min;
@@ -500,14 +511,14 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? 5 : (PPL == 4 ? 3 : 1)
                 const float r = wave_reduce16(acc, lane);
                 if (ATOMIC) {
                     // one 64-byte contiguous no-return fp32 atomic per (band, Gaussian)
-                    if (lane < 16) atomicAdd(&slab_b[slot * MISPLAT_REC + comp], r * out_scale);
+                    if (writer) atomicAdd(&slab_b[slot * MISPLAT_REC + comp], r * out_scale);
                     if (NXQ > 0) {
                         const float rx = wave_reduce16(accx, lane);
-                        if (lane < 16 && comp < NX) atomicAdd(&v_featx[slot * NX + comp], rx);
+                        if (writer && comp < NX) atomicAdd(&v_featx[slot * NX + comp], rx);
                     }
                 } else {
-                    if (lane < 16) slab_b[slot * MISPLAT_REC + comp] = r * out_scale;
-                    if (lane == 16) valid_b[slot] = 1;
+                    if (writer) slab_b[slot * MISPLAT_REC + comp] = r * out_scale;
+                    if (lane == 1) valid_b[slot] = 1;
                 }
                 if (ABS) {
                     ab0 = wave_sum(ab0); ab1 = wave_sum(ab1);
