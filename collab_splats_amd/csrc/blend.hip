@@ -439,15 +439,12 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? 5 : (PPL == 4 ? 3 : 1)
                                          ATOMIC ? nullptr : slots, xlo, xhi, ylo, yhi, amin, smx, featx);
         __syncthreads();
         if (n == 0) continue;
-        float4 n0 = sm[n - 1], n1 = sm[64 + n - 1], n2 = sm[128 + n - 1], n3 = sm[192 + n - 1];
-        int ni = sm_idx[n - 1], nslot = sm_slot[n - 1];
+        // The record of the next Gaussian is fetched from LDS into the SAME registers right after the last
+        // use of the current one (before the butterfly, which hides the latency): no second register set
+        // and no copies.
+        float4 q0 = sm[n - 1], q1 = sm[64 + n - 1], q2 = sm[128 + n - 1], q3 = sm[192 + n - 1];
+        int i = sm_idx[n - 1], islot = sm_slot[n - 1];
         for (int j = n - 1; j >= 0; j--) {
-            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-            const int i = ni;
-            const size_t slot = (size_t)nslot;
-            const int jn = j > 0 ? j - 1 : 0;                                  // prefetch
-            n0 = sm[jn]; n1 = sm[64 + jn]; n2 = sm[128 + jn]; n3 = sm[192 + jn];
-            ni = sm_idx[jn]; nslot = sm_slot[jn];
             float4 xq[NXQ > 0 ? NXQ : 1];
 #pragma unroll
             for (int q = 0; q < NXQ; q++) xq[q] = smx[q * 64 + j];
@@ -506,6 +503,12 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? 5 : (PPL == 4 ? 3 : 1)
                 const float vmy = (2.0f * q1.x * dy + q0.w * dx) * v_e - vzl * q2.x;
                 acc[0] += vmx; acc[1] += vmy;
                 if (ABS) { ab0 += fabsf(vmx); ab1 += fabsf(vmy); }
+            }
+            const size_t slot = (size_t)islot;
+            {
+                const int jn = j > 0 ? j - 1 : 0;
+                q0 = sm[jn]; q1 = sm[64 + jn]; q2 = sm[128 + jn]; q3 = sm[192 + jn];
+                i = sm_idx[jn]; islot = sm_slot[jn];
             }
             if (__ballot(amx > 0.f) != 0ull) {
                 const float r = wave_reduce16(acc, lane);
