@@ -248,6 +248,9 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     }
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+
 // ---- wave reductions (DPP / permlane: no LDS traffic) ------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -420,6 +423,24 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? 5 : (PPL == 4 ? 3 : 1)
     }
     const int maxlast = wave_max(mymax);
     if (maxlast < c.beg) return;
+    // pixel pairs (k = 2 kp, 2 kp + 1) as 2-vectors for the packed-math loop (even PPL)
+    constexpr int NP = PPL >= 2 ? PPL / 2 : 1;
+    v2f py2[NP], il2[NP], T2[NP], B2[NP], tf2[NP], vd2[NP], vm2[NP], vcol2[NP][CD], vn2[NP][3], vcolx2[NP][NX];
+    if constexpr (PPL % 2 == 0) {
+#pragma unroll
+        for (int kp = 0; kp < NP; kp++) {
+            const int k0 = 2 * kp, k1 = 2 * kp + 1;
+            py2[kp] = mk2(py[k0], py[k1]); il2[kp] = mk2(inv_ell[k0], inv_ell[k1]);
+            T2[kp] = mk2(T[k0], T[k1]); B2[kp] = mk2(B[k0], B[k1]); tf2[kp] = mk2(tfva[k0], tfva[k1]);
+            vd2[kp] = mk2(vd[k0], vd[k1]); vm2[kp] = mk2(vm[k0], vm[k1]);
+#pragma unroll
+            for (int ch = 0; ch < CD; ch++) vcol2[kp][ch] = mk2(vcol[k0][ch], vcol[k1][ch]);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) vn2[kp][ch] = mk2(vn[k0][ch], vn[k1][ch]);
+#pragma unroll
+            for (int ch = 0; ch < NX; ch++) vcolx2[kp][ch] = mk2(vcolx[k0][ch], vcolx[k1][ch]);
+        }
+    }
     const int comp = butterfly_comp(lane);
     const bool writer = (lane & 3) == 0;          // one lane per quad holds (and writes) component `comp`
     // per-lane scale undoing the conic pre-multiplication (component = record layout index)
@@ -459,50 +480,123 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? 5 : (PPL == 4 ? 3 : 1)
             for (int r = 0; r < 16; r++) accx[r] = 0.f;
             float ab0 = 0.f, ab1 = 0.f;
             float amx = 0.f;
+            if constexpr (PPL % 2 == 0) {
+                // Two pixels of the lane at a time in 2-vectors: on gfx950 v_pk_{fma,mul,add}_f32 process both at
+                // the price of one instruction, so everything but the transcendentals, compares and selects is
+                // halved.  Per-component sums stay packed until one horizontal add in front of the butterfly.
+                v2f accv[16], accxv[16];
+                const float dxx = dx * dx, ndx = -dx;
+                const float c1x = 2.0f * q0.z * dx, c1y = q0.w * dx;
 #pragma unroll
-            for (int k = 0; k < PPL; k++) {
-                const float dy = q0.y - py[k];
-                const float e = ea + (q1.x * dy + eb) * dy;
-                const float vis = __builtin_amdgcn_exp2f(e);
-                const float ov = q1.y * vis;
-                float a = fminf(amax, ov);
-                const bool ok = (i <= last[k]) && (e <= 0.f) && (a >= amin);
-                a = ok ? a : 0.f;
-                amx = fmaxf(amx, a);
-                const float ra = __builtin_amdgcn_rcpf(1.0f - a);
-                T[k] *= ra;
-                const float w = a * T[k];
-                const float zp = (tpx - q2.x * dy) * inv_ell[k];
-                float dot = q3.x * vcol[k][0];
-                if (CD > 1) dot += q3.y * vcol[k][CD > 1 ? 1 : 0];
-                if (CD > 2) dot += q3.z * vcol[k][CD > 2 ? 2 : 0];
-                if (CD > 3) dot += q3.w * vcol[k][CD > 3 ? 3 : 0];
+                for (int kp = 0; kp < PPL / 2; kp++) {
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    const v2f dy = q0.y - py2[kp];
+                    const v2f e = ea + (q1.x * dy + eb) * dy;
+                    v2f vis;
+                    vis.x = __builtin_amdgcn_exp2f(e.x); vis.y = __builtin_amdgcn_exp2f(e.y);
+                    const v2f ov = q1.y * vis;
+                    const bool ok0 = (i <= last[k0]) && (e.x <= 0.f) && (fminf(amax, ov.x) >= amin);
+                    const bool ok1 = (i <= last[k1]) && (e.y <= 0.f) && (fminf(amax, ov.y) >= amin);
+                    v2f a;
+                    a.x = ok0 ? fminf(amax, ov.x) : 0.f; a.y = ok1 ? fminf(amax, ov.y) : 0.f;
+                    amx = fmaxf(amx, fmaxf(a.x, a.y));
+                    const v2f om = 1.0f - a;
+                    v2f ra;
+                    ra.x = __builtin_amdgcn_rcpf(om.x); ra.y = __builtin_amdgcn_rcpf(om.y);
+                    T2[kp] *= ra;
+                    const v2f Tk = T2[kp];
+                    const v2f w = a * Tk;
+                    const v2f zp = (tpx - q2.x * dy) * il2[kp];
+                    v2f dot = q3.x * vcol2[kp][0];
+                    if (CD > 1) dot += q3.y * vcol2[kp][CD > 1 ? 1 : 0];
+                    if (CD > 2) dot += q3.z * vcol2[kp][CD > 2 ? 2 : 0];
+                    if (CD > 3) dot += q3.w * vcol2[kp][CD > 3 ? 3 : 0];
 #pragma unroll
-                for (int q = 0; q < NXQ; q++)
-                    dot += xq[q].x * vcolx[k][4 * q] + xq[q].y * vcolx[k][4 * q + 1] + xq[q].z * vcolx[k][4 * q + 2] +
-                           xq[q].w * vcolx[k][4 * q + 3];
-                dot += q2.y * vn[k][0] + q2.z * vn[k][1] + q2.w * vn[k][2] + zp * vd[k];
-                float v_a = (tfva[k] - B[k]) * ra + T[k] * dot;
-                v_a = ok ? v_a : 0.f;
-                B[k] += w * dot;
-                acc[12] += w * vcol[k][0];
-                if (CD > 1) acc[13] += w * vcol[k][CD > 1 ? 1 : 0];
-                if (CD > 2) acc[14] += w * vcol[k][CD > 2 ? 2 : 0];
-                if (CD > 3) acc[15] += w * vcol[k][CD > 3 ? 3 : 0];
+                    for (int q = 0; q < NXQ; q++)
+                        dot += xq[q].x * vcolx2[kp][4 * q] + xq[q].y * vcolx2[kp][4 * q + 1] +
+                               xq[q].z * vcolx2[kp][4 * q + 2] + xq[q].w * vcolx2[kp][4 * q + 3];
+                    dot += q2.y * vn2[kp][0] + q2.z * vn2[kp][1] + q2.w * vn2[kp][2] + zp * vd2[kp];
+                    v2f v_a = (tf2[kp] - B2[kp]) * ra + Tk * dot;
+                    v_a.x = ok0 ? v_a.x : 0.f; v_a.y = ok1 ? v_a.y : 0.f;
+                    B2[kp] += w * dot;
+                    v2f vz = w * vd2[kp];
+                    v2f vmed;
+                    vmed.x = (ok0 && i == medi[k0]) ? vm2[kp].x : 0.f; vmed.y = (ok1 && i == medi[k1]) ? vm2[kp].y : 0.f;
+                    vz += vmed;
+                    const v2f vzl = vz * il2[kp];
+                    v2f vam;
+                    vam.x = (ov.x <= amax) ? v_a.x : 0.f; vam.y = (ov.y <= amax) ? v_a.y : 0.f;
+                    const v2f v_e = (kLn2 * ov) * vam;
+                    const v2f dyve = dy * v_e;
+                    const v2f vmx = (c1x + q0.w * dy) * v_e - vzl * q1.w;
+                    const v2f vmy = (2.0f * q1.x * dy + c1y) * v_e - vzl * q2.x;
+                    // first pair: plain products, later pairs (PPL 4): fused accumulate
+#define MISPLAT_ACC(dst, val) do { if (kp == 0) dst = (val); else dst += (val); } while (0)
+                    MISPLAT_ACC(accv[0], vmx); MISPLAT_ACC(accv[1], vmy);
+                    MISPLAT_ACC(accv[2], dxx * v_e); MISPLAT_ACC(accv[3], dx * dyve); MISPLAT_ACC(accv[4], dy * dyve);
+                    MISPLAT_ACC(accv[5], vis * vam);
+                    MISPLAT_ACC(accv[6], vzl); MISPLAT_ACC(accv[7], ndx * vzl); MISPLAT_ACC(accv[8], -(vzl * dy));
+                    MISPLAT_ACC(accv[9], w * vn2[kp][0]); MISPLAT_ACC(accv[10], w * vn2[kp][1]);
+                    MISPLAT_ACC(accv[11], w * vn2[kp][2]);
+                    MISPLAT_ACC(accv[12], w * vcol2[kp][0]);
+                    if (CD > 1) MISPLAT_ACC(accv[13], w * vcol2[kp][CD > 1 ? 1 : 0]);
+                    if (CD > 2) MISPLAT_ACC(accv[14], w * vcol2[kp][CD > 2 ? 2 : 0]);
+                    if (CD > 3) MISPLAT_ACC(accv[15], w * vcol2[kp][CD > 3 ? 3 : 0]);
 #pragma unroll
-                for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) accx[ch] += w * vcolx[k][ch];
-                acc[9] += w * vn[k][0]; acc[10] += w * vn[k][1]; acc[11] += w * vn[k][2];
-                float vz = w * vd[k];
-                vz += (ok && i == medi[k]) ? vm[k] : 0.f;
-                const float vzl = vz * inv_ell[k];
-                acc[6] += vzl; acc[7] -= vzl * dx; acc[8] -= vzl * dy;
-                const float v_e = (ov <= amax) ? kLn2 * ov * v_a : 0.f;
-                acc[5] += vis * ((ov <= amax) ? v_a : 0.f);
-                acc[2] += dx * dx * v_e; acc[3] += dx * dy * v_e; acc[4] += dy * dy * v_e;
-                const float vmx = (2.0f * q0.z * dx + q0.w * dy) * v_e - vzl * q1.w;
-                const float vmy = (2.0f * q1.x * dy + q0.w * dx) * v_e - vzl * q2.x;
-                acc[0] += vmx; acc[1] += vmy;
-                if (ABS) { ab0 += fabsf(vmx); ab1 += fabsf(vmy); }
+                    for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) MISPLAT_ACC(accxv[ch], w * vcolx2[kp][ch]);
+#undef MISPLAT_ACC
+                    if (ABS) { ab0 += fabsf(vmx.x) + fabsf(vmx.y); ab1 += fabsf(vmy.x) + fabsf(vmy.y); }
+                }
+#pragma unroll
+                for (int r = 0; r < 12 + CD; r++) acc[r] = accv[r].x + accv[r].y;
+#pragma unroll
+                for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) accx[ch] = accxv[ch].x + accxv[ch].y;
+            } else {
+#pragma unroll
+                for (int k = 0; k < PPL; k++) {
+                    const float dy = q0.y - py[k];
+                    const float e = ea + (q1.x * dy + eb) * dy;
+                    const float vis = __builtin_amdgcn_exp2f(e);
+                    const float ov = q1.y * vis;
+                    float a = fminf(amax, ov);
+                    const bool ok = (i <= last[k]) && (e <= 0.f) && (a >= amin);
+                    a = ok ? a : 0.f;
+                    amx = fmaxf(amx, a);
+                    const float ra = __builtin_amdgcn_rcpf(1.0f - a);
+                    T[k] *= ra;
+                    const float w = a * T[k];
+                    const float zp = (tpx - q2.x * dy) * inv_ell[k];
+                    float dot = q3.x * vcol[k][0];
+                    if (CD > 1) dot += q3.y * vcol[k][CD > 1 ? 1 : 0];
+                    if (CD > 2) dot += q3.z * vcol[k][CD > 2 ? 2 : 0];
+                    if (CD > 3) dot += q3.w * vcol[k][CD > 3 ? 3 : 0];
+#pragma unroll
+                    for (int q = 0; q < NXQ; q++)
+                        dot += xq[q].x * vcolx[k][4 * q] + xq[q].y * vcolx[k][4 * q + 1] + xq[q].z * vcolx[k][4 * q + 2] +
+                               xq[q].w * vcolx[k][4 * q + 3];
+                    dot += q2.y * vn[k][0] + q2.z * vn[k][1] + q2.w * vn[k][2] + zp * vd[k];
+                    float v_a = (tfva[k] - B[k]) * ra + T[k] * dot;
+                    v_a = ok ? v_a : 0.f;
+                    B[k] += w * dot;
+                    acc[12] += w * vcol[k][0];
+                    if (CD > 1) acc[13] += w * vcol[k][CD > 1 ? 1 : 0];
+                    if (CD > 2) acc[14] += w * vcol[k][CD > 2 ? 2 : 0];
+                    if (CD > 3) acc[15] += w * vcol[k][CD > 3 ? 3 : 0];
+#pragma unroll
+                    for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) accx[ch] += w * vcolx[k][ch];
+                    acc[9] += w * vn[k][0]; acc[10] += w * vn[k][1]; acc[11] += w * vn[k][2];
+                    float vz = w * vd[k];
+                    vz += (ok && i == medi[k]) ? vm[k] : 0.f;
+                    const float vzl = vz * inv_ell[k];
+                    acc[6] += vzl; acc[7] -= vzl * dx; acc[8] -= vzl * dy;
+                    const float v_e = (ov <= amax) ? kLn2 * ov * v_a : 0.f;
+                    acc[5] += vis * ((ov <= amax) ? v_a : 0.f);
+                    acc[2] += dx * dx * v_e; acc[3] += dx * dy * v_e; acc[4] += dy * dy * v_e;
+                    const float vmx = (2.0f * q0.z * dx + q0.w * dy) * v_e - vzl * q1.w;
+                    const float vmy = (2.0f * q1.x * dy + q0.w * dx) * v_e - vzl * q2.x;
+                    acc[0] += vmx; acc[1] += vmy;
+                    if (ABS) { ab0 += fabsf(vmx); ab1 += fabsf(vmy); }
+                }
             }
             const size_t slot = (size_t)islot;
             {
