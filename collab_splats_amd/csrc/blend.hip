@@ -115,6 +115,9 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
     return __popcll(mask);
 }
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+
 // Forward.  The per-pixel loop is branch-free: a pixel that has terminated carries T = 0 (its
 // transmittance at termination is parked in Tfin), so every later weight w = a*T vanishes by itself;
 // "skip" is a = 0.  The next record is prefetched from LDS while the current one is consumed.
@@ -161,10 +164,37 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
     const float xlo = (float)(c.tx * MISPLAT_TILE) + 0.5f, xhi = xlo + 15.0f;
     const float ylo = (float)c.y0 + 0.5f, yhi = ylo + (float)(4 * PPL - 1);
 
-    for (int bs = c.beg; bs < c.end; bs += 64) {
-        float tmax = T[0];
+    // pixel pairs (k = 2 kp, 2 kp + 1) as 2-vectors for the packed-math loop (even PPL)
+    constexpr int NP = PPL >= 2 ? PPL / 2 : 1;
+    constexpr int NXF = NXQ > 0 ? 4 * NXQ : 1;
+    v2f py2[NP], il2[NP], T2[NP], Tfin2[NP], dep2[NP], med2[NP], col2[NP][CD], nrm2[NP][3], colx2[NP][NXF];
+    if constexpr (PPL % 2 == 0) {
 #pragma unroll
-        for (int k = 1; k < PPL; k++) tmax = fmaxf(tmax, T[k]);
+        for (int kp = 0; kp < NP; kp++) {
+            const int k0 = 2 * kp, k1 = 2 * kp + 1;
+            py2[kp] = mk2(py[k0], py[k1]); il2[kp] = mk2(inv_ell[k0], inv_ell[k1]);
+            T2[kp] = mk2(T[k0], T[k1]); Tfin2[kp] = mk2(1.0f, 1.0f);
+            dep2[kp] = mk2(0.f, 0.f); med2[kp] = mk2(0.f, 0.f);
+#pragma unroll
+            for (int ch = 0; ch < CD; ch++) col2[kp][ch] = mk2(0.f, 0.f);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) nrm2[kp][ch] = mk2(0.f, 0.f);
+#pragma unroll
+            for (int ch = 0; ch < NXF; ch++) colx2[kp][ch] = mk2(0.f, 0.f);
+        }
+    }
+
+    for (int bs = c.beg; bs < c.end; bs += 64) {
+        float tmax;
+        if constexpr (PPL % 2 == 0) {
+            tmax = fmaxf(T2[0].x, T2[0].y);
+#pragma unroll
+            for (int kp = 1; kp < NP; kp++) tmax = fmaxf(tmax, fmaxf(T2[kp].x, T2[kp].y));
+        } else {
+            tmax = T[0];
+#pragma unroll
+            for (int k = 1; k < PPL; k++) tmax = fmaxf(tmax, T[k]);
+        }
         if (__ballot(tmax > 0.f) == 0ull) break;
         __syncthreads();
         const int n = stage_records<NXQ>(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
@@ -185,39 +215,96 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
             const float ea = q0.z * dx * dx, eb = q0.w * dx;
             const float tpx = q1.z - q1.w * dx;
             float tm = 0.f;
+            if constexpr (PPL % 2 == 0) {
+                // two pixels of the lane per packed instruction (see blend_bwd_kernel)
 #pragma unroll
-            for (int k = 0; k < PPL; k++) {
-                const float dy = q0.y - py[k];
-                const float e = ea + (q1.x * dy + eb) * dy;
-                const float vis = __builtin_amdgcn_exp2f(e);
-                float a = fminf(amax, q1.y * vis);
-                a = (e <= 0.f && a >= amin) ? a : 0.f;
-                float w = a * T[k];
-                const float Tn = T[k] - w;
-                const bool stop = (w > 0.f) && (Tn <= tstop);       // this Gaussian is excluded
-                const bool use = (w > 0.f) && !stop;
-                Tfin[k] = stop ? T[k] : Tfin[k];
-                const bool is_med = use && (T[k] > tmed);
-                T[k] = stop ? 0.f : Tn;
-                w = stop ? 0.f : w;
-                const float zp = (tpx - q2.x * dy) * inv_ell[k];
-                col[k][0] += w * q3.x;
-                if (CD > 1) col[k][CD > 1 ? 1 : 0] += w * q3.y;
-                if (CD > 2) col[k][CD > 2 ? 2 : 0] += w * q3.z;
-                if (CD > 3) col[k][CD > 3 ? 3 : 0] += w * q3.w;
+                for (int kp = 0; kp < NP; kp++) {
+                    const v2f dy = q0.y - py2[kp];
+                    const v2f e = ea + (q1.x * dy + eb) * dy;
+                    v2f vis;
+                    vis.x = __builtin_amdgcn_exp2f(e.x); vis.y = __builtin_amdgcn_exp2f(e.y);
+                    const v2f ov = q1.y * vis;
+                    const float am0 = fminf(amax, ov.x), am1 = fminf(amax, ov.y);
+                    v2f a;
+                    a.x = (e.x <= 0.f && am0 >= amin) ? am0 : 0.f; a.y = (e.y <= 0.f && am1 >= amin) ? am1 : 0.f;
+                    const v2f Tk = T2[kp];
+                    v2f w = a * Tk;
+                    const v2f Tn = Tk - w;
+                    const bool stop0 = (w.x > 0.f) && (Tn.x <= tstop), stop1 = (w.y > 0.f) && (Tn.y <= tstop);
+                    const bool use0 = (w.x > 0.f) && !stop0, use1 = (w.y > 0.f) && !stop1;
+                    Tfin2[kp].x = stop0 ? Tk.x : Tfin2[kp].x; Tfin2[kp].y = stop1 ? Tk.y : Tfin2[kp].y;
+                    const bool med0 = use0 && (Tk.x > tmed), med1 = use1 && (Tk.y > tmed);
+                    T2[kp].x = stop0 ? 0.f : Tn.x; T2[kp].y = stop1 ? 0.f : Tn.y;
+                    w.x = stop0 ? 0.f : w.x; w.y = stop1 ? 0.f : w.y;
+                    const v2f zp = (tpx - q2.x * dy) * il2[kp];
+                    col2[kp][0] += w * q3.x;
+                    if (CD > 1) col2[kp][CD > 1 ? 1 : 0] += w * q3.y;
+                    if (CD > 2) col2[kp][CD > 2 ? 2 : 0] += w * q3.z;
+                    if (CD > 3) col2[kp][CD > 3 ? 3 : 0] += w * q3.w;
 #pragma unroll
-                for (int q = 0; q < NXQ; q++) {
-                    colx[k][4 * q + 0] += w * xq[q].x; colx[k][4 * q + 1] += w * xq[q].y;
-                    colx[k][4 * q + 2] += w * xq[q].z; colx[k][4 * q + 3] += w * xq[q].w;
+                    for (int q = 0; q < NXQ; q++) {
+                        colx2[kp][4 * q + 0] += w * xq[q].x; colx2[kp][4 * q + 1] += w * xq[q].y;
+                        colx2[kp][4 * q + 2] += w * xq[q].z; colx2[kp][4 * q + 3] += w * xq[q].w;
+                    }
+                    dep2[kp] += w * zp;
+                    nrm2[kp][0] += w * q2.y; nrm2[kp][1] += w * q2.z; nrm2[kp][2] += w * q2.w;
+                    med2[kp].x = med0 ? zp.x : med2[kp].x; med2[kp].y = med1 ? zp.y : med2[kp].y;
+                    medi[2 * kp] = med0 ? i : medi[2 * kp]; medi[2 * kp + 1] = med1 ? i : medi[2 * kp + 1];
+                    last[2 * kp] = use0 ? i : last[2 * kp]; last[2 * kp + 1] = use1 ? i : last[2 * kp + 1];
+                    tm = fmaxf(tm, fmaxf(T2[kp].x, T2[kp].y));
                 }
-                dep[k] += w * zp;
-                nrm[k][0] += w * q2.y; nrm[k][1] += w * q2.z; nrm[k][2] += w * q2.w;
-                med[k] = is_med ? zp : med[k];
-                medi[k] = is_med ? i : medi[k];
-                last[k] = use ? i : last[k];
-                tm = fmaxf(tm, T[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < PPL; k++) {
+                    const float dy = q0.y - py[k];
+                    const float e = ea + (q1.x * dy + eb) * dy;
+                    const float vis = __builtin_amdgcn_exp2f(e);
+                    float a = fminf(amax, q1.y * vis);
+                    a = (e <= 0.f && a >= amin) ? a : 0.f;
+                    float w = a * T[k];
+                    const float Tn = T[k] - w;
+                    const bool stop = (w > 0.f) && (Tn <= tstop);       // this Gaussian is excluded
+                    const bool use = (w > 0.f) && !stop;
+                    Tfin[k] = stop ? T[k] : Tfin[k];
+                    const bool is_med = use && (T[k] > tmed);
+                    T[k] = stop ? 0.f : Tn;
+                    w = stop ? 0.f : w;
+                    const float zp = (tpx - q2.x * dy) * inv_ell[k];
+                    col[k][0] += w * q3.x;
+                    if (CD > 1) col[k][CD > 1 ? 1 : 0] += w * q3.y;
+                    if (CD > 2) col[k][CD > 2 ? 2 : 0] += w * q3.z;
+                    if (CD > 3) col[k][CD > 3 ? 3 : 0] += w * q3.w;
+#pragma unroll
+                    for (int q = 0; q < NXQ; q++) {
+                        colx[k][4 * q + 0] += w * xq[q].x; colx[k][4 * q + 1] += w * xq[q].y;
+                        colx[k][4 * q + 2] += w * xq[q].z; colx[k][4 * q + 3] += w * xq[q].w;
+                    }
+                    dep[k] += w * zp;
+                    nrm[k][0] += w * q2.y; nrm[k][1] += w * q2.z; nrm[k][2] += w * q2.w;
+                    med[k] = is_med ? zp : med[k];
+                    medi[k] = is_med ? i : medi[k];
+                    last[k] = use ? i : last[k];
+                    tm = fmaxf(tm, T[k]);
+                }
             }
             if (__ballot(tm > 0.f) == 0ull) break;
+        }
+    }
+    if constexpr (PPL % 2 == 0) {
+#pragma unroll
+        for (int kp = 0; kp < NP; kp++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int k = 2 * kp + h;
+                T[k] = h ? T2[kp].y : T2[kp].x; Tfin[k] = h ? Tfin2[kp].y : Tfin2[kp].x;
+                dep[k] = h ? dep2[kp].y : dep2[kp].x; med[k] = h ? med2[kp].y : med2[kp].x;
+#pragma unroll
+                for (int ch = 0; ch < CD; ch++) col[k][ch] = h ? col2[kp][ch].y : col2[kp][ch].x;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) nrm[k][ch] = h ? nrm2[kp][ch].y : nrm2[kp][ch].x;
+#pragma unroll
+                for (int ch = 0; ch < (NXQ > 0 ? 4 * NXQ : 0); ch++) colx[k][ch] = h ? colx2[kp][ch].y : colx2[kp][ch].x;
+            }
         }
     }
 #pragma unroll
@@ -247,9 +334,6 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
         }
     }
 }
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
 
 // ---- wave reductions (DPP / permlane: no LDS traffic) ------------------------------------------
 template <int CTRL>
