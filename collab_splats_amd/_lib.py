@@ -67,7 +67,10 @@ SYMBOLS = {
     "misplat_sort32_pairs": (C.c_int, 9), "misplat_tile_offsets32": (C.c_int, 5),
     "misplat_isect_ids": (C.c_int, 6), "misplat_tile_sort": (C.c_int, 10),
     "misplat_tile_count_blocks": (C.c_int, 8),
-    "misplat_tile_emit_blocks": (C.c_int, 9),
+    "misplat_tile_emit_blocks": (C.c_int, 10),
+    "misplat_sort16_workspace_bytes": (C.c_size_t, 2),
+    "misplat_sort16_pairs": (C.c_int, 9),
+    "misplat_tile_offsets16": (C.c_int, 5),
     "misplat_tile_hist": (C.c_int, 6),
     "misplat_tile_scan": (C.c_int, 5),
     "misplat_tile_scatter": (C.c_int, 9),

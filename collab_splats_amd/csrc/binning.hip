@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void tile_emit_ordered_kernel(int64_t total, i
 
 // offsets[t] = first sorted position whose tile id is >= t.  Four positions per thread, all loads
 // issued before any use.
-__global__ __launch_bounds__(256) void tile_offsets32_kernel(const uint32_t* __restrict__ tiles, int64_t n,
+template <typename KT>
+__global__ __launch_bounds__(256) void tile_offsets32_kernel(const KT* __restrict__ tiles, int64_t n,
                                                              int n_tiles, int32_t* __restrict__ offsets) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 <= n; i0 += 4 * stride) {
@@ -621,12 +622,13 @@ __global__ __launch_bounds__(1024) void tile_block_scan_kernel(int n_blocks, con
     if (threadIdx.x == 1023) *n_isects = (int64_t)(carry + incl);
 }
 
+template <typename KT>
 __global__ __launch_bounds__(MISPLAT_COUNT_BLOCK) void tile_emit_blocks_kernel(int64_t total, int n_gauss, int tw, int th,
                                                                                const float* __restrict__ means2d,
                                                                                const int32_t* __restrict__ radii,
                                                                                const int32_t* __restrict__ tiles_per_gauss,
                                                                                const int64_t* __restrict__ block_offs,
-                                                                               uint32_t* __restrict__ tile_ids,
+                                                                               KT* __restrict__ tile_ids,
                                                                                int32_t* __restrict__ slot_ids,
                                                                                int32_t* __restrict__ isect_gid) {
     // slot_ids == NULL: only the Gaussian row is emitted (it is then the sort payload)
@@ -647,7 +649,7 @@ __global__ __launch_bounds__(MISPLAT_COUNT_BLOCK) void tile_emit_blocks_kernel(i
     const uint32_t base = (uint32_t)(idx / n_gauss) * (uint32_t)(tw * th);
     for (int ty = y0; ty < y1; ty++)
         for (int tx = x0; tx < x1; tx++) {
-            tile_ids[j] = base + (uint32_t)(ty * tw + tx);
+            tile_ids[j] = (KT)(base + (uint32_t)(ty * tw + tx));
             if (slot_ids) slot_ids[j] = (int32_t)j;
             isect_gid[j] = (int32_t)idx;
             j++;
@@ -866,9 +868,44 @@ extern "C" int misplat_sort32_pairs(void* workspace, size_t workspace_bytes, con
 extern "C" int misplat_tile_offsets32(const uint32_t* tiles_sorted, int64_t n_isects, int32_t n_tiles_total,
                                       int32_t* offsets, misplat_stream_t stream) {
     if (n_isects < 0 || n_tiles_total < 1) return MISPLAT_EINVAL;
-    hipLaunchKernelGGL(tile_offsets32_kernel, dim3(grid_for((n_isects + 4) / 4, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(tile_offsets32_kernel<uint32_t>, dim3(grid_for((n_isects + 4) / 4, 256)), dim3(256), 0,
                        (hipStream_t)stream, tiles_sorted, n_isects, n_tiles_total, offsets);
     return check_launch();
+}
+
+extern "C" int misplat_tile_offsets16(const uint16_t* tiles_sorted, int64_t n_isects, int32_t n_tiles_total,
+                                      int32_t* offsets, misplat_stream_t stream) {
+    if (n_isects < 0 || n_tiles_total < 1 || n_tiles_total > 65536) return MISPLAT_EINVAL;
+    hipLaunchKernelGGL(tile_offsets32_kernel<uint16_t>, dim3(grid_for((n_isects + 4) / 4, 256)), dim3(256), 0,
+                       (hipStream_t)stream, tiles_sorted, n_isects, n_tiles_total, offsets);
+    return check_launch();
+}
+
+// 16-bit tile keys (C * tiles <= 65536, i.e. everything up to 4K single views): 12 instead of 16 bytes
+// of traffic per pair and pass.
+extern "C" size_t misplat_sort16_workspace_bytes(int64_t n, int32_t end_bit) {
+    size_t bytes = 0;
+    if (n <= 0) return 16;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (const uint16_t*)nullptr, (uint16_t*)nullptr,
+                                             (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u,
+                                             (unsigned)end_bit, (hipStream_t) nullptr);
+    if (e != hipSuccess) return 0;
+    return bytes < 16 ? 16 : bytes;
+}
+
+extern "C" int misplat_sort16_pairs(void* workspace, size_t workspace_bytes, const uint16_t* keys_in,
+                                    uint16_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
+                                    int32_t end_bit, misplat_stream_t stream) {
+    if (n < 0 || end_bit < 1 || end_bit > 16) return MISPLAT_EINVAL;
+    if (n == 0) return MISPLAT_OK;
+    size_t need = 0;
+    if (rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
+                                  (unsigned)end_bit, (hipStream_t)stream) != hipSuccess)
+        return MISPLAT_ELAUNCH;
+    if (need > workspace_bytes) return MISPLAT_EWORKSPACE;
+    hipError_t e = rocprim::radix_sort_pairs(workspace, workspace_bytes, keys_in, keys_out, vals_in, vals_out,
+                                             (size_t)n, 0u, (unsigned)end_bit, (hipStream_t)stream);
+    return e == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
 }
 
 extern "C" int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, const float* depths,
@@ -977,14 +1014,21 @@ extern "C" int misplat_tile_count_blocks(const misplat_params* p, const float* m
 }
 
 extern "C" int misplat_tile_emit_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
-                                        const int32_t* tiles_per_gauss, const int64_t* block_offs, uint32_t* tile_ids,
-                                        int32_t* slot_ids, int32_t* isect_gid, misplat_stream_t stream) {
-    if (!p || p->tile_size != MISPLAT_TILE) return MISPLAT_EINVAL;
+                                        const int32_t* tiles_per_gauss, const int64_t* block_offs, void* tile_ids,
+                                        int32_t key_bytes, int32_t* slot_ids, int32_t* isect_gid,
+                                        misplat_stream_t stream) {
+    if (!p || p->tile_size != MISPLAT_TILE || (key_bytes != 2 && key_bytes != 4)) return MISPLAT_EINVAL;
+    if (key_bytes == 2 && (int64_t)p->tile_w * p->tile_h * p->n_cams > 65536) return MISPLAT_EINVAL;
     const int64_t total = (int64_t)p->n_gauss * p->n_cams;
     if (total == 0) return MISPLAT_OK;
     const int64_t n_blocks = (total + MISPLAT_COUNT_BLOCK - 1) / MISPLAT_COUNT_BLOCK;
-    hipLaunchKernelGGL(tile_emit_blocks_kernel, dim3((unsigned)n_blocks), dim3(MISPLAT_COUNT_BLOCK), 0,
-                       (hipStream_t)stream, total, p->n_gauss, p->tile_w, p->tile_h, means2d, radii, tiles_per_gauss,
-                       block_offs, tile_ids, slot_ids, isect_gid);
+    if (key_bytes == 2)
+        hipLaunchKernelGGL(tile_emit_blocks_kernel<uint16_t>, dim3((unsigned)n_blocks), dim3(MISPLAT_COUNT_BLOCK), 0,
+                           (hipStream_t)stream, total, p->n_gauss, p->tile_w, p->tile_h, means2d, radii,
+                           tiles_per_gauss, block_offs, (uint16_t*)tile_ids, slot_ids, isect_gid);
+    else
+        hipLaunchKernelGGL(tile_emit_blocks_kernel<uint32_t>, dim3((unsigned)n_blocks), dim3(MISPLAT_COUNT_BLOCK), 0,
+                           (hipStream_t)stream, total, p->n_gauss, p->tile_w, p->tile_h, means2d, radii,
+                           tiles_per_gauss, block_offs, (uint32_t*)tile_ids, slot_ids, isect_gid);
     return check_launch();
 }

@@ -208,7 +208,8 @@ def _sort_ws_bytes(lib, kind: str, n: int, end_bit: int) -> int:
     """rocPRIM temp-storage size; depends only on (n, end_bit), so cache it (host-side query)."""
     key = (kind, n, end_bit)
     if key not in _WS_CACHE:
-        fn = lib.misplat_sort_workspace_bytes if kind == "u64" else lib.misplat_sort32_workspace_bytes
+        fn = {"u64": lib.misplat_sort_workspace_bytes, "u32": lib.misplat_sort32_workspace_bytes,
+              "u16": lib.misplat_sort16_workspace_bytes}[kind]
         b = int(fn(C.c_int64(n), C.c_int32(end_bit)))
         if b == 0:
             raise _lib.MisplatError("sort workspace query failed")
@@ -345,25 +346,39 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor,
     if n_isects >= 2 ** 31:
         raise _lib.MisplatError(f"{n_isects} tile intersections exceed int32 indexing")
     # emit in that order, bucket by tile (stable radix on the tile bits)
-    tile_ids = torch.empty(n_isects, **i32)
+    key16 = pertile and SORT_BACKEND == "rocprim" and n_tiles <= 65536     # 12 instead of 16 B per pair and pass
+    tile_ids = torch.empty(n_isects, device=dev, dtype=torch.int16 if key16 else torch.int32)
     isect_gid = torch.empty(n_isects, **i32)
     slots = torch.empty(n_isects, **i32) if deterministic else None
     tile_ids_s, payload_s = torch.empty_like(tile_ids), torch.empty(n_isects, **i32)
     offsets = torch.empty(n_tiles, **i32)
+    tile_bits = max(1, (n_tiles - 1).bit_length())
     if n_isects > 0:
         if pertile:
             check(lib.misplat_tile_emit_blocks(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss),
-                                               ptr(block_offs), ptr(tile_ids), ptr(slots), ptr(isect_gid),
-                                               stream_ptr()), "misplat_tile_emit_blocks")
+                                               ptr(block_offs), ptr(tile_ids), C.c_int32(2 if key16 else 4), ptr(slots),
+                                               ptr(isect_gid), stream_ptr()), "misplat_tile_emit_blocks")
         else:
             check(lib.misplat_tile_emit_ordered(C.byref(P), ptr(order), ptr(means2d), ptr(radii), ptr(cum_ordered),
                                                 ptr(tile_ids), ptr(slots), ptr(isect_gid), stream_ptr()),
                   "misplat_tile_emit_ordered")
-        tile_bits = max(1, (n_tiles - 1).bit_length())
-        _sort32(lib, tile_ids, tile_ids_s, slots if deterministic else isect_gid, payload_s, n_isects, tile_bits,
-                SORT_BITS_TILE)
-    check(lib.misplat_tile_offsets32(ptr(tile_ids_s), C.c_int64(n_isects), C.c_int32(n_tiles), ptr(offsets),
-                                     stream_ptr()), "misplat_tile_offsets32")
+        if key16:
+            ws_bytes = _sort_ws_bytes(lib, "u16", n_isects, tile_bits)
+            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
+            check(lib.misplat_sort16_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(tile_ids), ptr(tile_ids_s),
+                                           ptr(slots if deterministic else isect_gid), ptr(payload_s),
+                                           C.c_int64(n_isects), C.c_int32(tile_bits), stream_ptr()),
+                  "misplat_sort16_pairs")
+        else:
+            _sort32(lib, tile_ids, tile_ids_s, slots if deterministic else isect_gid, payload_s, n_isects, tile_bits,
+                    SORT_BITS_TILE)
+    if key16:
+        check(lib.misplat_tile_offsets16(ptr(tile_ids_s), C.c_int64(n_isects), C.c_int32(n_tiles), ptr(offsets),
+                                         stream_ptr()), "misplat_tile_offsets16")
+        tile_ids_s = None                              # isect_ids() rebuilds the 32-bit tile ids from the offsets
+    else:
+        check(lib.misplat_tile_offsets32(ptr(tile_ids_s), C.c_int64(n_isects), C.c_int32(n_tiles), ptr(offsets),
+                                         stream_ptr()), "misplat_tile_offsets32")
     if pertile and n_isects > 0:
         # every tile's bucket -> (depth, row) order, one workgroup per tile, in LDS
         flatten_ids = torch.empty(n_isects, **i32)

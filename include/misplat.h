@@ -208,8 +208,16 @@ int misplat_tile_count_blocks(const misplat_params* p, const float* means2d, con
                               int32_t* tiles_per_gauss, int32_t* block_sums, int64_t* block_offs,
                               int64_t* n_isects, misplat_stream_t stream);
 int misplat_tile_emit_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
-                             const int32_t* tiles_per_gauss, const int64_t* block_offs, uint32_t* tile_ids,
-                             int32_t* slot_ids, int32_t* isect_gid, misplat_stream_t stream);
+                             const int32_t* tiles_per_gauss, const int64_t* block_offs, void* tile_ids,
+                             int32_t key_bytes, int32_t* slot_ids, int32_t* isect_gid, misplat_stream_t stream);
+/* key_bytes = 2: uint16 tile keys (C * tiles <= 65536), sorted with sort16_pairs and scanned with
+ * tile_offsets16 -- 12 instead of 16 bytes of traffic per pair and radix pass; key_bytes = 4: uint32. */
+size_t misplat_sort16_workspace_bytes(int64_t n, int32_t end_bit);
+int misplat_sort16_pairs(void* workspace, size_t workspace_bytes, const uint16_t* keys_in,
+                         uint16_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
+                         int32_t end_bit, misplat_stream_t stream);
+int misplat_tile_offsets16(const uint16_t* tiles_sorted, int64_t n_isects, int32_t n_tiles_total,
+                           int32_t* offsets, misplat_stream_t stream);
 
 /* Bucketing without a sort ("scatter" ordering; replaces tile_count + tile_emit + the tile-id sort +
  * tile_offsets of gsplat's isect_tiles / isect_offset_encode):

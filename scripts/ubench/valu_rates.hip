@@ -39,6 +39,47 @@ __global__ __launch_bounds__(256) void k(float* out, int n) {
             } else if (MODE == 5) {   // v_exp_f32 x8
                 a0 = __builtin_amdgcn_exp2f(a0); a1 = __builtin_amdgcn_exp2f(a1); a2 = __builtin_amdgcn_exp2f(a2); a3 = __builtin_amdgcn_exp2f(a3);
                 a4 = __builtin_amdgcn_exp2f(a4); a5 = __builtin_amdgcn_exp2f(a5); a6 = __builtin_amdgcn_exp2f(a6); a7 = __builtin_amdgcn_exp2f(a7);
+            } else if (MODE == 7) {   // 8 x v_pk_fma_f32 (4 independent 2-vectors, 2 rounds)
+                typedef float v2f __attribute__((ext_vector_type(2)));
+                v2f p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p0) : "v"(p1), "v"(p2));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p1) : "v"(p2), "v"(p3));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p2) : "v"(p3), "v"(p0));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p3) : "v"(p0), "v"(p1));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p0) : "v"(p1), "v"(p2));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p1) : "v"(p2), "v"(p3));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p2) : "v"(p3), "v"(p0));
+                asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p3) : "v"(p0), "v"(p1));
+                a0 = p0.x; a1 = p0.y; a2 = p1.x; a3 = p1.y; a4 = p2.x; a5 = p2.y; a6 = p3.x; a7 = p3.y;
+            } else if (MODE == 8) {   // 8 x v_fma_f32
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a0) : "v"(a1), "v"(a2));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a1) : "v"(a2), "v"(a3));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a2) : "v"(a3), "v"(a4));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a3) : "v"(a4), "v"(a5));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a4) : "v"(a5), "v"(a6));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a5) : "v"(a6), "v"(a7));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a6) : "v"(a7), "v"(a0));
+                asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a7) : "v"(a0), "v"(a1));
+            } else if (MODE == 9) {   // 4 x (v_cmp_e64 -> sgpr, v_cndmask_e64)
+                asm volatile("v_cmp_lt_f32_e64 s[20:21], %1, %2\n v_cndmask_b32_e64 %0, %1, %2, s[20:21]" : "=v"(a0) : "v"(a1), "v"(a2) : "s20", "s21");
+                asm volatile("v_cmp_lt_f32_e64 s[22:23], %1, %2\n v_cndmask_b32_e64 %0, %1, %2, s[22:23]" : "=v"(a1) : "v"(a2), "v"(a3) : "s22", "s23");
+                asm volatile("v_cmp_lt_f32_e64 s[24:25], %1, %2\n v_cndmask_b32_e64 %0, %1, %2, s[24:25]" : "=v"(a2) : "v"(a3), "v"(a4) : "s24", "s25");
+                asm volatile("v_cmp_lt_f32_e64 s[26:27], %1, %2\n v_cndmask_b32_e64 %0, %1, %2, s[26:27]" : "=v"(a3) : "v"(a4), "v"(a5) : "s26", "s27");
+            } else if (MODE == 10) {  // 8 x v_mul_f32 via asm (baseline for asm modes)
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a0) : "v"(a1));
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a1) : "v"(a2));
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a2) : "v"(a3));
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a3) : "v"(a4));
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a4) : "v"(a5));
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a5) : "v"(a6));
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a6) : "v"(a7));
+                asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a7) : "v"(a0));
+            } else if (MODE == 11) {  // 8 x ds_read_b128 broadcast (same address for all lanes)
+                __shared__ float4 lds[64];
+                float4 r;
+                asm volatile("ds_read_b128 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(r) : "v"((u & 7) * 16) : "memory");
+                a0 += r.x; a1 += r.y; a2 += r.z; a3 += r.w;
+                (void)lds;
             } else if (MODE == 6) {   // v_cndmask x8
                 const bool s = (threadIdx.x + i) & 4;
                 a0 = s ? a1 : a0; a1 = s ? a2 : a1; a2 = s ? a3 : a2; a3 = s ? a4 : a3; a4 = s ? a5 : a4; a5 = s ? a6 : a5; a6 = s ? a7 : a6; a7 = s ? a0 : a7;
@@ -70,5 +111,10 @@ int main() {
     run<4>("4 x (2 masked add_dpp + mul)", 12);
     run<5>("8 x v_exp_f32", 8);
     run<6>("8 x v_cndmask", 8);
+    run<7>("8 x v_pk_fma_f32", 8);
+    run<8>("8 x v_fma_f32", 8);
+    run<9>("4 x (v_cmp_e64 + v_cndmask)", 8);
+    run<10>("8 x v_mul_f32 (asm)", 8);
+    run<11>("1 x ds_read_b128 bcast + 4 add", 5);
     return 0;
 }
