@@ -91,11 +91,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MISPLAT_LIB", LIB_PATH)      # developer knob: an alternative build of the same ABI
+    if not os.path.exists(path):
         raise MisplatError(
-            f"{LIB_PATH} not found: build it with `python -m collab_splats_amd.build` "
+            f"{path} not found: build it with `python -m collab_splats_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, _) in SYMBOLS.items():
         getattr(lib, name).restype = res
     _lib = lib

@@ -425,7 +425,10 @@ __device__ __forceinline__ int wave_max(int v) {
 // scratch) 0.616 ms, 6 waves (80 VGPRs + 88 B scratch) 0.711 ms.
 // PPL 4: 2 waves (172 VGPRs) 0.73 ms, 3 waves 0.655 ms, 4 waves (spills) 1.28 ms.
 template <int CD, int PPL, bool ABS, bool ATOMIC, int NXQ = 0>
-__global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? 5 : (PPL == 4 ? 3 : 1)) void blend_bwd_kernel(
+#ifndef MISPLAT_BWD_WAVES
+#define MISPLAT_BWD_WAVES 5
+#endif
+__global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (PPL == 4 ? 3 : 1)) void blend_bwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ slots,
     const int32_t* __restrict__ offsets, int64_t n_isects, const float* __restrict__ alpha,
