@@ -10,6 +10,7 @@ from .rendering import rasterization  # noqa: F401
 from .wrapper import fully_fused_projection, spherical_harmonics  # noqa: F401
 from .strategy import DefaultStrategy  # noqa: F401
 from .ops import set_deterministic  # noqa: F401
+from .optim import FusedAdam, step_all as fused_adam_step_all  # noqa: F401
 
 __version__ = "0.1.0"
 

@@ -71,6 +71,7 @@ SYMBOLS = {
     "misplat_sort16_workspace_bytes": (C.c_size_t, 2),
     "misplat_sort16_pairs": (C.c_int, 9),
     "misplat_tile_offsets16": (C.c_int, 5),
+    "misplat_adam_step": (C.c_int, 12),
     "misplat_tile_hist": (C.c_int, 6),
     "misplat_tile_scan": (C.c_int, 5),
     "misplat_tile_scatter": (C.c_int, 9),

@@ -29,6 +29,7 @@ SOURCES = {
     "blend.hip": [],
     "epilogue.hip": [],
     "sort.hip": [],
+    "optim.hip": [],
 }
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Minimal training loop on the MI355X: RadegsModel (host mirror of the reference's rade-gs model) +
-one Adam optimizer per parameter group (learning rates of collab_splats/configs/rade_gs_method.py:44-71)
+one (fused) Adam optimizer per parameter group (learning rates of collab_splats/configs/rade_gs_method.py:44-71)
 + DefaultStrategy densification, fitting renders of a hidden synthetic scene from a ring of cameras.
 
     python examples/train_synthetic.py [--steps 300] [--gaussians 20000] [--width 320] [--height 200]
@@ -14,7 +14,7 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from collab_splats_amd import radegs  # noqa: E402
+from collab_splats_amd import FusedAdam, fused_adam_step_all, radegs  # noqa: E402
 from collab_splats_amd.synthetic import random_scene  # noqa: E402
 
 
@@ -56,7 +56,8 @@ def train(steps=300, n=20000, W=320, H=200, n_views=8, refine_every=50, seed=0, 
     model.step = 10                                    # all SH degrees active
     model.strategy.refine_start_iter, model.strategy.refine_every = 0, refine_every
     model.strategy.grow_grad2d, model.strategy.refine_stop_iter = 2e-4, steps
-    model.optimizers = {k: torch.optim.Adam([v], lr=LRS[k], eps=1e-15) for k, v in model.gauss_params.items()}
+    # one FusedAdam per parameter group (the interface the strategy edits), all stepped by ONE kernel launch
+    model.optimizers = {k: FusedAdam([v], lr=LRS[k], eps=1e-15) for k, v in model.gauss_params.items()}
     log = []
     t0 = time.perf_counter()
     for it in range(steps):
@@ -68,8 +69,7 @@ def train(steps=300, n=20000, W=320, H=200, n_views=8, refine_every=50, seed=0, 
         losses = model.get_loss_dict(out, {"image": tgt})
         loss = sum(losses.values())
         loss.backward()
-        for o in model.optimizers.values():
-            o.step()
+        fused_adam_step_all(model.optimizers)
         counts = model.strategy.step_post_backward(model.gauss_params, model.optimizers, model.strategy_state, it + 1, model.info)
         log.append((losses["rgb_loss"].item(), model.means.shape[0], counts))
         if verbose and (it % 50 == 0 or it == steps - 1):

@@ -352,6 +352,21 @@ int misplat_outputs_bwd(int64_t n_pix, int32_t color_dim, const float* backgroun
                         float* v_exp_depth, float* v_med_depth, float* v_exp_normal,
                         misplat_stream_t stream);
 
+/* ---- optimiser step --------------------------------------------
+ * Fused multi-tensor Adam with torch.optim.Adam semantics (no weight decay, no amsgrad, maximize = False),
+ * replacing the six per-group optimisers the reference configures at
+ * collab_splats/configs/rade_gs_method.py:44-71 (lr per group, eps = 1e-15):
+ *   m = m + (g - m)(1 - beta1);  v = beta2 v + (1 - beta2) g^2;
+ *   p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+ * params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors device pointers (16-byte aligned, fp32,
+ * contiguous); numel, lr, step (t >= 1, already incremented): host arrays.  One launch, in place.
+ * beta1 / beta2 / eps are doubles because torch forms 1 - beta and the bias corrections in double. */
+#define MISPLAT_ADAM_MAX_TENSORS 8
+int misplat_adam_step(int32_t n_tensors, float* const* params, const float* const* grads,
+                      float* const* exp_avg, float* const* exp_avg_sq, const int64_t* numel,
+                      const float* lr, const int64_t* step, double beta1, double beta2, double eps,
+                      misplat_stream_t stream);
+
 /* Library identification ("misplat <version> gfx950"). */
 const char* misplat_version(void);
 

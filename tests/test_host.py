@@ -154,3 +154,16 @@ def test_shard_views_partitions_exactly():
         got = [parallel.shard_views(n, r, w) for r in range(w)]
         assert sorted(sum(got, [])) == list(range(n))
         assert max(len(g) for g in got) - min(len(g) for g in got) <= 1
+
+
+def test_fused_adam_refuses_cpu_tensors():
+    """No CPU fallback: the fused optimiser fails loudly on CPU parameters."""
+    import torch
+    from collab_splats_amd import FusedAdam, MisplatError
+    p = torch.zeros(4, requires_grad=True)
+    p.grad = torch.ones(4)
+    opt = FusedAdam([p], lr=1e-3)
+    with pytest.raises(MisplatError):
+        opt.step()
+    with pytest.raises(ValueError):
+        FusedAdam([p], lr=-1.0)
