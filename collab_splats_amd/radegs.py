@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Union
+from typing import Dict, List, Optional, Sequence, Union
 
 import torch
 import torch.nn.functional as F
@@ -98,6 +98,20 @@ def camera_parameters(camera, device: Optional[torch.device] = None) -> Dict[str
     Ks = torch.tensor([[fx, 0.0, W / 2.0], [0.0, fy, H / 2.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
     return {"Ks": Ks[None].to(device), "viewmats": viewmat[None].to(device), "image_width": W,
             "image_height": H, "camera_center": c2w[:3, 3].to(device), "fx": fx, "fy": fy}
+
+
+def tsdf_frame(camera):
+    """Extrinsic / intrinsic pair the reference hands to Open3D's TSDF integration for one view
+    (mesh.py:1591-1604, 1626-1630): ``extrinsic = inv(c2w @ diag(1,-1,-1,1))`` (OpenGL -> OpenCV, world -> camera,
+    float64 numpy) and ``dict(width, height, fx, fy, cx, cy)`` for ``o3d.camera.PinholeCameraIntrinsic``."""
+    import numpy as np
+    c2w = torch.eye(4, dtype=torch.float64)
+    c2w[:3, :4] = camera.camera_to_worlds.reshape(-1, 3, 4)[0].detach().double().cpu()
+    c2w = c2w @ torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0], dtype=torch.float64))
+    K = camera.get_intrinsics_matrices().reshape(-1, 3, 3)[0].detach().double().cpu()
+    intr = dict(width=int(camera.width.item()), height=int(camera.height.item()), fx=float(K[0, 0]), fy=float(K[1, 1]),
+                cx=float(K[0, 2]), cy=float(K[1, 2]))
+    return np.linalg.inv(c2w.numpy()), intr
 
 
 def build_rotation(quats: Tensor) -> Tensor:
@@ -285,6 +299,50 @@ class RadegsModel(nn.Module):
             "middepth_normal_error_map": normal_error_map[1, ...].unsqueeze(-1),
             "background": background,
         }
+
+    @torch.no_grad()
+    def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, Union[Tensor, List, None]]:
+        """Splatfacto's no-grad entry used by the meshing loop (mesh.py:1581-1584).  ``obb_box`` cropping is a
+        nerfstudio feature on the other side of the boundary: only ``None`` is accepted."""
+        if obb_box is not None:
+            raise NotImplementedError("obb_box cropping is outside the rasterizer path (SURVEY.md section 8)")
+        return self.get_outputs(camera.to(self.device) if hasattr(camera, "to") else camera)
+
+    @torch.no_grad()
+    def render_views(self, cameras: Sequence, batch_size: int = 4) -> Dict[str, Tensor]:
+        """Eval-time batch rendering for the TSDF hand-off (the reference renders
+        every training view one by one through ``get_outputs_for_camera`` and copies each map to the host,
+        mesh.py:1572-1630).  ``batch_size`` views go through ONE rasterization call (the camera batch dimension of
+        the kernels), the a3 epilogue runs per view (its ``max`` reductions are per image), and the stacked maps
+        ``rgb[V,H,W,3] depth[V,H,W,1] median_depth[V,H,W,1] accumulation[V,H,W,1] normals[V,H,W,3]`` stay on
+        the device.  Values are identical to ``get_outputs`` in eval mode, view by view."""
+        if self.config.rasterize_mode not in ["antialiased", "classic"]:
+            raise ValueError("Unknown rasterize_mode: %s", self.config.rasterize_mode)
+        if self.config.sh_degree > 0:
+            colors = (self.features_dc, self.features_rest)
+            sh_degree_to_use = min(self.step // self.config.sh_degree_interval, self.config.sh_degree)
+        else:
+            colors, sh_degree_to_use = torch.sigmoid(self.features_dc), None
+        bg_list = self._background_list()
+        out: Dict[str, List[Tensor]] = {k: [] for k in ("rgb", "depth", "median_depth", "accumulation", "normals")}
+        cameras = list(cameras)
+        for b in range(0, len(cameras), max(1, int(batch_size))):
+            params = [self._get_camera_parameters(c) for c in cameras[b:b + max(1, int(batch_size))]]
+            W, H = int(params[0]["image_width"]), int(params[0]["image_height"])
+            if any((int(p["image_width"]), int(p["image_height"])) != (W, H) for p in params):
+                raise ValueError("render_views: the views of one batch must share a resolution")
+            cp = dict(params[0])
+            cp["viewmats"] = torch.cat([p["viewmats"] for p in params], dim=0)
+            cp["Ks"] = torch.cat([p["Ks"] for p in params], dim=0)
+            render, alpha, exp_d, med_d, exp_n, _ = self._render(
+                means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities, colors=colors,
+                render_mode="RGB+ED", sh_degree_to_use=sh_degree_to_use, camera_params=cp)
+            for c in range(len(params)):
+                sl = slice(c, c + 1)
+                ep = ops.outputs_epilogue(render[sl], alpha[sl], exp_d[sl], med_d[sl], exp_n[sl], bg_list, False)
+                out["rgb"].append(ep[0]); out["depth"].append(ep[1]); out["median_depth"].append(ep[2])
+                out["normals"].append(ep[3]); out["accumulation"].append(alpha[sl])
+        return {k: torch.cat(v, dim=0) for k, v in out.items()}
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
         """rade_gs_model.py:274-309.  The Splatfacto base loss (L1 + SSIM, third-party, absent) is

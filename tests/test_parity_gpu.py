@@ -729,3 +729,35 @@ def test_fused_adam_matches_torch_adam(dev):
         o1.step(); o2.step()
     for a, b in zip(many, many_ref):
         assert rel_err(a, b) < 2e-6
+
+
+def test_render_views_batch_equals_single_view_outputs(dev):
+    """Eval-time batch rendering (section 8(f) rank 4): V views through the camera batch dimension of the kernels
+    give, view by view, exactly what get_outputs_for_camera gives one at a time; tsdf_frame reproduces the
+    extrinsic / intrinsic the reference hands to Open3D (mesh.py:1591-1604, 1626-1630)."""
+    import math
+    from collab_splats_amd import radegs
+    from collab_splats_amd.synthetic import random_scene, view_matrix
+    W, H, N = 200, 120, 8000
+    sc = random_scene(N, W, H, seed=5)
+    cfg = radegs.RadegsModelConfig(rasterize_mode="antialiased")
+    model = radegs.RadegsModel(cfg, sc["means"], sc["log_scales"], sc["quats"], sc["opacity_logits"], sc["sh"][:, 0],
+                               sc["sh"][:, 1:]).to(dev).eval()
+    model.step = 10_000
+    flip = torch.diag(torch.tensor([1.0, -1.0, -1.0, 1.0]))
+    cams = []
+    for i in range(5):
+        c2w = torch.linalg.inv(view_matrix(i)[0]) @ flip                 # OpenCV w2c -> OpenGL c2w
+        cams.append(radegs.PinholeCamera.make(c2w[:3, :4], 0.9 * W, 0.9 * W, W, H))
+    batched = model.render_views(cams, batch_size=3)                        # batches of 3 + 2
+    assert batched["rgb"].shape == (5, H, W, 3) and batched["depth"].shape == (5, H, W, 1)
+    for i, cam in enumerate(cams):
+        one = model.get_outputs_for_camera(cam)
+        for k in ("rgb", "depth", "median_depth", "accumulation", "normals"):
+            assert torch.equal(batched[k][i], one[k]), (i, k)
+    assert (batched["accumulation"] > 0).float().mean() > 0.5
+    with pytest.raises(NotImplementedError):
+        model.get_outputs_for_camera(cams[0], obb_box=object())
+    ext, intr = radegs.tsdf_frame(cams[1])
+    assert np.allclose(ext, view_matrix(1)[0].double().numpy(), atol=1e-6)  # world -> OpenCV camera
+    assert intr == dict(width=W, height=H, fx=0.9 * W, fy=0.9 * W, cx=W / 2.0, cy=H / 2.0)
