@@ -761,3 +761,25 @@ def test_render_views_batch_equals_single_view_outputs(dev):
     ext, intr = radegs.tsdf_frame(cams[1])
     assert np.allclose(ext, view_matrix(1)[0].double().numpy(), atol=1e-6)  # world -> OpenCV camera
     assert intr == dict(width=W, height=H, fx=0.9 * W, fy=0.9 * W, cx=W / 2.0, cy=H / 2.0)
+
+
+def test_many_tiles_fall_back_to_32bit_tile_keys(dev):
+    """C * tiles > 65536 (5 cameras x 128 x 128 tiles) takes the 32-bit tile-key path of the bucket sort; every
+    camera of the batch must still equal its own single-camera render bit for bit."""
+    from collab_splats_amd import rasterization
+    from collab_splats_amd.synthetic import random_scene, view_matrix
+    W = H = 2048
+    N = 3000
+    sc = random_scene(N, W, H, seed=9)
+    base = [sc["means"].to(dev), sc["quats"].to(dev), torch.exp(sc["log_scales"]).to(dev) * 4.0,
+            torch.sigmoid(sc["opacity_logits"]).to(dev), sc["sh"].to(dev)]
+    V = torch.cat([view_matrix(i) for i in range(5)], dim=0).to(dev)
+    K = sc["Ks"].to(dev).expand(5, 3, 3).contiguous()
+    kw = dict(sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True)
+    full = rasterization(*base, V, K, W, H, **kw)
+    assert full[5]["isect_offsets"].numel() == 5 * 128 * 128 > 65536
+    for c in (0, 3, 4):
+        one = rasterization(*base, V[c:c + 1], K[c:c + 1], W, H, **kw)
+        for a, b in zip(full[:5], one[:5]):
+            assert torch.equal(a[c], b[0]), c
+        assert (one[1] > 0).any()
