@@ -124,7 +124,10 @@ __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; 
 // NXQ > 0: N-D colours (rade_features_model.py:441-476, D = 16 / 17): channels 0..3 ride in the record,
 // channels 4.. in featx[row][NXQ] (float4s, zero padded); n_channels = D' is the render width.
 template <int CD, int PPL, int NXQ = 0>
-__global__ __launch_bounds__(64) void blend_fwd_kernel(
+#ifndef MISPLAT_FWD_WAVES
+#define MISPLAT_FWD_WAVES 0            /* 0: let the compiler choose (80 VGPRs -> 6 waves/SIMD for PPL 2) */
+#endif
+__global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0) ? MISPLAT_FWD_WAVES : 1) void blend_fwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ offsets, int64_t n_isects,
     float* __restrict__ render, float* __restrict__ alpha, float* __restrict__ exp_depth,
@@ -201,22 +204,26 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
                                          nullptr, xlo, xhi, ylo, yhi, amin, smx, featx);
         __syncthreads();
         if (n == 0) continue;
-        float4 n0 = sm[0], n1 = sm[64], n2 = sm[128], n3 = sm[192];
-        int ni = sm_idx[0];
+        // LDS latency is hidden without a second register set: the half of the record consumed late (q2, q3 =
+        // ray plane / normal / colour, and the index) is read at the top of its own iteration, the half consumed
+        // early (q0, q1 = mean, conic, opacity) is read for the NEXT Gaussian as soon as this one's alpha is known.
+        // The scheduling fences keep the reads where they are written (the compiler otherwise sinks them to
+        // their first use and every iteration starts with an exposed ds_read).
+        float4 q0 = sm[0], q1 = sm[64];
         for (int j = 0; j < n; j++) {
-            const float4 q0 = n0, q1 = n1, q2 = n2, q3 = n3;
-            const int i = ni;
-            n0 = sm[j + 1]; n1 = sm[64 + j + 1]; n2 = sm[128 + j + 1]; n3 = sm[192 + j + 1];   // prefetch (padded)
-            ni = sm_idx[j + 1];
+            const float4 q2 = sm[128 + j], q3 = sm[192 + j];
+            const int i = sm_idx[j];
             float4 xq[NXQ > 0 ? NXQ : 1];
 #pragma unroll
             for (int q = 0; q < NXQ; q++) xq[q] = smx[q * 64 + j];
+            __builtin_amdgcn_sched_barrier(0);
             const float dx = q0.x - px;
             const float ea = q0.z * dx * dx, eb = q0.w * dx;
             const float tpx = q1.z - q1.w * dx;
             float tm = 0.f;
             if constexpr (PPL % 2 == 0) {
                 // two pixels of the lane per packed instruction (see blend_bwd_kernel)
+                v2f dy_[NP], a_[NP];
 #pragma unroll
                 for (int kp = 0; kp < NP; kp++) {
                     const v2f dy = q0.y - py2[kp];
@@ -227,6 +234,13 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
                     const float am0 = fminf(amax, ov.x), am1 = fminf(amax, ov.y);
                     v2f a;
                     a.x = (e.x <= 0.f && am0 >= amin) ? am0 : 0.f; a.y = (e.y <= 0.f && am1 >= amin) ? am1 : 0.f;
+                    dy_[kp] = dy; a_[kp] = a;
+                }
+                q0 = sm[j + 1]; q1 = sm[64 + j + 1];                   // next Gaussian (array padded)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int kp = 0; kp < NP; kp++) {
+                    const v2f dy = dy_[kp], a = a_[kp];
                     const v2f Tk = T2[kp];
                     v2f w = a * Tk;
                     const v2f Tn = Tk - w;
@@ -286,6 +300,7 @@ __global__ __launch_bounds__(64) void blend_fwd_kernel(
                     last[k] = use ? i : last[k];
                     tm = fmaxf(tm, T[k]);
                 }
+                q0 = sm[j + 1]; q1 = sm[64 + j + 1];                   // next Gaussian (array padded)
             }
             if (__ballot(tm > 0.f) == 0ull) break;
         }
