@@ -104,7 +104,15 @@ def load() -> C.CDLL:
     return lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr() -> C.c_void_p:
+    """The current HIP stream of the current device (what every entry point launches on).  Uses torch's raw
+    accessors when present: the public ``torch.cuda.current_stream()`` costs ~10 us per call, 11 calls a step."""
+    if _raw_stream is not None and _raw_device is not None:
+        return C.c_void_p(_raw_stream(_raw_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
