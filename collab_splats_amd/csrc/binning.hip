@@ -934,18 +934,22 @@ template <bool HAS_VALS, bool UNORDERED>
 static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
                             const int32_t* isect_gid, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,
                             hipStream_t s) {
-    // size classes (entries per bucket): <=1024 | <=8192 | longer (global scratch).  Every class walks all
-    // tiles with a grid-stride loop and skips buckets of the other classes, so the rarely used classes
-    // cost a few hundred (not n_tiles) workgroups.
-    const int g0 = n_tiles < 16384 ? n_tiles : 16384;
-    const int g2 = n_tiles < 256 ? n_tiles : 256;
-    hipLaunchKernelGGL((tile_sort_reg_kernel<4, 4, HAS_VALS, UNORDERED>), dim3(g0), dim3(256), 0, s, offsets, n_tiles,
+    // size classes (entries per bucket): <=1024 | <=4096 | <=8192 | longer (global scratch).  Every class walks
+    // all tiles and skips buckets of the other classes.  A class that the typical bucket (n_isects / n_tiles)
+    // can reach gets one workgroup per tile; the others get a small grid whose workgroups test their chunk of
+    // tiles in parallel first (tile_range), so an unused class costs a few microseconds.
+    const int64_t avg = n_isects / n_tiles;
+    const int full = n_tiles < 65536 ? n_tiles : 65536;
+    const int few = n_tiles < 256 ? n_tiles : 256;
+    hipLaunchKernelGGL((tile_sort_reg_kernel<4, 4, HAS_VALS, UNORDERED>), dim3(full), dim3(256), 0, s, offsets, n_tiles,
                        n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids);
-    hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS, UNORDERED>), dim3(g2), dim3(1024), 0, s, offsets,
-                       n_tiles, n_isects, 1024, 8192, depths, isect_gid, payload, flatten_ids);
-    hipLaunchKernelGGL((tile_sort_kernel<0, 16, HAS_VALS, true, UNORDERED>), dim3(g2 < 64 ? g2 : 64), dim3(1024),
-                       (size_t)16 * 256 * 4, s, offsets, n_tiles, n_isects, 8192, 0x7fffffff, depths, isect_gid,
-                       payload, flatten_ids, scratch);
+    hipLaunchKernelGGL((tile_sort_reg_kernel<8, 8, HAS_VALS, UNORDERED>), dim3(avg >= 1024 ? full : few), dim3(512), 0, s,
+                       offsets, n_tiles, n_isects, 1024, 4096, depths, isect_gid, payload, flatten_ids);
+    hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS, UNORDERED>), dim3(avg >= 2048 ? full : few), dim3(1024), 0,
+                       s, offsets, n_tiles, n_isects, 4096, 8192, depths, isect_gid, payload, flatten_ids);
+    hipLaunchKernelGGL((tile_sort_kernel<0, 16, HAS_VALS, true, UNORDERED>), dim3(avg >= 4096 ? full : (few < 64 ? few : 64)),
+                       dim3(1024), (size_t)16 * 256 * 4, s, offsets, n_tiles, n_isects, 8192, 0x7fffffff, depths,
+                       isect_gid, payload, flatten_ids, scratch);
     return check_launch();
 }
 
