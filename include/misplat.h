@@ -158,8 +158,8 @@ int misplat_tile_offsets(const uint64_t* keys_sorted, const int32_t* slots_sorte
                          const int32_t* isect_gid, int64_t n_isects, int32_t n_tiles_total,
                          int32_t* offsets, int32_t* flatten_ids, misplat_stream_t stream);
 
-/* Two-stage ordering (used by the shipped path; same final (tile, depth, Gaussian id) order as the
- * 64-bit sort above): (1) depth_keys (+ sort_pairs) or, for one camera, depth_keys32 (+ sort32_pairs)
+/* Two-stage ordering (ordering "twostage", an alternative to the default "pertile" below; same final
+ * (tile, depth, Gaussian id) order as the 64-bit sort above): (1) depth_keys (+ sort_pairs) or, for one camera, depth_keys32 (+ sort32_pairs)
  * order the C*N rows by (camera, depth bits), culled rows last; (2) tile_emit_ordered walks that
  * order (order[r] = row, cum_ordered = exclusive scan of tiles_per_gauss[order[r]]) and writes the
  * 32-bit tile id and the row of every intersection (isect_gid), plus its emission slot if slot_ids
@@ -186,10 +186,10 @@ int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, 
 /* Per-tile ordering: once the intersections have been bucketed by tile, one workgroup per tile sorts
  * its bucket by the 32 depth bits with a stable LSD radix sort whose entries stay in registers (exchange
  * through LDS), which is exactly the (tile, depth, id) order -- no global depth sort at all.
- *   unordered = 0: every bucket arrives in ascending row order (stable sort32_pairs on the tile bits of
- *                  pairs emitted in row order, ordering "pertile");
- *   unordered = 1: buckets arrive in arbitrary order (misplat_tile_scatter, ordering "scatter", the
- *                  shipped path); buckets with equal depths are re-sorted by (row, then depth).
+ *   unordered = 0: every bucket arrives in ascending row order (stable sort16/sort32_pairs on the tile bits
+ *                  of pairs emitted in row order: ordering "pertile", the default path);
+ *   unordered = 1: buckets arrive in arbitrary order (misplat_tile_scatter, ordering "scatter");
+ *                  buckets with equal depths are re-sorted by (row, then depth).
  * payload (in/out): rows, or emission slots when isect_gid != NULL (row = isect_gid[slot]);
  * flatten_ids (out): rows in final order; scratch[4 * n_isects] backs the rare tiles longer than 8192. */
 int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
