@@ -373,11 +373,11 @@ def test_sort_backends_give_identical_bins(dev, monkeypatch):
             assert torch.equal(x, y), key
 
 
-@pytest.mark.parametrize("n,size", [(40_000, (320, 200)), (30_000, (48, 32))])
+@pytest.mark.parametrize("n,size", [(40_000, (320, 200)), (80_000, (48, 32))])
 def test_orderings_agree_with_depth_ties_and_long_buckets(dev, monkeypatch, n, size):
     """Buckets filled through atomic cursors arrive in arbitrary order: equal depths must still come out in
     Gaussian-id order (the tie path of the per-tile sort), for short buckets and for buckets longer than
-    every LDS class (48x32 image: 6 tiles share 30k Gaussians)."""
+    every LDS class (48x32 image: 6 tiles share 80k Gaussians, > 8192 entries each)."""
     from collab_splats_amd import ops, rasterization
     from collab_splats_amd.synthetic import random_scene
     W, H = size
@@ -399,6 +399,9 @@ def test_orderings_agree_with_depth_ties_and_long_buckets(dev, monkeypatch, n, s
     a = outs[("twostage", False)]
     d = a[5]["depths"].flatten()[a[5]["flatten_ids"].long()]
     assert (d[1:] == d[:-1]).float().mean() > 0.5                      # the scene really is full of ties
+    offs = a[5]["isect_offsets"].reshape(-1).long()
+    longest = int(torch.diff(offs, append=offs.new_tensor([a[5]["n_isects"]])).max())
+    assert longest > (8192 if size == (48, 32) else 256)              # the global-scratch class is exercised
     for key, b in outs.items():
         assert torch.equal(a[5]["flatten_ids"], b[5]["flatten_ids"]), key
         assert torch.equal(a[5]["isect_offsets"], b[5]["isect_offsets"]), key
