@@ -129,7 +129,17 @@ def check(code: int, what: str) -> None:
 
 
 def require_gpu(*tensors: torch.Tensor) -> None:
+    cur = None
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise MisplatError("misplat runs on the MI355X only: got a CPU tensor "
                                "(there is no CPU fallback; oracle/ is test infrastructure)")
+        if cur is None:
+            cur = _raw_device() if _raw_device is not None else torch.cuda.current_device()
+        if t.device.index is not None and t.device.index != cur:
+            # kernels are launched on the current device's current stream: a tensor of another GPU would be
+            # dereferenced on the wrong device (one process per GPU is the supported layout)
+            raise MisplatError(f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: "
+                               "call torch.cuda.set_device() (one process per GPU) first")
