@@ -57,8 +57,8 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
 # name -> (restype, n_args); every symbol include/misplat.h declares
 SYMBOLS = {
     "misplat_project_fwd": (C.c_int, 16), "misplat_project_bwd": (C.c_int, 18),
-    "misplat_project_pack_fwd": (C.c_int, 13), "misplat_color_fwd": (C.c_int, 14),
-    "misplat_color_bwd": (C.c_int, 15), "misplat_project_pack_bwd": (C.c_int, 18),
+    "misplat_project_pack_fwd": (C.c_int, 13), "misplat_color_fwd": (C.c_int, 15),
+    "misplat_color_bwd": (C.c_int, 16), "misplat_project_pack_bwd": (C.c_int, 18),
     "misplat_sh_fwd": (C.c_int, 9), "misplat_sh_bwd": (C.c_int, 11),
     "misplat_tile_count": (C.c_int, 5), "misplat_tile_emit": (C.c_int, 9),
     "misplat_sort_workspace_bytes": (C.c_size_t, 2), "misplat_sort_pairs": (C.c_int, 9),

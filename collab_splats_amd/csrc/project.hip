@@ -579,13 +579,16 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
 // min(D, 4) entries of colors[(cam,) g, D] are copied.  depth_channel: channel n_color = depth.
 // SH coefficients ([N, K, 3], 12 K bytes per Gaussian) are staged through LDS in whole
 // coalesced lines and read back at a stride of 3K+1 floats (conflict-free).
-template <bool BWD, int BLOCK, bool MULTI>
+// AUX: the forward also leaves, per (camera, Gaussian), the 3x3 Jacobian d rgb / d dir of the clamped colour
+// (rows of clamped channels zeroed) and the three clamp flags in sh_aux[idx][12]; the backward then takes
+// v_dir = J^T v_rgb from those 48 bytes and never reads the 12 K bytes of coefficients again.
+template <bool BWD, int BLOCK, bool MULTI, bool AUX = false>
 __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
     misplat_params P, int K, int deg, int depth_channel, const float* __restrict__ means,
     const float* __restrict__ viewmats, const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest,
     const int32_t* __restrict__ radii, const float* __restrict__ depths, float* __restrict__ grec,
     const float* __restrict__ v_grec, float* __restrict__ v_coeffs, float* __restrict__ v_coeffs_rest,
-    float* __restrict__ v_means_dir) {
+    float* __restrict__ v_means_dir, float* __restrict__ sh_aux = nullptr) {
     // coeffs_rest == NULL: coeffs is [N,K,3]; else coeffs is features_dc [N,3] and coeffs_rest is
     // features_rest [N,K-1,3] (the two parameter tensors of rade_gs_model.py:119-120, read in place
     // instead of through the per-step torch.cat of :128-130)
@@ -597,7 +600,9 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
         const int g0 = blk * BLOCK;
         const int cnt = min(BLOCK, P.n_gauss - g0);
         __syncthreads();
-        if (coeffs_rest == nullptr) {
+        if (BWD && AUX) {
+            // nothing to stage: the LDS rows only carry the gradient back out
+        } else if (coeffs_rest == nullptr) {
             const float* src = coeffs + (size_t)g0 * row;
             for (int e = threadIdx.x; e < cnt * row; e += BLOCK) {
                 const int t = e / row, k = e - t * row;
@@ -640,11 +645,51 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
                     const float inv = n > 0.f ? 1.0f / n : 0.f;
                     const float x = dx * inv, y = dy * inv, z = dz * inv;
                     float b[16], bx[16], by[16], bz[16];
-                    sh_basis<BWD>(deg, x, y, z, b, bx, by, bz);
+                    sh_basis<(BWD && !AUX) || (!BWD && AUX)>(deg, x, y, z, b, bx, by, bz);
+                    if (!(BWD && AUX)) {
 #pragma unroll
-                    for (int k = 0; k < 16; k++)
-                        if (k < nb) { c0 += b[k] * cf[3 * k]; c1 += b[k] * cf[3 * k + 1]; c2 += b[k] * cf[3 * k + 2]; }
-                    if (BWD) {
+                        for (int k = 0; k < 16; k++)
+                            if (k < nb) { c0 += b[k] * cf[3 * k]; c1 += b[k] * cf[3 * k + 1]; c2 += b[k] * cf[3 * k + 2]; }
+                    }
+                    if (!BWD && AUX) {
+                        const float m0 = (c0 + 0.5f > 0.f) ? 1.f : 0.f, m1 = (c1 + 0.5f > 0.f) ? 1.f : 0.f;
+                        const float m2 = (c2 + 0.5f > 0.f) ? 1.f : 0.f;
+                        float J[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // J[ch][axis]
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                            if (k < nb) {
+                                J[0] += bx[k] * cf[3 * k]; J[1] += by[k] * cf[3 * k]; J[2] += bz[k] * cf[3 * k];
+                                J[3] += bx[k] * cf[3 * k + 1]; J[4] += by[k] * cf[3 * k + 1]; J[5] += bz[k] * cf[3 * k + 1];
+                                J[6] += bx[k] * cf[3 * k + 2]; J[7] += by[k] * cf[3 * k + 2]; J[8] += bz[k] * cf[3 * k + 2];
+                            }
+                        float4* ax = reinterpret_cast<float4*>(sh_aux + (size_t)idx * 12);
+                        ax[0] = make_float4(J[0] * m0, J[1] * m0, J[2] * m0, J[3] * m1);
+                        ax[1] = make_float4(J[4] * m1, J[5] * m1, J[6] * m2, J[7] * m2);
+                        ax[2] = make_float4(J[8] * m2, m0, m1, m2);
+                    }
+                    if (BWD && AUX) {
+                        const float4* ax = reinterpret_cast<const float4*>(sh_aux + (size_t)idx * 12);
+                        const float4 a0 = ax[0], a1 = ax[1], a2 = ax[2];
+                        const float* vg = v_grec + (size_t)idx * MISPLAT_REC + 12;
+                        const float g0v = vg[0], g1v = vg[1], g2v = vg[2];
+                        const float vc0 = a2.y * g0v, vc1 = a2.z * g1v, vc2 = a2.w * g2v;     // clamp flags are 0 / 1
+                        const float vd0 = a0.x * g0v + a0.w * g1v + a1.z * g2v;
+                        const float vd1 = a0.y * g0v + a1.x * g1v + a1.w * g2v;
+                        const float vd2 = a0.z * g0v + a1.y * g1v + a2.x * g2v;
+#pragma unroll
+                        for (int k = 0; k < 16; k++)
+                            if (k < nb) {
+                                if (MULTI) {
+                                    acc[3 * k] += b[k] * vc0; acc[3 * k + 1] += b[k] * vc1; acc[3 * k + 2] += b[k] * vc2;
+                                } else {
+                                    cf[3 * k] = b[k] * vc0; cf[3 * k + 1] = b[k] * vc1; cf[3 * k + 2] = b[k] * vc2;
+                                }
+                            }
+                        wrote = true;
+                        const float dot = x * vd0 + y * vd1 + z * vd2;
+                        vmd[0] += (vd0 - x * dot) * inv; vmd[1] += (vd1 - y * dot) * inv; vmd[2] += (vd2 - z * dot) * inv;
+                    }
+                    if (BWD && !AUX) {
                         const float* vg = v_grec + (size_t)idx * MISPLAT_REC + 12;
                         const float vc0 = (c0 + 0.5f > 0.f) ? vg[0] : 0.f;
                         const float vc1 = (c1 + 0.5f > 0.f) ? vg[1] : 0.f;
@@ -922,7 +967,7 @@ extern "C" int misplat_project_pack_fwd(const misplat_params* p, const float* me
 extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
                                  int32_t per_cam, int32_t depth_channel, const float* means,
                                  const float* viewmats, const float* coeffs_or_colors, const float* coeffs_rest,
-                                 const int32_t* radii, const float* depths, float* grec,
+                                 const int32_t* radii, const float* depths, float* grec, float* sh_aux,
                                  misplat_stream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
     if (n_color < 0 || n_color + (depth_channel ? 1 : 0) > 4) return MISPLAT_EINVAL;
@@ -933,9 +978,16 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
         constexpr int BLK = 64;
         const int n_blocks = (p->n_gauss + BLK - 1) / BLK;
         const size_t lds = (size_t)BLK * (3 * K_or_D + 1) * sizeof(float);
-        hipLaunchKernelGGL((color_sh_kernel<false, BLK, false>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK), lds, s, *p,
-                           K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, coeffs_rest, radii, depths,
-                           grec, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr);
+        if (sh_aux)
+            hipLaunchKernelGGL((color_sh_kernel<false, BLK, false, true>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK),
+                               lds, s, *p, K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, coeffs_rest,
+                               radii, depths, grec, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                               (float*)nullptr, sh_aux);
+        else
+            hipLaunchKernelGGL((color_sh_kernel<false, BLK, false>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK), lds, s,
+                               *p, K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, coeffs_rest, radii,
+                               depths, grec, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
+                               (float*)nullptr);
     } else {
         if (K_or_D < n_color) return MISPLAT_EINVAL;
         int64_t total = (int64_t)p->n_gauss * p->n_cams;
@@ -949,7 +1001,7 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
                                  int32_t per_cam, const float* means, const float* viewmats,
                                  const float* coeffs_or_colors, const float* coeffs_rest, const int32_t* radii,
                                  const float* v_grec, float* v_coeffs_or_colors, float* v_coeffs_rest,
-                                 float* v_means_dir, misplat_stream_t stream) {
+                                 float* v_means_dir, const float* sh_aux, misplat_stream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1 || n_color < 0 || n_color > 4) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -958,7 +1010,19 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
         constexpr int BLK = 64;
         const int n_blocks = (p->n_gauss + BLK - 1) / BLK;
         const size_t lds = (size_t)BLK * (3 * K_or_D + 1) * sizeof(float);
-        if (p->n_cams > 1)
+        if (sh_aux) {
+            float* ax = const_cast<float*>(sh_aux);
+            if (p->n_cams > 1)
+                hipLaunchKernelGGL((color_sh_kernel<true, BLK, true, true>), dim3(n_blocks < 16384 ? n_blocks : 16384),
+                                   dim3(BLK), lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, coeffs_rest,
+                                   radii, (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_coeffs_rest,
+                                   v_means_dir, ax);
+            else
+                hipLaunchKernelGGL((color_sh_kernel<true, BLK, false, true>), dim3(n_blocks < 16384 ? n_blocks : 16384),
+                                   dim3(BLK), lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, coeffs_rest,
+                                   radii, (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_coeffs_rest,
+                                   v_means_dir, ax);
+        } else if (p->n_cams > 1)
             hipLaunchKernelGGL((color_sh_kernel<true, BLK, true>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK),
                                lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, coeffs_rest, radii,
                                (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_coeffs_rest,

@@ -58,6 +58,8 @@ class _timed:
 # can be overlapped on one side stream per device (MISPLAT_OVERLAP=1).  Measured gain at 1 M / 1080p: <1 %
 # (every kernel already fills the chip), so it is off by default.
 OVERLAP = os.environ.get("MISPLAT_OVERLAP", "0") == "1"
+# SH colours: the forward keeps the Jacobian d rgb / d dir for the backward (see misplat_color_fwd)
+SH_AUX = os.environ.get("MISPLAT_SH_AUX", "1") == "1"
 _SIDE: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -549,16 +551,23 @@ class _ProjectPack(torch.autograd.Function):
             side.wait_stream(cur)
             for t in (grec, means, viewmats, colors, radii, depths):
                 t.record_stream(side)
+        # SH + a backward to come: keep d rgb / d dir (48 B per (camera, Gaussian)) so that the backward does not
+        # read the coefficients (192 B at degree 3) again
+        sh_aux = None
+        if SH_AUX and deg >= 0 and any(ctx.needs_input_grad[:6]):
+            sh_aux = torch.empty(Cn * N, 12, device=dev, dtype=torch.float32)
         with torch.cuda.stream(side):
             check(lib.misplat_color_fwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
                                         C.c_int32(per_cam), C.c_int32(int(depth_channel)), ptr(means), ptr(viewmats),
-                                        ptr(colors), ptr(colors_rest), ptr(radii), ptr(depths), ptr(grec),
+                                        ptr(colors), ptr(colors_rest), ptr(radii), ptr(depths), ptr(grec), ptr(sh_aux),
                                         stream_ptr()), "misplat_color_fwd")
         ctx.P, ctx.color_args = P, (deg, kd, n_color, per_cam)
         ctx.depth_slot = 12 + n_color if depth_channel else -1
         ctx.has_rest = colors_rest is not None
+        ctx.has_aux = sh_aux is not None
         ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps,
-                              colors_rest if colors_rest is not None else colors)
+                              colors_rest if colors_rest is not None else colors,
+                              sh_aux if sh_aux is not None else comps)
         ctx.mark_non_differentiable(radii, depths, comps)
         ctx.set_materialize_grads(False)               # no zero tensors for the non-differentiable outputs
         return radii, means2d, depths, comps, grec
@@ -566,9 +575,11 @@ class _ProjectPack(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _v_radii, v_means2d, _v_depths, _v_comps, v_grec):
         lib = _lib.load()
-        means, quats, scales, opacities, colors, viewmats, Ks, radii, comps, colors_rest = ctx.saved_tensors
+        means, quats, scales, opacities, colors, viewmats, Ks, radii, comps, colors_rest, sh_aux = ctx.saved_tensors
         if not ctx.has_rest:
             colors_rest = None
+        if not ctx.has_aux:
+            sh_aux = None
         P = ctx.P
         deg, kd, n_color, per_cam = ctx.color_args
         v_means2d, v_grec = _grads_of_pack(P, v_means2d, v_grec)
@@ -586,7 +597,7 @@ class _ProjectPack(torch.autograd.Function):
             check(lib.misplat_color_bwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
                                         C.c_int32(per_cam), ptr(means), ptr(viewmats), ptr(colors), ptr(colors_rest),
                                         ptr(radii), ptr(v_grec), ptr(v_colors), ptr(v_colors_rest), ptr(v_means_dir),
-                                        stream_ptr()), "misplat_color_bwd")
+                                        ptr(sh_aux), stream_ptr()), "misplat_color_bwd")
         v_means, v_quats = torch.empty_like(means), torch.empty_like(quats)
         v_scales, v_opac = torch.empty_like(scales), torch.empty_like(opacities)
         fused_dir = v_means_dir if side is cur else None        # overlapped: add the SH direction term afterwards

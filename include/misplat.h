@@ -117,16 +117,21 @@ int misplat_project_pack_fwd(const misplat_params* p, const float* means, const 
 /* coeffs_rest (SH only, may be NULL): when given, coeffs_or_colors is features_dc[N,3] and
  * coeffs_rest is features_rest[N,K-1,3] -- the reference's two parameter tensors
  * (rade_gs_model.py:119-120) read in place instead of through its per-step torch.cat (:128-130);
- * v_coeffs_rest is the matching gradient output. */
+ * v_coeffs_rest is the matching gradient output.
+ * sh_aux[C*N,12] (SH only, may be NULL): written by color_fwd -- the 3x3 Jacobian d rgb / d dir of the clamped
+ * colour (rows of clamped channels zeroed) and the three clamp flags -- and, when passed to color_bwd, used
+ * instead of re-reading the 12 K bytes of coefficients per Gaussian (48 B instead of 192 B at degree 3). */
 int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
                       int32_t per_cam, int32_t depth_channel, const float* means,
                       const float* viewmats, const float* coeffs_or_colors, const float* coeffs_rest,
-                      const int32_t* radii, const float* depths, float* grec, misplat_stream_t stream);
+                      const int32_t* radii, const float* depths, float* grec,
+                      float* sh_aux /* or NULL */, misplat_stream_t stream);
 int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
                       int32_t per_cam, const float* means, const float* viewmats,
                       const float* coeffs_or_colors, const float* coeffs_rest, const int32_t* radii,
                       const float* v_grec, float* v_coeffs_or_colors, float* v_coeffs_rest,
-                      float* v_means_dir /*[N,3], SH only*/, misplat_stream_t stream);
+                      float* v_means_dir /*[N,3], SH only*/, const float* sh_aux /* or NULL */,
+                      misplat_stream_t stream);
 /* depth_slot: 12..15 = record slot carrying the depth channel, -1 = none.  v_means_dir may be
  * NULL.  Outputs v_means[N,3] v_quats[N,4] v_scales[N,3] v_opacities[N], summed over cameras. */
 int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_slot, const float* means,
