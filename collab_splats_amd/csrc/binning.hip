@@ -631,29 +631,58 @@ __global__ __launch_bounds__(MISPLAT_COUNT_BLOCK) void tile_emit_blocks_kernel(i
                                                                                KT* __restrict__ tile_ids,
                                                                                int32_t* __restrict__ slot_ids,
                                                                                int32_t* __restrict__ isect_gid) {
-    // slot_ids == NULL: only the Gaussian row is emitted (it is then the sort payload)
+    // slot_ids == NULL: only the Gaussian row is emitted (it is then the sort payload).
+    // Cooperative expansion: the block's rows publish (exclusive offset, tile rectangle) in LDS; thread t then
+    // produces outputs t, t + 256, ... of the block -- it finds the owning row with an 8-step binary search and
+    // decodes the tile from the offset inside the row -- so every store instruction writes 64 consecutive
+    // elements and no lane idles while a neighbour walks a large rectangle.
     __shared__ uint32_t wsum[MISPLAT_COUNT_BLOCK / 64];
+    __shared__ uint32_t s_excl[MISPLAT_COUNT_BLOCK];
+    __shared__ uint32_t s_xy[MISPLAT_COUNT_BLOCK];        // x0 | y0 << 16
+    __shared__ uint32_t s_base[MISPLAT_COUNT_BLOCK];      // camera * tiles_per_camera
+    __shared__ float s_rw[MISPLAT_COUNT_BLOCK];           // 1 / rectangle width
+    __shared__ uint32_t s_w[MISPLAT_COUNT_BLOCK];
     const int64_t idx = (int64_t)blockIdx.x * MISPLAT_COUNT_BLOCK + threadIdx.x;
     const uint32_t n = idx < total ? (uint32_t)tiles_per_gauss[idx] : 0u;
     const uint32_t incl = wave_scan_incl(n, 0u, [](uint32_t a, uint32_t b) { return a + b; });
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 63) wsum[wave] = incl;
+    uint32_t xy = 0u, w = 1u, cbase = 0u;
+    if (n != 0u) {
+        int x0, x1, y0, y1;
+        tile_rect(means2d[2 * idx], means2d[2 * idx + 1], radii[2 * idx], radii[2 * idx + 1], tw, th, x0, x1, y0, y1);
+        xy = (uint32_t)x0 | ((uint32_t)y0 << 16);
+        w = (uint32_t)(x1 - x0);
+        cbase = (uint32_t)(idx / n_gauss) * (uint32_t)(tw * th);
+    }
     __syncthreads();
-    if (n == 0u) return;
-    uint32_t before = incl - n;
+    uint32_t before = incl - n, block_total = 0u;
 #pragma unroll
-    for (int w = 0; w < MISPLAT_COUNT_BLOCK / 64; w++) before += (w < wave) ? wsum[w] : 0u;
-    int64_t j = block_offs[blockIdx.x] + (int64_t)before;
-    int x0, x1, y0, y1;
-    tile_rect(means2d[2 * idx], means2d[2 * idx + 1], radii[2 * idx], radii[2 * idx + 1], tw, th, x0, x1, y0, y1);
-    const uint32_t base = (uint32_t)(idx / n_gauss) * (uint32_t)(tw * th);
-    for (int ty = y0; ty < y1; ty++)
-        for (int tx = x0; tx < x1; tx++) {
-            tile_ids[j] = (KT)(base + (uint32_t)(ty * tw + tx));
-            if (slot_ids) slot_ids[j] = (int32_t)j;
-            isect_gid[j] = (int32_t)idx;
-            j++;
+    for (int k = 0; k < MISPLAT_COUNT_BLOCK / 64; k++) { before += (k < wave) ? wsum[k] : 0u; block_total += wsum[k]; }
+    s_excl[threadIdx.x] = before; s_xy[threadIdx.x] = xy; s_base[threadIdx.x] = cbase;
+    s_w[threadIdx.x] = w; s_rw[threadIdx.x] = 1.0f / (float)w;
+    __syncthreads();
+    const int64_t j0 = block_offs[blockIdx.x];
+    const int64_t row0 = (int64_t)blockIdx.x * MISPLAT_COUNT_BLOCK;
+    for (uint32_t o = threadIdx.x; o < block_total; o += MISPLAT_COUNT_BLOCK) {
+        int lo = 0, hi = MISPLAT_COUNT_BLOCK - 1;            // largest r with s_excl[r] <= o (rows with n = 0 never win)
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (s_excl[mid] <= o) lo = mid; else hi = mid - 1;
         }
+        const uint32_t q = o - s_excl[lo];
+        const uint32_t rw_i = s_w[lo];
+        // (q + 0.5) / w is at least 0.5 / w away from an integer: the float quotient truncates exactly
+        const uint32_t ty = (uint32_t)(((float)q + 0.5f) * s_rw[lo]);
+        const uint32_t tx = q - ty * rw_i;
+        const uint32_t pxy = s_xy[lo];
+        const uint32_t tile = s_base[lo] + ((pxy >> 16) + ty) * (uint32_t)tw + (pxy & 0xffffu) + tx;
+        const int64_t j = j0 + (int64_t)o;
+        tile_ids[j] = (KT)tile;
+        if (slot_ids) slot_ids[j] = (int32_t)j;
+        isect_gid[j] = (int32_t)(row0 + lo);
+    }
 }
 
 // ---- bucketing without a sort ("scatter" ordering): count the intersections of every tile with atomics,
