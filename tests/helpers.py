@@ -32,7 +32,7 @@ def upstream(shapes, seed=5, dtype=torch.float64):
     return [torch.rand(s, generator=g, dtype=dtype) for s in shapes]
 
 
-def assert_close_flips(got, ref, name="", tol=1e-4, outlier_frac=2e-5, outlier_tol=2e-2):
+def assert_close_flips(got, ref, name="", tol=1e-4, outlier_frac=2e-5, outlier_tol=None, min_outliers=2):
     """Tensor-inf-norm relative comparison that tolerates fp32 THRESHOLD FLIPS.
 
     The algorithm is discontinuous at alpha == 1/255 (skip), T == 1e-4 (stop) and T == 0.5 (median):
@@ -40,13 +40,20 @@ def assert_close_flips(got, ref, name="", tol=1e-4, outlier_frac=2e-5, outlier_t
     isolated (pixel, Gaussian) pair sitting on a threshold, which moves that pixel by up to
     ~1/255 of a contribution (hard part 3).  So: all but `outlier_frac` of the
     elements must meet `tol`, and the rest must stay within `outlier_tol` (both relative to max|ref|).
+    On small images one flipped pixel already exceeds the fraction, so `min_outliers` pixels (rows of the last
+    dimension) are always allowed; a flip of the MEDIAN depth moves that pixel to the depth of a neighbouring Gaussian, i.e. by
+    anything inside the depth range, so tensors named "*med_depth*" get `outlier_tol` = 1.
     """
+    if outlier_tol is None:
+        outlier_tol = 1.0 if "med_depth" in name else 2e-2
     a = np.asarray(got.detach().cpu() if torch.is_tensor(got) else got, dtype=np.float64)
     b = np.asarray(ref.detach().cpu() if torch.is_tensor(ref) else ref, dtype=np.float64)
     assert a.shape == b.shape, (name, a.shape, b.shape)
     scale = max(np.abs(b).max(), 1e-30)
     d = np.abs(a - b) / scale
     frac = float((d > tol).mean())
-    assert frac <= outlier_frac, f"{name}: {frac:.2e} of elements exceed {tol} (max {d.max():.3e})"
+    width = a.shape[-1] if a.ndim > 1 else 1                     # a flipped pixel moves all its channels
+    allowed = max(outlier_frac, (min_outliers * width + 0.5) / max(d.size, 1))
+    assert frac <= allowed, f"{name}: {frac:.2e} of elements exceed {tol} (max {d.max():.3e})"
     assert d.max() <= outlier_tol, f"{name}: max rel err {d.max():.3e} > {outlier_tol}"
     return float(d.max()), frac
