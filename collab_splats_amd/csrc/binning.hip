@@ -259,11 +259,16 @@ __device__ __forceinline__ bool tile_range(const int32_t* __restrict__ offsets, 
     return __syncthreads_or(mine) != 0;
 }
 
+#ifndef MISPLAT_TS_HISTS
+#define MISPLAT_TS_HISTS 1            /* 1: one histogram (16 KB of LDS per 1024-entry block -> 8 blocks per CU), cleared after
+                                         the scatter at the price of one more barrier per pass: 75 -> 69 us at 1M / 1080p;
+                                         2: the idle histogram is cleared during the scan (24 KB, 6 blocks per CU) */
+#endif
 template <int WAVES, int R>
 struct tile_sort_lds {
     static constexpr int CAP = 64 * WAVES * R, DIG = 512;
     uint32_t xk[CAP], xv[CAP];
-    __attribute__((aligned(16))) uint32_t hist2[2][DIG * WAVES];
+    __attribute__((aligned(16))) uint32_t hist2[MISPLAT_TS_HISTS][DIG * WAVES];
     uint32_t wsum[WAVES];
     uint32_t kmin, kmax;
 };
@@ -307,8 +312,8 @@ __device__ __forceinline__ int tile_radix_regs(uint32_t (&key)[R], uint32_t (&va
         const int shift = pass * dbits;
         const uint32_t dmask = (1u << dbits) - 1u;
         uint32_t* hist = L.hist2[hb];
-        uint32_t* hnext = L.hist2[hb ^ 1];
-        hb ^= 1;
+        uint32_t* hnext = L.hist2[MISPLAT_TS_HISTS == 2 ? (hb ^ 1) : 0];
+        if (MISPLAT_TS_HISTS == 2) hb ^= 1;
         uint32_t plo[R], phi[R];
         // 1. peers of every entry inside its 64-entry round: one ballot per digit bit
 #pragma unroll
@@ -343,8 +348,10 @@ __device__ __forceinline__ int tile_radix_regs(uint32_t (&key)[R], uint32_t (&va
         const uint32_t tot = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
         const uint32_t incl = wave_scan_incl(tot, 0u, [](uint32_t a, uint32_t b) { return a + b; });
         if (lane == 63) L.wsum[wave] = incl;
-        reinterpret_cast<uint4*>(hnext)[2 * threadIdx.x] = zero4;
-        reinterpret_cast<uint4*>(hnext)[2 * threadIdx.x + 1] = zero4;
+        if (MISPLAT_TS_HISTS == 2) {
+            reinterpret_cast<uint4*>(hnext)[2 * threadIdx.x] = zero4;
+            reinterpret_cast<uint4*>(hnext)[2 * threadIdx.x + 1] = zero4;
+        }
         __syncthreads();
         uint32_t e = incl - tot;
 #pragma unroll
@@ -374,8 +381,13 @@ __device__ __forceinline__ int tile_radix_regs(uint32_t (&key)[R], uint32_t (&va
             const int i = wave * 64 * R + r * 64 + lane;
             if (i < n) { key[r] = L.xk[i]; val[r] = L.xv[i]; }
         }
-        // the next pass accumulates into hnext (cleared above, a barrier has passed); xk/xv are next
-        // written only after two more barriers
+        if (MISPLAT_TS_HISTS == 1) {          // single histogram: clear it now, one more barrier per pass
+            reinterpret_cast<uint4*>(hist)[2 * threadIdx.x] = zero4;
+            reinterpret_cast<uint4*>(hist)[2 * threadIdx.x + 1] = zero4;
+            __syncthreads();
+        }
+        // (two histograms) the next pass accumulates into hnext (cleared above, a barrier has passed); xk/xv are
+        // next written only after two more barriers
     }
 #pragma unroll
     for (int r = 0; r < R; r++) key[r] += kmin;
