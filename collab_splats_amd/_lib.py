@@ -80,7 +80,7 @@ SYMBOLS = {
     "misplat_color_fwd_x": (C.c_int, 11), "misplat_color_bwd_x": (C.c_int, 9),
     "misplat_blend_fwd_x": (C.c_int, 17), "misplat_blend_bwd_x_atomic": (C.c_int, 22),
     "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 19), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),
-    "misplat_depth_normal_bwd": (C.c_int, 13), "misplat_outputs_fwd": (C.c_int, 15), "misplat_outputs_bwd": (C.c_int, 16),
+    "misplat_depth_normal_bwd": (C.c_int, 14), "misplat_outputs_fwd": (C.c_int, 15), "misplat_outputs_bwd": (C.c_int, 16),
     "misplat_version": (C.c_char_p, 0),
 }
 
@@ -98,10 +98,24 @@ def load() -> C.CDLL:
             f"{path} not found: build it with `python -m collab_splats_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     lib = C.CDLL(path)
-    for name, (res, _) in SYMBOLS.items():
-        getattr(lib, name).restype = res
+    for name, (res, n_args) in SYMBOLS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        setattr(lib, name, _arity_checked(name, fn, n_args))
     _lib = lib
     return lib
+
+
+def _arity_checked(name: str, fn, n_args: int):
+    """ctypes without argtypes cannot tell a call with a missing argument from a correct one (the stream pointer
+    would silently land in the wrong slot): every entry point is called through this check of the argument count
+    that tests/test_abi.py keeps equal to include/misplat.h."""
+    def call(*args):
+        if len(args) != n_args:
+            raise MisplatError(f"{name}: {len(args)} arguments passed, the C ABI takes {n_args}")
+        return fn(*args)
+    call.__name__ = name
+    return call
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

@@ -874,7 +874,7 @@ __global__ __launch_bounds__(256) void depth_normal_bwd_kernel(DN d, const float
                                                                const float* __restrict__ v_err,
                                                                float* __restrict__ v_ed,
                                                                float* __restrict__ v_md,
-                                                               float* __restrict__ v_nr) {
+                                                               float* __restrict__ v_nr, const int accumulate) {
     const size_t P = (size_t)d.W * d.H;
     for (size_t pid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pid < P; pid += (size_t)gridDim.x * blockDim.x) {
         const int y = (int)(pid / d.W), x = (int)(pid - (size_t)y * d.W);
@@ -892,7 +892,9 @@ __global__ __launch_bounds__(256) void depth_normal_bwd_kernel(DN d, const float
             if (y + 1 < d.H) { dn_grad_ab(d, depth, nr, v_n2, v_err, k, y + 1, x, va, vb); g[0] -= va[0]; g[1] -= va[1]; g[2] -= va[2]; }
             if (x >= 1) { dn_grad_ab(d, depth, nr, v_n2, v_err, k, y, x - 1, va, vb); g[0] += vb[0]; g[1] += vb[1]; g[2] += vb[2]; }
             if (x + 1 < d.W) { dn_grad_ab(d, depth, nr, v_n2, v_err, k, y, x + 1, va, vb); g[0] -= vb[0]; g[1] -= vb[1]; g[2] -= vb[2]; }
-            (k == 0 ? v_ed : v_md)[pid] = g[0] * rx + g[1] * ry + g[2];
+            float* dst = k == 0 ? v_ed : v_md;
+            const float gd = g[0] * rx + g[1] * ry + g[2];
+            dst[pid] = accumulate ? dst[pid] + gd : gd;           // every element is owned by one thread: no atomics
             if (v_err && interior) {
                 float a[3], b[3], cr[3], len, n[3];
                 dn_normal(d, depth, y, x, a, b, cr, len, n);
@@ -900,6 +902,7 @@ __global__ __launch_bounds__(256) void depth_normal_bwd_kernel(DN d, const float
                 vnr[0] -= ve * n[0]; vnr[1] -= ve * n[1]; vnr[2] -= ve * n[2];
             }
         }
+        if (accumulate) { vnr[0] += v_nr[pid * 3]; vnr[1] += v_nr[pid * 3 + 1]; vnr[2] += v_nr[pid * 3 + 2]; }
         v_nr[pid * 3] = vnr[0]; v_nr[pid * 3 + 1] = vnr[1]; v_nr[pid * 3 + 2] = vnr[2];
     }
 }
@@ -1146,12 +1149,12 @@ extern "C" int misplat_depth_normal_bwd(int32_t width, int32_t height, float fx,
                                         const float* exp_depth, const float* med_depth,
                                         const float* n_render, const float* v_normals2,
                                         const float* v_err, float* v_exp_depth, float* v_med_depth,
-                                        float* v_n_render, misplat_stream_t stream) {
+                                        float* v_n_render, int32_t accumulate, misplat_stream_t stream) {
     if (width < 1 || height < 1 || !(fx > 0.f) || !(fy > 0.f)) return MISPLAT_EINVAL;
     DN d{width, height, fx, fy};
     hipLaunchKernelGGL(depth_normal_bwd_kernel, dim3(grid_for((int64_t)width * height, 256)), dim3(256), 0,
                        (hipStream_t)stream, d, exp_depth, med_depth, n_render, v_normals2, v_err, v_exp_depth,
-                       v_med_depth, v_n_render);
+                       v_med_depth, v_n_render, (int)(accumulate != 0));
     return check_launch();
 }
 

@@ -95,16 +95,16 @@ __global__ __launch_bounds__(256) void outputs_bwd_kernel(int64_t n_pix, int cd,
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
             const float pre = render[p * cd + ch] + ia * bg[ch];
-            const float g = (pre >= 0.f && pre <= 1.f) ? v_rgb[3 * p + ch] : 0.f;   // torch.clamp passes the edges
+            const float g = (v_rgb && pre >= 0.f && pre <= 1.f) ? v_rgb[3 * p + ch] : 0.f;   // torch.clamp passes the edges
             v_render[p * cd + ch] = g;
             va -= g * bg[ch];
         }
         if (cd > 3) v_render[p * cd + 3] = (v_depth_im && hit) ? v_depth_im[p] : 0.f;
         v_alpha[p] = va;
-        v_ed[p] = hit ? v_depth[p] : 0.f;
-        v_md[p] = hit ? v_median[p] : 0.f;
+        v_ed[p] = (hit && v_depth) ? v_depth[p] : 0.f;          // an absent upstream gradient (NULL) is zero
+        v_md[p] = (hit && v_median) ? v_median[p] : 0.f;
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) v_nr[3 * p + ch] = hit ? 0.5f * v_normals[3 * p + ch] : 0.f;
+        for (int ch = 0; ch < 3; ch++) v_nr[3 * p + ch] = (hit && v_normals) ? 0.5f * v_normals[3 * p + ch] : 0.f;
     }
 }
 

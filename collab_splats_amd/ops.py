@@ -865,7 +865,7 @@ class _DepthNormal(torch.autograd.Function):
         v_ed, v_md, v_nr = torch.empty_like(ed), torch.empty_like(md), torch.empty_like(nr)
         check(lib.misplat_depth_normal_bwd(C.c_int32(W), C.c_int32(H), C.c_float(ctx.fx), C.c_float(ctx.fy),
                                            ptr(ed), ptr(md), ptr(nr), ptr(_c(v_normals2)), ptr(_c(v_err)),
-                                           ptr(v_ed), ptr(v_md), ptr(v_nr), stream_ptr()),
+                                           ptr(v_ed), ptr(v_md), ptr(v_nr), C.c_int32(0), stream_ptr()),
               "misplat_depth_normal_bwd")
         return v_ed, v_md, v_nr, None, None
 
@@ -925,3 +925,70 @@ def outputs_epilogue(render, alpha, exp_depth, med_depth, exp_normal, background
     args = [_f32(t, n) for t, n in ((render, "render"), (alpha, "alpha"), (exp_depth, "expected_depths"),
                                     (med_depth, "median_depths"), (exp_normal, "expected_normals"))]
     return _Outputs.apply(*args, tuple(float(b) for b in background), bool(want_depth_im))
+
+
+class _GetOutputs(torch.autograd.Function):
+    """a3 + a4 in ONE autograd node: the depth->normal error maps
+    (rade_gs_model.py:206-214) and the output post-processing (:221-254) share their inputs, so the backward is
+    outputs_bwd followed by depth_normal_bwd ACCUMULATING into the same five gradient buffers -- no autograd
+    add kernels, and upstream gradients of outputs that took no part in the loss stay NULL instead of being
+    materialised as zero tensors."""
+
+    @staticmethod
+    def forward(ctx, render, alpha, exp_depth, med_depth, exp_normal, bg, want_depth_im: bool, fx: float, fy: float):
+        lib = _lib.load()
+        require_gpu(render, alpha, exp_depth, med_depth, exp_normal)
+        if alpha.shape[0] != 1:
+            raise ValueError("get_outputs epilogue: one camera per call (rade_gs_model.py:94-95)")
+        cd = render.shape[-1]
+        H, W = alpha.shape[1], alpha.shape[2]
+        f = dict(device=render.device, dtype=torch.float32)
+        rgb = torch.empty(1, H, W, 3, **f)
+        depth, median = torch.empty_like(alpha), torch.empty_like(alpha)
+        normals = torch.empty_like(exp_normal)
+        depth_im = torch.empty_like(alpha) if want_depth_im else None
+        maxes = torch.empty(4, **f)
+        err = torch.empty(2, H, W, **f)
+        normals2 = torch.empty(2, H, W, 3, **f)
+        bg_c = (C.c_float * 3)(*[float(b) for b in bg])
+        check(lib.misplat_depth_normal_fwd(C.c_int32(W), C.c_int32(H), C.c_float(fx), C.c_float(fy), ptr(exp_depth),
+                                           ptr(med_depth), ptr(exp_normal), ptr(normals2), ptr(err), stream_ptr()),
+              "misplat_depth_normal_fwd")
+        check(lib.misplat_outputs_fwd(C.c_int64(H * W), C.c_int32(cd), bg_c, ptr(render), ptr(alpha), ptr(exp_depth),
+                                      ptr(med_depth), ptr(exp_normal), ptr(maxes), ptr(rgb), ptr(depth), ptr(median),
+                                      ptr(normals), ptr(depth_im), stream_ptr()), "misplat_outputs_fwd")
+        ctx.save_for_backward(render, alpha, exp_depth, med_depth, exp_normal)
+        ctx.bg, ctx.cd, ctx.want_depth_im, ctx.fx, ctx.fy = bg_c, cd, want_depth_im, fx, fy
+        ctx.set_materialize_grads(False)
+        if want_depth_im:
+            return rgb, depth, median, normals, err, depth_im
+        return rgb, depth, median, normals, err
+
+    @staticmethod
+    def backward(ctx, v_rgb, v_depth, v_median, v_normals, v_err, v_depth_im=None):
+        lib = _lib.load()
+        render, alpha, ed, md, nr = ctx.saved_tensors
+        H, W = alpha.shape[1], alpha.shape[2]
+        v_render = torch.empty_like(render)
+        v_alpha, v_ed, v_md = torch.empty_like(alpha), torch.empty_like(alpha), torch.empty_like(alpha)
+        v_nr = torch.empty_like(nr)
+        check(lib.misplat_outputs_bwd(C.c_int64(H * W), C.c_int32(ctx.cd), ctx.bg, ptr(render), ptr(alpha),
+                                      ptr(_c(v_rgb)), ptr(_c(v_depth)), ptr(_c(v_median)), ptr(_c(v_normals)),
+                                      ptr(_c(v_depth_im) if ctx.want_depth_im else None), ptr(v_render), ptr(v_alpha),
+                                      ptr(v_ed), ptr(v_md), ptr(v_nr), stream_ptr()), "misplat_outputs_bwd")
+        if v_err is not None:
+            check(lib.misplat_depth_normal_bwd(C.c_int32(W), C.c_int32(H), C.c_float(ctx.fx), C.c_float(ctx.fy),
+                                               ptr(ed), ptr(md), ptr(nr), ptr(None), ptr(_c(v_err)), ptr(v_ed),
+                                               ptr(v_md), ptr(v_nr), C.c_int32(1), stream_ptr()),
+                  "misplat_depth_normal_bwd")
+        return v_render, v_alpha, v_ed, v_md, v_nr, None, None, None, None
+
+
+def get_outputs_epilogue(render, alpha, exp_depth, med_depth, exp_normal, background, want_depth_im: bool, fx: float,
+                         fy: float):
+    """(rgb, depth, median_depth, normals, err[2,H,W] (, depth_im)) -- rade_gs_model.py:206-254 as one node."""
+    if render.shape[-1] not in (3, 4) or (want_depth_im and render.shape[-1] != 4):
+        raise ValueError("get_outputs_epilogue needs render[..., 3] (RGB) or [..., 4] (RGB+ED)")
+    args = [_f32(t, n) for t, n in ((render, "render"), (alpha, "alpha"), (exp_depth, "expected_depths"),
+                                    (med_depth, "median_depths"), (exp_normal, "expected_normals"))]
+    return _GetOutputs.apply(*args, tuple(float(b) for b in background), bool(want_depth_im), float(fx), float(fy))

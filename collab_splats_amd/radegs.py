@@ -272,24 +272,24 @@ class RadegsModel(nn.Module):
             self.strategy.step_pre_backward(self.gauss_params, self.optimizers, self.strategy_state,
                                             self.step, self.info)
 
+        # a3 + a4: clamp / background / (n+1)/2 / where(alpha > 0, x, x.detach().max()) (rade_gs_model.py:221-254) and,
+        # when the depth-normal loss is active, depth_double_to_normal + "1 - <n, n_depth>" (:206-214) -- one
+        # autograd node, three kernels forward, two backward
+        bg_list = self._background_list()
+        background = self._get_background_color()
+        want_depth_im = render_mode == "RGB+ED"
         if self.config.use_depth_normal_loss and self.step >= self.config.regularization_from_iter:
-            # depth_double_to_normal + "1 - <n, n_depth>" (rade_gs_model.py:206-214), one fused kernel
-            _, normal_error_map = ops.depth_normal(expected_depths.reshape(H, W), median_depths.reshape(H, W),
-                                                   expected_normals.reshape(H, W, 3), camera_params["fx"],
-                                                   camera_params["fy"])
+            ep = ops.get_outputs_epilogue(render, alpha, expected_depths, median_depths, expected_normals, bg_list,
+                                          want_depth_im, camera_params["fx"], camera_params["fy"])
+            rgb, expected_depths, median_depths, normals, normal_error_map = ep[0], ep[1], ep[2], ep[3], ep[4]
+            depth_im = ep[5].squeeze(0) if want_depth_im else None
         else:
             # the reference builds zeros(2, 1, H) here (rade_gs_model.py:217-219); the
             # entries are unused under the same condition -- emit the intended [2, H, W]
             normal_error_map = torch.zeros(2, H, W, device=expected_normals.device)
-
-        # a3: clamp / background / (n+1)/2 / where(alpha > 0, x, x.detach().max()) -- rade_gs_model.py:221-254,
-        # fused into one reduction + one elementwise kernel (and one kernel backward)
-        bg_list = self._background_list()
-        background = self._get_background_color()
-        want_depth_im = render_mode == "RGB+ED"
-        ep = ops.outputs_epilogue(render, alpha, expected_depths, median_depths, expected_normals, bg_list, want_depth_im)
-        rgb, expected_depths, median_depths, normals = ep[0], ep[1], ep[2], ep[3]
-        depth_im = ep[4].squeeze(0) if want_depth_im else None
+            ep = ops.outputs_epilogue(render, alpha, expected_depths, median_depths, expected_normals, bg_list, want_depth_im)
+            rgb, expected_depths, median_depths, normals = ep[0], ep[1], ep[2], ep[3]
+            depth_im = ep[4].squeeze(0) if want_depth_im else None
         if background.shape[0] == 3 and not self.training:
             background = background.expand(H, W, 3)
         return {

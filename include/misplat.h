@@ -328,7 +328,9 @@ int misplat_slab_reduce(const misplat_params* p, int64_t n_rows, int64_t n_isect
 /* ---- a4 depth->normal (camera_utils.py:176-279) fused with the error map of
  * rade_gs_model.py:212-214: n_d = normalize(cross(dP/drow, dP/dcol)) of the back-projected
  * expected / median z-depth maps (interior pixels; border 0), err[k] = 1 - <n_render, n_d[k]>.
- * depths: exp_depth[H,W], med_depth[H,W]; n_render[H,W,3]; outputs normals2[2,H,W,3], err[2,H,W]. */
+ * depths: exp_depth[H,W], med_depth[H,W]; n_render[H,W,3]; outputs normals2[2,H,W,3], err[2,H,W]. 
+ * accumulate != 0 (backward): the three gradients are ADDED to the output buffers (which then already hold the
+ * gradients of the a3 epilogue, misplat_outputs_bwd) instead of stored. */
 int misplat_depth_normal_fwd(int32_t width, int32_t height, float fx, float fy,
                              const float* exp_depth, const float* med_depth,
                              const float* n_render, float* normals2, float* err,
@@ -337,7 +339,7 @@ int misplat_depth_normal_bwd(int32_t width, int32_t height, float fx, float fy,
                              const float* exp_depth, const float* med_depth,
                              const float* n_render, const float* v_normals2 /*or NULL*/,
                              const float* v_err /*or NULL*/, float* v_exp_depth,
-                             float* v_med_depth, float* v_n_render, misplat_stream_t stream);
+                             float* v_med_depth, float* v_n_render, int32_t accumulate, misplat_stream_t stream);
 
 /* ---- a3 get_outputs post-processing (rade_gs_model.py:221-254), one pixel = one image element
  * (C = 1).  background3_host: 3 floats in HOST memory.  maxes4: 4-float device scratch receiving

@@ -907,3 +907,40 @@ def test_random_configurations_vs_c_port(dev, craster, case):
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_fused_get_outputs_node_matches_separate_nodes(dev):
+    """The one-node a3 + a4 epilogue (ops.get_outputs_epilogue) against the two separate nodes: same outputs, same
+    gradients for every input, also when only some outputs take part in the loss (absent upstream gradients)."""
+    from collab_splats_amd import ops
+    g = torch.Generator().manual_seed(11)
+    H, W = 57, 83
+    base = [torch.rand(1, H, W, 4, generator=g), torch.rand(1, H, W, 1, generator=g),
+            2.0 + torch.rand(1, H, W, 1, generator=g), 2.0 + torch.rand(1, H, W, 1, generator=g),
+            torch.randn(1, H, W, 3, generator=g)]
+    base[1][0, :9, :11] = 0.0                                           # an empty region: where(alpha > 0, ...)
+    fx, fy, bg = 70.0, 66.0, (1.0, 1.0, 1.0)
+
+    def run(fused: bool, use):
+        ins = [t.clone().to(dev).requires_grad_(True) for t in base]
+        if fused:
+            rgb, dep, med, nrm, err, dim = ops.get_outputs_epilogue(*ins, bg, True, fx, fy)
+        else:
+            _, err = ops.depth_normal(ins[2].reshape(H, W), ins[3].reshape(H, W), ins[4].reshape(H, W, 3), fx, fy)
+            rgb, dep, med, nrm, dim = ops.outputs_epilogue(*ins, bg, True)
+        outs = dict(rgb=rgb, dep=dep, med=med, nrm=nrm, err=err, dim=dim)
+        gg = torch.Generator().manual_seed(5)
+        loss = sum((outs[k] * torch.rand(outs[k].shape, generator=gg).to(dev)).sum() for k in use)
+        loss.backward()
+        return outs, [t.grad for t in ins]
+
+    for use in (("rgb", "dep", "med", "nrm", "err", "dim"), ("rgb", "err"), ("err",), ("rgb",)):
+        o1, g1 = run(True, use)
+        o2, g2 = run(False, use)
+        for k in o1:
+            assert torch.allclose(o1[k], o2[k], rtol=1e-6, atol=1e-7), (use, k)
+        for a, b in zip(g1, g2):
+            if a is None or b is None:
+                assert (a is None or not a.any()) and (b is None or not b.any()), use
+            else:
+                assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), use
