@@ -196,6 +196,7 @@ def _sort32(lib, keys_in, keys_out, vals_in, vals_out, n: int, end_bit: int, bit
                                        ptr(vals_out), C.c_int64(n), C.c_int32(end_bit), stream_ptr()),
               "misplat_sort32_pairs")
         return
+    end_bit = max(end_bit, 2)                       # the hand-written sort needs >= 2 bits per pass; the extra key bits are zero
     bpp = min(bits_per_pass, end_bit)
     ws_bytes = int(lib.misplat_radix_workspace_bytes(C.c_int64(n), C.c_int32(0), C.c_int32(end_bit), C.c_int32(bpp)))
     if ws_bytes == 0:
