@@ -126,10 +126,30 @@ def parity_on_sample(args, sc, scales, op, ups, ref):
             "target": 1e-4}
 
 
+def spawn_ranks(args) -> int:
+    """``python bench.py --gpus N`` without a torchrun environment: start the N ranks as CHILD processes (nothing in
+    this process has touched the GPU yet) and relay their output; rank 0 of the children prints the JSON line."""
+    import subprocess
+    n_dev = torch.cuda.device_count()               # does not initialise the GPU
+    if n_dev < args.gpus and os.environ.get("MISPLAT_OVERSUBSCRIBE", "0") != "1":
+        print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible "
+              f"(MISPLAT_OVERSUBSCRIBE=1 rehearses N ranks on fewer devices)", file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     from collab_splats_amd import parallel
     rank, world, local = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
     local = local % torch.cuda.device_count()      # (a 1-GPU rehearsal of N > 1 puts every rank on cuda:0)

@@ -8,7 +8,7 @@ host side.  There is no CPU fallback.
 from ._lib import MisplatError, load as load_library  # noqa: F401
 from .rendering import rasterization  # noqa: F401
 from .wrapper import fully_fused_projection, spherical_harmonics  # noqa: F401
-from .strategy import DefaultStrategy  # noqa: F401
+from .strategy import DefaultStrategy, MCMCStrategy  # noqa: F401
 from .ops import set_deterministic  # noqa: F401
 from .optim import FusedAdam, step_all as fused_adam_step_all  # noqa: F401
 
@@ -35,5 +35,18 @@ def install_gsplat_alias() -> None:
     pkg.rendering, pkg.strategy, pkg.cuda = rendering, strategy, cuda
     pkg.rasterization = rendering.rasterization
     pkg.DefaultStrategy = strategy.DefaultStrategy
+    pkg.MCMCStrategy = strategy.MCMCStrategy
+
+    def _missing(modname):
+        def __getattr__(name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            raise ImportError(f"'{modname}.{name}' is not provided by collab_splats_amd's gsplat alias: only the "
+                              f"RaDe-GS rasterizer path is built (rasterization, fully_fused_projection, "
+                              f"spherical_harmonics, DefaultStrategy; MCMCStrategy is a placeholder)")
+        return __getattr__
+
+    pkg.__getattr__ = _missing("gsplat")
+    cuda.__getattr__ = _missing("gsplat.cuda")
     sys.modules.update({"gsplat": pkg, "gsplat.rendering": rendering, "gsplat.strategy": strategy,
                         "gsplat.cuda": cuda, "gsplat.cuda._wrapper": wrapper})

@@ -127,8 +127,8 @@ extern "C" int misplat_outputs_fwd(int64_t n_pix, int32_t color_dim, const float
     if (depth_im && color_dim < 4) return MISPLAT_EINVAL;
     if (n_pix == 0) return MISPLAT_OK;
     hipStream_t s = (hipStream_t)stream;
-    const float init[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
-    if (hipMemcpyAsync(maxes4, init, sizeof(init), hipMemcpyHostToDevice, s) != hipSuccess) return MISPLAT_ELAUNCH;
+    // seed the four maxima with -FLT_MAX on the device (a memset node: no pageable host buffer, no hidden sync)
+    if (hipMemsetD32Async((hipDeviceptr_t)maxes4, 0xff7fffff, 4, s) != hipSuccess) return MISPLAT_ELAUNCH;
     const int max_grid = grid_for(n_pix, 256) < 512 ? grid_for(n_pix, 256) : 512;
     hipLaunchKernelGGL(outputs_max_kernel, dim3(max_grid), dim3(256), 0, s, n_pix, color_dim, render,
                        exp_depth, med_depth, exp_normal, maxes4);

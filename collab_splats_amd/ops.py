@@ -437,8 +437,9 @@ class _Blend(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Params,
-                bins: Dict[str, Tensor], absgrad: bool):
+                bins: Dict[str, Tensor], absgrad: bool, pass_index: int = 0):
         lib = _lib.load()
+        ctx.pass_index = pass_index
         require_gpu(means2d)
         Cn, N, H, W = P.n_cams, P.n_gauss, P.height, P.width
         cd = colors.shape[-1]
@@ -475,21 +476,30 @@ class _Blend(torch.autograd.Function):
         Cn, N = P.n_cams, P.n_gauss
         g = v_grec.view(Cn, N, MISPLAT_REC)
         if ctx.absgrad:
-            # gsplat convention: the 2-D |gradient| rides on the means2d tensor for the strategy
-            ctx.means2d_ref.absgrad = v_abs.view(Cn, N, 2)
+            # gsplat convention: the 2-D |gradient| rides on the means2d tensor for the strategy; the 4-channel
+            # passes of one render (rendering.py generic path) each add their channels' share
+            # (|.| is taken per pass, so with more than one pass the sum is an upper bound of the one-pass value)
+            parts = ctx.means2d_ref.__dict__.setdefault("_absgrad_parts", {})
+            parts[ctx.pass_index] = v_abs.view(Cn, N, 2)
+            ctx.means2d_ref.absgrad = parts[0] if len(parts) == 1 and 0 in parts else sum(parts.values())
         return (g[..., 0:2], g[..., 2:5], g[..., 5], g[..., 12:12 + cd], g[..., 6], g[..., 7:9],
-                g[..., 9:12], None, None, None, None)
+                g[..., 9:12], None, None, None, None, None)
 
 
-def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Params, bins, absgrad=False):
+def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Params, bins, absgrad=False,
+          pass_index: int = 0):
+    """``pass_index``: which 4-channel pass of one render this is (rendering.py generic path); every pass adds its
+    channels' share to ``means2d.absgrad``."""
     if colors.shape[-1] < 1 or colors.shape[-1] > 4:
         raise ValueError("blend() takes 1..4 colour channels per pass")
+    if pass_index == 0:
+        means2d.__dict__.pop("_absgrad_parts", None)
     args = [_f32(t, n) for t, n in ((means2d, "means2d"), (conics, "conics"), (opac, "opacities"),
                                     (colors, "colors"), (ray_ts, "ray_ts"), (ray_planes, "ray_planes"),
                                     (normals, "normals"), (Ks, "Ks"))]
     if args[0] is not means2d:
         raise ValueError("means2d must be contiguous float32 so that its .grad/.absgrad can be retained")
-    return _Blend.apply(*args, P, bins, bool(absgrad))
+    return _Blend.apply(*args, P, bins, bool(absgrad), int(pass_index))
 
 
 # ----------------------------------------------------------------------------- fused path

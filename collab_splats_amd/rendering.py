@@ -166,7 +166,7 @@ def rasterization(
         first = None
         for s in range(0, D, 4):
             out = ops.blend(means2d, conics, opac, cols[..., s:s + 4], ray_ts, ray_planes, normals, Ks, P, bins,
-                            absgrad=absgrad and s == 0)
+                            absgrad=absgrad, pass_index=s // 4)
             renders.append(out[0])
             if first is None:
                 first = out

@@ -76,7 +76,11 @@ def split(params, optimizers, state: Dict[str, Any], mask: Tensor, revised_opaci
     sel, rest = torch.where(mask)[0], torch.where(~mask)[0]
     scales = torch.exp(params["scales"][sel])
     rot = _quat_to_rotmat(params["quats"][sel])
-    noise = torch.randn(2, len(sel), 3, device=scales.device, dtype=scales.dtype, generator=generator)
+    if generator is not None and generator.device != scales.device:
+        # a CPU generator gives the same samples on every rank and device type (lock-step replicas)
+        noise = torch.randn(2, len(sel), 3, dtype=scales.dtype, generator=generator).to(scales.device)
+    else:
+        noise = torch.randn(2, len(sel), 3, device=scales.device, dtype=scales.dtype, generator=generator)
     samples = torch.einsum("nij,nj,bnj->bni", rot, scales, noise)
 
     def param_fn(name: str, p: Tensor) -> Tensor:
@@ -136,6 +140,17 @@ class DefaultStrategy:
     revised_opacity: bool = False
     verbose: bool = False
     key_for_gradient: str = "means2d"
+    # Data-parallel training over views: every rank refines its replica from the SAME
+    # all-reduced gradients; with ``seed`` set, the split samples of step s come from a CPU generator seeded with
+    # (seed, s), so all ranks draw identical noise and the replicas stay bit-identical.  None = torch's global RNG.
+    seed: Optional[int] = None
+
+    def _generator(self, step: int) -> Optional[torch.Generator]:
+        if self.seed is None:
+            return None
+        g = torch.Generator()
+        g.manual_seed((int(self.seed) * 1_000_003 + int(step)) & 0x7FFFFFFFFFFFFFFF)
+        return g
 
     def initialize_state(self, scene_scale: float = 1.0) -> Dict[str, Any]:
         state: Dict[str, Any] = {"grad2d": None, "count": None, "scene_scale": scene_scale}
@@ -221,7 +236,8 @@ class DefaultStrategy:
             duplicate(params, optimizers, state, is_dupli)
         is_split = torch.cat([is_split, torch.zeros(n_dupli, dtype=torch.bool, device=is_split.device)])
         if n_split > 0:
-            split(params, optimizers, state, is_split, revised_opacity=self.revised_opacity)
+            split(params, optimizers, state, is_split, revised_opacity=self.revised_opacity,
+                  generator=self._generator(step))
         return n_dupli, n_split
 
     @torch.no_grad()
@@ -236,3 +252,13 @@ class DefaultStrategy:
         if n_prune > 0:
             remove(params, optimizers, state, is_prune)
         return n_prune
+
+
+class MCMCStrategy:
+    """Placeholder so that ``from gsplat.strategy import DefaultStrategy, MCMCStrategy`` (nerfstudio's Splatfacto
+    import line) resolves against the alias.  The reference's RaDe-GS models use ``DefaultStrategy`` only
+    (rade_gs_model.py:19, 456-458); the MCMC controller is outside the rasterizer path and is not built."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("MCMCStrategy is not part of the RaDe-GS rasterizer path built here "
+                                  "(SURVEY.md section 8); use DefaultStrategy")

@@ -595,6 +595,131 @@ void cr_blend_fwd(int D, const real* means2d, const real* conics, const real* op
     }
 }
 
+/* ------------------------------------------------------------------ threshold margins
+ * The compositing loop is discontinuous at alpha == alpha_min (skip), T' == t_stop (stop) and
+ * T == median_t (median switch).  margin[pixel] = the smallest RELATIVE perturbation eps of the
+ * alphas that could change one of these decisions for the pixel:
+ *   skip:    |alpha_i / alpha_min - 1|
+ *   stop:    |ln(T'_i / t_stop)| / S_i        with  S_i = sum_{j <= i} alpha_j / (1 - alpha_j)
+ *   median:  |ln(T_i / median_t)| / S_{i-1}
+ * (d ln T = -sum d alpha_j / (1 - alpha_j), so a relative error eps on every alpha moves ln T by at
+ * most eps * S; alphas clamped to alpha_max are exact in every implementation and do not count; each
+ * factor adds 0.1 for the rounding of the product itself).  Two correct fp32 implementations differ in
+ * alpha by ~1e-6 relative (v_exp_f32 vs expf, pre-multiplied conic), so a pixel with margin >> 1e-6
+ * cannot legitimately branch differently; tests/helpers.py::FlipProof uses this map to PROVE that an
+ * out-of-tolerance pixel sits on a threshold (test infrastructure only). */
+void cr_blend_margin(const real* means2d, const real* conics, const real* opac,
+                     const int32_t* flatten_ids, const int32_t* offsets, int64_t I,
+                     const cr_params* P, real* margin) {
+    int ts = P->tile_size;
+    int tw = (P->width + ts - 1) / ts, th = (P->height + ts - 1) / ts;
+    int nt = tw * th;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int t = 0; t < nt; t++) {
+        int ty = t / tw, tx = t % tw;
+        int64_t beg = offsets[t], end = (t + 1 < nt) ? offsets[t + 1] : I;
+        for (int ly = 0; ly < ts; ly++)
+            for (int lx = 0; lx < ts; lx++) {
+                int x = tx * ts + lx, y = ty * ts + ly;
+                if (x >= P->width || y >= P->height) continue;
+                real px = (real)x + R(0.5), py = (real)y + R(0.5);
+                double T = 1.0, S = 1e-3, m = 1e30;
+                for (int64_t i = beg; i < end; i++) {
+                    int g = flatten_ids[i];
+                    real dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                    real sigma = R(0.5) * (conics[3 * g] * dx * dx + conics[3 * g + 2] * dy * dy) + conics[3 * g + 1] * dx * dy;
+                    if (sigma < R(0)) continue;
+                    real raw = opac[g] * EXP(-sigma);
+                    real a = RMIN(P->alpha_max, raw);
+                    double ma = fabs((double)a / (double)P->alpha_min - 1.0);
+                    if (ma < m) m = ma;
+                    if (a < P->alpha_min) continue;
+                    double Sn = S + 0.1 + (raw < P->alpha_max ? (double)a / (1.0 - (double)a) : 0.0);
+                    double Tn = T * (1.0 - (double)a);
+                    double mt = fabs(log(Tn / (double)P->t_stop)) / Sn;
+                    if (mt < m) m = mt;
+                    if (Tn <= (double)P->t_stop) break;
+                    double mm = fabs(log(T / (double)P->median_t)) / S;
+                    if (mm < m) m = mm;
+                    T = Tn; S = Sn;
+                }
+                margin[(size_t)y * P->width + x] = (real)m;
+            }
+    }
+}
+
+/* ------------------------------------------------------------------ work statistics (design tooling)
+ * For block shapes bw x bh inside a 16 x 16 tile: how many (block, Gaussian) units a block-per-wave
+ * compositing design traverses and how many pixel pairs in them contribute.  out[s*4 + k]:
+ *   k=0 units with i <= maxlast(block)                       (traversed before any culling)
+ *   k=1 of those, units where SOME pixel of the block has alpha >= alpha_min     (exact cull)
+ *   k=2 of those, units where some pixel CONTRIBUTES (alpha >= alpha_min and i <= last(pixel))
+ *   k=3 contributing pixel pairs (independent of the shape)
+ * nshapes shapes given as (bw, bh) pairs.  */
+void cr_blend_stats(const real* means2d, const real* conics, const real* opac,
+                    const int32_t* flatten_ids, const int32_t* offsets, int64_t I,
+                    const cr_params* P, const int32_t* last_ids, int nshapes, const int32_t* shapes,
+                    int64_t* out) {
+    int ts = P->tile_size;
+    int tw = (P->width + ts - 1) / ts, th = (P->height + ts - 1) / ts;
+    int nt = tw * th;
+    for (int k = 0; k < nshapes * 4; k++) out[k] = 0;
+#pragma omp parallel
+    {
+        int64_t* loc = (int64_t*)calloc((size_t)nshapes * 4, sizeof(int64_t));
+#pragma omp for schedule(dynamic, 1)
+        for (int t = 0; t < nt; t++) {
+            int ty = t / tw, tx = t % tw;
+            int64_t beg = offsets[t], end = (t + 1 < nt) ? offsets[t + 1] : I;
+            unsigned char vis[256], con[256];
+            for (int64_t i = beg; i < end; i++) {
+                int g = flatten_ids[i];
+                int64_t npairs = 0;
+                for (int ly = 0; ly < ts; ly++)
+                    for (int lx = 0; lx < ts; lx++) {
+                        int x = tx * ts + lx, y = ty * ts + ly;
+                        int idx = ly * 16 + lx;
+                        vis[idx] = con[idx] = 0;
+                        if (x >= P->width || y >= P->height) continue;
+                        real px = (real)x + R(0.5), py = (real)y + R(0.5);
+                        real dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                        real sigma = R(0.5) * (conics[3 * g] * dx * dx + conics[3 * g + 2] * dy * dy) + conics[3 * g + 1] * dx * dy;
+                        if (sigma < R(0)) continue;
+                        real a = RMIN(P->alpha_max, opac[g] * EXP(-sigma));
+                        if (a < P->alpha_min) continue;
+                        vis[idx] = 1;
+                        if ((int32_t)i <= last_ids[(size_t)y * P->width + x]) { con[idx] = 1; npairs++; }
+                    }
+                for (int s = 0; s < nshapes; s++) {
+                    int bw = shapes[2 * s], bh = shapes[2 * s + 1];
+                    for (int by = 0; by < ts; by += bh)
+                        for (int bx = 0; bx < ts; bx += bw) {
+                            int32_t maxlast = -1;
+                            int anyv = 0, anyc = 0;
+                            for (int ly = by; ly < by + bh; ly++)
+                                for (int lx = bx; lx < bx + bw; lx++) {
+                                    int x = tx * ts + lx, y = ty * ts + ly;
+                                    if (x >= P->width || y >= P->height) continue;
+                                    int32_t l = last_ids[(size_t)y * P->width + x];
+                                    if (l > maxlast) maxlast = l;
+                                    anyv |= vis[ly * 16 + lx]; anyc |= con[ly * 16 + lx];
+                                }
+                            if ((int32_t)i <= maxlast) {
+                                loc[s * 4 + 0]++;
+                                if (anyv) loc[s * 4 + 1]++;
+                                if (anyc) loc[s * 4 + 2]++;
+                            }
+                        }
+                    loc[s * 4 + 3] += npairs;
+                }
+            }
+        }
+#pragma omp critical
+        for (int k = 0; k < nshapes * 4; k++) out[k] += loc[k];
+        free(loc);
+    }
+}
+
 /* ------------------------------------------------------------------ blend backward
  * Gradients are reduced per (tile, Gaussian) first and then added per Gaussian, the shape of
  * the HIP design.  v_* per-Gaussian outputs must be zeroed by the caller. */

@@ -150,6 +150,31 @@ class CRaster:
                                                           "normal", "last_ids", "median_ids")])
         return out
 
+    def blend_margin(self, st) -> np.ndarray:
+        """[H, W] relative distance of every pixel to the nearest branch threshold (alpha_min, t_stop,
+        median_t) over the Gaussians it traverses -- see cr_blend_margin.  ``st`` = result of ``forward``."""
+        P, pr, bs = st["P"], st["proj"], st["bins"]
+        m = np.zeros((P.height, P.width), self.dtype)
+        ins = [self._a(x) for x in (pr["means2d"], pr["conics"], st["opac"])]
+        fl, of = self._a(bs["flatten_ids"], np.int32), self._a(bs["isect_offsets"], np.int32).reshape(-1)
+        self.lib.cr_blend_margin(*[self._p(a) for a in ins], self._p(fl), self._p(of), C.c_int64(fl.shape[0]),
+                                 C.byref(P), self._p(m))
+        return m
+
+    def blend_stats(self, st, shapes=((16, 16), (16, 8), (16, 4), (8, 8), (8, 4), (4, 4))) -> Dict:
+        """Work statistics per block shape (design tooling; see cr_blend_stats)."""
+        P, pr, bs = st["P"], st["proj"], st["bins"]
+        ins = [self._a(x) for x in (pr["means2d"], pr["conics"], st["opac"])]
+        fl, of = self._a(bs["flatten_ids"], np.int32), self._a(bs["isect_offsets"], np.int32).reshape(-1)
+        li = self._a(st["fwd"]["last_ids"], np.int32)
+        sh = np.asarray(shapes, np.int32).reshape(-1)
+        out = np.zeros(len(shapes) * 4, np.int64)
+        self.lib.cr_blend_stats(*[self._p(a) for a in ins], self._p(fl), self._p(of), C.c_int64(fl.shape[0]),
+                                C.byref(P), self._p(li), C.c_int(len(shapes)), self._p(sh), self._p(out))
+        out = out.reshape(len(shapes), 4)
+        return {tuple(s): dict(traversed=int(o[0]), culled=int(o[1]), hit=int(o[2]), pairs=int(o[3]))
+                for s, o in zip(shapes, out)}
+
     def blend_bwd(self, P, means2d, conics, opac, colors, ray_ts, ray_planes, normals, flatten_ids,
                   offsets, fwd, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
         N, D = means2d.shape[0], colors.shape[1]

@@ -32,8 +32,49 @@ def upstream(shapes, seed=5, dtype=torch.float64):
     return [torch.rand(s, generator=g, dtype=dtype) for s in shapes]
 
 
-def assert_close_flips(got, ref, name="", tol=1e-4, outlier_frac=2e-5, outlier_tol=None, min_outliers=2):
-    """Tensor-inf-norm relative comparison that tolerates fp32 THRESHOLD FLIPS.
+MARGIN_TOL = 1e-5      # relative distance to a branch threshold below which two correct fp32 implementations may differ
+
+
+class FlipProof:
+    """Evidence that an out-of-tolerance element is a THRESHOLD FLIP and nothing else.
+
+    Built from the C restatement's per-pixel margin map (oracle/craster.c::cr_blend_margin: the smallest relative
+    distance of alpha to alpha_min, of T' to t_stop and of T to median_t over the Gaussians the pixel traverses).
+    A pixel may only miss the tolerance if its margin is below MARGIN_TOL; a per-Gaussian gradient row may only
+    miss it if the Gaussian's screen-space box (mean2d +- radii) contains such a pixel."""
+
+    def __init__(self, margin, means2d=None, radii=None, margin_tol=MARGIN_TOL):
+        self.margin = np.asarray(margin, dtype=np.float64)
+        self.low = self.margin < margin_tol
+        self.margin_tol = margin_tol
+        self.means2d = None if means2d is None else np.asarray(means2d, dtype=np.float64)
+        self.radii = None if radii is None else np.asarray(radii, dtype=np.int64)
+        # summed-area table of the low-margin pixels: box queries in O(1)
+        self.sat = np.zeros((self.low.shape[0] + 1, self.low.shape[1] + 1), dtype=np.int64)
+        self.sat[1:, 1:] = self.low.astype(np.int64).cumsum(0).cumsum(1)
+
+    def check_pixels(self, bad_mask, name):
+        """bad_mask [H, W] bool: every bad pixel must sit on a threshold."""
+        unexplained = bad_mask & ~self.low
+        assert not unexplained.any(), (
+            f"{name}: {int(unexplained.sum())} pixel(s) miss the tolerance with threshold margin >= {self.margin_tol} "
+            f"(first at {tuple(np.argwhere(unexplained)[0])}, margin {self.margin[unexplained].min():.3e}): not a flip")
+
+    def check_rows(self, bad_rows, name):
+        """bad_rows: indices of Gaussians whose gradient misses the tolerance."""
+        assert self.means2d is not None, "FlipProof needs means2d/radii for gradient tensors"
+        H, W = self.low.shape
+        for g in np.asarray(bad_rows).reshape(-1):
+            mx, my = self.means2d[g]
+            rx, ry = self.radii[g]
+            x0, x1 = int(np.clip(np.floor(mx - rx - 1), 0, W)), int(np.clip(np.ceil(mx + rx + 1), 0, W))
+            y0, y1 = int(np.clip(np.floor(my - ry - 1), 0, H)), int(np.clip(np.ceil(my + ry + 1), 0, H))
+            n = self.sat[y1, x1] - self.sat[y0, x1] - self.sat[y1, x0] + self.sat[y0, x0]
+            assert n > 0, f"{name}: Gaussian {int(g)} misses the tolerance but covers no threshold pixel: not a flip"
+
+
+def assert_close_flips(got, ref, name="", tol=1e-4, outlier_frac=2e-5, outlier_tol=None, min_outliers=2, proof=None):
+    """Tensor-inf-norm relative comparison that tolerates fp32 THRESHOLD FLIPS -- and only those.
 
     The algorithm is discontinuous at alpha == 1/255 (skip), T == 1e-4 (stop) and T == 0.5 (median):
     two correct fp32 implementations (v_exp_f32 vs libm expf) can take different branches for an
@@ -43,6 +84,10 @@ def assert_close_flips(got, ref, name="", tol=1e-4, outlier_frac=2e-5, outlier_t
     On small images one flipped pixel already exceeds the fraction, so `min_outliers` pixels (rows of the last
     dimension) are always allowed; a flip of the MEDIAN depth moves that pixel to the depth of a neighbouring Gaussian, i.e. by
     anything inside the depth range, so tensors named "*med_depth*" get `outlier_tol` = 1.
+
+    With ``proof`` (a FlipProof) the blanket allowance becomes a demonstrated one: every out-of-tolerance pixel of an
+    image [H, W, ...] must have a threshold margin < MARGIN_TOL, and every out-of-tolerance row of a per-Gaussian
+    tensor [N, ...] must cover such a pixel; anything else fails.
     """
     if outlier_tol is None:
         outlier_tol = 1.0 if "med_depth" in name else 2e-2
@@ -56,4 +101,10 @@ def assert_close_flips(got, ref, name="", tol=1e-4, outlier_frac=2e-5, outlier_t
     allowed = max(outlier_frac, (min_outliers * width + 0.5) / max(d.size, 1))
     assert frac <= allowed, f"{name}: {frac:.2e} of elements exceed {tol} (max {d.max():.3e})"
     assert d.max() <= outlier_tol, f"{name}: max rel err {d.max():.3e} > {outlier_tol}"
+    if proof is not None and frac > 0:
+        bad = d > tol
+        if a.shape[:2] == proof.low.shape:                       # image [H, W] or [H, W, C]
+            proof.check_pixels(bad.reshape(bad.shape[0], bad.shape[1], -1).any(-1), name)
+        else:                                                    # per-Gaussian [N] or [N, ...]
+            proof.check_rows(np.nonzero(bad.reshape(bad.shape[0], -1).any(-1))[0], name)
     return float(d.max()), frac

@@ -117,3 +117,32 @@ def test_gsplat_alias_resolves_reference_imports():
             "from gsplat.cuda._wrapper import fully_fused_projection, spherical_harmonics;"
             "assert rasterization is m.rasterization and DefaultStrategy().absgrad is False")
     subprocess.check_call([sys.executable, "-c", code], cwd=ROOT)
+
+
+def test_gsplat_alias_serves_nerfstudio_style_imports_and_names_what_is_missing():
+    """nerfstudio's Splatfacto imports more of gsplat than the reference itself
+    (``from gsplat.strategy import DefaultStrategy, MCMCStrategy``): those lines must resolve against the alias, and
+    anything that is not built must say so instead of failing with a bare AttributeError."""
+    import importlib
+    import sys
+    import collab_splats_amd
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "gsplat" or k.startswith("gsplat.")}
+    try:
+        collab_splats_amd.install_gsplat_alias()
+        ns = {}
+        exec("from gsplat.strategy import DefaultStrategy, MCMCStrategy\n"
+             "from gsplat.rendering import rasterization\n"
+             "from gsplat.cuda._wrapper import fully_fused_projection, spherical_harmonics\n"
+             "from gsplat import rasterization as r2, DefaultStrategy as d2\n"
+             "import gsplat", ns)
+        assert ns["DefaultStrategy"] is collab_splats_amd.DefaultStrategy and ns["r2"] is collab_splats_amd.rasterization
+        with pytest.raises(NotImplementedError):
+            ns["MCMCStrategy"]()
+        with pytest.raises(ImportError, match="not provided by collab_splats_amd"):
+            exec("from gsplat import rasterization_2dgs", {})
+        with pytest.raises(ImportError, match="not provided"):
+            getattr(ns["gsplat"].cuda, "_backend")
+    finally:
+        for k in [k for k in sys.modules if k == "gsplat" or k.startswith("gsplat.")]:
+            sys.modules.pop(k)
+        sys.modules.update(saved)

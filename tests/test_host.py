@@ -167,3 +167,100 @@ def test_fused_adam_refuses_cpu_tensors():
         opt.step()
     with pytest.raises(ValueError):
         FusedAdam([p], lr=-1.0)
+
+
+def test_get_loss_dict_value_vs_reference_goldens():
+    """a5 (rade_gs_model.py:289-307) through the product function on CPU: the reference's own error maps in, the
+    reference's own loss value out; the term is absent before ``regularization_from_iter``."""
+    import numpy as np
+    import os
+    from collab_splats_amd import radegs
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "camera_goldens.npz"))
+    one = torch.zeros(1, 3)
+    model = radegs.RadegsModel(radegs.RadegsModelConfig(), one, one, torch.ones(1, 4), torch.zeros(1), one,
+                               torch.zeros(1, 15, 3))
+    for i in range(3):
+        err = torch.from_numpy(g[f"dn{i}_err"])
+        outputs = {"rgb": torch.zeros(*err.shape[1:], 3), "depth_normal_error_map": err[0].unsqueeze(-1),
+                   "middepth_normal_error_map": err[1].unsqueeze(-1)}
+        model.step = 100
+        assert model.get_loss_dict(outputs, None) == {}
+        model.step = 15000
+        loss = model.get_loss_dict(outputs, None)
+        assert abs(float(loss["depth_normal_loss"]) - float(g[f"dn{i}_loss"])) < 1e-7
+        model.config.use_depth_normal_loss = False
+        assert model.get_loss_dict(outputs, None) == {}
+        model.config.use_depth_normal_loss = True
+
+
+def _np_refine(P, grad2d_avg, noise, step, cfg):
+    """Second, independent restatement (numpy fp64) of one 3DGS refinement step -- clone small high-gradient
+    Gaussians, split large ones into two samples with scales / 1.6, prune transparent (and, after the first opacity
+    reset, oversized) ones -- written from Kerbl et al. 2023 section 5, NOT from strategy.py.  [UNVERIFIED-UPSTREAM:
+    gsplat's own controller is absent; this pins strategy.py against a second reading of the paper only.]"""
+    means, scales, quats, opac = (np.asarray(P[k], np.float64) for k in ("means", "scales", "quats", "opacities"))
+    extra = {k: np.asarray(v, np.float64) for k, v in P.items() if k not in ("means", "scales", "quats", "opacities")}
+    s_lin = np.exp(scales)
+    high = grad2d_avg > cfg["grow_grad2d"]
+    small = s_lin.max(1) <= cfg["grow_scale3d"] * cfg["scene_scale"]
+    clone, splt = high & small, high & ~small
+    n = len(means)
+    # (1) clones are appended unchanged
+    idx_c = np.nonzero(clone)[0]
+    order = list(range(n)) + list(idx_c)
+    means, scales, quats, opac = means[order], scales[order], quats[order], opac[order]
+    extra = {k: v[order] for k, v in extra.items()}
+    splt = np.concatenate([splt, np.zeros(len(idx_c), bool)])
+    # (2) every split parent is replaced by two samples  mu + R diag(s) z, scales / 1.6
+    idx_s, idx_r = np.nonzero(splt)[0], np.nonzero(~splt)[0]
+    q = quats[idx_s] / np.linalg.norm(quats[idx_s], axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                  2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                  2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], axis=1).reshape(-1, 3, 3)
+    sl = np.exp(scales[idx_s])
+    kids = [means[idx_s] + np.einsum("nij,nj->ni", R, sl * noise[b]) for b in range(2)]
+    means = np.concatenate([means[idx_r]] + kids)
+    scales = np.concatenate([scales[idx_r], np.log(sl / 1.6), np.log(sl / 1.6)])
+    quats = np.concatenate([quats[idx_r], quats[idx_s], quats[idx_s]])
+    opac = np.concatenate([opac[idx_r], opac[idx_s], opac[idx_s]])
+    extra = {k: np.concatenate([v[idx_r], v[idx_s], v[idx_s]]) for k, v in extra.items()}
+    # (3) prune
+    dead = 1.0 / (1.0 + np.exp(-opac.reshape(len(opac), -1)[:, 0])) < cfg["prune_opa"]
+    if step > cfg["reset_every"]:
+        dead |= np.exp(scales).max(1) > cfg["prune_scale3d"] * cfg["scene_scale"]
+    keep = ~dead
+    out = dict(means=means[keep], scales=scales[keep], quats=quats[keep], opacities=opac[keep])
+    out.update({k: v[keep] for k, v in extra.items()})
+    return out, (int(clone.sum()), int(len(idx_s)), int(dead.sum()))
+
+
+@pytest.mark.parametrize("step", [10, 3010])
+def test_strategy_matches_an_independent_numpy_restatement_unverified_upstream(step):
+    """[UNVERIFIED-UPSTREAM] ``DefaultStrategy.step_post_backward`` against ``_np_refine`` on a 12-Gaussian toy state:
+    same survivors in the same order, same children, same counts.  gsplat's controller is absent, so this pins the
+    product against a second independent reading of the published algorithm, not against upstream."""
+    n = 12
+    params, optimizers = _toy_training_state(n)
+    cfg = dict(grow_grad2d=0.5, grow_scale3d=0.01, prune_opa=0.005, prune_scale3d=0.1, reset_every=3000, scene_scale=1.0)
+    s = DefaultStrategy(refine_start_iter=0, refine_every=10, reset_every=3000, grow_grad2d=0.5, grow_scale3d=0.01,
+                        prune_opa=0.005, seed=7)
+    st = s.initialize_state(scene_scale=1.0)
+    with torch.no_grad():
+        params["scales"][4:8] = float(np.log(0.05))
+        params["scales"][8] = float(np.log(0.2))              # oversized: pruned only after the first opacity reset
+        params["opacities"][10:12] = -9.0
+    grad = torch.zeros(1, n, 2)
+    grad[0, [0, 1, 4, 5], 0] = 1.0
+    m2d = torch.zeros(1, n, 2, requires_grad=True)
+    m2d.grad = grad
+    info = {"means2d": m2d, "radii": torch.ones(1, n, 2, dtype=torch.int32), "width": 2, "height": 2, "n_cameras": 1}
+    before = {k: v.detach().double().numpy().copy() for k, v in params.items()}
+    noise = torch.randn(2, 2, 3, generator=s._generator(step)).double().numpy()        # 2 split parents
+    avg = np.hypot(grad[0, :, 0].numpy() * 2 / 2.0, 0.0)                                # one observation each
+    want, counts = _np_refine(before, avg, noise, step, cfg)
+    got_counts = s.step_post_backward(params, optimizers, st, step, info)
+    assert tuple(got_counts) == counts
+    for k in params:
+        assert params[k].shape == want[k].shape, k
+        assert np.abs(params[k].detach().double().numpy() - want[k]).max() < 1e-6, k
