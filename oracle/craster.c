@@ -597,17 +597,20 @@ void cr_blend_fwd(int D, const real* means2d, const real* conics, const real* op
 
 /* ------------------------------------------------------------------ threshold margins
  * The compositing loop is discontinuous at alpha == alpha_min (skip), T' == t_stop (stop) and
- * T == median_t (median switch).  margin[pixel] = the smallest RELATIVE perturbation eps of the
- * alphas that could change one of these decisions for the pixel:
- *   skip:    |alpha_i / alpha_min - 1|
- *   stop:    |ln(T'_i / t_stop)| / S_i        with  S_i = sum_{j <= i} alpha_j / (1 - alpha_j)
+ * T == median_t (median switch).  Two correct fp32 implementations evaluate
+ *     sigma = 0.5 (a dx^2 + c dy^2) + b dx dy
+ * with a rounding error proportional to the SIZE OF ITS TERMS (which cancel for needle-shaped
+ * Gaussians), i.e. |d sigma_i| <= m * E_i with E_i = 1 + |0.5 a dx^2| + |0.5 c dy^2| + |b dx dy| and m a
+ * small multiple of the fp32 unit roundoff 2^-24 = 6e-8 (the 1 covers exp itself and the opacity
+ * product).  alpha_i then moves by the relative amount m * E_i, and ln T by at most
+ * m * S with S = sum_j (E_j alpha_j / (1 - alpha_j) + 1) over the unclamped alphas (+1 per factor for
+ * the rounding of the running product).  margin[pixel] = the smallest m that could change a decision:
+ *   skip:    |ln(alpha_i / alpha_min)| / E_i      (alphas clamped to alpha_max are exact: never)
+ *   stop:    |ln(T'_i / t_stop)| / S_i
  *   median:  |ln(T_i / median_t)| / S_{i-1}
- * (d ln T = -sum d alpha_j / (1 - alpha_j), so a relative error eps on every alpha moves ln T by at
- * most eps * S; alphas clamped to alpha_max are exact in every implementation and do not count; each
- * factor adds 0.1 for the rounding of the product itself).  Two correct fp32 implementations differ in
- * alpha by ~1e-6 relative (v_exp_f32 vs expf, pre-multiplied conic), so a pixel with margin >> 1e-6
- * cannot legitimately branch differently; tests/helpers.py::FlipProof uses this map to PROVE that an
- * out-of-tolerance pixel sits on a threshold (test infrastructure only). */
+ * A pixel whose margin is far above a few units of 6e-8 cannot legitimately branch differently;
+ * tests/helpers.py::FlipProof uses this map to PROVE that an out-of-tolerance pixel sits on a
+ * threshold (test infrastructure only). */
 void cr_blend_margin(const real* means2d, const real* conics, const real* opac,
                      const int32_t* flatten_ids, const int32_t* offsets, int64_t I,
                      const cr_params* P, real* margin) {
@@ -627,14 +630,23 @@ void cr_blend_margin(const real* means2d, const real* conics, const real* opac,
                 for (int64_t i = beg; i < end; i++) {
                     int g = flatten_ids[i];
                     real dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                    real t1 = R(0.5) * conics[3 * g] * dx * dx, t2 = R(0.5) * conics[3 * g + 2] * dy * dy;
+                    real t3 = conics[3 * g + 1] * dx * dy;
                     real sigma = R(0.5) * (conics[3 * g] * dx * dx + conics[3 * g + 2] * dy * dy) + conics[3 * g + 1] * dx * dy;
-                    if (sigma < R(0)) continue;
+                    double E = 1.0 + fabs((double)t1) + fabs((double)t2) + fabs((double)t3);
+                    if (sigma < R(0)) {          /* sigma < 0 is itself a branch: distance of sigma to 0 */
+                        double ms = fabs((double)sigma) / E;
+                        if (ms < m) m = ms;
+                        continue;
+                    }
                     real raw = opac[g] * EXP(-sigma);
                     real a = RMIN(P->alpha_max, raw);
-                    double ma = fabs((double)a / (double)P->alpha_min - 1.0);
-                    if (ma < m) m = ma;
+                    if (raw < P->alpha_max) {
+                        double ma = fabs(log((double)a / (double)P->alpha_min)) / E;
+                        if (ma < m) m = ma;
+                    }
                     if (a < P->alpha_min) continue;
-                    double Sn = S + 0.1 + (raw < P->alpha_max ? (double)a / (1.0 - (double)a) : 0.0);
+                    double Sn = S + 1.0 + (raw < P->alpha_max ? E * (double)a / (1.0 - (double)a) : 0.0);
                     double Tn = T * (1.0 - (double)a);
                     double mt = fabs(log(Tn / (double)P->t_stop)) / Sn;
                     if (mt < m) m = mt;

@@ -32,14 +32,17 @@ def upstream(shapes, seed=5, dtype=torch.float64):
     return [torch.rand(s, generator=g, dtype=dtype) for s in shapes]
 
 
-MARGIN_TOL = 1e-5      # relative distance to a branch threshold below which two correct fp32 implementations may differ
+MARGIN_TOL = 8 * 2.0 ** -24   # 8 units of the fp32 roundoff in the sigma evaluation (cr_blend_margin): below this two
+                              # correct fp32 implementations may branch differently.  Measured on MI355X
+                              # (scripts/flip_margins.py): every differing pixel sits at <= 1.2 units.
 
 
 class FlipProof:
     """Evidence that an out-of-tolerance element is a THRESHOLD FLIP and nothing else.
 
-    Built from the C restatement's per-pixel margin map (oracle/craster.c::cr_blend_margin: the smallest relative
-    distance of alpha to alpha_min, of T' to t_stop and of T to median_t over the Gaussians the pixel traverses).
+    Built from the C restatement's per-pixel margin map (oracle/craster.c::cr_blend_margin: the smallest rounding
+    error of the sigma evaluation, in units of the size of its terms, that could move alpha across alpha_min, T'
+    across t_stop or T across median_t for any Gaussian the pixel traverses).
     A pixel may only miss the tolerance if its margin is below MARGIN_TOL; a per-Gaussian gradient row may only
     miss it if the Gaussian's screen-space box (mean2d +- radii) contains such a pixel."""
 
@@ -99,6 +102,10 @@ def assert_close_flips(got, ref, name="", tol=1e-4, outlier_frac=2e-5, outlier_t
     frac = float((d > tol).mean())
     width = a.shape[-1] if a.ndim > 1 else 1                     # a flipped pixel moves all its channels
     allowed = max(outlier_frac, (min_outliers * width + 0.5) / max(d.size, 1))
+    if proof is not None:
+        # every outlier is checked individually below; one flipped pixel moves the gradients of all the Gaussians
+        # composited behind it, so the count of (proven) outliers only gets a loose sanity bound
+        allowed = max(allowed, 20 * outlier_frac)
     assert frac <= allowed, f"{name}: {frac:.2e} of elements exceed {tol} (max {d.max():.3e})"
     assert d.max() <= outlier_tol, f"{name}: max rel err {d.max():.3e} > {outlier_tol}"
     if proof is not None and frac > 0:
