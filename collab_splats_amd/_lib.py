@@ -35,7 +35,8 @@ class Params(C.Structure):
                 ("far_plane", C.c_float), ("radius_clip", C.c_float), ("radius_sigma", C.c_float),
                 ("alpha_max", C.c_float), ("alpha_min", C.c_float), ("t_stop", C.c_float),
                 ("median_t", C.c_float), ("jacobian_margin", C.c_float), ("plane_eps", C.c_float),
-                ("ppl_fwd", C.c_int32), ("ppl_bwd", C.c_int32), ("ed_slot", C.c_int32)]
+                ("ppl_fwd", C.c_int32), ("ppl_bwd", C.c_int32), ("ed_slot", C.c_int32), ("reserved0", C.c_int32),
+                ("unit_perm", C.c_void_p), ("unit_work", C.c_void_p)]
 
 
 def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: int = 16,
@@ -51,7 +52,8 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
     return Params(n_gauss, n_cams, width, height, tile_size, tw, th, int(antialiased),
                   int(opacity_aware_radius), eps2d, near_plane, far_plane, radius_clip, radius_sigma,
                   alpha_max, alpha_min, t_stop, median_t, jacobian_margin, plane_eps,
-                  int(os.environ.get("MISPLAT_PPL_FWD", ppl_fwd)), int(os.environ.get("MISPLAT_PPL_BWD", ppl_bwd)), int(ed_slot))
+                  int(os.environ.get("MISPLAT_PPL_FWD", ppl_fwd)), int(os.environ.get("MISPLAT_PPL_BWD", ppl_bwd)), int(ed_slot),
+                  0, None, None)
 
 
 # name -> (restype, n_args); every symbol include/misplat.h declares
@@ -60,10 +62,7 @@ SYMBOLS = {
     "misplat_project_pack_fwd": (C.c_int, 13), "misplat_color_fwd": (C.c_int, 15),
     "misplat_color_bwd": (C.c_int, 16), "misplat_project_pack_bwd": (C.c_int, 18),
     "misplat_sh_fwd": (C.c_int, 9), "misplat_sh_bwd": (C.c_int, 11),
-    "misplat_tile_count": (C.c_int, 5), "misplat_tile_emit": (C.c_int, 9),
-    "misplat_sort_workspace_bytes": (C.c_size_t, 2), "misplat_sort_pairs": (C.c_int, 9),
-    "misplat_tile_offsets": (C.c_int, 8), "misplat_depth_keys": (C.c_int, 6),
-    "misplat_tile_emit_ordered": (C.c_int, 9), "misplat_sort32_workspace_bytes": (C.c_size_t, 2),
+    "misplat_sort32_workspace_bytes": (C.c_size_t, 2),
     "misplat_sort32_pairs": (C.c_int, 9), "misplat_tile_offsets32": (C.c_int, 5),
     "misplat_isect_ids": (C.c_int, 6), "misplat_tile_sort": (C.c_int, 10),
     "misplat_tile_count_blocks": (C.c_int, 8),
@@ -72,15 +71,15 @@ SYMBOLS = {
     "misplat_sort16_pairs": (C.c_int, 9),
     "misplat_tile_offsets16": (C.c_int, 5),
     "misplat_adam_step": (C.c_int, 12),
-    "misplat_tile_hist": (C.c_int, 6),
-    "misplat_tile_scan": (C.c_int, 5),
-    "misplat_tile_scatter": (C.c_int, 9),
-    "misplat_radix_workspace_bytes": (C.c_size_t, 4), "misplat_radix_sort_pairs": (C.c_int, 11), "misplat_depth_keys32": (C.c_int, 6), "misplat_pack": (C.c_int, 11),
+    "misplat_radix_workspace_bytes": (C.c_size_t, 4), "misplat_radix_sort_pairs": (C.c_int, 11), "misplat_pack": (C.c_int, 11),
     "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_bwd": (C.c_int, 21),
     "misplat_color_fwd_x": (C.c_int, 11), "misplat_color_bwd_x": (C.c_int, 9),
     "misplat_blend_fwd_x": (C.c_int, 17), "misplat_blend_bwd_x_atomic": (C.c_int, 22),
     "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 19), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),
     "misplat_depth_normal_bwd": (C.c_int, 14), "misplat_outputs_fwd": (C.c_int, 15), "misplat_outputs_bwd": (C.c_int, 16),
+    "misplat_bucket_plan": (C.c_int, 3), "misplat_bucket_count": (C.c_int, 9), "misplat_bucket_rows": (C.c_int, 10),
+    "misplat_bucket_tiles": (C.c_int, 11),
+    "misplat_unit_order": (C.c_int, 5),
     "misplat_version": (C.c_char_p, 0),
 }
 

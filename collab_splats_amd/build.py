@@ -26,6 +26,7 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-I", INCLUDE,
 SOURCES = {
     "project.hip": ["-ffp-contract=off"],
     "binning.hip": [],
+    "bucket.hip": [],
     "blend.hip": [],
     "epilogue.hip": [],
     "sort.hip": [],

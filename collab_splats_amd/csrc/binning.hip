@@ -1,10 +1,11 @@
-// binning.hip -- tile intersection, key emission, radix sort, per-tile offsets, record packing.
+// binning.hip -- the per-tile depth sort (one workgroup per tile, register-resident LDS radix), the
+// "pertile" pair emission + tile-bit radix sort (rocPRIM) + per-tile offsets, record packing.
 // gfx950 only.  SURVEY.md section 8 row a2.3 (inside gsplat-rade's rasterization(), called at
 // /root/reference/collab_splats/models/rade_gs_model.py:439-465).  Integer stage: results are
-// bit-exact against the CPU restatement (tests/test_parity_gpu.py).
+// bit-exact against the CPU restatement (tests/test_parity_gpu.py).  The default bucketing is in
+// csrc/bucket.hip; what both feed is misplat_tile_sort below.
 //
-// HBM-bound integer/byte work: no MFMA.  key = ((cam*tiles + tile) << 32) | depth bits, value =
-// emission slot; the sort only touches the significant bits (32 + ceil(log2(C*tiles))).
+// HBM-bound integer/byte work: no MFMA.
 #include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
@@ -43,70 +44,8 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t x, uint32_t ident, O
     return x;
 }
 
-__global__ __launch_bounds__(256) void tile_count_kernel(int64_t total, int tw, int th,
-                                                         const float* __restrict__ means2d,
-                                                         const int32_t* __restrict__ radii,
-                                                         int32_t* __restrict__ tiles_per_gauss) {
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        int rx = radii[2 * idx], ry = radii[2 * idx + 1];
-        int n = 0;
-        if (rx > 0 || ry > 0) {
-            int x0, x1, y0, y1;
-            tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rx, ry, tw, th, x0, x1, y0, y1);
-            n = (x1 - x0) * (y1 - y0);
-        }
-        tiles_per_gauss[idx] = n;
-    }
-}
 
-__global__ __launch_bounds__(256) void tile_emit_kernel(int64_t total, int n_gauss, int tw, int th,
-                                                        const float* __restrict__ means2d,
-                                                        const int32_t* __restrict__ radii,
-                                                        const float* __restrict__ depths,
-                                                        const int64_t* __restrict__ cum,
-                                                        uint64_t* __restrict__ keys,
-                                                        int32_t* __restrict__ slot_ids,
-                                                        int32_t* __restrict__ isect_gid) {
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        int rx = radii[2 * idx], ry = radii[2 * idx + 1];
-        if (!(rx > 0 || ry > 0)) continue;
-        int x0, x1, y0, y1;
-        tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rx, ry, tw, th, x0, x1, y0, y1);
-        const int cam = (int)(idx / n_gauss);
-        const uint64_t base = (uint64_t)cam * (uint64_t)(tw * th);
-        const uint64_t dbits = (uint64_t)__float_as_uint(depths[idx]);
-        int64_t j = cum[idx];
-        for (int ty = y0; ty < y1; ty++)
-            for (int tx = x0; tx < x1; tx++) {
-                keys[j] = ((base + (uint64_t)(ty * tw + tx)) << 32) | dbits;
-                slot_ids[j] = (int32_t)j;
-                isect_gid[j] = (int32_t)idx;
-                j++;
-            }
-    }
-}
 
-// threads 0..n (inclusive): thread i closes every tile in (tile(i-1), tile(i)]
-__global__ __launch_bounds__(256) void tile_offsets_kernel(const uint64_t* __restrict__ keys,
-                                                           const int32_t* __restrict__ slots,
-                                                           const int32_t* __restrict__ isect_gid,
-                                                           int64_t n, int n_tiles,
-                                                           int32_t* __restrict__ offsets,
-                                                           int32_t* __restrict__ flatten_ids) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t cur = (i < n) ? (int64_t)(keys[i] >> 32) : (int64_t)n_tiles - 1;
-        int64_t prev = (i > 0) ? (int64_t)(keys[i - 1] >> 32) : -1;
-        if (i == n) {
-            for (int64_t t = prev + 1; t < n_tiles; t++) offsets[t] = (int32_t)n;
-        } else {
-            for (int64_t t = prev + 1; t <= cur; t++) offsets[t] = (int32_t)i;
-            flatten_ids[i] = isect_gid[slots[i]];
-        }
-    }
-}
 
 __global__ __launch_bounds__(256) void pack_kernel(int64_t n_rows, int cd,
                                                    const float* __restrict__ means2d,
@@ -129,51 +68,7 @@ __global__ __launch_bounds__(256) void pack_kernel(int64_t n_rows, int cd,
     }
 }
 
-// ---- two-stage ordering (what bin_tiles() uses): Gaussians are sorted by (camera, depth) once,
-// intersections are emitted in that order, and a STABLE sort on the tile id alone then yields exactly
-// the (tile, depth, Gaussian id) order of the one-shot 64-bit key sort, touching 4-byte keys in 2
-// radix passes instead of 12-byte pairs in 5-6.
-__global__ __launch_bounds__(256) void depth_keys_kernel(int64_t total, int n_gauss, int n_cams,
-                                                         const int32_t* __restrict__ radii,
-                                                         const float* __restrict__ depths,
-                                                         uint64_t* __restrict__ keys, int32_t* __restrict__ ids) {
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const bool vis = radii[2 * idx] > 0 || radii[2 * idx + 1] > 0;
-        const uint64_t cam = vis ? (uint64_t)(idx / n_gauss) : (uint64_t)n_cams;   // culled rows sort last
-        keys[idx] = (cam << 32) | (uint64_t)(vis ? __float_as_uint(depths[idx]) : 0u);
-        ids[idx] = (int32_t)idx;
-    }
-}
 
-// rank r of the depth order -> Gaussian row order[r]; cum_ordered = exclusive scan of its tile counts
-__global__ __launch_bounds__(256) void tile_emit_ordered_kernel(int64_t total, int n_gauss, int tw, int th,
-                                                                const int32_t* __restrict__ order,
-                                                                const float* __restrict__ means2d,
-                                                                const int32_t* __restrict__ radii,
-                                                                const int64_t* __restrict__ cum_ordered,
-                                                                uint32_t* __restrict__ tile_ids,
-                                                                int32_t* __restrict__ slot_ids,
-                                                                int32_t* __restrict__ isect_gid) {
-    // slot_ids == NULL: only the Gaussian row is emitted (it is then the sort payload)
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < total;
-         r += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t idx = order ? (int64_t)order[r] : r;       // order == NULL: rows in their own order
-        int rx = radii[2 * idx], ry = radii[2 * idx + 1];
-        if (!(rx > 0 || ry > 0)) continue;
-        int x0, x1, y0, y1;
-        tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rx, ry, tw, th, x0, x1, y0, y1);
-        const uint32_t base = (uint32_t)(idx / n_gauss) * (uint32_t)(tw * th);
-        int64_t j = cum_ordered[r];
-        for (int ty = y0; ty < y1; ty++)
-            for (int tx = x0; tx < x1; tx++) {
-                tile_ids[j] = base + (uint32_t)(ty * tw + tx);
-                if (slot_ids) slot_ids[j] = (int32_t)j;
-                isect_gid[j] = (int32_t)idx;
-                j++;
-            }
-    }
-}
 
 // offsets[t] = first sorted position whose tile id is >= t.  Four positions per thread, all loads
 // issued before any use.
@@ -207,17 +102,6 @@ __global__ __launch_bounds__(256) void isect_ids_kernel(const uint32_t* __restri
         isect_ids[i] = ((uint64_t)tiles[i] << 32) | (uint64_t)__float_as_uint(depths[flatten_ids[i]]);
 }
 
-// 32-bit depth keys for the single-camera case (culled rows: 0xffffffff, sorted last)
-__global__ __launch_bounds__(256) void depth_keys32_kernel(int64_t total, const int32_t* __restrict__ radii,
-                                                           const float* __restrict__ depths,
-                                                           uint32_t* __restrict__ keys, int32_t* __restrict__ ids) {
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const bool vis = radii[2 * idx] > 0 || radii[2 * idx + 1] > 0;
-        keys[idx] = vis ? __float_as_uint(depths[idx]) : 0xffffffffu;
-        ids[idx] = (int32_t)idx;
-    }
-}
 
 // ---- per-tile ordering: after the intersections have been bucketed by tile with a STABLE sort of
 // pairs emitted in row order (so every bucket is in ascending row order), ONE workgroup per tile sorts
@@ -253,7 +137,7 @@ __device__ __forceinline__ bool tile_range(const int32_t* __restrict__ offsets, 
     t_step = 1;
     bool mine = false;
     for (int t = t_first + threadIdx.x; t < t_last; t += blockDim.x) {
-        const int n = ((t + 1 < n_tiles) ? offsets[t + 1] : (int)n_isects) - offsets[t];
+        const int n = offsets[t + 1] - offsets[t];
         mine |= (n > lo && n <= hi);
     }
     return __syncthreads_or(mine) != 0;
@@ -410,7 +294,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
     if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step)) return;
     for (int t = t_first; t < t_last; t += t_step) {
         const int beg = offsets[t];
-        const int end = (t + 1 < n_tiles) ? offsets[t + 1] : (int)n_isects;
+        const int end = offsets[t + 1];            // offsets: n_tiles + 1 entries
         const int n = end - beg;
         if (n <= lo || n > hi) continue;               // uniform over the block (n >= 1 from here)
         uint32_t key[R], val[R];
@@ -479,7 +363,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __
     if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step)) return;
     for (int t = t_first; t < t_last; t += t_step) {
     const int beg = offsets[t];
-    const int end = (t + 1 < n_tiles) ? offsets[t + 1] : (int)n_isects;
+    const int end = offsets[t + 1];
     const int n = end - beg;
     if (n <= lo || n > hi) continue;                 // another size class (uniform over the block)
     constexpr int THREADS = 64 * WAVES;
@@ -697,90 +581,8 @@ __global__ __launch_bounds__(MISPLAT_COUNT_BLOCK) void tile_emit_blocks_kernel(i
     }
 }
 
-// ---- bucketing without a sort ("scatter" ordering): count the intersections of every tile with atomics,
-// scan the counts into offsets, then every intersection takes the next free slot of its tile's bucket
-// (atomic cursor).  The buckets come out in arbitrary order; misplat_tile_sort(unordered = 1) then
-// establishes the (depth, row) order inside each, so the result is deterministic all the same.
-__global__ __launch_bounds__(256) void tile_hist_kernel(int64_t total, int n_gauss, int tw, int th,
-                                                        const float* __restrict__ means2d,
-                                                        const int32_t* __restrict__ radii,
-                                                        int32_t* __restrict__ tiles_per_gauss,
-                                                        int32_t* __restrict__ tile_counts) {
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int rx = radii[2 * idx], ry = radii[2 * idx + 1];
-        int n = 0;
-        if (rx > 0 || ry > 0) {
-            int x0, x1, y0, y1;
-            tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rx, ry, tw, th, x0, x1, y0, y1);
-            n = (x1 - x0) * (y1 - y0);
-            int32_t* base = tile_counts + (int64_t)(idx / n_gauss) * (tw * th);
-            for (int ty = y0; ty < y1; ty++)
-                for (int tx = x0; tx < x1; tx++) atomicAdd(&base[ty * tw + tx], 1);
-        }
-        tiles_per_gauss[idx] = n;
-    }
-}
 
-// one workgroup: offsets = exclusive scan of the counts, total -> *n_isects; the counts are cleared so
-// the same buffer serves as the cursors of tile_scatter_kernel
-__global__ __launch_bounds__(1024) void tile_scan_kernel(int n_tiles, int32_t* __restrict__ counts,
-                                                         int32_t* __restrict__ offsets,
-                                                         int64_t* __restrict__ n_isects) {
-    __shared__ unsigned long long wsum[16];
-    const int per = (n_tiles + 1023) / 1024;
-    const int b = threadIdx.x * per, e = min(b + per, n_tiles);
-    unsigned long long tot = 0;
-    for (int i = b; i < e; i++) tot += (unsigned long long)counts[i];
-    // wave inclusive scan of 64-bit totals (shuffles: this kernel is launch-latency bound anyway)
-    unsigned long long incl = tot;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long up = __shfl_up(incl, off);
-        if (lane >= off) incl += up;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    unsigned long long carry = 0;
-    for (int w = 0; w < wave; w++) carry += wsum[w];
-    unsigned long long run = carry + incl - tot;
-    for (int i = b; i < e; i++) {
-        const int32_t c = counts[i];
-        offsets[i] = (int32_t)run;                 // meaningless beyond 2^31: the host checks *n_isects first
-        counts[i] = 0;
-        run += (unsigned long long)c;
-    }
-    if (threadIdx.x == 1023) *n_isects = (int64_t)(carry + incl);
-}
 
-// slot_base (deterministic backward): first emission slot of every row; the payload is then the emission
-// slot and isect_gid[slot] = row.  Otherwise the payload is the row itself.
-__global__ __launch_bounds__(256) void tile_scatter_kernel(int64_t total, int n_gauss, int tw, int th,
-                                                           const float* __restrict__ means2d,
-                                                           const int32_t* __restrict__ radii,
-                                                           const int32_t* __restrict__ offsets,
-                                                           int32_t* __restrict__ cursors,
-                                                           const int64_t* __restrict__ slot_base,
-                                                           int32_t* __restrict__ payload,
-                                                           int32_t* __restrict__ isect_gid) {
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int rx = radii[2 * idx], ry = radii[2 * idx + 1];
-        if (!(rx > 0 || ry > 0)) continue;
-        int x0, x1, y0, y1;
-        tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rx, ry, tw, th, x0, x1, y0, y1);
-        const int64_t tbase = (int64_t)(idx / n_gauss) * (tw * th);
-        int64_t j = slot_base ? slot_base[idx] : 0;
-        for (int ty = y0; ty < y1; ty++)
-            for (int tx = x0; tx < x1; tx++) {
-                const int64_t tile = tbase + ty * tw + tx;
-                const int pos = offsets[tile] + atomicAdd(&cursors[tile], 1);
-                if (slot_base) { payload[pos] = (int32_t)j; isect_gid[j] = (int32_t)idx; j++; }
-                else payload[pos] = (int32_t)idx;
-            }
-    }
-}
 
 inline int grid_for(int64_t n, int block) {
     int64_t b = (n + block - 1) / block;
@@ -792,60 +594,10 @@ inline int check_launch() { return hipGetLastError() == hipSuccess ? MISPLAT_OK 
 
 }  // namespace
 
-extern "C" int misplat_tile_count(const misplat_params* p, const float* means2d, const int32_t* radii,
-                                  int32_t* tiles_per_gauss, misplat_stream_t stream) {
-    if (!p || p->tile_size != MISPLAT_TILE) return MISPLAT_EINVAL;
-    int64_t total = (int64_t)p->n_gauss * p->n_cams;
-    if (total == 0) return MISPLAT_OK;
-    hipLaunchKernelGGL(tile_count_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
-                       p->tile_w, p->tile_h, means2d, radii, tiles_per_gauss);
-    return check_launch();
-}
 
-extern "C" int misplat_tile_emit(const misplat_params* p, const float* means2d, const int32_t* radii,
-                                 const float* depths, const int64_t* cum, uint64_t* keys,
-                                 int32_t* slot_ids, int32_t* isect_gid, misplat_stream_t stream) {
-    if (!p || p->tile_size != MISPLAT_TILE) return MISPLAT_EINVAL;
-    int64_t total = (int64_t)p->n_gauss * p->n_cams;
-    if (total == 0) return MISPLAT_OK;
-    hipLaunchKernelGGL(tile_emit_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
-                       p->n_gauss, p->tile_w, p->tile_h, means2d, radii, depths, cum, keys, slot_ids, isect_gid);
-    return check_launch();
-}
 
-extern "C" size_t misplat_sort_workspace_bytes(int64_t n_isects, int32_t end_bit) {
-    size_t bytes = 0;
-    if (n_isects <= 0) return 16;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                             (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n_isects, 0u,
-                                             (unsigned)end_bit, (hipStream_t) nullptr);
-    if (e != hipSuccess) return 0;
-    return bytes < 16 ? 16 : bytes;
-}
 
-extern "C" int misplat_sort_pairs(void* workspace, size_t workspace_bytes, const uint64_t* keys_in,
-                                  uint64_t* keys_out, const int32_t* vals_in, int32_t* vals_out,
-                                  int64_t n_isects, int32_t end_bit, misplat_stream_t stream) {
-    if (n_isects < 0 || end_bit < 1 || end_bit > 64) return MISPLAT_EINVAL;
-    if (n_isects == 0) return MISPLAT_OK;
-    size_t need = 0;
-    if (rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)n_isects, 0u,
-                                  (unsigned)end_bit, (hipStream_t)stream) != hipSuccess)
-        return MISPLAT_ELAUNCH;
-    if (need > workspace_bytes) return MISPLAT_EWORKSPACE;
-    hipError_t e = rocprim::radix_sort_pairs(workspace, workspace_bytes, keys_in, keys_out, vals_in, vals_out,
-                                             (size_t)n_isects, 0u, (unsigned)end_bit, (hipStream_t)stream);
-    return e == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
-}
 
-extern "C" int misplat_tile_offsets(const uint64_t* keys_sorted, const int32_t* slots_sorted,
-                                    const int32_t* isect_gid, int64_t n_isects, int32_t n_tiles_total,
-                                    int32_t* offsets, int32_t* flatten_ids, misplat_stream_t stream) {
-    if (n_isects < 0 || n_tiles_total < 1) return MISPLAT_EINVAL;
-    hipLaunchKernelGGL(tile_offsets_kernel, dim3(grid_for(n_isects + 1, 256)), dim3(256), 0, (hipStream_t)stream,
-                       keys_sorted, slots_sorted, isect_gid, n_isects, n_tiles_total, offsets, flatten_ids);
-    return check_launch();
-}
 
 extern "C" int misplat_pack(int64_t n_rows, int32_t color_dim, const float* means2d, const float* conics,
                             const float* opacities_eff, const float* ray_ts, const float* ray_planes,
@@ -859,27 +611,7 @@ extern "C" int misplat_pack(int64_t n_rows, int32_t color_dim, const float* mean
     return check_launch();
 }
 
-extern "C" int misplat_depth_keys(const misplat_params* p, const int32_t* radii, const float* depths,
-                                  uint64_t* keys, int32_t* ids, misplat_stream_t stream) {
-    if (!p || p->n_cams < 1) return MISPLAT_EINVAL;
-    int64_t total = (int64_t)p->n_gauss * p->n_cams;
-    if (total == 0) return MISPLAT_OK;
-    hipLaunchKernelGGL(depth_keys_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
-                       p->n_gauss, p->n_cams, radii, depths, keys, ids);
-    return check_launch();
-}
 
-extern "C" int misplat_tile_emit_ordered(const misplat_params* p, const int32_t* order, const float* means2d,
-                                         const int32_t* radii, const int64_t* cum_ordered, uint32_t* tile_ids,
-                                         int32_t* slot_ids, int32_t* isect_gid, misplat_stream_t stream) {
-    if (!p || p->tile_size != MISPLAT_TILE) return MISPLAT_EINVAL;
-    int64_t total = (int64_t)p->n_gauss * p->n_cams;
-    if (total == 0) return MISPLAT_OK;
-    hipLaunchKernelGGL(tile_emit_ordered_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
-                       p->n_gauss, p->tile_w, p->tile_h, order, means2d, radii, cum_ordered, tile_ids, slot_ids,
-                       isect_gid);
-    return check_launch();
-}
 
 extern "C" size_t misplat_sort32_workspace_bytes(int64_t n, int32_t end_bit) {
     size_t bytes = 0;
@@ -916,7 +648,7 @@ extern "C" int misplat_tile_offsets32(const uint32_t* tiles_sorted, int64_t n_is
 
 extern "C" int misplat_tile_offsets16(const uint16_t* tiles_sorted, int64_t n_isects, int32_t n_tiles_total,
                                       int32_t* offsets, misplat_stream_t stream) {
-    if (n_isects < 0 || n_tiles_total < 1 || n_tiles_total > 65536) return MISPLAT_EINVAL;
+    if (n_isects < 0 || n_tiles_total < 1 || n_tiles_total > 65537) return MISPLAT_EINVAL;
     hipLaunchKernelGGL(tile_offsets32_kernel<uint16_t>, dim3(grid_for((n_isects + 4) / 4, 256)), dim3(256), 0,
                        (hipStream_t)stream, tiles_sorted, n_isects, n_tiles_total, offsets);
     return check_launch();
@@ -958,15 +690,6 @@ extern "C" int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* fl
     return check_launch();
 }
 
-extern "C" int misplat_depth_keys32(const misplat_params* p, const int32_t* radii, const float* depths,
-                                    uint32_t* keys, int32_t* ids, misplat_stream_t stream) {
-    if (!p || p->n_cams != 1) return MISPLAT_EINVAL;
-    int64_t total = (int64_t)p->n_gauss;
-    if (total == 0) return MISPLAT_OK;
-    hipLaunchKernelGGL(depth_keys32_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
-                       radii, depths, keys, ids);
-    return check_launch();
-}
 
 // Sort every tile's bucket (ascending row order on entry) by the depth bits, stably.  payload: in/out
 // (rows, or emission slots when isect_gid != NULL); flatten_ids: out (rows in final order);
@@ -1012,35 +735,8 @@ extern "C" int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, 
                                                       flatten_ids, scratch, s);
 }
 
-extern "C" int misplat_tile_hist(const misplat_params* p, const float* means2d, const int32_t* radii,
-                                 int32_t* tiles_per_gauss, int32_t* tile_counts, misplat_stream_t stream) {
-    if (!p || p->tile_size != MISPLAT_TILE) return MISPLAT_EINVAL;
-    int64_t total = (int64_t)p->n_gauss * p->n_cams;
-    if (total == 0) return MISPLAT_OK;
-    hipLaunchKernelGGL(tile_hist_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
-                       p->n_gauss, p->tile_w, p->tile_h, means2d, radii, tiles_per_gauss, tile_counts);
-    return check_launch();
-}
 
-extern "C" int misplat_tile_scan(int32_t n_tiles_total, int32_t* tile_counts, int32_t* offsets, int64_t* n_isects,
-                                 misplat_stream_t stream) {
-    if (n_tiles_total < 1 || !tile_counts || !offsets || !n_isects) return MISPLAT_EINVAL;
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, n_tiles_total, tile_counts,
-                       offsets, n_isects);
-    return check_launch();
-}
 
-extern "C" int misplat_tile_scatter(const misplat_params* p, const float* means2d, const int32_t* radii,
-                                    const int32_t* offsets, int32_t* cursors, const int64_t* slot_base,
-                                    int32_t* payload, int32_t* isect_gid, misplat_stream_t stream) {
-    if (!p || p->tile_size != MISPLAT_TILE || (slot_base && !isect_gid)) return MISPLAT_EINVAL;
-    int64_t total = (int64_t)p->n_gauss * p->n_cams;
-    if (total == 0) return MISPLAT_OK;
-    hipLaunchKernelGGL(tile_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, total,
-                       p->n_gauss, p->tile_w, p->tile_h, means2d, radii, offsets, cursors, slot_base, payload,
-                       isect_gid);
-    return check_launch();
-}
 
 extern "C" int misplat_tile_count_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
                                          int32_t* tiles_per_gauss, int32_t* block_sums, int64_t* block_offs,

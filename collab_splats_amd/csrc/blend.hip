@@ -35,7 +35,7 @@ constexpr float kLn2 = 0.6931471805599453f;
 // independent waves per tile (more waves in flight, finer early termination and culling, at the
 // price of re-staging the tile's list per wave).
 struct BandCtx {
-    int tile, cam, band, tx, ty, y0, beg, end;
+    int tile, cam, band, tx, ty, y0, beg, end, unit;
     float fx, fy, cx, cy;
 };
 
@@ -51,8 +51,11 @@ __device__ __forceinline__ bool band_ctx(const misplat_params& P, const float* _
     const int total = total_tiles * WPT;
     const int per_xcd = (total + 7) >> 3;
     const int b = blockIdx.x;
-    const int unit = (b & 7) * per_xcd + (b >> 3);
+    int unit = (b & 7) * per_xcd + (b >> 3);
+    if (P.unit_perm) unit = P.unit_perm[b];      // caller-supplied launch order (longest first); the grid has exactly
+                                                 // 8 * ceil(total / 8) workgroups = entries of unit_perm (padding: total)
     if (unit >= total) return false;
+    c.unit = unit;
     c.tile = unit / WPT;
     c.band = unit - c.tile * WPT;
     c.cam = c.tile / tiles_per_cam;
@@ -60,9 +63,12 @@ __device__ __forceinline__ bool band_ctx(const misplat_params& P, const float* _
     c.ty = t / P.tile_w;
     c.tx = t - c.ty * P.tile_w;
     c.y0 = c.ty * MISPLAT_TILE + c.band * 4 * PPL;
-    if (c.y0 >= P.height) return false;
+    if (c.y0 >= P.height) {                      // band below the image: nothing to do (and it costs nothing)
+        if (P.unit_work && threadIdx.x == 0) P.unit_work[unit] = 0;
+        return false;
+    }
     c.beg = offsets[c.tile];
-    c.end = (c.tile + 1 < total_tiles) ? offsets[c.tile + 1] : (int)n_isects;
+    c.end = offsets[c.tile + 1];               // offsets has C*tiles + 1 entries (the last one = number of intersections)
     c.fx = Ks[9 * c.cam]; c.fy = Ks[9 * c.cam + 4]; c.cx = Ks[9 * c.cam + 2]; c.cy = Ks[9 * c.cam + 5];
     return true;
 }
@@ -187,6 +193,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
         }
     }
 
+    int work = 0;                               // staged Gaussians composited by this unit (its measured cost)
     for (int bs = c.beg; bs < c.end; bs += 64) {
         float tmax;
         if constexpr (PPL % 2 == 0) {
@@ -204,6 +211,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
                                          nullptr, xlo, xhi, ylo, yhi, amin, smx, featx);
         __syncthreads();
         if (n == 0) continue;
+        work += n;
         // LDS latency is hidden without a second register set: the half of the record consumed late (q2, q3 =
         // ray plane / normal / colour, and the index) is read at the top of its own iteration, the half consumed
         // early (q0, q1 = mean, conic, opacity) is read for the NEXT Gaussian as soon as this one's alpha is known.
@@ -305,6 +313,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
             if (__ballot(tm > 0.f) == 0ull) break;
         }
     }
+    if (P.unit_work && lane == 0) P.unit_work[c.unit] = work;
     if constexpr (PPL % 2 == 0) {
 #pragma unroll
         for (int kp = 0; kp < NP; kp++) {
@@ -907,6 +916,58 @@ __global__ __launch_bounds__(256) void depth_normal_bwd_kernel(DN d, const float
     }
 }
 
+// ---- launch order of the compositing kernels: longest units first, per XCD strip ---------------------------
+// A compositing launch is ~3 "rounds" of one-wave workgroups whose durations differ by 2x; dealt in tile order,
+// the last round runs at low occupancy (a 40 % / 10 % tail of the forward / backward).  Dealt longest-first the
+// tail disappears.  The cost of a unit is what the forward measured (unit_work = staged Gaussians composited);
+// workgroup b runs on XCD b & 7 (round-robin dispatch), so strip x = units [x * per, (x + 1) * per) keeps its XCD
+// (its Gaussian records stay in that L2) and is ordered by descending work inside: perm[rank * 8 + x] = unit.
+// Counting sort on 256 work classes -- an approximate order is all a greedy scheduler needs.
+__global__ __launch_bounds__(1024) void unit_order_kernel(int units, int per, const int32_t* __restrict__ work,
+                                                          int32_t* __restrict__ perm) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t wmax[16];
+    const int x = blockIdx.x;
+    const int lo = x * per, hi = min(lo + per, units);
+    int mx = 0;
+    for (int u = lo + threadIdx.x; u < hi; u += 1024) mx = max(mx, work[u]);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mx = max(mx, __shfl_xor(mx, m));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = (uint32_t)mx;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    uint32_t top = 1u;
+#pragma unroll
+    for (int w = 0; w < 16; w++) top = max(top, wmax[w]);
+    const float scale = 255.0f / (float)top;
+    for (int u = lo + threadIdx.x; u < hi; u += 1024) atomicAdd(&hist[255 - (int)((float)work[u] * scale)], 1u);
+    __syncthreads();
+    // exclusive scan of the 256 classes (class 0 = heaviest): waves 0..3, one class per lane
+    uint32_t v = 0u, incl = 0u;
+    if (threadIdx.x < 256) {
+        v = hist[threadIdx.x];
+        incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off);
+            if ((threadIdx.x & 63) >= off) incl += o;
+        }
+        if ((threadIdx.x & 63) == 63) wmax[threadIdx.x >> 6] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        uint32_t carry = 0u;
+        for (int w = 0; w < (threadIdx.x >> 6); w++) carry += wmax[w];
+        hist[threadIdx.x] = carry + incl - v;
+    }
+    __syncthreads();
+    for (int u = lo + threadIdx.x; u < hi; u += 1024) {
+        const uint32_t rank = atomicAdd(&hist[255 - (int)((float)work[u] * scale)], 1u);
+        perm[rank * 8 + x] = u;
+    }
+    for (int r = (hi > lo ? hi - lo : 0) + threadIdx.x; r < per; r += 1024) perm[r * 8 + x] = units;   // padding: no unit
+}
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH; }
 inline int grid_for(int64_t n, int block) {
     int64_t b = (n + block - 1) / block;
@@ -928,6 +989,16 @@ inline int pick_ppl(int requested, int dflt) { return (requested == 1 || request
 constexpr int kDefaultPplFwd = 2, kDefaultPplBwd = 2;
 
 extern "C" int misplat_blend_planes(const misplat_params* p) { return p ? 4 / pick_ppl(p->ppl_bwd, kDefaultPplBwd) : 0; }
+
+extern "C" int misplat_unit_order(const misplat_params* p, int32_t ppl, const int32_t* unit_work, int32_t* unit_perm,
+                                  misplat_stream_t stream) {
+    if (!params_ok(p) || !unit_work || !unit_perm) return MISPLAT_EINVAL;
+    const int q = pick_ppl(ppl, kDefaultPplFwd);
+    const int units = p->tile_w * p->tile_h * p->n_cams * (4 / q);
+    const int per = (units + 7) >> 3;
+    hipLaunchKernelGGL(unit_order_kernel, dim3(8), dim3(1024), 0, (hipStream_t)stream, units, per, unit_work, unit_perm);
+    return check_launch();
+}
 
 extern "C" int misplat_blend_fwd(const misplat_params* p, int32_t color_dim, const float* Ks,
                                  const float* grec, const int32_t* flatten_ids, const int32_t* offsets,

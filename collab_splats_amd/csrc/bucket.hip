@@ -1,0 +1,480 @@
+// bucket.hip -- cell-ordered bucketing of the (tile, Gaussian) intersections: the default ordering
+// ("cells") of the binning stage.  gfx950 only.  SURVEY.md section 8 row a2.3 (inside gsplat-rade's
+// rasterization(), called at /root/reference/collab_splats/models/rade_gs_model.py:439-465).
+//
+// What has to be produced: for every tile the list of Gaussian rows whose screen rectangle touches it
+// (then sorted by depth, misplat_tile_sort).  That is a counting sort of I ~ 6.4 M items into ~8 160 bins.
+// gsplat (and round 1 of this build) emits (tile, row) pairs and radix-sorts them: every pair crosses HBM
+// 5+ times.  Here every pair is written ONCE (4 bytes: the row) and no tile-id array exists at all:
+//
+//   1. bucket_count   per row: tile rectangle, count, and the coarse screen CELL (4x4 tiles or larger) of the
+//                     rectangle's centre; per-workgroup LDS histogram of the cells, one global atomic per
+//                     (workgroup, cell)
+//   2. bucket_rows    scan of the cell counts, then the visible rows are scattered into CELL ORDER
+//                     (order[]): rows that are neighbours in order[] are neighbours on screen
+//   3. bucket_tiles   a workgroup of 1024 consecutive rows of order[] touches a compact window of ~100 tiles:
+//                     it counts its intersections per tile in an LDS table and adds ONE global atomic per
+//                     (workgroup, tile) -> tile counts -> scan -> offsets; the same walk a second time
+//                     reserves a range per (workgroup, tile) with one returning atomic and fills
+//                     payload[offsets[tile] + ...] = row, ~50 consecutive entries at a time.
+//
+// Buckets fill in an arbitrary order, so misplat_tile_sort(unordered = 1) establishes the (depth, row)
+// order inside each: the final lists are bit-identical to the (tile, depth, id) order of a 64-bit key sort.
+// Every count lives on the DEVICE (counters[0] = number of intersections, counters[1] = visible rows):
+// nothing here needs a host read-back, so the whole forward can be enqueued speculatively (capacity
+// `cap_isects`, overflow checked by the host afterwards) and captured in a hipGraph.
+// HBM-bound integer work: no MFMA.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "misplat.h"
+
+namespace {
+
+constexpr int kCountThreads = 1024;     // few, large counting workgroups: one global atomic per (workgroup, cell)
+constexpr int kRowsPerWg = 1024;        // rows of order[] per workgroup of the tile passes (one per thread)
+constexpr int kWinMax = 2048;           // LDS window: at most this many tiles
+constexpr int kSmallRect = 16;          // rectangles up to 16 x 16 tiles take part in the window
+
+struct CellGrid {
+    int shift, cells_x, cells_y, n_cells, n_blocks, rows_per_block;
+};
+
+inline CellGrid make_grid(const misplat_params* p) {
+    CellGrid g;
+    g.shift = 2;                                               // 4 x 4 tiles = 64 x 64 pixels
+    for (;;) {
+        g.cells_x = (p->tile_w + (1 << g.shift) - 1) >> g.shift;
+        g.cells_y = (p->tile_h + (1 << g.shift) - 1) >> g.shift;
+        g.n_cells = g.cells_x * g.cells_y * p->n_cams;
+        if (g.n_cells <= MISPLAT_BUCKET_MAX_CELLS || g.shift >= 12) break;
+        g.shift++;
+    }
+    const int64_t total = (int64_t)p->n_gauss * p->n_cams;
+    int64_t nb = (total + 4095) / 4096;                        // >= 4096 rows per workgroup: few, long histograms
+    if (nb > MISPLAT_BUCKET_MAX_BLOCKS) nb = MISPLAT_BUCKET_MAX_BLOCKS;
+    if (nb < 1) nb = 1;
+    g.n_blocks = (int)nb;
+    int64_t rpb = (total + nb - 1) / nb;
+    rpb = (rpb + kCountThreads - 1) / kCountThreads * kCountThreads;
+    g.rows_per_block = (int)rpb;
+    return g;
+}
+
+__device__ __forceinline__ void tile_rect(float mx, float my, int rxi, int ryi, int tw, int th,
+                                          int& x0, int& x1, int& y0, int& y1) {
+    // the fixed fp32 expression sequence the CPU restatement of the tests uses too (bit-exact rectangles)
+    const float ts = (float)MISPLAT_TILE;
+    float rx = (float)rxi, ry = (float)ryi;
+    float fx0 = floorf((mx - rx) / ts), fx1 = ceilf((mx + rx) / ts);
+    float fy0 = floorf((my - ry) / ts), fy1 = ceilf((my + ry) / ts);
+    float ftw = (float)tw, fth = (float)th;
+    fx0 = fx0 > 0.f ? fx0 : 0.f; fx1 = fx1 > 0.f ? fx1 : 0.f;
+    fy0 = fy0 > 0.f ? fy0 : 0.f; fy1 = fy1 > 0.f ? fy1 : 0.f;
+    x0 = (int)(fx0 < ftw ? fx0 : ftw); x1 = (int)(fx1 < ftw ? fx1 : ftw);
+    y0 = (int)(fy0 < fth ? fy0 : fth); y1 = (int)(fy1 < fth ? fy1 : fth);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_take(uint32_t ident, uint32_t x) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {      // inclusive; lane 63 holds the total
+    x += dpp_take<0x111, 0xF>(0u, x);
+    x += dpp_take<0x112, 0xF>(0u, x);
+    x += dpp_take<0x114, 0xF>(0u, x);
+    x += dpp_take<0x118, 0xF>(0u, x);
+    x += dpp_take<0x142, 0xA>(0u, x);
+    x += dpp_take<0x143, 0xC>(0u, x);
+    return x;
+}
+
+__device__ __forceinline__ int cell_of(uint32_t xy, uint32_t wh, int cam, int shift, int cells_x, int cells_per_cam) {
+    const int cx = (int)(((xy & 0xffffu) + ((wh & 0xffffu) >> 1)) >> shift);
+    const int cy = (int)(((xy >> 16) + ((wh >> 16) >> 1)) >> shift);
+    return cam * cells_per_cam + cy * cells_x + cx;
+}
+
+// ---- 1. per row: rectangle + count; per workgroup: cell histogram (kept per workgroup in cellhist[b][c] and added
+// to the global cell counts with one atomic per non-empty cell) and the sum of the counts ------------------------
+__global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(
+    int64_t total, int n_gauss, int tw, int th, int shift, int cells_x, int cells_per_cam, int n_cells, int rows_per_block,
+    const float* __restrict__ means2d, const int32_t* __restrict__ radii, int32_t* __restrict__ tiles_per_gauss,
+    uint2* __restrict__ rect2, uint32_t* __restrict__ cellhist, uint32_t* __restrict__ cell_count,
+    unsigned long long* __restrict__ n_isects) {
+    __shared__ uint32_t hist[MISPLAT_BUCKET_MAX_CELLS];
+    __shared__ unsigned long long wsum[kCountThreads / 64];
+    for (int c = threadIdx.x; c < n_cells; c += kCountThreads) hist[c] = 0u;
+    __syncthreads();
+    const int64_t beg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t end = beg + rows_per_block < total ? beg + rows_per_block : total;
+    unsigned long long mine = 0ull;
+    for (int64_t idx = beg + threadIdx.x; idx < end; idx += kCountThreads) {
+        const int rx = radii[2 * idx], ry = radii[2 * idx + 1];
+        int n = 0;
+        uint2 r2 = make_uint2(0u, 0u);
+        if (rx > 0 || ry > 0) {
+            int x0, x1, y0, y1;
+            tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rx, ry, tw, th, x0, x1, y0, y1);
+            n = (x1 - x0) * (y1 - y0);
+            if (n > 0) {
+                r2 = make_uint2((uint32_t)x0 | ((uint32_t)y0 << 16), (uint32_t)(x1 - x0) | ((uint32_t)(y1 - y0) << 16));
+                atomicAdd(&hist[cell_of(r2.x, r2.y, (int)(idx / n_gauss), shift, cells_x, cells_per_cam)], 1u);
+            }
+        }
+        tiles_per_gauss[idx] = n;
+        rect2[idx] = r2;
+        mine += (unsigned long long)n;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0ull;
+#pragma unroll
+        for (int w = 0; w < kCountThreads / 64; w++) t += wsum[w];
+        if (t) atomicAdd(n_isects, t);
+    }
+    for (int c = threadIdx.x; c < n_cells; c += kCountThreads) {
+        const uint32_t h = hist[c];
+        cellhist[(size_t)blockIdx.x * n_cells + c] = h;
+        if (h) atomicAdd(&cell_count[c], h);
+    }
+}
+
+// ---- 2a. one workgroup: cell_offs = exclusive scan of the cell counts (the counts are cleared: they become the
+// cursors of 2b); counters[1] = visible rows; the tile counters are cleared for pass 3 ------------------------
+__global__ __launch_bounds__(1024) void bucket_cell_scan_kernel(int n_cells, uint32_t* __restrict__ cell_count,
+                                                                uint32_t* __restrict__ cell_offs,
+                                                                int64_t* __restrict__ counters,
+                                                                int32_t* __restrict__ tile_count, int n_tiles1) {
+    __shared__ uint32_t wsum[16];
+    for (int i = threadIdx.x; i < n_tiles1; i += 1024) tile_count[i] = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // thread t owns cells 2t, 2t+1 (n_cells <= 2048)
+    const int c0 = 2 * threadIdx.x, c1 = c0 + 1;
+    const uint32_t a = c0 < n_cells ? cell_count[c0] : 0u, b2 = c1 < n_cells ? cell_count[c1] : 0u;
+    if (c0 < n_cells) cell_count[c0] = 0u;
+    if (c1 < n_cells) cell_count[c1] = 0u;
+    const uint32_t incl = wave_scan_add(a + b2);
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t carry = 0u, all = 0u;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { carry += (w < wave) ? wsum[w] : 0u; all += wsum[w]; }
+    const uint32_t e = carry + incl - (a + b2);
+    if (c0 < n_cells) cell_offs[c0] = e;
+    if (c1 < n_cells) cell_offs[c1] = e + a;
+    if (threadIdx.x == 0) {
+        cell_offs[n_cells] = all;
+        counters[1] = (int64_t)all;
+    }
+}
+
+// ---- 2b. visible rows -> cell order (the slices of pass 1 again): every workgroup reserves its range of each cell
+// with one returning atomic, positions inside the range come from an LDS cursor ---------------------------------
+__global__ __launch_bounds__(kCountThreads) void bucket_rows_kernel(
+    int64_t total, int n_gauss, int shift, int cells_x, int cells_per_cam, int n_cells, int rows_per_block,
+    const int32_t* __restrict__ tiles_per_gauss, const uint2* __restrict__ rect2, const uint32_t* __restrict__ cellhist,
+    const uint32_t* __restrict__ cell_offs, uint32_t* __restrict__ cell_cursor, int32_t* __restrict__ order) {
+    __shared__ uint32_t base[MISPLAT_BUCKET_MAX_CELLS];
+    for (int c = threadIdx.x; c < n_cells; c += kCountThreads) {
+        const uint32_t h = cellhist[(size_t)blockIdx.x * n_cells + c];
+        base[c] = h ? cell_offs[c] + atomicAdd(&cell_cursor[c], h) : 0u;
+    }
+    __syncthreads();
+    const int64_t beg = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t end = beg + rows_per_block < total ? beg + rows_per_block : total;
+    for (int64_t idx = beg + threadIdx.x; idx < end; idx += kCountThreads) {
+        if (tiles_per_gauss[idx] > 0) {
+            const uint2 r2 = rect2[idx];
+            const int c = cell_of(r2.x, r2.y, (int)(idx / n_gauss), shift, cells_x, cells_per_cam);
+            order[atomicAdd(&base[c], 1u)] = (int32_t)idx;       // LDS cursor: any order inside a cell will do
+        }
+    }
+}
+
+// ---- 3. tile passes over order[] -----------------------------------------------------------------------------
+// Shared prologue of the count and the fill pass: load up to 1024 consecutive rows of order[], publish their
+// rectangles and the exclusive scan of their tile counts in LDS, and choose the workgroup's tile WINDOW: the
+// bounding box of the "small" rectangles (<= 16 x 16 tiles) of the first row's camera, if it has at most
+// kWinMax tiles.  Intersections inside the window are counted in LDS; the rest (large rectangles, a second
+// camera in the same workgroup, an oversized box) go to global atomics one by one.
+struct TileWg {
+    uint32_t excl[kRowsPerWg];      // exclusive scan of the tile counts
+    uint32_t xy[kRowsPerWg];        // x0 | y0 << 16
+    uint32_t wflag[kRowsPerWg];     // rectangle width | in_window << 31
+    float rw[kRowsPerWg];           // 1 / width
+    int32_t row[kRowsPerWg];
+    uint32_t tab[kWinMax];
+    uint32_t wsum[kRowsPerWg / 64];
+    int bb[4];                      // min x, min y, max x, max y of the small rectangles
+    uint32_t total;
+};
+
+__device__ __forceinline__ void tile_wg_prologue(TileWg& L, int64_t n_vis, int n_gauss, const int32_t* __restrict__ order,
+                                                 const uint2* __restrict__ rect2, int& cam0, int& wx0, int& wy0, int& ww,
+                                                 int& wh) {
+    const int64_t first = (int64_t)blockIdx.x * kRowsPerWg;
+    if (threadIdx.x == 0) { L.bb[0] = 0x7fffffff; L.bb[1] = 0x7fffffff; L.bb[2] = -1; L.bb[3] = -1; }
+    cam0 = (int)(order[first] / n_gauss);                       // first < n_vis is guaranteed by the caller
+    __syncthreads();
+    // element e = thread
+    const int e = threadIdx.x;
+    const int64_t pos = first + e;
+    uint32_t cnt = 0u, xy = 0u, wf = 1u;
+    int32_t r = 0;
+    int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1;
+    if (pos < n_vis) {
+        r = order[pos];
+        const uint2 r2 = rect2[r];
+        const int w = (int)(r2.y & 0xffffu), h = (int)(r2.y >> 16);
+        const int x0 = (int)(r2.x & 0xffffu), y0 = (int)(r2.x >> 16);
+        cnt = (uint32_t)(w * h);
+        xy = r2.x;
+        wf = (uint32_t)w;
+        if (w <= kSmallRect && h <= kSmallRect && (int)(r / n_gauss) == cam0) {
+            wf |= 0x80000000u;
+            mnx = x0; mny = y0; mxx = x0 + w - 1; mxy = y0 + h - 1;
+        }
+    }
+    L.xy[e] = xy; L.wflag[e] = wf; L.rw[e] = 1.0f / (float)(wf & 0xffffu); L.row[e] = r;
+    const uint32_t incl = wave_scan_add(cnt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 63) L.wsum[wave] = incl;
+    // wave-level min / max before the LDS atomics
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, m)); mny = min(mny, __shfl_xor(mny, m));
+        mxx = max(mxx, __shfl_xor(mxx, m)); mxy = max(mxy, __shfl_xor(mxy, m));
+    }
+    if (lane == 0 && mxx >= 0) {
+        atomicMin(&L.bb[0], mnx); atomicMin(&L.bb[1], mny); atomicMax(&L.bb[2], mxx); atomicMax(&L.bb[3], mxy);
+    }
+    __syncthreads();
+    uint32_t before = incl - cnt, all = 0u;
+#pragma unroll
+    for (int w = 0; w < kRowsPerWg / 64; w++) { before += (w < wave) ? L.wsum[w] : 0u; all += L.wsum[w]; }
+    L.excl[e] = before;
+    if (threadIdx.x == 0) L.total = all;
+    wx0 = L.bb[0]; wy0 = L.bb[1];
+    ww = L.bb[2] >= 0 ? L.bb[2] - L.bb[0] + 1 : 0;
+    wh = L.bb[2] >= 0 ? L.bb[3] - L.bb[1] + 1 : 0;
+    if ((int64_t)ww * wh > kWinMax) { ww = 0; wh = 0; }         // oversized box: everything goes the slow way
+    for (int i = threadIdx.x; i < ww * wh; i += kRowsPerWg) L.tab[i] = 0u;
+    __syncthreads();
+}
+
+// output o of the workgroup -> (element e, tile x, tile y, offset inside the row)
+__device__ __forceinline__ void tile_wg_decode(const TileWg& L, uint32_t o, int& e, int& tx, int& ty, uint32_t& q) {
+    int lo = 0, hi = kRowsPerWg - 1;                             // largest e with excl[e] <= o (empty rows never win)
+#pragma unroll
+    for (int it = 0; it < 10; it++) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (L.excl[mid] <= o) lo = mid; else hi = mid - 1;
+    }
+    e = lo;
+    q = o - L.excl[lo];
+    const uint32_t w = L.wflag[lo] & 0xffffu;
+    // (q + 0.5) / w is at least 0.5 / w away from an integer: the float quotient truncates exactly
+    const uint32_t ry = (uint32_t)(((float)q + 0.5f) * L.rw[lo]);
+    const uint32_t rx = q - ry * w;
+    const uint32_t pxy = L.xy[lo];
+    tx = (int)((pxy & 0xffffu) + rx);
+    ty = (int)((pxy >> 16) + ry);
+}
+
+__global__ __launch_bounds__(kRowsPerWg) void bucket_tile_count_kernel(
+    int n_gauss, int tw, int tiles_per_cam, const int64_t* __restrict__ counters, const int32_t* __restrict__ order,
+    const uint2* __restrict__ rect2, int32_t* __restrict__ tile_count) {
+    __shared__ TileWg L;
+    const int64_t n_vis = counters[1];
+    if ((int64_t)blockIdx.x * kRowsPerWg >= n_vis) return;
+    int cam0, wx0, wy0, ww, wh;
+    tile_wg_prologue(L, n_vis, n_gauss, order, rect2, cam0, wx0, wy0, ww, wh);
+    const uint32_t total = L.total;
+    for (uint32_t o = threadIdx.x; o < total; o += kRowsPerWg) {
+        int e, tx, ty;
+        uint32_t q;
+        tile_wg_decode(L, o, e, tx, ty, q);
+        if (ww > 0 && (L.wflag[e] >> 31)) atomicAdd(&L.tab[(ty - wy0) * ww + (tx - wx0)], 1u);
+        else atomicAdd(&tile_count[(L.row[e] / n_gauss) * tiles_per_cam + ty * tw + tx], 1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < ww * wh; i += kRowsPerWg) {
+        const uint32_t c = L.tab[i];
+        if (c) atomicAdd(&tile_count[cam0 * tiles_per_cam + (wy0 + i / ww) * tw + wx0 + i % ww], (int32_t)c);
+    }
+}
+
+// one workgroup: offsets[0 .. n_tiles] = exclusive scan of the counts (offsets[n_tiles] = total); the counts are
+// cleared so that the same buffer serves as the cursors of the fill pass.  Coalesced through LDS chunks.
+__global__ __launch_bounds__(1024) void bucket_tile_scan_kernel(int n_tiles, int32_t* __restrict__ tile_count,
+                                                                int32_t* __restrict__ offsets) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0u;
+    __syncthreads();
+    for (int base = 0; base < n_tiles; base += 4096) {
+        // thread t owns tiles base + 4t .. base + 4t + 3 (one 16-byte load)
+        const int i0 = base + 4 * threadIdx.x;
+        uint32_t c[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) c[j] = (i0 + j < n_tiles) ? (uint32_t)tile_count[i0 + j] : 0u;
+        const uint32_t s = c[0] + c[1] + c[2] + c[3];
+        const uint32_t incl = wave_scan_add(s);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry_s + incl - s, all = 0u;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { before += (w < wave) ? wsum[w] : 0u; all += wsum[w]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i0 + j < n_tiles) { offsets[i0 + j] = (int32_t)before; tile_count[i0 + j] = 0; }
+            before += c[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[n_tiles] = (int32_t)carry_s;
+}
+
+// fill: payload[offsets[tile] + k] = row (DET: the emission slot cum[row] + q, and isect_gid[slot] = row)
+template <bool DET>
+__global__ __launch_bounds__(kRowsPerWg) void bucket_tile_fill_kernel(
+    int n_gauss, int tw, int tiles_per_cam, const int64_t* __restrict__ counters, const int32_t* __restrict__ order,
+    const uint2* __restrict__ rect2, const int32_t* __restrict__ offsets, int32_t* __restrict__ cursors,
+    const int64_t* __restrict__ cum, int64_t cap, int32_t* __restrict__ payload, int32_t* __restrict__ isect_gid) {
+    __shared__ TileWg L;
+    __shared__ uint32_t tbase[kWinMax];
+    const int64_t n_vis = counters[1];
+    if ((int64_t)blockIdx.x * kRowsPerWg >= n_vis) return;
+    int cam0, wx0, wy0, ww, wh;
+    tile_wg_prologue(L, n_vis, n_gauss, order, rect2, cam0, wx0, wy0, ww, wh);
+    const uint32_t total = L.total;
+    if (ww > 0) {
+        for (uint32_t o = threadIdx.x; o < total; o += kRowsPerWg) {
+            int e, tx, ty;
+            uint32_t q;
+            tile_wg_decode(L, o, e, tx, ty, q);
+            if (L.wflag[e] >> 31) atomicAdd(&L.tab[(ty - wy0) * ww + (tx - wx0)], 1u);
+        }
+        __syncthreads();
+        // one returning atomic per (workgroup, tile): a contiguous range of the tile's bucket
+        for (int i = threadIdx.x; i < ww * wh; i += kRowsPerWg) {
+            const uint32_t c = L.tab[i];
+            const int gt = cam0 * tiles_per_cam + (wy0 + i / ww) * tw + wx0 + i % ww;
+            tbase[i] = c ? (uint32_t)offsets[gt] + (uint32_t)atomicAdd(&cursors[gt], (int32_t)c) : 0u;
+            L.tab[i] = 0u;
+        }
+        __syncthreads();
+    }
+    for (uint32_t o = threadIdx.x; o < total; o += kRowsPerWg) {
+        int e, tx, ty;
+        uint32_t q;
+        tile_wg_decode(L, o, e, tx, ty, q);
+        const int32_t r = L.row[e];
+        int64_t slot;
+        if (ww > 0 && (L.wflag[e] >> 31)) {
+            const int i = (ty - wy0) * ww + (tx - wx0);
+            slot = (int64_t)tbase[i] + (int64_t)atomicAdd(&L.tab[i], 1u);
+        } else {
+            const int gt = (r / n_gauss) * tiles_per_cam + ty * tw + tx;
+            slot = (int64_t)offsets[gt] + (int64_t)atomicAdd(&cursors[gt], 1);
+        }
+        if (slot < cap) {
+            if (DET) {
+                const int64_t es = cum[r] + (int64_t)q;             // emission slot: the rows of the gradient slab
+                payload[slot] = (int32_t)es;
+                if (es < cap) isect_gid[es] = r;
+            } else {
+                payload[slot] = r;
+            }
+        }
+    }
+}
+
+inline int check_launch() { return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH; }
+
+}  // namespace
+
+extern "C" int misplat_bucket_plan(const misplat_params* p, int32_t* n_cells, int32_t* n_blocks) {
+    if (!p || p->tile_size != MISPLAT_TILE || p->n_cams < 1 || !n_cells || !n_blocks) return MISPLAT_EINVAL;
+    if (p->tile_w > 0xffff || p->tile_h > 0xffff) return MISPLAT_EINVAL;
+    const CellGrid g = make_grid(p);
+    if (g.n_cells > MISPLAT_BUCKET_MAX_CELLS) return MISPLAT_EINVAL;
+    *n_cells = g.n_cells;
+    *n_blocks = g.n_blocks;
+    return MISPLAT_OK;
+}
+
+extern "C" int misplat_bucket_count(const misplat_params* p, const float* means2d, const int32_t* radii,
+                                    int32_t* tiles_per_gauss, uint32_t* rect2, uint32_t* cellhist,
+                                    uint32_t* cell_count, int64_t* counters, misplat_stream_t stream) {
+    int32_t nc, nb;
+    if (misplat_bucket_plan(p, &nc, &nb) != MISPLAT_OK || !cellhist || !cell_count || !counters) return MISPLAT_EINVAL;
+    const CellGrid g = make_grid(p);
+    const int64_t total = (int64_t)p->n_gauss * p->n_cams;
+    if (total > 0 && (!tiles_per_gauss || !rect2)) return MISPLAT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    // cell counts and the two counters start from zero (memset nodes on the stream: graph-capturable)
+    if (hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)g.n_cells, s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (hipMemsetAsync(counters, 0, 2 * sizeof(int64_t), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (total > 0)
+        hipLaunchKernelGGL(bucket_count_kernel, dim3(g.n_blocks), dim3(kCountThreads), 0, s, total, p->n_gauss, p->tile_w,
+                           p->tile_h, g.shift, g.cells_x, g.cells_x * g.cells_y, g.n_cells, g.rows_per_block, means2d, radii,
+                           tiles_per_gauss, (uint2*)rect2, cellhist, cell_count, (unsigned long long*)counters);
+    return check_launch();
+}
+
+extern "C" int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles_per_gauss, const uint32_t* rect2,
+                                   const uint32_t* cellhist, uint32_t* cell_count, uint32_t* cell_offs, int32_t* order,
+                                   int64_t* counters, int32_t* tile_count, misplat_stream_t stream) {
+    int32_t nc, nb;
+    if (misplat_bucket_plan(p, &nc, &nb) != MISPLAT_OK || !cell_count || !cell_offs || !counters || !tile_count)
+        return MISPLAT_EINVAL;
+    const CellGrid g = make_grid(p);
+    const int64_t total = (int64_t)p->n_gauss * p->n_cams;
+    if (total > 0 && !order) return MISPLAT_EINVAL;
+    const int64_t n_tiles = (int64_t)p->tile_w * p->tile_h * p->n_cams;
+    if (n_tiles + 1 > 0x7fffffffLL) return MISPLAT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bucket_cell_scan_kernel, dim3(1), dim3(1024), 0, s, g.n_cells, cell_count, cell_offs, counters,
+                       tile_count, (int)(n_tiles + 1));
+    if (total > 0)
+        hipLaunchKernelGGL(bucket_rows_kernel, dim3(g.n_blocks), dim3(kCountThreads), 0, s, total, p->n_gauss, g.shift,
+                           g.cells_x, g.cells_x * g.cells_y, g.n_cells, g.rows_per_block, tiles_per_gauss,
+                           (const uint2*)rect2, cellhist, cell_offs, cell_count, order);
+    return check_launch();
+}
+
+extern "C" int misplat_bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect2,
+                                    const int64_t* counters, int32_t* tile_count, int32_t* offsets, const int64_t* cum,
+                                    int64_t cap_isects, int32_t* payload, int32_t* isect_gid, misplat_stream_t stream) {
+    if (!p || p->tile_size != MISPLAT_TILE || !counters || !tile_count || !offsets || cap_isects < 0 ||
+        cap_isects > 0x7fffffffLL || (cum && !isect_gid && cap_isects > 0))
+        return MISPLAT_EINVAL;
+    const int64_t total = (int64_t)p->n_gauss * p->n_cams;
+    if (total > 0 && (!order || !rect2)) return MISPLAT_EINVAL;
+    const int64_t n_tiles = (int64_t)p->tile_w * p->tile_h * p->n_cams;
+    const int tiles_per_cam = p->tile_w * p->tile_h;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((total + kRowsPerWg - 1) / kRowsPerWg);     // upper bound: workgroups past n_vis leave
+    if (grid > 0)
+        hipLaunchKernelGGL(bucket_tile_count_kernel, dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
+                           tiles_per_cam, counters, order, (const uint2*)rect2, tile_count);
+    hipLaunchKernelGGL(bucket_tile_scan_kernel, dim3(1), dim3(1024), 0, s, (int)n_tiles, tile_count, offsets);
+    if (grid > 0 && cap_isects > 0 && payload) {
+        if (cum)
+            hipLaunchKernelGGL(bucket_tile_fill_kernel<true>, dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
+                               tiles_per_cam, counters, order, (const uint2*)rect2, offsets, tile_count, cum, cap_isects,
+                               payload, isect_gid);
+        else
+            hipLaunchKernelGGL(bucket_tile_fill_kernel<false>, dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
+                               tiles_per_cam, counters, order, (const uint2*)rect2, offsets, tile_count, cum, cap_isects,
+                               payload, isect_gid);
+    }
+    return check_launch();
+}

@@ -31,6 +31,60 @@ def set_deterministic(flag: bool) -> None:
     global DETERMINISTIC_BACKWARD
     DETERMINISTIC_BACKWARD = bool(flag)
 
+# Launch order of the compositing kernels (speed only; results never depend on it -- DESIGN.md section 6).  The
+# forward records what every (tile, band) unit cost; misplat_unit_order turns that into a longest-first order per XCD
+# strip, which the BACKWARD of the same step uses (always valid: same lists, same early termination) and which is
+# remembered per image shape for the NEXT FORWARD (pays when consecutive calls look at similar views -- evaluation
+# sweeps, repeated benchmark steps; harmless otherwise: a stale order is just another arbitrary order).
+UNIT_ORDER = os.environ.get("MISPLAT_UNIT_ORDER", "1") == "1"
+UNIT_ORDER_FWD = os.environ.get("MISPLAT_UNIT_ORDER_FWD", "1") == "1"
+_LAST_ORDER: Dict[tuple, Tensor] = {}
+
+
+def _eff_ppl(v: int) -> int:
+    return v if v in (1, 2, 4) else 2
+
+
+class _UnitSchedule:
+    """Per-call launch-order state of one compositing forward/backward pair."""
+
+    def __init__(self, P: Params, dev: torch.device):
+        self.on = UNIT_ORDER
+        self.perm_bwd = None
+        if not self.on:
+            return
+        self.ppl_f, self.ppl_b = _eff_ppl(P.ppl_fwd), _eff_ppl(P.ppl_bwd)
+        self.units = P.tile_w * P.tile_h * P.n_cams * (4 // self.ppl_f)
+        self.key = (dev.index, P.n_cams, P.tile_w, P.tile_h, self.ppl_f)
+        self.work, self.perm = _carve(dev, (self.units, 8 * ((self.units + 7) // 8)))
+
+    def before_forward(self, P: Params) -> None:
+        if not self.on:
+            return
+        last = _LAST_ORDER.get(self.key) if UNIT_ORDER_FWD else None
+        P.unit_perm = last.data_ptr() if last is not None else None
+        P.unit_work = self.work.data_ptr()
+        self._keep = last                                      # stays alive until the launch has been enqueued
+
+    def after_forward(self, P: Params) -> None:
+        P.unit_perm, P.unit_work = None, None
+        if not self.on:
+            return
+        check(_lib.load().misplat_unit_order(C.byref(P), C.c_int32(self.ppl_f), ptr(self.work), ptr(self.perm),
+                                             stream_ptr()), "misplat_unit_order")
+        _LAST_ORDER[self.key] = self.perm
+        if self.ppl_b == self.ppl_f:
+            self.perm_bwd = self.perm
+
+    def before_backward(self, P: Params) -> None:
+        P.unit_perm = self.perm_bwd.data_ptr() if self.perm_bwd is not None else None
+        P.unit_work = None
+
+    @staticmethod
+    def done(P: Params) -> None:
+        P.unit_perm, P.unit_work = None, None
+
+
 # Optional per-kernel timing (bench.py): name -> list of (start_event, end_event) recorded on the
 # current stream, i.e. the stream the kernels are launched on.  None = off (no events recorded).
 KERNEL_EVENTS: Optional[Dict[str, list]] = None
@@ -175,15 +229,33 @@ def spherical_harmonics_raw(degree: int, dirs: Tensor, coeffs: Tensor, radii: Op
 
 # ----------------------------------------------------------------------------- binning
 
-# Ordering backend: "rocprim" = rocPRIM's radix_sort_pairs (default: 0.28 ms for both sorts at
-# 1 M / 1080p), "misplat" = the hand-written, spin-free radix sort of csrc/sort.hip (bit-identical
-# results, tests/test_parity_gpu.py; measured 0.43 ms, i.e. +0.15 ms per step -- launch/latency bound
-# at these sizes; kept as the library-free path and as the base for a onesweep-style version).
+# Ordering scheme; both give exactly the (tile, depth, Gaussian id) order of a one-shot 64-bit key sort:
+#   "cells"   = (default, hand-written, csrc/bucket.hip) rows are put into coarse screen-cell order, a workgroup of
+#               1024 neighbouring rows counts / fills its intersections per tile through an LDS window with one
+#               global atomic per (workgroup, tile): every intersection is written once (its row, 4 bytes) and no
+#               tile-id array exists; one workgroup per tile then sorts its bucket by (depth, row).  All sizes live
+#               on the device.
+#   "pertile" = (round-1 path, kept as a tested alternative) emit (tile, row) pairs in row order, stable radix sort
+#               on the tile bits (SORT_BACKEND "rocprim" = rocPRIM's radix_sort_pairs, "misplat" = the hand-written
+#               spin-free radix sort of csrc/sort.hip), per-tile offsets, per-tile depth sort.
+ORDERING = os.environ.get("MISPLAT_ORDERING", "cells")
 SORT_BACKEND = os.environ.get("MISPLAT_SORT", "rocprim")
-SORT_BITS_DEPTH = int(os.environ.get("MISPLAT_SORT_BITS_DEPTH", "8"))
-SORT_BITS_TILE = int(os.environ.get("MISPLAT_SORT_BITS_TILE", "5"))
+SORT_BITS_TILE = int(os.environ.get("MISPLAT_SORT_BITS_TILE", "7"))
 
 _WS_CACHE: Dict[tuple, int] = {}
+_PLAN_CACHE: Dict[tuple, Tuple[int, int]] = {}
+COUNT_BLOCK = 256                                     # MISPLAT_COUNT_BLOCK (include/misplat.h)
+
+
+def _carve(dev: torch.device, sizes) -> list:
+    """One int32 allocation cut into views of the given element counts (each 256-byte aligned): a single trip
+    through the caching allocator instead of one per scratch array."""
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (int(n) + 63) // 64 * 64
+    buf = torch.empty(max(tot, 64), device=dev, dtype=torch.int32)
+    return [buf[o:o + int(n)] for o, n in zip(offs, sizes)]
 
 
 def _sort32(lib, keys_in, keys_out, vals_in, vals_out, n: int, end_bit: int, bits_per_pass: int) -> None:
@@ -211,8 +283,7 @@ def _sort_ws_bytes(lib, kind: str, n: int, end_bit: int) -> int:
     """rocPRIM temp-storage size; depends only on (n, end_bit), so cache it (host-side query)."""
     key = (kind, n, end_bit)
     if key not in _WS_CACHE:
-        fn = {"u64": lib.misplat_sort_workspace_bytes, "u32": lib.misplat_sort32_workspace_bytes,
-              "u16": lib.misplat_sort16_workspace_bytes}[kind]
+        fn = {"u32": lib.misplat_sort32_workspace_bytes, "u16": lib.misplat_sort16_workspace_bytes}[kind]
         b = int(fn(C.c_int64(n), C.c_int32(end_bit)))
         if b == 0:
             raise _lib.MisplatError("sort workspace query failed")
@@ -220,80 +291,58 @@ def _sort_ws_bytes(lib, kind: str, n: int, end_bit: int) -> int:
     return _WS_CACHE[key]
 
 
-# Ordering scheme, all giving exactly the (tile, depth, Gaussian id) order of a one-shot 64-bit key sort:
-#   "pertile"  = emit in row order, stable radix sort on the tile bits, then one workgroup per tile sorts its
-#                bucket by depth (register-resident LDS radix) -- the default;
-#   "twostage" = depth-sort the rows, emit in that order, stable sort on the tile bits;
-#   "scatter"  = count per tile (atomics) -> scan -> every intersection takes the next slot of its tile's
-#                bucket (atomic cursor) -> per-tile sort by (depth, row); no global sort at all, but 2 x 6.4 M
-#                scattered 4-byte atomics run at the memory-side atomic rate (~25 G/s): 0.60 ms against
-#                0.19 ms for emit + tile-bit sort at 1M / 1080p.  Kept as a tested alternative.
-ORDERING = os.environ.get("MISPLAT_ORDERING", "pertile")
+def bucket_plan(P: Params) -> Tuple[int, int]:
+    """(n_cells, n_blocks) of the cell-ordered bucketing for this configuration (host-side query, cached)."""
+    key = (P.n_gauss, P.n_cams, P.tile_w, P.tile_h)
+    if key not in _PLAN_CACHE:
+        nc, nb = C.c_int32(0), C.c_int32(0)
+        check(_lib.load().misplat_bucket_plan(C.byref(P), C.byref(nc), C.byref(nb)), "misplat_bucket_plan")
+        _PLAN_CACHE[key] = (int(nc.value), int(nb.value))
+    return _PLAN_CACHE[key]
 
 
-def _bin_tiles_scatter(lib, P: Params, means2d: Tensor, radii: Tensor, depths: Tensor) -> Dict[str, Tensor]:
-    dev = means2d.device
-    total = P.n_gauss * P.n_cams
-    n_tiles = P.tile_w * P.tile_h * P.n_cams
-    deterministic = DETERMINISTIC_BACKWARD
-    i32 = dict(device=dev, dtype=torch.int32)
-    tiles_per_gauss = torch.empty(total, **i32)
-    counts = torch.zeros(n_tiles, **i32)                          # tile counts, then the scatter cursors
-    offsets = torch.empty(n_tiles, **i32)
-    n_dev = torch.zeros(1, device=dev, dtype=torch.int64)
-    check(lib.misplat_tile_hist(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(counts),
-                                stream_ptr()), "misplat_tile_hist")
-    check(lib.misplat_tile_scan(C.c_int32(n_tiles), ptr(counts), ptr(offsets), ptr(n_dev), stream_ptr()),
-          "misplat_tile_scan")
-    n_isects = int(n_dev.item()) if total > 0 else 0              # the one unavoidable sync
-    if n_isects >= 2 ** 31:
-        raise _lib.MisplatError(f"{n_isects} tile intersections exceed int32 indexing")
-    cum = None
-    if deterministic:                                             # emission slots index the gradient slab
-        incl = torch.cumsum(tiles_per_gauss, dim=0, dtype=torch.int64)
-        cum = (incl - tiles_per_gauss).contiguous()
-    payload = torch.empty(n_isects, **i32)
-    flatten_ids = torch.empty(n_isects, **i32)
-    isect_gid = torch.empty(n_isects, **i32) if deterministic else None
-    if n_isects > 0:
-        check(lib.misplat_tile_scatter(C.byref(P), ptr(means2d), ptr(radii), ptr(offsets), ptr(counts), ptr(cum),
-                                       ptr(payload), ptr(isect_gid), stream_ptr()), "misplat_tile_scatter")
-        scratch = torch.empty(4 * n_isects, **i32)               # only touched by tiles longer than 8192 entries
-        check(lib.misplat_tile_sort(ptr(offsets), C.c_int32(n_tiles), C.c_int64(n_isects), ptr(depths.contiguous()),
-                                    ptr(isect_gid), ptr(payload), ptr(flatten_ids), ptr(scratch), C.c_int32(1),
-                                    stream_ptr()), "misplat_tile_sort")
-    return dict(tiles_per_gauss=tiles_per_gauss, tile_ids=None, slots=payload if deterministic else None,
-                flatten_ids=flatten_ids, isect_offsets=offsets, n_isects=n_isects, order=None, cum_ordered=cum,
-                depths=depths, n_tiles=n_tiles)
-
-
-COUNT_BLOCK = 256                                     # MISPLAT_COUNT_BLOCK (include/misplat.h)
-
-
-@torch.no_grad()
-def start_binning(P: Params, means2d: Tensor, radii: Tensor) -> Optional[Dict[str, Tensor]]:
-    """First half of ``bin_tiles`` for the "pertile" ordering: tile counts, block scan, and an ASYNCHRONOUS
-    read-back of n_isects (pinned buffer + event).  Called right after the projection kernel, before the colour
-    kernel is launched, so that the host's wait for n_isects -- the one unavoidable sync of the step -- and the
-    launches that follow it are hidden behind the colour kernel instead of idling the GPU."""
-    if ORDERING != "pertile":
-        return None
-    lib = _lib.load()
-    dev = means2d.device
-    total = P.n_gauss * P.n_cams
-    n_blocks = (total + COUNT_BLOCK - 1) // COUNT_BLOCK
-    i32 = dict(device=dev, dtype=torch.int32)
-    tiles_per_gauss = torch.empty(total, **i32)
-    block_sums = torch.empty(max(n_blocks, 1), **i32)
-    block_offs = torch.empty(max(n_blocks, 1), device=dev, dtype=torch.int64)
-    n_dev = torch.empty(1, device=dev, dtype=torch.int64)
-    check(lib.misplat_tile_count_blocks(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(block_sums),
-                                        ptr(block_offs), ptr(n_dev), stream_ptr()), "misplat_tile_count_blocks")
+def _read_back(n_dev: Tensor) -> Dict:
+    """Asynchronous read-back of a device int64 (pinned buffer + event)."""
     host = torch.empty(1, dtype=torch.int64, pin_memory=True)
     host.copy_(n_dev, non_blocking=True)
     event = torch.cuda.Event()
     event.record()
-    return dict(tiles_per_gauss=tiles_per_gauss, block_offs=block_offs, host=host, event=event, n_dev=n_dev)
+    return dict(host=host, event=event)
+
+
+@torch.no_grad()
+def start_binning(P: Params, means2d: Tensor, radii: Tensor) -> Dict[str, Tensor]:
+    """First half of ``bin_tiles``: everything that does not need the number of intersections on the host (tile
+    counts; "cells": also the cell ordering of the rows), and an ASYNCHRONOUS read-back of that number.  Called right
+    after the projection kernel, before the colour kernel is launched, so that the host's wait for n_isects -- the one
+    sync of the step -- and the launches that follow it are hidden behind the colour kernel instead of idling the GPU."""
+    lib = _lib.load()
+    dev = means2d.device
+    total = P.n_gauss * P.n_cams
+    n_tiles = P.tile_w * P.tile_h * P.n_cams
+    if ORDERING == "cells":
+        n_cells, n_blocks = bucket_plan(P)
+        tiles_per_gauss, rect2, cellhist, cell_count, cell_offs, order, counters, tile_count = _carve(
+            dev, (total, 2 * total, n_blocks * n_cells, n_cells, n_cells + 1, total, 4, n_tiles + 1))
+        counters = counters.view(torch.int64)
+        check(lib.misplat_bucket_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(rect2),
+                                       ptr(cellhist), ptr(cell_count), ptr(counters), stream_ptr()), "misplat_bucket_count")
+        pend = _read_back(counters[0:1])
+        check(lib.misplat_bucket_rows(C.byref(P), ptr(tiles_per_gauss), ptr(rect2), ptr(cellhist), ptr(cell_count),
+                                      ptr(cell_offs), ptr(order), ptr(counters), ptr(tile_count), stream_ptr()),
+              "misplat_bucket_rows")
+        pend.update(tiles_per_gauss=tiles_per_gauss, rect2=rect2, order=order, counters=counters, tile_count=tile_count)
+        return pend
+    if ORDERING != "pertile":
+        raise ValueError(f"unknown MISPLAT_ORDERING {ORDERING!r}")
+    n_blocks = (total + COUNT_BLOCK - 1) // COUNT_BLOCK
+    tiles_per_gauss, block_sums, block_offs, n_dev = _carve(dev, (total, max(n_blocks, 1), 2 * max(n_blocks, 1), 2))
+    block_offs, n_dev = block_offs.view(torch.int64), n_dev.view(torch.int64)
+    check(lib.misplat_tile_count_blocks(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(block_sums),
+                                        ptr(block_offs), ptr(n_dev), stream_ptr()), "misplat_tile_count_blocks")
+    pend = _read_back(n_dev)
+    pend.update(tiles_per_gauss=tiles_per_gauss, block_offs=block_offs)
+    return pend
 
 
 @torch.no_grad()
@@ -301,70 +350,54 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor,
               pending: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
     """Tile intersection + ordering + offsets.  One host read-back: n_isects.
 
-    In the default (atomic) backward mode the sort payload is the Gaussian row itself; the deterministic mode
-    carries the emission slot instead (the gradient slab is indexed by it)."""
+    Result: ``flatten_ids[n_isects]`` (Gaussian rows in (tile, depth, id) order), ``isect_offsets[n_tiles + 1]`` (the
+    last entry is n_isects), ``tiles_per_gauss``; in deterministic mode also ``slots`` (the emission slot of every
+    sorted intersection: the row of the gradient slab)."""
     lib = _lib.load()
-    if ORDERING == "scatter":
-        return _bin_tiles_scatter(lib, P, means2d, radii, depths)
-    if ORDERING not in ("pertile", "twostage"):
-        raise ValueError(f"unknown MISPLAT_ORDERING {ORDERING!r}")
     dev = means2d.device
     total = P.n_gauss * P.n_cams
     n_tiles = P.tile_w * P.tile_h * P.n_cams
     deterministic = DETERMINISTIC_BACKWARD
-    pertile = ORDERING == "pertile"
-    i32 = dict(device=dev, dtype=torch.int32)
-    order = cum_ordered = block_offs = None
-    if pertile:
-        pend = pending if pending is not None else start_binning(P, means2d, radii)
-        tiles_per_gauss, block_offs = pend["tiles_per_gauss"], pend["block_offs"]
-        pend["event"].synchronize()                               # the one unavoidable sync (usually long past)
-        n_isects = int(pend["host"][0])
-    else:
-        tiles_per_gauss = torch.empty(total, **i32)
-        check(lib.misplat_tile_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), stream_ptr()),
-              "misplat_tile_count")
-        # rows in (camera, depth) order
-        ids, order = torch.empty(total, **i32), torch.empty(total, **i32)
-        if total > 0 and P.n_cams == 1:
-            dkeys = torch.empty(total, **i32)
-            dkeys_s = torch.empty_like(dkeys)
-            check(lib.misplat_depth_keys32(C.byref(P), ptr(radii), ptr(depths), ptr(dkeys), ptr(ids), stream_ptr()),
-                  "misplat_depth_keys32")
-            _sort32(lib, dkeys, dkeys_s, ids, order, total, 32, SORT_BITS_DEPTH)
-        elif total > 0:
-            dkeys = torch.empty(total, device=dev, dtype=torch.int64)
-            dkeys_s = torch.empty_like(dkeys)
-            check(lib.misplat_depth_keys(C.byref(P), ptr(radii), ptr(depths), ptr(dkeys), ptr(ids), stream_ptr()),
-                  "misplat_depth_keys")
-            end_bit = 32 + max(1, P.n_cams.bit_length())
-            ws_bytes = _sort_ws_bytes(lib, "u64", total, end_bit)
-            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-            check(lib.misplat_sort_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(dkeys), ptr(dkeys_s), ptr(ids), ptr(order),
-                                         C.c_int64(total), C.c_int32(end_bit), stream_ptr()), "misplat_sort_pairs")
-        tpg_ordered = tiles_per_gauss[order.long()]
-        incl = torch.cumsum(tpg_ordered, dim=0, dtype=torch.int64)
-        n_isects = int(incl[-1].item()) if total > 0 else 0      # the one unavoidable sync
-        cum_ordered = (incl - tpg_ordered).contiguous()           # exclusive scan in emission order, int64
+    pend = pending if pending is not None else start_binning(P, means2d, radii)
+    tiles_per_gauss = pend["tiles_per_gauss"]
+    pend["event"].synchronize()                                   # the one sync of the step (usually long past)
+    n_isects = int(pend["host"][0])
     if n_isects >= 2 ** 31:
         raise _lib.MisplatError(f"{n_isects} tile intersections exceed int32 indexing")
-    # emit in that order, bucket by tile (stable radix on the tile bits)
-    key16 = pertile and SORT_BACKEND == "rocprim" and n_tiles <= 65536     # 12 instead of 16 B per pair and pass
+    depths = depths.contiguous()
+    out = dict(tiles_per_gauss=tiles_per_gauss, n_isects=n_isects, depths=depths, tile_ids=None, n_tiles=n_tiles)
+    if ORDERING == "cells":
+        offsets, payload, flatten_ids, scratch, isect_gid = _carve(
+            dev, (n_tiles + 1, n_isects, n_isects, 4 * n_isects, n_isects if deterministic else 0))
+        cum = None
+        if deterministic:                                         # emission slots index the gradient slab
+            cum = (torch.cumsum(tiles_per_gauss, dim=0, dtype=torch.int64) - tiles_per_gauss).contiguous()
+            out["cum"] = cum
+        else:
+            isect_gid = None
+        check(lib.misplat_bucket_tiles(C.byref(P), ptr(pend["order"]), ptr(pend["rect2"]), ptr(pend["counters"]),
+                                       ptr(pend["tile_count"]), ptr(offsets), ptr(cum), C.c_int64(n_isects), ptr(payload),
+                                       ptr(isect_gid), stream_ptr()), "misplat_bucket_tiles")
+        if n_isects > 0:
+            check(lib.misplat_tile_sort(ptr(offsets), C.c_int32(n_tiles), C.c_int64(n_isects), ptr(depths), ptr(isect_gid),
+                                        ptr(payload), ptr(flatten_ids), ptr(scratch), C.c_int32(1), stream_ptr()),
+                  "misplat_tile_sort")
+        out.update(slots=payload if deterministic else None, flatten_ids=flatten_ids, isect_offsets=offsets)
+        return out
+    # ---- "pertile": (tile, row) pairs in row order -> stable radix sort on the tile bits -> offsets -> per-tile sort
+    key16 = SORT_BACKEND == "rocprim" and n_tiles < 65536         # 12 instead of 16 B per pair and pass
+    i32 = dict(device=dev, dtype=torch.int32)
     tile_ids = torch.empty(n_isects, device=dev, dtype=torch.int16 if key16 else torch.int32)
-    isect_gid = torch.empty(n_isects, **i32)
-    slots = torch.empty(n_isects, **i32) if deterministic else None
-    tile_ids_s, payload_s = torch.empty_like(tile_ids), torch.empty(n_isects, **i32)
-    offsets = torch.empty(n_tiles, **i32)
+    tile_ids_s = torch.empty_like(tile_ids)
+    isect_gid, payload_s, flatten_ids, scratch, offsets, slots = _carve(
+        dev, (n_isects, n_isects, n_isects, 4 * n_isects, n_tiles + 1, n_isects if deterministic else 0))
+    if not deterministic:
+        slots = None
     tile_bits = max(1, (n_tiles - 1).bit_length())
     if n_isects > 0:
-        if pertile:
-            check(lib.misplat_tile_emit_blocks(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss),
-                                               ptr(block_offs), ptr(tile_ids), C.c_int32(2 if key16 else 4), ptr(slots),
-                                               ptr(isect_gid), stream_ptr()), "misplat_tile_emit_blocks")
-        else:
-            check(lib.misplat_tile_emit_ordered(C.byref(P), ptr(order), ptr(means2d), ptr(radii), ptr(cum_ordered),
-                                                ptr(tile_ids), ptr(slots), ptr(isect_gid), stream_ptr()),
-                  "misplat_tile_emit_ordered")
+        check(lib.misplat_tile_emit_blocks(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss),
+                                           ptr(pend["block_offs"]), ptr(tile_ids), C.c_int32(2 if key16 else 4), ptr(slots),
+                                           ptr(isect_gid), stream_ptr()), "misplat_tile_emit_blocks")
         if key16:
             ws_bytes = _sort_ws_bytes(lib, "u16", n_isects, tile_bits)
             ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
@@ -375,28 +408,18 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor,
         else:
             _sort32(lib, tile_ids, tile_ids_s, slots if deterministic else isect_gid, payload_s, n_isects, tile_bits,
                     SORT_BITS_TILE)
-    if key16:
-        check(lib.misplat_tile_offsets16(ptr(tile_ids_s), C.c_int64(n_isects), C.c_int32(n_tiles), ptr(offsets),
-                                         stream_ptr()), "misplat_tile_offsets16")
-        tile_ids_s = None                              # isect_ids() rebuilds the 32-bit tile ids from the offsets
-    else:
-        check(lib.misplat_tile_offsets32(ptr(tile_ids_s), C.c_int64(n_isects), C.c_int32(n_tiles), ptr(offsets),
-                                         stream_ptr()), "misplat_tile_offsets32")
-    if pertile and n_isects > 0:
+    # n_tiles + 1 "tiles": the extra entry receives n_isects
+    fn = lib.misplat_tile_offsets16 if key16 else lib.misplat_tile_offsets32
+    check(fn(ptr(tile_ids_s), C.c_int64(n_isects), C.c_int32(n_tiles + 1), ptr(offsets), stream_ptr()),
+          "misplat_tile_offsets")
+    if n_isects > 0:
         # every tile's bucket -> (depth, row) order, one workgroup per tile, in LDS
-        flatten_ids = torch.empty(n_isects, **i32)
-        scratch = torch.empty(4 * n_isects, **i32)               # only touched by tiles longer than 8192 entries
-        check(lib.misplat_tile_sort(ptr(offsets), C.c_int32(n_tiles), C.c_int64(n_isects), ptr(depths.contiguous()),
+        check(lib.misplat_tile_sort(ptr(offsets), C.c_int32(n_tiles), C.c_int64(n_isects), ptr(depths),
                                     ptr(isect_gid if deterministic else None), ptr(payload_s), ptr(flatten_ids),
                                     ptr(scratch), C.c_int32(0), stream_ptr()), "misplat_tile_sort")
-        slots_s = payload_s if deterministic else None
-    elif deterministic:
-        slots_s = payload_s
-        flatten_ids = isect_gid[slots_s.long()] if n_isects > 0 else payload_s
-    else:
-        slots_s, flatten_ids = None, payload_s
-    return dict(tiles_per_gauss=tiles_per_gauss, tile_ids=tile_ids_s, slots=slots_s, flatten_ids=flatten_ids,
-                isect_offsets=offsets, n_isects=n_isects, order=order, cum_ordered=cum_ordered, depths=depths)
+    out.update(slots=payload_s if deterministic else None, flatten_ids=flatten_ids, isect_offsets=offsets,
+               tile_ids=None if key16 else tile_ids_s)
+    return out
 
 
 @torch.no_grad()
@@ -405,12 +428,10 @@ def isect_ids(bins: Dict[str, Tensor]) -> Tensor:
     lib = _lib.load()
     n = bins["n_isects"]
     out = torch.empty(n, device=bins["flatten_ids"].device, dtype=torch.int64)
-    if bins["tile_ids"] is None:                       # "scatter" ordering never materialises the tile ids
-        off = bins["isect_offsets"].long()
-        cnt = torch.diff(off, append=off.new_tensor([n]))
-        bins["tile_ids"] = torch.repeat_interleave(torch.arange(off.numel(), device=off.device, dtype=torch.int32),
-                                                   cnt)
-    check(lib.misplat_isect_ids(ptr(bins["tile_ids"]), ptr(bins["flatten_ids"]), ptr(bins["depths"].contiguous()),
+    if bins["tile_ids"] is None:                       # no sorted tile-id array exists: rebuild it from the offsets
+        cnt = torch.diff(bins["isect_offsets"].long())
+        bins["tile_ids"] = torch.repeat_interleave(torch.arange(cnt.numel(), device=cnt.device, dtype=torch.int32), cnt)
+    check(lib.misplat_isect_ids(ptr(bins["tile_ids"]), ptr(bins["flatten_ids"]), ptr(bins["depths"]),
                                 C.c_int64(n), ptr(out), stream_ptr()), "misplat_isect_ids")
     return out
 
@@ -418,15 +439,8 @@ def isect_ids(bins: Dict[str, Tensor]) -> Tensor:
 def _cum_by_row(bins: Dict[str, Tensor]) -> Tensor:
     """First emission slot of every Gaussian row (deterministic backward only; built lazily)."""
     if "cum" not in bins:
-        if bins["order"] is None and bins["cum_ordered"] is None:     # "pertile": row order, no scan array kept
-            tpg = bins["tiles_per_gauss"]
-            bins["cum"] = (torch.cumsum(tpg, dim=0, dtype=torch.int64) - tpg).contiguous()
-        elif bins["order"] is None:                    # emission was in row order already
-            bins["cum"] = bins["cum_ordered"]
-        else:
-            cum = torch.empty_like(bins["cum_ordered"])
-            cum[bins["order"].long()] = bins["cum_ordered"]
-            bins["cum"] = cum
+        tpg = bins["tiles_per_gauss"]
+        bins["cum"] = (torch.cumsum(tpg, dim=0, dtype=torch.int64) - tpg).contiguous()
     return bins["cum"]
 
 
@@ -457,11 +471,15 @@ class _Blend(torch.autograd.Function):
         normal = torch.empty(Cn, H, W, 3, **f)
         last_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
         median_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
+        sched = _UnitSchedule(P, dev)
         with _timed("blend_fwd"):
+            sched.before_forward(P)
             check(lib.misplat_blend_fwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
                                         ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(render),
                                         ptr(alpha), ptr(exp_depth), ptr(med_depth), ptr(normal), ptr(last_ids),
                                         ptr(median_ids), stream_ptr()), "misplat_blend_fwd")
+        sched.after_forward(P)
+        ctx.sched = sched
         ctx.P, ctx.bins, ctx.absgrad, ctx.cd = P, bins, absgrad, cd
         ctx.means2d_ref = means2d if absgrad else None
         ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids, render)
@@ -471,7 +489,9 @@ class _Blend(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, _l, _m):
+        ctx.sched.before_backward(ctx.P)
         v_grec, v_abs = _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
+        _UnitSchedule.done(ctx.P)
         P, cd = ctx.P, ctx.cd
         Cn, N = P.n_cams, P.n_gauss
         g = v_grec.view(Cn, N, MISPLAT_REC)
@@ -654,11 +674,15 @@ class _BlendPacked(torch.autograd.Function):
         normal = torch.empty(Cn, H, W, 3, **f)
         last_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
         median_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
+        sched = _UnitSchedule(P, dev)
         with _timed("blend_fwd"):
+            sched.before_forward(P)
             check(lib.misplat_blend_fwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
                                         ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(render),
                                         ptr(alpha), ptr(exp_depth), ptr(med_depth), ptr(normal), ptr(last_ids),
                                         ptr(median_ids), stream_ptr()), "misplat_blend_fwd")
+        sched.after_forward(P)
+        ctx.sched = sched
         ctx.P, ctx.bins, ctx.absgrad, ctx.cd = P, bins, absgrad, cd
         ctx.means2d_ref = means2d if absgrad else None
         ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids, render)
@@ -668,7 +692,9 @@ class _BlendPacked(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, _l, _m):
+        ctx.sched.before_backward(ctx.P)
         v_grec, v_abs = _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
+        _UnitSchedule.done(ctx.P)
         P = ctx.P
         if ctx.absgrad:
             ctx.means2d_ref.absgrad = v_abs.view(P.n_cams, P.n_gauss, 2)
@@ -809,12 +835,16 @@ class _BlendPackedX(torch.autograd.Function):
         normal = torch.empty(Cn, H, W, 3, **f)
         last_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
         median_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
+        sched = _UnitSchedule(P, dev)
+        ctx.sched = sched
         with _timed("blend_fwd"):
+            sched.before_forward(P)
             check(lib.misplat_blend_fwd_x(C.byref(P), C.c_int32(n_channels), C.c_int32(nxq), ptr(Ks), ptr(grec),
                                           ptr(featx), ptr(bins["flatten_ids"]), ptr(bins["isect_offsets"]),
                                           C.c_int64(bins["n_isects"]), ptr(render), ptr(alpha), ptr(exp_depth),
                                           ptr(med_depth), ptr(normal), ptr(last_ids), ptr(median_ids), stream_ptr()),
                   "misplat_blend_fwd_x")
+        sched.after_forward(P)
         ctx.P, ctx.bins, ctx.absgrad, ctx.n_channels, ctx.nxq = P, bins, absgrad, n_channels, nxq
         ctx.means2d_ref = means2d if absgrad else None
         ctx.save_for_backward(grec, featx, Ks, alpha, last_ids, median_ids, render)
@@ -833,6 +863,7 @@ class _BlendPackedX(torch.autograd.Function):
         v_featx = torch.empty(rows, 4 * ctx.nxq, device=dev, dtype=torch.float32)
         v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
         ups = _upstream(P, ctx.n_channels, dev, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
+        ctx.sched.before_backward(P)
         with _timed("blend_bwd"):
             check(lib.misplat_blend_bwd_x_atomic(C.byref(P), C.c_int32(ctx.n_channels), C.c_int32(ctx.nxq), ptr(Ks),
                                                  ptr(grec), ptr(featx), ptr(bins["flatten_ids"]),
@@ -840,6 +871,7 @@ class _BlendPackedX(torch.autograd.Function):
                                                  ptr(last_ids), ptr(median_ids), ptr(render), *[ptr(t) for t in ups],
                                                  ptr(v_grec), ptr(v_featx), ptr(v_abs), stream_ptr()),
                   "misplat_blend_bwd_x_atomic")
+        _UnitSchedule.done(P)
         if ctx.absgrad:
             ctx.means2d_ref.absgrad = v_abs.view(P.n_cams, P.n_gauss, 2)
         return (v_grec.view(P.n_cams, P.n_gauss, MISPLAT_REC)[..., 0:2], v_grec, v_featx, None, None, None, None, None,

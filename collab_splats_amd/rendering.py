@@ -186,7 +186,7 @@ def rasterization(
         "compensations": comps, "ray_ts": ray_ts, "ray_planes": ray_planes, "normals": normals,
         "tile_width": P.tile_w, "tile_height": P.tile_h, "tiles_per_gauss": bins["tiles_per_gauss"].view(Cn, N),
         "flatten_ids": bins["flatten_ids"],
-        "isect_offsets": bins["isect_offsets"].view(Cn, P.tile_h, P.tile_w),
+        "isect_offsets": bins["isect_offsets"][:-1].view(Cn, P.tile_h, P.tile_w),
         "n_isects": bins["n_isects"], "last_ids": first[5], "median_ids": first[6],
         "width": width, "height": height, "tile_size": tile_size, "n_cameras": Cn,
     })

@@ -66,6 +66,13 @@ typedef struct misplat_params {
     int32_t ppl_bwd;      /* a tile is covered by 4/ppl independent wavefronts ("bands")          */
     int32_t ed_slot;      /* colour channel (0..3) the compositing kernels divide by max(alpha,1e-10)
                              (the "ED" of render_mode RGB+ED / ED, rade_gs_model.py:237), or -1     */
+    int32_t reserved0;    /* (keeps the pointers below 8-byte aligned) */
+    /* Launch order of the compositing kernels (speed only; results never depend on it).  A "unit" is one band of
+     * one tile: unit = tile * (4 / ppl) + band.  unit_work (or NULL): the forward writes the number of staged
+     * Gaussians each unit composited -- its measured cost; unit_perm (or NULL): workgroup b of a compositing launch
+     * processes unit unit_perm[b] instead of the default XCD-strip map (misplat_unit_order builds it, longest first). */
+    const int32_t* unit_perm;
+    int32_t* unit_work;
 } misplat_params;
 
 /* ---- a2.1 projection: fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, ...)
@@ -141,50 +148,22 @@ int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_slot, const 
                              const float* v_means_dir, float* v_means, float* v_quats,
                              float* v_scales, float* v_opacities, misplat_stream_t stream);
 
-/* ---- a2.3 binning.  tiles_per_gauss[C*N] = number of 16x16 tiles the rect mean2d +- radii
- * touches (0 if culled). */
-int misplat_tile_count(const misplat_params* p, const float* means2d, const int32_t* radii,
-                       int32_t* tiles_per_gauss, misplat_stream_t stream);
-/* cum[C*N] = EXCLUSIVE prefix sum of tiles_per_gauss (int64).  Writes, for every intersection j
- * in emission order (ascending camera, Gaussian id, then row-major tiles):
- * keys[j] = ((cam*tile_w*tile_h + tile) << 32) | bits(depth), slot_ids[j] = j,
- * isect_gid[j] = cam*N + gid. */
-int misplat_tile_emit(const misplat_params* p, const float* means2d, const int32_t* radii,
-                      const float* depths, const int64_t* cum, uint64_t* keys, int32_t* slot_ids,
-                      int32_t* isect_gid, misplat_stream_t stream);
-/* Stable ascending radix sort of (key, value) pairs on bits [0, end_bit). */
-size_t misplat_sort_workspace_bytes(int64_t n_isects, int32_t end_bit);
-int misplat_sort_pairs(void* workspace, size_t workspace_bytes, const uint64_t* keys_in,
-                       uint64_t* keys_out, const int32_t* vals_in, int32_t* vals_out,
-                       int64_t n_isects, int32_t end_bit, misplat_stream_t stream);
-/* offsets[t] = first sorted position whose tile is >= t (t over C*tile_w*tile_h);
- * flatten_ids[i] = isect_gid[slots_sorted[i]]. */
-int misplat_tile_offsets(const uint64_t* keys_sorted, const int32_t* slots_sorted,
-                         const int32_t* isect_gid, int64_t n_isects, int32_t n_tiles_total,
-                         int32_t* offsets, int32_t* flatten_ids, misplat_stream_t stream);
-
-/* Two-stage ordering (ordering "twostage", an alternative to the default "pertile" below; same final
- * (tile, depth, Gaussian id) order as the 64-bit sort above): (1) depth_keys (+ sort_pairs) or, for one camera, depth_keys32 (+ sort32_pairs)
- * order the C*N rows by (camera, depth bits), culled rows last; (2) tile_emit_ordered walks that
- * order (order[r] = row, cum_ordered = exclusive scan of tiles_per_gauss[order[r]]) and writes the
- * 32-bit tile id and the row of every intersection (isect_gid), plus its emission slot if slot_ids
- * != NULL; (3) sort32_pairs is a STABLE radix sort on the ceil(log2(C*tiles)) tile bits only, the
- * payload being the row (=> flatten_ids directly) or the slot; (4) tile_offsets32 builds the per-tile
- * offsets; isect_ids rebuilds the 64-bit keys (tile << 32 | depth bits) on demand. */
-int misplat_depth_keys(const misplat_params* p, const int32_t* radii, const float* depths,
-                       uint64_t* keys, int32_t* ids, misplat_stream_t stream);
-int misplat_depth_keys32(const misplat_params* p, const int32_t* radii, const float* depths,
-                         uint32_t* keys, int32_t* ids, misplat_stream_t stream);
-int misplat_tile_emit_ordered(const misplat_params* p, const int32_t* order, const float* means2d,
-                              const int32_t* radii, const int64_t* cum_ordered, uint32_t* tile_ids,
-                              int32_t* slot_ids /* or NULL */, int32_t* isect_gid,
-                              misplat_stream_t stream);
+/* ---- a2.3 binning: for every tile the Gaussian rows whose rectangle mean2d +- radii touches it, in
+ * (depth, row) order -- the order of gsplat's 64-bit (tile | depth) key sort, without the keys.  Two routes to the
+ * per-tile buckets: the cell-ordered bucketing (bucket_*, the default, below) or (tile, row) pairs emitted in row
+ * order and stably radix-sorted on the tile bits (tile_count_blocks / tile_emit_blocks / sort16|32_pairs /
+ * tile_offsets16|32; the round-1 path, kept as an alternative); then misplat_tile_sort orders every bucket by depth.
+ * offsets arrays have C*tiles + 1 entries: the last one is the number of intersections. */
 size_t misplat_sort32_workspace_bytes(int64_t n, int32_t end_bit);
+/* Stable ascending radix sort (rocPRIM) of (key, value) pairs on key bits [0, end_bit). */
 int misplat_sort32_pairs(void* workspace, size_t workspace_bytes, const uint32_t* keys_in,
                          uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
                          int32_t end_bit, misplat_stream_t stream);
+/* offsets[t] = first sorted position whose tile id is >= t, t < n_tiles_total; pass C*tiles + 1 so that the
+ * extra entry receives n_isects. */
 int misplat_tile_offsets32(const uint32_t* tiles_sorted, int64_t n_isects, int32_t n_tiles_total,
                            int32_t* offsets, misplat_stream_t stream);
+/* gsplat's meta["isect_ids"] on demand: (tile << 32) | bits(depth[flatten_ids[i]]). */
 int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, const float* depths,
                       int64_t n_isects, uint64_t* isect_ids, misplat_stream_t stream);
 
@@ -192,11 +171,13 @@ int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, 
  * its bucket by the 32 depth bits with a stable LSD radix sort whose entries stay in registers (exchange
  * through LDS), which is exactly the (tile, depth, id) order -- no global depth sort at all.
  *   unordered = 0: every bucket arrives in ascending row order (stable sort16/sort32_pairs on the tile bits
- *                  of pairs emitted in row order: ordering "pertile", the default path);
- *   unordered = 1: buckets arrive in arbitrary order (misplat_tile_scatter, ordering "scatter");
+ *                  of pairs emitted in row order: ordering "pertile");
+ *   unordered = 1: buckets arrive in arbitrary order (misplat_bucket_tiles, ordering "cells", the default);
  *                  buckets with equal depths are re-sorted by (row, then depth).
- * payload (in/out): rows, or emission slots when isect_gid != NULL (row = isect_gid[slot]);
- * flatten_ids (out): rows in final order; scratch[4 * n_isects] backs the rare tiles longer than 8192. */
+ * offsets: n_tiles_total + 1 entries; n_isects: the number of intersections or an upper bound of it (only used to
+ * size the grids of the size classes); payload (in/out): rows, or emission slots when isect_gid != NULL
+ * (row = isect_gid[slot]); flatten_ids (out): rows in final order; scratch[4 * n_isects] backs the rare tiles
+ * longer than 8192 entries. */
 int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
                       const float* depths, const int32_t* isect_gid, int32_t* payload,
                       int32_t* flatten_ids, uint32_t* scratch, int32_t unordered, misplat_stream_t stream);
@@ -224,20 +205,33 @@ int misplat_sort16_pairs(void* workspace, size_t workspace_bytes, const uint16_t
 int misplat_tile_offsets16(const uint16_t* tiles_sorted, int64_t n_isects, int32_t n_tiles_total,
                            int32_t* offsets, misplat_stream_t stream);
 
-/* Bucketing without a sort ("scatter" ordering; replaces tile_count + tile_emit + the tile-id sort +
- * tile_offsets of gsplat's isect_tiles / isect_offset_encode):
- *   tile_hist    tiles_per_gauss[C*N] and, with atomics, tile_counts[C*tiles] (+=; caller zeroes it);
- *   tile_scan    offsets = exclusive scan of tile_counts, *n_isects = total (device int64), and
- *                tile_counts cleared again so that the same buffer is the cursor array of
- *   tile_scatter payload[offsets[tile] + cursor[tile]++] = row (or the emission slot slot_base[row] + j,
- *                with isect_gid[slot] = row, when slot_base != NULL: deterministic backward). */
-int misplat_tile_hist(const misplat_params* p, const float* means2d, const int32_t* radii,
-                      int32_t* tiles_per_gauss, int32_t* tile_counts, misplat_stream_t stream);
-int misplat_tile_scan(int32_t n_tiles_total, int32_t* tile_counts, int32_t* offsets, int64_t* n_isects,
-                      misplat_stream_t stream);
-int misplat_tile_scatter(const misplat_params* p, const float* means2d, const int32_t* radii,
-                         const int32_t* offsets, int32_t* cursors, const int64_t* slot_base,
-                         int32_t* payload, int32_t* isect_gid, misplat_stream_t stream);
+/* ---- Cell-ordered bucketing (ordering "cells", the default; csrc/bucket.hip).  Replaces gsplat's isect_tiles +
+ * radix sort + isect_offset_encode: every intersection is written once (its row) and no tile-id array exists.
+ *   bucket_plan   (host only) number of screen cells and of counting workgroups for this configuration:
+ *                 cellhist holds n_blocks * n_cells uint32, cell_count n_cells, cell_offs n_cells + 1;
+ *   bucket_count  tiles_per_gauss[C*N], rect2[C*N] (x0 | y0 << 16, w | h << 16 of the tile rectangle), the
+ *                 per-workgroup cell histograms, the global cell counts; counters[0] = number of intersections
+ *                 (device int64; counters[2] is zeroed here on `stream`);
+ *   bucket_rows   cell_offs = scan of the cell counts, counters[1] = visible rows, order[0 .. n_vis) = the visible
+ *                 rows in cell order; tile_count[n_tiles + 1] is cleared;
+ *   bucket_tiles  offsets[0 .. n_tiles] (offsets[n_tiles] = number of intersections) and
+ *                 payload[offsets[t] .. offsets[t + 1]) = the rows touching tile t, in arbitrary order
+ *                 (misplat_tile_sort(unordered = 1) follows).  cum != NULL (deterministic backward): the payload
+ *                 is the emission slot cum[row] + k and isect_gid[slot] = row.  Writes beyond cap_isects entries
+ *                 are dropped: the caller compares counters[0] with cap_isects afterwards.
+ * Nothing here needs a host read-back: all sizes live in `counters` on the device. */
+#define MISPLAT_BUCKET_MAX_CELLS 2048
+#define MISPLAT_BUCKET_MAX_BLOCKS 256
+int misplat_bucket_plan(const misplat_params* p, int32_t* n_cells, int32_t* n_blocks);
+int misplat_bucket_count(const misplat_params* p, const float* means2d, const int32_t* radii,
+                         int32_t* tiles_per_gauss, uint32_t* rect2, uint32_t* cellhist, uint32_t* cell_count,
+                         int64_t* counters, misplat_stream_t stream);
+int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles_per_gauss, const uint32_t* rect2,
+                        const uint32_t* cellhist, uint32_t* cell_count, uint32_t* cell_offs, int32_t* order,
+                        int64_t* counters, int32_t* tile_count, misplat_stream_t stream);
+int misplat_bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect2,
+                         const int64_t* counters, int32_t* tile_count, int32_t* offsets, const int64_t* cum,
+                         int64_t cap_isects, int32_t* payload, int32_t* isect_gid, misplat_stream_t stream);
 
 /* Hand-written stable LSD radix sort of (uint32 key, int32 value) pairs on key bits
  * [begin_bit, end_bit), bits_per_pass (1..11) bits per pass, three launches per pass, no
@@ -257,6 +251,8 @@ int misplat_pack(int64_t n_rows, int32_t color_dim, const float* means2d, const 
                  const float* normals, const float* colors, float* grec, misplat_stream_t stream);
 
 /* Forward: one wavefront per band of 16 x (4*ppl) pixels of a tile (ppl pixels per lane).
+ * offsets: C*tiles + 1 entries (tile t owns flatten_ids[offsets[t] .. offsets[t+1])); n_isects: the number of
+ * intersections or an upper bound (the backward's slab stride).
  * Outputs [C,H,W,...]: render[.,color_dim], alpha[.], exp_depth[.] (sum w*z, un-normalised),
  * med_depth[.], normal[.,3], last_ids[.], median_ids[.] (sorted positions; -1 = none).
  * color_dim in 1..4. */
@@ -265,6 +261,14 @@ int misplat_blend_fwd(const misplat_params* p, int32_t color_dim, const float* K
                       int64_t n_isects, float* render, float* alpha, float* exp_depth,
                       float* med_depth, float* normal, int32_t* last_ids, int32_t* median_ids,
                       misplat_stream_t stream);
+
+/* Launch order for the compositing kernels (speed only): unit_perm[8 * ceil(units / 8)] from the per-unit cost
+ * unit_work[units] the forward measured (misplat_params.unit_work), longest first inside every XCD strip;
+ * units = C * tiles * (4 / ppl), ppl = pixels per lane of the launch that will use it (0 = default).  Padding
+ * entries hold `units` (no unit).  Pass the result as misplat_params.unit_perm to any later compositing launch of
+ * the same ppl -- the backward of the same step, or the next forward of the same view. */
+int misplat_unit_order(const misplat_params* p, int32_t ppl, const int32_t* unit_work, int32_t* unit_perm,
+                       misplat_stream_t stream);
 
 /* Number of gradient planes (= bands per tile) the backward of this configuration writes. */
 int misplat_blend_planes(const misplat_params* p);

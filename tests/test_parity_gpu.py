@@ -387,7 +387,8 @@ def test_meta_serves_the_reference_consumers(dev):
 
 
 def test_sort_backends_give_identical_bins(dev, monkeypatch):
-    """rocPRIM and the hand-written sort must produce the same tile lists (bit for bit)."""
+    """The hand-written cell-ordered bucketing (default), and the round-1 pair sort with rocPRIM and with the
+    hand-written radix sort, must all produce the same tile lists (bit for bit), in both gradient modes."""
     from collab_splats_amd import ops, rasterization
     from collab_splats_amd.synthetic import random_scene
     W, H, N = 640, 360, 50_000
@@ -395,15 +396,15 @@ def test_sort_backends_give_identical_bins(dev, monkeypatch):
     args = [sc["means"].to(dev), sc["quats"].to(dev), torch.exp(sc["log_scales"]).to(dev),
             torch.sigmoid(sc["opacity_logits"]).to(dev), sc["sh"].to(dev), sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H]
     outs = {}
-    for ordering in ("scatter", "pertile", "twostage"):
-        for backend in ("rocprim", "misplat"):
+    for ordering in ("cells", "pertile"):
+        for backend in (("rocprim", "misplat") if ordering == "pertile" else ("rocprim",)):
             for det in (False, True):
                 monkeypatch.setattr(ops, "ORDERING", ordering)
                 monkeypatch.setattr(ops, "SORT_BACKEND", backend)
                 monkeypatch.setattr(ops, "DETERMINISTIC_BACKWARD", det)
                 outs[(ordering, backend, det)] = rasterization(*args, sh_degree=3, render_mode="RGB+ED",
                                                                return_depth_normal=True)
-    a = outs[("twostage", "rocprim", False)]
+    a = outs[("pertile", "rocprim", False)]
     for key, b in outs.items():
         assert torch.equal(a[5]["flatten_ids"], b[5]["flatten_ids"]), key
         assert torch.equal(a[5]["isect_offsets"], b[5]["isect_offsets"]), key
@@ -430,12 +431,12 @@ def test_orderings_agree_with_depth_ties_and_long_buckets(dev, monkeypatch, n, s
     args = [means.to(dev), sc["quats"].to(dev), torch.exp(sc["log_scales"]).to(dev),
             torch.sigmoid(sc["opacity_logits"]).to(dev), sc["sh"].to(dev), vm.to(dev), sc["Ks"][:1].to(dev), W, H]
     outs = {}
-    for ordering in ("scatter", "pertile", "twostage"):
+    for ordering in ("cells", "pertile"):
         for det in (False, True):
             monkeypatch.setattr(ops, "ORDERING", ordering)
             monkeypatch.setattr(ops, "DETERMINISTIC_BACKWARD", det)
             outs[(ordering, det)] = rasterization(*args, sh_degree=3, render_mode="RGB+ED", return_depth_normal=True)
-    a = outs[("twostage", False)]
+    a = outs[("pertile", False)]
     d = a[5]["depths"].flatten()[a[5]["flatten_ids"].long()]
     assert (d[1:] == d[:-1]).float().mean() > 0.5                      # the scene really is full of ties
     offs = a[5]["isect_offsets"].reshape(-1).long()
