@@ -207,7 +207,7 @@ def main():
         I = int(info["n_isects"])
         n_vis = int((info["n_visible"] > 0).any(-1).sum().item())
         ktimes = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in events.items() if v}  # ms
-        dom = max(ktimes, key=ktimes.get)
+        dom = max((k for k in ktimes if k in ("blend_bwd", "blend_fwd", "slab_reduce")), key=ktimes.get)
         abytes = algorithmic_bytes(dom, N, I, W * H)
         achieved = abytes / (ktimes[dom] * 1e-3) / 1e9
         traffic = None

@@ -39,6 +39,20 @@ class Params(C.Structure):
                 ("unit_perm", C.c_void_p), ("unit_work", C.c_void_p)]
 
 
+class RasterArgs(C.Structure):
+    """Mirror of ``misplat_raster_args`` (include/misplat.h)."""
+    _P = C.c_void_p
+    _fields_ = ([(n, C.c_void_p) for n in ("means", "quats", "scales", "opacities", "colors", "colors_rest", "viewmats", "Ks")]
+                + [(n, C.c_int32) for n in ("sh_degree", "K_or_D", "n_color", "per_cam", "depth_channel", "color_dim")]
+                + [(n, C.c_void_p) for n in ("radii", "means2d", "depths", "compensations", "grec", "sh_aux",
+                                             "tiles_per_gauss", "rect2", "cellhist", "cell_count", "cell_offs", "order",
+                                             "counters", "tile_count", "offsets", "payload", "flatten_ids", "scratch")]
+                + [("cap_isects", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("n_isects_host", "reserved1", "render", "alpha", "exp_depth", "med_depth",
+                                             "normal", "last_ids", "median_ids", "unit_perm_in", "unit_work",
+                                             "unit_perm_out")])
+
+
 def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: int = 16,
                 antialiased: bool = False, opacity_aware_radius: bool = True, eps2d: float = 0.3,
                 near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0,
@@ -59,7 +73,7 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
 # name -> (restype, n_args); every symbol include/misplat.h declares
 SYMBOLS = {
     "misplat_project_fwd": (C.c_int, 16), "misplat_project_bwd": (C.c_int, 18),
-    "misplat_project_pack_fwd": (C.c_int, 13), "misplat_color_fwd": (C.c_int, 15),
+    "misplat_project_pack_fwd": (C.c_int, 15), "misplat_color_fwd": (C.c_int, 15),
     "misplat_color_bwd": (C.c_int, 16), "misplat_project_pack_bwd": (C.c_int, 18),
     "misplat_sh_fwd": (C.c_int, 9), "misplat_sh_bwd": (C.c_int, 11),
     "misplat_sort32_workspace_bytes": (C.c_size_t, 2),
@@ -77,9 +91,10 @@ SYMBOLS = {
     "misplat_blend_fwd_x": (C.c_int, 17), "misplat_blend_bwd_x_atomic": (C.c_int, 22),
     "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 19), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),
     "misplat_depth_normal_bwd": (C.c_int, 14), "misplat_outputs_fwd": (C.c_int, 15), "misplat_outputs_bwd": (C.c_int, 16),
-    "misplat_bucket_plan": (C.c_int, 3), "misplat_bucket_count": (C.c_int, 9), "misplat_bucket_rows": (C.c_int, 10),
+    "misplat_bucket_plan": (C.c_int, 3), "misplat_bucket_count": (C.c_int, 10), "misplat_bucket_rows": (C.c_int, 10),
     "misplat_bucket_tiles": (C.c_int, 11),
-    "misplat_unit_order": (C.c_int, 5),
+    "misplat_unit_order": (C.c_int, 5), "misplat_raster_fwd": (C.c_int, 5), "misplat_graph_cache_create": (C.c_void_p, 1),
+    "misplat_graph_cache_destroy": (None, 1), "misplat_graph_cache_stats": (C.c_int, 3), "misplat_wait_count": (C.c_int64, 2), "misplat_zero_bytes": (C.c_int, 3),
     "misplat_version": (C.c_char_p, 0),
 }
 

@@ -27,6 +27,7 @@ SOURCES = {
     "project.hip": ["-ffp-contract=off"],
     "binning.hip": [],
     "bucket.hip": [],
+    "raster.hip": [],
     "blend.hip": [],
     "epilogue.hip": [],
     "sort.hip": [],

@@ -137,7 +137,8 @@ __device__ __forceinline__ bool tile_range(const int32_t* __restrict__ offsets, 
     t_step = 1;
     bool mine = false;
     for (int t = t_first + threadIdx.x; t < t_last; t += blockDim.x) {
-        const int n = offsets[t + 1] - offsets[t];
+        const int e1 = min(offsets[t + 1], (int)n_isects);
+        const int n = e1 - min(offsets[t], e1);
         mine |= (n > lo && n <= hi);
     }
     return __syncthreads_or(mine) != 0;
@@ -293,8 +294,8 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
     int t_first, t_last, t_step;
     if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step)) return;
     for (int t = t_first; t < t_last; t += t_step) {
-        const int beg = offsets[t];
-        const int end = offsets[t + 1];            // offsets: n_tiles + 1 entries
+        const int end = min(offsets[t + 1], (int)n_isects);     // offsets: n_tiles + 1 entries; n_isects: buffer capacity
+        const int beg = min(offsets[t], end);
         const int n = end - beg;
         if (n <= lo || n > hi) continue;               // uniform over the block (n >= 1 from here)
         uint32_t key[R], val[R];
@@ -362,8 +363,8 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __
     int t_first, t_last, t_step;
     if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step)) return;
     for (int t = t_first; t < t_last; t += t_step) {
-    const int beg = offsets[t];
-    const int end = offsets[t + 1];
+    const int end = min(offsets[t + 1], (int)n_isects);
+    const int beg = min(offsets[t], end);
     const int n = end - beg;
     if (n <= lo || n > hi) continue;                 // another size class (uniform over the block)
     constexpr int THREADS = 64 * WAVES;

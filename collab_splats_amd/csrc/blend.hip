@@ -67,8 +67,10 @@ __device__ __forceinline__ bool band_ctx(const misplat_params& P, const float* _
         if (P.unit_work && threadIdx.x == 0) P.unit_work[unit] = 0;
         return false;
     }
-    c.beg = offsets[c.tile];
-    c.end = offsets[c.tile + 1];               // offsets has C*tiles + 1 entries (the last one = number of intersections)
+    // offsets has C*tiles + 1 entries (the last one = number of intersections); n_isects is the capacity of
+    // flatten_ids: a speculative launch whose capacity turned out too small must stay inside its buffers
+    c.end = min(offsets[c.tile + 1], (int)n_isects);
+    c.beg = min(offsets[c.tile], c.end);
     c.fx = Ks[9 * c.cam]; c.fy = Ks[9 * c.cam + 4]; c.cx = Ks[9 * c.cam + 2]; c.cy = Ks[9 * c.cam + 5];
     return true;
 }

@@ -412,16 +412,19 @@ extern "C" int misplat_bucket_plan(const misplat_params* p, int32_t* n_cells, in
 
 extern "C" int misplat_bucket_count(const misplat_params* p, const float* means2d, const int32_t* radii,
                                     int32_t* tiles_per_gauss, uint32_t* rect2, uint32_t* cellhist,
-                                    uint32_t* cell_count, int64_t* counters, misplat_stream_t stream) {
+                                    uint32_t* cell_count, int64_t* counters, int32_t already_zero,
+                                    misplat_stream_t stream) {
     int32_t nc, nb;
     if (misplat_bucket_plan(p, &nc, &nb) != MISPLAT_OK || !cellhist || !cell_count || !counters) return MISPLAT_EINVAL;
     const CellGrid g = make_grid(p);
     const int64_t total = (int64_t)p->n_gauss * p->n_cams;
     if (total > 0 && (!tiles_per_gauss || !rect2)) return MISPLAT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    // cell counts and the two counters start from zero (memset nodes on the stream: graph-capturable)
-    if (hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)g.n_cells, s) != hipSuccess) return MISPLAT_ELAUNCH;
-    if (hipMemsetAsync(counters, 0, 2 * sizeof(int64_t), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    // cell counts and the two counters start from zero (already_zero: an earlier kernel of the stream cleared them)
+    if (!already_zero) {
+        if (hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)g.n_cells, s) != hipSuccess) return MISPLAT_ELAUNCH;
+        if (hipMemsetAsync(counters, 0, 2 * sizeof(int64_t), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    }
     if (total > 0)
         hipLaunchKernelGGL(bucket_count_kernel, dim3(g.n_blocks), dim3(kCountThreads), 0, s, total, p->n_gauss, p->tile_w,
                            p->tile_h, g.shift, g.cells_x, g.cells_x * g.cells_y, g.n_cells, g.rows_per_block, means2d, radii,

@@ -517,7 +517,10 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
     const float* __restrict__ scales, const float* __restrict__ opacities,
     const float* __restrict__ viewmats, const float* __restrict__ Ks, int32_t* __restrict__ radii,
     float* __restrict__ means2d, float* __restrict__ depths, float* __restrict__ comps,
-    float4* __restrict__ grec) {
+    float4* __restrict__ grec, uint32_t* __restrict__ zero_words, int n_zero) {
+    // scratch the NEXT kernels of the stream accumulate into (bucketing counters): cleared here, no memset launch
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0u;
     const int64_t total = (int64_t)P.n_cams * P.n_gauss;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -953,14 +956,16 @@ extern "C" int misplat_sh_bwd(int32_t n_gauss, int32_t n_cams, int32_t K, int32_
 extern "C" int misplat_project_pack_fwd(const misplat_params* p, const float* means, const float* quats,
                                         const float* scales, const float* opacities, const float* viewmats,
                                         const float* Ks, int32_t* radii, float* means2d, float* depths,
-                                        float* compensations, float* grec, misplat_stream_t stream) {
+                                        float* compensations, float* grec, uint32_t* zero_words, int32_t n_zero,
+                                        misplat_stream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1 || p->width < 1 || p->height < 1) return MISPLAT_EINVAL;
     int64_t total = (int64_t)p->n_gauss * p->n_cams;
-    if (total == 0) return MISPLAT_OK;
-    if (!opacities) return MISPLAT_EINVAL;
+    if (n_zero < 0 || (n_zero > 0 && !zero_words)) return MISPLAT_EINVAL;
+    if (total == 0 && n_zero == 0) return MISPLAT_OK;
+    if (total > 0 && !opacities) return MISPLAT_EINVAL;
     hipLaunchKernelGGL(project_pack_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                        means, quats, scales, opacities, viewmats, Ks, radii, means2d, depths, compensations,
-                       (float4*)grec);
+                       (float4*)grec, zero_words, n_zero);
     return check_launch();
 }
 

@@ -1,0 +1,244 @@
+// raster.hip -- the whole rasterization() forward as ONE host entry (two phases) instead of ~15 separate calls,
+// optionally replayed as a hipGraph.  gfx950 only.  Replaces, on the host side, the kernel sequence inside
+// gsplat-rade's rasterization(..., return_depth_normal=True) as called at
+// /root/reference/collab_splats/models/rade_gs_model.py:439-465 (one call per training step on the caller's main
+// thread): every launch below is one of the stages of include/misplat.h, enqueued back to back on the caller's
+// stream with NO host read-back inside:
+//   phase A  projection -> cell-ordered row bucketing (tile counts on the device) -> asynchronous copy of the
+//            intersection count to pinned host memory -> colours (SH or pass-through)
+//   phase B  per-tile buckets (capacity cap_isects) -> per-tile depth sort -> compositing -> launch order
+// The caller may enqueue B right behind A with a SPECULATIVE capacity (e.g. 1.25 x the previous call's count) and
+// only then wait for the count (misplat_wait_count): if it is <= cap_isects the results are exact; otherwise the
+// caller allocates the exact size and enqueues B again.  The step's one host wait is thereby hidden behind the
+// whole chain instead of stalling it.
+// Small scenes are launch-bound (~16 launches of a few microseconds of GPU work each, ~6 us of host time per
+// launch): with a misplat_graph_cache the sequence is captured once per distinct argument block and replayed with
+// one hipGraphLaunch (~10-15 us of host time).  The cache is an explicit, caller-owned object: the library keeps
+// no global state.  HBM-bound integer work + the VALU-bound compositing: no MFMA anywhere on this path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <sched.h>
+#include <time.h>
+#include <mutex>
+#include <vector>
+#include "misplat.h"
+
+namespace {
+
+int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32_t phases, hipStream_t s) {
+    misplat_stream_t stream = (misplat_stream_t)s;
+    int rc;
+    if (phases & 1) {
+        // the projection kernel also clears the cell counts and the two counters (contiguous: cell_count ... counters),
+        // so phase A contains no memset at all
+        const int64_t n_zero = ((const uint32_t*)a->counters + 4) - a->cell_count;
+        if (!a->cell_count || !a->counters || n_zero < 4 || n_zero > (1 << 20)) return MISPLAT_EINVAL;
+        rc = misplat_project_pack_fwd(p, a->means, a->quats, a->scales, a->opacities, a->viewmats, a->Ks, a->radii,
+                                      a->means2d, a->depths, a->compensations, a->grec, a->cell_count, (int32_t)n_zero, stream);
+        if (rc != MISPLAT_OK) return rc;
+        rc = misplat_bucket_count(p, a->means2d, a->radii, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count,
+                                  a->counters, 1, stream);
+        if (rc != MISPLAT_OK) return rc;
+        if (a->n_isects_host &&
+            hipMemcpyAsync(a->n_isects_host, a->counters, sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess)
+            return MISPLAT_ELAUNCH;
+        rc = misplat_bucket_rows(p, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count, a->cell_offs, a->order,
+                                 a->counters, a->tile_count, stream);
+        if (rc != MISPLAT_OK) return rc;
+        rc = misplat_color_fwd(p, a->sh_degree, a->K_or_D, a->n_color, a->per_cam, a->depth_channel, a->means, a->viewmats,
+                               a->colors, a->colors_rest, a->radii, a->depths, a->grec, a->sh_aux, stream);
+        if (rc != MISPLAT_OK) return rc;
+    }
+    if (phases & 2) {
+        if (a->cap_isects < 0 || a->cap_isects > 0x7fffffffLL) return MISPLAT_EINVAL;
+        rc = misplat_bucket_tiles(p, a->order, a->rect2, a->counters, a->tile_count, a->offsets, nullptr, a->cap_isects,
+                                  a->payload, nullptr, stream);
+        if (rc != MISPLAT_OK) return rc;
+        if (a->cap_isects > 0) {
+            rc = misplat_tile_sort(a->offsets, p->tile_w * p->tile_h * p->n_cams, a->cap_isects, a->depths, nullptr,
+                                   a->payload, a->flatten_ids, a->scratch, 1, stream);
+            if (rc != MISPLAT_OK) return rc;
+        }
+        misplat_params q = *p;
+        q.unit_perm = a->unit_perm_in;
+        q.unit_work = a->unit_work;
+        rc = misplat_blend_fwd(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects, a->render,
+                               a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, stream);
+        if (rc != MISPLAT_OK) return rc;
+        if (a->unit_work && a->unit_perm_out) {
+            rc = misplat_unit_order(p, p->ppl_fwd, a->unit_work, a->unit_perm_out, stream);
+            if (rc != MISPLAT_OK) return rc;
+        }
+    }
+    return MISPLAT_OK;
+}
+
+struct GraphEntry {
+    std::vector<uint8_t> key;
+    hipGraphExec_t exec;
+    hipGraph_t graph;               // the captured template stays alive as long as its executable does
+    uint64_t stamp;
+    hipStream_t last_stream;        // where it was launched last
+};
+struct Retired {                    // an evicted graph may still be executing: destroyed once `done` has fired
+    hipGraphExec_t exec;
+    hipGraph_t graph;
+    hipEvent_t done;
+};
+
+}  // namespace
+
+struct misplat_graph_cache {
+    std::mutex mu;
+    std::vector<GraphEntry> entries;
+    std::vector<Retired> retired;
+    uint64_t clock = 0, hits = 0, captures = 0;
+    uint64_t window_calls = 0, window_misses = 0, bypass_until = 0;
+    int max_entries = 16;
+    // Sequences are captured on this private stream (the caller's may be the legacy default stream, which cannot be
+    // captured) and the resulting graph is launched on the caller's stream.
+    hipStream_t capture_stream = nullptr;
+};
+
+extern "C" misplat_graph_cache* misplat_graph_cache_create(int32_t max_entries) {
+    misplat_graph_cache* c = new (std::nothrow) misplat_graph_cache();
+    if (!c) return nullptr;
+    if (max_entries > 0) c->max_entries = max_entries;
+    if (hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+extern "C" void misplat_graph_cache_destroy(misplat_graph_cache* c) {
+    if (!c) return;
+    (void)hipDeviceSynchronize();                                   // nothing of ours is in flight any more
+    for (auto& e : c->entries) { (void)hipGraphExecDestroy(e.exec); (void)hipGraphDestroy(e.graph); }
+    for (auto& r : c->retired) { (void)hipGraphExecDestroy(r.exec); (void)hipGraphDestroy(r.graph); (void)hipEventDestroy(r.done); }
+    if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream);
+    delete c;
+}
+
+extern "C" int misplat_graph_cache_stats(misplat_graph_cache* c, int64_t* hits, int64_t* captures) {
+    if (!c || !hits || !captures) return MISPLAT_EINVAL;
+    std::lock_guard<std::mutex> g(c->mu);
+    *hits = (int64_t)c->hits;
+    *captures = (int64_t)c->captures;
+    return MISPLAT_OK;
+}
+
+extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_args* a, int32_t phases,
+                                  misplat_stream_t stream, misplat_graph_cache* cache) {
+    if (!p || !a || (phases & ~3) != 0 || phases == 0) return MISPLAT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (!cache) return enqueue_forward(p, a, phases, s);
+    // key: everything the enqueued work depends on -- the two argument blocks, the phases and the stream
+    std::vector<uint8_t> key(sizeof(int32_t) + sizeof(void*) + sizeof(*p) + sizeof(*a));
+    uint8_t* k = key.data();
+    memcpy(k, &phases, sizeof(int32_t)); k += sizeof(int32_t);
+    memcpy(k, &s, sizeof(void*)); k += sizeof(void*);
+    memcpy(k, p, sizeof(*p)); k += sizeof(*p);
+    memcpy(k, a, sizeof(*a));
+    std::lock_guard<std::mutex> g(cache->mu);
+    cache->clock++;
+    // retired graphs whose last launch has completed can go now
+    for (size_t i = 0; i < cache->retired.size();) {
+        if (hipEventQuery(cache->retired[i].done) == hipSuccess) {
+            (void)hipGraphExecDestroy(cache->retired[i].exec);
+            (void)hipGraphDestroy(cache->retired[i].graph);
+            (void)hipEventDestroy(cache->retired[i].done);
+            cache->retired.erase(cache->retired.begin() + i);
+        } else {
+            (void)hipGetLastError();                                // hipErrorNotReady is not an error
+            i++;
+        }
+    }
+    for (auto& e : cache->entries)
+        if (e.key == key) {
+            e.stamp = cache->clock;
+            e.last_stream = s;
+            cache->hits++;
+            cache->window_calls++;
+            return hipGraphLaunch(e.exec, s) == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+        }
+    // A caller whose argument blocks never repeat (addresses or sizes change every call) gains nothing from
+    // capturing: after a window with mostly misses, plain launches are used for a while.
+    cache->window_calls++;
+    cache->window_misses++;
+    if (cache->window_calls >= 64) {
+        if (2 * cache->window_misses > cache->window_calls) cache->bypass_until = cache->clock + 512;
+        cache->window_calls = cache->window_misses = 0;
+    }
+    if (cache->clock < cache->bypass_until) return enqueue_forward(p, a, phases, s);
+    // capture on the private stream (thread-local mode: other host threads keep using the runtime normally)
+    hipStream_t cs = cache->capture_stream;
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return enqueue_forward(p, a, phases, s);
+    }
+    const int rc = enqueue_forward(p, a, phases, cs);
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(cs, &graph);
+    if (rc != MISPLAT_OK || ec != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        return rc != MISPLAT_OK ? rc : enqueue_forward(p, a, phases, s);
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    if (ei != hipSuccess || !exec) {
+        (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        return enqueue_forward(p, a, phases, s);
+    }
+    if ((int)cache->entries.size() >= cache->max_entries) {       // evict the least recently used graph
+        size_t victim = 0;
+        for (size_t i = 1; i < cache->entries.size(); i++)
+            if (cache->entries[i].stamp < cache->entries[victim].stamp) victim = i;
+        Retired r{cache->entries[victim].exec, cache->entries[victim].graph, nullptr};
+        // it may still be running: keep it until an event recorded behind its last launch has fired
+        if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) == hipSuccess &&
+            hipEventRecord(r.done, cache->entries[victim].last_stream) == hipSuccess) {
+            cache->retired.push_back(r);
+        } else {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(cache->entries[victim].last_stream);
+            (void)hipGraphExecDestroy(r.exec);
+            (void)hipGraphDestroy(r.graph);
+            if (r.done) (void)hipEventDestroy(r.done);
+        }
+        cache->entries.erase(cache->entries.begin() + victim);
+    }
+    cache->entries.push_back(GraphEntry{std::move(key), exec, graph, cache->clock, s});
+    cache->captures++;
+    return hipGraphLaunch(exec, s) == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+}
+
+// Clears a device buffer on `stream` (the retry of phase B clears tile_count with it: the buffers of one forward are
+// slices of one allocation, so a framework-level in-place clear would invalidate tensors saved for the backward).
+extern "C" int misplat_zero_bytes(void* dst, size_t bytes, misplat_stream_t stream) {
+    if (!dst && bytes) return MISPLAT_EINVAL;
+    if (bytes == 0) return MISPLAT_OK;
+    return hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream) == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+}
+
+// Host-side wait for the intersection count of phase A: *slot was set to -1 by the caller before the launch and is
+// overwritten (>= 0) by the asynchronous device-to-host copy.  Returns the count, or -1 after timeout_us.
+extern "C" int64_t misplat_wait_count(const volatile int64_t* slot, int64_t timeout_us) {
+    if (!slot) return -1;
+    struct timespec t0, t;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (uint32_t spin = 0;; spin++) {
+        const int64_t v = *slot;
+        if (v >= 0) return v;
+        if ((spin & 63) == 63) {
+            clock_gettime(CLOCK_MONOTONIC, &t);
+            const int64_t us = (int64_t)(t.tv_sec - t0.tv_sec) * 1000000 + (t.tv_nsec - t0.tv_nsec) / 1000;
+            if (us > timeout_us) return -1;
+            if (us > 200) sched_yield();
+        }
+    }
+}

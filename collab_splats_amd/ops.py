@@ -16,7 +16,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import MISPLAT_REC, Params, check, ptr, require_gpu, stream_ptr
+from ._lib import MISPLAT_REC, Params, RasterArgs, check, ptr, require_gpu, stream_ptr
 
 
 # False (default): every (band, Gaussian) gradient row is added into the per-Gaussian gradient with
@@ -326,7 +326,8 @@ def start_binning(P: Params, means2d: Tensor, radii: Tensor) -> Dict[str, Tensor
             dev, (total, 2 * total, n_blocks * n_cells, n_cells, n_cells + 1, total, 4, n_tiles + 1))
         counters = counters.view(torch.int64)
         check(lib.misplat_bucket_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(rect2),
-                                       ptr(cellhist), ptr(cell_count), ptr(counters), stream_ptr()), "misplat_bucket_count")
+                                       ptr(cellhist), ptr(cell_count), ptr(counters), C.c_int32(0), stream_ptr()),
+              "misplat_bucket_count")
         pend = _read_back(counters[0:1])
         check(lib.misplat_bucket_rows(C.byref(P), ptr(tiles_per_gauss), ptr(rect2), ptr(cellhist), ptr(cell_count),
                                       ptr(cell_offs), ptr(order), ptr(counters), ptr(tile_count), stream_ptr()),
@@ -522,6 +523,182 @@ def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Par
     return _Blend.apply(*args, P, bins, bool(absgrad), int(pass_index))
 
 
+# ----------------------------------------------------------------------------- one host entry per phase
+
+# The reference's path (RGB / RGB+ED with SH or pass-through colours, atomic gradient mode, "cells" ordering) goes
+# through misplat_raster_fwd: phase A inside _ProjectPack.forward, phase B inside _BlendPacked.forward -- two C calls
+# and three allocations per forward instead of ~15 calls and ~30 allocations.  SPECULATE: phase B is enqueued with a
+# capacity guessed from the previous call of the same shape BEFORE the host has seen the intersection count; the
+# count is checked afterwards (exact results always: an overflow re-runs phase B with the exact size).
+FUSED_ENTRY = os.environ.get("MISPLAT_FUSED", "1") == "1"
+SPECULATE = os.environ.get("MISPLAT_SPECULATE", "1") == "1"
+CAP_MARGIN = float(os.environ.get("MISPLAT_CAP_MARGIN", "1.25"))
+_CAP_HINT: Dict[tuple, int] = {}
+_READBACK: Dict[int, tuple] = {}
+
+
+def _carve_f(dev: torch.device, sizes) -> list:
+    offs, tot = [], 0
+    for n in sizes:
+        offs.append(tot)
+        tot += (int(n) + 63) // 64 * 64
+    buf = torch.empty(max(tot, 64), device=dev, dtype=torch.float32)
+    return [buf[o:o + int(n)] for o, n in zip(offs, sizes)]
+
+
+# hipGraph replay of the launch sequences (csrc/raster.hip): one graph per distinct argument block, LRU of 16 per device.
+GRAPHS = os.environ.get("MISPLAT_GRAPH", "1") == "1"
+_GRAPH_CACHE: Dict[int, int] = {}
+
+
+def _readback_slot(dev: torch.device) -> Tensor:
+    """Pinned int64[1] of this device that receives the intersection count: every forward waits for its own count
+    before it returns, so one slot per device is enough."""
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _READBACK:
+        _READBACK[idx] = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+    return _READBACK[idx]
+
+
+def _graph_cache(dev: torch.device):
+    if not GRAPHS:
+        return None
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _GRAPH_CACHE:
+        h = _lib.load().misplat_graph_cache_create(C.c_int32(16))
+        if not h:
+            raise _lib.MisplatError("misplat_graph_cache_create failed")
+        _GRAPH_CACHE[idx] = h
+    return C.c_void_p(_GRAPH_CACHE[idx])
+
+
+def graph_cache_stats(dev: Optional[torch.device] = None) -> Dict[str, int]:
+    """{"hits", "captures"} of the device's graph cache (zeros when graphs are off or unused)."""
+    idx = torch.cuda.current_device() if dev is None or dev.index is None else dev.index
+    if idx not in _GRAPH_CACHE:
+        return dict(hits=0, captures=0)
+    h, c = C.c_int64(0), C.c_int64(0)
+    check(_lib.load().misplat_graph_cache_stats(C.c_void_p(_GRAPH_CACHE[idx]), C.byref(h), C.byref(c)), "misplat_graph_cache_stats")
+    return dict(hits=int(h.value), captures=int(c.value))
+
+
+def _wait_count(host: Tensor) -> int:
+    n = int(_lib.load().misplat_wait_count(C.c_void_p(host.data_ptr()), C.c_int64(20_000_000)))
+    if n < 0:
+        raise _lib.MisplatError("timed out waiting for the intersection count (GPU hung?)")
+    return n
+
+
+def _quantise_cap(x: int) -> int:
+    """Round a capacity up to 8 steps per octave: the speculative buffers (and with them the pointers the allocator
+    hands out and the graph-cache key) then stay the same while the count moves by a few percent from step to step."""
+    x = max(int(x), 4096)
+    step = 1 << max(x.bit_length() - 4, 0)
+    return (x + step - 1) // step * step
+
+
+def fused_entry_ok() -> bool:
+    return FUSED_ENTRY and ORDERING == "cells" and not DETERMINISTIC_BACKWARD and not OVERLAP
+
+
+def _dp(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg: int, kd: int,
+                    n_color: int, per_cam: int, depth_channel: bool, want_aux: bool):
+    """Allocations + phase A of misplat_raster_fwd.  Returns (radii, means2d, depths, comps, grec, sh_aux, state)."""
+    lib = _lib.load()
+    dev = means.device
+    N, Cn = P.n_gauss, P.n_cams
+    rows = Cn * N
+    n_tiles = P.tile_w * P.tile_h * Cn
+    n_cells, n_blocks = bucket_plan(P)
+    means2d, depths, comps, grec, sh_aux = _carve_f(dev, (2 * rows, rows, rows, MISPLAT_REC * rows, 12 * rows if want_aux else 0))
+    # (counters directly behind cell_count: the projection kernel clears that contiguous range, no memset launch)
+    radii, tiles_per_gauss, rect2, cellhist, cell_count, counters, cell_offs, order, tile_count = _carve(
+        dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, 4, n_cells + 1, rows, n_tiles + 1))
+    host = _readback_slot(dev)
+    host[0] = -1                                                      # overwritten by the asynchronous copy of phase A
+    a = RasterArgs()
+    a.means, a.quats, a.scales, a.opacities = _dp(means), _dp(quats), _dp(scales), _dp(opacities)
+    a.colors, a.colors_rest, a.viewmats, a.Ks = _dp(colors), _dp(colors_rest), _dp(viewmats), _dp(Ks)
+    a.sh_degree, a.K_or_D, a.n_color, a.per_cam, a.depth_channel = deg, kd, n_color, per_cam, int(depth_channel)
+    a.radii, a.means2d, a.depths, a.compensations, a.grec = _dp(radii), _dp(means2d), _dp(depths), _dp(comps), _dp(grec)
+    a.sh_aux = _dp(sh_aux) if want_aux else None
+    a.tiles_per_gauss, a.rect2, a.cellhist, a.cell_count = _dp(tiles_per_gauss), _dp(rect2), _dp(cellhist), _dp(cell_count)
+    a.cell_offs, a.order, a.counters, a.tile_count = _dp(cell_offs), _dp(order), _dp(counters), _dp(tile_count)
+    a.n_isects_host = host.data_ptr()
+    check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
+          "misplat_raster_fwd(A)")
+    state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths,
+                 keep=(rect2, cellhist, cell_count, cell_offs, order, counters, tile_count, radii))
+    return (radii.view(Cn, N, 2), means2d.view(Cn, N, 2), depths.view(Cn, N), comps.view(Cn, N), grec.view(rows, MISPLAT_REC),
+            sh_aux.view(rows, 12) if want_aux else None, state)
+
+
+def _raster_phase_b(P: Params, state: dict, cd: int):
+    """Phase B of misplat_raster_fwd with a speculative capacity; returns (images..., bins, sched)."""
+    lib = _lib.load()
+    a = state["args"]
+    dev = state["depths"].device
+    Cn, H, W = P.n_cams, P.height, P.width
+    n_pix = Cn * H * W
+    n_tiles = P.tile_w * P.tile_h * Cn
+    key = (dev.index, P.n_gauss, Cn, W, H)
+    hint = _CAP_HINT.get(key) if SPECULATE else None
+    n_known = None
+    if hint is None:                                                  # first call of this shape: exact, as before
+        n_known = _wait_count(state["host"])
+        cap = max(n_known, 1)
+    else:
+        cap = _quantise_cap(int(hint * CAP_MARGIN))
+    if cap >= 2 ** 31:
+        raise _lib.MisplatError(f"{cap} tile intersections exceed int32 indexing")
+    render, alpha, exp_depth, med_depth, normal = _carve_f(dev, (cd * n_pix, n_pix, n_pix, n_pix, 3 * n_pix))
+    sched = _UnitSchedule(P, dev)
+    last_ids, median_ids, offsets = _carve(dev, (n_pix, n_pix, n_tiles + 1))
+
+    def isect_buffers(c):
+        return _carve(dev, (c, c, 4 * c))
+
+    payload, flatten_ids, scratch = isect_buffers(cap)
+    a.color_dim = cd
+    a.offsets, a.render, a.alpha, a.exp_depth, a.med_depth, a.normal = (_dp(offsets), _dp(render), _dp(alpha), _dp(exp_depth),
+                                                                        _dp(med_depth), _dp(normal))
+    a.last_ids, a.median_ids = _dp(last_ids), _dp(median_ids)
+    if sched.on:
+        last = _LAST_ORDER.get(sched.key) if UNIT_ORDER_FWD else None
+        a.unit_perm_in, a.unit_work, a.unit_perm_out = _dp(last), _dp(sched.work), _dp(sched.perm)
+    else:
+        a.unit_perm_in, a.unit_work, a.unit_perm_out = None, None, None
+    while True:
+        a.payload, a.flatten_ids, a.scratch, a.cap_isects = _dp(payload), _dp(flatten_ids), _dp(scratch), cap
+        with _timed("raster_fwd_B"):
+            check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(2), stream_ptr(), _graph_cache(dev)),
+                  "misplat_raster_fwd(B)")
+        if n_known is None:
+            n_known = _wait_count(state["host"])                      # usually long there: phase B was enqueued meanwhile
+        if n_known <= cap:
+            break
+        cap = n_known                                                 # the guess was too small: exact size, once more
+        tc = state["keep"][6]                                         # tile_count: phase B expects it cleared
+        check(lib.misplat_zero_bytes(ptr(tc), C.c_size_t(4 * tc.numel()), stream_ptr()), "misplat_zero_bytes")
+        if cap >= 2 ** 31:
+            raise _lib.MisplatError(f"{cap} tile intersections exceed int32 indexing")
+        payload, flatten_ids, scratch = isect_buffers(cap)
+    _CAP_HINT[key] = n_known
+    if sched.on:
+        _LAST_ORDER[sched.key] = sched.perm
+        if sched.ppl_b == sched.ppl_f:
+            sched.perm_bwd = sched.perm
+    bins = dict(tiles_per_gauss=state["tiles_per_gauss"], n_isects=n_known, depths=state["depths"], tile_ids=None,
+                n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:n_known], isect_offsets=offsets, _keep=(scratch, payload))
+    imgs = (render.view(Cn, H, W, cd), alpha.view(Cn, H, W, 1), exp_depth.view(Cn, H, W, 1), med_depth.view(Cn, H, W, 1),
+            normal.view(Cn, H, W, 3), last_ids.view(Cn, H, W), median_ids.view(Cn, H, W))
+    return imgs, bins, sched
+
+
 # ----------------------------------------------------------------------------- fused path
 
 def _grads_of_pack(P: Params, v_means2d, v_grec):
@@ -558,6 +735,29 @@ class _ProjectPack(torch.autograd.Function):
         require_gpu(means, quats, scales, opacities, colors, viewmats, Ks)
         N, Cn = P.n_gauss, P.n_cams
         dev = means.device
+        if sh_degree is not None:
+            kd = colors.shape[1] if colors_rest is None else 1 + colors_rest.shape[1]
+            deg, n_color, per_cam = int(sh_degree), 3, 0
+        else:
+            deg, kd, per_cam = -1, colors.shape[-1], int(colors.dim() == 3)
+            n_color = kd
+        if prebin is not None and fused_entry_ok() and N > 0:
+            # one host entry: projection, row bucketing, asynchronous n_isects read-back, colours
+            want_aux = SH_AUX and deg >= 0 and any(ctx.needs_input_grad[:6])
+            radii, means2d, depths, comps, grec, sh_aux, state = _raster_phase_a(
+                P, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam,
+                depth_channel, want_aux)
+            prebin["fused"] = state
+            ctx.P, ctx.color_args = P, (deg, kd, n_color, per_cam)
+            ctx.depth_slot = 12 + n_color if depth_channel else -1
+            ctx.has_rest = colors_rest is not None
+            ctx.has_aux = sh_aux is not None
+            ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps,
+                                  colors_rest if colors_rest is not None else colors,
+                                  sh_aux if sh_aux is not None else comps)
+            ctx.mark_non_differentiable(radii, depths, comps)
+            ctx.set_materialize_grads(False)
+            return radii, means2d, depths, comps, grec
         radii = torch.empty(Cn, N, 2, device=dev, dtype=torch.int32)
         means2d = torch.empty(Cn, N, 2, device=dev, dtype=torch.float32)
         depths = torch.empty(Cn, N, device=dev, dtype=torch.float32)
@@ -565,15 +765,10 @@ class _ProjectPack(torch.autograd.Function):
         grec = torch.empty(Cn * N, MISPLAT_REC, device=dev, dtype=torch.float32)
         check(lib.misplat_project_pack_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
                                            ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
-                                           ptr(comps), ptr(grec), stream_ptr()), "misplat_project_pack_fwd")
+                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), stream_ptr()),
+              "misplat_project_pack_fwd")
         if prebin is not None:                         # count tiles + start the n_isects read-back before the colours
             prebin["pending"] = start_binning(P, means2d, radii)
-        if sh_degree is not None:
-            kd = colors.shape[1] if colors_rest is None else 1 + colors_rest.shape[1]
-            deg, n_color, per_cam = int(sh_degree), 3, 0
-        else:
-            deg, kd, per_cam = -1, colors.shape[-1], int(colors.dim() == 3)
-            n_color = kd
         # the colour slots of grec are only needed by the compositing kernels: launch on the side
         # stream so the kernel overlaps the binning chain; blend_packed() joins it
         cur = torch.cuda.current_stream()
@@ -666,6 +861,18 @@ class _BlendPacked(torch.autograd.Function):
         lib = _lib.load()
         Cn, H, W = P.n_cams, P.height, P.width
         dev = grec.device
+        if "args" in bins:                             # phase-A state of the one-entry path: buckets, sort, compositing
+            imgs, done, sched = _raster_phase_b(P, bins, cd)
+            bins.clear()
+            bins.update(done)                          # the caller's dict becomes the finished bins (meta reads it)
+            render, alpha, exp_depth, med_depth, normal, last_ids, median_ids = imgs
+            ctx.sched = sched
+            ctx.P, ctx.bins, ctx.absgrad, ctx.cd = P, bins, absgrad, cd
+            ctx.means2d_ref = means2d if absgrad else None
+            ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids, render)
+            ctx.mark_non_differentiable(last_ids, median_ids)
+            ctx.set_materialize_grads(False)
+            return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
         f = dict(device=dev, dtype=torch.float32)
         render = torch.empty(Cn, H, W, cd, **f)
         alpha = torch.empty(Cn, H, W, 1, **f)
@@ -774,7 +981,8 @@ class _ProjectPackX(torch.autograd.Function):
         featx = torch.empty(Cn * N, 4 * nxq, device=dev, dtype=torch.float32)
         check(lib.misplat_project_pack_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
                                            ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
-                                           ptr(comps), ptr(grec), stream_ptr()), "misplat_project_pack_fwd")
+                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), stream_ptr()),
+              "misplat_project_pack_fwd")
         D, per_cam = colors.shape[-1], int(colors.dim() == 3)
         check(lib.misplat_color_fwd_x(C.byref(P), C.c_int32(D), C.c_int32(per_cam), C.c_int32(int(depth_channel)),
                                       C.c_int32(nxq), ptr(colors), ptr(radii), ptr(depths), ptr(grec), ptr(featx),

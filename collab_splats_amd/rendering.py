@@ -125,8 +125,11 @@ def rasterization(
         radii, means2d, depths, comps, grec = ops.project_pack(
             means, quats, scales, opacities, cin if n_user > 0 else cin[:, :0].contiguous(), viewmats, Ks, P,
             sh_degree if n_user > 0 else None, depth_channel, prebin)
-        bins = ops.bin_tiles(P, means2d, radii, depths, pending=prebin.get("pending"))
         D = n_user + int(depth_channel)
+        if "fused" in prebin:                         # one host entry per phase (ops._raster_phase_a / _b)
+            bins = prebin["fused"]
+        else:
+            bins = ops.bin_tiles(P, means2d, radii, depths, pending=prebin.get("pending"))
         first = ops.blend_packed(means2d, grec, Ks, P, bins, absgrad, D)
         render = first[0]
         gv = grec.view(Cn, N, 16)

@@ -120,7 +120,10 @@ int misplat_sh_bwd(int32_t n_gauss, int32_t n_cams, int32_t K, int32_t degree, c
 int misplat_project_pack_fwd(const misplat_params* p, const float* means, const float* quats,
                              const float* scales, const float* opacities, const float* viewmats,
                              const float* Ks, int32_t* radii, float* means2d, float* depths,
-                             float* compensations, float* grec, misplat_stream_t stream);
+                             float* compensations, float* grec,
+                             uint32_t* zero_words /* or NULL */, int32_t n_zero /* words the kernel clears for its
+                             successors on the stream (the bucketing counters): saves a memset launch */,
+                             misplat_stream_t stream);
 /* coeffs_rest (SH only, may be NULL): when given, coeffs_or_colors is features_dc[N,3] and
  * coeffs_rest is features_rest[N,K-1,3] -- the reference's two parameter tensors
  * (rade_gs_model.py:119-120) read in place instead of through its per-step torch.cat (:128-130);
@@ -211,10 +214,11 @@ int misplat_tile_offsets16(const uint16_t* tiles_sorted, int64_t n_isects, int32
  *                 cellhist holds n_blocks * n_cells uint32, cell_count n_cells, cell_offs n_cells + 1;
  *   bucket_count  tiles_per_gauss[C*N], rect2[C*N] (x0 | y0 << 16, w | h << 16 of the tile rectangle), the
  *                 per-workgroup cell histograms, the global cell counts; counters[0] = number of intersections
- *                 (device int64; counters[2] is zeroed here on `stream`);
+ *                 (device int64; cell_count and counters[2] are zeroed here on `stream` unless already_zero);
  *   bucket_rows   cell_offs = scan of the cell counts, counters[1] = visible rows, order[0 .. n_vis) = the visible
  *                 rows in cell order; tile_count[n_tiles + 1] is cleared;
- *   bucket_tiles  offsets[0 .. n_tiles] (offsets[n_tiles] = number of intersections) and
+ *   bucket_tiles  (tile_count must be all zero on entry, as bucket_rows leaves it; it is NOT zero afterwards)
+ *                 offsets[0 .. n_tiles] (offsets[n_tiles] = number of intersections) and
  *                 payload[offsets[t] .. offsets[t + 1]) = the rows touching tile t, in arbitrary order
  *                 (misplat_tile_sort(unordered = 1) follows).  cum != NULL (deterministic backward): the payload
  *                 is the emission slot cum[row] + k and isect_gid[slot] = row.  Writes beyond cap_isects entries
@@ -225,7 +229,9 @@ int misplat_tile_offsets16(const uint16_t* tiles_sorted, int64_t n_isects, int32
 int misplat_bucket_plan(const misplat_params* p, int32_t* n_cells, int32_t* n_blocks);
 int misplat_bucket_count(const misplat_params* p, const float* means2d, const int32_t* radii,
                          int32_t* tiles_per_gauss, uint32_t* rect2, uint32_t* cellhist, uint32_t* cell_count,
-                         int64_t* counters, misplat_stream_t stream);
+                         int64_t* counters, int32_t already_zero /* cell_count and counters were cleared by an
+                         earlier kernel of the stream (misplat_project_pack_fwd's zero_words): no memset here */,
+                         misplat_stream_t stream);
 int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles_per_gauss, const uint32_t* rect2,
                         const uint32_t* cellhist, uint32_t* cell_count, uint32_t* cell_offs, int32_t* order,
                         int64_t* counters, int32_t* tile_count, misplat_stream_t stream);
@@ -362,6 +368,56 @@ int misplat_outputs_bwd(int64_t n_pix, int32_t color_dim, const float* backgroun
                         const float* v_depth_im /* or NULL */, float* v_render, float* v_alpha,
                         float* v_exp_depth, float* v_med_depth, float* v_exp_normal,
                         misplat_stream_t stream);
+
+/* ---- the whole forward of rasterization() (rade_gs_model.py:439-465) as ONE host entry: csrc/raster.hip.
+ * Every pointer is a caller-allocated device buffer of the size the per-stage entry points above document
+ * (n_isects_host: 8 bytes of PINNED host memory).
+ *   phases & 1 (A): project_pack_fwd, bucket_count, copy counters[0] -> *n_isects_host, bucket_rows, color_fwd
+ *   phases & 2 (B): bucket_tiles, tile_sort (unordered), blend_fwd (+ unit_work), unit_order
+ * B only reads device-side sizes, so it may be enqueued with a speculative cap_isects before the host knows the count:
+ * the result is exact iff the count (misplat_wait_count) is <= cap_isects (else: clear tile_count and call B again
+ * with the exact size).  Atomic gradient mode only (the deterministic slab needs the emission-slot scan between A and B). */
+typedef struct misplat_raster_args {
+    /* inputs (rasterization() arguments) */
+    const float *means, *quats, *scales, *opacities, *colors, *colors_rest, *viewmats, *Ks;
+    int32_t sh_degree;      /* -1: pass-through colours */
+    int32_t K_or_D, n_color, per_cam, depth_channel;
+    int32_t color_dim;      /* channels the compositing kernels carry (1..4) */
+    /* per (camera, Gaussian) outputs */
+    int32_t* radii;
+    float *means2d, *depths, *compensations, *grec, *sh_aux /* or NULL */;
+    /* bucketing workspace + results */
+    int32_t* tiles_per_gauss;
+    uint32_t *rect2, *cellhist, *cell_count, *cell_offs;
+    int32_t* order;
+    int64_t* counters;
+    int32_t *tile_count, *offsets, *payload, *flatten_ids;
+    uint32_t* scratch;
+    int64_t cap_isects;
+    int64_t* n_isects_host; /* pinned host memory, or NULL */
+    void* reserved1;
+    /* images */
+    float *render, *alpha, *exp_depth, *med_depth, *normal;
+    int32_t *last_ids, *median_ids;
+    /* launch order (speed only): see misplat_params.unit_perm / unit_work */
+    const int32_t* unit_perm_in;
+    int32_t *unit_work, *unit_perm_out;
+} misplat_raster_args;
+/* Graph cache (optional, caller-owned, thread-safe; the library itself keeps no state): with a cache, the launch
+ * sequence of a call is captured into a hipGraph the first time a given (params, args, phases, stream) block is seen
+ * and replayed with one hipGraphLaunch afterwards -- small scenes are launch-bound (~16 launches per forward).  The
+ * least recently used of max_entries graphs is evicted.  A cache must not outlive the device context. */
+typedef struct misplat_graph_cache misplat_graph_cache;
+misplat_graph_cache* misplat_graph_cache_create(int32_t max_entries);
+void misplat_graph_cache_destroy(misplat_graph_cache* cache);
+int misplat_graph_cache_stats(misplat_graph_cache* cache, int64_t* hits, int64_t* captures);
+int misplat_raster_fwd(const misplat_params* p, const misplat_raster_args* a, int32_t phases, misplat_stream_t stream,
+                       misplat_graph_cache* cache /* or NULL: plain launches */);
+/* Host-side wait for phase A's count: the caller stores -1 in *n_isects_host before the call; returns the count as
+ * soon as the device-to-host copy has landed, or -1 after timeout_us. */
+int64_t misplat_wait_count(const volatile int64_t* n_isects_host, int64_t timeout_us);
+/* hipMemsetAsync(dst, 0, bytes) on `stream` (used to clear tile_count before phase B is enqueued a second time). */
+int misplat_zero_bytes(void* dst, size_t bytes, misplat_stream_t stream);
 
 /* ---- optimiser step --------------------------------------------
  * Fused multi-tensor Adam with torch.optim.Adam semantics (no weight decay, no amsgrad, maximize = False),

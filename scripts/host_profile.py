@@ -1,0 +1,32 @@
+"""Where does the HOST spend a step at a small size? (cProfile of the bench step, GPU box)"""
+import cProfile, os, pstats, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from collab_splats_amd.rendering import rasterization
+from collab_splats_amd.synthetic import random_scene
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+dev = torch.device("cuda:0")
+sc = random_scene(N, W, H, seed=42)
+params = {k: sc[k].to(dev).requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+V, K = sc["viewmats"].to(dev), sc["Ks"].to(dev)
+g = torch.Generator().manual_seed(7)
+ups = [torch.rand(s, generator=g).to(dev) for s in ((1, H, W, 4), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3))]
+def step():
+    for p in params.values():
+        p.grad = None
+    out = rasterization(params["means"], params["quats"], torch.exp(params["log_scales"]), torch.sigmoid(params["opacity_logits"]),
+                        params["sh"], V, K, W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True)
+    torch.autograd.backward(list(out[:5]), ups)
+for _ in range(20): step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(200): step()
+torch.cuda.synchronize()
+print("ms/step", (time.perf_counter() - t0) / 200 * 1e3)
+pr = cProfile.Profile(); pr.enable()
+for _ in range(200): step()
+torch.cuda.synchronize(); pr.disable()
+st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)

@@ -57,6 +57,21 @@ def test_params_struct_layout_matches_c(built_lib):
     assert vals[1:] == [getattr(Params, f).offset for f in fields]
 
 
+def test_raster_args_struct_layout_matches_c(built_lib):
+    from collab_splats_amd._lib import RasterArgs
+    fields = [f[0] for f in RasterArgs._fields_]
+    src = "#include <stdio.h>\n#include <stddef.h>\n#include \"misplat.h\"\nint main(){printf(\"%zu\\n\", sizeof(misplat_raster_args));\n"
+    src += "".join(f'printf("%zu\\n", offsetof(misplat_raster_args, {f}));\n' for f in fields) + "return 0;}\n"
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
+        vals = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert vals[0] == C.sizeof(RasterArgs)
+    assert vals[1:] == [getattr(RasterArgs, f).offset for f in fields]
+
+
 @pytest.mark.gpu
 def test_sort_workspace_query(built_lib):
     from collab_splats_amd import _lib
