@@ -217,6 +217,20 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
     return hipGraphLaunch(exec, s) == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
 }
 
+// float4 streaming copy: the measured HBM roof of the box the benchmark runs on (bench.py reports fractions of it
+// next to the 8 TB/s specification).
+__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int misplat_stream_copy(const void* src, void* dst, int64_t n_float4, misplat_stream_t stream) {
+    if (n_float4 < 0 || (n_float4 > 0 && (!src || !dst))) return MISPLAT_EINVAL;
+    if (n_float4 == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst,
+                       n_float4);
+    return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+}
+
 // Clears a device buffer on `stream` (the retry of phase B clears tile_count with it: the buffers of one forward are
 // slices of one allocation, so a framework-level in-place clear would invalidate tensors saved for the backward).
 extern "C" int misplat_zero_bytes(void* dst, size_t bytes, misplat_stream_t stream) {

@@ -85,6 +85,19 @@ class _UnitSchedule:
         P.unit_perm, P.unit_work = None, None
 
 
+# Data-parallel training: a parallel.GradientBuckets object (or None).  While set, the backward of the per-Gaussian
+# stages writes parameter gradients straight into its flat buffer and tells it when the colour bucket is complete.
+GRAD_SINK = None
+
+
+def _grad_out(inp: Tensor) -> Tensor:
+    if GRAD_SINK is not None:
+        v = GRAD_SINK.sink(inp)
+        if v is not None:
+            return v
+    return torch.empty_like(inp)
+
+
 # Optional per-kernel timing (bench.py): name -> list of (start_event, end_event) recorded on the
 # current stream, i.e. the stream the kernels are launched on.  None = off (no events recorded).
 KERNEL_EVENTS: Optional[Dict[str, list]] = None
@@ -809,8 +822,8 @@ class _ProjectPack(torch.autograd.Function):
         P = ctx.P
         deg, kd, n_color, per_cam = ctx.color_args
         v_means2d, v_grec = _grads_of_pack(P, v_means2d, v_grec)
-        v_colors = torch.empty_like(colors)
-        v_colors_rest = torch.empty_like(colors_rest) if colors_rest is not None else None
+        v_colors = _grad_out(colors)
+        v_colors_rest = _grad_out(colors_rest) if colors_rest is not None else None
         v_means_dir = torch.empty_like(means) if deg >= 0 else None
         cur = torch.cuda.current_stream()
         side = _side_stream(means.device) if OVERLAP else cur
@@ -824,8 +837,10 @@ class _ProjectPack(torch.autograd.Function):
                                         C.c_int32(per_cam), ptr(means), ptr(viewmats), ptr(colors), ptr(colors_rest),
                                         ptr(radii), ptr(v_grec), ptr(v_colors), ptr(v_colors_rest), ptr(v_means_dir),
                                         ptr(sh_aux), stream_ptr()), "misplat_color_bwd")
-        v_means, v_quats = torch.empty_like(means), torch.empty_like(quats)
-        v_scales, v_opac = torch.empty_like(scales), torch.empty_like(opacities)
+        if GRAD_SINK is not None and side is cur:
+            GRAD_SINK.colour_ready()                   # the colour bucket's all-reduce starts now, overlapped with the rest
+        v_means, v_quats = _grad_out(means), _grad_out(quats)
+        v_scales, v_opac = _grad_out(scales), _grad_out(opacities)
         fused_dir = v_means_dir if side is cur else None        # overlapped: add the SH direction term afterwards
         check(lib.misplat_project_pack_bwd(C.byref(P), C.c_int32(ctx.depth_slot), ptr(means), ptr(quats),
                                            ptr(scales), ptr(opacities), ptr(viewmats), ptr(Ks), ptr(radii),

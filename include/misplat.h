@@ -434,6 +434,10 @@ int misplat_adam_step(int32_t n_tensors, float* const* params, const float* cons
                       const float* lr, const int64_t* step, double beta1, double beta2, double eps,
                       misplat_stream_t stream);
 
+/* Measurement helper: dst[i] = src[i] over n_float4 16-byte elements (a plain streaming copy; bench.py times it to
+ * report the HBM roof of the box it runs on). */
+int misplat_stream_copy(const void* src, void* dst, int64_t n_float4, misplat_stream_t stream);
+
 /* Library identification ("misplat <version> gfx950"). */
 const char* misplat_version(void);
 
