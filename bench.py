@@ -78,6 +78,10 @@ def git_rev() -> str:
     try:
         return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
     except Exception:
+        pass
+    try:                                              # no .git on the GPU box: the revision the library was built from
+        return open(os.path.join(ROOT, "collab_splats_amd", "_build_rev.txt")).read().strip()
+    except Exception:
         return "unknown"
 
 

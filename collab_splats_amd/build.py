@@ -72,6 +72,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
             list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs)
+    try:                                              # the source revision travels with the library (the GPU box has no .git)
+        rev = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        dirty = subprocess.call(["git", "-C", ROOT, "diff", "--quiet", "HEAD", "--", "collab_splats_amd", "include", "bench.py"]) != 0
+        with open(os.path.join(HERE, "_build_rev.txt"), "w") as f:
+            f.write(rev + ("+" if dirty else "") + "\n")
+    except Exception:
+        pass
     return LIB
 
 
