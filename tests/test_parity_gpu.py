@@ -1065,15 +1065,15 @@ def test_one_entry_forward_speculation_and_graph_replay_change_nothing(dev):
 
 def test_speculative_capacity_overflow_is_detected_and_redone_exactly(dev):
     """A capacity guessed from the previous call that turns out too small must not change anything: the second scene
-    has the same shape but ~6x the intersections of the first, so the speculative launch overflows and phase B runs
+    has the same shape but several times the intersections of the first, so the speculative launch overflows and phase B runs
     again with the exact size."""
     from collab_splats_amd import ops
     small = _bench_like_scene(dev, 20_000, 480, 270, seed=8)
-    big = _bench_like_scene(dev, 20_000, 480, 270, seed=8, scale_mul=3.0)
+    big = _bench_like_scene(dev, 20_000, 480, 270, seed=8, scale_mul=5.0)
     ref_img, ref_grad, ref_meta = _fwd_bwd(big, FUSED_ENTRY=False)
     ops._CAP_HINT.clear()
     _, _, m_small = _fwd_bwd(small, FUSED_ENTRY=True, SPECULATE=True)
-    assert ref_meta["n_isects"] > 2 * ops._quantise_cap(int(m_small["n_isects"] * ops.CAP_MARGIN))     # it WILL overflow
+    assert ref_meta["n_isects"] > 1.5 * ops._quantise_cap(int(m_small["n_isects"] * ops.CAP_MARGIN))     # it WILL overflow
     img, grad, meta = _fwd_bwd(big, FUSED_ENTRY=True, SPECULATE=True)
     assert meta["n_isects"] == ref_meta["n_isects"] == int(meta["tiles_per_gauss"].sum())
     assert torch.equal(meta["flatten_ids"], ref_meta["flatten_ids"])
@@ -1102,11 +1102,11 @@ def test_unit_order_is_a_permutation_sorted_by_measured_work(dev):
     work = work.cpu().numpy()
     real = perm[perm < units]
     assert np.array_equal(np.sort(real), np.arange(units)) and (perm[perm >= units] == units).all()
-    top = max(int(work.max()), 1)
     for x in range(8):
         strip = perm[x::8]
         strip = strip[strip < units]
         assert ((strip >= x * per) & (strip < (x + 1) * per)).all()                  # strips keep their XCD
+        top = max(int(work[x * per:min((x + 1) * per, units)].max()), 1)              # classes are relative to the strip's maximum
         cls = (work[strip].astype(np.float32) * np.float32(255.0 / top)).astype(np.int64)
         assert (np.diff(cls) <= 0).all()                                               # descending work classes
 
