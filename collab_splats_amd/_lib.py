@@ -46,7 +46,7 @@ class RasterArgs(C.Structure):
                 + [(n, C.c_int32) for n in ("sh_degree", "K_or_D", "n_color", "per_cam", "depth_channel", "color_dim")]
                 + [(n, C.c_void_p) for n in ("radii", "means2d", "depths", "compensations", "grec", "sh_aux",
                                              "tiles_per_gauss", "rect2", "cellhist", "cell_count", "cell_offs", "order",
-                                             "counters", "tile_count", "offsets", "payload", "flatten_ids", "scratch")]
+                                             "rect_sorted", "counters", "tile_count", "offsets", "payload", "flatten_ids", "scratch")]
                 + [("cap_isects", C.c_int64)]
                 + [(n, C.c_void_p) for n in ("n_isects_host", "reserved1", "render", "alpha", "exp_depth", "med_depth",
                                              "normal", "last_ids", "median_ids", "unit_perm_in", "unit_work",
@@ -91,7 +91,7 @@ SYMBOLS = {
     "misplat_blend_fwd_x": (C.c_int, 17), "misplat_blend_bwd_x_atomic": (C.c_int, 22),
     "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 19), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),
     "misplat_depth_normal_bwd": (C.c_int, 14), "misplat_outputs_fwd": (C.c_int, 15), "misplat_outputs_bwd": (C.c_int, 16),
-    "misplat_bucket_plan": (C.c_int, 3), "misplat_bucket_count": (C.c_int, 10), "misplat_bucket_rows": (C.c_int, 10),
+    "misplat_bucket_plan": (C.c_int, 3), "misplat_bucket_count": (C.c_int, 10), "misplat_bucket_rows": (C.c_int, 11),
     "misplat_bucket_tiles": (C.c_int, 11),
     "misplat_unit_order": (C.c_int, 5), "misplat_raster_fwd": (C.c_int, 5), "misplat_graph_cache_create": (C.c_void_p, 1),
     "misplat_graph_cache_destroy": (None, 1), "misplat_graph_cache_stats": (C.c_int, 3), "misplat_wait_count": (C.c_int64, 2), "misplat_zero_bytes": (C.c_int, 3), "misplat_stream_copy": (C.c_int, 4),

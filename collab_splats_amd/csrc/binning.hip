@@ -126,7 +126,9 @@ __global__ __launch_bounds__(256) void isect_ids_kernel(const uint32_t* __restri
 // rare classes): a contiguous chunk per workgroup, first tested in parallel (one tile per thread) so that
 // workgroups without a bucket of the class leave after one round of loads instead of a serial walk.
 __device__ __forceinline__ bool tile_range(const int32_t* __restrict__ offsets, int n_tiles, int64_t n_isects, int lo,
-                                           int hi, int& t_first, int& t_last, int& t_step) {
+                                           int hi, int& t_first, int& t_last, int& t_step, int has_longest) {
+    // offsets[n_tiles + 1] (when present) is the longest bucket: a size class above it has nothing to do
+    if (has_longest && offsets[n_tiles + 1] <= lo) return false;
     if ((int)gridDim.x >= n_tiles) {
         t_first = blockIdx.x; t_last = n_tiles; t_step = gridDim.x;
         return true;
@@ -288,11 +290,11 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
                                                                    const float* __restrict__ depths,
                                                                    const int32_t* __restrict__ isect_gid,
                                                                    int32_t* __restrict__ payload,
-                                                                   int32_t* __restrict__ flatten_ids) {
+                                                                   int32_t* __restrict__ flatten_ids, int has_longest) {
     __shared__ tile_sort_lds<WAVES, R> L;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int t_first, t_last, t_step;
-    if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step)) return;
+    if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step, has_longest)) return;
     for (int t = t_first; t < t_last; t += t_step) {
         const int end = min(offsets[t + 1], (int)n_isects);     // offsets: n_tiles + 1 entries; n_isects: buffer capacity
         const int beg = min(offsets[t], end);
@@ -358,10 +360,10 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __
                                                                const int32_t* __restrict__ isect_gid,
                                                                int32_t* __restrict__ payload,
                                                                int32_t* __restrict__ flatten_ids,
-                                                               uint32_t* __restrict__ scratch) {
+                                                               uint32_t* __restrict__ scratch, int has_longest) {
     extern __shared__ uint32_t lds32[];
     int t_first, t_last, t_step;
-    if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step)) return;
+    if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step, has_longest)) return;
     for (int t = t_first; t < t_last; t += t_step) {
     const int end = min(offsets[t + 1], (int)n_isects);
     const int beg = min(offsets[t], end);
@@ -698,7 +700,7 @@ extern "C" int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* fl
 template <bool HAS_VALS, bool UNORDERED>
 static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
                             const int32_t* isect_gid, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,
-                            hipStream_t s) {
+                            int has_longest, hipStream_t s) {
     // size classes (entries per bucket): <=1024 | <=4096 | <=8192 | longer (global scratch).  Every class walks
     // all tiles and skips buckets of the other classes.  A class that the typical bucket (n_isects / n_tiles)
     // can reach gets one workgroup per tile; the others get a small grid whose workgroups test their chunk of
@@ -707,37 +709,35 @@ static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_i
     const int full = n_tiles < 65536 ? n_tiles : 65536;
     const int few = n_tiles < 256 ? n_tiles : 256;
     hipLaunchKernelGGL((tile_sort_reg_kernel<4, 4, HAS_VALS, UNORDERED>), dim3(full), dim3(256), 0, s, offsets, n_tiles,
-                       n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids);
+                       n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
     hipLaunchKernelGGL((tile_sort_reg_kernel<8, 8, HAS_VALS, UNORDERED>), dim3(avg >= 1024 ? full : few), dim3(512), 0, s,
-                       offsets, n_tiles, n_isects, 1024, 4096, depths, isect_gid, payload, flatten_ids);
+                       offsets, n_tiles, n_isects, 1024, 4096, depths, isect_gid, payload, flatten_ids, has_longest);
     hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS, UNORDERED>), dim3(avg >= 2048 ? full : few), dim3(1024), 0,
-                       s, offsets, n_tiles, n_isects, 4096, 8192, depths, isect_gid, payload, flatten_ids);
+                       s, offsets, n_tiles, n_isects, 4096, 8192, depths, isect_gid, payload, flatten_ids, has_longest);
     hipLaunchKernelGGL((tile_sort_kernel<0, 16, HAS_VALS, true, UNORDERED>), dim3(avg >= 4096 ? full : (few < 64 ? few : 64)),
                        dim3(1024), (size_t)16 * 256 * 4, s, offsets, n_tiles, n_isects, 8192, 0x7fffffff, depths,
-                       isect_gid, payload, flatten_ids, scratch);
+                       isect_gid, payload, flatten_ids, scratch, has_longest);
     return check_launch();
 }
 
 extern "C" int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
                                  const float* depths, const int32_t* isect_gid, int32_t* payload,
-                                 int32_t* flatten_ids, uint32_t* scratch, int32_t unordered,
+                                 int32_t* flatten_ids, uint32_t* scratch, int32_t flags,
                                  misplat_stream_t stream) {
-    if (n_isects < 0 || n_tiles_total < 1 || n_isects > 0x7fffffffLL || !scratch) return MISPLAT_EINVAL;
+    if (n_isects < 0 || n_tiles_total < 1 || n_isects > 0x7fffffffLL || !scratch || (flags & ~3)) return MISPLAT_EINVAL;
     if (n_isects == 0) return MISPLAT_OK;
     hipStream_t s = (hipStream_t)stream;
+    const int unordered = flags & 1, has_longest = (flags >> 1) & 1;
     if (isect_gid)
         return unordered ? launch_tile_sort<true, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
-                                                        flatten_ids, scratch, s)
+                                                        flatten_ids, scratch, has_longest, s)
                          : launch_tile_sort<true, false>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
-                                                         flatten_ids, scratch, s);
+                                                         flatten_ids, scratch, has_longest, s);
     return unordered ? launch_tile_sort<false, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
-                                                     flatten_ids, scratch, s)
+                                                     flatten_ids, scratch, has_longest, s)
                      : launch_tile_sort<false, false>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
-                                                      flatten_ids, scratch, s);
+                                                      flatten_ids, scratch, has_longest, s);
 }
-
-
-
 
 extern "C" int misplat_tile_count_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
                                          int32_t* tiles_per_gauss, int32_t* block_sums, int64_t* block_offs,

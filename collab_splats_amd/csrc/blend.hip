@@ -573,6 +573,11 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                                          ATOMIC ? nullptr : slots, xlo, xhi, ylo, yhi, amin, smx, featx);
         __syncthreads();
         if (n == 0) continue;
+        // does any pixel of the band take its median depth from a Gaussian of this batch?
+        bool mine_med = false;
+#pragma unroll
+        for (int k = 0; k < PPL; k++) mine_med |= (unsigned)(medi[k] - bs) < 64u;
+        const bool batch_has_median = __ballot(mine_med) != 0ull;
         // The record of the next Gaussian is fetched from LDS into the SAME registers right after the last
         // use of the current one (before the butterfly, which hides the latency): no second register set
         // and no copies.
@@ -594,10 +599,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
             float ab0 = 0.f, ab1 = 0.f;
             float amx = 0.f;
             if constexpr (PPL % 2 == 0) {
-                // Two pixels of the lane at a time in 2-vectors: on gfx950 v_pk_{fma,mul,add}_f32 process both at
-                // the price of one instruction, so everything but the transcendentals, compares and selects is
-                // halved.  Per-component sums stay packed until one horizontal add in front of the butterfly.
-                v2f accv[16], accxv[16];
+                // Two pixels of the lane at a time in 2-vectors (v_pk_{fma,mul,add}_f32) for the per-pixel chain.
                 const float dxx = dx * dx, ndx = -dx;
                 const float c1x = 2.0f * q0.z * dx, c1y = q0.w * dx;
 #pragma unroll
@@ -633,9 +635,11 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                     v_a.x = ok0 ? v_a.x : 0.f; v_a.y = ok1 ? v_a.y : 0.f;
                     B2[kp] += w * dot;
                     v2f vz = w * vd2[kp];
-                    v2f vmed;
-                    vmed.x = (ok0 && i == medi[k0]) ? vm2[kp].x : 0.f; vmed.y = (ok1 && i == medi[k1]) ? vm2[kp].y : 0.f;
-                    vz += vmed;
+                    if (batch_has_median) {          // wave-uniform: most batches hold no pixel's median Gaussian
+                        v2f vmed;
+                        vmed.x = (ok0 && i == medi[k0]) ? vm2[kp].x : 0.f; vmed.y = (ok1 && i == medi[k1]) ? vm2[kp].y : 0.f;
+                        vz += vmed;
+                    }
                     const v2f vzl = vz * il2[kp];
                     v2f vam;
                     vam.x = (ov.x <= amax) ? v_a.x : 0.f; vam.y = (ov.y <= amax) ? v_a.y : 0.f;
@@ -644,26 +648,31 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                     const v2f vmx = (c1x + q0.w * dy) * v_e - vzl * q1.w;
                     const v2f vmy = (2.0f * q1.x * dy + c1y) * v_e - vzl * q2.x;
                     // first pair: plain products, later pairs (PPL 4): fused accumulate
-#define MISPLAT_ACC(dst, val) do { if (kp == 0) dst = (val); else dst += (val); } while (0)
-                    MISPLAT_ACC(accv[0], vmx); MISPLAT_ACC(accv[1], vmy);
-                    MISPLAT_ACC(accv[2], dxx * v_e); MISPLAT_ACC(accv[3], dx * dyve); MISPLAT_ACC(accv[4], dy * dyve);
-                    MISPLAT_ACC(accv[5], vis * vam);
-                    MISPLAT_ACC(accv[6], vzl); MISPLAT_ACC(accv[7], ndx * vzl); MISPLAT_ACC(accv[8], -(vzl * dy));
-                    MISPLAT_ACC(accv[9], w * vn2[kp][0]); MISPLAT_ACC(accv[10], w * vn2[kp][1]);
-                    MISPLAT_ACC(accv[11], w * vn2[kp][2]);
-                    MISPLAT_ACC(accv[12], w * vcol2[kp][0]);
-                    if (CD > 1) MISPLAT_ACC(accv[13], w * vcol2[kp][CD > 1 ? 1 : 0]);
-                    if (CD > 2) MISPLAT_ACC(accv[14], w * vcol2[kp][CD > 2 ? 2 : 0]);
-                    if (CD > 3) MISPLAT_ACC(accv[15], w * vcol2[kp][CD > 3 ? 3 : 0]);
+                    // Per-Gaussian sums over the lane's pixels.  A packed multiply costs two plain issue slots on gfx950
+                    // (scripts/ubench/valu_rates.hip), so forming 16 packed products and then adding their halves
+                    // (16 v_pk_mul + 16 v_add = 48 slots) loses against scalar mul + fma on the halves (<= 2 per
+                    // component); sums that share a factor are factored (dxx * (v_e.x + v_e.y), ...): 28 slots.
+#define MISPLAT_DOT2(dst, A, B) do { if (kp == 0) dst = fmaf((A).y, (B).y, (A).x * (B).x);                       \
+                                     else dst = fmaf((A).y, (B).y, fmaf((A).x, (B).x, dst)); } while (0)
+#define MISPLAT_ADD1(dst, val) do { if (kp == 0) dst = (val); else dst += (val); } while (0)
+                    const float s_ve = v_e.x + v_e.y, s_dyve = dyve.x + dyve.y, s_vzl = vzl.x + vzl.y;
+                    MISPLAT_ADD1(acc[0], vmx.x + vmx.y); MISPLAT_ADD1(acc[1], vmy.x + vmy.y);
+                    MISPLAT_ADD1(acc[2], dxx * s_ve); MISPLAT_ADD1(acc[3], dx * s_dyve); MISPLAT_DOT2(acc[4], dy, dyve);
+                    MISPLAT_DOT2(acc[5], vis, vam);
+                    MISPLAT_ADD1(acc[6], s_vzl); MISPLAT_ADD1(acc[7], ndx * s_vzl);
+                    { const v2f nvzl = -vzl; MISPLAT_DOT2(acc[8], nvzl, dy); }
+                    MISPLAT_DOT2(acc[9], w, vn2[kp][0]); MISPLAT_DOT2(acc[10], w, vn2[kp][1]);
+                    MISPLAT_DOT2(acc[11], w, vn2[kp][2]);
+                    MISPLAT_DOT2(acc[12], w, vcol2[kp][0]);
+                    if (CD > 1) MISPLAT_DOT2(acc[13], w, vcol2[kp][CD > 1 ? 1 : 0]);
+                    if (CD > 2) MISPLAT_DOT2(acc[14], w, vcol2[kp][CD > 2 ? 2 : 0]);
+                    if (CD > 3) MISPLAT_DOT2(acc[15], w, vcol2[kp][CD > 3 ? 3 : 0]);
 #pragma unroll
-                    for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) MISPLAT_ACC(accxv[ch], w * vcolx2[kp][ch]);
-#undef MISPLAT_ACC
+                    for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) MISPLAT_DOT2(accx[ch], w, vcolx2[kp][ch]);
+#undef MISPLAT_DOT2
+#undef MISPLAT_ADD1
                     if (ABS) { ab0 += fabsf(vmx.x) + fabsf(vmx.y); ab1 += fabsf(vmy.x) + fabsf(vmy.y); }
                 }
-#pragma unroll
-                for (int r = 0; r < 12 + CD; r++) acc[r] = accv[r].x + accv[r].y;
-#pragma unroll
-                for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) accx[ch] = accxv[ch].x + accxv[ch].y;
             } else {
 #pragma unroll
                 for (int k = 0; k < PPL; k++) {

@@ -32,7 +32,8 @@ namespace {
 
 constexpr int kCountThreads = 1024;     // few, large counting workgroups: one global atomic per (workgroup, cell)
 constexpr int kRowsPerWg = 1024;        // rows of order[] per workgroup of the tile passes (one per thread)
-constexpr int kWinMax = 2048;           // LDS window: at most this many tiles
+constexpr int kWinMax = 2560;           // LDS window: (width + 1) * (height + 1) <= this
+constexpr int kOwnerChunk = 8 * kRowsPerWg;     // outputs whose owners are resolved at once (8 per thread)
 constexpr int kSmallRect = 16;          // rectangles up to 16 x 16 tiles take part in the window
 
 struct CellGrid {
@@ -176,7 +177,8 @@ __global__ __launch_bounds__(1024) void bucket_cell_scan_kernel(int n_cells, uin
 __global__ __launch_bounds__(kCountThreads) void bucket_rows_kernel(
     int64_t total, int n_gauss, int shift, int cells_x, int cells_per_cam, int n_cells, int rows_per_block,
     const int32_t* __restrict__ tiles_per_gauss, const uint2* __restrict__ rect2, const uint32_t* __restrict__ cellhist,
-    const uint32_t* __restrict__ cell_offs, uint32_t* __restrict__ cell_cursor, int32_t* __restrict__ order) {
+    const uint32_t* __restrict__ cell_offs, uint32_t* __restrict__ cell_cursor, int32_t* __restrict__ order,
+    uint2* __restrict__ rect_sorted) {
     __shared__ uint32_t base[MISPLAT_BUCKET_MAX_CELLS];
     for (int c = threadIdx.x; c < n_cells; c += kCountThreads) {
         const uint32_t h = cellhist[(size_t)blockIdx.x * n_cells + c];
@@ -189,59 +191,68 @@ __global__ __launch_bounds__(kCountThreads) void bucket_rows_kernel(
         if (tiles_per_gauss[idx] > 0) {
             const uint2 r2 = rect2[idx];
             const int c = cell_of(r2.x, r2.y, (int)(idx / n_gauss), shift, cells_x, cells_per_cam);
-            order[atomicAdd(&base[c], 1u)] = (int32_t)idx;       // LDS cursor: any order inside a cell will do
+            const uint32_t pos = atomicAdd(&base[c], 1u);        // LDS cursor: any order inside a cell will do
+            order[pos] = (int32_t)idx;
+            rect_sorted[pos] = r2;                               // the tile passes read rectangles without a gather
         }
     }
 }
 
 // ---- 3. tile passes over order[] -----------------------------------------------------------------------------
-// Shared prologue of the count and the fill pass: load up to 1024 consecutive rows of order[], publish their
-// rectangles and the exclusive scan of their tile counts in LDS, and choose the workgroup's tile WINDOW: the
-// bounding box of the "small" rectangles (<= 16 x 16 tiles) of the first row's camera, if it has at most
-// kWinMax tiles.  Intersections inside the window are counted in LDS; the rest (large rectangles, a second
-// camera in the same workgroup, an oversized box) go to global atomics one by one.
+// Shared prologue of the count and the fill pass: load up to 1024 consecutive rows of order[] and choose the
+// workgroup's tile WINDOW: the bounding box of the "small" rectangles (<= 16 x 16 tiles) of the first row's camera,
+// if (width + 1) * (height + 1) <= kWinMax.  The number of the workgroup's intersections per window tile is obtained
+// WITHOUT visiting the intersections: every rectangle adds +1 / -1 at its four corners of a difference array in LDS
+// (four LDS atomics per row instead of one per intersection), and a 2-D prefix sum turns that into the counts.
+// Rows that take no part in the window (large rectangles, a second camera in the same workgroup, an oversized box)
+// touch global memory tile by tile.
 struct TileWg {
-    uint32_t excl[kRowsPerWg];      // exclusive scan of the tile counts
-    uint32_t xy[kRowsPerWg];        // x0 | y0 << 16
-    uint32_t wflag[kRowsPerWg];     // rectangle width | in_window << 31
-    float rw[kRowsPerWg];           // 1 / width
+    uint4 info[kRowsPerWg];         // (fill pass) per row: exclusive scan of the tile counts | x0 | y0 << 16 |
+                                    //   rectangle width | in_window << 31 | bits of 1 / width
     int32_t row[kRowsPerWg];
-    uint32_t tab[kWinMax];
+    int32_t tab[kWinMax];           // difference array -> counts (stride ww + 1) -> (fill pass) cursors
     uint32_t wsum[kRowsPerWg / 64];
     int bb[4];                      // min x, min y, max x, max y of the small rectangles
     uint32_t total;
 };
 
+// Loads the rows, publishes rectangles (and, SCAN: the exclusive scan of their tile counts), finds the window and
+// leaves the per-tile counts of the window rows in L.tab[(y - wy0) * (ww + 1) + (x - wx0)].  Returns this thread's
+// row (or -1), its rectangle and whether it takes part in the window.
+template <bool SCAN>
 __device__ __forceinline__ void tile_wg_prologue(TileWg& L, int64_t n_vis, int n_gauss, const int32_t* __restrict__ order,
                                                  const uint2* __restrict__ rect2, int& cam0, int& wx0, int& wy0, int& ww,
-                                                 int& wh) {
+                                                 int& wh, int32_t& my_row, uint2& my_rect, bool& my_in) {
     const int64_t first = (int64_t)blockIdx.x * kRowsPerWg;
     if (threadIdx.x == 0) { L.bb[0] = 0x7fffffff; L.bb[1] = 0x7fffffff; L.bb[2] = -1; L.bb[3] = -1; }
     cam0 = (int)(order[first] / n_gauss);                       // first < n_vis is guaranteed by the caller
     __syncthreads();
-    // element e = thread
     const int e = threadIdx.x;
     const int64_t pos = first + e;
     uint32_t cnt = 0u, xy = 0u, wf = 1u;
-    int32_t r = 0;
+    int32_t r = -1;
+    uint2 r2 = make_uint2(0u, 0u);
     int mnx = 0x7fffffff, mny = 0x7fffffff, mxx = -1, mxy = -1;
+    bool in = false;
     if (pos < n_vis) {
         r = order[pos];
-        const uint2 r2 = rect2[r];
+        r2 = rect2[pos];                                         // rectangles in order[] order (bucket_rows)
         const int w = (int)(r2.y & 0xffffu), h = (int)(r2.y >> 16);
         const int x0 = (int)(r2.x & 0xffffu), y0 = (int)(r2.x >> 16);
         cnt = (uint32_t)(w * h);
         xy = r2.x;
         wf = (uint32_t)w;
         if (w <= kSmallRect && h <= kSmallRect && (int)(r / n_gauss) == cam0) {
-            wf |= 0x80000000u;
+            in = true;
             mnx = x0; mny = y0; mxx = x0 + w - 1; mxy = y0 + h - 1;
         }
     }
-    L.xy[e] = xy; L.wflag[e] = wf; L.rw[e] = 1.0f / (float)(wf & 0xffffu); L.row[e] = r;
-    const uint32_t incl = wave_scan_add(cnt);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 63) L.wsum[wave] = incl;
+    uint32_t incl = 0u;
+    if (SCAN) {
+        incl = wave_scan_add(cnt);
+        if (lane == 63) L.wsum[wave] = incl;
+    }
     // wave-level min / max before the LDS atomics
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -252,36 +263,54 @@ __device__ __forceinline__ void tile_wg_prologue(TileWg& L, int64_t n_vis, int n
         atomicMin(&L.bb[0], mnx); atomicMin(&L.bb[1], mny); atomicMax(&L.bb[2], mxx); atomicMax(&L.bb[3], mxy);
     }
     __syncthreads();
-    uint32_t before = incl - cnt, all = 0u;
-#pragma unroll
-    for (int w = 0; w < kRowsPerWg / 64; w++) { before += (w < wave) ? L.wsum[w] : 0u; all += L.wsum[w]; }
-    L.excl[e] = before;
-    if (threadIdx.x == 0) L.total = all;
     wx0 = L.bb[0]; wy0 = L.bb[1];
     ww = L.bb[2] >= 0 ? L.bb[2] - L.bb[0] + 1 : 0;
     wh = L.bb[2] >= 0 ? L.bb[3] - L.bb[1] + 1 : 0;
-    if ((int64_t)ww * wh > kWinMax) { ww = 0; wh = 0; }         // oversized box: everything goes the slow way
-    for (int i = threadIdx.x; i < ww * wh; i += kRowsPerWg) L.tab[i] = 0u;
+    if ((int64_t)(ww + 1) * (wh + 1) > kWinMax) { ww = 0; wh = 0; }     // oversized box: everything goes the slow way
+    in = in && ww > 0;
+    if (SCAN) {
+        uint32_t before = incl - cnt, all = 0u;
+#pragma unroll
+        for (int w = 0; w < kRowsPerWg / 64; w++) { before += (w < wave) ? L.wsum[w] : 0u; all += L.wsum[w]; }
+        if (threadIdx.x == 0) L.total = all;
+        L.info[e] = make_uint4(before, xy, wf | (in ? 0x80000000u : 0u), __float_as_uint(1.0f / (float)(wf & 0xffffu)));
+        L.row[e] = r;
+    }
+    const int stride = ww + 1;
+    const int n_tab = ww > 0 ? stride * (wh + 1) : 0;
+    for (int i = threadIdx.x; i < n_tab; i += kRowsPerWg) L.tab[i] = 0;
     __syncthreads();
+    if (in) {                                                    // +1 / -1 at the four corners
+        const int x0 = (int)(r2.x & 0xffffu) - wx0, y0 = (int)(r2.x >> 16) - wy0;
+        const int x1 = x0 + (int)(r2.y & 0xffffu), y1 = y0 + (int)(r2.y >> 16);
+        atomicAdd(&L.tab[y0 * stride + x0], 1);
+        atomicAdd(&L.tab[y0 * stride + x1], -1);
+        atomicAdd(&L.tab[y1 * stride + x0], -1);
+        atomicAdd(&L.tab[y1 * stride + x1], 1);
+    }
+    __syncthreads();
+    // 2-D inclusive prefix sum: along x (one thread per window row), then along y (one thread per window column)
+    for (int y = threadIdx.x; y < wh; y += kRowsPerWg) {
+        int run = 0;
+        for (int x = 0; x < ww; x++) { run += L.tab[y * stride + x]; L.tab[y * stride + x] = run; }
+    }
+    __syncthreads();
+    for (int x = threadIdx.x; x < ww; x += kRowsPerWg) {
+        int run = 0;
+        for (int y = 0; y < wh; y++) { run += L.tab[y * stride + x]; L.tab[y * stride + x] = run; }
+    }
+    __syncthreads();
+    my_row = r; my_rect = r2; my_in = in;
 }
 
-// output o of the workgroup -> (element e, tile x, tile y, offset inside the row)
-__device__ __forceinline__ void tile_wg_decode(const TileWg& L, uint32_t o, int& e, int& tx, int& ty, uint32_t& q) {
-    int lo = 0, hi = kRowsPerWg - 1;                             // largest e with excl[e] <= o (empty rows never win)
-#pragma unroll
-    for (int it = 0; it < 10; it++) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (L.excl[mid] <= o) lo = mid; else hi = mid - 1;
-    }
-    e = lo;
-    q = o - L.excl[lo];
-    const uint32_t w = L.wflag[lo] & 0xffffu;
-    // (q + 0.5) / w is at least 0.5 / w away from an integer: the float quotient truncates exactly
-    const uint32_t ry = (uint32_t)(((float)q + 0.5f) * L.rw[lo]);
-    const uint32_t rx = q - ry * w;
-    const uint32_t pxy = L.xy[lo];
-    tx = (int)((pxy & 0xffffu) + rx);
-    ty = (int)((pxy >> 16) + ry);
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {      // inclusive; lane 63 holds the wave maximum
+    x = max(x, dpp_take<0x111, 0xF>(0u, x));
+    x = max(x, dpp_take<0x112, 0xF>(0u, x));
+    x = max(x, dpp_take<0x114, 0xF>(0u, x));
+    x = max(x, dpp_take<0x118, 0xF>(0u, x));
+    x = max(x, dpp_take<0x142, 0xA>(0u, x));
+    x = max(x, dpp_take<0x143, 0xC>(0u, x));
+    return x;
 }
 
 __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_count_kernel(
@@ -291,19 +320,21 @@ __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_count_kernel(
     const int64_t n_vis = counters[1];
     if ((int64_t)blockIdx.x * kRowsPerWg >= n_vis) return;
     int cam0, wx0, wy0, ww, wh;
-    tile_wg_prologue(L, n_vis, n_gauss, order, rect2, cam0, wx0, wy0, ww, wh);
-    const uint32_t total = L.total;
-    for (uint32_t o = threadIdx.x; o < total; o += kRowsPerWg) {
-        int e, tx, ty;
-        uint32_t q;
-        tile_wg_decode(L, o, e, tx, ty, q);
-        if (ww > 0 && (L.wflag[e] >> 31)) atomicAdd(&L.tab[(ty - wy0) * ww + (tx - wx0)], 1u);
-        else atomicAdd(&tile_count[(L.row[e] / n_gauss) * tiles_per_cam + ty * tw + tx], 1);
+    int32_t r;
+    uint2 r2;
+    bool in;
+    tile_wg_prologue<false>(L, n_vis, n_gauss, order, rect2, cam0, wx0, wy0, ww, wh, r, r2, in);
+    if (r >= 0 && !in) {                                         // a row outside the window: tile by tile, global
+        const int x0 = (int)(r2.x & 0xffffu), y0 = (int)(r2.x >> 16), w = (int)(r2.y & 0xffffu), h = (int)(r2.y >> 16);
+        int32_t* base = tile_count + (r / n_gauss) * tiles_per_cam;
+        for (int y = y0; y < y0 + h; y++)
+            for (int x = x0; x < x0 + w; x++) atomicAdd(&base[y * tw + x], 1);
     }
-    __syncthreads();
+    const int stride = ww + 1;
     for (int i = threadIdx.x; i < ww * wh; i += kRowsPerWg) {
-        const uint32_t c = L.tab[i];
-        if (c) atomicAdd(&tile_count[cam0 * tiles_per_cam + (wy0 + i / ww) * tw + wx0 + i % ww], (int32_t)c);
+        const int y = i / ww, x = i - y * ww;
+        const int c = L.tab[y * stride + x];
+        if (c) atomicAdd(&tile_count[cam0 * tiles_per_cam + (wy0 + y) * tw + wx0 + x], c);
     }
 }
 
@@ -312,10 +343,11 @@ __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_count_kernel(
 __global__ __launch_bounds__(1024) void bucket_tile_scan_kernel(int n_tiles, int32_t* __restrict__ tile_count,
                                                                 int32_t* __restrict__ offsets) {
     __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
+    __shared__ uint32_t carry_s, longest_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) carry_s = 0u;
+    if (threadIdx.x == 0) { carry_s = 0u; longest_s = 0u; }
     __syncthreads();
+    uint32_t longest = 0u;
     for (int base = 0; base < n_tiles; base += 4096) {
         // thread t owns tiles base + 4t .. base + 4t + 3 (one 16-byte load)
         const int i0 = base + 4 * threadIdx.x;
@@ -323,6 +355,7 @@ __global__ __launch_bounds__(1024) void bucket_tile_scan_kernel(int n_tiles, int
 #pragma unroll
         for (int j = 0; j < 4; j++) c[j] = (i0 + j < n_tiles) ? (uint32_t)tile_count[i0 + j] : 0u;
         const uint32_t s = c[0] + c[1] + c[2] + c[3];
+        longest = max(max(longest, max(c[0], c[1])), max(c[2], c[3]));
         const uint32_t incl = wave_scan_add(s);
         if (lane == 63) wsum[wave] = incl;
         __syncthreads();
@@ -338,7 +371,13 @@ __global__ __launch_bounds__(1024) void bucket_tile_scan_kernel(int n_tiles, int
         if (threadIdx.x == 0) carry_s += all;
         __syncthreads();
     }
-    if (threadIdx.x == 0) offsets[n_tiles] = (int32_t)carry_s;
+    longest = wave_scan_max(longest);
+    if (lane == 63) atomicMax(&longest_s, longest);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        offsets[n_tiles] = (int32_t)carry_s;
+        offsets[n_tiles + 1] = (int32_t)longest_s;      // the longest bucket: lets the per-tile sort skip unused size classes
+    }
 }
 
 // fill: payload[offsets[tile] + k] = row (DET: the emission slot cum[row] + q, and isect_gid[slot] = row)
@@ -349,50 +388,87 @@ __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_fill_kernel(
     const int64_t* __restrict__ cum, int64_t cap, int32_t* __restrict__ payload, int32_t* __restrict__ isect_gid) {
     __shared__ TileWg L;
     __shared__ uint32_t tbase[kWinMax];
+    __shared__ __attribute__((aligned(16))) uint16_t owner[kOwnerChunk];
     const int64_t n_vis = counters[1];
     if ((int64_t)blockIdx.x * kRowsPerWg >= n_vis) return;
     int cam0, wx0, wy0, ww, wh;
-    tile_wg_prologue(L, n_vis, n_gauss, order, rect2, cam0, wx0, wy0, ww, wh);
+    int32_t r_;
+    uint2 r2_;
+    bool in_;
+    tile_wg_prologue<true>(L, n_vis, n_gauss, order, rect2, cam0, wx0, wy0, ww, wh, r_, r2_, in_);
     const uint32_t total = L.total;
-    if (ww > 0) {
-        for (uint32_t o = threadIdx.x; o < total; o += kRowsPerWg) {
-            int e, tx, ty;
-            uint32_t q;
-            tile_wg_decode(L, o, e, tx, ty, q);
-            if (L.wflag[e] >> 31) atomicAdd(&L.tab[(ty - wy0) * ww + (tx - wx0)], 1u);
-        }
-        __syncthreads();
-        // one returning atomic per (workgroup, tile): a contiguous range of the tile's bucket
-        for (int i = threadIdx.x; i < ww * wh; i += kRowsPerWg) {
-            const uint32_t c = L.tab[i];
-            const int gt = cam0 * tiles_per_cam + (wy0 + i / ww) * tw + wx0 + i % ww;
-            tbase[i] = c ? (uint32_t)offsets[gt] + (uint32_t)atomicAdd(&cursors[gt], (int32_t)c) : 0u;
-            L.tab[i] = 0u;
-        }
-        __syncthreads();
+    const int stride = ww + 1;
+    // one returning atomic per (workgroup, tile): a contiguous range of the tile's bucket; tab becomes the cursors
+    for (int i = threadIdx.x; i < ww * wh; i += kRowsPerWg) {
+        const int y = i / ww, x = i - y * ww;
+        const int c = L.tab[y * stride + x];
+        const int gt = cam0 * tiles_per_cam + (wy0 + y) * tw + wx0 + x;
+        tbase[y * stride + x] = c ? (uint32_t)offsets[gt] + (uint32_t)atomicAdd(&cursors[gt], c) : 0u;
     }
-    for (uint32_t o = threadIdx.x; o < total; o += kRowsPerWg) {
-        int e, tx, ty;
-        uint32_t q;
-        tile_wg_decode(L, o, e, tx, ty, q);
-        const int32_t r = L.row[e];
-        int64_t slot;
-        if (ww > 0 && (L.wflag[e] >> 31)) {
-            const int i = (ty - wy0) * ww + (tx - wx0);
-            slot = (int64_t)tbase[i] + (int64_t)atomicAdd(&L.tab[i], 1u);
-        } else {
-            const int gt = (r / n_gauss) * tiles_per_cam + ty * tw + tx;
-            slot = (int64_t)offsets[gt] + (int64_t)atomicAdd(&cursors[gt], 1);
-        }
-        if (slot < cap) {
-            if (DET) {
-                const int64_t es = cum[r] + (int64_t)q;             // emission slot: the rows of the gradient slab
-                payload[slot] = (int32_t)es;
-                if (es < cap) isect_gid[es] = r;
-            } else {
-                payload[slot] = r;
+    __syncthreads();
+    for (int i = threadIdx.x; i < stride * (wh + 1); i += kRowsPerWg) L.tab[i] = 0;
+    __syncthreads();
+    // Expansion: output o of the workgroup belongs to the row e with excl[e] <= o < excl[e] + count[e].  Instead of
+    // a 10-step binary search per output, the owners of 8192 consecutive outputs are found at once: every row marks
+    // its first output with its index, and a max-scan spreads the marks (rows are in ascending output order).
+    for (uint32_t base = 0; base < total; base += kOwnerChunk) {
+        reinterpret_cast<uint4*>(owner)[threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        {
+            const int e = threadIdx.x;
+            const uint32_t s0 = L.info[e].x;
+            const uint32_t s1 = (e + 1 < kRowsPerWg) ? L.info[e + 1].x : total;
+            if (s1 > s0) {                                       // a row with at least one output
+                if (s0 >= base && s0 < base + kOwnerChunk) owner[s0 - base] = (uint16_t)(e + 1);
+                else if (s0 < base && s1 > base) owner[0] = (uint16_t)(e + 1);
             }
         }
+        __syncthreads();
+        const uint4 pk = reinterpret_cast<const uint4*>(owner)[threadIdx.x];       // 8 entries of 16 bits
+        uint32_t own[8] = {pk.x & 0xffffu, pk.x >> 16, pk.y & 0xffffu, pk.y >> 16,
+                           pk.z & 0xffffu, pk.z >> 16, pk.w & 0xffffu, pk.w >> 16};
+#pragma unroll
+        for (int j = 1; j < 8; j++) own[j] = max(own[j], own[j - 1]);
+        const uint32_t incl = wave_scan_max(own[7]);
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 63) L.wsum[wave] = incl;
+        uint32_t before = dpp_take<0x138, 0xF>(0u, incl);        // wave_shr:1 -> the maximum of the lanes before this one
+        if (lane == 0) before = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < kRowsPerWg / 64; w++) before = max(before, (w < wave) ? L.wsum[w] : 0u);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t o = base + 8u * threadIdx.x + j;
+            if (o >= total) break;
+            const int e = (int)max(own[j], before) - 1;
+            const uint4 inf = L.info[e];
+            const uint32_t q = o - inf.x;
+            const uint32_t w = inf.z & 0xffffu;
+            // (q + 0.5) / w is at least 0.5 / w away from an integer: the float quotient truncates exactly
+            const uint32_t ry = (uint32_t)(((float)q + 0.5f) * __uint_as_float(inf.w));
+            const uint32_t rx = q - ry * w;
+            const int tx = (int)((inf.y & 0xffffu) + rx), ty = (int)((inf.y >> 16) + ry);
+            const int32_t r = L.row[e];
+            int64_t slot;
+            if (inf.z >> 31) {
+                const int i = (ty - wy0) * stride + (tx - wx0);
+                slot = (int64_t)tbase[i] + (int64_t)atomicAdd(&L.tab[i], 1);
+            } else {
+                const int gt = (r / n_gauss) * tiles_per_cam + ty * tw + tx;
+                slot = (int64_t)offsets[gt] + (int64_t)atomicAdd(&cursors[gt], 1);
+            }
+            if (slot < cap) {
+                if (DET) {
+                    const int64_t es = cum[r] + (int64_t)q;         // emission slot: the rows of the gradient slab
+                    payload[slot] = (int32_t)es;
+                    if (es < cap) isect_gid[es] = r;
+                } else {
+                    payload[slot] = r;
+                }
+            }
+        }
+        __syncthreads();                                         // owner[] and wsum[] are reused by the next chunk
     }
 }
 
@@ -434,13 +510,13 @@ extern "C" int misplat_bucket_count(const misplat_params* p, const float* means2
 
 extern "C" int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles_per_gauss, const uint32_t* rect2,
                                    const uint32_t* cellhist, uint32_t* cell_count, uint32_t* cell_offs, int32_t* order,
-                                   int64_t* counters, int32_t* tile_count, misplat_stream_t stream) {
+                                   uint32_t* rect_sorted, int64_t* counters, int32_t* tile_count, misplat_stream_t stream) {
     int32_t nc, nb;
     if (misplat_bucket_plan(p, &nc, &nb) != MISPLAT_OK || !cell_count || !cell_offs || !counters || !tile_count)
         return MISPLAT_EINVAL;
     const CellGrid g = make_grid(p);
     const int64_t total = (int64_t)p->n_gauss * p->n_cams;
-    if (total > 0 && !order) return MISPLAT_EINVAL;
+    if (total > 0 && (!order || !rect_sorted)) return MISPLAT_EINVAL;
     const int64_t n_tiles = (int64_t)p->tile_w * p->tile_h * p->n_cams;
     if (n_tiles + 1 > 0x7fffffffLL) return MISPLAT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
@@ -449,34 +525,34 @@ extern "C" int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles
     if (total > 0)
         hipLaunchKernelGGL(bucket_rows_kernel, dim3(g.n_blocks), dim3(kCountThreads), 0, s, total, p->n_gauss, g.shift,
                            g.cells_x, g.cells_x * g.cells_y, g.n_cells, g.rows_per_block, tiles_per_gauss,
-                           (const uint2*)rect2, cellhist, cell_offs, cell_count, order);
+                           (const uint2*)rect2, cellhist, cell_offs, cell_count, order, (uint2*)rect_sorted);
     return check_launch();
 }
 
-extern "C" int misplat_bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect2,
+extern "C" int misplat_bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect_sorted,
                                     const int64_t* counters, int32_t* tile_count, int32_t* offsets, const int64_t* cum,
                                     int64_t cap_isects, int32_t* payload, int32_t* isect_gid, misplat_stream_t stream) {
     if (!p || p->tile_size != MISPLAT_TILE || !counters || !tile_count || !offsets || cap_isects < 0 ||
         cap_isects > 0x7fffffffLL || (cum && !isect_gid && cap_isects > 0))
         return MISPLAT_EINVAL;
     const int64_t total = (int64_t)p->n_gauss * p->n_cams;
-    if (total > 0 && (!order || !rect2)) return MISPLAT_EINVAL;
+    if (total > 0 && (!order || !rect_sorted)) return MISPLAT_EINVAL;
     const int64_t n_tiles = (int64_t)p->tile_w * p->tile_h * p->n_cams;
     const int tiles_per_cam = p->tile_w * p->tile_h;
     hipStream_t s = (hipStream_t)stream;
     const unsigned grid = (unsigned)((total + kRowsPerWg - 1) / kRowsPerWg);     // upper bound: workgroups past n_vis leave
     if (grid > 0)
         hipLaunchKernelGGL(bucket_tile_count_kernel, dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
-                           tiles_per_cam, counters, order, (const uint2*)rect2, tile_count);
+                           tiles_per_cam, counters, order, (const uint2*)rect_sorted, tile_count);
     hipLaunchKernelGGL(bucket_tile_scan_kernel, dim3(1), dim3(1024), 0, s, (int)n_tiles, tile_count, offsets);
     if (grid > 0 && cap_isects > 0 && payload) {
         if (cum)
             hipLaunchKernelGGL(bucket_tile_fill_kernel<true>, dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
-                               tiles_per_cam, counters, order, (const uint2*)rect2, offsets, tile_count, cum, cap_isects,
+                               tiles_per_cam, counters, order, (const uint2*)rect_sorted, offsets, tile_count, cum, cap_isects,
                                payload, isect_gid);
         else
             hipLaunchKernelGGL(bucket_tile_fill_kernel<false>, dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
-                               tiles_per_cam, counters, order, (const uint2*)rect2, offsets, tile_count, cum, cap_isects,
+                               tiles_per_cam, counters, order, (const uint2*)rect_sorted, offsets, tile_count, cum, cap_isects,
                                payload, isect_gid);
     }
     return check_launch();

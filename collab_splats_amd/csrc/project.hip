@@ -585,7 +585,9 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
 // AUX: the forward also leaves, per (camera, Gaussian), the 3x3 Jacobian d rgb / d dir of the clamped colour
 // (rows of clamped channels zeroed) and the three clamp flags in sh_aux[idx][12]; the backward then takes
 // v_dir = J^T v_rgb from those 48 bytes and never reads the 12 K bytes of coefficients again.
-template <bool BWD, int BLOCK, bool MULTI, bool AUX = false>
+// KC: compile-time K (16 = degree-3 storage: the row length 48 and the LDS stride 49 become constants, the
+// coefficients move as 16-byte vectors, and rows of Gaussians culled in every camera are never read) or 0 (any K).
+template <bool BWD, int BLOCK, bool MULTI, bool AUX = false, int KC = 0>
 __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
     misplat_params P, int K, int deg, int depth_channel, const float* __restrict__ means,
     const float* __restrict__ viewmats, const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest,
@@ -596,6 +598,8 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
     // features_rest [N,K-1,3] (the two parameter tensors of rade_gs_model.py:119-120, read in place
     // instead of through the per-step torch.cat of :128-130)
     extern __shared__ float lds[];
+    __shared__ uint8_t s_vis[BLOCK];
+    if (KC) K = KC;
     const int row = 3 * K, stride = row + 1;
     const int nb = (deg + 1) * (deg + 1);
     const int n_blocks = (P.n_gauss + BLOCK - 1) / BLOCK;
@@ -603,8 +607,82 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
         const int g0 = blk * BLOCK;
         const int cnt = min(BLOCK, P.n_gauss - g0);
         __syncthreads();
+        if (KC && BWD && !AUX) {
+            // visible in any camera?  (rows that are not are not staged)  Only where the staged rows are consumed late
+            // enough: in the forward, waiting for the radii before the first coefficient load costs more (a dependent
+            // round trip per block) than the culled rows' 192 bytes save.
+            bool v = false;
+            if ((int)threadIdx.x < cnt)
+                for (int ci = 0; ci < P.n_cams; ci++) {
+                    const int64_t idx = (int64_t)ci * P.n_gauss + g0 + threadIdx.x;
+                    v |= radii[2 * idx] > 0 || radii[2 * idx + 1] > 0;
+                }
+            s_vis[threadIdx.x] = v ? 1 : 0;
+            __syncthreads();
+        } else if (KC) {
+            s_vis[threadIdx.x] = 1;
+            __syncthreads();
+        }
         if (BWD && AUX) {
             // nothing to stage: the LDS rows only carry the gradient back out
+        } else if (KC && coeffs_rest == nullptr) {
+            // [N, 16, 3]: a row is 12 aligned float4s
+            const float4* src4 = reinterpret_cast<const float4*>(coeffs + (size_t)g0 * row);
+            constexpr int V4 = 3 * KC / 4;
+            for (int e0 = threadIdx.x; e0 < cnt * V4; e0 += 4 * BLOCK) {
+                float4 v[4];
+                int tt[4], kk[4];
+                bool on[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {                    // all loads of a round are issued before the first LDS store
+                    const int e4 = e0 + u * BLOCK;
+                    tt[u] = e4 / V4; kk[u] = 4 * (e4 - tt[u] * V4);
+                    on[u] = e4 < cnt * V4 && s_vis[tt[u]];
+                    if (on[u]) v[u] = src4[e4];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (on[u]) {
+                        float* d = lds + tt[u] * stride + kk[u];
+                        d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                    }
+            }
+        } else if (KC) {
+            // features_dc [N, 3] + features_rest [N, 15, 3]: rows of 3 and 45 floats; vectors may straddle two rows
+            const float* src_dc = coeffs + (size_t)g0 * 3;
+            for (int e = threadIdx.x; e < cnt * 3; e += BLOCK) lds[(e / 3) * stride + (e % 3)] = src_dc[e];
+            constexpr int RR = 3 * KC - 3;
+            const float4* src4 = reinterpret_cast<const float4*>(coeffs_rest + (size_t)g0 * RR);
+            const int n4 = (cnt * RR) / 4;                        // cnt * 45 is a multiple of 4 for full blocks
+            for (int e0 = threadIdx.x; e0 < n4; e0 += 4 * BLOCK) {
+                float4 v[4];
+                bool on[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int e4 = e0 + u * BLOCK;
+                    on[u] = false;
+                    if (e4 < n4) {
+                        const int ta = (4 * e4) / RR, tb = (4 * e4 + 3) / RR;
+                        on[u] = s_vis[ta] || s_vis[tb];
+                        if (on[u]) v[u] = src4[e4];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (on[u]) {
+                        const int e = 4 * (e0 + u * BLOCK);
+                        const float vv[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const int t = (e + j) / RR, k = (e + j) - t * RR;
+                            lds[t * stride + 3 + k] = vv[j];
+                        }
+                    }
+            }
+            for (int e = 4 * n4 + threadIdx.x; e < cnt * RR; e += BLOCK) {      // tail of a partial last block
+                const int t = e / RR, k = e - t * RR;
+                lds[t * stride + 3 + k] = coeffs_rest[(size_t)g0 * RR + e];
+            }
         } else if (coeffs_rest == nullptr) {
             const float* src = coeffs + (size_t)g0 * row;
             for (int e = threadIdx.x; e < cnt * row; e += BLOCK) {
@@ -743,7 +821,34 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
                 v_means_dir[3 * g] = vmd[0]; v_means_dir[3 * g + 1] = vmd[1]; v_means_dir[3 * g + 2] = vmd[2];
             }
             __syncthreads();
-            if (v_coeffs_rest == nullptr) {
+            if (KC && v_coeffs_rest == nullptr) {
+                float4* dst4 = reinterpret_cast<float4*>(v_coeffs + (size_t)g0 * row);
+                constexpr int V4 = 3 * KC / 4;
+                for (int e4 = threadIdx.x; e4 < cnt * V4; e4 += BLOCK) {
+                    const int tt = e4 / V4, k = 4 * (e4 - tt * V4);
+                    const float* sp = lds + tt * stride + k;
+                    dst4[e4] = make_float4(sp[0], sp[1], sp[2], sp[3]);
+                }
+            } else if (KC) {
+                float* dst_dc = v_coeffs + (size_t)g0 * 3;
+                for (int e = threadIdx.x; e < cnt * 3; e += BLOCK) dst_dc[e] = lds[(e / 3) * stride + (e % 3)];
+                constexpr int RR = 3 * KC - 3;
+                float4* dst4 = reinterpret_cast<float4*>(v_coeffs_rest + (size_t)g0 * RR);
+                const int n4 = (cnt * RR) / 4;
+                for (int e4 = threadIdx.x; e4 < n4; e4 += BLOCK) {
+                    float vv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const int e = 4 * e4 + j, t = e / RR, k = e - t * RR;
+                        vv[j] = lds[t * stride + 3 + k];
+                    }
+                    dst4[e4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+                }
+                for (int e = 4 * n4 + threadIdx.x; e < cnt * RR; e += BLOCK) {
+                    const int t = e / RR, k = e - t * RR;
+                    v_coeffs_rest[(size_t)g0 * RR + e] = lds[t * stride + 3 + k];
+                }
+            } else if (v_coeffs_rest == nullptr) {
                 float* dst = v_coeffs + (size_t)g0 * row;
                 for (int e = threadIdx.x; e < cnt * row; e += BLOCK) {
                     const int tt = e / row, k = e - tt * row;
@@ -983,16 +1088,16 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
         constexpr int BLK = 64;
         const int n_blocks = (p->n_gauss + BLK - 1) / BLK;
         const size_t lds = (size_t)BLK * (3 * K_or_D + 1) * sizeof(float);
-        if (sh_aux)
-            hipLaunchKernelGGL((color_sh_kernel<false, BLK, false, true>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK),
-                               lds, s, *p, K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, coeffs_rest,
-                               radii, depths, grec, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
-                               (float*)nullptr, sh_aux);
-        else
-            hipLaunchKernelGGL((color_sh_kernel<false, BLK, false>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK), lds, s,
-                               *p, K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, coeffs_rest, radii,
-                               depths, grec, (const float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr,
-                               (float*)nullptr);
+        // K = 16 with 16-byte aligned coefficient arrays: the vectorised variant (compile-time row length)
+        const bool k16 = K_or_D == 16 && ((uintptr_t)coeffs_or_colors & 15) == 0 && ((uintptr_t)coeffs_rest & 15) == 0;
+#define LAUNCH_SH_FWD(AUX_, KC_)                                                                                   \
+    hipLaunchKernelGGL((color_sh_kernel<false, BLK, false, AUX_, KC_>), dim3(n_blocks < 16384 ? n_blocks : 16384),  \
+                       dim3(BLK), lds, s, *p, K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, \
+                       coeffs_rest, radii, depths, grec, (const float*)nullptr, (float*)nullptr, (float*)nullptr,  \
+                       (float*)nullptr, sh_aux)
+        if (sh_aux) { if (k16) LAUNCH_SH_FWD(true, 16); else LAUNCH_SH_FWD(true, 0); }
+        else { if (k16) LAUNCH_SH_FWD(false, 16); else LAUNCH_SH_FWD(false, 0); }
+#undef LAUNCH_SH_FWD
     } else {
         if (K_or_D < n_color) return MISPLAT_EINVAL;
         int64_t total = (int64_t)p->n_gauss * p->n_cams;
@@ -1015,28 +1120,23 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
         constexpr int BLK = 64;
         const int n_blocks = (p->n_gauss + BLK - 1) / BLK;
         const size_t lds = (size_t)BLK * (3 * K_or_D + 1) * sizeof(float);
-        if (sh_aux) {
-            float* ax = const_cast<float*>(sh_aux);
-            if (p->n_cams > 1)
-                hipLaunchKernelGGL((color_sh_kernel<true, BLK, true, true>), dim3(n_blocks < 16384 ? n_blocks : 16384),
-                                   dim3(BLK), lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, coeffs_rest,
-                                   radii, (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_coeffs_rest,
-                                   v_means_dir, ax);
-            else
-                hipLaunchKernelGGL((color_sh_kernel<true, BLK, false, true>), dim3(n_blocks < 16384 ? n_blocks : 16384),
-                                   dim3(BLK), lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, coeffs_rest,
-                                   radii, (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_coeffs_rest,
-                                   v_means_dir, ax);
-        } else if (p->n_cams > 1)
-            hipLaunchKernelGGL((color_sh_kernel<true, BLK, true>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK),
-                               lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, coeffs_rest, radii,
-                               (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_coeffs_rest,
-                               v_means_dir);
-        else
-            hipLaunchKernelGGL((color_sh_kernel<true, BLK, false>), dim3(n_blocks < 16384 ? n_blocks : 16384), dim3(BLK),
-                               lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, coeffs_rest, radii,
-                               (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_coeffs_rest,
-                               v_means_dir);
+        float* ax = const_cast<float*>(sh_aux);
+        const bool k16 = K_or_D == 16 && ((uintptr_t)coeffs_or_colors & 15) == 0 && ((uintptr_t)coeffs_rest & 15) == 0 &&
+                         ((uintptr_t)v_coeffs_or_colors & 15) == 0 && ((uintptr_t)v_coeffs_rest & 15) == 0;
+#define LAUNCH_SH_BWD(MULTI_, AUX_, KC_)                                                                             \
+    hipLaunchKernelGGL((color_sh_kernel<true, BLK, MULTI_, AUX_, KC_>), dim3(n_blocks < 16384 ? n_blocks : 16384),     \
+                       dim3(BLK), lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, coeffs_rest,   \
+                       radii, (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_coeffs_rest,     \
+                       v_means_dir, ax)
+#define DISPATCH_SH_BWD(MULTI_)                                                          \
+    do {                                                                                 \
+        if (sh_aux) { if (k16) LAUNCH_SH_BWD(MULTI_, true, 16); else LAUNCH_SH_BWD(MULTI_, true, 0); }   \
+        else { if (k16) LAUNCH_SH_BWD(MULTI_, false, 16); else LAUNCH_SH_BWD(MULTI_, false, 0); }        \
+    } while (0)
+        if (p->n_cams > 1) DISPATCH_SH_BWD(true);
+        else DISPATCH_SH_BWD(false);
+#undef DISPATCH_SH_BWD
+#undef LAUNCH_SH_BWD
     } else {
         int64_t rows = per_cam ? (int64_t)p->n_gauss * p->n_cams : p->n_gauss;
         hipLaunchKernelGGL(color_copy_bwd_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, s, *p, K_or_D, n_color,

@@ -44,7 +44,7 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
             hipMemcpyAsync(a->n_isects_host, a->counters, sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess)
             return MISPLAT_ELAUNCH;
         rc = misplat_bucket_rows(p, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count, a->cell_offs, a->order,
-                                 a->counters, a->tile_count, stream);
+                                 a->rect_sorted, a->counters, a->tile_count, stream);
         if (rc != MISPLAT_OK) return rc;
         rc = misplat_color_fwd(p, a->sh_degree, a->K_or_D, a->n_color, a->per_cam, a->depth_channel, a->means, a->viewmats,
                                a->colors, a->colors_rest, a->radii, a->depths, a->grec, a->sh_aux, stream);
@@ -52,12 +52,12 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
     }
     if (phases & 2) {
         if (a->cap_isects < 0 || a->cap_isects > 0x7fffffffLL) return MISPLAT_EINVAL;
-        rc = misplat_bucket_tiles(p, a->order, a->rect2, a->counters, a->tile_count, a->offsets, nullptr, a->cap_isects,
+        rc = misplat_bucket_tiles(p, a->order, a->rect_sorted, a->counters, a->tile_count, a->offsets, nullptr, a->cap_isects,
                                   a->payload, nullptr, stream);
         if (rc != MISPLAT_OK) return rc;
         if (a->cap_isects > 0) {
             rc = misplat_tile_sort(a->offsets, p->tile_w * p->tile_h * p->n_cams, a->cap_isects, a->depths, nullptr,
-                                   a->payload, a->flatten_ids, a->scratch, 1, stream);
+                                   a->payload, a->flatten_ids, a->scratch, 3, stream);
             if (rc != MISPLAT_OK) return rc;
         }
         misplat_params q = *p;

@@ -335,17 +335,17 @@ def start_binning(P: Params, means2d: Tensor, radii: Tensor) -> Dict[str, Tensor
     n_tiles = P.tile_w * P.tile_h * P.n_cams
     if ORDERING == "cells":
         n_cells, n_blocks = bucket_plan(P)
-        tiles_per_gauss, rect2, cellhist, cell_count, cell_offs, order, counters, tile_count = _carve(
-            dev, (total, 2 * total, n_blocks * n_cells, n_cells, n_cells + 1, total, 4, n_tiles + 1))
+        tiles_per_gauss, rect2, cellhist, cell_count, cell_offs, order, rect_sorted, counters, tile_count = _carve(
+            dev, (total, 2 * total, n_blocks * n_cells, n_cells, n_cells + 1, total, 2 * total, 4, n_tiles + 1))
         counters = counters.view(torch.int64)
         check(lib.misplat_bucket_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(rect2),
                                        ptr(cellhist), ptr(cell_count), ptr(counters), C.c_int32(0), stream_ptr()),
               "misplat_bucket_count")
         pend = _read_back(counters[0:1])
         check(lib.misplat_bucket_rows(C.byref(P), ptr(tiles_per_gauss), ptr(rect2), ptr(cellhist), ptr(cell_count),
-                                      ptr(cell_offs), ptr(order), ptr(counters), ptr(tile_count), stream_ptr()),
-              "misplat_bucket_rows")
-        pend.update(tiles_per_gauss=tiles_per_gauss, rect2=rect2, order=order, counters=counters, tile_count=tile_count)
+                                      ptr(cell_offs), ptr(order), ptr(rect_sorted), ptr(counters), ptr(tile_count),
+                                      stream_ptr()), "misplat_bucket_rows")
+        pend.update(tiles_per_gauss=tiles_per_gauss, rect2=rect_sorted, order=order, counters=counters, tile_count=tile_count)
         return pend
     if ORDERING != "pertile":
         raise ValueError(f"unknown MISPLAT_ORDERING {ORDERING!r}")
@@ -382,7 +382,7 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor,
     out = dict(tiles_per_gauss=tiles_per_gauss, n_isects=n_isects, depths=depths, tile_ids=None, n_tiles=n_tiles)
     if ORDERING == "cells":
         offsets, payload, flatten_ids, scratch, isect_gid = _carve(
-            dev, (n_tiles + 1, n_isects, n_isects, 4 * n_isects, n_isects if deterministic else 0))
+            dev, (n_tiles + 2, n_isects, n_isects, 4 * n_isects, n_isects if deterministic else 0))
         cum = None
         if deterministic:                                         # emission slots index the gradient slab
             cum = (torch.cumsum(tiles_per_gauss, dim=0, dtype=torch.int64) - tiles_per_gauss).contiguous()
@@ -394,9 +394,9 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor,
                                        ptr(isect_gid), stream_ptr()), "misplat_bucket_tiles")
         if n_isects > 0:
             check(lib.misplat_tile_sort(ptr(offsets), C.c_int32(n_tiles), C.c_int64(n_isects), ptr(depths), ptr(isect_gid),
-                                        ptr(payload), ptr(flatten_ids), ptr(scratch), C.c_int32(1), stream_ptr()),
+                                        ptr(payload), ptr(flatten_ids), ptr(scratch), C.c_int32(3), stream_ptr()),
                   "misplat_tile_sort")
-        out.update(slots=payload if deterministic else None, flatten_ids=flatten_ids, isect_offsets=offsets)
+        out.update(slots=payload if deterministic else None, flatten_ids=flatten_ids, isect_offsets=offsets[:n_tiles + 1])
         return out
     # ---- "pertile": (tile, row) pairs in row order -> stable radix sort on the tile bits -> offsets -> per-tile sort
     key16 = SORT_BACKEND == "rocprim" and n_tiles < 65536         # 12 instead of 16 B per pair and pass
@@ -629,8 +629,8 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     n_cells, n_blocks = bucket_plan(P)
     means2d, depths, comps, grec, sh_aux = _carve_f(dev, (2 * rows, rows, rows, MISPLAT_REC * rows, 12 * rows if want_aux else 0))
     # (counters directly behind cell_count: the projection kernel clears that contiguous range, no memset launch)
-    radii, tiles_per_gauss, rect2, cellhist, cell_count, counters, cell_offs, order, tile_count = _carve(
-        dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, 4, n_cells + 1, rows, n_tiles + 1))
+    radii, tiles_per_gauss, rect2, cellhist, cell_count, counters, cell_offs, order, rect_sorted, tile_count = _carve(
+        dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, 4, n_cells + 1, rows, 2 * rows, n_tiles + 1))
     host = _readback_slot(dev)
     host[0] = -1                                                      # overwritten by the asynchronous copy of phase A
     a = RasterArgs()
@@ -641,6 +641,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     a.sh_aux = _dp(sh_aux) if want_aux else None
     a.tiles_per_gauss, a.rect2, a.cellhist, a.cell_count = _dp(tiles_per_gauss), _dp(rect2), _dp(cellhist), _dp(cell_count)
     a.cell_offs, a.order, a.counters, a.tile_count = _dp(cell_offs), _dp(order), _dp(counters), _dp(tile_count)
+    a.rect_sorted = _dp(rect_sorted)
     a.n_isects_host = host.data_ptr()
     check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
           "misplat_raster_fwd(A)")
@@ -670,7 +671,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         raise _lib.MisplatError(f"{cap} tile intersections exceed int32 indexing")
     render, alpha, exp_depth, med_depth, normal = _carve_f(dev, (cd * n_pix, n_pix, n_pix, n_pix, 3 * n_pix))
     sched = _UnitSchedule(P, dev)
-    last_ids, median_ids, offsets = _carve(dev, (n_pix, n_pix, n_tiles + 1))
+    last_ids, median_ids, offsets = _carve(dev, (n_pix, n_pix, n_tiles + 2))
 
     def isect_buffers(c):
         return _carve(dev, (c, c, 4 * c))
@@ -706,7 +707,8 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         if sched.ppl_b == sched.ppl_f:
             sched.perm_bwd = sched.perm
     bins = dict(tiles_per_gauss=state["tiles_per_gauss"], n_isects=n_known, depths=state["depths"], tile_ids=None,
-                n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:n_known], isect_offsets=offsets, _keep=(scratch, payload))
+                n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:n_known], isect_offsets=offsets[:n_tiles + 1],
+                _keep=(scratch, payload))
     imgs = (render.view(Cn, H, W, cd), alpha.view(Cn, H, W, 1), exp_depth.view(Cn, H, W, 1), med_depth.view(Cn, H, W, 1),
             normal.view(Cn, H, W, 3), last_ids.view(Cn, H, W), median_ids.view(Cn, H, W))
     return imgs, bins, sched

@@ -183,7 +183,9 @@ int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, 
  * longer than 8192 entries. */
 int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
                       const float* depths, const int32_t* isect_gid, int32_t* payload,
-                      int32_t* flatten_ids, uint32_t* scratch, int32_t unordered, misplat_stream_t stream);
+                      int32_t* flatten_ids, uint32_t* scratch, int32_t flags /* bit 0: unordered; bit 1:
+                      offsets[n_tiles_total + 1] holds the longest bucket (misplat_bucket_tiles writes it), so the
+                      launches of unused size classes return at once */, misplat_stream_t stream);
 
 /* Row-order emission without a global scan array (ordering "pertile"; replaces gsplat's cumsum between
  * its projection and isect_tiles): rows are cut into blocks of MISPLAT_COUNT_BLOCK.
@@ -216,9 +218,11 @@ int misplat_tile_offsets16(const uint16_t* tiles_sorted, int64_t n_isects, int32
  *                 per-workgroup cell histograms, the global cell counts; counters[0] = number of intersections
  *                 (device int64; cell_count and counters[2] are zeroed here on `stream` unless already_zero);
  *   bucket_rows   cell_offs = scan of the cell counts, counters[1] = visible rows, order[0 .. n_vis) = the visible
- *                 rows in cell order; tile_count[n_tiles + 1] is cleared;
+ *                 rows in cell order and rect_sorted[0 .. n_vis) their rectangles (layout of rect2, capacity C*N);
+ *                 tile_count[n_tiles + 1] is cleared;
  *   bucket_tiles  (tile_count must be all zero on entry, as bucket_rows leaves it; it is NOT zero afterwards)
- *                 offsets[0 .. n_tiles] (offsets[n_tiles] = number of intersections) and
+ *                 offsets[0 .. n_tiles + 1] (offsets[n_tiles] = number of intersections, offsets[n_tiles + 1] = the
+ *                 longest bucket: n_tiles + 2 entries) and
  *                 payload[offsets[t] .. offsets[t + 1]) = the rows touching tile t, in arbitrary order
  *                 (misplat_tile_sort(unordered = 1) follows).  cum != NULL (deterministic backward): the payload
  *                 is the emission slot cum[row] + k and isect_gid[slot] = row.  Writes beyond cap_isects entries
@@ -234,8 +238,8 @@ int misplat_bucket_count(const misplat_params* p, const float* means2d, const in
                          misplat_stream_t stream);
 int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles_per_gauss, const uint32_t* rect2,
                         const uint32_t* cellhist, uint32_t* cell_count, uint32_t* cell_offs, int32_t* order,
-                        int64_t* counters, int32_t* tile_count, misplat_stream_t stream);
-int misplat_bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect2,
+                        uint32_t* rect_sorted, int64_t* counters, int32_t* tile_count, misplat_stream_t stream);
+int misplat_bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect_sorted,
                          const int64_t* counters, int32_t* tile_count, int32_t* offsets, const int64_t* cum,
                          int64_t cap_isects, int32_t* payload, int32_t* isect_gid, misplat_stream_t stream);
 
@@ -390,6 +394,7 @@ typedef struct misplat_raster_args {
     int32_t* tiles_per_gauss;
     uint32_t *rect2, *cellhist, *cell_count, *cell_offs;
     int32_t* order;
+    uint32_t* rect_sorted;
     int64_t* counters;
     int32_t *tile_count, *offsets, *payload, *flatten_ids;
     uint32_t* scratch;
