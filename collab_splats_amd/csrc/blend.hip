@@ -1094,12 +1094,12 @@ extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_d
                                         const float* render, const float* v_render, const float* v_alpha,
                                         const float* v_exp_depth, const float* v_med_depth,
                                         const float* v_normal, float* v_grec, float* v_abs,
-                                        misplat_stream_t stream) {
+                                        int32_t v_grec_is_zero, misplat_stream_t stream) {
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !v_grec) return MISPLAT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const size_t rows = (size_t)p->n_gauss * p->n_cams;
     if (rows == 0) return MISPLAT_OK;
-    if (hipMemsetAsync(v_grec, 0, rows * MISPLAT_REC * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (!v_grec_is_zero && hipMemsetAsync(v_grec, 0, rows * MISPLAT_REC * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
     if (v_abs && hipMemsetAsync(v_abs, 0, rows * 2 * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
     if (n_isects == 0) return MISPLAT_OK;
     const int ppl = pick_ppl(p->ppl_bwd, kDefaultPplBwd);

@@ -593,7 +593,7 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
     const float* __restrict__ viewmats, const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest,
     const int32_t* __restrict__ radii, const float* __restrict__ depths, float* __restrict__ grec,
     const float* __restrict__ v_grec, float* __restrict__ v_coeffs, float* __restrict__ v_coeffs_rest,
-    float* __restrict__ v_means_dir, float* __restrict__ sh_aux = nullptr) {
+    float* __restrict__ v_means_dir, float* __restrict__ sh_aux = nullptr, float4* __restrict__ zero_rows = nullptr) {
     // coeffs_rest == NULL: coeffs is [N,K,3]; else coeffs is features_dc [N,3] and coeffs_rest is
     // features_rest [N,K-1,3] (the two parameter tensors of rade_gs_model.py:119-120, read in place
     // instead of through the per-step torch.cat of :128-130)
@@ -626,32 +626,31 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
         if (BWD && AUX) {
             // nothing to stage: the LDS rows only carry the gradient back out
         } else if (KC && coeffs_rest == nullptr) {
-            // [N, 16, 3]: a row is 12 aligned float4s
+            // [N, 16, 3]: a row is 12 aligned float4s; the whole block (64 rows = 12 vectors per lane) is requested
+            // in ONE round of loads -- three dependent rounds of four cost two more HBM round trips per block
             const float4* src4 = reinterpret_cast<const float4*>(coeffs + (size_t)g0 * row);
-            constexpr int V4 = 3 * KC / 4;
-            for (int e0 = threadIdx.x; e0 < cnt * V4; e0 += 4 * BLOCK) {
-                float4 v[4];
-                int tt[4], kk[4];
-                bool on[4];
+            constexpr int V4 = KC ? 3 * KC / 4 : 1;
+            float4 v[V4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) {                    // all loads of a round are issued before the first LDS store
-                    const int e4 = e0 + u * BLOCK;
-                    tt[u] = e4 / V4; kk[u] = 4 * (e4 - tt[u] * V4);
-                    on[u] = e4 < cnt * V4 && s_vis[tt[u]];
-                    if (on[u]) v[u] = src4[e4];
+            for (int u = 0; u < V4; u++) {
+                const int e4 = threadIdx.x + u * BLOCK;
+                const int tt = e4 / V4;
+                if (e4 < cnt * V4 && s_vis[tt]) v[u] = src4[e4];
+            }
+#pragma unroll
+            for (int u = 0; u < V4; u++) {
+                const int e4 = threadIdx.x + u * BLOCK;
+                const int tt = e4 / V4, kk = 4 * (e4 - tt * V4);
+                if (e4 < cnt * V4 && s_vis[tt]) {
+                    float* d = lds + tt * stride + kk;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
                 }
-#pragma unroll
-                for (int u = 0; u < 4; u++)
-                    if (on[u]) {
-                        float* d = lds + tt[u] * stride + kk[u];
-                        d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
-                    }
             }
         } else if (KC) {
             // features_dc [N, 3] + features_rest [N, 15, 3]: rows of 3 and 45 floats; vectors may straddle two rows
             const float* src_dc = coeffs + (size_t)g0 * 3;
             for (int e = threadIdx.x; e < cnt * 3; e += BLOCK) lds[(e / 3) * stride + (e % 3)] = src_dc[e];
-            constexpr int RR = 3 * KC - 3;
+            constexpr int RR = KC ? 3 * KC - 3 : 1;
             const float4* src4 = reinterpret_cast<const float4*>(coeffs_rest + (size_t)g0 * RR);
             const int n4 = (cnt * RR) / 4;                        // cnt * 45 is a multiple of 4 for full blocks
             for (int e0 = threadIdx.x; e0 < n4; e0 += 4 * BLOCK) {
@@ -798,6 +797,10 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
                                            depth_channel ? depths[idx] : 0.f);
                     if (!vis) c = make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(o) = c;
+                    if (zero_rows) {                 // the gradient row the backward's atomics will add into: no memset later
+                        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                        zero_rows[4 * idx] = z; zero_rows[4 * idx + 1] = z; zero_rows[4 * idx + 2] = z; zero_rows[4 * idx + 3] = z;
+                    }
                 }
             }
         }
@@ -823,7 +826,7 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
             __syncthreads();
             if (KC && v_coeffs_rest == nullptr) {
                 float4* dst4 = reinterpret_cast<float4*>(v_coeffs + (size_t)g0 * row);
-                constexpr int V4 = 3 * KC / 4;
+                constexpr int V4 = KC ? 3 * KC / 4 : 1;
                 for (int e4 = threadIdx.x; e4 < cnt * V4; e4 += BLOCK) {
                     const int tt = e4 / V4, k = 4 * (e4 - tt * V4);
                     const float* sp = lds + tt * stride + k;
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
             } else if (KC) {
                 float* dst_dc = v_coeffs + (size_t)g0 * 3;
                 for (int e = threadIdx.x; e < cnt * 3; e += BLOCK) dst_dc[e] = lds[(e / 3) * stride + (e % 3)];
-                constexpr int RR = 3 * KC - 3;
+                constexpr int RR = KC ? 3 * KC - 3 : 1;
                 float4* dst4 = reinterpret_cast<float4*>(v_coeffs_rest + (size_t)g0 * RR);
                 const int n4 = (cnt * RR) / 4;
                 for (int e4 = threadIdx.x; e4 < n4; e4 += BLOCK) {
@@ -872,10 +875,15 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
 __global__ __launch_bounds__(256) void color_copy_kernel(misplat_params P, int D, int n_color, int per_cam,
                                                          int depth_channel, const float* __restrict__ colors,
                                                          const int32_t* __restrict__ radii,
-                                                         const float* __restrict__ depths, float* __restrict__ grec) {
+                                                         const float* __restrict__ depths, float* __restrict__ grec,
+                                                         float4* __restrict__ zero_rows) {
     const int64_t total = (int64_t)P.n_cams * P.n_gauss;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
+        if (zero_rows) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            zero_rows[4 * idx] = z; zero_rows[4 * idx + 1] = z; zero_rows[4 * idx + 2] = z; zero_rows[4 * idx + 3] = z;
+        }
         const int64_t src = per_cam ? idx : idx % P.n_gauss;
         float c[4] = {0.f, 0.f, 0.f, 0.f};
         if (radii[2 * idx] > 0 || radii[2 * idx + 1] > 0) {
@@ -1078,7 +1086,7 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
                                  int32_t per_cam, int32_t depth_channel, const float* means,
                                  const float* viewmats, const float* coeffs_or_colors, const float* coeffs_rest,
                                  const int32_t* radii, const float* depths, float* grec, float* sh_aux,
-                                 misplat_stream_t stream) {
+                                 float* zero_rows, misplat_stream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
     if (n_color < 0 || n_color + (depth_channel ? 1 : 0) > 4) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
@@ -1094,7 +1102,7 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
     hipLaunchKernelGGL((color_sh_kernel<false, BLK, false, AUX_, KC_>), dim3(n_blocks < 16384 ? n_blocks : 16384),  \
                        dim3(BLK), lds, s, *p, K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, \
                        coeffs_rest, radii, depths, grec, (const float*)nullptr, (float*)nullptr, (float*)nullptr,  \
-                       (float*)nullptr, sh_aux)
+                       (float*)nullptr, sh_aux, (float4*)zero_rows)
         if (sh_aux) { if (k16) LAUNCH_SH_FWD(true, 16); else LAUNCH_SH_FWD(true, 0); }
         else { if (k16) LAUNCH_SH_FWD(false, 16); else LAUNCH_SH_FWD(false, 0); }
 #undef LAUNCH_SH_FWD
@@ -1102,7 +1110,7 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
         if (K_or_D < n_color) return MISPLAT_EINVAL;
         int64_t total = (int64_t)p->n_gauss * p->n_cams;
         hipLaunchKernelGGL(color_copy_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, *p, K_or_D, n_color,
-                           per_cam, depth_channel, coeffs_or_colors, radii, depths, grec);
+                           per_cam, depth_channel, coeffs_or_colors, radii, depths, grec, (float4*)zero_rows);
     }
     return check_launch();
 }

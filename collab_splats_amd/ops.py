@@ -619,7 +619,7 @@ def _dp(t: Optional[Tensor]):
 
 
 def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg: int, kd: int,
-                    n_color: int, per_cam: int, depth_channel: bool, want_aux: bool):
+                    n_color: int, per_cam: int, depth_channel: bool, want_aux: bool, want_grad: bool):
     """Allocations + phase A of misplat_raster_fwd.  Returns (radii, means2d, depths, comps, grec, sh_aux, state)."""
     lib = _lib.load()
     dev = means.device
@@ -628,6 +628,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     n_tiles = P.tile_w * P.tile_h * Cn
     n_cells, n_blocks = bucket_plan(P)
     means2d, depths, comps, grec, sh_aux = _carve_f(dev, (2 * rows, rows, rows, MISPLAT_REC * rows, 12 * rows if want_aux else 0))
+    v_grec_zero = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32) if want_grad else None
     # (counters directly behind cell_count: the projection kernel clears that contiguous range, no memset launch)
     radii, tiles_per_gauss, rect2, cellhist, cell_count, counters, cell_offs, order, rect_sorted, tile_count = _carve(
         dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, 4, n_cells + 1, rows, 2 * rows, n_tiles + 1))
@@ -639,13 +640,14 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     a.sh_degree, a.K_or_D, a.n_color, a.per_cam, a.depth_channel = deg, kd, n_color, per_cam, int(depth_channel)
     a.radii, a.means2d, a.depths, a.compensations, a.grec = _dp(radii), _dp(means2d), _dp(depths), _dp(comps), _dp(grec)
     a.sh_aux = _dp(sh_aux) if want_aux else None
+    a.v_grec_zero = _dp(v_grec_zero)
     a.tiles_per_gauss, a.rect2, a.cellhist, a.cell_count = _dp(tiles_per_gauss), _dp(rect2), _dp(cellhist), _dp(cell_count)
     a.cell_offs, a.order, a.counters, a.tile_count = _dp(cell_offs), _dp(order), _dp(counters), _dp(tile_count)
     a.rect_sorted = _dp(rect_sorted)
     a.n_isects_host = host.data_ptr()
     check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
           "misplat_raster_fwd(A)")
-    state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths,
+    state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero,
                  keep=(rect2, cellhist, cell_count, cell_offs, order, counters, tile_count, radii))
     return (radii.view(Cn, N, 2), means2d.view(Cn, N, 2), depths.view(Cn, N), comps.view(Cn, N), grec.view(rows, MISPLAT_REC),
             sh_aux.view(rows, 12) if want_aux else None, state)
@@ -707,6 +709,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         if sched.ppl_b == sched.ppl_f:
             sched.perm_bwd = sched.perm
     bins = dict(tiles_per_gauss=state["tiles_per_gauss"], n_isects=n_known, depths=state["depths"], tile_ids=None,
+                v_grec_zero=state.get("v_grec_zero"),
                 n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:n_known], isect_offsets=offsets[:n_tiles + 1],
                 _keep=(scratch, payload))
     imgs = (render.view(Cn, H, W, cd), alpha.view(Cn, H, W, 1), exp_depth.view(Cn, H, W, 1), med_depth.view(Cn, H, W, 1),
@@ -758,10 +761,11 @@ class _ProjectPack(torch.autograd.Function):
             n_color = kd
         if prebin is not None and fused_entry_ok() and N > 0:
             # one host entry: projection, row bucketing, asynchronous n_isects read-back, colours
-            want_aux = SH_AUX and deg >= 0 and any(ctx.needs_input_grad[:6])
+            want_grad = any(ctx.needs_input_grad[:6])
+            want_aux = SH_AUX and deg >= 0 and want_grad
             radii, means2d, depths, comps, grec, sh_aux, state = _raster_phase_a(
                 P, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam,
-                depth_channel, want_aux)
+                depth_channel, want_aux, want_grad)
             prebin["fused"] = state
             ctx.P, ctx.color_args = P, (deg, kd, n_color, per_cam)
             ctx.depth_slot = 12 + n_color if depth_channel else -1
@@ -801,7 +805,7 @@ class _ProjectPack(torch.autograd.Function):
             check(lib.misplat_color_fwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
                                         C.c_int32(per_cam), C.c_int32(int(depth_channel)), ptr(means), ptr(viewmats),
                                         ptr(colors), ptr(colors_rest), ptr(radii), ptr(depths), ptr(grec), ptr(sh_aux),
-                                        stream_ptr()), "misplat_color_fwd")
+                                        ptr(None), stream_ptr()), "misplat_color_fwd")
         ctx.P, ctx.color_args = P, (deg, kd, n_color, per_cam)
         ctx.depth_slot = 12 + n_color if depth_channel else -1
         ctx.has_rest = colors_rest is not None
@@ -943,13 +947,18 @@ def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
     dev = grec.device
     ups = _upstream(P, cd, dev, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
     if bins["slots"] is None:                      # binned in atomic mode (ops.DETERMINISTIC_BACKWARD was False)
-        v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
+        # the one-entry forward left a cleared gradient buffer behind (written by the colour kernel): first backward only
+        v_grec = bins.pop("v_grec_zero", None)
+        prezeroed = v_grec is not None
+        if v_grec is None:
+            v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
         v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
         with _timed("blend_bwd"):
             check(lib.misplat_blend_bwd_atomic(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
                                                ptr(bins["isect_offsets"]), C.c_int64(n_isects), ptr(alpha),
                                                ptr(last_ids), ptr(median_ids), ptr(render), *[ptr(t) for t in ups],
-                                               ptr(v_grec), ptr(v_abs), stream_ptr()), "misplat_blend_bwd_atomic")
+                                               ptr(v_grec), ptr(v_abs), C.c_int32(int(prezeroed)), stream_ptr()),
+                  "misplat_blend_bwd_atomic")
         return v_grec, v_abs
     planes = int(lib.misplat_blend_planes(C.byref(P)))
     rows_s = max(n_isects, 1) * planes

@@ -135,7 +135,10 @@ int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D
                       int32_t per_cam, int32_t depth_channel, const float* means,
                       const float* viewmats, const float* coeffs_or_colors, const float* coeffs_rest,
                       const int32_t* radii, const float* depths, float* grec,
-                      float* sh_aux /* or NULL */, misplat_stream_t stream);
+                      float* sh_aux /* or NULL */,
+                      float* zero_rows /* or NULL: [C*N,16] cleared by the kernel -- the gradient rows the backward's
+                      atomics add into (misplat_blend_bwd_atomic, v_grec_is_zero): saves the 64 B/row memset launch */,
+                      misplat_stream_t stream);
 int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color,
                       int32_t per_cam, const float* means, const float* viewmats,
                       const float* coeffs_or_colors, const float* coeffs_rest, const int32_t* radii,
@@ -306,7 +309,8 @@ int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const f
                              const int32_t* median_ids, const float* render, const float* v_render,
                              const float* v_alpha, const float* v_exp_depth, const float* v_med_depth,
                              const float* v_normal, float* v_grec, float* v_abs,
-                             misplat_stream_t stream);
+                             int32_t v_grec_is_zero /* v_grec was cleared by misplat_color_fwd (zero_rows) and has not
+                             been used since: skip the memset */, misplat_stream_t stream);
 /* ---- a8: N-D colours in one pass (rade_features_model.py:441-476: D = 16 fused channels, 17 with
  * RGB+ED).  n_channels = D' in 5..20; channels 0..3 live in the record's colour slots, channels 4..
  * in featx[C*N, 4*nxq] (nxq = ceil((D'-4)/4) float4s per row, zero padded); color_fwd_x writes both
@@ -390,6 +394,7 @@ typedef struct misplat_raster_args {
     /* per (camera, Gaussian) outputs */
     int32_t* radii;
     float *means2d, *depths, *compensations, *grec, *sh_aux /* or NULL */;
+    float* v_grec_zero; /* or NULL: gradient rows [C*N,16] cleared by the colour kernel (see misplat_color_fwd) */
     /* bucketing workspace + results */
     int32_t* tiles_per_gauss;
     uint32_t *rect2, *cellhist, *cell_count, *cell_offs;
