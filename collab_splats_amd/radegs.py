@@ -247,24 +247,32 @@ class RadegsModel(nn.Module):
             return {}
         if self.training:
             assert camera.shape[0] == 1, "Only one camera at a time"
+        # cropping (rade_gs_model.py:96-119): evaluation only; an empty crop short-circuits to get_empty_outputs
+        crop_ids = None
+        if self.crop_box is not None and not self.training:
+            crop_ids = self.crop_box.within(self.means).squeeze()
+            if crop_ids.sum() == 0:
+                return self.get_empty_outputs(int(camera.width.item()), int(camera.height.item()),
+                                              self._get_background_color())
+        pick = (lambda t: t[crop_ids]) if crop_ids is not None else (lambda t: t)
         # the reference concatenates the two colour parameters every step (rade_gs_model.py:128-130:
         # a 192 B/Gaussian copy + its backward split); the colour kernels read them in place instead
-        colors_crop = (self.features_dc, self.features_rest)
+        colors_crop = (pick(self.features_dc), pick(self.features_rest))
         W, H = int(camera.width.item()), int(camera.height.item())
         self.last_size = (H, W)
         camera_params = self._get_camera_parameters(camera)
-        voxel_visible_mask = self._prefilter_voxel(camera_params) if self.config.prefilter_voxel else None
+        voxel_visible_mask = self._prefilter_voxel(camera_params) if (self.config.prefilter_voxel and crop_ids is None) else None
         if self.config.rasterize_mode not in ["antialiased", "classic"]:
             raise ValueError("Unknown rasterize_mode: %s", self.config.rasterize_mode)
         render_mode = "RGB+ED" if (self.config.output_depth_during_training or not self.training) else "RGB"
         if self.config.sh_degree > 0:
             sh_degree_to_use = min(self.step // self.config.sh_degree_interval, self.config.sh_degree)
         else:
-            colors_crop = torch.sigmoid(self.features_dc)               # [N, 1, 3] -> [N, 3]  (:163)
+            colors_crop = torch.sigmoid(pick(self.features_dc))         # [N, 1, 3] -> [N, 3]  (:163)
             sh_degree_to_use = None
 
         render, alpha, expected_depths, median_depths, expected_normals, self.info = self._render(
-            means=self.means, quats=self.quats, scales=self.scales, opacities=self.opacities,
+            means=pick(self.means), quats=pick(self.quats), scales=pick(self.scales), opacities=pick(self.opacities),
             colors=colors_crop, render_mode=render_mode, sh_degree_to_use=sh_degree_to_use,
             visible_mask=voxel_visible_mask, camera_params=camera_params)
 
@@ -299,6 +307,16 @@ class RadegsModel(nn.Module):
             "middepth_normal_error_map": normal_error_map[1, ...].unsqueeze(-1),
             "background": background,
         }
+
+    @staticmethod
+    def get_empty_outputs(width: int, height: int, background: Tensor) -> Dict[str, Union[Tensor, List]]:
+        """Splatfacto's outputs for a view that contains no Gaussian (what rade_gs_model.py:100-105 returns for an
+        empty crop): the background colour everywhere, depth 10, zero accumulation [UNVERIFIED-UPSTREAM: nerfstudio
+        is absent; restated from its public Splatfacto]."""
+        rgb = background.repeat(height, width, 1)
+        depth = background.new_ones(*rgb.shape[:2], 1) * 10
+        accumulation = background.new_zeros(*rgb.shape[:2], 1)
+        return {"rgb": rgb, "depth": depth, "accumulation": accumulation, "background": background}
 
     @torch.no_grad()
     def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, Union[Tensor, List, None]]:

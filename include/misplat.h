@@ -249,7 +249,9 @@ int misplat_bucket_tiles(const misplat_params* p, const int32_t* order, const ui
 /* Hand-written stable LSD radix sort of (uint32 key, int32 value) pairs on key bits
  * [begin_bit, end_bit), bits_per_pass (1..11) bits per pass, three launches per pass, no
  * inter-workgroup waiting (csrc/sort.hip).  keys_in / vals_in are not modified; the result is in
- * keys_out / vals_out; workspace holds one ping-pong pair and the per-chunk digit counts. */
+ * keys_out / vals_out; workspace holds one ping-pong pair and the per-chunk digit counts.
+ * Precondition: a pass is at least 2 bits wide, so when (end_bit - begin_bit) leaves a last pass of 1 bit that pass
+ * also looks at bit `end_bit`: the key bits at and above end_bit must be zero (they are for tile ids). */
 size_t misplat_radix_workspace_bytes(int64_t n, int32_t begin_bit, int32_t end_bit, int32_t bits_per_pass);
 int misplat_radix_sort_pairs(void* workspace, size_t workspace_bytes, const uint32_t* keys_in,
                              uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,

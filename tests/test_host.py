@@ -264,3 +264,37 @@ def test_strategy_matches_an_independent_numpy_restatement_unverified_upstream(s
     for k in params:
         assert params[k].shape == want[k].shape, k
         assert np.abs(params[k].detach().double().numpy() - want[k]).max() < 1e-6, k
+
+
+def test_empty_crop_returns_empty_outputs_without_touching_the_gpu():
+    """rade_gs_model.py:96-105: in evaluation an empty crop box short-circuits to ``get_empty_outputs`` (no render)."""
+    one = torch.zeros(3, 3)
+    model = radegs.RadegsModel(radegs.RadegsModelConfig(), one, one, torch.ones(3, 4), torch.zeros(3), one,
+                               torch.zeros(3, 15, 3))
+    model.eval()
+
+    class Box:
+        def within(self, pts):
+            return torch.zeros(pts.shape[0], 1, dtype=torch.bool)
+
+    model.crop_box = Box()
+    cam = radegs.PinholeCamera.make(torch.eye(4)[:3], 20.0, 20.0, 8, 6)
+    out = model.get_outputs(cam)
+    assert set(out) == {"rgb", "depth", "accumulation", "background"}
+    assert out["rgb"].shape == (6, 8, 3) and out["depth"].shape == (6, 8, 1) and float(out["depth"].min()) == 10.0
+    assert not out["accumulation"].any()
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_tsdf_frame_extrinsic_equals_the_reference_viewmat(i):
+    """f4 hand-off (mesh.py:1591-1630): the extrinsic given to Open3D, inv(c2w @ diag(1,-1,-1,1)), is the same OpenGL ->
+    OpenCV world-to-camera matrix the reference's own ``convert_to_colmap_camera`` produced for this pose -- so it is
+    pinned by the reference-generated camera goldens; the intrinsics are the camera's own (not the fov-rebuilt ones)."""
+    g = np.load(GOLD)
+    W, H = [int(v) for v in g[f"cam{i}_WH"]]
+    K = g[f"cam{i}_K"]
+    cam = radegs.PinholeCamera.make(torch.from_numpy(g[f"cam{i}_c2w"]), K[0, 0], K[1, 1], W, H, cx=K[0, 2], cy=K[1, 2])
+    ext, intr = radegs.tsdf_frame(cam)
+    assert ext.shape == (4, 4) and ext.dtype == np.float64
+    assert np.abs(ext - g[f"cam{i}_viewmat"]).max() < 1e-5
+    assert intr == dict(width=W, height=H, fx=float(K[0, 0]), fy=float(K[1, 1]), cx=float(K[0, 2]), cy=float(K[1, 2]))

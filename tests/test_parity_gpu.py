@@ -642,6 +642,40 @@ def test_model_get_outputs_and_loss(dev):
     assert mask.shape == (n_now,) and mask.dtype == torch.bool and 0 < int(mask.sum()) < n_now
 
 
+def test_crop_box_renders_exactly_the_cropped_subset(dev):
+    """rade_gs_model.py:96-119 (evaluation only): a crop box selects Gaussians by ``within(means)``; the outputs are those
+    of a model that holds only the selected ones, and an empty crop returns ``get_empty_outputs``."""
+    from collab_splats_amd import radegs
+    from collab_splats_amd.synthetic import random_scene
+    W, H, N = 200, 120, 5000
+    sc = random_scene(N, W, H, seed=4)
+    cfg = radegs.RadegsModelConfig(rasterize_mode="antialiased")
+
+    def make(sel):
+        return radegs.RadegsModel(cfg, sc["means"][sel], sc["log_scales"][sel], sc["quats"][sel], sc["opacity_logits"][sel],
+                                  sc["sh"][sel, 0], sc["sh"][sel, 1:]).to(dev).eval()
+
+    class Box:
+        def __init__(self, lo):
+            self.lo = lo
+
+        def within(self, pts):
+            return (pts[:, 0] > self.lo)[:, None]
+
+    c2w = torch.tensor([[1.0, 0, 0, 0], [0, -1.0, 0, 0], [0, 0, -1.0, 0]])
+    cam = radegs.PinholeCamera.make(c2w, 0.9 * W, 0.9 * W, W, H)
+    full = make(slice(None))
+    full.crop_box = Box(0.0)
+    sel = sc["means"][:, 0] > 0.0
+    part = make(sel)
+    a, b = full.get_outputs_for_camera(cam), part.get_outputs_for_camera(cam)
+    for k in ("rgb", "depth", "median_depth", "accumulation", "normals", "depth_im"):
+        assert torch.equal(a[k], b[k]), k
+    full.crop_box = Box(1e9)
+    e = full.get_outputs_for_camera(cam)
+    assert set(e) == {"rgb", "depth", "accumulation", "background"} and e["rgb"].shape == (H, W, 3)
+
+
 def test_end_to_end_optimisation_recovers_a_scene(dev):
     """Independent of every oracle: perturb a scene, fit it back to its own renders (colour + expected depth +
     normals) with Adam through the HIP backward.  Wrong-signed or mis-scaled gradients cannot pass this."""
