@@ -43,7 +43,8 @@ class RasterArgs(C.Structure):
     """Mirror of ``misplat_raster_args`` (include/misplat.h)."""
     _P = C.c_void_p
     _fields_ = ([(n, C.c_void_p) for n in ("means", "quats", "scales", "opacities", "colors", "colors_rest", "viewmats", "Ks")]
-                + [(n, C.c_int32) for n in ("sh_degree", "K_or_D", "n_color", "per_cam", "depth_channel", "color_dim")]
+                + [(n, C.c_int32) for n in ("sh_degree", "K_or_D", "n_color", "per_cam", "depth_channel", "color_dim",
+                                            "colour_pending", "reserved2")]
                 + [(n, C.c_void_p) for n in ("radii", "means2d", "depths", "compensations", "grec", "sh_aux", "v_grec_zero",
                                              "tiles_per_gauss", "rect2", "cellhist", "cell_count", "cell_offs", "order",
                                              "rect_sorted", "counters", "tile_count", "offsets", "payload", "flatten_ids", "scratch")]

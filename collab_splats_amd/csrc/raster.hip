@@ -26,9 +26,25 @@
 
 namespace {
 
-int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32_t phases, hipStream_t s) {
+// `fork`: a second stream + two events owned by the graph cache, or NULL.  With it the colour kernel (memory-latency
+// bound, ~100 us at 1 M Gaussians) runs BESIDE the bucketing kernels and the per-tile sort (latency bound, ~170 us) and
+// joins in front of the compositing: captured into a graph this becomes two parallel branches.
+struct Fork {
+    hipStream_t side;
+    hipEvent_t forked, joined;
+};
+
+int enqueue_colour(const misplat_params* p, const misplat_raster_args* a, misplat_stream_t stream) {
+    return misplat_color_fwd(p, a->sh_degree, a->K_or_D, a->n_color, a->per_cam, a->depth_channel, a->means, a->viewmats,
+                             a->colors, a->colors_rest, a->radii, a->depths, a->grec, a->sh_aux, a->v_grec_zero, stream);
+}
+
+int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32_t phases, hipStream_t s, const Fork* fork) {
     misplat_stream_t stream = (misplat_stream_t)s;
     int rc;
+    // The colour kernel belongs to phase A, but nothing before the compositing reads its output: when phase B follows in
+    // the same call it is deferred to B's parallel branch.
+    const bool colour_in_b = (phases & 2) && a->colour_pending != 0;
     if (phases & 1) {
         // the projection kernel also clears the cell counts and the two counters (contiguous: cell_count ... counters),
         // so phase A contains no memset at all
@@ -46,12 +62,25 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         rc = misplat_bucket_rows(p, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count, a->cell_offs, a->order,
                                  a->rect_sorted, a->counters, a->tile_count, stream);
         if (rc != MISPLAT_OK) return rc;
-        rc = misplat_color_fwd(p, a->sh_degree, a->K_or_D, a->n_color, a->per_cam, a->depth_channel, a->means, a->viewmats,
-                               a->colors, a->colors_rest, a->radii, a->depths, a->grec, a->sh_aux, a->v_grec_zero, stream);
-        if (rc != MISPLAT_OK) return rc;
+        if (!a->colour_pending) {
+            rc = enqueue_colour(p, a, stream);
+            if (rc != MISPLAT_OK) return rc;
+        }
     }
     if (phases & 2) {
         if (a->cap_isects < 0 || a->cap_isects > 0x7fffffffLL) return MISPLAT_EINVAL;
+        bool forked = false;
+        if (colour_in_b) {
+            if (fork && hipEventRecord(fork->forked, s) == hipSuccess && hipStreamWaitEvent(fork->side, fork->forked, 0) == hipSuccess) {
+                rc = enqueue_colour(p, a, (misplat_stream_t)fork->side);
+                if (rc != MISPLAT_OK) return rc;
+                forked = true;
+            } else {
+                (void)hipGetLastError();
+                rc = enqueue_colour(p, a, stream);
+                if (rc != MISPLAT_OK) return rc;
+            }
+        }
         rc = misplat_bucket_tiles(p, a->order, a->rect_sorted, a->counters, a->tile_count, a->offsets, nullptr, a->cap_isects,
                                   a->payload, nullptr, stream);
         if (rc != MISPLAT_OK) return rc;
@@ -60,6 +89,8 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
                                    a->payload, a->flatten_ids, a->scratch, 3, stream);
             if (rc != MISPLAT_OK) return rc;
         }
+        if (forked && (hipEventRecord(fork->joined, fork->side) != hipSuccess || hipStreamWaitEvent(s, fork->joined, 0) != hipSuccess))
+            return MISPLAT_ELAUNCH;
         misplat_params q = *p;
         q.unit_perm = a->unit_perm_in;
         q.unit_work = a->unit_work;
@@ -99,15 +130,19 @@ struct misplat_graph_cache {
     // Sequences are captured on this private stream (the caller's may be the legacy default stream, which cannot be
     // captured) and the resulting graph is launched on the caller's stream.
     hipStream_t capture_stream = nullptr;
+    Fork fork{nullptr, nullptr, nullptr};       // the parallel branch of a captured sequence (side stream: capture only)
 };
 
 extern "C" misplat_graph_cache* misplat_graph_cache_create(int32_t max_entries) {
     misplat_graph_cache* c = new (std::nothrow) misplat_graph_cache();
     if (!c) return nullptr;
     if (max_entries > 0) c->max_entries = max_entries;
-    if (hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->fork.side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fork.forked, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fork.joined, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
-        delete c;
+        misplat_graph_cache_destroy(c);
         return nullptr;
     }
     return c;
@@ -119,6 +154,9 @@ extern "C" void misplat_graph_cache_destroy(misplat_graph_cache* c) {
     for (auto& e : c->entries) { (void)hipGraphExecDestroy(e.exec); (void)hipGraphDestroy(e.graph); }
     for (auto& r : c->retired) { (void)hipGraphExecDestroy(r.exec); (void)hipGraphDestroy(r.graph); (void)hipEventDestroy(r.done); }
     if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream);
+    if (c->fork.side) (void)hipStreamDestroy(c->fork.side);
+    if (c->fork.forked) (void)hipEventDestroy(c->fork.forked);
+    if (c->fork.joined) (void)hipEventDestroy(c->fork.joined);
     delete c;
 }
 
@@ -134,7 +172,7 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
                                   misplat_stream_t stream, misplat_graph_cache* cache) {
     if (!p || !a || (phases & ~3) != 0 || phases == 0) return MISPLAT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (!cache) return enqueue_forward(p, a, phases, s);
+    if (!cache) return enqueue_forward(p, a, phases, s, nullptr);
     // key: everything the enqueued work depends on -- the two argument blocks, the phases and the stream
     std::vector<uint8_t> key(sizeof(int32_t) + sizeof(void*) + sizeof(*p) + sizeof(*a));
     uint8_t* k = key.data();
@@ -172,27 +210,27 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
         if (2 * cache->window_misses > cache->window_calls) cache->bypass_until = cache->clock + 512;
         cache->window_calls = cache->window_misses = 0;
     }
-    if (cache->clock < cache->bypass_until) return enqueue_forward(p, a, phases, s);
+    if (cache->clock < cache->bypass_until) return enqueue_forward(p, a, phases, s, nullptr);
     // capture on the private stream (thread-local mode: other host threads keep using the runtime normally)
     hipStream_t cs = cache->capture_stream;
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
-        return enqueue_forward(p, a, phases, s);
+        return enqueue_forward(p, a, phases, s, nullptr);
     }
-    const int rc = enqueue_forward(p, a, phases, cs);
+    const int rc = enqueue_forward(p, a, phases, cs, &cache->fork);
     hipGraph_t graph = nullptr;
     const hipError_t ec = hipStreamEndCapture(cs, &graph);
     if (rc != MISPLAT_OK || ec != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        return rc != MISPLAT_OK ? rc : enqueue_forward(p, a, phases, s);
+        return rc != MISPLAT_OK ? rc : enqueue_forward(p, a, phases, s, nullptr);
     }
     hipGraphExec_t exec = nullptr;
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (ei != hipSuccess || !exec) {
         (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        return enqueue_forward(p, a, phases, s);
+        return enqueue_forward(p, a, phases, s, nullptr);
     }
     if ((int)cache->entries.size() >= cache->max_entries) {       // evict the least recently used graph
         size_t victim = 0;

@@ -546,6 +546,7 @@ def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Par
 FUSED_ENTRY = os.environ.get("MISPLAT_FUSED", "1") == "1"
 SPECULATE = os.environ.get("MISPLAT_SPECULATE", "1") == "1"
 CAP_MARGIN = float(os.environ.get("MISPLAT_CAP_MARGIN", "1.25"))
+COLOUR_BRANCH = os.environ.get("MISPLAT_COLOUR_BRANCH", "1") == "1"    # colour kernel beside the bucketing (graph branch)
 _CAP_HINT: Dict[tuple, int] = {}
 _READBACK: Dict[int, tuple] = {}
 
@@ -645,6 +646,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     a.cell_offs, a.order, a.counters, a.tile_count = _dp(cell_offs), _dp(order), _dp(counters), _dp(tile_count)
     a.rect_sorted = _dp(rect_sorted)
     a.n_isects_host = host.data_ptr()
+    a.colour_pending = int(COLOUR_BRANCH)           # the colour kernel moves into phase B's parallel branch
     check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
           "misplat_raster_fwd(A)")
     state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero,
@@ -698,6 +700,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         if n_known <= cap:
             break
         cap = n_known                                                 # the guess was too small: exact size, once more
+        a.colour_pending = 0                                          # (the colours were written by the first attempt)
         tc = state["keep"][6]                                         # tile_count: phase B expects it cleared
         check(lib.misplat_zero_bytes(ptr(tc), C.c_size_t(4 * tc.numel()), stream_ptr()), "misplat_zero_bytes")
         if cap >= 2 ** 31:

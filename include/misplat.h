@@ -383,7 +383,7 @@ int misplat_outputs_bwd(int64_t n_pix, int32_t color_dim, const float* backgroun
  * Every pointer is a caller-allocated device buffer of the size the per-stage entry points above document
  * (n_isects_host: 8 bytes of PINNED host memory).
  *   phases & 1 (A): project_pack_fwd, bucket_count, copy counters[0] -> *n_isects_host, bucket_rows, color_fwd
- *   phases & 2 (B): bucket_tiles, tile_sort (unordered), blend_fwd (+ unit_work), unit_order
+ *   phases & 2 (B): [color_fwd, if colour_pending] || bucket_tiles, tile_sort (unordered); blend_fwd (+ unit_work), unit_order
  * B only reads device-side sizes, so it may be enqueued with a speculative cap_isects before the host knows the count:
  * the result is exact iff the count (misplat_wait_count) is <= cap_isects (else: clear tile_count and call B again
  * with the exact size).  Atomic gradient mode only (the deterministic slab needs the emission-slot scan between A and B). */
@@ -393,6 +393,10 @@ typedef struct misplat_raster_args {
     int32_t sh_degree;      /* -1: pass-through colours */
     int32_t K_or_D, n_color, per_cam, depth_channel;
     int32_t color_dim;      /* channels the compositing kernels carry (1..4) */
+    int32_t colour_pending; /* != 0: the colour kernel is left out of phase A and runs at the start of phase B instead
+                               (nothing before the compositing reads it) -- beside the bucketing kernels when the call
+                               goes through a graph cache (two parallel branches) */
+    int32_t reserved2;
     /* per (camera, Gaussian) outputs */
     int32_t* radii;
     float *means2d, *depths, *compensations, *grec, *sh_aux /* or NULL */;
