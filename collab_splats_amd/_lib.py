@@ -54,6 +54,18 @@ class RasterArgs(C.Structure):
                                              "unit_perm_out")])
 
 
+class RasterBwdArgs(C.Structure):
+    """Mirror of ``misplat_raster_bwd_args`` (include/misplat.h)."""
+    _fields_ = ([(n, C.c_void_p) for n in ("Ks", "grec", "flatten_ids", "offsets")] + [("n_isects", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("alpha", "last_ids", "median_ids", "render", "v_render", "v_alpha", "v_exp_depth",
+                                             "v_med_depth", "v_normal", "v_grec", "v_abs", "unit_perm")]
+                + [(n, C.c_int32) for n in ("color_dim", "zero_flags", "sh_degree", "K_or_D", "n_color", "per_cam",
+                                            "depth_slot", "reserved")]
+                + [(n, C.c_void_p) for n in ("means", "quats", "scales", "opacities", "colors", "colors_rest", "viewmats",
+                                             "radii", "compensations", "sh_aux", "v_means2d", "v_colors", "v_colors_rest",
+                                             "v_means_dir", "v_means", "v_quats", "v_scales", "v_opacities")])
+
+
 def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: int = 16,
                 antialiased: bool = False, opacity_aware_radius: bool = True, eps2d: float = 0.3,
                 near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0,
@@ -94,7 +106,7 @@ SYMBOLS = {
     "misplat_depth_normal_bwd": (C.c_int, 14), "misplat_outputs_fwd": (C.c_int, 15), "misplat_outputs_bwd": (C.c_int, 16),
     "misplat_bucket_plan": (C.c_int, 3), "misplat_bucket_count": (C.c_int, 10), "misplat_bucket_rows": (C.c_int, 11),
     "misplat_bucket_tiles": (C.c_int, 11),
-    "misplat_unit_order": (C.c_int, 5), "misplat_raster_fwd": (C.c_int, 5), "misplat_graph_cache_create": (C.c_void_p, 1),
+    "misplat_unit_order": (C.c_int, 5), "misplat_raster_fwd": (C.c_int, 5), "misplat_raster_bwd": (C.c_int, 4), "misplat_graph_cache_create": (C.c_void_p, 1),
     "misplat_graph_cache_destroy": (None, 1), "misplat_graph_cache_stats": (C.c_int, 3), "misplat_wait_count": (C.c_int64, 2), "misplat_zero_bytes": (C.c_int, 3), "misplat_stream_copy": (C.c_int, 4),
     "misplat_version": (C.c_char_p, 0),
 }

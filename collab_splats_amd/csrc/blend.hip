@@ -1099,8 +1099,9 @@ extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_d
     hipStream_t s = (hipStream_t)stream;
     const size_t rows = (size_t)p->n_gauss * p->n_cams;
     if (rows == 0) return MISPLAT_OK;
-    if (!v_grec_is_zero && hipMemsetAsync(v_grec, 0, rows * MISPLAT_REC * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
-    if (v_abs && hipMemsetAsync(v_abs, 0, rows * 2 * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    // v_grec_is_zero: bit 0 = v_grec, bit 1 = v_abs have been cleared by the caller
+    if (!(v_grec_is_zero & 1) && hipMemsetAsync(v_grec, 0, rows * MISPLAT_REC * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (v_abs && !(v_grec_is_zero & 2) && hipMemsetAsync(v_abs, 0, rows * 2 * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
     if (n_isects == 0) return MISPLAT_OK;
     const int ppl = pick_ppl(p->ppl_bwd, kDefaultPplBwd);
     const int total = p->tile_w * p->tile_h * p->n_cams * (4 / ppl);

@@ -168,18 +168,9 @@ extern "C" int misplat_graph_cache_stats(misplat_graph_cache* c, int64_t* hits, 
     return MISPLAT_OK;
 }
 
-extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_args* a, int32_t phases,
-                                  misplat_stream_t stream, misplat_graph_cache* cache) {
-    if (!p || !a || (phases & ~3) != 0 || phases == 0) return MISPLAT_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    if (!cache) return enqueue_forward(p, a, phases, s, nullptr);
-    // key: everything the enqueued work depends on -- the two argument blocks, the phases and the stream
-    std::vector<uint8_t> key(sizeof(int32_t) + sizeof(void*) + sizeof(*p) + sizeof(*a));
-    uint8_t* k = key.data();
-    memcpy(k, &phases, sizeof(int32_t)); k += sizeof(int32_t);
-    memcpy(k, &s, sizeof(void*)); k += sizeof(void*);
-    memcpy(k, p, sizeof(*p)); k += sizeof(*p);
-    memcpy(k, a, sizeof(*a));
+// Run `enqueue(stream, fork)` through the cache: replay the graph captured for `key`, or capture it now.
+template <class Enqueue>
+static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hipStream_t s, Enqueue enqueue) {
     std::lock_guard<std::mutex> g(cache->mu);
     cache->clock++;
     // retired graphs whose last launch has completed can go now
@@ -210,27 +201,27 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
         if (2 * cache->window_misses > cache->window_calls) cache->bypass_until = cache->clock + 512;
         cache->window_calls = cache->window_misses = 0;
     }
-    if (cache->clock < cache->bypass_until) return enqueue_forward(p, a, phases, s, nullptr);
+    if (cache->clock < cache->bypass_until) return enqueue(s, (const Fork*)nullptr);
     // capture on the private stream (thread-local mode: other host threads keep using the runtime normally)
     hipStream_t cs = cache->capture_stream;
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
-        return enqueue_forward(p, a, phases, s, nullptr);
+        return enqueue(s, (const Fork*)nullptr);
     }
-    const int rc = enqueue_forward(p, a, phases, cs, &cache->fork);
+    const int rc = enqueue(cs, &cache->fork);
     hipGraph_t graph = nullptr;
     const hipError_t ec = hipStreamEndCapture(cs, &graph);
     if (rc != MISPLAT_OK || ec != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        return rc != MISPLAT_OK ? rc : enqueue_forward(p, a, phases, s, nullptr);
+        return rc != MISPLAT_OK ? rc : enqueue(s, (const Fork*)nullptr);
     }
     hipGraphExec_t exec = nullptr;
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (ei != hipSuccess || !exec) {
         (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        return enqueue_forward(p, a, phases, s, nullptr);
+        return enqueue(s, (const Fork*)nullptr);
     }
     if ((int)cache->entries.size() >= cache->max_entries) {       // evict the least recently used graph
         size_t victim = 0;
@@ -253,6 +244,57 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
     cache->entries.push_back(GraphEntry{std::move(key), exec, graph, cache->clock, s});
     cache->captures++;
     return hipGraphLaunch(exec, s) == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+}
+
+template <class A>
+static std::vector<uint8_t> make_key(int32_t tag, hipStream_t s, const misplat_params* p, const A* a) {
+    // everything the enqueued work depends on: the two argument blocks, the entry / phases tag and the stream
+    std::vector<uint8_t> key(sizeof(int32_t) + sizeof(void*) + sizeof(*p) + sizeof(*a));
+    uint8_t* k = key.data();
+    memcpy(k, &tag, sizeof(int32_t)); k += sizeof(int32_t);
+    memcpy(k, &s, sizeof(void*)); k += sizeof(void*);
+    memcpy(k, p, sizeof(*p)); k += sizeof(*p);
+    memcpy(k, a, sizeof(*a));
+    return key;
+}
+
+extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_args* a, int32_t phases,
+                                  misplat_stream_t stream, misplat_graph_cache* cache) {
+    if (!p || !a || (phases & ~3) != 0 || phases == 0) return MISPLAT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (!cache) return enqueue_forward(p, a, phases, s, nullptr);
+    return run_cached(cache, make_key(phases, s, p, a), s,
+                      [&](hipStream_t st, const Fork* f) { return enqueue_forward(p, a, phases, st, f); });
+}
+
+// ---- the whole backward of rasterization(): compositing backward (atomic gradient rows), colour backward,
+// projection backward -- three launches, no memset when the forward left cleared gradient rows behind
+static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_args* b, hipStream_t s) {
+    misplat_stream_t stream = (misplat_stream_t)s;
+    misplat_params q = *p;
+    q.unit_perm = b->unit_perm;
+    q.unit_work = nullptr;
+    int rc = misplat_blend_bwd_atomic(&q, b->color_dim, b->Ks, b->grec, b->flatten_ids, b->offsets, b->n_isects, b->alpha,
+                                      b->last_ids, b->median_ids, b->render, b->v_render, b->v_alpha, b->v_exp_depth,
+                                      b->v_med_depth, b->v_normal, b->v_grec, b->v_abs, b->zero_flags, stream);
+    if (rc != MISPLAT_OK) return rc;
+    rc = misplat_color_bwd(p, b->sh_degree, b->K_or_D, b->n_color, b->per_cam, b->means, b->viewmats, b->colors,
+                           b->colors_rest, b->radii, b->v_grec, b->v_colors, b->v_colors_rest, b->v_means_dir, b->sh_aux,
+                           stream);
+    if (rc != MISPLAT_OK) return rc;
+    return misplat_project_pack_bwd(p, b->depth_slot, b->means, b->quats, b->scales, b->opacities, b->viewmats, b->Ks,
+                                    b->radii, b->compensations, b->v_means2d, b->v_grec, b->v_means_dir, b->v_means,
+                                    b->v_quats, b->v_scales, b->v_opacities, stream);
+}
+
+extern "C" int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
+                                  misplat_graph_cache* cache) {
+    if (!p || !b) return MISPLAT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    // memset nodes are kept out of graphs (see the note on phase A): only the memset-free form is captured
+    const bool memset_free = (b->zero_flags & 1) && (!b->v_abs || (b->zero_flags & 2));
+    if (!cache || !memset_free) return enqueue_backward(p, b, s);
+    return run_cached(cache, make_key(0x100, s, p, b), s, [&](hipStream_t st, const Fork*) { return enqueue_backward(p, b, st); });
 }
 
 // float4 streaming copy: the measured HBM roof of the box the benchmark runs on (bench.py reports fractions of it

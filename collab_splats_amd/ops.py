@@ -16,7 +16,7 @@ import torch
 from torch import Tensor
 
 from . import _lib
-from ._lib import MISPLAT_REC, Params, RasterArgs, check, ptr, require_gpu, stream_ptr
+from ._lib import MISPLAT_REC, Params, RasterArgs, RasterBwdArgs, check, ptr, require_gpu, stream_ptr
 
 
 # False (default): every (band, Gaussian) gradient row is added into the per-Gaussian gradient with
@@ -547,6 +547,7 @@ FUSED_ENTRY = os.environ.get("MISPLAT_FUSED", "1") == "1"
 SPECULATE = os.environ.get("MISPLAT_SPECULATE", "1") == "1"
 CAP_MARGIN = float(os.environ.get("MISPLAT_CAP_MARGIN", "1.25"))
 COLOUR_BRANCH = os.environ.get("MISPLAT_COLOUR_BRANCH", "1") == "1"    # colour kernel beside the bucketing (graph branch)
+COLOUR_BRANCH_MIN_ROWS = 500_000
 _CAP_HINT: Dict[tuple, int] = {}
 _READBACK: Dict[int, tuple] = {}
 
@@ -646,7 +647,9 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     a.cell_offs, a.order, a.counters, a.tile_count = _dp(cell_offs), _dp(order), _dp(counters), _dp(tile_count)
     a.rect_sorted = _dp(rect_sorted)
     a.n_isects_host = host.data_ptr()
-    a.colour_pending = int(COLOUR_BRANCH)           # the colour kernel moves into phase B's parallel branch
+    # the colour kernel moves into phase B's parallel graph branch -- worth it only for large scenes (a two-branch
+    # graph costs ~40 us more host time per launch; gains ~10 us of GPU time at 1 M Gaussians)
+    a.colour_pending = int(COLOUR_BRANCH and rows >= COLOUR_BRANCH_MIN_ROWS)
     check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
           "misplat_raster_fwd(A)")
     state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero,
@@ -718,6 +721,149 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
     imgs = (render.view(Cn, H, W, cd), alpha.view(Cn, H, W, 1), exp_depth.view(Cn, H, W, 1), med_depth.view(Cn, H, W, 1),
             normal.view(Cn, H, W, 3), last_ids.view(Cn, H, W), median_ids.view(Cn, H, W))
     return imgs, bins, sched
+
+
+# ----------------------------------------------------------------------------- one autograd node for the whole call
+
+# The reference's path as ONE autograd node: forward = phases A + B (two C calls, or one graph each), backward = one C
+# call (misplat_raster_bwd: compositing, colour, projection backward; replayed as a graph when memset-free).  Halves
+# the autograd bookkeeping of the two-node form, which is what a small scene spends its time on.  ``means2d`` is an
+# OUTPUT of the node; gsplat's contract -- ``meta["means2d"].grad`` / ``.absgrad`` hold the screen-space gradient
+# after ``backward()`` (rade_gs_model.py:191-198) -- is kept by assigning both from inside the backward.  The other
+# per-Gaussian intermediates in ``meta`` (conics, ray planes, ...) are not differentiable in this form; set
+# MISPLAT_FUSED_NODE=0 (the two-node form) to differentiate through them.
+FUSED_NODE = os.environ.get("MISPLAT_FUSED_NODE", "1") == "1"
+
+
+def fused_node_ok() -> bool:
+    return FUSED_NODE and fused_entry_ok()
+
+
+class _RasterFused(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, P: Params, sh_degree,
+                depth_channel: bool, cd: int, absgrad: bool, extra: dict):
+        import weakref
+        require_gpu(means, quats, scales, opacities, colors, viewmats, Ks)
+        if sh_degree is not None:
+            kd = colors.shape[1] if colors_rest is None else 1 + colors_rest.shape[1]
+            deg, n_color, per_cam = int(sh_degree), 3, 0
+        else:
+            deg, kd, per_cam = -1, colors.shape[-1], int(colors.dim() == 3)
+            n_color = kd
+        want_grad = any(ctx.needs_input_grad[:6])
+        want_aux = SH_AUX and deg >= 0 and want_grad
+        radii, means2d, depths, comps, grec, sh_aux, state = _raster_phase_a(
+            P, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam, depth_channel,
+            want_aux, want_grad)
+        imgs, bins, sched = _raster_phase_b(P, state, cd)
+        render, alpha, exp_depth, med_depth, normal, last_ids, median_ids = imgs
+        extra["bins"] = bins
+        ctx.P, ctx.bins, ctx.sched, ctx.cd, ctx.absgrad = P, bins, sched, cd, absgrad
+        ctx.color_args = (deg, kd, n_color, per_cam)
+        ctx.depth_slot = 12 + n_color if depth_channel else -1
+        ctx.has_rest, ctx.has_aux = colors_rest is not None, sh_aux is not None
+        ctx.means2d_ref = weakref.ref(means2d)
+        ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps,
+                              colors_rest if colors_rest is not None else colors,
+                              sh_aux if sh_aux is not None else comps, grec, alpha, last_ids, median_ids, render)
+        ctx.mark_non_differentiable(radii, depths, comps, grec, last_ids, median_ids)
+        ctx.set_materialize_grads(False)
+        return render, alpha, exp_depth, med_depth, normal, means2d, radii, depths, comps, grec, last_ids, median_ids
+
+    @staticmethod
+    def backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, v_means2d_in, *_unused):
+        lib = _lib.load()
+        (means, quats, scales, opacities, colors, viewmats, Ks, radii, comps, colors_rest, sh_aux, grec, alpha, last_ids,
+         median_ids, render) = ctx.saved_tensors
+        if not ctx.has_rest:
+            colors_rest = None
+        if not ctx.has_aux:
+            sh_aux = None
+        P, bins, cd = ctx.P, ctx.bins, ctx.cd
+        deg, kd, n_color, per_cam = ctx.color_args
+        dev = grec.device
+        rows = P.n_cams * P.n_gauss
+        ups = _upstream(P, cd, dev, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
+        v_grec = bins.pop("v_grec_zero", None)
+        flags = 1 if v_grec is not None else 0
+        if v_grec is None:
+            v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
+        v_abs = None
+        if ctx.absgrad:
+            v_abs = torch.zeros(rows, 2, device=dev, dtype=torch.float32)
+            flags |= 2
+        v_colors = _grad_out(colors)
+        v_colors_rest = _grad_out(colors_rest) if colors_rest is not None else None
+        v_means_dir = torch.empty_like(means) if deg >= 0 else None
+        v_means, v_quats = _grad_out(means), _grad_out(quats)
+        v_scales, v_opac = _grad_out(scales), _grad_out(opacities)
+        perm = ctx.sched.perm_bwd if ctx.sched is not None else None
+        simple = GRAD_SINK is None and v_means2d_in is None
+        if simple:
+            b = RasterBwdArgs()
+            b.Ks, b.grec, b.flatten_ids, b.offsets = _dp(Ks), _dp(grec), _dp(bins["flatten_ids"]), _dp(bins["isect_offsets"])
+            b.n_isects = bins["n_isects"]
+            b.alpha, b.last_ids, b.median_ids, b.render = _dp(alpha), _dp(last_ids), _dp(median_ids), _dp(render)
+            b.v_render, b.v_alpha, b.v_exp_depth, b.v_med_depth, b.v_normal = [_dp(t) for t in ups]
+            b.v_grec, b.v_abs, b.unit_perm = _dp(v_grec), _dp(v_abs), _dp(perm)
+            b.color_dim, b.zero_flags = cd, flags
+            b.sh_degree, b.K_or_D, b.n_color, b.per_cam, b.depth_slot = deg, kd, n_color, per_cam, ctx.depth_slot
+            b.means, b.quats, b.scales, b.opacities = _dp(means), _dp(quats), _dp(scales), _dp(opacities)
+            b.colors, b.colors_rest, b.viewmats, b.radii = _dp(colors), _dp(colors_rest), _dp(viewmats), _dp(radii)
+            b.compensations, b.sh_aux, b.v_means2d = _dp(comps), _dp(sh_aux), None
+            b.v_colors, b.v_colors_rest, b.v_means_dir = _dp(v_colors), _dp(v_colors_rest), _dp(v_means_dir)
+            b.v_means, b.v_quats, b.v_scales, b.v_opacities = _dp(v_means), _dp(v_quats), _dp(v_scales), _dp(v_opac)
+            with _timed("raster_bwd"):
+                check(lib.misplat_raster_bwd(C.byref(P), C.byref(b), stream_ptr(), _graph_cache(dev)), "misplat_raster_bwd")
+        else:
+            # data-parallel gradient sink (the colour bucket's all-reduce starts between the kernels) or a gradient that
+            # reached means2d from another consumer: stage by stage
+            _with_perm = C.c_void_p(perm.data_ptr()) if perm is not None else None
+            P.unit_perm = _with_perm
+            check(lib.misplat_blend_bwd_atomic(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
+                                               ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(alpha),
+                                               ptr(last_ids), ptr(median_ids), ptr(render), *[ptr(t) for t in ups],
+                                               ptr(v_grec), ptr(v_abs), C.c_int32(flags), stream_ptr()),
+                  "misplat_blend_bwd_atomic")
+            P.unit_perm = None
+            check(lib.misplat_color_bwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
+                                        C.c_int32(per_cam), ptr(means), ptr(viewmats), ptr(colors), ptr(colors_rest),
+                                        ptr(radii), ptr(v_grec), ptr(v_colors), ptr(v_colors_rest), ptr(v_means_dir),
+                                        ptr(sh_aux), stream_ptr()), "misplat_color_bwd")
+            if GRAD_SINK is not None:
+                GRAD_SINK.colour_ready()
+            vm2d = None
+            if v_means2d_in is not None:
+                vm2d = (v_grec.view(P.n_cams, P.n_gauss, MISPLAT_REC)[..., 0:2] + v_means2d_in).contiguous()
+            check(lib.misplat_project_pack_bwd(C.byref(P), C.c_int32(ctx.depth_slot), ptr(means), ptr(quats),
+                                               ptr(scales), ptr(opacities), ptr(viewmats), ptr(Ks), ptr(radii),
+                                               ptr(comps), ptr(vm2d), ptr(v_grec), ptr(v_means_dir), ptr(v_means),
+                                               ptr(v_quats), ptr(v_scales), ptr(v_opac), stream_ptr()),
+                  "misplat_project_pack_bwd")
+        # gsplat's contract: the screen-space gradient rides on meta["means2d"]
+        m2d = ctx.means2d_ref()
+        if m2d is not None:
+            g2d = v_grec.view(P.n_cams, P.n_gauss, MISPLAT_REC)[..., 0:2]
+            m2d.grad = g2d if v_means2d_in is None else g2d + v_means2d_in
+            if ctx.absgrad:
+                m2d.absgrad = v_abs.view(P.n_cams, P.n_gauss, 2)
+        return (v_means, v_quats, v_scales, v_opac, v_colors, v_colors_rest, None, None, None, None, None, None, None, None)
+
+
+def raster_fused(means, quats, scales, opacities, colors, viewmats, Ks, P: Params, sh_degree, depth_channel: bool,
+                 cd: int, absgrad: bool):
+    """(render, alpha, exp_depth, med_depth, normal, means2d, radii, depths, comps, grec, last_ids, median_ids), bins."""
+    rest = None
+    if isinstance(colors, (tuple, list)):
+        colors, rest = colors
+        rest = _f32(rest, "features_rest")
+    args = [_f32(t, n) for t, n in ((means, "means"), (quats, "quats"), (scales, "scales"),
+                                    (opacities, "opacities"), (colors, "colors"))]
+    extra: dict = {}
+    out = _RasterFused.apply(*args, rest, _f32(viewmats, "viewmats"), _f32(Ks, "Ks"), P, sh_degree, bool(depth_channel),
+                             int(cd), bool(absgrad), extra)
+    return out, extra["bins"]
 
 
 # ----------------------------------------------------------------------------- fused path

@@ -118,8 +118,18 @@ def rasterization(
                     opacity_aware_radius=opacity_aware_radius, eps2d=eps2d, near_plane=near_plane,
                     far_plane=far_plane, radius_clip=radius_clip, radius_sigma=radius_sigma,
                     alpha_max=alpha_max, ed_slot=n_user if ed_fused else -1)
-    if fused:
-        # ---- the reference's path (RGB / RGB+ED, SH or RGB colours): two autograd nodes, no glue kernels
+    if fused and ops.fused_node_ok() and N > 0:
+        # ---- the reference's path as ONE autograd node (ops._RasterFused): two C calls forward, one backward
+        cin = colors if n_user > 0 else means.new_zeros(N, 1)[:, :0].contiguous()
+        D = n_user + int(depth_channel)
+        out12, bins = ops.raster_fused(means, quats, scales, opacities, cin, viewmats, Ks, P,
+                                       sh_degree if n_user > 0 else None, depth_channel, D, absgrad)
+        render, alpha_, ed_, md_, nrm_, means2d, radii, depths, comps, grec, last_ids_, median_ids_ = out12
+        first = (render, alpha_, ed_, md_, nrm_, last_ids_, median_ids_)
+        gv = grec.view(Cn, N, 16)
+        conics, opac, ray_ts, ray_planes, normals = gv[..., 2:5], gv[..., 5], gv[..., 6], gv[..., 7:9], gv[..., 9:12]
+    elif fused:
+        # ---- the same path as two autograd nodes (differentiable per-Gaussian intermediates in meta), no glue kernels
         cin = colors if n_user > 0 else means.new_zeros(N, 1)
         prebin = {}                                   # tile counting starts inside the node, before the colour kernel
         radii, means2d, depths, comps, grec = ops.project_pack(

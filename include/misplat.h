@@ -311,8 +311,9 @@ int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const f
                              const int32_t* median_ids, const float* render, const float* v_render,
                              const float* v_alpha, const float* v_exp_depth, const float* v_med_depth,
                              const float* v_normal, float* v_grec, float* v_abs,
-                             int32_t v_grec_is_zero /* v_grec was cleared by misplat_color_fwd (zero_rows) and has not
-                             been used since: skip the memset */, misplat_stream_t stream);
+                             int32_t v_grec_is_zero /* bit 0: v_grec was cleared by misplat_color_fwd (zero_rows) and has
+                             not been used since; bit 1: v_abs was cleared by the caller: skip that memset */,
+                             misplat_stream_t stream);
 /* ---- a8: N-D colours in one pass (rade_features_model.py:441-476: D = 16 fused channels, 17 with
  * RGB+ED).  n_channels = D' in 5..20; channels 0..3 live in the record's colour slots, channels 4..
  * in featx[C*N, 4*nxq] (nxq = ceil((D'-4)/4) float4s per row, zero padded); color_fwd_x writes both
@@ -429,6 +430,32 @@ void misplat_graph_cache_destroy(misplat_graph_cache* cache);
 int misplat_graph_cache_stats(misplat_graph_cache* cache, int64_t* hits, int64_t* captures);
 int misplat_raster_fwd(const misplat_params* p, const misplat_raster_args* a, int32_t phases, misplat_stream_t stream,
                        misplat_graph_cache* cache /* or NULL: plain launches */);
+/* The whole backward of rasterization() as ONE host entry: misplat_blend_bwd_atomic, misplat_color_bwd,
+ * misplat_project_pack_bwd back to back (arguments as documented there).  zero_flags: see misplat_blend_bwd_atomic;
+ * with a cache the sequence is replayed as a graph when it contains no memset (zero_flags covers v_grec and v_abs). */
+typedef struct misplat_raster_bwd_args {
+    /* compositing backward: saved by the forward */
+    const float *Ks, *grec;
+    const int32_t *flatten_ids, *offsets;
+    int64_t n_isects;
+    const float* alpha;
+    const int32_t *last_ids, *median_ids;
+    const float* render;
+    /* upstream gradients of the five images (all given) */
+    const float *v_render, *v_alpha, *v_exp_depth, *v_med_depth, *v_normal;
+    float *v_grec, *v_abs /* or NULL */;
+    const int32_t* unit_perm /* or NULL */;
+    int32_t color_dim, zero_flags;
+    /* per-Gaussian backward */
+    int32_t sh_degree, K_or_D, n_color, per_cam, depth_slot, reserved;
+    const float *means, *quats, *scales, *opacities, *colors, *colors_rest, *viewmats;
+    const int32_t* radii;
+    const float *compensations, *sh_aux /* or NULL */;
+    const float* v_means2d /* or NULL: the mean2d gradient is columns 0:2 of v_grec */;
+    float *v_colors, *v_colors_rest /* or NULL */, *v_means_dir /* or NULL */, *v_means, *v_quats, *v_scales, *v_opacities;
+} misplat_raster_bwd_args;
+int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
+                       misplat_graph_cache* cache /* or NULL */);
 /* Host-side wait for phase A's count: the caller stores -1 in *n_isects_host before the call; returns the count as
  * soon as the device-to-host copy has landed, or -1 after timeout_us. */
 int64_t misplat_wait_count(const volatile int64_t* n_isects_host, int64_t timeout_us);

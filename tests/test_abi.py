@@ -57,11 +57,13 @@ def test_params_struct_layout_matches_c(built_lib):
     assert vals[1:] == [getattr(Params, f).offset for f in fields]
 
 
-def test_raster_args_struct_layout_matches_c(built_lib):
-    from collab_splats_amd._lib import RasterArgs
+@pytest.mark.parametrize("cname,pyname", [("misplat_raster_args", "RasterArgs"), ("misplat_raster_bwd_args", "RasterBwdArgs")])
+def test_raster_args_struct_layout_matches_c(built_lib, cname, pyname):
+    from collab_splats_amd import _lib
+    RasterArgs = getattr(_lib, pyname)
     fields = [f[0] for f in RasterArgs._fields_]
-    src = "#include <stdio.h>\n#include <stddef.h>\n#include \"misplat.h\"\nint main(){printf(\"%zu\\n\", sizeof(misplat_raster_args));\n"
-    src += "".join(f'printf("%zu\\n", offsetof(misplat_raster_args, {f}));\n' for f in fields) + "return 0;}\n"
+    src = "#include <stdio.h>\n#include <stddef.h>\n#include \"misplat.h\"\nint main(){printf(\"%zu\\n\", sizeof(" + cname + "));\n"
+    src += "".join(f'printf("%zu\\n", offsetof({cname}, {f}));\n' for f in fields) + "return 0;}\n"
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "t.c")
         open(c, "w").write(src)
