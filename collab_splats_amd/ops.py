@@ -546,7 +546,9 @@ def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Par
 FUSED_ENTRY = os.environ.get("MISPLAT_FUSED", "1") == "1"
 SPECULATE = os.environ.get("MISPLAT_SPECULATE", "1") == "1"
 CAP_MARGIN = float(os.environ.get("MISPLAT_CAP_MARGIN", "1.25"))
-COLOUR_BRANCH = os.environ.get("MISPLAT_COLOUR_BRANCH", "1") == "1"    # colour kernel beside the bucketing (graph branch)
+# colour kernel beside the bucketing as a parallel graph branch: measured +-1 % at 1 M Gaussians (both branches are
+# latency-bound but share the memory system) and +40 us of host time per launch, so it is off by default
+COLOUR_BRANCH = os.environ.get("MISPLAT_COLOUR_BRANCH", "0") == "1"
 COLOUR_BRANCH_MIN_ROWS = 500_000
 _CAP_HINT: Dict[tuple, int] = {}
 _READBACK: Dict[int, tuple] = {}
