@@ -750,6 +750,313 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
     }
 }
 
+// ---- backward, four sub-blocks per wave ("quad") --------------------------------------------------
+// The band kernel above walks ONE culled list per 16 x 8 band, and a Gaussian that survives the band's cull touches on
+// average under half of the band's pixels (scripts/work_stats.py: lane use 0.49).  Here the band is split into four
+// 8 x 4 SUB-BLOCKS, each owned by 16 lanes and each with its own culled list: in one loop trip the four lane groups
+// work on four DIFFERENT Gaussians of the staged batch (a group that has run out of entries idles on a null record).
+// 1 M / 1080p: 1.78 M band units -> 5.01 M sub-block units in 1.47 M trips (-17 %), exact counts from the CPU
+// restatement.  The per-Gaussian gradient rows of a batch are accumulated in LDS (ds_add_f32, one per lane and trip)
+// and leave as global atomics once per batch, so the number of global atomics does not grow with the finer split.
+//
+// MEASURED (1 M / 1080p, MI355X): 0.649 ms against 0.478 ms of the band kernel -- NOT the default (misplat_params.
+// sub_blocks = 4 selects it).  The loop executes the same 148 vector instructions per trip as the band kernel and
+// 17 % fewer trips, but ds_add_f32 is serialised in the LDS (SQ_LDS_IDX_ACTIVE 8.5x the band kernel's: the LDS is busy
+// 85 % of the kernel, 220 array cycles per trip against 22).  Bounds on any repair, measured with the same kernel: a
+// plain (racy, so wrong) read-add-write in place of the atomic: 0.448 ms, i.e. -7 % at best before the ~10 instructions
+// per trip that detecting two groups on the same slot would cost; one global atomic per sub-block unit instead of the
+// LDS rows (5.0 M x 64 B instead of 1.8 M): 1.43 ms, the memory-side atomic units saturate.  The per-batch overhead
+// (four box tests, list building, flush: ~600 instructions x 57 k batches) eats the rest of the 17 %.
+//
+// Lane map: the sub-block of lane l is s = (l & 3) ^ ((l & 4) ? 3 : 0), its pixel slot m = l >> 2: the four lanes of
+// a DPP quad belong to the four sub-blocks.  The reduction over a sub-block's 16 lanes is then a reduction over lane
+// bits 2..5 -- exactly the cheap stages of wave_reduce16 (bank-masked DPP for bits 2 and 3: row_half_mirror pairs l
+// with l ^ 7, which is why s is mirrored in the odd banks; v_permlane{16,32}_swap for bits 4 and 5) -- and the two
+// quad stages are simply left out: lane l ends with component (l >> 2) & 15 of ITS sub-block's Gaussian.
+__device__ __forceinline__ float sub_reduce16(float (&v)[16]) {
+#define MISPLAT_XU(k, n, ctrl, m_hi, m_lo)                                                            \
+    "v_add_f32_dpp %" #k ", %" #k ", %" #k " " ctrl " row_mask:0xf bank_mask:" m_hi "\n\t"            \
+    "v_add_f32_dpp %" #k ", %" #n ", %" #n " " ctrl " row_mask:0xf bank_mask:" m_lo "\n\t"
+    asm("s_nop 1\n\t"
+        MISPLAT_XU(0, 8, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(1, 9, "row_half_mirror", "0xa", "0x5")
+        MISPLAT_XU(2, 10, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(3, 11, "row_half_mirror", "0xa", "0x5")
+        MISPLAT_XU(4, 12, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(5, 13, "row_half_mirror", "0xa", "0x5")
+        MISPLAT_XU(6, 14, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(7, 15, "row_half_mirror", "0xa", "0x5")
+        : "+v"(v[1]), "+v"(v[3]), "+v"(v[5]), "+v"(v[7]), "+v"(v[9]), "+v"(v[11]), "+v"(v[13]), "+v"(v[15])
+        : "v"(v[0]), "v"(v[2]), "v"(v[4]), "v"(v[6]), "v"(v[8]), "v"(v[10]), "v"(v[12]), "v"(v[14]));
+    asm("s_nop 1\n\t"
+        MISPLAT_XU(0, 4, "row_ror:8", "0xc", "0x3") MISPLAT_XU(1, 5, "row_ror:8", "0xc", "0x3")
+        MISPLAT_XU(2, 6, "row_ror:8", "0xc", "0x3") MISPLAT_XU(3, 7, "row_ror:8", "0xc", "0x3")
+        : "+v"(v[3]), "+v"(v[7]), "+v"(v[11]), "+v"(v[15])
+        : "v"(v[1]), "v"(v[5]), "v"(v[9]), "v"(v[13]));
+#undef MISPLAT_XU
+    asm("s_nop 1\n\t"
+        "v_permlane16_swap_b32 %0, %1\n\t"
+        "v_permlane16_swap_b32 %2, %3"
+        : "+v"(v[3]), "+v"(v[7]), "+v"(v[11]), "+v"(v[15]));
+    float lo = v[3] + v[7], hi = v[11] + v[15];
+    asm("s_nop 1\n\t"
+        "v_permlane32_swap_b32 %0, %1"
+        : "+v"(lo), "+v"(hi));
+    return lo + hi;
+}
+__device__ __forceinline__ float sub_sum(float v) {            // sum over the 16 lanes of the caller's sub-block
+    v += dpp_mov<kDppHalfMirror>(v);
+    v += dpp_mov<kDppRor8>(v);
+    return cross_row_sum(v);
+}
+
+constexpr int kQS = 65;                // slots per staged batch + the null slot (64)
+
+template <int CD, bool ABS>
+#ifndef MISPLAT_BWDQ_WAVES
+#define MISPLAT_BWDQ_WAVES 4
+#endif
+__global__ __launch_bounds__(64, MISPLAT_BWDQ_WAVES) void blend_bwd_quad_kernel(
+    misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
+    const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ offsets, int64_t n_isects,
+    const float* __restrict__ alpha, const int32_t* __restrict__ last_ids, const int32_t* __restrict__ median_ids,
+    const float* __restrict__ render, const float* __restrict__ v_render, const float* __restrict__ v_alpha,
+    const float* __restrict__ v_exp_depth, const float* __restrict__ v_med_depth,
+    const float* __restrict__ v_normal, float* __restrict__ v_grec, float* __restrict__ v_abs) {
+    __shared__ float4 sm[4 * kQS];                 // component c of slot p: sm[c * kQS + p]; slot 64 = null record
+    __shared__ int sm_idx[kQS];                    // list position of the slot's Gaussian ([64] = INT_MAX)
+    __shared__ int sm_row[64];                     // its row of v_grec
+    __shared__ float gacc[kQS * MISPLAT_REC];      // gradient rows of the batch (row 64 collects the idle groups' zeros)
+    __shared__ float gabs[ABS ? kQS * 2 : 2];
+    __shared__ uint8_t lst[4][64];                 // per sub-block: the slots it has to visit, ascending
+    BandCtx c;
+    if (!band_ctx<2>(P, Ks, offsets, n_isects, c)) return;
+    if (c.end <= c.beg) return;
+    const int lane = threadIdx.x;
+    const int sub = (lane & 3) ^ ((lane & 4) ? 3 : 0);
+    const int m = lane >> 2;
+    const int x = c.tx * MISPLAT_TILE + (sub & 1) * 8 + (m & 7);
+    const int ybase = c.y0 + (sub >> 1) * 4 + (m >> 3);
+    const float px = (float)x + 0.5f;
+    const float rxn = (px - c.cx) / c.fx;
+    float T[2], tfva[2], vd[2], vm[2], vcol[2][CD], vn[2][3], py[2], inv_ell[2];
+    int last[2], medi[2];
+    int mymax = -1;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int y = ybase + 2 * k;
+        py[k] = (float)y + 0.5f;
+        const float ryn = (py[k] - c.cy) / c.fy;
+        inv_ell[k] = 1.0f / sqrtf(rxn * rxn + ryn * ryn + 1.0f);
+        last[k] = -1; medi[k] = -1; T[k] = 1.f; tfva[k] = 0.f; vd[k] = 0.f; vm[k] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < CD; ch++) vcol[k][ch] = 0.f;
+        vn[k][0] = vn[k][1] = vn[k][2] = 0.f;
+        if (x < P.width && y < P.height) {
+            const size_t pid = ((size_t)c.cam * P.height + y) * P.width + x;
+            last[k] = last_ids[pid];
+            medi[k] = median_ids[pid];
+            const float al = alpha[pid];
+            const float Tf = 1.0f - al;
+            T[k] = Tf;
+            float va = v_alpha[pid];
+#pragma unroll
+            for (int ch = 0; ch < CD; ch++) {
+                float g = v_render[pid * CD + ch];
+                if (ch == P.ed_slot) {         // out = raw / max(alpha, 1e-10)
+                    const float inv_al = 1.0f / fmaxf(al, 1e-10f);
+                    g *= inv_al;
+                    if (al > 1e-10f) va -= g * render[pid * CD + ch];
+                }
+                vcol[k][ch] = g;
+            }
+            tfva[k] = Tf * va;
+            vn[k][0] = v_normal[pid * 3]; vn[k][1] = v_normal[pid * 3 + 1]; vn[k][2] = v_normal[pid * 3 + 2];
+            vd[k] = v_exp_depth[pid];
+            vm[k] = v_med_depth[pid];
+        }
+        mymax = max(mymax, last[k]);
+    }
+    const int maxlast = wave_max(mymax);
+    if (maxlast < c.beg) return;
+    // largest last_id of each sub-block: a sub-block skips the entries behind it
+    int sl = mymax;
+    sl = max(sl, __shfl_xor(sl, 7)); sl = max(sl, __shfl_xor(sl, 8));
+    sl = max(sl, __shfl_xor(sl, 16)); sl = max(sl, __shfl_xor(sl, 32));
+    const int sl0 = __builtin_amdgcn_readlane(sl, 0), sl1 = __builtin_amdgcn_readlane(sl, 1);
+    const int sl2 = __builtin_amdgcn_readlane(sl, 2), sl3 = __builtin_amdgcn_readlane(sl, 3);
+    const v2f py2 = mk2(py[0], py[1]), il2 = mk2(inv_ell[0], inv_ell[1]), tf2 = mk2(tfva[0], tfva[1]);
+    const v2f vd2 = mk2(vd[0], vd[1]), vm2 = mk2(vm[0], vm[1]);
+    v2f T2 = mk2(T[0], T[1]), B2 = mk2(0.f, 0.f), vcol2[CD], vn2[3];
+#pragma unroll
+    for (int ch = 0; ch < CD; ch++) vcol2[ch] = mk2(vcol[0][ch], vcol[1][ch]);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) vn2[ch] = mk2(vn[0][ch], vn[1][ch]);
+    const int comp = (lane >> 2) & 15;
+    const float amax = P.alpha_max, amin = P.alpha_min;
+    const float bx0 = (float)(c.tx * MISPLAT_TILE) + 0.5f, by0 = (float)c.y0 + 0.5f;
+    // LDS: accumulators start (and are left by every flush) at zero; the null record has opacity 0
+    for (int k = lane; k < kQS * MISPLAT_REC; k += 64) gacc[k] = 0.f;
+    if (ABS) for (int k = lane; k < kQS * 2; k += 64) gabs[k] = 0.f;
+    if (lane < 4) sm[lane * kQS + 64] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane == 0) sm_idx[64] = 0x7fffffff;
+    const uint8_t* my_list = lst[sub];
+    const int fl_comp = lane & 15;                 // component this lane flushes
+    const float fl_scale = (fl_comp == 2 || fl_comp == 4) ? -0.5f * kLog2e : (fl_comp == 3 ? -kLog2e : 1.0f);
+
+    for (int b = (maxlast - c.beg) >> 6; b >= 0; b--) {
+        const int bs = c.beg + (b << 6);
+        __syncthreads();
+        // ---- stage: one list entry per lane, culled against each of the four sub-blocks
+        int n, n0, n1, n2, n3;
+        {
+            const int ii = bs + lane;
+            bool k0 = false, k1 = false, k2 = false, k3 = false;
+            float4 q0, q1, q2, q3;
+            int g = 0;
+            if (ii <= maxlast) {
+                g = flatten_ids[ii];
+                q0 = grec[4 * (size_t)g + 0]; q1 = grec[4 * (size_t)g + 1];
+                q2 = grec[4 * (size_t)g + 2]; q3 = grec[4 * (size_t)g + 3];
+                const float dxa = q0.x - bx0, dya = q0.y - by0;         // mean - centre of the band's first pixel
+                const float thr = amin / (q1.y * 1.002f);
+                const float s0 = sigma_min_box(q0.z, q0.w, q1.x, dxa - 7.f, dxa, dya - 3.f, dya);
+                const float s1 = sigma_min_box(q0.z, q0.w, q1.x, dxa - 15.f, dxa - 8.f, dya - 3.f, dya);
+                const float s2 = sigma_min_box(q0.z, q0.w, q1.x, dxa - 7.f, dxa, dya - 7.f, dya - 4.f);
+                const float s3 = sigma_min_box(q0.z, q0.w, q1.x, dxa - 15.f, dxa - 8.f, dya - 7.f, dya - 4.f);
+                k0 = ii <= sl0 && __builtin_amdgcn_exp2f(-s0 * kLog2e) >= thr;
+                k1 = ii <= sl1 && __builtin_amdgcn_exp2f(-s1 * kLog2e) >= thr;
+                k2 = ii <= sl2 && __builtin_amdgcn_exp2f(-s2 * kLog2e) >= thr;
+                k3 = ii <= sl3 && __builtin_amdgcn_exp2f(-s3 * kLog2e) >= thr;
+            }
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const unsigned long long mk = __ballot(k0 || k1 || k2 || k3);
+            const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
+            n = __popcll(mk); n0 = __popcll(m0); n1 = __popcll(m1); n2 = __popcll(m2); n3 = __popcll(m3);
+            if (k0 || k1 || k2 || k3) {
+                const int pos = __popcll(mk & lt);
+                q0.z *= -0.5f * kLog2e; q0.w *= -kLog2e; q1.x *= -0.5f * kLog2e;
+                sm[pos] = q0; sm[kQS + pos] = q1; sm[2 * kQS + pos] = q2; sm[3 * kQS + pos] = q3;
+                sm_idx[pos] = ii;
+                sm_row[pos] = g;
+                if (k0) lst[0][__popcll(m0 & lt)] = (uint8_t)pos;
+                if (k1) lst[1][__popcll(m1 & lt)] = (uint8_t)pos;
+                if (k2) lst[2][__popcll(m2 & lt)] = (uint8_t)pos;
+                if (k3) lst[3][__popcll(m3 & lt)] = (uint8_t)pos;
+            }
+        }
+        __syncthreads();
+        if (n == 0) continue;
+        const int trips = max(max(n0, n1), max(n2, n3));
+        bool mine_med = (unsigned)(medi[0] - bs) < 64u || (unsigned)(medi[1] - bs) < 64u;
+        const bool batch_has_median = __ballot(mine_med) != 0ull;
+        const int my_n = sub == 0 ? n0 : (sub == 1 ? n1 : (sub == 2 ? n2 : n3));
+        // walk the sub-block's list back to front; the slot of the trip after next and the record of the next trip are
+        // fetched ahead
+        int t = my_n - 1;
+        int pos = t >= 0 ? (int)my_list[t] : 64;
+        int pos_nx = t >= 1 ? (int)my_list[t - 1] : 64;
+        float4 q0 = sm[pos], q1 = sm[kQS + pos], q2 = sm[2 * kQS + pos], q3 = sm[3 * kQS + pos];
+        int i = sm_idx[pos];
+        // LDS returns in order: the accumulate of trip k is issued at the top of trip k + 1, ahead of that trip's
+        // record reads, so that no wait in the loop ever sits right behind it
+        float r_pend = 0.f, a0_pend = 0.f;
+        int addr_pend = 64 * MISPLAT_REC + comp, aaddr_pend = 64 * 2;
+        for (int step = 0; step < trips; step++) {
+            atomicAdd(&gacc[addr_pend], r_pend);                          // ds_add_f32, every lane its own address
+            if (ABS) { if (m < 2) atomicAdd(&gabs[aaddr_pend], a0_pend); }
+            const float dx = q0.x - px;
+            const float ea = q0.z * dx * dx, eb = q0.w * dx;
+            const float tpx = q1.z - q1.w * dx;
+            float acc[16];
+            float ab0 = 0.f, ab1 = 0.f;
+            const float dxx = dx * dx, ndx = -dx;
+            const float c1x = 2.0f * q0.z * dx, c1y = q0.w * dx;
+            const v2f dy = q0.y - py2;
+            const v2f e = ea + (q1.x * dy + eb) * dy;
+            v2f vis;
+            vis.x = __builtin_amdgcn_exp2f(e.x); vis.y = __builtin_amdgcn_exp2f(e.y);
+            const v2f ov = q1.y * vis;
+            const bool ok0 = (i <= last[0]) && (e.x <= 0.f) && (fminf(amax, ov.x) >= amin);
+            const bool ok1 = (i <= last[1]) && (e.y <= 0.f) && (fminf(amax, ov.y) >= amin);
+            v2f a;
+            a.x = ok0 ? fminf(amax, ov.x) : 0.f; a.y = ok1 ? fminf(amax, ov.y) : 0.f;
+            const float amx = fmaxf(a.x, a.y);
+            const v2f om = 1.0f - a;
+            v2f ra;
+            ra.x = __builtin_amdgcn_rcpf(om.x); ra.y = __builtin_amdgcn_rcpf(om.y);
+            T2 *= ra;
+            const v2f Tk = T2;
+            const v2f w = a * Tk;
+            const v2f zp = (tpx - q2.x * dy) * il2;
+            v2f dot = q3.x * vcol2[0];
+            if (CD > 1) dot += q3.y * vcol2[CD > 1 ? 1 : 0];
+            if (CD > 2) dot += q3.z * vcol2[CD > 2 ? 2 : 0];
+            if (CD > 3) dot += q3.w * vcol2[CD > 3 ? 3 : 0];
+            dot += q2.y * vn2[0] + q2.z * vn2[1] + q2.w * vn2[2] + zp * vd2;
+            v2f v_a = (tf2 - B2) * ra + Tk * dot;
+            v_a.x = ok0 ? v_a.x : 0.f; v_a.y = ok1 ? v_a.y : 0.f;
+            B2 += w * dot;
+            v2f vz = w * vd2;
+            if (batch_has_median) {
+                v2f vmed;
+                vmed.x = (ok0 && i == medi[0]) ? vm2.x : 0.f; vmed.y = (ok1 && i == medi[1]) ? vm2.y : 0.f;
+                vz += vmed;
+            }
+            const v2f vzl = vz * il2;
+            v2f vam;
+            vam.x = (ov.x <= amax) ? v_a.x : 0.f; vam.y = (ov.y <= amax) ? v_a.y : 0.f;
+            const v2f v_e = (kLn2 * ov) * vam;
+            const v2f dyve = dy * v_e;
+            const v2f vmx = (c1x + q0.w * dy) * v_e - vzl * q1.w;
+            const v2f vmy = (2.0f * q1.x * dy + c1y) * v_e - vzl * q2.x;
+            const float s_ve = v_e.x + v_e.y, s_dyve = dyve.x + dyve.y, s_vzl = vzl.x + vzl.y;
+            acc[0] = vmx.x + vmx.y; acc[1] = vmy.x + vmy.y;
+            acc[2] = dxx * s_ve; acc[3] = dx * s_dyve; acc[4] = fmaf(dy.y, dyve.y, dy.x * dyve.x);
+            acc[5] = fmaf(vis.y, vam.y, vis.x * vam.x);
+            acc[6] = s_vzl; acc[7] = ndx * s_vzl; acc[8] = -fmaf(vzl.y, dy.y, vzl.x * dy.x);
+            acc[9] = fmaf(w.y, vn2[0].y, w.x * vn2[0].x); acc[10] = fmaf(w.y, vn2[1].y, w.x * vn2[1].x);
+            acc[11] = fmaf(w.y, vn2[2].y, w.x * vn2[2].x);
+            acc[12] = fmaf(w.y, vcol2[0].y, w.x * vcol2[0].x);
+            acc[13] = CD > 1 ? fmaf(w.y, vcol2[CD > 1 ? 1 : 0].y, w.x * vcol2[CD > 1 ? 1 : 0].x) : 0.f;
+            acc[14] = CD > 2 ? fmaf(w.y, vcol2[CD > 2 ? 2 : 0].y, w.x * vcol2[CD > 2 ? 2 : 0].x) : 0.f;
+            acc[15] = CD > 3 ? fmaf(w.y, vcol2[CD > 3 ? 3 : 0].y, w.x * vcol2[CD > 3 ? 3 : 0].x) : 0.f;
+            if (ABS) { ab0 = fabsf(vmx.x) + fabsf(vmx.y); ab1 = fabsf(vmy.x) + fabsf(vmy.y); }
+            const int pos_cur = pos;
+            {   // next trip's record, the slot of the one after
+                pos = pos_nx;
+                q0 = sm[pos]; q1 = sm[kQS + pos]; q2 = sm[2 * kQS + pos]; q3 = sm[3 * kQS + pos];
+                i = sm_idx[pos];
+                t--;
+                pos_nx = t >= 1 ? (int)my_list[t - 1] : 64;
+            }
+            r_pend = 0.f;
+            if (__ballot(amx > 0.f) != 0ull) {
+                r_pend = sub_reduce16(acc);
+                addr_pend = pos_cur * MISPLAT_REC + comp;
+                if (ABS) {
+                    ab0 = sub_sum(ab0); ab1 = sub_sum(ab1);
+                    a0_pend = m == 0 ? ab0 : ab1;
+                    aaddr_pend = pos_cur * 2 + (m & 1);
+                }
+            } else if (ABS) a0_pend = 0.f;
+        }
+        atomicAdd(&gacc[addr_pend], r_pend);
+        if (ABS) { if (m < 2) atomicAdd(&gabs[aaddr_pend], a0_pend); }
+        __syncthreads();
+        // ---- flush the batch: one no-return global atomic per (slot, component), accumulators back to zero
+        for (int k = lane; k < n * MISPLAT_REC; k += 64) {
+            const float val = gacc[k];
+            gacc[k] = 0.f;
+            const size_t row = (size_t)sm_row[k >> 4];
+            if (val != 0.f) atomicAdd(&v_grec[row * MISPLAT_REC + fl_comp], val * fl_scale);
+        }
+        if (ABS) {
+            for (int k = lane; k < n * 2; k += 64) {
+                const float val = gabs[k];
+                gabs[k] = 0.f;
+                if (val != 0.f) atomicAdd(&v_abs[(size_t)sm_row[k >> 1] * 2 + (k & 1)], val);
+            }
+        }
+    }
+}
+
 // 16 lanes per Gaussian row r: v_grec[r][c] = sum over its intersections (ascending slot) and over
 // the bands (ascending) of the VALID slab rows: a fixed order, so the result is bitwise
 // reproducible.  Rows are fetched four slots at a time with unconditional loads (invalid rows are
@@ -1106,6 +1413,25 @@ extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_d
     const int ppl = pick_ppl(p->ppl_bwd, kDefaultPplBwd);
     const int total = p->tile_w * p->tile_h * p->n_cams * (4 / ppl);
     const int grid = ((total + 7) / 8) * 8;
+    if (ppl == 2 && p->sub_blocks == 4 && color_dim >= 1 && color_dim <= 4) {
+#define LAUNCH_BWDQ(CD_)                                                                                       \
+        do {                                                                                                   \
+            if (v_abs) hipLaunchKernelGGL((blend_bwd_quad_kernel<CD_, true>), dim3(grid), dim3(64), 0, s, *p, Ks, \
+                                          (const float4*)grec, flatten_ids, offsets, n_isects, alpha, last_ids, \
+                                          median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth,     \
+                                          v_normal, v_grec, v_abs);                                            \
+            else hipLaunchKernelGGL((blend_bwd_quad_kernel<CD_, false>), dim3(grid), dim3(64), 0, s, *p, Ks,   \
+                                    (const float4*)grec, flatten_ids, offsets, n_isects, alpha, last_ids,      \
+                                    median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, \
+                                    v_grec, v_abs);                                                            \
+        } while (0)
+        if (color_dim == 1) LAUNCH_BWDQ(1);
+        else if (color_dim == 2) LAUNCH_BWDQ(2);
+        else if (color_dim == 3) LAUNCH_BWDQ(3);
+        else LAUNCH_BWDQ(4);
+#undef LAUNCH_BWDQ
+        return check_launch();
+    }
 #define LAUNCH_BWDA(CD_, PPL_, ABS_)                                                                         \
     hipLaunchKernelGGL((blend_bwd_kernel<CD_, PPL_, ABS_, true>), dim3(grid), dim3(64), 0, s, *p, Ks,          \
                        (const float4*)grec, flatten_ids, (const int32_t*)nullptr, offsets, n_isects, alpha,    \

@@ -66,7 +66,8 @@ typedef struct misplat_params {
     int32_t ppl_bwd;      /* a tile is covered by 4/ppl independent wavefronts ("bands")          */
     int32_t ed_slot;      /* colour channel (0..3) the compositing kernels divide by max(alpha,1e-10)
                              (the "ED" of render_mode RGB+ED / ED, rade_gs_model.py:237), or -1     */
-    int32_t reserved0;    /* (keeps the pointers below 8-byte aligned) */
+    int32_t sub_blocks;   /* atomic backward, ppl_bwd 2, <= 4 channels: 4 = split every band into four 8x4 sub-blocks
+                             with their own culled lists (fewer idle pixel slots); 0 / 1 = one list per band        */
     /* Launch order of the compositing kernels (speed only; results never depend on it).  A "unit" is one band of
      * one tile: unit = tile * (4 / ppl) + band.  unit_work (or NULL): the forward writes the number of staged
      * Gaussians each unit composited -- its measured cost; unit_perm (or NULL): workgroup b of a compositing launch

@@ -732,6 +732,83 @@ void cr_blend_stats(const real* means2d, const real* conics, const real* opac,
     }
 }
 
+/* Design tooling: loop trips of a "four sub-blocks per wave" compositing backward.  A wave owns a 16x8 band; each
+ * of its four 16-lane rows owns a sub-block (sw x sh pixels, sw*sh = 32) with its own culled list.  The band's
+ * traversal (back to front from its largest last_id) is staged 64 entries at a time; survivors of the band-level
+ * cull queue up, and when at least `th` are queued (or the list ends) every row walks its own queued entries: the
+ * wave spends max-over-rows trips.  out: [0] band units, [1] sub-block units, [2] trips with th = 1 (every batch),
+ * [3] trips with the given th, [4] processing rounds with the given th, [5] batches staged. */
+void cr_quad_stats(const real* means2d, const real* conics, const real* opac,
+                   const int32_t* flatten_ids, const int32_t* offsets, int64_t I,
+                   const cr_params* P, const int32_t* last_ids, int sw, int sh, int th, int64_t* out) {
+    int ts = P->tile_size;
+    int tw = (P->width + ts - 1) / ts, tht = (P->height + ts - 1) / ts;
+    int nt = tw * tht;
+    for (int k = 0; k < 6; k++) out[k] = 0;
+#pragma omp parallel
+    {
+        int64_t loc[6] = {0, 0, 0, 0, 0, 0};
+#pragma omp for schedule(dynamic, 1)
+        for (int t = 0; t < nt; t++) {
+            int ty = t / tw, tx = t % tw;
+            int64_t beg = offsets[t], end = (t + 1 < nt) ? offsets[t + 1] : I;
+            for (int band = 0; band < 2; band++) {
+                int y0 = band * 8;
+                if (ty * ts + y0 >= P->height) continue;
+                int32_t maxlast = -1, sublast[4] = {-1, -1, -1, -1};
+                int nsx = 16 / sw;
+                for (int ly = 0; ly < 8; ly++)
+                    for (int lx = 0; lx < 16; lx++) {
+                        int x = tx * ts + lx, y = ty * ts + y0 + ly;
+                        if (x >= P->width || y >= P->height) continue;
+                        int32_t l = last_ids[(size_t)y * P->width + x];
+                        int r = (ly / sh) * nsx + lx / sw;
+                        if (l > maxlast) maxlast = l;
+                        if (l > sublast[r]) sublast[r] = l;
+                    }
+                if (maxlast < beg) continue;
+                int q = 0, cnt[4] = {0, 0, 0, 0}, cnt1[4] = {0, 0, 0, 0}, inb = 0;
+                for (int64_t i = maxlast; i >= beg; i--) {
+                    int g = flatten_ids[i];
+                    int sv[4] = {0, 0, 0, 0}, any = 0;
+                    for (int ly = 0; ly < 8; ly++)
+                        for (int lx = 0; lx < 16; lx++) {
+                            int x = tx * ts + lx, y = ty * ts + y0 + ly;
+                            if (x >= P->width || y >= P->height) continue;
+                            real px = (real)x + R(0.5), py = (real)y + R(0.5);
+                            real dx = means2d[2 * g] - px, dy = means2d[2 * g + 1] - py;
+                            real sigma = R(0.5) * (conics[3 * g] * dx * dx + conics[3 * g + 2] * dy * dy) + conics[3 * g + 1] * dx * dy;
+                            if (sigma < R(0)) continue;
+                            real a = RMIN(P->alpha_max, opac[g] * EXP(-sigma));
+                            if (a < P->alpha_min) continue;
+                            any = 1;
+                            sv[(ly / sh) * nsx + lx / sw] = 1;
+                        }
+                    if (any) {
+                        loc[0]++; q++;
+                        for (int r = 0; r < 4; r++)
+                            if (sv[r] && (int32_t)i <= sublast[r]) { loc[1]++; cnt[r]++; cnt1[r]++; }
+                    }
+                    inb++;
+                    if (inb == 64 || i == beg) {
+                        int m1 = 0;
+                        for (int r = 0; r < 4; r++) { if (cnt1[r] > m1) m1 = cnt1[r]; cnt1[r] = 0; }
+                        loc[2] += m1; loc[5]++; inb = 0;
+                        if (q >= th || i == beg) {
+                            int m = 0;
+                            for (int r = 0; r < 4; r++) { if (cnt[r] > m) m = cnt[r]; cnt[r] = 0; }
+                            loc[3] += m; if (q) loc[4]++;
+                            q = 0;
+                        }
+                    }
+                }
+            }
+        }
+#pragma omp critical
+        for (int k = 0; k < 6; k++) out[k] += loc[k];
+    }
+}
+
 /* ------------------------------------------------------------------ blend backward
  * Gradients are reduced per (tile, Gaussian) first and then added per Gaussian, the shape of
  * the HIP design.  v_* per-Gaussian outputs must be zeroed by the caller. */

@@ -175,6 +175,18 @@ class CRaster:
         return {tuple(s): dict(traversed=int(o[0]), culled=int(o[1]), hit=int(o[2]), pairs=int(o[3]))
                 for s, o in zip(shapes, out)}
 
+    def quad_stats(self, st, sw=8, sh=4, th=32) -> Dict:
+        """Loop trips of a four-sub-blocks-per-wave backward (design tooling; see cr_quad_stats)."""
+        P, pr, bs = st["P"], st["proj"], st["bins"]
+        ins = [self._a(x) for x in (pr["means2d"], pr["conics"], st["opac"])]
+        fl, of = self._a(bs["flatten_ids"], np.int32), self._a(bs["isect_offsets"], np.int32).reshape(-1)
+        li = self._a(st["fwd"]["last_ids"], np.int32)
+        out = np.zeros(6, np.int64)
+        self.lib.cr_quad_stats(*[self._p(a) for a in ins], self._p(fl), self._p(of), C.c_int64(fl.shape[0]),
+                               C.byref(P), self._p(li), C.c_int(sw), C.c_int(sh), C.c_int(th), self._p(out))
+        return dict(band_units=int(out[0]), sub_units=int(out[1]), trips_every_batch=int(out[2]),
+                    trips=int(out[3]), rounds=int(out[4]), batches=int(out[5]))
+
     def blend_bwd(self, P, means2d, conics, opac, colors, ray_ts, ray_planes, normals, flatten_ids,
                   offsets, fwd, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
         N, D = means2d.shape[0], colors.shape[1]

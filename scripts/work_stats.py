@@ -34,3 +34,10 @@ for (bw, bh), r in res.items():
     px = bw * bh
     print(f"{bw:2d}x{bh:<2d}: traversed {r['traversed']/1e6:7.2f} M  culled(exact) {r['culled']/1e6:7.2f} M  hit {r['hit']/1e6:7.2f} M"
           f"  pixel slots after cull {r['culled']*px/1e6:8.1f} M  lane use {pairs/max(r['culled']*px,1):.3f}")
+
+if os.environ.get("QUAD", "1") == "1":
+    for (sw, sh) in ((8, 4), (16, 2), (4, 8)):
+        for th in (16, 32, 64):
+            q = cr.quad_stats(st, sw, sh, th)
+            print(f"quad {sw}x{sh} th={th}: band units {q['band_units']/1e6:.2f} M  sub units {q['sub_units']/1e6:.2f} M  trips/batch-sync "
+                  f"{q['trips_every_batch']/1e6:.2f} M  trips(th) {q['trips']/1e6:.2f} M  rounds {q['rounds']/1e6:.3f} M  batches {q['batches']/1e6:.3f} M", flush=True)

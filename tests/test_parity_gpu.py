@@ -1168,6 +1168,39 @@ def test_speculative_capacity_overflow_is_detected_and_redone_exactly(dev):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("N,W,H,scale_mul,absgrad", [(30_000, 640, 360, 1.0, False), (5_000, 333, 197, 1.0, True),
+                                                     (4_000, 96, 64, 4.0, True), (20_000, 480, 270, 0.3, False)])
+def test_four_sub_blocks_per_band_backward_equals_the_band_backward(dev, monkeypatch, N, W, H, scale_mul, absgrad):
+    """MISPLAT_SUB_BLOCKS=4 (four 8x4 sub-blocks per wave, each with its own culled list, gradient rows gathered in LDS)
+    evaluates exactly the same per-pixel expressions as the band kernel that the C restatement pins: the gradients may
+    differ by summation order only.  Cases: bench-like, ragged image, deep stacks of large Gaussians (many batches,
+    early termination per sub-block), small Gaussians (most sub-block lists empty)."""
+    from collab_splats_amd import rasterization
+    args = _bench_like_scene(dev, N, W, H, seed=13, scale_mul=scale_mul)
+
+    def run(sub):
+        monkeypatch.setenv("MISPLAT_SUB_BLOCKS", str(sub))
+        leaves = [t.clone().requires_grad_(True) for t in args[:5]]
+        out = rasterization(*leaves, *args[5:], sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased",
+                            return_depth_normal=True, absgrad=absgrad)
+        out[5]["means2d"].retain_grad()
+        ups = [u.to(dev) for u in upstream([t.shape for t in out[:5]], dtype=torch.float32)]
+        torch.autograd.backward(list(out[:5]), ups)
+        torch.cuda.synchronize()
+        g = [l.grad.clone() for l in leaves] + [out[5]["means2d"].grad.clone()]
+        if absgrad:
+            g.append(out[5]["means2d"].absgrad.clone())
+        return [t.detach() for t in out[:5]], g
+
+    img1, g1 = run(1)
+    img4, g4 = run(4)
+    for a, b in zip(img1, img4):
+        assert torch.equal(a, b)
+    for k, (a, b) in enumerate(zip(g1, g4)):
+        assert torch.isfinite(b).all()
+        assert rel_err(b, a) < 2e-5, (k, rel_err(b, a))
+
+
 def test_unit_order_is_a_permutation_sorted_by_measured_work(dev):
     """misplat_unit_order: every unit exactly once, heaviest first inside each XCD strip, padding = units."""
     from collab_splats_amd import _lib
