@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--shared-grads", action="store_true", help="shared Gaussians: all-reduce the gradients over RCCL")
     ap.add_argument("--dn-loss", action="store_true",
                     help="step = RadegsModel.get_outputs -> L1 + depth-normal consistency loss -> backward (configs[4])")
+    ap.add_argument("--graphed", action="store_true",
+                    help="capture the whole step (activations, forward, backward) into ONE hipGraph with a fixed "
+                         "intersection capacity (collab_splats_amd.graphs.GraphedStep) and time its replays: the "
+                         "host-bound small configurations; not the default protocol")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="Gaussians in the CPU-baseline sample")
     return ap.parse_args()
@@ -293,6 +297,16 @@ def main():
         torch.cuda.synchronize()
 
     roof = copy_roof(dev) if rank == 0 else 0.0
+    eager_step, graphed = step, None
+    if args.graphed:
+        if args.dn_loss or shared:
+            raise SystemExit("bench.py: --graphed covers the plain rasterization step only")
+        from collab_splats_amd import graphs
+        step()                                     # one eager step: learn the intersection count
+        torch.cuda.synchronize()
+        capacity = int(int(info["n_isects"]) * 1.5) + 4096
+        graphed = graphs.GraphedStep(step, capacity=capacity)
+        step = graphed.replay
     for _ in range(args.warmup):
         step()
     info["allreduce_ms"].clear()
@@ -308,6 +322,10 @@ def main():
     dt = parallel.max_over_ranks(dt, dev)
     dev_ms = sorted(a.elapsed_time(b) for a, b in evs)
     dev_med = dev_ms[len(dev_ms) // 2]
+    if graphed is not None:
+        graphed.check()                            # the fixed capacity held for every replay
+        step = eager_step
+        step()                                     # (eager again: info[...] must not point into the graph's pool)
     allreduce_ms = sorted(ev[0].elapsed_time(ev[1]) for ev in info["allreduce_ms"] if ev is not None)
 
     # ---- instrumented pass (outside the timed region): HIP events on the launch stream around the compositing kernels
@@ -358,7 +376,10 @@ def main():
                        "parallelism": ("independent views, no collective" if not shared
                                        else "shared Gaussians, RCCL all-reduce of 236 B/Gaussian grads (two buckets, "
                                             "zero-copy flat buffer)"),
-                       "git_rev": git_rev(), "graph_cache": ops.graph_cache_stats()},
+                       "git_rev": git_rev(), "graph_cache": ops.graph_cache_stats(),
+                       "host": (f"whole step replayed as one hipGraph (graphs.GraphedStep, fixed capacity "
+                                f"{graphed.capacity} intersections, no host synchronisation)" if graphed is not None
+                                else "eager PyTorch step (the reference's training loop is eager)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": pmc.get(dom), "traffic_git_rev": pmc.get("git_rev"),

@@ -54,7 +54,7 @@ __device__ __forceinline__ bool band_ctx(const misplat_params& P, const float* _
     int unit = (b & 7) * per_xcd + (b >> 3);
     if (P.unit_perm) unit = P.unit_perm[b];      // caller-supplied launch order (longest first); the grid has exactly
                                                  // 8 * ceil(total / 8) workgroups = entries of unit_perm (padding: total)
-    if (unit >= total) return false;
+    if ((unsigned)unit >= (unsigned)total) return false;
     c.unit = unit;
     c.tile = unit / WPT;
     c.band = unit - c.tile * WPT;

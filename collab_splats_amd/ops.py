@@ -578,8 +578,8 @@ def _readback_slot(dev: torch.device) -> Tensor:
 
 
 def _graph_cache(dev: torch.device):
-    if not GRAPHS:
-        return None
+    if not GRAPHS or _STATIC_CAP is not None and torch.cuda.is_current_stream_capturing():
+        return None                                     # (the caller is capturing the whole step: plain launches)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx not in _GRAPH_CACHE:
         h = _lib.load().misplat_graph_cache_create(C.c_int32(16))
@@ -622,9 +622,57 @@ def _dp(t: Optional[Tensor]):
     return None if t is None else t.data_ptr()
 
 
+# One call for BOTH phases when the capacity of the intersection buffers is known before phase A runs (a hint from the
+# previous call of this shape, or a capacity fixed by the caller): one hipGraphLaunch and no Python between the phases.
+MERGE_PHASES = os.environ.get("MISPLAT_MERGE_PHASES", "1") == "1"
+# Fixed capacity (``static_capacity``): the intersection buffers get exactly this size and NOTHING on the host waits for
+# the count -- the call contains no host synchronisation at all, so a whole training step can be captured into one
+# hipGraph (graphs.GraphedStep).  ``meta["n_isects"]`` is then a device tensor, the lists beyond it are unspecified, and
+# an overflow (count > capacity) is reported by ``check_static_capacity()`` after the fact.
+_STATIC_CAP: Optional[int] = None
+
+
+class static_capacity:
+    """``with ops.static_capacity(n): rasterization(...)`` -- see _STATIC_CAP."""
+
+    def __init__(self, n: Optional[int]):
+        self.n = None if n is None else int(n)
+
+    def __enter__(self):
+        global _STATIC_CAP
+        self.old, _STATIC_CAP = _STATIC_CAP, self.n
+        return self
+
+    def __exit__(self, *exc):
+        global _STATIC_CAP
+        _STATIC_CAP = self.old
+        return False
+
+
+_STATIC_SEEN: Dict[int, int] = {}
+_CAPTURE_KEEP: Optional[list] = None      # set by graphs.GraphedStep while it captures: buffers its graph reads later
+
+
+def check_static_capacity(dev: Optional[torch.device] = None) -> int:
+    """After a synchronisation: the intersection count of the last fixed-capacity forward on this device; raises if it
+    did not fit (its images are then incomplete)."""
+    idx = torch.cuda.current_device() if dev is None or dev.index is None else dev.index
+    if idx not in _READBACK or idx not in _STATIC_SEEN:
+        return 0
+    n = int(_READBACK[idx][0])
+    if n > _STATIC_SEEN[idx]:
+        raise _lib.MisplatError(f"{n} tile intersections exceed the fixed capacity {_STATIC_SEEN[idx]}: rerun with a larger one")
+    return n
+
+
+def _cap_key(P: Params, dev: torch.device):
+    return (dev.index, P.n_gauss, P.n_cams, P.width, P.height)
+
+
 def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg: int, kd: int,
-                    n_color: int, per_cam: int, depth_channel: bool, want_aux: bool, want_grad: bool):
-    """Allocations + phase A of misplat_raster_fwd.  Returns (radii, means2d, depths, comps, grec, sh_aux, state)."""
+                    n_color: int, per_cam: int, depth_channel: bool, want_aux: bool, want_grad: bool, defer: bool = False):
+    """Allocations + phase A of misplat_raster_fwd (``defer``: phase A is launched together with B, by _raster_phase_b).
+    Returns (radii, means2d, depths, comps, grec, sh_aux, state)."""
     lib = _lib.load()
     dev = means.device
     N, Cn = P.n_gauss, P.n_cams
@@ -652,9 +700,11 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     # the colour kernel moves into phase B's parallel graph branch -- worth it only for large scenes (a two-branch
     # graph costs ~40 us more host time per launch; gains ~10 us of GPU time at 1 M Gaussians)
     a.colour_pending = int(COLOUR_BRANCH and rows >= COLOUR_BRANCH_MIN_ROWS)
-    check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
-          "misplat_raster_fwd(A)")
-    state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero,
+    if not defer:
+        check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
+              "misplat_raster_fwd(A)")
+    state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero, deferred=defer,
+                 counters=counters,
                  keep=(rect2, cellhist, cell_count, cell_offs, order, counters, tile_count, radii))
     return (radii.view(Cn, N, 2), means2d.view(Cn, N, 2), depths.view(Cn, N), comps.view(Cn, N), grec.view(rows, MISPLAT_REC),
             sh_aux.view(rows, 12) if want_aux else None, state)
@@ -668,10 +718,14 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
     Cn, H, W = P.n_cams, P.height, P.width
     n_pix = Cn * H * W
     n_tiles = P.tile_w * P.tile_h * Cn
-    key = (dev.index, P.n_gauss, Cn, W, H)
+    key = _cap_key(P, dev)
     hint = _CAP_HINT.get(key) if SPECULATE else None
     n_known = None
-    if hint is None:                                                  # first call of this shape: exact, as before
+    static = _STATIC_CAP is not None and state.get("deferred")
+    if static:
+        cap = max(int(_STATIC_CAP), 1)
+    elif hint is None:                                                # first call of this shape: exact, as before
+        assert not state.get("deferred")
         n_known = _wait_count(state["host"])
         cap = max(n_known, 1)
     else:
@@ -692,14 +746,21 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
     a.last_ids, a.median_ids = _dp(last_ids), _dp(median_ids)
     if sched.on:
         last = _LAST_ORDER.get(sched.key) if UNIT_ORDER_FWD else None
+        if last is not None and _CAPTURE_KEEP is not None:
+            _CAPTURE_KEEP.append(last)                                # a captured graph keeps reading this buffer
         a.unit_perm_in, a.unit_work, a.unit_perm_out = _dp(last), _dp(sched.work), _dp(sched.perm)
     else:
         a.unit_perm_in, a.unit_work, a.unit_perm_out = None, None, None
+    phases = 3 if state.get("deferred") else 2
     while True:
         a.payload, a.flatten_ids, a.scratch, a.cap_isects = _dp(payload), _dp(flatten_ids), _dp(scratch), cap
         with _timed("raster_fwd_B"):
-            check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(2), stream_ptr(), _graph_cache(dev)),
+            check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(phases), stream_ptr(), _graph_cache(dev)),
                   "misplat_raster_fwd(B)")
+        phases = 2
+        if static:                                                    # nobody waits: the count stays on the device
+            _STATIC_SEEN[dev.index if dev.index is not None else torch.cuda.current_device()] = cap
+            break
         if n_known is None:
             n_known = _wait_count(state["host"])                      # usually long there: phase B was enqueued meanwhile
         if n_known <= cap:
@@ -711,15 +772,17 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         if cap >= 2 ** 31:
             raise _lib.MisplatError(f"{cap} tile intersections exceed int32 indexing")
         payload, flatten_ids, scratch = isect_buffers(cap)
-    _CAP_HINT[key] = n_known
+    if not static:
+        _CAP_HINT[key] = n_known
     if sched.on:
         _LAST_ORDER[sched.key] = sched.perm
         if sched.ppl_b == sched.ppl_f:
             sched.perm_bwd = sched.perm
-    bins = dict(tiles_per_gauss=state["tiles_per_gauss"], n_isects=n_known, depths=state["depths"], tile_ids=None,
-                v_grec_zero=state.get("v_grec_zero"),
-                n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:n_known], isect_offsets=offsets[:n_tiles + 1],
-                _keep=(scratch, payload))
+    bins = dict(tiles_per_gauss=state["tiles_per_gauss"], n_isects=cap if static else n_known, depths=state["depths"],
+                tile_ids=None, v_grec_zero=state.get("v_grec_zero"),
+                n_isects_dev=state["counters"].view(torch.int64)[0] if static else None,
+                n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:cap if static else n_known],
+                isect_offsets=offsets[:n_tiles + 1], _keep=(scratch, payload))
     imgs = (render.view(Cn, H, W, cd), alpha.view(Cn, H, W, 1), exp_depth.view(Cn, H, W, 1), med_depth.view(Cn, H, W, 1),
             normal.view(Cn, H, W, 3), last_ids.view(Cn, H, W), median_ids.view(Cn, H, W))
     return imgs, bins, sched
@@ -755,9 +818,10 @@ class _RasterFused(torch.autograd.Function):
             n_color = kd
         want_grad = any(ctx.needs_input_grad[:6])
         want_aux = SH_AUX and deg >= 0 and want_grad
+        defer = _STATIC_CAP is not None or (MERGE_PHASES and SPECULATE and _cap_key(P, means.device) in _CAP_HINT)
         radii, means2d, depths, comps, grec, sh_aux, state = _raster_phase_a(
             P, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam, depth_channel,
-            want_aux, want_grad)
+            want_aux, want_grad, defer=defer)
         imgs, bins, sched = _raster_phase_b(P, state, cd)
         render, alpha, exp_depth, med_depth, normal, last_ids, median_ids = imgs
         extra["bins"] = bins

@@ -200,7 +200,7 @@ def rasterization(
         "tile_width": P.tile_w, "tile_height": P.tile_h, "tiles_per_gauss": bins["tiles_per_gauss"].view(Cn, N),
         "flatten_ids": bins["flatten_ids"],
         "isect_offsets": bins["isect_offsets"][:-1].view(Cn, P.tile_h, P.tile_w),
-        "n_isects": bins["n_isects"], "last_ids": first[5], "median_ids": first[6],
+        "n_isects": bins["n_isects"] if bins.get("n_isects_dev") is None else bins["n_isects_dev"], "last_ids": first[5], "median_ids": first[6],
         "width": width, "height": height, "tile_size": tile_size, "n_cameras": Cn,
     })
     if return_depth_normal:

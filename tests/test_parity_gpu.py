@@ -1201,6 +1201,54 @@ def test_four_sub_blocks_per_band_backward_equals_the_band_backward(dev, monkeyp
         assert rel_err(b, a) < 2e-5, (k, rel_err(b, a))
 
 
+def test_whole_step_graph_replays_equal_eager_steps(dev):
+    """graphs.GraphedStep: activations + forward + backward captured once with a fixed intersection capacity (no host
+    synchronisation inside), replayed after the parameters changed in place: same images (bitwise) and gradients as an
+    eager step on the same values; a capacity that is too small is reported, not silently truncated."""
+    from collab_splats_amd import graphs, rasterization, MisplatError
+    from collab_splats_amd.synthetic import random_scene
+    N, W, H = 10_000, 256, 256
+    sc = random_scene(N, W, H, seed=3)
+    names = ("means", "log_scales", "quats", "opacity_logits", "sh")
+    params = {k: sc[k].to(dev).requires_grad_(True) for k in names}
+    V, K = sc["viewmats"].to(dev), sc["Ks"].to(dev)
+    ups = [u.to(dev) for u in upstream([(1, H, W, 4), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3)], dtype=torch.float32)]
+
+    def run(p):
+        for t in p.values():
+            t.grad = None
+        out = rasterization(p["means"], p["quats"], torch.exp(p["log_scales"]), torch.sigmoid(p["opacity_logits"]), p["sh"],
+                            V, K, W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased",
+                            return_depth_normal=True)
+        torch.autograd.backward(list(out[:5]), ups)
+        # (nothing with autograd history may outlive the call: a graph kept alive from the previous iteration on another
+        # stream breaks the capture -- PyTorch's AccumulateGrad stream rule)
+        return [t.detach() for t in out[:5]], out[5]["n_isects"]
+
+    _, n0 = run(params)
+    torch.cuda.synchronize()
+    n0 = int(n0)
+    with pytest.raises(MisplatError):
+        graphs.GraphedStep(lambda: run(params), capacity=n0 // 3)
+    g = graphs.GraphedStep(lambda: run(params), capacity=2 * n0)
+    static_grads = [params[k].grad for k in names]            # the graph writes these tensors on every replay
+    for rep in range(3):
+        with torch.no_grad():                                  # the optimiser's in-place update
+            params["means"].add_(0.01 * (rep + 1))
+            params["log_scales"].add_(0.02)
+        imgs, n_dev = g.replay()
+        n_graph = g.check()                                    # synchronises
+        assert n_graph == int(n_dev)
+        ref = {k: params[k].detach().clone().requires_grad_(True) for k in names}   # eager, same values, other tensors
+        ref_imgs, ref_n = run(ref)
+        torch.cuda.synchronize()
+        assert n_graph == int(ref_n)
+        for a, b in zip(imgs, ref_imgs):
+            assert torch.equal(a, b), rep
+        for a, k in zip(static_grads, names):
+            assert rel_err(a, ref[k].grad) < 1e-5, (rep, k)
+
+
 def test_unit_order_is_a_permutation_sorted_by_measured_work(dev):
     """misplat_unit_order: every unit exactly once, heaviest first inside each XCD strip, padding = units."""
     from collab_splats_amd import _lib
