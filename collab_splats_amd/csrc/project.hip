@@ -433,6 +433,58 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
+// Colour (and, JAC, its 3x3 Jacobian d colour / d direction, J[ch][axis]) of one Gaussian from its staged
+// coefficient row cf[3k + ch], one basis function at a time: a term needs its basis value, its three derivatives and
+// three coefficients, nothing else stays live (12 accumulators + the shared monomials).  The array form (sh_basis into
+// b / bx / by / bz[16], then the sums) made the forward colour kernel a 245-VGPR kernel with two waves per SIMD, which
+// is what a streaming kernel waiting on HBM can least afford; the scheduling barriers keep the compiler from hoisting
+// all 48 LDS reads and 64 basis values back to the top.  Same operation order per accumulator as the array form.
+template <bool JAC>
+__device__ __forceinline__ void sh_eval(int deg, float x, float y, float z, const float* cf, float& c0, float& c1, float& c2,
+                                        float (&J)[9]) {
+#define SH_TERM(k, B, BX, BY, BZ)                                                              \
+    {                                                                                          \
+        const float f0 = cf[3 * (k)], f1 = cf[3 * (k) + 1], f2 = cf[3 * (k) + 2];              \
+        const float b_ = (B);                                                                  \
+        c0 += b_ * f0; c1 += b_ * f1; c2 += b_ * f2;                                           \
+        if (JAC) {                                                                             \
+            const float bx_ = (BX), by_ = (BY), bz_ = (BZ);                                    \
+            J[0] += bx_ * f0; J[1] += by_ * f0; J[2] += bz_ * f0;                              \
+            J[3] += bx_ * f1; J[4] += by_ * f1; J[5] += bz_ * f1;                              \
+            J[6] += bx_ * f2; J[7] += by_ * f2; J[8] += bz_ * f2;                              \
+        }                                                                                      \
+    }
+    SH_TERM(0, C0, 0.f, 0.f, 0.f)
+    if (deg > 0) {
+        SH_TERM(1, -C1 * y, 0.f, -C1, 0.f) SH_TERM(2, C1 * z, 0.f, 0.f, C1) SH_TERM(3, -C1 * x, -C1, 0.f, 0.f)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (deg > 1) {
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        SH_TERM(4, C2[0] * xy, C2[0] * y, C2[0] * x, 0.f)
+        SH_TERM(5, C2[1] * yz, 0.f, C2[1] * z, C2[1] * y)
+        SH_TERM(6, C2[2] * (2.f * zz - xx - yy), -2.f * C2[2] * x, -2.f * C2[2] * y, 4.f * C2[2] * z)
+        __builtin_amdgcn_sched_barrier(0);
+        SH_TERM(7, C2[3] * xz, C2[3] * z, 0.f, C2[3] * x)
+        SH_TERM(8, C2[4] * (xx - yy), 2.f * C2[4] * x, -2.f * C2[4] * y, 0.f)
+        __builtin_amdgcn_sched_barrier(0);
+        if (deg > 2) {
+            SH_TERM(9, C3[0] * y * (3.f * xx - yy), 6.f * C3[0] * xy, C3[0] * (3.f * xx - 3.f * yy), 0.f)
+            SH_TERM(10, C3[1] * xy * z, C3[1] * yz, C3[1] * xz, C3[1] * xy)
+            __builtin_amdgcn_sched_barrier(0);
+            SH_TERM(11, C3[2] * y * (4.f * zz - xx - yy), -2.f * C3[2] * xy, C3[2] * (4.f * zz - xx - 3.f * yy), 8.f * C3[2] * yz)
+            SH_TERM(12, C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), -6.f * C3[3] * xz, -6.f * C3[3] * yz,
+                    C3[3] * (6.f * zz - 3.f * xx - 3.f * yy))
+            __builtin_amdgcn_sched_barrier(0);
+            SH_TERM(13, C3[4] * x * (4.f * zz - xx - yy), C3[4] * (4.f * zz - 3.f * xx - yy), -2.f * C3[4] * xy, 8.f * C3[4] * xz)
+            SH_TERM(14, C3[5] * z * (xx - yy), 2.f * C3[5] * xz, -2.f * C3[5] * yz, C3[5] * (xx - yy))
+            __builtin_amdgcn_sched_barrier(0);
+            SH_TERM(15, C3[6] * x * (xx - 3.f * yy), C3[6] * (3.f * xx - 3.f * yy), -6.f * C3[6] * xy, 0.f)
+        }
+    }
+#undef SH_TERM
+}
+
 __global__ __launch_bounds__(256) void sh_fwd_kernel(int n_gauss, int n_cams, int K, int deg,
                                                      const float* __restrict__ dirs,
                                                      const float* __restrict__ coeffs,
@@ -585,10 +637,22 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
 // AUX: the forward also leaves, per (camera, Gaussian), the 3x3 Jacobian d rgb / d dir of the clamped colour
 // (rows of clamped channels zeroed) and the three clamp flags in sh_aux[idx][12]; the backward then takes
 // v_dir = J^T v_rgb from those 48 bytes and never reads the 12 K bytes of coefficients again.
+// Measured (1 M Gaussians, one camera, K = 16, forward with AUX; 99.7 us before this list): term-by-term evaluation
+// (sh_eval: 245 -> 151 VGPRs, two -> three waves per SIMD) +-0; gradient rows and Jacobian rows written as whole lines
+// instead of one strided row per lane -6 us; the lane's own radii / mean / depth requested before the staging barrier
+// (one HBM round trip per block instead of two) -3 us: 90.4 us.  What the streams cost, by leaving one out at a time:
+// the 192 MB of coefficients 55 us (3.5 TB/s), the 64 MB of cleared gradient rows 9 us, the 48 MB of Jacobians 11 us, and
+// the 16 MB of colours 11 us -- 16 bytes into each 64-byte record that the projection kernel started, the one
+// partial-line stream left (closing it means fusing this kernel into the projection).
 // KC: compile-time K (16 = degree-3 storage: the row length 48 and the LDS stride 49 become constants, the
 // coefficients move as 16-byte vectors, and rows of Gaussians culled in every camera are never read) or 0 (any K).
-template <bool BWD, int BLOCK, bool MULTI, bool AUX = false, int KC = 0>
-__global__ __launch_bounds__(BLOCK) void color_sh_kernel(
+// SPLIT: 0 = [N,K,3] coefficients, 1 = features_dc + features_rest, -1 = decided at run time (the staging variants
+// differ a lot in registers: compiled together the kernel is allocated for the hungriest of them).
+template <bool BWD, int BLOCK, bool MULTI, bool AUX = false, int KC = 0, int SPLIT = -1>
+#ifndef MISPLAT_SH_FWD_WAVES
+#define MISPLAT_SH_FWD_WAVES 1         /* waves per SIMD the K = 16 forward is compiled for (1: no constraint) */
+#endif
+__global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : 1) void color_sh_kernel(
     misplat_params P, int K, int deg, int depth_channel, const float* __restrict__ means,
     const float* __restrict__ viewmats, const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest,
     const int32_t* __restrict__ radii, const float* __restrict__ depths, float* __restrict__ grec,
@@ -599,6 +663,7 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
     // instead of through the per-step torch.cat of :128-130)
     extern __shared__ float lds[];
     __shared__ uint8_t s_vis[BLOCK];
+    if (SPLIT == 0) { coeffs_rest = nullptr; v_coeffs_rest = nullptr; }
     if (KC) K = KC;
     const int row = 3 * K, stride = row + 1;
     const int nb = (deg + 1) * (deg + 1);
@@ -607,7 +672,18 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
         const int g0 = blk * BLOCK;
         const int cnt = min(BLOCK, P.n_gauss - g0);
         __syncthreads();
-        if (KC && BWD && !AUX) {
+        // forward: what the lane needs about its own row for camera 0 is requested NOW, together with the coefficient
+        // lines below -- behind the staging barrier it would be a second dependent HBM round trip per block
+        int pr0 = 0, pr1 = 0;
+        float pm0 = 0.f, pm1 = 0.f, pm2 = 0.f, pdep = 0.f;
+        if (!BWD && (int)threadIdx.x < cnt) {
+            const int gp = g0 + threadIdx.x;
+            pr0 = radii[2 * (int64_t)gp]; pr1 = radii[2 * (int64_t)gp + 1];
+            pm0 = means[3 * gp]; pm1 = means[3 * gp + 1]; pm2 = means[3 * gp + 2];
+            if (depth_channel) pdep = depths[gp];
+        }
+        constexpr bool USE_VIS = KC && BWD && !AUX;
+        if (USE_VIS) {
             // visible in any camera?  (rows that are not are not staged)  Only where the staged rows are consumed late
             // enough: in the forward, waiting for the radii before the first coefficient load costs more (a dependent
             // round trip per block) than the culled rows' 192 bytes save.
@@ -619,13 +695,10 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
                 }
             s_vis[threadIdx.x] = v ? 1 : 0;
             __syncthreads();
-        } else if (KC) {
-            s_vis[threadIdx.x] = 1;
-            __syncthreads();
         }
         if (BWD && AUX) {
             // nothing to stage: the LDS rows only carry the gradient back out
-        } else if (KC && coeffs_rest == nullptr) {
+        } else if (KC && SPLIT != 1 && coeffs_rest == nullptr) {
             // [N, 16, 3]: a row is 12 aligned float4s; the whole block (64 rows = 12 vectors per lane) is requested
             // in ONE round of loads -- three dependent rounds of four cost two more HBM round trips per block
             const float4* src4 = reinterpret_cast<const float4*>(coeffs + (size_t)g0 * row);
@@ -635,18 +708,18 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
             for (int u = 0; u < V4; u++) {
                 const int e4 = threadIdx.x + u * BLOCK;
                 const int tt = e4 / V4;
-                if (e4 < cnt * V4 && s_vis[tt]) v[u] = src4[e4];
+                if (e4 < cnt * V4 && (!USE_VIS || s_vis[tt])) v[u] = src4[e4];
             }
 #pragma unroll
             for (int u = 0; u < V4; u++) {
                 const int e4 = threadIdx.x + u * BLOCK;
                 const int tt = e4 / V4, kk = 4 * (e4 - tt * V4);
-                if (e4 < cnt * V4 && s_vis[tt]) {
+                if (e4 < cnt * V4 && (!USE_VIS || s_vis[tt])) {
                     float* d = lds + tt * stride + kk;
                     d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
                 }
             }
-        } else if (KC) {
+        } else if (KC && SPLIT != 0) {
             // features_dc [N, 3] + features_rest [N, 15, 3]: rows of 3 and 45 floats; vectors may straddle two rows
             const float* src_dc = coeffs + (size_t)g0 * 3;
             for (int e = threadIdx.x; e < cnt * 3; e += BLOCK) lds[(e / 3) * stride + (e % 3)] = src_dc[e];
@@ -662,7 +735,7 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
                     on[u] = false;
                     if (e4 < n4) {
                         const int ta = (4 * e4) / RR, tb = (4 * e4 + 3) / RR;
-                        on[u] = s_vis[ta] || s_vis[tb];
+                        on[u] = !USE_VIS || s_vis[ta] || s_vis[tb];
                         if (on[u]) v[u] = src4[e4];
                     }
                 }
@@ -712,7 +785,8 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
             float* cf = lds + t * stride;
             for (int ci = 0; ci < P.n_cams; ci++) {
                 const int64_t idx = (int64_t)ci * P.n_gauss + g;
-                const bool vis = radii[2 * idx] > 0 || radii[2 * idx + 1] > 0;
+                const bool first = !BWD && ci == 0;
+                const bool vis = first ? (pr0 > 0 || pr1 > 0) : (radii[2 * idx] > 0 || radii[2 * idx + 1] > 0);
                 float c0 = 0.f, c1 = 0.f, c2 = 0.f;
                 if (vis) {
                     const float* V = viewmats + 16 * ci;
@@ -720,13 +794,16 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
                     const float ccx = -(V[0] * V[3] + V[4] * V[7] + V[8] * V[11]);
                     const float ccy = -(V[1] * V[3] + V[5] * V[7] + V[9] * V[11]);
                     const float ccz = -(V[2] * V[3] + V[6] * V[7] + V[10] * V[11]);
-                    const float dx = means[3 * g] - ccx, dy = means[3 * g + 1] - ccy, dz = means[3 * g + 2] - ccz;
+                    const float mx_ = !BWD ? pm0 : means[3 * g], my_ = !BWD ? pm1 : means[3 * g + 1], mz_ = !BWD ? pm2 : means[3 * g + 2];
+                    const float dx = mx_ - ccx, dy = my_ - ccy, dz = mz_ - ccz;
                     const float n = sqrtf(dx * dx + dy * dy + dz * dz);
                     const float inv = n > 0.f ? 1.0f / n : 0.f;
                     const float x = dx * inv, y = dy * inv, z = dz * inv;
                     float b[16], bx[16], by[16], bz[16];
-                    sh_basis<(BWD && !AUX) || (!BWD && AUX)>(deg, x, y, z, b, bx, by, bz);
-                    if (!(BWD && AUX)) {
+                    float J[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};         // J[ch][axis]
+                    if (!BWD) sh_eval<AUX>(deg, x, y, z, cf, c0, c1, c2, J);
+                    else sh_basis<!AUX>(deg, x, y, z, b, bx, by, bz);
+                    if (BWD && !AUX) {
 #pragma unroll
                         for (int k = 0; k < 16; k++)
                             if (k < nb) { c0 += b[k] * cf[3 * k]; c1 += b[k] * cf[3 * k + 1]; c2 += b[k] * cf[3 * k + 2]; }
@@ -734,18 +811,18 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
                     if (!BWD && AUX) {
                         const float m0 = (c0 + 0.5f > 0.f) ? 1.f : 0.f, m1 = (c1 + 0.5f > 0.f) ? 1.f : 0.f;
                         const float m2 = (c2 + 0.5f > 0.f) ? 1.f : 0.f;
-                        float J[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // J[ch][axis]
-#pragma unroll
-                        for (int k = 0; k < 16; k++)
-                            if (k < nb) {
-                                J[0] += bx[k] * cf[3 * k]; J[1] += by[k] * cf[3 * k]; J[2] += bz[k] * cf[3 * k];
-                                J[3] += bx[k] * cf[3 * k + 1]; J[4] += by[k] * cf[3 * k + 1]; J[5] += bz[k] * cf[3 * k + 1];
-                                J[6] += bx[k] * cf[3 * k + 2]; J[7] += by[k] * cf[3 * k + 2]; J[8] += bz[k] * cf[3 * k + 2];
-                            }
-                        float4* ax = reinterpret_cast<float4*>(sh_aux + (size_t)idx * 12);
-                        ax[0] = make_float4(J[0] * m0, J[1] * m0, J[2] * m0, J[3] * m1);
-                        ax[1] = make_float4(J[4] * m1, J[5] * m1, J[6] * m2, J[7] * m2);
-                        ax[2] = make_float4(J[8] * m2, m0, m1, m2);
+                        if (KC && P.n_cams == 1) {
+                            // the coefficients of this row are dead: its first 12 LDS slots carry the Jacobian out, so that
+                            // the block's 64 x 48 bytes leave as whole contiguous lines below
+                            cf[0] = J[0] * m0; cf[1] = J[1] * m0; cf[2] = J[2] * m0; cf[3] = J[3] * m1;
+                            cf[4] = J[4] * m1; cf[5] = J[5] * m1; cf[6] = J[6] * m2; cf[7] = J[7] * m2;
+                            cf[8] = J[8] * m2; cf[9] = m0; cf[10] = m1; cf[11] = m2;
+                        } else {
+                            float4* ax = reinterpret_cast<float4*>(sh_aux + (size_t)idx * 12);
+                            ax[0] = make_float4(J[0] * m0, J[1] * m0, J[2] * m0, J[3] * m1);
+                            ax[1] = make_float4(J[4] * m1, J[5] * m1, J[6] * m2, J[7] * m2);
+                            ax[2] = make_float4(J[8] * m2, m0, m1, m2);
+                        }
                     }
                     if (BWD && AUX) {
                         const float4* ax = reinterpret_cast<const float4*>(sh_aux + (size_t)idx * 12);
@@ -794,13 +871,33 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
                 if (!BWD) {
                     float* o = grec + (size_t)idx * MISPLAT_REC + 12;
                     float4 c = make_float4(fmaxf(c0 + 0.5f, 0.f), fmaxf(c1 + 0.5f, 0.f), fmaxf(c2 + 0.5f, 0.f),
-                                           depth_channel ? depths[idx] : 0.f);
+                                           depth_channel ? (first ? pdep : depths[idx]) : 0.f);
                     if (!vis) c = make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(o) = c;
-                    if (zero_rows) {                 // the gradient row the backward's atomics will add into: no memset later
+                    if (zero_rows && !KC) {          // the gradient row the backward's atomics will add into: no memset later
                         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                         zero_rows[4 * idx] = z; zero_rows[4 * idx + 1] = z; zero_rows[4 * idx + 2] = z; zero_rows[4 * idx + 3] = z;
                     }
+                }
+            }
+        }
+        if (!BWD && KC) {
+            // K = 16 forward: the block's gradient rows (64 x 64 B) and Jacobian rows (64 x 48 B) are contiguous in
+            // memory: written as whole lines, 16 bytes per lane and instruction, instead of one strided row per lane
+            if (zero_rows) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int ci = 0; ci < P.n_cams; ci++) {
+                    float4* zr = zero_rows + 4 * ((size_t)ci * P.n_gauss + g0);
+                    for (int e4 = threadIdx.x; e4 < cnt * 4; e4 += BLOCK) zr[e4] = z;
+                }
+            }
+            if (AUX && P.n_cams == 1) {
+                __syncthreads();
+                float4* ax4 = reinterpret_cast<float4*>(sh_aux + (size_t)g0 * 12);
+                for (int e4 = threadIdx.x; e4 < cnt * 3; e4 += BLOCK) {
+                    const int tt = e4 / 3, k = 4 * (e4 - 3 * tt);
+                    const float* sp = lds + tt * stride + k;
+                    ax4[e4] = make_float4(sp[0], sp[1], sp[2], sp[3]);
                 }
             }
         }
@@ -824,7 +921,7 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
                 v_means_dir[3 * g] = vmd[0]; v_means_dir[3 * g + 1] = vmd[1]; v_means_dir[3 * g + 2] = vmd[2];
             }
             __syncthreads();
-            if (KC && v_coeffs_rest == nullptr) {
+            if (KC && SPLIT != 1 && v_coeffs_rest == nullptr) {
                 float4* dst4 = reinterpret_cast<float4*>(v_coeffs + (size_t)g0 * row);
                 constexpr int V4 = KC ? 3 * KC / 4 : 1;
                 for (int e4 = threadIdx.x; e4 < cnt * V4; e4 += BLOCK) {
@@ -832,7 +929,7 @@ __global__ __launch_bounds__(BLOCK) void color_sh_kernel(
                     const float* sp = lds + tt * stride + k;
                     dst4[e4] = make_float4(sp[0], sp[1], sp[2], sp[3]);
                 }
-            } else if (KC) {
+            } else if (KC && SPLIT != 0) {
                 float* dst_dc = v_coeffs + (size_t)g0 * 3;
                 for (int e = threadIdx.x; e < cnt * 3; e += BLOCK) dst_dc[e] = lds[(e / 3) * stride + (e % 3)];
                 constexpr int RR = KC ? 3 * KC - 3 : 1;
@@ -1098,13 +1195,20 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
         const size_t lds = (size_t)BLK * (3 * K_or_D + 1) * sizeof(float);
         // K = 16 with 16-byte aligned coefficient arrays: the vectorised variant (compile-time row length)
         const bool k16 = K_or_D == 16 && ((uintptr_t)coeffs_or_colors & 15) == 0 && ((uintptr_t)coeffs_rest & 15) == 0;
-#define LAUNCH_SH_FWD(AUX_, KC_)                                                                                   \
-    hipLaunchKernelGGL((color_sh_kernel<false, BLK, false, AUX_, KC_>), dim3(n_blocks < 16384 ? n_blocks : 16384),  \
+#define LAUNCH_SH_FWD(AUX_, KC_, SPLIT_)                                                                           \
+    hipLaunchKernelGGL((color_sh_kernel<false, BLK, false, AUX_, KC_, SPLIT_>),                                     \
+                       dim3(n_blocks < 16384 ? n_blocks : 16384),                                                   \
                        dim3(BLK), lds, s, *p, K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, \
                        coeffs_rest, radii, depths, grec, (const float*)nullptr, (float*)nullptr, (float*)nullptr,  \
                        (float*)nullptr, sh_aux, (float4*)zero_rows)
-        if (sh_aux) { if (k16) LAUNCH_SH_FWD(true, 16); else LAUNCH_SH_FWD(true, 0); }
-        else { if (k16) LAUNCH_SH_FWD(false, 16); else LAUNCH_SH_FWD(false, 0); }
+#define LAUNCH_SH_FWD_K(AUX_)                                                                                      \
+    do {                                                                                                           \
+        if (!k16) LAUNCH_SH_FWD(AUX_, 0, -1);                                                                      \
+        else if (coeffs_rest) LAUNCH_SH_FWD(AUX_, 16, 1);                                                          \
+        else LAUNCH_SH_FWD(AUX_, 16, 0);                                                                           \
+    } while (0)
+        if (sh_aux) LAUNCH_SH_FWD_K(true); else LAUNCH_SH_FWD_K(false);
+#undef LAUNCH_SH_FWD_K
 #undef LAUNCH_SH_FWD
     } else {
         if (K_or_D < n_color) return MISPLAT_EINVAL;
