@@ -300,6 +300,37 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
         const int beg = min(offsets[t], end);
         const int n = end - beg;
         if (n <= lo || n > hi) continue;               // uniform over the block (n >= 1 from here)
+        if (lo == 0 && n <= 64 * WAVES) {
+            // Short bucket (one entry per thread): rank = number of entries that sort before mine, counted against
+            // all n through LDS broadcasts -- n iterations of two compares instead of 3 radix passes of 5 barriers each.
+            // Ties break by row (UNORDERED: the (depth, row) order) or by arrival (stable).  ~3x faster than the
+            // radix path at n <= 256 (the typical bucket of a 100 k scene at 1080p).
+            const int i = threadIdx.x;
+            uint32_t v = 0u, k = 0xffffffffu, tb = 0xffffffffu;
+            if (i < n) {
+                v = (uint32_t)payload[beg + i];
+                const int32_t rw = HAS_VALS ? isect_gid[v] : (int32_t)v;
+                k = __float_as_uint(depths[rw]);
+                tb = UNORDERED ? (uint32_t)rw : (uint32_t)i;
+            }
+            uint2* pk = reinterpret_cast<uint2*>(L.xk);                 // (key, tie-break) pairs: 2 * 64 * WAVES <= CAP words
+            __syncthreads();                                            // (the previous bucket's readers are done)
+            pk[i] = make_uint2(k, tb);
+            __syncthreads();
+            int rank = 0;
+            const uint4* pk2 = reinterpret_cast<const uint4*>(L.xk);
+            const int n2 = (n + 1) >> 1;                                // the pad entry (0xffffffff, 0xffffffff) never sorts before
+            for (int j = 0; j < n2; j++) {
+                const uint4 q = pk2[j];
+                rank += (q.x < k || (q.x == k && q.y < tb)) ? 1 : 0;
+                rank += (q.z < k || (q.z == k && q.w < tb)) ? 1 : 0;
+            }
+            if (i < n) {
+                payload[beg + rank] = (int32_t)v;
+                flatten_ids[beg + rank] = HAS_VALS ? isect_gid[v] : (int32_t)v;
+            }
+            continue;
+        }
         uint32_t key[R], val[R];
         int32_t row[R];
         // all loads of one level are issued before the first use (index clamped instead of predicated)
@@ -358,9 +389,8 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __
                                                                int64_t n_isects, int lo, int hi,
                                                                const float* __restrict__ depths,
                                                                const int32_t* __restrict__ isect_gid,
-                                                               int32_t* __restrict__ payload,
-                                                               int32_t* __restrict__ flatten_ids,
-                                                               uint32_t* __restrict__ scratch, int has_longest) {
+                                                               int32_t* payload, int32_t* flatten_ids,   // (aliased below)
+                                                               uint32_t* scratch, int has_longest) {
     extern __shared__ uint32_t lds32[];
     int t_first, t_last, t_step;
     if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step, has_longest)) return;
@@ -372,12 +402,14 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __
     constexpr int THREADS = 64 * WAVES;
     // buffers: keys / values, ping and pong; hist[WAVES][256] always in LDS
     uint32_t* hist = lds32;
-    uint32_t* buf = GLOBAL ? scratch + (size_t)beg * 4 : lds32 + WAVES * 256;
+    // GLOBAL: the bucket's own ranges of flatten_ids (keys) and payload (values) are one of the two buffers -- the even
+    // number of passes ends there -- and scratch[2 * n_isects] holds the other
+    uint32_t* buf = GLOBAL ? scratch + (size_t)beg * 2 : lds32 + WAVES * 256;
     const int cap = GLOBAL ? n : CAP;
-    uint32_t* k0 = buf;
-    uint32_t* k1 = buf + cap;
-    uint32_t* v0 = buf + 2 * cap;
-    uint32_t* v1 = buf + 3 * cap;
+    uint32_t* k0 = GLOBAL ? reinterpret_cast<uint32_t*>(flatten_ids) + beg : buf;
+    uint32_t* k1 = GLOBAL ? buf : buf + cap;
+    uint32_t* v0 = GLOBAL ? reinterpret_cast<uint32_t*>(payload) + beg : buf + 2 * cap;
+    uint32_t* v1 = GLOBAL ? buf + cap : buf + 3 * cap;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < n; i += THREADS) {
         const int32_t v = payload[beg + i];
@@ -696,7 +728,7 @@ extern "C" int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* fl
 
 // Sort every tile's bucket (ascending row order on entry) by the depth bits, stably.  payload: in/out
 // (rows, or emission slots when isect_gid != NULL); flatten_ids: out (rows in final order);
-// scratch: 4 * n_isects uint32, only touched by tiles longer than the largest LDS class (8192 entries).
+// scratch: 2 * n_isects uint32, only touched by tiles longer than the largest LDS class (8192 entries).
 template <bool HAS_VALS, bool UNORDERED>
 static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
                             const int32_t* isect_gid, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,

@@ -382,7 +382,7 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor,
     out = dict(tiles_per_gauss=tiles_per_gauss, n_isects=n_isects, depths=depths, tile_ids=None, n_tiles=n_tiles)
     if ORDERING == "cells":
         offsets, payload, flatten_ids, scratch, isect_gid = _carve(
-            dev, (n_tiles + 2, n_isects, n_isects, 4 * n_isects, n_isects if deterministic else 0))
+            dev, (n_tiles + 2, n_isects, n_isects, 2 * n_isects, n_isects if deterministic else 0))
         cum = None
         if deterministic:                                         # emission slots index the gradient slab
             cum = (torch.cumsum(tiles_per_gauss, dim=0, dtype=torch.int64) - tiles_per_gauss).contiguous()
@@ -404,7 +404,7 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor,
     tile_ids = torch.empty(n_isects, device=dev, dtype=torch.int16 if key16 else torch.int32)
     tile_ids_s = torch.empty_like(tile_ids)
     isect_gid, payload_s, flatten_ids, scratch, offsets, slots = _carve(
-        dev, (n_isects, n_isects, n_isects, 4 * n_isects, n_tiles + 1, n_isects if deterministic else 0))
+        dev, (n_isects, n_isects, n_isects, 2 * n_isects, n_tiles + 1, n_isects if deterministic else 0))
     if not deterministic:
         slots = None
     tile_bits = max(1, (n_tiles - 1).bit_length())
@@ -737,7 +737,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
     last_ids, median_ids, offsets = _carve(dev, (n_pix, n_pix, n_tiles + 2))
 
     def isect_buffers(c):
-        return _carve(dev, (c, c, 4 * c))
+        return _carve(dev, (c, c, 2 * c))
 
     payload, flatten_ids, scratch = isect_buffers(cap)
     a.color_dim = cd

@@ -183,7 +183,7 @@ int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, 
  *                  buckets with equal depths are re-sorted by (row, then depth).
  * offsets: n_tiles_total + 1 entries; n_isects: the number of intersections or an upper bound of it (only used to
  * size the grids of the size classes); payload (in/out): rows, or emission slots when isect_gid != NULL
- * (row = isect_gid[slot]); flatten_ids (out): rows in final order; scratch[4 * n_isects] backs the rare tiles
+ * (row = isect_gid[slot]); flatten_ids (out): rows in final order; scratch[2 * n_isects] backs the rare tiles
  * longer than 8192 entries. */
 int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
                       const float* depths, const int32_t* isect_gid, int32_t* payload,
