@@ -72,6 +72,34 @@ def focal2fov(focal: float, pixels: float) -> float:
     return 2 * math.atan(pixels / (2 * focal))
 
 
+# Small host->device transfers without a hidden synchronisation: ``torch.tensor(..., device=cuda)`` and ``.to(cuda)`` of
+# pageable memory block the host until the copy has run, i.e. until everything queued before it on the stream -- the
+# whole previous step -- has finished, and the GPU then idles through this step's host work (measured: 0.36 ms per 1 M
+# model step).  Camera data therefore travels as ONE asynchronous copy from a ring of pinned buffers, and constants
+# are cached per device.
+_PIN_RING: Dict[torch.device, list] = {}
+_DEV_CONST: Dict[tuple, Tensor] = {}
+
+
+def _upload(values: Tensor, device: torch.device) -> Tensor:
+    """float32 CPU tensor (flat) -> device, asynchronously, through a ring of pinned staging buffers."""
+    if device.type != "cuda":
+        return values.to(device)
+    ring = _PIN_RING.setdefault(device, [0, [torch.empty(64, dtype=torch.float32).pin_memory() for _ in range(32)]])
+    ring[0] = (ring[0] + 1) % len(ring[1])
+    buf = ring[1][ring[0]][:values.numel()]
+    buf.copy_(values)
+    return buf.to(device, non_blocking=True)
+
+
+def _device_const(key: tuple, device: torch.device, make) -> Tensor:
+    k = (key, device)
+    t = _DEV_CONST.get(k)
+    if t is None:
+        t = _DEV_CONST[k] = make().to(device)
+    return t
+
+
 def camera_parameters(camera, device: Optional[torch.device] = None) -> Dict[str, Union[Tensor, int, float]]:
     """``_get_camera_parameters`` (rade_gs_model.py:311-346) without the reference's host syncs.
 
@@ -81,22 +109,41 @@ def camera_parameters(camera, device: Optional[torch.device] = None) -> Dict[str
     principal point FORCED to the image centre (rade_gs_model.py:322-334).
     """
     c2w = camera.camera_to_worlds[0].to(torch.float32)                  # [3,4]
-    device = device or c2w.device
+    device = torch.device(device) if device is not None else c2w.device
     W, H = int(camera.width.item()), int(camera.height.item())
-    K = camera.get_intrinsics_matrices()
-    fovx = focal2fov(float(K[0, 0, 0]), W)
-    fovy = focal2fov(float(K[0, 1, 1]), H)
+    if isinstance(getattr(camera, "fx", None), float) and isinstance(getattr(camera, "fy", None), float):
+        fx_in, fy_in = camera.fx, camera.fy                               # host floats: no intrinsics matrix round trip
+    else:
+        K = camera.get_intrinsics_matrices()
+        fx_in, fy_in = float(K[0, 0, 0]), float(K[0, 1, 1])
+    fovx = focal2fov(fx_in, W)
+    fovy = focal2fov(fy_in, H)
     fx = W / (2 * math.tan(fovx * 0.5))
     fy = H / (2 * math.tan(fovy * 0.5))
-    flip = torch.tensor([1.0, -1.0, -1.0], dtype=torch.float32, device=c2w.device)
+    if c2w.device.type == "cpu":
+        # 4x4 arithmetic on the host, one asynchronous upload of viewmat (16) + Ks (9) + camera centre (3)
+        Rw = (c2w[:3, :3] * torch.tensor([1.0, -1.0, -1.0])).transpose(0, 1)
+        t = -(Rw @ c2w[:3, 3])
+        pack = torch.zeros(28, dtype=torch.float32)
+        vm = pack[:16].view(4, 4)
+        vm[:3, :3] = Rw
+        vm[:3, 3] = t
+        vm[3, 3] = 1.0
+        pack[16], pack[18], pack[20], pack[21], pack[24] = fx, W / 2.0, fy, H / 2.0, 1.0
+        pack[25:28] = c2w[:3, 3]
+        d = _upload(pack, device)
+        return {"Ks": d[16:25].view(1, 3, 3), "viewmats": d[:16].view(1, 4, 4), "image_width": W, "image_height": H,
+                "camera_center": d[25:28], "fx": fx, "fy": fy}
+    flip = _device_const(("flip",), c2w.device, lambda: torch.tensor([1.0, -1.0, -1.0], dtype=torch.float32))
     Rc = c2w[:3, :3] * flip[None, :]                                      # c2w[:3, 1:3] *= -1
     Rw = Rc.transpose(0, 1)
     t = -(Rw @ c2w[:3, 3])
-    viewmat = torch.eye(4, dtype=torch.float32, device=c2w.device)
+    viewmat = _device_const(("eye4",), c2w.device, lambda: torch.eye(4, dtype=torch.float32)).clone()
     viewmat[:3, :3] = Rw
     viewmat[:3, 3] = t
-    Ks = torch.tensor([[fx, 0.0, W / 2.0], [0.0, fy, H / 2.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
-    return {"Ks": Ks[None].to(device), "viewmats": viewmat[None].to(device), "image_width": W,
+    Ks = _device_const(("Ks", fx, fy, W, H), device,
+                       lambda: torch.tensor([[[fx, 0.0, W / 2.0], [0.0, fy, H / 2.0], [0.0, 0.0, 1.0]]], dtype=torch.float32))
+    return {"Ks": Ks, "viewmats": viewmat[None].to(device), "image_width": W,
             "image_height": H, "camera_center": c2w[:3, 3].to(device), "fx": fx, "fy": fy}
 
 
@@ -201,7 +248,8 @@ class RadegsModel(nn.Module):
         return c
 
     def _get_background_color(self) -> Tensor:
-        return torch.tensor(self._background_list(), device=self.device)
+        c = self._background_list()
+        return _device_const(("background", tuple(c)), torch.device(self.device), lambda: torch.tensor(c, dtype=torch.float32))
 
     def _get_camera_parameters(self, camera) -> Dict:
         return camera_parameters(camera, self.device)
