@@ -1164,74 +1164,117 @@ __global__ __launch_bounds__(256) void depth_normal_fwd_kernel(DN d, const float
     }
 }
 
-// gradient of the normal at interior pixel (yn, xn) w.r.t. its own a (row diff) and b (col diff)
-__device__ __forceinline__ void dn_grad_ab(const DN& d, const float* __restrict__ depth,
-                                           const float* __restrict__ nr, const float* __restrict__ v_n2,
-                                           const float* __restrict__ v_err, int k, int yn, int xn,
-                                           float* va, float* vb) {
-    va[0] = va[1] = va[2] = 0.f; vb[0] = vb[1] = vb[2] = 0.f;
-    if (!(xn >= 1 && yn >= 1 && xn < d.W - 1 && yn < d.H - 1)) return;
-    const size_t P = (size_t)d.W * d.H, pid = (size_t)yn * d.W + xn;
-    float a[3], b[3], cr[3], len, n[3];
-    dn_normal(d, depth, yn, xn, a, b, cr, len, n);
-    float vn[3] = {0.f, 0.f, 0.f};
-    if (v_n2) { const float* s = v_n2 + ((size_t)k * P + pid) * 3; vn[0] = s[0]; vn[1] = s[1]; vn[2] = s[2]; }
-    if (v_err) {
-        const float ve = v_err[(size_t)k * P + pid];
-        vn[0] -= ve * nr[pid * 3]; vn[1] -= ve * nr[pid * 3 + 1]; vn[2] -= ve * nr[pid * 3 + 2];
-    }
-    float vc[3];
-    if (len > 1e-12f) {
-        const float dot = n[0] * vn[0] + n[1] * vn[1] + n[2] * vn[2];
-#pragma unroll
-        for (int q = 0; q < 3; q++) vc[q] = (vn[q] - n[q] * dot) / len;
-    } else {
-#pragma unroll
-        for (int q = 0; q < 3; q++) vc[q] = vn[q] / 1e-12f;
-    }
-    // c = a x b :  v_a = b x v_c,  v_b = v_c x a
-    va[0] = b[1] * vc[2] - b[2] * vc[1]; va[1] = b[2] * vc[0] - b[0] * vc[2]; va[2] = b[0] * vc[1] - b[1] * vc[0];
-    vb[0] = vc[1] * a[2] - vc[2] * a[1]; vb[1] = vc[2] * a[0] - vc[0] * a[2]; vb[2] = vc[0] * a[1] - vc[1] * a[0];
-}
-
-__global__ __launch_bounds__(256) void depth_normal_bwd_kernel(DN d, const float* __restrict__ ed,
-                                                               const float* __restrict__ md,
-                                                               const float* __restrict__ nr,
-                                                               const float* __restrict__ v_n2,
-                                                               const float* __restrict__ v_err,
-                                                               float* __restrict__ v_ed,
-                                                               float* __restrict__ v_md,
-                                                               float* __restrict__ v_nr, const int accumulate) {
+// Backward of a4.  A pixel's depth feeds the normals of its four neighbours; v_a / v_b are what a normal's gradient
+// sends back along its row / column difference (c = a x b: v_a = b x v_c, v_b = v_c x a).  The first version was
+// pixel-parallel -- every pixel re-evaluated the normals of its four neighbours and its own from global memory, ten
+// evaluations per pixel for the two depth maps: 94 us at 1080p against ~21 us of algorithmic traffic.  Here a 32 x 8
+// tile stages both depth maps with a halo of 2, every pixel of the tile + halo 1 gets its adjoint vectors ONCE into
+// LDS, and the owners gather the four they need: 1.33 evaluations per pixel and map.  Every element of the outputs is
+// owned by one thread: no atomics.
+constexpr int kDnTX = 32, kDnTY = 8;
+__global__ __launch_bounds__(kDnTX * kDnTY) void depth_normal_bwd_tiled_kernel(
+    DN d, const float* __restrict__ ed, const float* __restrict__ md, const float* __restrict__ nr,
+    const float* __restrict__ v_n2, const float* __restrict__ v_err, float* __restrict__ v_ed, float* __restrict__ v_md,
+    float* __restrict__ v_nr, const int accumulate) {
+    constexpr int DW = kDnTX + 4, DH = kDnTY + 4;           // depth tile, halo 2
+    constexpr int RW = kDnTX + 2, RH = kDnTY + 2;           // adjoint tile, halo 1
+    __shared__ float dep[2][DH][DW];
+    __shared__ float adj[2][9][RH][RW];                     // per map: v_a[3], v_b[3], v_err * n[3]
+    const int x0 = blockIdx.x * kDnTX, y0 = blockIdx.y * kDnTY;
     const size_t P = (size_t)d.W * d.H;
-    for (size_t pid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; pid < P; pid += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(pid / d.W), x = (int)(pid - (size_t)y * d.W);
-        const float rx = ((float)x + 0.5f) / d.fx - (float)d.W / (2.0f * d.fx);
-        const float ry = ((float)y + 0.5f) / d.fy - (float)d.H / (2.0f * d.fy);
-        const bool interior = x >= 1 && y >= 1 && x < d.W - 1 && y < d.H - 1;
-        float vnr[3] = {0.f, 0.f, 0.f};
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 2 * DH * DW; e += kDnTX * kDnTY) {
+        const int k = e / (DH * DW), r = e - k * DH * DW, ly = r / DW, lx = r - ly * DW;
+        const int y = y0 + ly - 2, x = x0 + lx - 2;
+        float z = 0.f;
+        if (x >= 0 && y >= 0 && x < d.W && y < d.H) z = (k == 0 ? ed : md)[(size_t)y * d.W + x];
+        dep[k][ly][lx] = z;
+    }
+    __syncthreads();
+    for (int e = tid; e < RH * RW; e += kDnTX * kDnTY) {
+        const int ly = e / RW, lx = e - ly * RW;
+        const int yn = y0 + ly - 1, xn = x0 + lx - 1;
+        const bool interior = xn >= 1 && yn >= 1 && xn < d.W - 1 && yn < d.H - 1;
+        const size_t pid = interior ? (size_t)yn * d.W + xn : 0;
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+        if (interior && v_err) { r0 = nr[pid * 3]; r1 = nr[pid * 3 + 1]; r2 = nr[pid * 3 + 2]; }
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            const float* depth = k == 0 ? ed : md;
-            // P(y,x) is the +row neighbour of (y-1,x), the -row neighbour of (y+1,x),
-            // the +col neighbour of (y,x-1) and the -col neighbour of (y,x+1)
-            float va[3], vb[3], g[3] = {0.f, 0.f, 0.f};
-            if (y >= 1) { dn_grad_ab(d, depth, nr, v_n2, v_err, k, y - 1, x, va, vb); g[0] += va[0]; g[1] += va[1]; g[2] += va[2]; }
-            if (y + 1 < d.H) { dn_grad_ab(d, depth, nr, v_n2, v_err, k, y + 1, x, va, vb); g[0] -= va[0]; g[1] -= va[1]; g[2] -= va[2]; }
-            if (x >= 1) { dn_grad_ab(d, depth, nr, v_n2, v_err, k, y, x - 1, va, vb); g[0] += vb[0]; g[1] += vb[1]; g[2] += vb[2]; }
-            if (x + 1 < d.W) { dn_grad_ab(d, depth, nr, v_n2, v_err, k, y, x + 1, va, vb); g[0] -= vb[0]; g[1] -= vb[1]; g[2] -= vb[2]; }
-            float* dst = k == 0 ? v_ed : v_md;
-            const float gd = g[0] * rx + g[1] * ry + g[2];
-            dst[pid] = accumulate ? dst[pid] + gd : gd;           // every element is owned by one thread: no atomics
-            if (v_err && interior) {
-                float a[3], b[3], cr[3], len, n[3];
-                dn_normal(d, depth, y, x, a, b, cr, len, n);
-                const float ve = v_err[(size_t)k * P + pid];
-                vnr[0] -= ve * n[0]; vnr[1] -= ve * n[1]; vnr[2] -= ve * n[2];
+            float va[3] = {0.f, 0.f, 0.f}, vb[3] = {0.f, 0.f, 0.f}, ven[3] = {0.f, 0.f, 0.f};
+            if (interior) {
+                // points of the four neighbours (dn_point), from the staged tile: (ly, lx) of the adjoint tile is
+                // (ly + 1, lx + 1) of the depth tile
+                float pt[4][3];
+                const int ny[4] = {yn + 1, yn - 1, yn, yn}, nx[4] = {xn, xn, xn + 1, xn - 1};
+                const int dy[4] = {ly + 2, ly, ly + 1, ly + 1}, dx[4] = {lx + 1, lx + 1, lx + 2, lx};
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float z = dep[k][dy[q]][dx[q]];
+                    pt[q][0] = z * (((float)nx[q] + 0.5f) / d.fx - (float)d.W / (2.0f * d.fx));
+                    pt[q][1] = z * (((float)ny[q] + 0.5f) / d.fy - (float)d.H / (2.0f * d.fy));
+                    pt[q][2] = z;
+                }
+                float a[3], b[3], cr[3], n[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++) { a[q] = pt[0][q] - pt[1][q]; b[q] = pt[2][q] - pt[3][q]; }
+                cr[0] = a[1] * b[2] - a[2] * b[1];
+                cr[1] = a[2] * b[0] - a[0] * b[2];
+                cr[2] = a[0] * b[1] - a[1] * b[0];
+                const float len = sqrtf(cr[0] * cr[0] + cr[1] * cr[1] + cr[2] * cr[2]);
+                const float inv = 1.0f / fmaxf(len, 1e-12f);
+                n[0] = cr[0] * inv; n[1] = cr[1] * inv; n[2] = cr[2] * inv;
+                float vn[3] = {0.f, 0.f, 0.f};
+                if (v_n2) { const float* sp = v_n2 + ((size_t)k * P + pid) * 3; vn[0] = sp[0]; vn[1] = sp[1]; vn[2] = sp[2]; }
+                if (v_err) {
+                    const float ve = v_err[(size_t)k * P + pid];
+                    vn[0] -= ve * r0; vn[1] -= ve * r1; vn[2] -= ve * r2;
+                    ven[0] = ve * n[0]; ven[1] = ve * n[1]; ven[2] = ve * n[2];
+                }
+                float vc[3];
+                if (len > 1e-12f) {
+                    const float dot = n[0] * vn[0] + n[1] * vn[1] + n[2] * vn[2];
+#pragma unroll
+                    for (int q = 0; q < 3; q++) vc[q] = (vn[q] - n[q] * dot) / len;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 3; q++) vc[q] = vn[q] / 1e-12f;
+                }
+                va[0] = b[1] * vc[2] - b[2] * vc[1]; va[1] = b[2] * vc[0] - b[0] * vc[2]; va[2] = b[0] * vc[1] - b[1] * vc[0];
+                vb[0] = vc[1] * a[2] - vc[2] * a[1]; vb[1] = vc[2] * a[0] - vc[0] * a[2]; vb[2] = vc[0] * a[1] - vc[1] * a[0];
             }
+#pragma unroll
+            for (int q = 0; q < 3; q++) { adj[k][q][ly][lx] = va[q]; adj[k][3 + q][ly][lx] = vb[q]; adj[k][6 + q][ly][lx] = ven[q]; }
         }
-        if (accumulate) { vnr[0] += v_nr[pid * 3]; vnr[1] += v_nr[pid * 3 + 1]; vnr[2] += v_nr[pid * 3 + 2]; }
-        v_nr[pid * 3] = vnr[0]; v_nr[pid * 3 + 1] = vnr[1]; v_nr[pid * 3 + 2] = vnr[2];
     }
+    __syncthreads();
+    const int lx = tid % kDnTX, ly = tid / kDnTX;
+    const int x = x0 + lx, y = y0 + ly;
+    if (x >= d.W || y >= d.H) return;
+    const size_t pid = (size_t)y * d.W + x;
+    const float rx = ((float)x + 0.5f) / d.fx - (float)d.W / (2.0f * d.fx);
+    const float ry = ((float)y + 0.5f) / d.fy - (float)d.H / (2.0f * d.fy);
+    float vnr[3] = {0.f, 0.f, 0.f};
+    const int cy = ly + 1, cx = lx + 1;                      // own position in the adjoint tile
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        float g[3] = {0.f, 0.f, 0.f};
+        // P(y,x) is the +row neighbour of (y-1,x), the -row neighbour of (y+1,x), the +col neighbour of (y,x-1) and
+        // the -col neighbour of (y,x+1); adjoints of pixels outside the image are zero
+#pragma unroll
+        for (int q = 0; q < 3; q++) g[q] += adj[k][q][cy - 1][cx];
+#pragma unroll
+        for (int q = 0; q < 3; q++) g[q] -= adj[k][q][cy + 1][cx];
+#pragma unroll
+        for (int q = 0; q < 3; q++) g[q] += adj[k][3 + q][cy][cx - 1];
+#pragma unroll
+        for (int q = 0; q < 3; q++) g[q] -= adj[k][3 + q][cy][cx + 1];
+        float* dst = k == 0 ? v_ed : v_md;
+        const float gd = g[0] * rx + g[1] * ry + g[2];
+        dst[pid] = accumulate ? dst[pid] + gd : gd;
+        vnr[0] -= adj[k][6][cy][cx]; vnr[1] -= adj[k][7][cy][cx]; vnr[2] -= adj[k][8][cy][cx];
+    }
+    if (accumulate) { vnr[0] += v_nr[pid * 3]; vnr[1] += v_nr[pid * 3 + 1]; vnr[2] += v_nr[pid * 3 + 2]; }
+    v_nr[pid * 3] = vnr[0]; v_nr[pid * 3 + 1] = vnr[1]; v_nr[pid * 3 + 2] = vnr[2];
 }
 
 // ---- launch order of the compositing kernels: longest units first, per XCD strip ---------------------------
@@ -1561,9 +1604,9 @@ extern "C" int misplat_depth_normal_bwd(int32_t width, int32_t height, float fx,
                                         float* v_n_render, int32_t accumulate, misplat_stream_t stream) {
     if (width < 1 || height < 1 || !(fx > 0.f) || !(fy > 0.f)) return MISPLAT_EINVAL;
     DN d{width, height, fx, fy};
-    hipLaunchKernelGGL(depth_normal_bwd_kernel, dim3(grid_for((int64_t)width * height, 256)), dim3(256), 0,
-                       (hipStream_t)stream, d, exp_depth, med_depth, n_render, v_normals2, v_err, v_exp_depth,
-                       v_med_depth, v_n_render, (int)(accumulate != 0));
+    hipLaunchKernelGGL(depth_normal_bwd_tiled_kernel, dim3((width + kDnTX - 1) / kDnTX, (height + kDnTY - 1) / kDnTY),
+                       dim3(kDnTX * kDnTY), 0, (hipStream_t)stream, d, exp_depth, med_depth, n_render, v_normals2, v_err,
+                       v_exp_depth, v_med_depth, v_n_render, (int)(accumulate != 0));
     return check_launch();
 }
 
