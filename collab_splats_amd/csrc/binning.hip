@@ -344,17 +344,39 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
 #pragma unroll
         for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[row[r]]);
         const int passes = tile_radix_regs<WAVES, R>(key, val, n, L);
+        int pos[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) pos[r] = wave * 64 * R + r * 64 + lane;
         if (UNORDERED) {
-            bool tie = false;
-            if (passes == 0) tie = n > 1;
+            // Equal depths: with 4 000 entries per bucket (5 M Gaussians at 1080p) a third of the buckets holds a pair of
+            // equal floats, and re-sorting the whole bucket twice for it tripled their cost.  A run of equal keys is
+            // short: every entry of one looks at its run (the sorted keys and values are still in LDS) and takes the
+            // slot its row earns inside it; only a run longer than 8 falls back to the two extra sorts.
+            bool redo = false;
+            if (passes == 0) redo = n > 1;
             else {
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     const int i = wave * 64 * R + r * 64 + lane;
-                    if (i + 1 < n && L.xk[i] == L.xk[i + 1]) tie = true;
+                    if (i >= n) continue;
+                    const uint32_t k = L.xk[i];
+                    const bool tp = i > 0 && L.xk[i - 1] == k, tn = i + 1 < n && L.xk[i + 1] == k;
+                    if (!(tp || tn)) continue;
+                    int s = i, e = i;
+                    while (s > 0 && i - s < 8 && L.xk[s - 1] == k) s--;
+                    while (e + 1 < n && e - i < 8 && L.xk[e + 1] == k) e++;
+                    if (i - s == 8 || e - i == 8) { redo = true; continue; }
+                    const uint32_t mine = HAS_VALS ? (uint32_t)isect_gid[val[r]] : val[r];
+                    int before = 0;
+                    for (int j = s; j <= e; j++) {
+                        if (j == i) continue;
+                        const uint32_t vj = L.xv[j];
+                        before += ((HAS_VALS ? (uint32_t)isect_gid[vj] : vj) < mine) ? 1 : 0;
+                    }
+                    pos[r] = s + before;
                 }
             }
-            if (__syncthreads_or(tie)) {
+            if (__syncthreads_or(redo)) {
 #pragma unroll
                 for (int r = 0; r < R; r++) key[r] = HAS_VALS ? (uint32_t)isect_gid[val[r]] : val[r];
                 tile_radix_regs<WAVES, R>(key, val, n, L);            // by row
@@ -362,6 +384,8 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
 #pragma unroll
                 for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[key[r]]);
                 tile_radix_regs<WAVES, R>(key, val, n, L);            // stably by depth
+#pragma unroll
+                for (int r = 0; r < R; r++) pos[r] = wave * 64 * R + r * 64 + lane;
             }
         }
         if (HAS_VALS) {
@@ -372,8 +396,8 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
         for (int r = 0; r < R; r++) {
             const int i = wave * 64 * R + r * 64 + lane;
             if (i < n) {
-                payload[beg + i] = (int32_t)val[r];
-                flatten_ids[beg + i] = HAS_VALS ? row[r] : (int32_t)val[r];
+                payload[beg + pos[r]] = (int32_t)val[r];
+                flatten_ids[beg + pos[r]] = HAS_VALS ? row[r] : (int32_t)val[r];
             }
         }
         __syncthreads();
