@@ -285,7 +285,7 @@ __device__ __forceinline__ int tile_radix_regs(uint32_t (&key)[R], uint32_t (&va
 // depth sort alone is then only deterministic when all depths differ, so after it neighbours are compared
 // and a bucket with ties (rare in a real scene) is re-sorted by row and then, stably, by depth again.
 template <int WAVES, int R, bool HAS_VALS, bool UNORDERED>
-__global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t* __restrict__ offsets, int n_tiles,
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? 6 : 1) void tile_sort_reg_kernel(const int32_t* __restrict__ offsets, int n_tiles,
                                                                    int64_t n_isects, int lo, int hi,
                                                                    const float* __restrict__ depths,
                                                                    const int32_t* __restrict__ isect_gid,
@@ -344,18 +344,18 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
 #pragma unroll
         for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[row[r]]);
         const int passes = tile_radix_regs<WAVES, R>(key, val, n, L);
-        int pos[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) pos[r] = wave * 64 * R + r * 64 + lane;
+        unsigned placed = 0u;                          // bit r: entry r was written by the tie pass below
         if (UNORDERED) {
             // Equal depths: with 4 000 entries per bucket (5 M Gaussians at 1080p) a third of the buckets holds a pair of
             // equal floats, and re-sorting the whole bucket twice for it tripled their cost.  A run of equal keys is
-            // short: every entry of one looks at its run (the sorted keys and values are still in LDS) and takes the
-            // slot its row earns inside it; only a run longer than 8 falls back to the two extra sorts.
+            // short: every entry of one looks at its run (the sorted keys and values are still in LDS), takes the slot
+            // its row earns inside it and is written there; only a run longer than 8 falls back to the two extra sorts
+            // (which then rewrite everything).  Rolled loop over LDS, not over the register arrays: unrolled it cost
+            // 45 VGPRs and half the occupancy of the common path.
             bool redo = false;
             if (passes == 0) redo = n > 1;
             else {
-#pragma unroll
+#pragma unroll 1
                 for (int r = 0; r < R; r++) {
                     const int i = wave * 64 * R + r * 64 + lane;
                     if (i >= n) continue;
@@ -366,14 +366,17 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
                     while (s > 0 && i - s < 8 && L.xk[s - 1] == k) s--;
                     while (e + 1 < n && e - i < 8 && L.xk[e + 1] == k) e++;
                     if (i - s == 8 || e - i == 8) { redo = true; continue; }
-                    const uint32_t mine = HAS_VALS ? (uint32_t)isect_gid[val[r]] : val[r];
+                    const uint32_t v = L.xv[i];
+                    const uint32_t mine = HAS_VALS ? (uint32_t)isect_gid[v] : v;
                     int before = 0;
                     for (int j = s; j <= e; j++) {
                         if (j == i) continue;
                         const uint32_t vj = L.xv[j];
                         before += ((HAS_VALS ? (uint32_t)isect_gid[vj] : vj) < mine) ? 1 : 0;
                     }
-                    pos[r] = s + before;
+                    payload[beg + s + before] = (int32_t)v;
+                    flatten_ids[beg + s + before] = (int32_t)mine;
+                    placed |= 1u << r;
                 }
             }
             if (__syncthreads_or(redo)) {
@@ -384,8 +387,7 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
 #pragma unroll
                 for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[key[r]]);
                 tile_radix_regs<WAVES, R>(key, val, n, L);            // stably by depth
-#pragma unroll
-                for (int r = 0; r < R; r++) pos[r] = wave * 64 * R + r * 64 + lane;
+                placed = 0u;
             }
         }
         if (HAS_VALS) {
@@ -395,9 +397,9 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_reg_kernel(const int32_t
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = wave * 64 * R + r * 64 + lane;
-            if (i < n) {
-                payload[beg + pos[r]] = (int32_t)val[r];
-                flatten_ids[beg + pos[r]] = HAS_VALS ? row[r] : (int32_t)val[r];
+            if (i < n && !((placed >> r) & 1u)) {
+                payload[beg + i] = (int32_t)val[r];
+                flatten_ids[beg + i] = HAS_VALS ? row[r] : (int32_t)val[r];
             }
         }
         __syncthreads();
