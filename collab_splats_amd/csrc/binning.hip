@@ -285,7 +285,7 @@ __device__ __forceinline__ int tile_radix_regs(uint32_t (&key)[R], uint32_t (&va
 // depth sort alone is then only deterministic when all depths differ, so after it neighbours are compared
 // and a bucket with ties (rare in a real scene) is re-sorted by row and then, stably, by depth again.
 template <int WAVES, int R, bool HAS_VALS, bool UNORDERED>
-__global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? 6 : 1) void tile_sort_reg_kernel(const int32_t* __restrict__ offsets, int n_tiles,
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? 6 : (WAVES == 1 ? 4 : 1)) void tile_sort_reg_kernel(const int32_t* __restrict__ offsets, int n_tiles,
                                                                    int64_t n_isects, int lo, int hi,
                                                                    const float* __restrict__ depths,
                                                                    const int32_t* __restrict__ isect_gid,
@@ -300,34 +300,48 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? 6 : 1) void ti
         const int beg = min(offsets[t], end);
         const int n = end - beg;
         if (n <= lo || n > hi) continue;               // uniform over the block (n >= 1 from here)
-        if (lo == 0 && n <= 64 * WAVES) {
-            // Short bucket (one entry per thread): rank = number of entries that sort before mine, counted against
-            // all n through LDS broadcasts -- n iterations of two compares instead of 3 radix passes of 5 barriers each.
-            // Ties break by row (UNORDERED: the (depth, row) order) or by arrival (stable).  ~3x faster than the
-            // radix path at n <= 256 (the typical bucket of a 100 k scene at 1080p).
-            const int i = threadIdx.x;
-            uint32_t v = 0u, k = 0xffffffffu, tb = 0xffffffffu;
-            if (i < n) {
-                v = (uint32_t)payload[beg + i];
-                const int32_t rw = HAS_VALS ? isect_gid[v] : (int32_t)v;
-                k = __float_as_uint(depths[rw]);
-                tb = UNORDERED ? (uint32_t)rw : (uint32_t)i;
+        if (lo == 0 && n <= 128 * WAVES) {
+            // Short bucket (at most two entries per thread): rank = number of entries that sort before mine, counted
+            // against all n through LDS broadcasts -- n / 2 iterations of a few compares instead of 3 radix passes.
+            // Ties break by row (UNORDERED: the (depth, row) order) or by arrival (stable).
+            constexpr int T = 64 * WAVES;
+            uint32_t v[2], k[2], tb[2];
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int i = threadIdx.x + q * T;
+                v[q] = 0u; k[q] = 0xffffffffu; tb[q] = 0xffffffffu;
+                if (i < n) {
+                    v[q] = (uint32_t)payload[beg + i];
+                    const int32_t rw = HAS_VALS ? isect_gid[v[q]] : (int32_t)v[q];
+                    k[q] = __float_as_uint(depths[rw]);
+                    tb[q] = UNORDERED ? (uint32_t)rw : (uint32_t)i;
+                }
             }
-            uint2* pk = reinterpret_cast<uint2*>(L.xk);                 // (key, tie-break) pairs: 2 * 64 * WAVES <= CAP words
+            uint2* pk = reinterpret_cast<uint2*>(L.xk);                 // (key, tie-break) pairs: 4 T <= CAP words (R >= 4)
             __syncthreads();                                            // (the previous bucket's readers are done)
-            pk[i] = make_uint2(k, tb);
+            pk[threadIdx.x] = make_uint2(k[0], tb[0]);
+            pk[threadIdx.x + T] = make_uint2(k[1], tb[1]);
             __syncthreads();
-            int rank = 0;
+            int rank0 = 0, rank1 = 0;
             const uint4* pk2 = reinterpret_cast<const uint4*>(L.xk);
             const int n2 = (n + 1) >> 1;                                // the pad entry (0xffffffff, 0xffffffff) never sorts before
+            const bool two = n > T;                                     // (uniform)
             for (int j = 0; j < n2; j++) {
-                const uint4 q = pk2[j];
-                rank += (q.x < k || (q.x == k && q.y < tb)) ? 1 : 0;
-                rank += (q.z < k || (q.z == k && q.w < tb)) ? 1 : 0;
+                const uint4 p = pk2[j];
+                rank0 += (p.x < k[0] || (p.x == k[0] && p.y < tb[0])) ? 1 : 0;
+                rank0 += (p.z < k[0] || (p.z == k[0] && p.w < tb[0])) ? 1 : 0;
+                if (two) {
+                    rank1 += (p.x < k[1] || (p.x == k[1] && p.y < tb[1])) ? 1 : 0;
+                    rank1 += (p.z < k[1] || (p.z == k[1] && p.w < tb[1])) ? 1 : 0;
+                }
             }
-            if (i < n) {
-                payload[beg + rank] = (int32_t)v;
-                flatten_ids[beg + rank] = HAS_VALS ? isect_gid[v] : (int32_t)v;
+            if ((int)threadIdx.x < n) {
+                payload[beg + rank0] = (int32_t)v[0];
+                flatten_ids[beg + rank0] = HAS_VALS ? isect_gid[v[0]] : (int32_t)v[0];
+            }
+            if ((int)threadIdx.x + T < n) {
+                payload[beg + rank1] = (int32_t)v[1];
+                flatten_ids[beg + rank1] = HAS_VALS ? isect_gid[v[1]] : (int32_t)v[1];
             }
             continue;
         }
@@ -766,8 +780,15 @@ static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_i
     const int64_t avg = n_isects / n_tiles;
     const int full = n_tiles < 65536 ? n_tiles : 65536;
     const int few = n_tiles < 256 ? n_tiles : 256;
-    hipLaunchKernelGGL((tile_sort_reg_kernel<4, 4, HAS_VALS, UNORDERED>), dim3(full), dim3(256), 0, s, offsets, n_tiles,
-                       n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
+    // <= 1024 entries.  Sparse scenes (typical bucket under 256 entries: 100 k Gaussians at 1080p): ONE wavefront per
+    // bucket, 16 entries per lane, no barrier ever waits for another wave (0.496 -> 0.471 ms per step there); dense ones:
+    // four waves, 4 entries per lane (the one-wave form is 12 us slower at 1 M, where the typical bucket holds 800).
+    if (avg < 256)
+        hipLaunchKernelGGL((tile_sort_reg_kernel<1, 16, HAS_VALS, UNORDERED>), dim3(full), dim3(64), 0, s, offsets, n_tiles,
+                           n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
+    else
+        hipLaunchKernelGGL((tile_sort_reg_kernel<4, 4, HAS_VALS, UNORDERED>), dim3(full), dim3(256), 0, s, offsets, n_tiles,
+                           n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
     hipLaunchKernelGGL((tile_sort_reg_kernel<8, 8, HAS_VALS, UNORDERED>), dim3(avg >= 1024 ? full : few), dim3(512), 0, s,
                        offsets, n_tiles, n_isects, 1024, 4096, depths, isect_gid, payload, flatten_ids, has_longest);
     hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS, UNORDERED>), dim3(avg >= 2048 ? full : few), dim3(1024), 0,
