@@ -782,12 +782,12 @@ static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_i
     const int few = n_tiles < 256 ? n_tiles : 256;
     // <= 1024 entries.  Sparse scenes (typical bucket under 256 entries: 100 k Gaussians at 1080p): ONE wavefront per
     // bucket, 16 entries per lane, no barrier ever waits for another wave (0.496 -> 0.471 ms per step there); dense ones:
-    // four waves, 4 entries per lane (the one-wave form is 12 us slower at 1 M, where the typical bucket holds 800).
+    // two waves, 8 entries per lane (measured at 1 M, typical bucket 800: one wave x 16 +12 us, four waves x 4 +5 us).
     if (avg < 256)
         hipLaunchKernelGGL((tile_sort_reg_kernel<1, 16, HAS_VALS, UNORDERED>), dim3(full), dim3(64), 0, s, offsets, n_tiles,
                            n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
     else
-        hipLaunchKernelGGL((tile_sort_reg_kernel<4, 4, HAS_VALS, UNORDERED>), dim3(full), dim3(256), 0, s, offsets, n_tiles,
+        hipLaunchKernelGGL((tile_sort_reg_kernel<2, 8, HAS_VALS, UNORDERED>), dim3(full), dim3(128), 0, s, offsets, n_tiles,
                            n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
     hipLaunchKernelGGL((tile_sort_reg_kernel<8, 8, HAS_VALS, UNORDERED>), dim3(avg >= 1024 ? full : few), dim3(512), 0, s,
                        offsets, n_tiles, n_isects, 1024, 4096, depths, isect_gid, payload, flatten_ids, has_longest);

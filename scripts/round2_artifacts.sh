@@ -26,6 +26,24 @@ cd $GRAFT_REPO_ROOT
 bash scripts/pmc_run.sh $TAG/pmc > $OUT/pmc.log 2>&1 || true
 python3 scripts/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1 || true
 python3 scripts/pmc_traffic.py $OUT/pmc $(cat collab_splats_amd/_build_rev.txt 2>/dev/null || echo unknown) > $OUT/pmc_traffic.json 2> $OUT/pmc_traffic.err || true
+# the other configurations (bench lines only) and the small-scene timelines
+python3 bench.py --no-cpu-baseline --gaussians 10000 --width 256 --height 256 > $OUT/bench_10k.json 2> $OUT/b10k.err
+python3 bench.py --no-cpu-baseline --gaussians 10000 --width 256 --height 256 --graphed > $OUT/bench_10k_graphed.json 2>> $OUT/b10k.err
+python3 bench.py --no-cpu-baseline --gaussians 100000 > $OUT/bench_100k.json 2> $OUT/b100k.err
+python3 bench.py --no-cpu-baseline --gaussians 100000 --graphed > $OUT/bench_100k_graphed.json 2>> $OUT/b100k.err
+python3 bench.py --no-cpu-baseline --dn-loss > $OUT/bench_1M_dnloss.json 2> $OUT/b1mdn.err
+python3 bench.py --no-cpu-baseline --dn-loss --gaussians 5000000 > $OUT/bench_5M_dnloss.json 2> $OUT/b5m.err
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t10k -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --gaussians 10000 --width 256 --height 256 --steps 40 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t100k -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --gaussians 100000 --steps 40 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT
+for t in t10k t100k; do
+  python3 scripts/timeline.py $(find $OUT/$t -name "*kernel_trace.csv" | head -1) > $OUT/timeline_$t.txt 2>&1 || true
+  rm -rf $OUT/$t
+done
+rm -rf $OUT/stats
+for f in bench_10k bench_10k_graphed bench_100k bench_100k_graphed bench_1M_dnloss bench_5M_dnloss; do python3 -c "
+import json; d=json.load(open('$OUT/$f.json')); print('$f', d['ms_per_step'], d['device_ms_median'], d['value'])"; done
 cut -c1-700 $OUT/bench.json
 head -16 $OUT/kernel_summary.txt
 cat $OUT/pmc_traffic.json | head -12
