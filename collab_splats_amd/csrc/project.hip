@@ -825,10 +825,13 @@ __global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : 
                         }
                     }
                     if (BWD && AUX) {
-                        const float4* ax = reinterpret_cast<const float4*>(sh_aux + (size_t)idx * 12);
-                        const float4 a0 = ax[0], a1 = ax[1], a2 = ax[2];
                         const float* vg = v_grec + (size_t)idx * MISPLAT_REC + 12;
                         const float g0v = vg[0], g1v = vg[1], g2v = vg[2];
+                        // a Gaussian the compositing never reached has a zero colour gradient: its gradient row is
+                        // zeros (written below) and its 48 bytes of Jacobian are not fetched
+                        if (g0v == 0.f && g1v == 0.f && g2v == 0.f) continue;
+                        const float4* ax = reinterpret_cast<const float4*>(sh_aux + (size_t)idx * 12);
+                        const float4 a0 = ax[0], a1 = ax[1], a2 = ax[2];
                         const float vc0 = a2.y * g0v, vc1 = a2.z * g1v, vc2 = a2.w * g2v;     // clamp flags are 0 / 1
                         const float vd0 = a0.x * g0v + a0.w * g1v + a1.z * g2v;
                         const float vd1 = a0.y * g0v + a1.x * g1v + a1.w * g2v;
@@ -1101,6 +1104,88 @@ __global__ __launch_bounds__(256) void project_pack_bwd_kernel(
     }
 }
 
+// One camera: most rows of a dense scene never receive a gradient -- the compositing stops at the first opaque layers,
+// and the packed gradient row of a Gaussian behind them is still the zeros the forward left (1 M random Gaussians at
+// 1080p: 11 % of the visible rows get one, at 5 M 2 %; scripts/touched_fraction.py).  A zero row in gives a zero row out,
+// but a thread-per-row kernel gains nothing from skipping it: a wave runs as long as its one live lane.  So every wave
+// SCANS its rows 64 at a time (visibility, the 64-byte row, is it non-zero?), writes the outputs of the dead rows at
+// once, queues the live ones in LDS, and runs the ~1 400-instruction backward only on full batches of 64 live rows.
+__global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
+    misplat_params P, int depth_slot, const float* __restrict__ means, const float* __restrict__ quats,
+    const float* __restrict__ scales, const float* __restrict__ opacities,
+    const float* __restrict__ viewmats, const float* __restrict__ Ks, const int32_t* __restrict__ radii,
+    const float* __restrict__ comps, const float* __restrict__ v_means2d, const float* __restrict__ v_grec,
+    const float* __restrict__ v_means_dir, float* __restrict__ v_means, float* __restrict__ v_quats,
+    float* __restrict__ v_scales, float* __restrict__ v_opacities) {
+    __shared__ int queue[128];
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int qn = 0;
+    const Cam cam = load_cam(viewmats, Ks);
+    auto heavy = [&](int g) {
+        float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+        float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
+        float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+        const float opac = opacities[g];
+        float o_m[3] = {0.f, 0.f, 0.f}, o_q[4] = {0.f, 0.f, 0.f, 0.f}, o_s[3] = {0.f, 0.f, 0.f};
+        float o_op = 0.f;
+        if (v_means_dir) { o_m[0] = v_means_dir[3 * g]; o_m[1] = v_means_dir[3 * g + 1]; o_m[2] = v_means_dir[3 * g + 2]; }
+        const float4* vg = reinterpret_cast<const float4*>(v_grec + (size_t)g * MISPLAT_REC);
+        const float4 g0 = vg[0], g1 = vg[1], g2 = vg[2], g3 = vg[3];
+        ProjGrads G;
+        G.v_m2d[0] = v_means2d ? v_means2d[2 * g] : g0.x;
+        G.v_m2d[1] = v_means2d ? v_means2d[2 * g + 1] : g0.y;
+        G.v_conic[0] = g0.z; G.v_conic[1] = g0.w; G.v_conic[2] = g1.x;
+        const float v_oeff = g1.y;
+        G.v_rt = g1.z; G.v_rp[0] = g1.w; G.v_rp[1] = g2.x;
+        G.v_nr[0] = g2.y; G.v_nr[1] = g2.z; G.v_nr[2] = g2.w;
+        G.v_depth = depth_slot == 12 ? g3.x : (depth_slot == 13 ? g3.y : (depth_slot == 14 ? g3.z : (depth_slot == 15 ? g3.w : 0.f)));
+        if (P.antialiased) { o_op += v_oeff * comps[g]; G.v_comp = v_oeff * opac; }
+        else { o_op += v_oeff; G.v_comp = 0.f; }
+        project_bwd_one(mean, quat, sc, cam, P, G, o_m, o_q, o_s);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { v_means[3 * g + k] = o_m[k]; v_scales[3 * g + k] = o_s[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) v_quats[4 * g + k] = o_q[k];
+        v_opacities[g] = o_op;
+    };
+    for (int base = blockIdx.x * 64; base < P.n_gauss; base += gridDim.x * 64) {
+        const int g = base + lane;
+        bool live = false;
+        if (g < P.n_gauss) {
+            if (radii[2 * g] > 0 || radii[2 * g + 1] > 0) {
+                const float4* vg = reinterpret_cast<const float4*>(v_grec + (size_t)g * MISPLAT_REC);
+                const float4 g0 = vg[0], g1 = vg[1], g2 = vg[2], g3 = vg[3];
+                live = g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f || g1.x != 0.f || g1.y != 0.f || g1.z != 0.f ||
+                       g1.w != 0.f || g2.x != 0.f || g2.y != 0.f || g2.z != 0.f || g2.w != 0.f || g3.x != 0.f || g3.y != 0.f ||
+                       g3.z != 0.f || g3.w != 0.f;
+                if (v_means2d) live = live || v_means2d[2 * g] != 0.f || v_means2d[2 * g + 1] != 0.f;
+            }
+            if (!live) {
+                float m0 = 0.f, m1 = 0.f, m2 = 0.f;
+                if (v_means_dir) { m0 = v_means_dir[3 * g]; m1 = v_means_dir[3 * g + 1]; m2 = v_means_dir[3 * g + 2]; }
+                v_means[3 * g] = m0; v_means[3 * g + 1] = m1; v_means[3 * g + 2] = m2;
+                v_scales[3 * g] = 0.f; v_scales[3 * g + 1] = 0.f; v_scales[3 * g + 2] = 0.f;
+                *reinterpret_cast<float4*>(v_quats + 4 * (size_t)g) = make_float4(0.f, 0.f, 0.f, 0.f);
+                v_opacities[g] = 0.f;
+            }
+        }
+        const unsigned long long mask = __ballot(live);
+        if (live) queue[qn + __popcll(mask & lt)] = g;
+        qn += __popcll(mask);
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64) {
+            const int gq = queue[lane];
+            const int keep = lane + 64 < qn ? queue[lane + 64] : 0;
+            __builtin_amdgcn_wave_barrier();
+            queue[lane] = keep;
+            qn -= 64;
+            heavy(gq);
+        }
+    }
+    if (lane < qn) heavy(queue[lane]);
+}
+
 inline int grid_for(int64_t n, int block) {
     int64_t b = (n + block - 1) / block;
     if (b > 8192) b = 8192;
@@ -1266,6 +1351,16 @@ extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_s
     if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
     if (depth_slot != -1 && (depth_slot < 12 || depth_slot > 15)) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
+    if (p->n_cams == 1) {
+        // one wave per workgroup, at most 2 048 of them (the kernel's 2 waves per SIMD): every wave scans enough rows to
+        // fill batches of live ones
+        int64_t waves = ((int64_t)p->n_gauss + 63) / 64;
+        if (waves > 2048) waves = 2048;
+        hipLaunchKernelGGL(project_pack_bwd_sparse_kernel, dim3((unsigned)waves), dim3(64), 0, (hipStream_t)stream,
+                           *p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii, compensations, v_means2d,
+                           v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities);
+        return check_launch();
+    }
     hipLaunchKernelGGL(project_pack_bwd_kernel, dim3(grid_for(p->n_gauss, 256)), dim3(256), 0, (hipStream_t)stream,
                        *p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii, compensations, v_means2d,
                        v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities);
