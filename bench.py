@@ -385,6 +385,8 @@ def main():
                          "traffic": pmc.get(dom), "traffic_git_rev": pmc.get("git_rev"),
                          "valu_issue_frac": vif.get(dom) if isinstance(vif, dict) else None,
                          "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
+                         "kernel_ms_note": "HIP events around the stage-by-stage entries in a separate pass (there blend_fwd "
+                                           "runs without the on-demand colours of the default path: profiles/ has both)",
                          "algorithmic_bytes": abytes,
                          "copy_roof_GBs": round(roof, 1), "frac_of_copy_roof": round(achieved / max(roof, 1e-9), 5),
                          "step_algorithmic_bytes": step_bytes, "step_GBs": round(step_gbs, 1),

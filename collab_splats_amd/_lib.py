@@ -44,7 +44,7 @@ class RasterArgs(C.Structure):
     _P = C.c_void_p
     _fields_ = ([(n, C.c_void_p) for n in ("means", "quats", "scales", "opacities", "colors", "colors_rest", "viewmats", "Ks")]
                 + [(n, C.c_int32) for n in ("sh_degree", "K_or_D", "n_color", "per_cam", "depth_channel", "color_dim",
-                                            "colour_pending", "reserved2")]
+                                            "colour_pending", "lazy_colour")]
                 + [(n, C.c_void_p) for n in ("radii", "means2d", "depths", "compensations", "grec", "sh_aux", "v_grec_zero",
                                              "tiles_per_gauss", "rect2", "cellhist", "cell_count", "cell_offs", "order",
                                              "rect_sorted", "counters", "tile_count", "offsets", "payload", "flatten_ids", "scratch")]
@@ -86,7 +86,7 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
 # name -> (restype, n_args); every symbol include/misplat.h declares
 SYMBOLS = {
     "misplat_project_fwd": (C.c_int, 16), "misplat_project_bwd": (C.c_int, 18),
-    "misplat_project_pack_fwd": (C.c_int, 15), "misplat_color_fwd": (C.c_int, 16),
+    "misplat_project_pack_fwd": (C.c_int, 16), "misplat_color_fwd": (C.c_int, 16),
     "misplat_color_bwd": (C.c_int, 16), "misplat_project_pack_bwd": (C.c_int, 18),
     "misplat_sh_fwd": (C.c_int, 9), "misplat_sh_bwd": (C.c_int, 11),
     "misplat_sort32_workspace_bytes": (C.c_size_t, 2),
@@ -99,7 +99,7 @@ SYMBOLS = {
     "misplat_tile_offsets16": (C.c_int, 5),
     "misplat_adam_step": (C.c_int, 12),
     "misplat_radix_workspace_bytes": (C.c_size_t, 4), "misplat_radix_sort_pairs": (C.c_int, 11), "misplat_pack": (C.c_int, 11),
-    "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_bwd": (C.c_int, 21),
+    "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_fwd_lazy": (C.c_int, 23), "misplat_blend_bwd": (C.c_int, 21),
     "misplat_color_fwd_x": (C.c_int, 11), "misplat_color_bwd_x": (C.c_int, 9),
     "misplat_blend_fwd_x": (C.c_int, 17), "misplat_blend_bwd_x_atomic": (C.c_int, 22),
     "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 20), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),

@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "misplat.h"
+#include "sh_eval.h"
 
 namespace {
 
@@ -91,13 +92,58 @@ __device__ __forceinline__ float sigma_min_box(float a, float b, float c, float 
 // wave's pixel band (conservatively: kept unless max alpha over the band is provably < alpha_min),
 // and the survivors are compacted with a ballot prefix into LDS, conic pre-multiplied so that
 // vis = exp2(e), e = cA' dx^2 + cC' dy^2 + cB' dx dy (= -sigma log2 e).  Returns the survivor count.
-template <int NXQ = 0>
+// On-demand colours (LAZY): the projection kernel leaves the colour slots of every record UNSET, and the first wave
+// that stages a record past its cull evaluates the SH colour (and its Jacobian for the backward) and stores it.  A dense
+// scene is mostly a hidden scene -- 1 M random Gaussians at 1080p: a third of the visible ones is ever staged, 11 % are
+// composited -- so most colours are never computed.  Two waves that meet at a record compute the same bits twice.
+constexpr uint32_t kColourUnset = 0x7fc0dead;      // a NaN no colour can be (colours are max(c + 0.5, 0))
+struct LazyColour {
+    const float* means; const float* coeffs; const float* coeffs_rest; const float* depths; const float* viewmats;
+    float4* grec_rw; float* sh_aux;
+    float ccx, ccy, ccz;                             // camera centre of the workgroup's tile (set in the kernel)
+    int deg, depth_channel, n_gauss;
+};
+
+// Colour of row g from its 16 x 3 coefficients, term by term (MISPLAT_SH_WALK: the same expressions in the same order as
+// the colour kernel, and like it without FMA contraction, so both produce the same bits -- which of the two runs is a
+// speed decision the results must not show).  The coefficients are read straight from global memory as the walk
+// reaches them; its scheduling barriers keep the compiler from hoisting all 48 loads to the top: the evaluation sits
+// inside the compositing kernel and must not cost it its occupancy (80 VGPRs without it, 111 with).
+__device__ __forceinline__ float4 lazy_colour(const LazyColour& lz, int g) {
+#pragma clang fp contract(off)
+    using namespace misplat_sh;
+    const int gg = g % lz.n_gauss;
+    const float dx = lz.means[3 * gg] - lz.ccx, dy = lz.means[3 * gg + 1] - lz.ccy, dz = lz.means[3 * gg + 2] - lz.ccz;
+    const float nn = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float inv = nn > 0.f ? 1.0f / nn : 0.f;
+    const float x = dx * inv, y = dy * inv, z = dz * inv;
+    const bool split = lz.coeffs_rest != nullptr;
+    // coefficient (k, ch): float 3 k + ch of the row ([N,16,3]), or dc[ch] for k = 0 and rest[3 (k - 1) + ch] (split)
+    const float* row = split ? lz.coeffs_rest + (size_t)gg * 45 - 3 : lz.coeffs + (size_t)gg * 48;
+    const float* dc = split ? lz.coeffs + (size_t)gg * 3 : row;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#define LZ_TERM(k, B, BX, BY, BZ)                                                       \
+    {                                                                                   \
+        const float* f_ = (k) == 0 ? dc : row + 3 * (k);                                \
+        const float b_ = (B);                                                           \
+        c0 += b_ * f_[0]; c1 += b_ * f_[1]; c2 += b_ * f_[2];                           \
+    }
+    MISPLAT_SH_WALK(lz.deg, x, y, z, LZ_TERM)
+#undef LZ_TERM
+    const float4 q3 = make_float4(fmaxf(c0 + 0.5f, 0.f), fmaxf(c1 + 0.5f, 0.f), fmaxf(c2 + 0.5f, 0.f),
+                                  lz.depth_channel ? lz.depths[g] : 0.f);
+    lz.grec_rw[4 * (size_t)g + 3] = q3;
+    return q3;
+}
+
+template <int NXQ = 0, bool LAZY = false>
 __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_slot, int lane, int i, bool valid,
-                                             const float4* __restrict__ grec,
+                                             const float4* grec,
                                              const int32_t* __restrict__ flatten_ids,
                                              const int32_t* __restrict__ slots, float xlo, float xhi,
                                              float ylo, float yhi, float alpha_min,
-                                             float4* smx = nullptr, const float4* __restrict__ featx = nullptr) {
+                                             float4* smx = nullptr, const float4* __restrict__ featx = nullptr,
+                                             const LazyColour* lz = nullptr) {
     float4 q0, q1, q2, q3;
     bool keep = false;
     int slot = 0;
@@ -109,6 +155,10 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
         if (slots) slot = slots[i]; else slot = g;
         const float smin = sigma_min_box(q0.z, q0.w, q1.x, q0.x - xhi, q0.x - xlo, q0.y - yhi, q0.y - ylo);
         keep = q1.y * __builtin_amdgcn_exp2f(-smin * kLog2e) * 1.002f >= alpha_min;
+    }
+    if (LAZY) {
+        // (a real call, not inlined: the evaluation needs ~100 registers that the compositing loop must not pay for)
+        if (keep && __float_as_uint(q3.x) == kColourUnset) q3 = lazy_colour(*lz, g);
     }
     const unsigned long long mask = __ballot(keep);
     if (keep) {
@@ -131,16 +181,17 @@ __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; 
 // "skip" is a = 0.  The next record is prefetched from LDS while the current one is consumed.
 // NXQ > 0: N-D colours (rade_features_model.py:441-476, D = 16 / 17): channels 0..3 ride in the record,
 // channels 4.. in featx[row][NXQ] (float4s, zero padded); n_channels = D' is the render width.
-template <int CD, int PPL, int NXQ = 0>
+template <int CD, int PPL, int NXQ = 0, bool LAZY = false>
 #ifndef MISPLAT_FWD_WAVES
 #define MISPLAT_FWD_WAVES 0            /* 0: let the compiler choose (80 VGPRs -> 6 waves/SIMD for PPL 2) */
 #endif
 __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0) ? MISPLAT_FWD_WAVES : 1) void blend_fwd_kernel(
-    misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
+    misplat_params P, const float* __restrict__ Ks, const float4* grec,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ offsets, int64_t n_isects,
     float* __restrict__ render, float* __restrict__ alpha, float* __restrict__ exp_depth,
     float* __restrict__ med_depth, float* __restrict__ normal, int32_t* __restrict__ last_ids,
-    int32_t* __restrict__ median_ids, const float4* __restrict__ featx = nullptr, int n_channels = CD) {
+    int32_t* __restrict__ median_ids, const float4* __restrict__ featx = nullptr, int n_channels = CD,
+    LazyColour lz = LazyColour()) {
     __shared__ float4 sm[4 * 64 + 4];
     __shared__ int sm_idx[64 + 4];
     __shared__ float4 smx[NXQ > 0 ? NXQ * 64 + 4 : 1];
@@ -151,6 +202,13 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
         for (int ch = 0; ch < (NXQ > 0 ? 4 * NXQ : 1); ch++) colx[k][ch] = 0.f;
     BandCtx c;
     if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c)) return;
+    if (LAZY) {                                  // camera centre = -R^T t of the tile's camera (as the colour kernel has it)
+#pragma clang fp contract(off)
+        const float* V = lz.viewmats + 16 * c.cam;
+        lz.ccx = -(V[0] * V[3] + V[4] * V[7] + V[8] * V[11]);
+        lz.ccy = -(V[1] * V[3] + V[5] * V[7] + V[9] * V[11]);
+        lz.ccz = -(V[2] * V[3] + V[6] * V[7] + V[10] * V[11]);
+    }
     const int lane = threadIdx.x;
     const int x = c.tx * MISPLAT_TILE + (lane & 15);
     const int ybase = c.y0 + (lane >> 4);
@@ -209,8 +267,8 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
         }
         if (__ballot(tmax > 0.f) == 0ull) break;
         __syncthreads();
-        const int n = stage_records<NXQ>(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
-                                         nullptr, xlo, xhi, ylo, yhi, amin, smx, featx);
+        const int n = stage_records<NXQ, LAZY>(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
+                                               nullptr, xlo, xhi, ylo, yhi, amin, smx, featx, &lz);
         __syncthreads();
         if (n == 0) continue;
         work += n;
@@ -1388,6 +1446,38 @@ extern "C" int misplat_blend_fwd(const misplat_params* p, int32_t color_dim, con
     else return MISPLAT_EINVAL;
 #undef DISPATCH_FWD
 #undef LAUNCH_FWD
+    return check_launch();
+}
+
+// The same forward with ON-DEMAND SH colours (see LazyColour): the colour slots of grec must hold the "unset" pattern
+// (misplat_project_pack_fwd with lazy_rows) and are filled here for the records that are staged past their cull; sh_aux
+// (or NULL) receives the Jacobians of those records.  K = 16 coefficients per Gaussian ([N,16,3], or [N,3] + [N,15,3]).
+extern "C" int misplat_blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const float* Ks, float* grec,
+                                      const int32_t* flatten_ids, const int32_t* offsets, int64_t n_isects,
+                                      float* render, float* alpha, float* exp_depth, float* med_depth, float* normal,
+                                      int32_t* last_ids, int32_t* median_ids, const float* means, const float* viewmats,
+                                      const float* coeffs, const float* coeffs_rest, int32_t sh_degree,
+                                      int32_t depth_channel, const float* depths, float* sh_aux,
+                                      misplat_stream_t stream) {
+    if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !means || !viewmats || !coeffs || sh_degree < 0 ||
+        sh_degree > 3 || (depth_channel && !depths) || color_dim < 3 || color_dim > 4)
+        return MISPLAT_EINVAL;
+    if (pick_ppl(p->ppl_fwd, kDefaultPplFwd) != 2) return MISPLAT_EINVAL;
+    const int total = p->tile_w * p->tile_h * p->n_cams * 2;
+    const int grid = ((total + 7) / 8) * 8;
+    LazyColour lz;
+    lz.means = means; lz.coeffs = coeffs; lz.coeffs_rest = coeffs_rest; lz.depths = depths; lz.viewmats = viewmats;
+    lz.grec_rw = (float4*)grec; lz.sh_aux = sh_aux; lz.ccx = lz.ccy = lz.ccz = 0.f;
+    lz.deg = sh_degree; lz.depth_channel = depth_channel; lz.n_gauss = p->n_gauss;
+    hipStream_t s = (hipStream_t)stream;
+    if (color_dim == 3)
+        hipLaunchKernelGGL((blend_fwd_kernel<3, 2, 0, true>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec, flatten_ids,
+                           offsets, n_isects, render, alpha, exp_depth, med_depth, normal, last_ids, median_ids,
+                           (const float4*)nullptr, 3, lz);
+    else
+        hipLaunchKernelGGL((blend_fwd_kernel<4, 2, 0, true>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec, flatten_ids,
+                           offsets, n_isects, render, alpha, exp_depth, med_depth, normal, last_ids, median_ids,
+                           (const float4*)nullptr, 4, lz);
     return check_launch();
 }
 

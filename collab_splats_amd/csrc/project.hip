@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "misplat.h"
+#include "sh_eval.h"
 
 namespace {
 
@@ -393,9 +394,8 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(
 }
 
 // ------------------------------------------------------------------ spherical harmonics
-constexpr float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
-__device__ constexpr float C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f, -1.0925484305920792f, 0.5462742152960396f};
-__device__ constexpr float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f, -0.5900435899266435f};
+
+using misplat_sh::C0; using misplat_sh::C1; using misplat_sh::C2; using misplat_sh::C3; using misplat_sh::sh_eval;
 
 template <bool GRAD>
 __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* b, float* bx, float* by, float* bz) {
@@ -433,57 +433,6 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
     }
 }
 
-// Colour (and, JAC, its 3x3 Jacobian d colour / d direction, J[ch][axis]) of one Gaussian from its staged
-// coefficient row cf[3k + ch], one basis function at a time: a term needs its basis value, its three derivatives and
-// three coefficients, nothing else stays live (12 accumulators + the shared monomials).  The array form (sh_basis into
-// b / bx / by / bz[16], then the sums) made the forward colour kernel a 245-VGPR kernel with two waves per SIMD, which
-// is what a streaming kernel waiting on HBM can least afford; the scheduling barriers keep the compiler from hoisting
-// all 48 LDS reads and 64 basis values back to the top.  Same operation order per accumulator as the array form.
-template <bool JAC>
-__device__ __forceinline__ void sh_eval(int deg, float x, float y, float z, const float* cf, float& c0, float& c1, float& c2,
-                                        float (&J)[9]) {
-#define SH_TERM(k, B, BX, BY, BZ)                                                              \
-    {                                                                                          \
-        const float f0 = cf[3 * (k)], f1 = cf[3 * (k) + 1], f2 = cf[3 * (k) + 2];              \
-        const float b_ = (B);                                                                  \
-        c0 += b_ * f0; c1 += b_ * f1; c2 += b_ * f2;                                           \
-        if (JAC) {                                                                             \
-            const float bx_ = (BX), by_ = (BY), bz_ = (BZ);                                    \
-            J[0] += bx_ * f0; J[1] += by_ * f0; J[2] += bz_ * f0;                              \
-            J[3] += bx_ * f1; J[4] += by_ * f1; J[5] += bz_ * f1;                              \
-            J[6] += bx_ * f2; J[7] += by_ * f2; J[8] += bz_ * f2;                              \
-        }                                                                                      \
-    }
-    SH_TERM(0, C0, 0.f, 0.f, 0.f)
-    if (deg > 0) {
-        SH_TERM(1, -C1 * y, 0.f, -C1, 0.f) SH_TERM(2, C1 * z, 0.f, 0.f, C1) SH_TERM(3, -C1 * x, -C1, 0.f, 0.f)
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (deg > 1) {
-        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-        SH_TERM(4, C2[0] * xy, C2[0] * y, C2[0] * x, 0.f)
-        SH_TERM(5, C2[1] * yz, 0.f, C2[1] * z, C2[1] * y)
-        SH_TERM(6, C2[2] * (2.f * zz - xx - yy), -2.f * C2[2] * x, -2.f * C2[2] * y, 4.f * C2[2] * z)
-        __builtin_amdgcn_sched_barrier(0);
-        SH_TERM(7, C2[3] * xz, C2[3] * z, 0.f, C2[3] * x)
-        SH_TERM(8, C2[4] * (xx - yy), 2.f * C2[4] * x, -2.f * C2[4] * y, 0.f)
-        __builtin_amdgcn_sched_barrier(0);
-        if (deg > 2) {
-            SH_TERM(9, C3[0] * y * (3.f * xx - yy), 6.f * C3[0] * xy, C3[0] * (3.f * xx - 3.f * yy), 0.f)
-            SH_TERM(10, C3[1] * xy * z, C3[1] * yz, C3[1] * xz, C3[1] * xy)
-            __builtin_amdgcn_sched_barrier(0);
-            SH_TERM(11, C3[2] * y * (4.f * zz - xx - yy), -2.f * C3[2] * xy, C3[2] * (4.f * zz - xx - 3.f * yy), 8.f * C3[2] * yz)
-            SH_TERM(12, C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), -6.f * C3[3] * xz, -6.f * C3[3] * yz,
-                    C3[3] * (6.f * zz - 3.f * xx - 3.f * yy))
-            __builtin_amdgcn_sched_barrier(0);
-            SH_TERM(13, C3[4] * x * (4.f * zz - xx - yy), C3[4] * (4.f * zz - 3.f * xx - yy), -2.f * C3[4] * xy, 8.f * C3[4] * xz)
-            SH_TERM(14, C3[5] * z * (xx - yy), 2.f * C3[5] * xz, -2.f * C3[5] * yz, C3[5] * (xx - yy))
-            __builtin_amdgcn_sched_barrier(0);
-            SH_TERM(15, C3[6] * x * (xx - 3.f * yy), C3[6] * (3.f * xx - 3.f * yy), -6.f * C3[6] * xy, 0.f)
-        }
-    }
-#undef SH_TERM
-}
 
 __global__ __launch_bounds__(256) void sh_fwd_kernel(int n_gauss, int n_cams, int K, int deg,
                                                      const float* __restrict__ dirs,
@@ -569,13 +518,26 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
     const float* __restrict__ scales, const float* __restrict__ opacities,
     const float* __restrict__ viewmats, const float* __restrict__ Ks, int32_t* __restrict__ radii,
     float* __restrict__ means2d, float* __restrict__ depths, float* __restrict__ comps,
-    float4* __restrict__ grec, uint32_t* __restrict__ zero_words, int n_zero) {
+    float4* __restrict__ grec, uint32_t* __restrict__ zero_words, int n_zero, float4* __restrict__ lazy_rows) {
     // scratch the NEXT kernels of the stream accumulate into (bucketing counters): cleared here, no memset launch
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0u;
     const int64_t total = (int64_t)P.n_cams * P.n_gauss;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + blockDim.x - 1 - (total + blockDim.x - 1) % blockDim.x;
          idx += (int64_t)gridDim.x * blockDim.x) {
+        if (lazy_rows) {
+            // on-demand colours (misplat_blend_fwd_lazy): the colour slots start UNSET, and the gradient rows the
+            // backward adds into are cleared here, as whole lines (the block's 256 rows are contiguous)
+            const int64_t base = idx - threadIdx.x;
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int64_t e4 = 4 * base + threadIdx.x + u * (int64_t)blockDim.x;
+                if (e4 < 4 * total) lazy_rows[e4] = z;
+            }
+            if (idx < total) grec[4 * idx + 3] = make_float4(__uint_as_float(0x7fc0deadu), 0.f, 0.f, 0.f);
+        }
+        if (idx >= total) continue;
         const int cam_i = (int)(idx / P.n_gauss);
         const int g = (int)(idx - (int64_t)cam_i * P.n_gauss);
         const Cam cam = load_cam(viewmats + 16 * cam_i, Ks + 9 * cam_i);
@@ -652,7 +614,7 @@ template <bool BWD, int BLOCK, bool MULTI, bool AUX = false, int KC = 0, int SPL
 #ifndef MISPLAT_SH_FWD_WAVES
 #define MISPLAT_SH_FWD_WAVES 1         /* waves per SIMD the K = 16 forward is compiled for (1: no constraint) */
 #endif
-__global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : 1) void color_sh_kernel(
+__global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : ((BWD && !AUX && !MULTI && KC == 16) ? 4 : 1)) void color_sh_kernel(
     misplat_params P, int K, int deg, int depth_channel, const float* __restrict__ means,
     const float* __restrict__ viewmats, const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest,
     const int32_t* __restrict__ radii, const float* __restrict__ depths, float* __restrict__ grec,
@@ -683,15 +645,27 @@ __global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : 
             if (depth_channel) pdep = depths[gp];
         }
         constexpr bool USE_VIS = KC && BWD && !AUX;
+        float pv0 = 0.f, pv1 = 0.f, pv2 = 0.f;      // (USE_VIS) camera 0: the row's colour gradient, fetched with the radii
+        if (USE_VIS && (int)threadIdx.x < cnt) {
+            const int gp = g0 + threadIdx.x;
+            pr0 = radii[2 * (int64_t)gp]; pr1 = radii[2 * (int64_t)gp + 1];
+            pm0 = means[3 * gp]; pm1 = means[3 * gp + 1]; pm2 = means[3 * gp + 2];
+            const float* vg = v_grec + (size_t)gp * MISPLAT_REC + 12;
+            pv0 = vg[0]; pv1 = vg[1]; pv2 = vg[2];
+        }
         if (USE_VIS) {
             // visible in any camera?  (rows that are not are not staged)  Only where the staged rows are consumed late
             // enough: in the forward, waiting for the radii before the first coefficient load costs more (a dependent
             // round trip per block) than the culled rows' 192 bytes save.
             bool v = false;
             if ((int)threadIdx.x < cnt)
-                for (int ci = 0; ci < P.n_cams; ci++) {
-                    const int64_t idx = (int64_t)ci * P.n_gauss + g0 + threadIdx.x;
-                    v |= radii[2 * idx] > 0 || radii[2 * idx + 1] > 0;
+                {   // ... and with a colour gradient: a row the compositing never reached needs no coefficients
+                    v = (pr0 > 0 || pr1 > 0) && (pv0 != 0.f || pv1 != 0.f || pv2 != 0.f);
+                    for (int ci = 1; ci < P.n_cams; ci++) {
+                        const int64_t idx = (int64_t)ci * P.n_gauss + g0 + threadIdx.x;
+                        const float* vg = v_grec + (size_t)idx * MISPLAT_REC + 12;
+                        v |= (radii[2 * idx] > 0 || radii[2 * idx + 1] > 0) && (vg[0] != 0.f || vg[1] != 0.f || vg[2] != 0.f);
+                    }
                 }
             s_vis[threadIdx.x] = v ? 1 : 0;
             __syncthreads();
@@ -703,20 +677,26 @@ __global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : 
             // in ONE round of loads -- three dependent rounds of four cost two more HBM round trips per block
             const float4* src4 = reinterpret_cast<const float4*>(coeffs + (size_t)g0 * row);
             constexpr int V4 = KC ? 3 * KC / 4 : 1;
-            float4 v[V4];
+            // forward: all 12 vectors of a lane in flight at once; backward (few rows are staged at all: only those with
+            // a colour gradient): 4 at a time, the kernel's registers set its occupancy for the dense stores that follow
+            constexpr int CH = BWD ? 4 : V4;
 #pragma unroll
-            for (int u = 0; u < V4; u++) {
-                const int e4 = threadIdx.x + u * BLOCK;
-                const int tt = e4 / V4;
-                if (e4 < cnt * V4 && (!USE_VIS || s_vis[tt])) v[u] = src4[e4];
-            }
+            for (int u0 = 0; u0 < V4; u0 += CH) {
+                float4 v[CH];
 #pragma unroll
-            for (int u = 0; u < V4; u++) {
-                const int e4 = threadIdx.x + u * BLOCK;
-                const int tt = e4 / V4, kk = 4 * (e4 - tt * V4);
-                if (e4 < cnt * V4 && (!USE_VIS || s_vis[tt])) {
-                    float* d = lds + tt * stride + kk;
-                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                for (int u = 0; u < CH; u++) {
+                    const int e4 = threadIdx.x + (u0 + u) * BLOCK;
+                    const int tt = e4 / V4;
+                    if (e4 < cnt * V4 && (!USE_VIS || s_vis[tt])) v[u] = src4[e4];
+                }
+#pragma unroll
+                for (int u = 0; u < CH; u++) {
+                    const int e4 = threadIdx.x + (u0 + u) * BLOCK;
+                    const int tt = e4 / V4, kk = 4 * (e4 - tt * V4);
+                    if (e4 < cnt * V4 && (!USE_VIS || s_vis[tt])) {
+                        float* d = lds + tt * stride + kk;
+                        d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                    }
                 }
             }
         } else if (KC && SPLIT != 0) {
@@ -785,8 +765,13 @@ __global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : 
             float* cf = lds + t * stride;
             for (int ci = 0; ci < P.n_cams; ci++) {
                 const int64_t idx = (int64_t)ci * P.n_gauss + g;
-                const bool first = !BWD && ci == 0;
-                const bool vis = first ? (pr0 > 0 || pr1 > 0) : (radii[2 * idx] > 0 || radii[2 * idx + 1] > 0);
+                const bool first = (!BWD || USE_VIS) && ci == 0;
+                bool vis = first ? (pr0 > 0 || pr1 > 0) : (radii[2 * idx] > 0 || radii[2 * idx + 1] > 0);
+                float vgc0 = pv0, vgc1 = pv1, vgc2 = pv2;             // (USE_VIS) this camera's colour gradient
+                if (USE_VIS) {                       // (its coefficients were staged only if some camera has a gradient for it)
+                    if (ci > 0) { const float* vg = v_grec + (size_t)idx * MISPLAT_REC + 12; vgc0 = vg[0]; vgc1 = vg[1]; vgc2 = vg[2]; }
+                    vis = vis && s_vis[t] && (vgc0 != 0.f || vgc1 != 0.f || vgc2 != 0.f);
+                }
                 float c0 = 0.f, c1 = 0.f, c2 = 0.f;
                 if (vis) {
                     const float* V = viewmats + 16 * ci;
@@ -794,20 +779,16 @@ __global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : 
                     const float ccx = -(V[0] * V[3] + V[4] * V[7] + V[8] * V[11]);
                     const float ccy = -(V[1] * V[3] + V[5] * V[7] + V[9] * V[11]);
                     const float ccz = -(V[2] * V[3] + V[6] * V[7] + V[10] * V[11]);
-                    const float mx_ = !BWD ? pm0 : means[3 * g], my_ = !BWD ? pm1 : means[3 * g + 1], mz_ = !BWD ? pm2 : means[3 * g + 2];
+                    const bool pre = !BWD || USE_VIS;
+                    const float mx_ = pre ? pm0 : means[3 * g], my_ = pre ? pm1 : means[3 * g + 1], mz_ = pre ? pm2 : means[3 * g + 2];
                     const float dx = mx_ - ccx, dy = my_ - ccy, dz = mz_ - ccz;
                     const float n = sqrtf(dx * dx + dy * dy + dz * dz);
                     const float inv = n > 0.f ? 1.0f / n : 0.f;
                     const float x = dx * inv, y = dy * inv, z = dz * inv;
                     float b[16], bx[16], by[16], bz[16];
                     float J[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};         // J[ch][axis]
-                    if (!BWD) sh_eval<AUX>(deg, x, y, z, cf, c0, c1, c2, J);
-                    else sh_basis<!AUX>(deg, x, y, z, b, bx, by, bz);
-                    if (BWD && !AUX) {
-#pragma unroll
-                        for (int k = 0; k < 16; k++)
-                            if (k < nb) { c0 += b[k] * cf[3 * k]; c1 += b[k] * cf[3 * k + 1]; c2 += b[k] * cf[3 * k + 2]; }
-                    }
+                    if (!BWD || !AUX) sh_eval<(!BWD && AUX)>(deg, x, y, z, cf, c0, c1, c2, J);
+                    else sh_basis<false>(deg, x, y, z, b, bx, by, bz);
                     if (!BWD && AUX) {
                         const float m0 = (c0 + 0.5f > 0.f) ? 1.f : 0.f, m1 = (c1 + 0.5f > 0.f) ? 1.f : 0.f;
                         const float m2 = (c2 + 0.5f > 0.f) ? 1.f : 0.f;
@@ -851,21 +832,12 @@ __global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : 
                     }
                     if (BWD && !AUX) {
                         const float* vg = v_grec + (size_t)idx * MISPLAT_REC + 12;
-                        const float vc0 = (c0 + 0.5f > 0.f) ? vg[0] : 0.f;
-                        const float vc1 = (c1 + 0.5f > 0.f) ? vg[1] : 0.f;
-                        const float vc2 = (c2 + 0.5f > 0.f) ? vg[2] : 0.f;
+                        const float vc0 = (c0 + 0.5f > 0.f) ? (USE_VIS ? vgc0 : vg[0]) : 0.f;
+                        const float vc1 = (c1 + 0.5f > 0.f) ? (USE_VIS ? vgc1 : vg[1]) : 0.f;
+                        const float vc2 = (c2 + 0.5f > 0.f) ? (USE_VIS ? vgc2 : vg[2]) : 0.f;
                         float vd0 = 0.f, vd1 = 0.f, vd2 = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 16; k++)
-                            if (k < nb) {
-                                const float s = cf[3 * k] * vc0 + cf[3 * k + 1] * vc1 + cf[3 * k + 2] * vc2;
-                                vd0 += bx[k] * s; vd1 += by[k] * s; vd2 += bz[k] * s;
-                                if (MULTI) {
-                                    acc[3 * k] += b[k] * vc0; acc[3 * k + 1] += b[k] * vc1; acc[3 * k + 2] += b[k] * vc2;
-                                } else {      // the coefficient is dead now: its slot takes the gradient
-                                    cf[3 * k] = b[k] * vc0; cf[3 * k + 1] = b[k] * vc1; cf[3 * k + 2] = b[k] * vc2;
-                                }
-                            }
+                        // (one camera: the coefficient is dead once its term is done, its slot takes the gradient)
+                        misplat_sh::sh_grad<MULTI>(deg, x, y, z, cf, vc0, vc1, vc2, vd0, vd1, vd2, acc);
                         wrote = true;
                         const float dot = x * vd0 + y * vd1 + z * vd2;
                         vmd[0] += (vd0 - x * dot) * inv; vmd[1] += (vd1 - y * dot) * inv; vmd[2] += (vd2 - z * dot) * inv;
@@ -1252,7 +1224,7 @@ extern "C" int misplat_project_pack_fwd(const misplat_params* p, const float* me
                                         const float* scales, const float* opacities, const float* viewmats,
                                         const float* Ks, int32_t* radii, float* means2d, float* depths,
                                         float* compensations, float* grec, uint32_t* zero_words, int32_t n_zero,
-                                        misplat_stream_t stream) {
+                                        float* lazy_rows, misplat_stream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1 || p->width < 1 || p->height < 1) return MISPLAT_EINVAL;
     int64_t total = (int64_t)p->n_gauss * p->n_cams;
     if (n_zero < 0 || (n_zero > 0 && !zero_words)) return MISPLAT_EINVAL;
@@ -1260,7 +1232,7 @@ extern "C" int misplat_project_pack_fwd(const misplat_params* p, const float* me
     if (total > 0 && !opacities) return MISPLAT_EINVAL;
     hipLaunchKernelGGL(project_pack_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                        means, quats, scales, opacities, viewmats, Ks, radii, means2d, depths, compensations,
-                       (float4*)grec, zero_words, n_zero);
+                       (float4*)grec, zero_words, n_zero, (float4*)lazy_rows);
     return check_launch();
 }
 
@@ -1320,19 +1292,26 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
         float* ax = const_cast<float*>(sh_aux);
         const bool k16 = K_or_D == 16 && ((uintptr_t)coeffs_or_colors & 15) == 0 && ((uintptr_t)coeffs_rest & 15) == 0 &&
                          ((uintptr_t)v_coeffs_or_colors & 15) == 0 && ((uintptr_t)v_coeffs_rest & 15) == 0;
-#define LAUNCH_SH_BWD(MULTI_, AUX_, KC_)                                                                             \
-    hipLaunchKernelGGL((color_sh_kernel<true, BLK, MULTI_, AUX_, KC_>), dim3(n_blocks < 16384 ? n_blocks : 16384),     \
+#define LAUNCH_SH_BWD(MULTI_, AUX_, KC_, SPLIT_)                                                                     \
+    hipLaunchKernelGGL((color_sh_kernel<true, BLK, MULTI_, AUX_, KC_, SPLIT_>),                                       \
+                       dim3(n_blocks < 16384 ? n_blocks : 16384),                                                     \
                        dim3(BLK), lds, s, *p, K_or_D, sh_degree, 0, means, viewmats, coeffs_or_colors, coeffs_rest,   \
                        radii, (const float*)nullptr, (float*)nullptr, v_grec, v_coeffs_or_colors, v_coeffs_rest,     \
                        v_means_dir, ax)
+#define LAUNCH_SH_BWD_K(MULTI_, AUX_)                                                    \
+    do {                                                                                 \
+        if (!k16) LAUNCH_SH_BWD(MULTI_, AUX_, 0, -1);                                    \
+        else if (coeffs_rest || v_coeffs_rest) LAUNCH_SH_BWD(MULTI_, AUX_, 16, 1);       \
+        else LAUNCH_SH_BWD(MULTI_, AUX_, 16, 0);                                         \
+    } while (0)
 #define DISPATCH_SH_BWD(MULTI_)                                                          \
     do {                                                                                 \
-        if (sh_aux) { if (k16) LAUNCH_SH_BWD(MULTI_, true, 16); else LAUNCH_SH_BWD(MULTI_, true, 0); }   \
-        else { if (k16) LAUNCH_SH_BWD(MULTI_, false, 16); else LAUNCH_SH_BWD(MULTI_, false, 0); }        \
+        if (sh_aux) LAUNCH_SH_BWD_K(MULTI_, true); else LAUNCH_SH_BWD_K(MULTI_, false);  \
     } while (0)
         if (p->n_cams > 1) DISPATCH_SH_BWD(true);
         else DISPATCH_SH_BWD(false);
 #undef DISPATCH_SH_BWD
+#undef LAUNCH_SH_BWD_K
 #undef LAUNCH_SH_BWD
     } else {
         int64_t rows = per_cam ? (int64_t)p->n_gauss * p->n_cams : p->n_gauss;

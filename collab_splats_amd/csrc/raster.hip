@@ -44,14 +44,15 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
     int rc;
     // The colour kernel belongs to phase A, but nothing before the compositing reads its output: when phase B follows in
     // the same call it is deferred to B's parallel branch.
-    const bool colour_in_b = (phases & 2) && a->colour_pending != 0;
+    const bool colour_in_b = (phases & 2) && a->colour_pending != 0 && !a->lazy_colour;
     if (phases & 1) {
         // the projection kernel also clears the cell counts and the two counters (contiguous: cell_count ... counters),
         // so phase A contains no memset at all
         const int64_t n_zero = ((const uint32_t*)a->counters + 4) - a->cell_count;
         if (!a->cell_count || !a->counters || n_zero < 4 || n_zero > (1 << 20)) return MISPLAT_EINVAL;
         rc = misplat_project_pack_fwd(p, a->means, a->quats, a->scales, a->opacities, a->viewmats, a->Ks, a->radii,
-                                      a->means2d, a->depths, a->compensations, a->grec, a->cell_count, (int32_t)n_zero, stream);
+                                      a->means2d, a->depths, a->compensations, a->grec, a->cell_count, (int32_t)n_zero,
+                                      a->lazy_colour ? a->v_grec_zero : nullptr, stream);
         if (rc != MISPLAT_OK) return rc;
         rc = misplat_bucket_count(p, a->means2d, a->radii, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count,
                                   a->counters, 1, stream);
@@ -62,7 +63,7 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         rc = misplat_bucket_rows(p, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count, a->cell_offs, a->order,
                                  a->rect_sorted, a->counters, a->tile_count, stream);
         if (rc != MISPLAT_OK) return rc;
-        if (!a->colour_pending) {
+        if (!a->colour_pending && !a->lazy_colour) {
             rc = enqueue_colour(p, a, stream);
             if (rc != MISPLAT_OK) return rc;
         }
@@ -94,8 +95,14 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         misplat_params q = *p;
         q.unit_perm = a->unit_perm_in;
         q.unit_work = a->unit_work;
-        rc = misplat_blend_fwd(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects, a->render,
-                               a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, stream);
+        if (a->lazy_colour)
+            rc = misplat_blend_fwd_lazy(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects, a->render,
+                                        a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, a->means,
+                                        a->viewmats, a->colors, a->colors_rest, a->sh_degree, a->depth_channel, a->depths,
+                                        nullptr, stream);
+        else
+            rc = misplat_blend_fwd(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects, a->render,
+                                   a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, stream);
         if (rc != MISPLAT_OK) return rc;
         if (a->unit_work && a->unit_perm_out) {
             rc = misplat_unit_order(p, p->ppl_fwd, a->unit_work, a->unit_perm_out, stream);

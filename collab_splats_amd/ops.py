@@ -669,8 +669,27 @@ def _cap_key(P: Params, dev: torch.device):
     return (dev.index, P.n_gauss, P.n_cams, P.width, P.height)
 
 
+# On-demand SH colours (csrc/blend.hip, LazyColour): no colour kernel -- the compositing forward evaluates the colour of
+# a record when it first stages it.  Pays when most visible Gaussians are never composited (dense scenes: 1 M random
+# Gaussians at 1080p stage a third of the visible ones); "auto" switches it on from the typical bucket length.
+LAZY_SH = os.environ.get("MISPLAT_LAZY_SH", "auto")
+LAZY_SH_MIN_BUCKET = int(os.environ.get("MISPLAT_LAZY_SH_MIN_BUCKET", "400"))
+
+
+def _lazy_colour_ok(P: Params, dev, deg: int, kd: int, n_color: int, want_grad: bool, cd: int) -> bool:
+    if LAZY_SH == "0" or deg < 0 or kd != 16 or n_color != 3 or not want_grad or cd not in (3, 4):
+        return False
+    if _eff_ppl(P.ppl_fwd) != 2 or _eff_ppl(P.ppl_bwd) != 2:
+        return False
+    if LAZY_SH == "1":
+        return True
+    hint = _CAP_HINT.get(_cap_key(P, dev))
+    return hint is not None and hint >= LAZY_SH_MIN_BUCKET * P.tile_w * P.tile_h * P.n_cams
+
+
 def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg: int, kd: int,
-                    n_color: int, per_cam: int, depth_channel: bool, want_aux: bool, want_grad: bool, defer: bool = False):
+                    n_color: int, per_cam: int, depth_channel: bool, want_aux: bool, want_grad: bool, defer: bool = False,
+                    lazy: bool = False):
     """Allocations + phase A of misplat_raster_fwd (``defer``: phase A is launched together with B, by _raster_phase_b).
     Returns (radii, means2d, depths, comps, grec, sh_aux, state)."""
     lib = _lib.load()
@@ -700,6 +719,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     # the colour kernel moves into phase B's parallel graph branch -- worth it only for large scenes (a two-branch
     # graph costs ~40 us more host time per launch; gains ~10 us of GPU time at 1 M Gaussians)
     a.colour_pending = int(COLOUR_BRANCH and rows >= COLOUR_BRANCH_MIN_ROWS)
+    a.lazy_colour = int(lazy)
     if not defer:
         check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
               "misplat_raster_fwd(A)")
@@ -817,11 +837,12 @@ class _RasterFused(torch.autograd.Function):
             deg, kd, per_cam = -1, colors.shape[-1], int(colors.dim() == 3)
             n_color = kd
         want_grad = any(ctx.needs_input_grad[:6])
-        want_aux = SH_AUX and deg >= 0 and want_grad
+        lazy = _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd)
+        want_aux = SH_AUX and deg >= 0 and want_grad and not lazy
         defer = _STATIC_CAP is not None or (MERGE_PHASES and SPECULATE and _cap_key(P, means.device) in _CAP_HINT)
         radii, means2d, depths, comps, grec, sh_aux, state = _raster_phase_a(
             P, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam, depth_channel,
-            want_aux, want_grad, defer=defer)
+            want_aux, want_grad, defer=defer, lazy=lazy)
         imgs, bins, sched = _raster_phase_b(P, state, cd)
         render, alpha, exp_depth, med_depth, normal, last_ids, median_ids = imgs
         extra["bins"] = bins
@@ -999,7 +1020,7 @@ class _ProjectPack(torch.autograd.Function):
         grec = torch.empty(Cn * N, MISPLAT_REC, device=dev, dtype=torch.float32)
         check(lib.misplat_project_pack_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
                                            ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
-                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), stream_ptr()),
+                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), ptr(None), stream_ptr()),
               "misplat_project_pack_fwd")
         if prebin is not None:                         # count tiles + start the n_isects read-back before the colours
             prebin["pending"] = start_binning(P, means2d, radii)
@@ -1222,7 +1243,7 @@ class _ProjectPackX(torch.autograd.Function):
         featx = torch.empty(Cn * N, 4 * nxq, device=dev, dtype=torch.float32)
         check(lib.misplat_project_pack_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
                                            ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
-                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), stream_ptr()),
+                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), ptr(None), stream_ptr()),
               "misplat_project_pack_fwd")
         D, per_cam = colors.shape[-1], int(colors.dim() == 3)
         check(lib.misplat_color_fwd_x(C.byref(P), C.c_int32(D), C.c_int32(per_cam), C.c_int32(int(depth_channel)),

@@ -124,6 +124,8 @@ int misplat_project_pack_fwd(const misplat_params* p, const float* means, const 
                              float* compensations, float* grec,
                              uint32_t* zero_words /* or NULL */, int32_t n_zero /* words the kernel clears for its
                              successors on the stream (the bucketing counters): saves a memset launch */,
+                             float* lazy_rows /* or NULL.  Given (v_grec-shaped, [C*N,16]): on-demand colours -- the colour
+                             slots of grec are left UNSET for misplat_blend_fwd_lazy, and these gradient rows are cleared */,
                              misplat_stream_t stream);
 /* coeffs_rest (SH only, may be NULL): when given, coeffs_or_colors is features_dc[N,3] and
  * coeffs_rest is features_rest[N,K-1,3] -- the reference's two parameter tensors
@@ -277,6 +279,17 @@ int misplat_blend_fwd(const misplat_params* p, int32_t color_dim, const float* K
                       int64_t n_isects, float* render, float* alpha, float* exp_depth,
                       float* med_depth, float* normal, int32_t* last_ids, int32_t* median_ids,
                       misplat_stream_t stream);
+/* The same forward with ON-DEMAND SH colours: the colour slots of grec hold the "unset" pattern left by
+ * misplat_project_pack_fwd(lazy_rows != NULL) and are filled here (grec is read AND written) for the records that are
+ * staged past their cull -- in a dense scene most visible Gaussians never are.  16 coefficients per Gaussian: coeffs
+ * [N,16,3], or features_dc [N,3] + coeffs_rest [N,15,3].  pixels-per-lane 2 only. */
+int misplat_blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const float* Ks, float* grec,
+                           const int32_t* flatten_ids, const int32_t* offsets, int64_t n_isects, float* render,
+                           float* alpha, float* exp_depth, float* med_depth, float* normal, int32_t* last_ids,
+                           int32_t* median_ids, const float* means, const float* viewmats, const float* coeffs,
+                           const float* coeffs_rest, int32_t sh_degree, int32_t depth_channel, const float* depths,
+                           float* sh_aux /* NULL */, misplat_stream_t stream);
+
 
 /* Launch order for the compositing kernels (speed only): unit_perm[8 * ceil(units / 8)] from the per-unit cost
  * unit_work[units] the forward measured (misplat_params.unit_work), longest first inside every XCD strip;
@@ -398,7 +411,9 @@ typedef struct misplat_raster_args {
     int32_t colour_pending; /* != 0: the colour kernel is left out of phase A and runs at the start of phase B instead
                                (nothing before the compositing reads it) -- beside the bucketing kernels when the call
                                goes through a graph cache (two parallel branches) */
-    int32_t reserved2;
+    int32_t lazy_colour;    /* != 0 (SH colours with K = 16, one pass, ppl 2/2 only): no colour kernel -- the compositing
+                               forward evaluates the colour of a record when it first stages it (misplat_blend_fwd_lazy);
+                               sh_aux is not written */
     /* per (camera, Gaussian) outputs */
     int32_t* radii;
     float *means2d, *depths, *compensations, *grec, *sh_aux /* or NULL */;

@@ -1249,6 +1249,23 @@ def test_whole_step_graph_replays_equal_eager_steps(dev):
             assert rel_err(a, ref[k].grad) < 1e-5, (rep, k)
 
 
+@pytest.mark.parametrize("N,W,H,scale_mul", [(30_000, 640, 360, 1.0), (5_000, 333, 197, 1.0), (60_000, 320, 200, 2.0)])
+def test_on_demand_colours_equal_the_colour_kernel(dev, N, W, H, scale_mul):
+    """MISPLAT_LAZY_SH: the compositing forward evaluates a record's SH colour when it first stages it (and the backward
+    recomputes the Jacobian for the rows that have a gradient) instead of a colour kernel over all visible rows: the
+    same images bit for bit (which of the two runs is a speed decision), the same bins, gradients equal up to rounding."""
+    args = _bench_like_scene(dev, N, W, H, seed=21, scale_mul=scale_mul)
+    ref_img, ref_grad, ref_meta = _fwd_bwd(args, LAZY_SH="0")
+    for rep in range(2):
+        img, grad, meta = _fwd_bwd(args, LAZY_SH="1")
+        assert torch.equal(meta["flatten_ids"], ref_meta["flatten_ids"])
+        for k, (a, b) in enumerate(zip(img, ref_img)):
+            assert torch.equal(a, b), k                        # same colour bits from either evaluation: same images
+        for k, (a, b) in enumerate(zip(grad, ref_grad)):
+            assert torch.isfinite(a).all()
+            assert rel_err(a, b) < 2e-5, (k, rel_err(a, b))
+
+
 def test_unit_order_is_a_permutation_sorted_by_measured_work(dev):
     """misplat_unit_order: every unit exactly once, heaviest first inside each XCD strip, padding = units."""
     from collab_splats_amd import _lib
