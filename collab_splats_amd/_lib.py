@@ -36,7 +36,7 @@ class Params(C.Structure):
                 ("alpha_max", C.c_float), ("alpha_min", C.c_float), ("t_stop", C.c_float),
                 ("median_t", C.c_float), ("jacobian_margin", C.c_float), ("plane_eps", C.c_float),
                 ("ppl_fwd", C.c_int32), ("ppl_bwd", C.c_int32), ("ed_slot", C.c_int32), ("sub_blocks", C.c_int32),
-                ("unit_perm", C.c_void_p), ("unit_work", C.c_void_p)]
+                ("unit_perm", C.c_void_p), ("unit_work", C.c_void_p), ("touched", C.c_void_p)]
 
 
 class RasterArgs(C.Structure):
@@ -80,7 +80,7 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
                   int(opacity_aware_radius), eps2d, near_plane, far_plane, radius_clip, radius_sigma,
                   alpha_max, alpha_min, t_stop, median_t, jacobian_margin, plane_eps,
                   int(os.environ.get("MISPLAT_PPL_FWD", ppl_fwd)), int(os.environ.get("MISPLAT_PPL_BWD", ppl_bwd)), int(ed_slot),
-                  int(os.environ.get("MISPLAT_SUB_BLOCKS", 0)), None, None)
+                  int(os.environ.get("MISPLAT_SUB_BLOCKS", 0)), None, None, None)
 
 
 # name -> (restype, n_args); every symbol include/misplat.h declares

@@ -789,6 +789,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                 if (ATOMIC) {
                     // one 64-byte contiguous no-return fp32 atomic per (band, Gaussian)
                     if (writer) atomicAdd(&slab_b[slot * MISPLAT_REC + comp], r * out_scale);
+                    if (P.touched && lane == 1) P.touched[slot] = 1;
                     if (NXQ > 0) {
                         const float rx = wave_reduce16(accx, lane);
                         if (writer && comp < NX) atomicAdd(&v_featx[slot * NX + comp], rx);
@@ -1104,6 +1105,7 @@ __global__ __launch_bounds__(64, MISPLAT_BWDQ_WAVES) void blend_bwd_quad_kernel(
             gacc[k] = 0.f;
             const size_t row = (size_t)sm_row[k >> 4];
             if (val != 0.f) atomicAdd(&v_grec[row * MISPLAT_REC + fl_comp], val * fl_scale);
+            if (P.touched && val != 0.f) P.touched[row] = 1;
         }
         if (ABS) {
             for (int k = lane; k < n * 2; k += 64) {

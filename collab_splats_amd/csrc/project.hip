@@ -538,6 +538,7 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
             if (idx < total) grec[4 * idx + 3] = make_float4(__uint_as_float(0x7fc0deadu), 0.f, 0.f, 0.f);
         }
         if (idx >= total) continue;
+        if (P.touched) P.touched[idx] = 0;
         const int cam_i = (int)(idx / P.n_gauss);
         const int g = (int)(idx - (int64_t)cam_i * P.n_gauss);
         const Cam cam = load_cam(viewmats + 16 * cam_i, Ks + 9 * cam_i);
@@ -1076,6 +1077,152 @@ __global__ __launch_bounds__(256) void project_pack_bwd_kernel(
     }
 }
 
+// SH backward for scenes where few rows have a colour gradient (one camera, 16 coefficients, no Jacobian cache -- the
+// companion of the on-demand forward).  The LDS-staged kernel above exists to turn per-lane gradient rows into whole
+// coalesced lines; when nine rows in ten are zeros that is the wrong shape.  Two launches instead: zero_fill_kernel
+// streams zeros over the whole gradient tensor at full occupancy (7 TB/s), then this kernel scans the rows -- a row whose
+// `touched` flag was never set costs one byte --, queues the live ones per wave (as project_pack_bwd_sparse_kernel
+// does) and, in batches of 64, fetches their 16 x 3 coefficients, walks the terms once for the clamp and once for the
+// gradients, and stores the rows over the zeros.  (One kernel doing
+// both was latency-bound at three waves per SIMD: 60 us, 74 with the flag's extra round trip; LDS-staged: 69.)
+__global__ __launch_bounds__(256) void zero_fill_kernel(float4* __restrict__ dst, int64_t n4, float* __restrict__ tail, int n_tail) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) dst[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail[threadIdx.x] = 0.f;
+}
+
+// zero_blocks > 0 ([N,16,3] layout with `touched` flags only): the first zero_blocks workgroups clear the rows whose flag
+// is NOT set (and all of v_means_dir's dead rows) while the others compute the flagged rows -- the two halves touch
+// disjoint rows, so they need no order and run side by side instead of one behind the other.
+template <bool SPLIT>
+__global__ __launch_bounds__(64) void color_sh_bwd_sparse_kernel(
+    misplat_params P, int deg, const float* __restrict__ means, const float* __restrict__ viewmats,
+    const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest, const int32_t* __restrict__ radii,
+    const float* __restrict__ v_grec, float* __restrict__ v_coeffs, float* __restrict__ v_coeffs_rest,
+    float* __restrict__ v_means_dir, int zero_blocks) {
+    __shared__ int queue[128];
+    const int lane = threadIdx.x;
+    // (the live workgroups come first in the grid: they are few and long, the zero workgroups fill the machine around them)
+    const int n_live_blocks = (int)gridDim.x - zero_blocks;
+    if (!SPLIT && (int)blockIdx.x >= n_live_blocks) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* d4 = reinterpret_cast<float4*>(v_coeffs);
+        const int64_t n4 = (int64_t)P.n_gauss * 12;
+        for (int64_t e4 = (int64_t)((int)blockIdx.x - n_live_blocks) * 64 + lane; e4 < n4; e4 += (int64_t)zero_blocks * 64) {
+            const int64_t row = e4 / 12;
+            if (P.touched[row] == 0) {
+                d4[e4] = z;
+                if (e4 - row * 12 < 3) v_means_dir[3 * row + (int)(e4 - row * 12)] = 0.f;
+            }
+        }
+        return;
+    }
+    const int live_block = (int)blockIdx.x;
+    const int live_grid = n_live_blocks;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const float* V = viewmats;
+    const float ccx = -(V[0] * V[3] + V[4] * V[7] + V[8] * V[11]);
+    const float ccy = -(V[1] * V[3] + V[5] * V[7] + V[9] * V[11]);
+    const float ccz = -(V[2] * V[3] + V[6] * V[7] + V[10] * V[11]);
+    // the gradient of one row (its colour gradient is non-zero): coefficients in, gradient row out, in place
+    auto heavy = [&](int g) {
+        const float* vg = v_grec + (size_t)g * MISPLAT_REC + 12;
+        const float vg0 = vg[0], vg1 = vg[1], vg2 = vg[2];
+        const float dx = means[3 * g] - ccx, dy = means[3 * g + 1] - ccy, dz = means[3 * g + 2] - ccz;
+        const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float inv = n > 0.f ? 1.0f / n : 0.f;
+        const float x = dx * inv, y = dy * inv, z = dz * inv;
+        float cf[48];
+        if (!SPLIT) {
+            const float4* s4 = reinterpret_cast<const float4*>(coeffs + (size_t)g * 48);
+#pragma unroll
+            for (int u = 0; u < 12; u++) { const float4 v = s4[u]; cf[4 * u] = v.x; cf[4 * u + 1] = v.y; cf[4 * u + 2] = v.z; cf[4 * u + 3] = v.w; }
+        } else {
+            cf[0] = coeffs[3 * (size_t)g]; cf[1] = coeffs[3 * (size_t)g + 1]; cf[2] = coeffs[3 * (size_t)g + 2];
+            const float* sr = coeffs_rest + (size_t)g * 45;
+#pragma unroll
+            for (int u = 0; u < 45; u++) cf[3 + u] = sr[u];
+        }
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        float J[9];
+        sh_eval<false>(deg, x, y, z, cf, c0, c1, c2, J);
+        const float vc0 = (c0 + 0.5f > 0.f) ? vg0 : 0.f, vc1 = (c1 + 0.5f > 0.f) ? vg1 : 0.f, vc2 = (c2 + 0.5f > 0.f) ? vg2 : 0.f;
+        float vd0 = 0.f, vd1 = 0.f, vd2 = 0.f;
+        misplat_sh::sh_grad<false>(deg, x, y, z, cf, vc0, vc1, vc2, vd0, vd1, vd2, nullptr);
+        const int nb = (deg + 1) * (deg + 1);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k >= nb) { cf[3 * k] = 0.f; cf[3 * k + 1] = 0.f; cf[3 * k + 2] = 0.f; }       // above the active degree
+        if (!SPLIT) {
+            float4* o4 = reinterpret_cast<float4*>(v_coeffs + (size_t)g * 48);
+#pragma unroll
+            for (int u = 0; u < 12; u++) o4[u] = make_float4(cf[4 * u], cf[4 * u + 1], cf[4 * u + 2], cf[4 * u + 3]);
+        } else {
+            v_coeffs[3 * (size_t)g] = cf[0]; v_coeffs[3 * (size_t)g + 1] = cf[1]; v_coeffs[3 * (size_t)g + 2] = cf[2];
+            float* orr = v_coeffs_rest + (size_t)g * 45;
+#pragma unroll
+            for (int u = 0; u < 45; u++) orr[u] = cf[3 + u];
+        }
+        const float dot = x * vd0 + y * vd1 + z * vd2;
+        v_means_dir[3 * g] = (vd0 - x * dot) * inv; v_means_dir[3 * g + 1] = (vd1 - y * dot) * inv;
+        v_means_dir[3 * g + 2] = (vd2 - z * dot) * inv;
+    };
+    int qn = 0;
+    auto push = [&](bool live, int g) {
+        const unsigned long long mask = __ballot(live);
+        if (live) queue[qn + __popcll(mask & lt)] = g;
+        qn += __popcll(mask);
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64) {
+            const int gq = queue[lane];
+            const int keep = lane + 64 < qn ? queue[lane + 64] : 0;
+            __builtin_amdgcn_wave_barrier();
+            queue[lane] = keep;
+            qn -= 64;
+            heavy(gq);
+        }
+    };
+    // (v_means_dir was cleared with the gradient tensor: the dead rows are done)
+    if (P.touched && (((uintptr_t)P.touched) & 15) == 0) {
+        // flags 16 at a time per lane: one load covers 1 024 rows of the wave, the 16 ballots run from registers (a
+        // dependent one-byte load per 64 rows made the scan, not the gradients, the cost of this kernel)
+        for (int64_t base = (int64_t)live_block * 1024; base < P.n_gauss; base += (int64_t)live_grid * 1024) {
+            const int64_t r0 = base + 16 * lane;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (r0 + 16 <= P.n_gauss) {
+                const uint4 v = *reinterpret_cast<const uint4*>(P.touched + r0);
+                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+            } else {
+                for (int b = 0; b < 16; b++)
+                    if (r0 + b < P.n_gauss) w[b >> 2] |= (uint32_t)P.touched[r0 + b] << (8 * (b & 3));
+            }
+            if (__ballot((w[0] | w[1] | w[2] | w[3]) != 0u) == 0ull) continue;
+            unsigned long long lo = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+            unsigned long long hi = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
+#pragma unroll 1
+            for (int b = 0; b < 16; b++) {                   // (rolled: `push` holds the whole gradient evaluation)
+                push((lo & 0xffull) != 0ull, (int)(r0 + b));
+                lo = (lo >> 8) | (hi << 56);
+                hi >>= 8;
+            }
+        }
+    } else {
+        for (int base = live_block * 64; base < P.n_gauss; base += live_grid * 64) {
+            const int g = base + lane;
+            bool live = false;
+            if (g < P.n_gauss) {
+                if (P.touched) live = P.touched[g] != 0;
+                else {
+                    const float* vg = v_grec + (size_t)g * MISPLAT_REC + 12;
+                    live = (radii[2 * (int64_t)g] > 0 || radii[2 * (int64_t)g + 1] > 0) && (vg[0] != 0.f || vg[1] != 0.f || vg[2] != 0.f);
+                }
+            }
+            push(live, g);
+        }
+    }
+    if (lane < qn) heavy(queue[lane]);
+}
+
 // One camera: most rows of a dense scene never receive a gradient -- the compositing stops at the first opaque layers,
 // and the packed gradient row of a Gaussian behind them is still the zeros the forward left (1 M random Gaussians at
 // 1080p: 11 % of the visible rows get one, at 5 M 2 %; scripts/touched_fraction.py).  A zero row in gives a zero row out,
@@ -1125,7 +1272,8 @@ __global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
         const int g = base + lane;
         bool live = false;
         if (g < P.n_gauss) {
-            if (radii[2 * g] > 0 || radii[2 * g + 1] > 0) {
+            if (P.touched && !v_means2d) live = P.touched[g] != 0;         // (set by the compositing backward: no row fetch)
+            else if (radii[2 * g] > 0 || radii[2 * g + 1] > 0) {
                 const float4* vg = reinterpret_cast<const float4*>(v_grec + (size_t)g * MISPLAT_REC);
                 const float4 g0 = vg[0], g1 = vg[1], g2 = vg[2], g3 = vg[3];
                 live = g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f || g1.x != 0.f || g1.y != 0.f || g1.z != 0.f ||
@@ -1292,6 +1440,31 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
         float* ax = const_cast<float*>(sh_aux);
         const bool k16 = K_or_D == 16 && ((uintptr_t)coeffs_or_colors & 15) == 0 && ((uintptr_t)coeffs_rest & 15) == 0 &&
                          ((uintptr_t)v_coeffs_or_colors & 15) == 0 && ((uintptr_t)v_coeffs_rest & 15) == 0;
+        if (k16 && !sh_aux && p->n_cams == 1 && (coeffs_rest != nullptr) == (v_coeffs_rest != nullptr)) {
+            // no Jacobian cache: the on-demand forward ran, i.e. a scene where few rows have a gradient
+            const int grid = n_blocks < 2048 ? n_blocks : 2048;          // one wave each: every wave scans enough rows to fill batches
+            auto zero = [&](float* ptr_, int64_t n_floats) {            // (16-byte aligned by the k16 test above)
+                const int64_t n4 = n_floats / 4;
+                hipLaunchKernelGGL(zero_fill_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, s, (float4*)ptr_, n4, ptr_ + 4 * n4,
+                                   (int)(n_floats - 4 * n4));
+            };
+            if (((uintptr_t)v_means_dir & 15) != 0) return MISPLAT_EINVAL;
+            const bool side_by_side = !coeffs_rest && p->touched && (((uintptr_t)p->touched) & 15) == 0;
+            if (coeffs_rest) { zero(v_coeffs_or_colors, (int64_t)p->n_gauss * 3); zero(v_coeffs_rest, (int64_t)p->n_gauss * 45); }
+            else if (!side_by_side) zero(v_coeffs_or_colors, (int64_t)p->n_gauss * 48);
+            if (!side_by_side) zero(v_means_dir, (int64_t)p->n_gauss * 3);
+            if (coeffs_rest)
+                hipLaunchKernelGGL(color_sh_bwd_sparse_kernel<true>, dim3(grid), dim3(64), 0, s, *p, sh_degree, means, viewmats,
+                                   coeffs_or_colors, coeffs_rest, radii, v_grec, v_coeffs_or_colors, v_coeffs_rest, v_means_dir, 0);
+            else {
+                const int zb = side_by_side ? 8192 : 0;
+                const int lb = (int)(((int64_t)p->n_gauss + 1023) / 1024) < 2048 ? (int)(((int64_t)p->n_gauss + 1023) / 1024) : 2048;
+                hipLaunchKernelGGL(color_sh_bwd_sparse_kernel<false>, dim3(side_by_side ? zb + lb : grid), dim3(64), 0, s, *p,
+                                   sh_degree, means, viewmats, coeffs_or_colors, coeffs_rest, radii, v_grec, v_coeffs_or_colors,
+                                   v_coeffs_rest, v_means_dir, zb);
+            }
+            return check_launch();
+        }
 #define LAUNCH_SH_BWD(MULTI_, AUX_, KC_, SPLIT_)                                                                     \
     hipLaunchKernelGGL((color_sh_kernel<true, BLK, MULTI_, AUX_, KC_, SPLIT_>),                                       \
                        dim3(n_blocks < 16384 ? n_blocks : 16384),                                                     \

@@ -701,8 +701,12 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     means2d, depths, comps, grec, sh_aux = _carve_f(dev, (2 * rows, rows, rows, MISPLAT_REC * rows, 12 * rows if want_aux else 0))
     v_grec_zero = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32) if want_grad else None
     # (counters directly behind cell_count: the projection kernel clears that contiguous range, no memset launch)
-    radii, tiles_per_gauss, rect2, cellhist, cell_count, counters, cell_offs, order, rect_sorted, tile_count = _carve(
-        dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, 4, n_cells + 1, rows, 2 * rows, n_tiles + 1))
+    radii, tiles_per_gauss, rect2, cellhist, cell_count, counters, cell_offs, order, rect_sorted, tile_count, touched = _carve(
+        dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, 4, n_cells + 1, rows, 2 * rows, n_tiles + 1,
+              (rows + 3) // 4 if want_grad else 0))
+    # one byte per row: cleared by the projection kernel, set by the compositing backward, read by the per-Gaussian
+    # backward kernels (misplat_params.touched)
+    P.touched = touched.data_ptr() if want_grad else None
     host = _readback_slot(dev)
     host[0] = -1                                                      # overwritten by the asynchronous copy of phase A
     a = RasterArgs()
@@ -724,7 +728,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
         check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
               "misplat_raster_fwd(A)")
     state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero, deferred=defer,
-                 counters=counters,
+                 counters=counters, touched=touched,
                  keep=(rect2, cellhist, cell_count, cell_offs, order, counters, tile_count, radii))
     return (radii.view(Cn, N, 2), means2d.view(Cn, N, 2), depths.view(Cn, N), comps.view(Cn, N), grec.view(rows, MISPLAT_REC),
             sh_aux.view(rows, 12) if want_aux else None, state)

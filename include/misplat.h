@@ -74,6 +74,11 @@ typedef struct misplat_params {
      * processes unit unit_perm[b] instead of the default XCD-strip map (misplat_unit_order builds it, longest first). */
     const int32_t* unit_perm;
     int32_t* unit_work;
+    /* (or NULL) one byte per (camera, Gaussian) row, a speed hint that never changes a result: cleared by
+     * misplat_project_pack_fwd, set by the ATOMIC compositing backward for every row it adds a gradient to, read by the
+     * per-Gaussian backward kernels -- a row that was never set has an all-zero gradient row, which then is not fetched
+     * (in a dense scene nine rows in ten; their 64-byte rows were the largest read of both kernels). */
+    uint8_t* touched;
 } misplat_params;
 
 /* ---- a2.1 projection: fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, ...)
