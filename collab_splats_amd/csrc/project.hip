@@ -1094,6 +1094,8 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float4* __restrict__ dst
 // zero_blocks > 0 ([N,16,3] layout with `touched` flags only): the first zero_blocks workgroups clear the rows whose flag
 // is NOT set (and all of v_means_dir's dead rows) while the others compute the flagged rows -- the two halves touch
 // disjoint rows, so they need no order and run side by side instead of one behind the other.
+constexpr int kFlagStep = 512;          // rows a wave of the sparse backward kernels scans per step (8 flag bytes per lane)
+
 template <bool SPLIT>
 __global__ __launch_bounds__(64) void color_sh_bwd_sparse_kernel(
     misplat_params P, int deg, const float* __restrict__ means, const float* __restrict__ viewmats,
@@ -1184,26 +1186,21 @@ __global__ __launch_bounds__(64) void color_sh_bwd_sparse_kernel(
     };
     // (v_means_dir was cleared with the gradient tensor: the dead rows are done)
     if (P.touched && (((uintptr_t)P.touched) & 15) == 0) {
-        // flags 16 at a time per lane: one load covers 1 024 rows of the wave, the 16 ballots run from registers (a
-        // dependent one-byte load per 64 rows made the scan, not the gradients, the cost of this kernel)
-        for (int64_t base = (int64_t)live_block * 1024; base < P.n_gauss; base += (int64_t)live_grid * 1024) {
-            const int64_t r0 = base + 16 * lane;
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-            if (r0 + 16 <= P.n_gauss) {
-                const uint4 v = *reinterpret_cast<const uint4*>(P.touched + r0);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else {
-                for (int b = 0; b < 16; b++)
-                    if (r0 + b < P.n_gauss) w[b >> 2] |= (uint32_t)P.touched[r0 + b] << (8 * (b & 3));
-            }
-            if (__ballot((w[0] | w[1] | w[2] | w[3]) != 0u) == 0ull) continue;
-            unsigned long long lo = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
-            unsigned long long hi = (unsigned long long)w[2] | ((unsigned long long)w[3] << 32);
+        // flags 8 at a time per lane: one load covers kFlagStep = 512 rows of the wave, the ballots run from registers (a
+        // dependent one-byte load per 64 rows made the scan, not the gradients, the cost of this kernel; 1 024 rows per
+        // step left too few waves: a wave's two batches ran one behind the other at one wave per SIMD)
+        for (int64_t base = (int64_t)live_block * kFlagStep; base < P.n_gauss; base += (int64_t)live_grid * kFlagStep) {
+            const int64_t r0 = base + 8 * lane;
+            unsigned long long fl = 0ull;
+            if (r0 + 8 <= P.n_gauss) fl = *reinterpret_cast<const unsigned long long*>(P.touched + r0);
+            else
+                for (int b = 0; b < 8; b++)
+                    if (r0 + b < P.n_gauss) fl |= (unsigned long long)P.touched[r0 + b] << (8 * b);
+            if (__ballot(fl != 0ull) == 0ull) continue;
 #pragma unroll 1
-            for (int b = 0; b < 16; b++) {                   // (rolled: `push` holds the whole gradient evaluation)
-                push((lo & 0xffull) != 0ull, (int)(r0 + b));
-                lo = (lo >> 8) | (hi << 56);
-                hi >>= 8;
+            for (int b = 0; b < 8; b++) {                    // (rolled: `push` holds the whole gradient evaluation)
+                push((fl & 0xffull) != 0ull, (int)(r0 + b));
+                fl >>= 8;
             }
         }
     } else {
@@ -1235,11 +1232,25 @@ __global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
     const float* __restrict__ viewmats, const float* __restrict__ Ks, const int32_t* __restrict__ radii,
     const float* __restrict__ comps, const float* __restrict__ v_means2d, const float* __restrict__ v_grec,
     const float* __restrict__ v_means_dir, float* __restrict__ v_means, float* __restrict__ v_quats,
-    float* __restrict__ v_scales, float* __restrict__ v_opacities) {
+    float* __restrict__ v_scales, float* __restrict__ v_opacities, int zero_blocks) {
     __shared__ int queue[128];
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int qn = 0;
+    // zero_blocks > 0 (`touched` flags given, no separate mean2d gradient): the LAST zero_blocks workgroups clear the
+    // outputs of the rows whose flag is not set while the first ones compute the flagged rows (disjoint rows, no order
+    // needed: side by side instead of one scan doing both).  A dead row's SH direction gradient is zero as well.
+    const int n_live_blocks = (int)gridDim.x - zero_blocks;
+    if ((int)blockIdx.x >= n_live_blocks) {
+        for (int64_t g = (int64_t)((int)blockIdx.x - n_live_blocks) * 64 + lane; g < P.n_gauss; g += (int64_t)zero_blocks * 64) {
+            if (P.touched[g] != 0) continue;
+            v_means[3 * g] = 0.f; v_means[3 * g + 1] = 0.f; v_means[3 * g + 2] = 0.f;
+            v_scales[3 * g] = 0.f; v_scales[3 * g + 1] = 0.f; v_scales[3 * g + 2] = 0.f;
+            *reinterpret_cast<float4*>(v_quats + 4 * (size_t)g) = make_float4(0.f, 0.f, 0.f, 0.f);
+            v_opacities[g] = 0.f;
+        }
+        return;
+    }
     const Cam cam = load_cam(viewmats, Ks);
     auto heavy = [&](int g) {
         float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
@@ -1268,6 +1279,37 @@ __global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
         for (int k = 0; k < 4; k++) v_quats[4 * g + k] = o_q[k];
         v_opacities[g] = o_op;
     };
+    if (zero_blocks > 0) {
+        // flags 8 at a time per lane (one load covers kFlagStep rows of the wave), the ballots run from registers
+        for (int64_t base = (int64_t)blockIdx.x * kFlagStep; base < P.n_gauss; base += (int64_t)n_live_blocks * kFlagStep) {
+            const int64_t r0 = base + 8 * lane;
+            unsigned long long lo = 0ull;
+            if (r0 + 8 <= P.n_gauss) lo = *reinterpret_cast<const unsigned long long*>(P.touched + r0);
+            else
+                for (int b = 0; b < 8; b++)
+                    if (r0 + b < P.n_gauss) lo |= (unsigned long long)P.touched[r0 + b] << (8 * b);
+            if (__ballot(lo != 0ull) == 0ull) continue;
+#pragma unroll 1
+            for (int b = 0; b < 8; b++) {
+                const bool live = (lo & 0xffull) != 0ull;
+                const unsigned long long mask = __ballot(live);
+                if (live) queue[qn + __popcll(mask & lt)] = (int)(r0 + b);
+                qn += __popcll(mask);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= 64) {
+                    const int gq = queue[lane];
+                    const int keep = lane + 64 < qn ? queue[lane + 64] : 0;
+                    __builtin_amdgcn_wave_barrier();
+                    queue[lane] = keep;
+                    qn -= 64;
+                    heavy(gq);
+                }
+                lo >>= 8;
+            }
+        }
+        if (lane < qn) heavy(queue[lane]);
+        return;
+    }
     for (int base = blockIdx.x * 64; base < P.n_gauss; base += gridDim.x * 64) {
         const int g = base + lane;
         bool live = false;
@@ -1458,7 +1500,7 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
                                    coeffs_or_colors, coeffs_rest, radii, v_grec, v_coeffs_or_colors, v_coeffs_rest, v_means_dir, 0);
             else {
                 const int zb = side_by_side ? 8192 : 0;
-                const int lb = (int)(((int64_t)p->n_gauss + 1023) / 1024) < 2048 ? (int)(((int64_t)p->n_gauss + 1023) / 1024) : 2048;
+                const int lb = (int)(((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep) < 2048 ? (int)(((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep) : 2048;
                 hipLaunchKernelGGL(color_sh_bwd_sparse_kernel<false>, dim3(side_by_side ? zb + lb : grid), dim3(64), 0, s, *p,
                                    sh_degree, means, viewmats, coeffs_or_colors, coeffs_rest, radii, v_grec, v_coeffs_or_colors,
                                    v_coeffs_rest, v_means_dir, zb);
@@ -1508,9 +1550,15 @@ extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_s
         // fill batches of live ones
         int64_t waves = ((int64_t)p->n_gauss + 63) / 64;
         if (waves > 2048) waves = 2048;
-        hipLaunchKernelGGL(project_pack_bwd_sparse_kernel, dim3((unsigned)waves), dim3(64), 0, (hipStream_t)stream,
-                           *p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii, compensations, v_means2d,
-                           v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities);
+        int zero_blocks = 0;
+        if (p->touched && !v_means2d && (((uintptr_t)p->touched) & 15) == 0) {
+            waves = ((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep;   // the live half
+            if (waves > 2048) waves = 2048;
+            zero_blocks = 2048;
+        }
+        hipLaunchKernelGGL(project_pack_bwd_sparse_kernel, dim3((unsigned)(waves + zero_blocks)), dim3(64), 0,
+                           (hipStream_t)stream, *p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii,
+                           compensations, v_means2d, v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities, zero_blocks);
         return check_launch();
     }
     hipLaunchKernelGGL(project_pack_bwd_kernel, dim3(grid_for(p->n_gauss, 256)), dim3(256), 0, (hipStream_t)stream,
