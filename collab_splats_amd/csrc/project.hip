@@ -1491,7 +1491,9 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
                                    (int)(n_floats - 4 * n4));
             };
             if (((uintptr_t)v_means_dir & 15) != 0) return MISPLAT_EINVAL;
-            const bool side_by_side = !coeffs_rest && p->touched && (((uintptr_t)p->touched) & 15) == 0;
+            // (512 rows per scan step: only when that still leaves enough waves -- a small scene with most rows live would
+            // run its batches one behind the other in a handful of waves)
+            const bool side_by_side = !coeffs_rest && p->touched && (((uintptr_t)p->touched) & 15) == 0 && p->n_gauss >= 262144;
             if (coeffs_rest) { zero(v_coeffs_or_colors, (int64_t)p->n_gauss * 3); zero(v_coeffs_rest, (int64_t)p->n_gauss * 45); }
             else if (!side_by_side) zero(v_coeffs_or_colors, (int64_t)p->n_gauss * 48);
             if (!side_by_side) zero(v_means_dir, (int64_t)p->n_gauss * 3);
@@ -1499,7 +1501,9 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
                 hipLaunchKernelGGL(color_sh_bwd_sparse_kernel<true>, dim3(grid), dim3(64), 0, s, *p, sh_degree, means, viewmats,
                                    coeffs_or_colors, coeffs_rest, radii, v_grec, v_coeffs_or_colors, v_coeffs_rest, v_means_dir, 0);
             else {
-                const int zb = side_by_side ? 8192 : 0;
+                // (a workgroup of the zero half clears 64 x 16 bytes per step: at least ~16 steps each, at most 8 192 workgroups)
+                const int64_t zwant = ((int64_t)p->n_gauss * 12 + 1023) / 1024;
+                const int zb = side_by_side ? (int)(zwant < 1 ? 1 : (zwant > 8192 ? 8192 : zwant)) : 0;
                 const int lb = (int)(((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep) < 2048 ? (int)(((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep) : 2048;
                 hipLaunchKernelGGL(color_sh_bwd_sparse_kernel<false>, dim3(side_by_side ? zb + lb : grid), dim3(64), 0, s, *p,
                                    sh_degree, means, viewmats, coeffs_or_colors, coeffs_rest, radii, v_grec, v_coeffs_or_colors,
@@ -1551,10 +1555,11 @@ extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_s
         int64_t waves = ((int64_t)p->n_gauss + 63) / 64;
         if (waves > 2048) waves = 2048;
         int zero_blocks = 0;
-        if (p->touched && !v_means2d && (((uintptr_t)p->touched) & 15) == 0) {
+        if (p->touched && !v_means2d && (((uintptr_t)p->touched) & 15) == 0 && p->n_gauss >= 262144) {
             waves = ((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep;   // the live half
             if (waves > 2048) waves = 2048;
-            zero_blocks = 2048;
+            const int64_t zwant = ((int64_t)p->n_gauss + 1023) / 1024;       // ~16 rows per lane of the zero half, at most 2 048
+            zero_blocks = (int)(zwant < 1 ? 1 : (zwant > 2048 ? 2048 : zwant));
         }
         hipLaunchKernelGGL(project_pack_bwd_sparse_kernel, dim3((unsigned)(waves + zero_blocks)), dim3(64), 0,
                            (hipStream_t)stream, *p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii,
