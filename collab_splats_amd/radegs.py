@@ -85,7 +85,9 @@ def _upload(values: Tensor, device: torch.device) -> Tensor:
     """float32 CPU tensor (flat) -> device, asynchronously, through a ring of pinned staging buffers."""
     if device.type != "cuda":
         return values.to(device)
-    ring = _PIN_RING.setdefault(device, [0, [torch.empty(64, dtype=torch.float32).pin_memory() for _ in range(32)]])
+    ring = _PIN_RING.get(device)
+    if ring is None:                                      # (not setdefault: its default would be built -- 32 pinned allocations -- on every call)
+        ring = _PIN_RING[device] = [0, [torch.empty(64, dtype=torch.float32).pin_memory() for _ in range(32)]]
     ring[0] = (ring[0] + 1) % len(ring[1])
     buf = ring[1][ring[0]][:values.numel()]
     buf.copy_(values)
