@@ -1201,12 +1201,16 @@ def test_four_sub_blocks_per_band_backward_equals_the_band_backward(dev, monkeyp
         assert rel_err(b, a) < 2e-5, (k, rel_err(b, a))
 
 
-def test_whole_step_graph_replays_equal_eager_steps(dev):
-    """graphs.GraphedStep: activations + forward + backward captured once with a fixed intersection capacity (no host
+@pytest.mark.parametrize("lazy", ["0", "1"])
+def test_whole_step_graph_replays_equal_eager_steps(dev, monkeypatch, lazy):
+    """(also with the on-demand colours forced on: the unset pattern, the flags and the sparse backward kernels inside a
+    captured graph)
+    graphs.GraphedStep: activations + forward + backward captured once with a fixed intersection capacity (no host
     synchronisation inside), replayed after the parameters changed in place: same images (bitwise) and gradients as an
     eager step on the same values; a capacity that is too small is reported, not silently truncated."""
-    from collab_splats_amd import graphs, rasterization, MisplatError
+    from collab_splats_amd import graphs, ops, rasterization, MisplatError
     from collab_splats_amd.synthetic import random_scene
+    monkeypatch.setattr(ops, "LAZY_SH", lazy)
     N, W, H = 10_000, 256, 256
     sc = random_scene(N, W, H, seed=3)
     names = ("means", "log_scales", "quats", "opacity_logits", "sh")
