@@ -909,11 +909,14 @@ def test_many_tiles_fall_back_to_32bit_tile_keys(dev):
         assert (one[1] > 0).any()
 
 
-def test_shared_gaussians_multi_view_gradients_add_up(dev):
-    """BASELINE configs[4]/[5] semantics: with C views in one call the parameter gradients are the SUM of the
+@pytest.mark.parametrize("lazy", ["0", "1"])
+def test_shared_gaussians_multi_view_gradients_add_up(dev, monkeypatch, lazy):
+    """(also with the on-demand colours forced on: several cameras in one call)
+    BASELINE configs[4]/[5] semantics: with C views in one call the parameter gradients are the SUM of the
     per-view gradients (what data-parallel ranks all-reduce), and the per-view images equal the single-view ones."""
-    from collab_splats_amd import rasterization
+    from collab_splats_amd import ops, rasterization
     from collab_splats_amd.synthetic import random_scene, view_matrix
+    monkeypatch.setattr(ops, "LAZY_SH", lazy)
     W, H, N, C = 480, 270, 60_000, 4
     sc = random_scene(N, W, H, seed=17)
     V = torch.cat([view_matrix(i) for i in range(C)], dim=0).to(dev)
