@@ -158,7 +158,11 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
     }
     if (LAZY) {
         // (a real call, not inlined: the evaluation needs ~100 registers that the compositing loop must not pay for)
-        if (keep && __float_as_uint(q3.x) == kColourUnset) q3 = lazy_colour(*lz, g);
+        // (all four slots start unset and any unset slot means "not there yet": correct whatever the granularity at which a
+        // concurrent 16-byte store of another wave becomes visible)
+        if (keep && (__float_as_uint(q3.x) == kColourUnset || __float_as_uint(q3.y) == kColourUnset ||
+                     __float_as_uint(q3.z) == kColourUnset || __float_as_uint(q3.w) == kColourUnset))
+            q3 = lazy_colour(*lz, g);
     }
     const unsigned long long mask = __ballot(keep);
     if (keep) {

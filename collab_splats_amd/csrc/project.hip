@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
                 const int64_t e4 = 4 * base + threadIdx.x + u * (int64_t)blockDim.x;
                 if (e4 < 4 * total) lazy_rows[e4] = z;
             }
-            if (idx < total) grec[4 * idx + 3] = make_float4(__uint_as_float(0x7fc0deadu), 0.f, 0.f, 0.f);
+            if (idx < total) { const float u_ = __uint_as_float(0x7fc0deadu); grec[4 * idx + 3] = make_float4(u_, u_, u_, u_); }
         }
         if (idx >= total) continue;
         if (P.touched) P.touched[idx] = 0;
