@@ -673,7 +673,7 @@ def _cap_key(P: Params, dev: torch.device):
 # a record when it first stages it.  Pays when most visible Gaussians are never composited (dense scenes: 1 M random
 # Gaussians at 1080p stage a third of the visible ones); "auto" switches it on from the typical bucket length.
 LAZY_SH = os.environ.get("MISPLAT_LAZY_SH", "auto")
-LAZY_SH_MIN_BUCKET = int(os.environ.get("MISPLAT_LAZY_SH_MIN_BUCKET", "400"))
+LAZY_SH_MIN_BUCKET = int(os.environ.get("MISPLAT_LAZY_SH_MIN_BUCKET", "450"))   # measured crossover at 1080p: 391 even, 549 ahead
 
 
 def _lazy_colour_ok(P: Params, dev, deg: int, kd: int, n_color: int, want_grad: bool, cd: int) -> bool:
