@@ -298,3 +298,55 @@ def test_tsdf_frame_extrinsic_equals_the_reference_viewmat(i):
     assert ext.shape == (4, 4) and ext.dtype == np.float64
     assert np.abs(ext - g[f"cam{i}_viewmat"]).max() < 1e-5
     assert intr == dict(width=W, height=H, fx=float(K[0, 0]), fy=float(K[1, 1]), cx=float(K[0, 2]), cy=float(K[1, 2]))
+
+
+def test_capacity_quantisation_and_static_capacity_context():
+    """Host logic of the speculative forward: capacities are rounded UP to 8 steps per octave (buffers, addresses and
+    graph keys stay put while the count drifts), never below the request; ``static_capacity`` nests and restores."""
+    from collab_splats_amd import ops
+    for x in (1, 4095, 4096, 4097, 100_000, 6_404_069, 2 ** 30 + 5):
+        q = ops._quantise_cap(x)
+        assert q >= max(x, 4096)
+        assert q <= max(x, 4096) * 1.13                                    # at most one step (1/8 octave) above
+        assert ops._quantise_cap(q) == q                                   # a quantised value is a fixed point
+    assert ops._quantise_cap(1_000_000) == ops._quantise_cap(1_010_000)    # a 1 % drift keeps the capacity
+    assert ops._STATIC_CAP is None
+    with ops.static_capacity(1000):
+        assert ops._STATIC_CAP == 1000
+        with ops.static_capacity(None):
+            assert ops._STATIC_CAP is None
+        assert ops._STATIC_CAP == 1000
+    assert ops._STATIC_CAP is None
+
+
+def test_on_demand_colour_switch_conditions(monkeypatch):
+    """``_lazy_colour_ok``: only SH colours with 16 coefficients in training, pixels-per-lane 2/2, 3 or 4 composited
+    channels; "auto" needs a capacity hint of a dense scene (typical bucket >= MISPLAT_LAZY_SH_MIN_BUCKET)."""
+    from collab_splats_amd import _lib, ops
+    P = _lib.make_params(1000, 1, 1920, 1080)
+    dev = torch.device("cuda", 0)                                          # (only used as a dictionary key here)
+    key = ops._cap_key(P, dev)
+    monkeypatch.setattr(ops, "LAZY_SH", "1")
+    assert ops._lazy_colour_ok(P, dev, 3, 16, 3, True, 4)
+    assert not ops._lazy_colour_ok(P, dev, -1, 16, 3, True, 4)             # not SH
+    assert not ops._lazy_colour_ok(P, dev, 3, 9, 3, True, 4)               # not 16 coefficients
+    assert not ops._lazy_colour_ok(P, dev, 3, 16, 3, False, 4)             # inference: the colour kernel
+    assert not ops._lazy_colour_ok(P, dev, 3, 16, 3, True, 1)              # depth-only render
+    P4 = _lib.make_params(1000, 1, 1920, 1080, ppl_fwd=4)
+    assert not ops._lazy_colour_ok(P4, dev, 3, 16, 3, True, 4)
+    monkeypatch.setattr(ops, "LAZY_SH", "0")
+    assert not ops._lazy_colour_ok(P, dev, 3, 16, 3, True, 4)
+    monkeypatch.setattr(ops, "LAZY_SH", "auto")
+    monkeypatch.setitem(ops._CAP_HINT, key, 100 * 8160)                    # sparse: 100 entries per tile
+    assert not ops._lazy_colour_ok(P, dev, 3, 16, 3, True, 4)
+    monkeypatch.setitem(ops._CAP_HINT, key, 800 * 8160)                    # dense
+    assert ops._lazy_colour_ok(P, dev, 3, 16, 3, True, 4)
+    ops._CAP_HINT.pop(key, None)
+    assert not ops._lazy_colour_ok(P, dev, 3, 16, 3, True, 4)              # first call of a shape: no hint yet
+
+
+def test_camera_upload_on_cpu_is_a_plain_copy():
+    """``_upload`` stages camera data through pinned memory for a GPU only; for a CPU device it is the identity copy."""
+    vals = torch.arange(28, dtype=torch.float32)
+    out = radegs._upload(vals, torch.device("cpu"))
+    assert torch.equal(out, vals) and not radegs._PIN_RING
