@@ -126,7 +126,7 @@ __device__ __forceinline__ float4 lazy_colour(const LazyColour& lz, int g) {
     {                                                                                   \
         const float* f_ = (k) == 0 ? dc : row + 3 * (k);                                \
         const float b_ = (B);                                                           \
-        c0 += b_ * f_[0]; c1 += b_ * f_[1]; c2 += b_ * f_[2];                           \
+        c0 = fmaf(b_, f_[0], c0); c1 = fmaf(b_, f_[1], c1); c2 = fmaf(b_, f_[2], c2);   \
     }
     MISPLAT_SH_WALK(lz.deg, x, y, z, LZ_TERM)
 #undef LZ_TERM

@@ -14,7 +14,9 @@ __device__ constexpr float C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0
 // three coefficients, nothing else stays live (12 accumulators + the shared monomials).  The array form (sh_basis into
 // b / bx / by / bz[16], then the sums) made the forward colour kernel a 245-VGPR kernel with two waves per SIMD, which
 // is what a streaming kernel waiting on HBM can least afford; the scheduling barriers keep the compiler from hoisting
-// all 48 LDS reads and 64 basis values back to the top.  Same operation order per accumulator as the array form.
+// all 48 LDS reads and 64 basis values back to the top.  The accumulations are explicit fused multiply-adds (the same
+// bits whatever the translation unit's contraction setting: the colour kernel and the on-demand evaluation in blend.hip
+// must agree bit for bit); the basis expressions are evaluated without contraction in both.
 // The 16 basis functions as a list: MISPLAT_SH_WALK(deg, x, y, z, T) expands T(k, B, BX, BY, BZ) -- basis value and
 // its derivatives by x, y, z -- for every k of the active degree, degree band by degree band (monomials xx ... xz are in
 // scope for degree >= 2), with a scheduling barrier between groups.
@@ -55,12 +57,12 @@ __device__ __forceinline__ void sh_eval(int deg, float x, float y, float z, cons
     {                                                                                          \
         const float f0 = cf[3 * (k)], f1 = cf[3 * (k) + 1], f2 = cf[3 * (k) + 2];              \
         const float b_ = (B);                                                                  \
-        c0 += b_ * f0; c1 += b_ * f1; c2 += b_ * f2;                                           \
+        c0 = fmaf(b_, f0, c0); c1 = fmaf(b_, f1, c1); c2 = fmaf(b_, f2, c2);                   \
         if (JAC) {                                                                             \
             const float bx_ = (BX), by_ = (BY), bz_ = (BZ);                                    \
-            J[0] += bx_ * f0; J[1] += by_ * f0; J[2] += bz_ * f0;                              \
-            J[3] += bx_ * f1; J[4] += by_ * f1; J[5] += bz_ * f1;                              \
-            J[6] += bx_ * f2; J[7] += by_ * f2; J[8] += bz_ * f2;                              \
+            J[0] = fmaf(bx_, f0, J[0]); J[1] = fmaf(by_, f0, J[1]); J[2] = fmaf(bz_, f0, J[2]); \
+            J[3] = fmaf(bx_, f1, J[3]); J[4] = fmaf(by_, f1, J[4]); J[5] = fmaf(bz_, f1, J[5]); \
+            J[6] = fmaf(bx_, f2, J[6]); J[7] = fmaf(by_, f2, J[7]); J[8] = fmaf(bz_, f2, J[8]); \
         }                                                                                      \
     }
     MISPLAT_SH_WALK(deg, x, y, z, SH_TERM)
