@@ -689,7 +689,7 @@ def _lazy_colour_ok(P: Params, dev, deg: int, kd: int, n_color: int, want_grad: 
 
 def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg: int, kd: int,
                     n_color: int, per_cam: int, depth_channel: bool, want_aux: bool, want_grad: bool, defer: bool = False,
-                    lazy: bool = False):
+                    lazy: bool = False, flags: bool = False):
     """Allocations + phase A of misplat_raster_fwd (``defer``: phase A is launched together with B, by _raster_phase_b).
     Returns (radii, means2d, depths, comps, grec, sh_aux, state)."""
     lib = _lib.load()
@@ -705,8 +705,10 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
         dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, 4, n_cells + 1, rows, 2 * rows, n_tiles + 1,
               (rows + 3) // 4 if want_grad else 0))
     # one byte per row: cleared by the projection kernel, set by the compositing backward, read by the per-Gaussian
-    # backward kernels (misplat_params.touched)
-    P.touched = touched.data_ptr() if want_grad else None
+    # backward kernels (misplat_params.touched).  Only where the compositing backward is the ONLY source of the packed
+    # gradient rows (the single autograd node): with the two-node form a loss on the projection's own outputs reaches the
+    # projection backward without ever passing the compositing kernels.
+    P.touched = touched.data_ptr() if (want_grad and flags) else None
     host = _readback_slot(dev)
     host[0] = -1                                                      # overwritten by the asynchronous copy of phase A
     a = RasterArgs()
@@ -846,7 +848,7 @@ class _RasterFused(torch.autograd.Function):
         defer = _STATIC_CAP is not None or (MERGE_PHASES and SPECULATE and _cap_key(P, means.device) in _CAP_HINT)
         radii, means2d, depths, comps, grec, sh_aux, state = _raster_phase_a(
             P, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam, depth_channel,
-            want_aux, want_grad, defer=defer, lazy=lazy)
+            want_aux, want_grad, defer=defer, lazy=lazy, flags=True)
         imgs, bins, sched = _raster_phase_b(P, state, cd)
         render, alpha, exp_depth, med_depth, normal, last_ids, median_ids = imgs
         extra["bins"] = bins
