@@ -1273,6 +1273,28 @@ def test_on_demand_colours_equal_the_colour_kernel(dev, N, W, H, scale_mul):
             assert rel_err(a, b) < 2e-5, (k, rel_err(a, b))
 
 
+def test_two_node_form_backpropagates_a_loss_on_projection_outputs(dev, monkeypatch):
+    """MISPLAT_FUSED_NODE=0: the projection's own outputs in ``meta`` are differentiable, and a loss on them reaches the
+    projection backward WITHOUT passing the compositing kernels -- the `touched` row flags (set by the compositing
+    backward) must not be in play there.  The gradient of a loss on the per-Gaussian normals equals the one the projection
+    wrapper gives."""
+    from collab_splats_amd import ops, rasterization, fully_fused_projection
+    monkeypatch.setattr(ops, "FUSED_NODE", False)
+    N, W, H = 20_000, 320, 200
+    args = _bench_like_scene(dev, N, W, H, seed=4)
+    for rep in range(2):                                       # (second call: capacity hint, merged phases, graphs)
+        leaves = [t.clone().requires_grad_(True) for t in args[:5]]
+        out = rasterization(*leaves, *args[5:], sh_degree=3, render_mode="RGB+ED", rasterize_mode="classic",
+                            return_depth_normal=True)        # (classic: the wrapper has no anti-aliasing compensation)
+        (out[5]["normals"] * out[5]["normals"].new_tensor([0.3, -0.7, 1.1])).sum().backward()
+        ref = [t.clone().requires_grad_(True) for t in args[:3]]
+        proj = fully_fused_projection(ref[0], None, ref[1], ref[2], args[5], args[6], W, H, opacities=args[3])
+        (proj[7] * proj[7].new_tensor([0.3, -0.7, 1.1])).sum().backward()
+        assert float(leaves[0].grad.abs().sum()) > 0
+        assert rel_err(leaves[0].grad, ref[0].grad) < 1e-5, rep
+        assert leaves[4].grad is None or float(leaves[4].grad.abs().sum()) == 0.0
+
+
 def test_unit_order_is_a_permutation_sorted_by_measured_work(dev):
     """misplat_unit_order: every unit exactly once, heaviest first inside each XCD strip, padding = units."""
     from collab_splats_amd import _lib
