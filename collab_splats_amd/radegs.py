@@ -87,11 +87,19 @@ def _upload(values: Tensor, device: torch.device) -> Tensor:
         return values.to(device)
     ring = _PIN_RING.get(device)
     if ring is None:                                      # (not setdefault: its default would be built -- 32 pinned allocations -- on every call)
-        ring = _PIN_RING[device] = [0, [torch.empty(64, dtype=torch.float32).pin_memory() for _ in range(32)]]
+        ring = _PIN_RING[device] = [0, [torch.empty(64, dtype=torch.float32).pin_memory() for _ in range(32)], [None] * 32]
     ring[0] = (ring[0] + 1) % len(ring[1])
+    ev = ring[2][ring[0]]
+    if ev is not None:
+        ev.synchronize()                                  # the copy that last used this slot (32 uploads ago) has long run
     buf = ring[1][ring[0]][:values.numel()]
     buf.copy_(values)
-    return buf.to(device, non_blocking=True)
+    out = buf.to(device, non_blocking=True)
+    if not torch.cuda.is_current_stream_capturing():
+        ev = ring[2][ring[0]] or torch.cuda.Event()
+        ev.record()
+        ring[2][ring[0]] = ev
+    return out
 
 
 def _device_const(key: tuple, device: torch.device, make) -> Tensor:
