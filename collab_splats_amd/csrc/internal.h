@@ -1,0 +1,27 @@
+// internal.h -- entry points shared between the translation units of libmisplat.so that are NOT part of the C ABI
+// (C++ linkage: they do not appear among the exported misplat_* symbols).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "misplat.h"
+
+namespace misplat_internal {
+
+// dst[0 .. n_floats) = 0 with at most max_blocks workgroups of 256 threads (0: as many as it takes).  A small grid makes
+// a background fill: beside a compute-bound kernel on another graph branch it trickles along without taking the
+// machine away from it.
+int zero_fill(float* dst, int64_t n_floats, int max_blocks, hipStream_t s);
+
+// misplat_color_bwd / misplat_project_pack_bwd with one more piece of knowledge: outputs_zero != 0 -- every output
+// gradient tensor has already been cleared (by zero_fill on a side branch), only the rows that have a gradient are
+// written.
+int color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color, int32_t per_cam, const float* means,
+              const float* viewmats, const float* coeffs_or_colors, const float* coeffs_rest, const int32_t* radii,
+              const float* v_grec, float* v_coeffs_or_colors, float* v_coeffs_rest, float* v_means_dir, const float* sh_aux,
+              int outputs_zero, hipStream_t s);
+int project_pack_bwd(const misplat_params* p, int32_t depth_slot, const float* means, const float* quats, const float* scales,
+                     const float* opacities, const float* viewmats, const float* Ks, const int32_t* radii,
+                     const float* compensations, const float* v_means2d, const float* v_grec, const float* v_means_dir,
+                     float* v_means, float* v_quats, float* v_scales, float* v_opacities, int outputs_zero, hipStream_t s);
+
+}  // namespace misplat_internal

@@ -12,8 +12,10 @@
 // written per Gaussian forward); arithmetic is irrelevant to their run time.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "misplat.h"
 #include "sh_eval.h"
+#include "internal.h"
 
 namespace {
 
@@ -1240,7 +1242,9 @@ __global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
     // zero_blocks > 0 (`touched` flags given, no separate mean2d gradient): the LAST zero_blocks workgroups clear the
     // outputs of the rows whose flag is not set while the first ones compute the flagged rows (disjoint rows, no order
     // needed: side by side instead of one scan doing both).  A dead row's SH direction gradient is zero as well.
-    const int n_live_blocks = (int)gridDim.x - zero_blocks;
+    // zero_blocks < 0: the outputs were cleared beforehand (a background fill beside the compositing backward): flagged
+    // rows only, nobody clears anything here.
+    const int n_live_blocks = (int)gridDim.x - (zero_blocks > 0 ? zero_blocks : 0);
     if ((int)blockIdx.x >= n_live_blocks) {
         for (int64_t g = (int64_t)((int)blockIdx.x - n_live_blocks) * 64 + lane; g < P.n_gauss; g += (int64_t)zero_blocks * 64) {
             if (P.touched[g] != 0) continue;
@@ -1279,7 +1283,7 @@ __global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
         for (int k = 0; k < 4; k++) v_quats[4 * g + k] = o_q[k];
         v_opacities[g] = o_op;
     };
-    if (zero_blocks > 0) {
+    if (zero_blocks != 0) {
         // flags 8 at a time per lane (one load covers kFlagStep rows of the wave), the ballots run from registers
         for (int64_t base = (int64_t)blockIdx.x * kFlagStep; base < P.n_gauss; base += (int64_t)n_live_blocks * kFlagStep) {
             const int64_t r0 = base + 8 * lane;
@@ -1357,6 +1361,16 @@ inline int grid_for(int64_t n, int block) {
 inline int check_launch() { return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH; }
 
 }  // namespace
+
+int misplat_internal::zero_fill(float* dst, int64_t n_floats, int max_blocks, hipStream_t s) {
+    if (n_floats <= 0) return MISPLAT_OK;
+    if (((uintptr_t)dst) & 15) return MISPLAT_EINVAL;
+    const int64_t n4 = n_floats / 4;
+    int g = grid_for(n4, 256);
+    if (max_blocks > 0 && g > max_blocks) g = max_blocks;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(g), dim3(256), 0, s, (float4*)dst, n4, dst + 4 * n4, (int)(n_floats - 4 * n4));
+    return check_launch();
+}
 
 extern "C" int misplat_project_fwd(const misplat_params* p, const float* means, const float* quats,
                                    const float* scales, const float* opacities, const float* viewmats,
@@ -1471,9 +1485,18 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
                                  const float* coeffs_or_colors, const float* coeffs_rest, const int32_t* radii,
                                  const float* v_grec, float* v_coeffs_or_colors, float* v_coeffs_rest,
                                  float* v_means_dir, const float* sh_aux, misplat_stream_t stream) {
+    return misplat_internal::color_bwd(p, sh_degree, K_or_D, n_color, per_cam, means, viewmats, coeffs_or_colors, coeffs_rest,
+                                       radii, v_grec, v_coeffs_or_colors, v_coeffs_rest, v_means_dir, sh_aux, 0,
+                                       (hipStream_t)stream);
+}
+
+int misplat_internal::color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color, int32_t per_cam,
+                                const float* means, const float* viewmats, const float* coeffs_or_colors,
+                                const float* coeffs_rest, const int32_t* radii, const float* v_grec,
+                                float* v_coeffs_or_colors, float* v_coeffs_rest, float* v_means_dir, const float* sh_aux,
+                                int outputs_zero, hipStream_t s) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1 || n_color < 0 || n_color > 4) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
-    hipStream_t s = (hipStream_t)stream;
     if (sh_degree >= 0) {
         if (sh_degree > 3 || K_or_D < (sh_degree + 1) * (sh_degree + 1) || K_or_D > 16 || !v_means_dir) return MISPLAT_EINVAL;
         constexpr int BLK = 64;
@@ -1493,10 +1516,12 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
             if (((uintptr_t)v_means_dir & 15) != 0) return MISPLAT_EINVAL;
             // (512 rows per scan step: only when that still leaves enough waves -- a small scene with most rows live would
             // run its batches one behind the other in a handful of waves)
-            const bool side_by_side = !coeffs_rest && p->touched && (((uintptr_t)p->touched) & 15) == 0 && p->n_gauss >= 262144;
-            if (coeffs_rest) { zero(v_coeffs_or_colors, (int64_t)p->n_gauss * 3); zero(v_coeffs_rest, (int64_t)p->n_gauss * 45); }
+            const bool prefilled = outputs_zero != 0;
+            const bool side_by_side = !prefilled && !coeffs_rest && p->touched && (((uintptr_t)p->touched) & 15) == 0 && p->n_gauss >= 262144;
+            if (prefilled) {}
+            else if (coeffs_rest) { zero(v_coeffs_or_colors, (int64_t)p->n_gauss * 3); zero(v_coeffs_rest, (int64_t)p->n_gauss * 45); }
             else if (!side_by_side) zero(v_coeffs_or_colors, (int64_t)p->n_gauss * 48);
-            if (!side_by_side) zero(v_means_dir, (int64_t)p->n_gauss * 3);
+            if (!side_by_side && !prefilled) zero(v_means_dir, (int64_t)p->n_gauss * 3);
             if (coeffs_rest)
                 hipLaunchKernelGGL(color_sh_bwd_sparse_kernel<true>, dim3(grid), dim3(64), 0, s, *p, sh_degree, means, viewmats,
                                    coeffs_or_colors, coeffs_rest, radii, v_grec, v_coeffs_or_colors, v_coeffs_rest, v_means_dir, 0);
@@ -1546,6 +1571,16 @@ extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_s
                                         const float* compensations, const float* v_means2d, const float* v_grec,
                                         const float* v_means_dir, float* v_means, float* v_quats,
                                         float* v_scales, float* v_opacities, misplat_stream_t stream) {
+    return misplat_internal::project_pack_bwd(p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii, compensations,
+                                              v_means2d, v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities, 0,
+                                              (hipStream_t)stream);
+}
+
+int misplat_internal::project_pack_bwd(const misplat_params* p, int32_t depth_slot, const float* means, const float* quats,
+                                       const float* scales, const float* opacities, const float* viewmats, const float* Ks,
+                                       const int32_t* radii, const float* compensations, const float* v_means2d,
+                                       const float* v_grec, const float* v_means_dir, float* v_means, float* v_quats,
+                                       float* v_scales, float* v_opacities, int outputs_zero, hipStream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
     if (depth_slot != -1 && (depth_slot < 12 || depth_slot > 15)) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
@@ -1559,9 +1594,9 @@ extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_s
             waves = ((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep;   // the live half
             if (waves > 2048) waves = 2048;
             const int64_t zwant = ((int64_t)p->n_gauss + 1023) / 1024;       // ~16 rows per lane of the zero half, at most 2 048
-            zero_blocks = (int)(zwant < 1 ? 1 : (zwant > 2048 ? 2048 : zwant));
+            zero_blocks = outputs_zero ? -1 : (int)(zwant < 1 ? 1 : (zwant > 2048 ? 2048 : zwant));
         }
-        hipLaunchKernelGGL(project_pack_bwd_sparse_kernel, dim3((unsigned)(waves + zero_blocks)), dim3(64), 0,
+        hipLaunchKernelGGL(project_pack_bwd_sparse_kernel, dim3((unsigned)(waves + (zero_blocks > 0 ? zero_blocks : 0))), dim3(64), 0,
                            (hipStream_t)stream, *p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii,
                            compensations, v_means2d, v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities, zero_blocks);
         return check_launch();

@@ -23,6 +23,7 @@
 #include <mutex>
 #include <vector>
 #include "misplat.h"
+#include "internal.h"
 
 namespace {
 
@@ -132,12 +133,12 @@ struct misplat_graph_cache {
     std::vector<GraphEntry> entries;
     std::vector<Retired> retired;
     uint64_t clock = 0, hits = 0, captures = 0;
-    uint64_t window_calls = 0, window_misses = 0, bypass_until = 0;
+    uint64_t window_calls = 0, window_misses = 0, bypass_until = 0, miss_run = 0;
     int max_entries = 16;
     // Sequences are captured on this private stream (the caller's may be the legacy default stream, which cannot be
     // captured) and the resulting graph is launched on the caller's stream.
     hipStream_t capture_stream = nullptr;
-    Fork fork{nullptr, nullptr, nullptr};       // the parallel branch of a captured sequence (side stream: capture only)
+    Fork fork{nullptr, nullptr, nullptr};       // the parallel branch of a sequence (captured, or eager when captures are bypassed)
 };
 
 extern "C" misplat_graph_cache* misplat_graph_cache_create(int32_t max_entries) {
@@ -198,17 +199,22 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
             e.last_stream = s;
             cache->hits++;
             cache->window_calls++;
+            cache->miss_run = 0;
             return hipGraphLaunch(e.exec, s) == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
         }
     // A caller whose argument blocks never repeat (addresses or sizes change every call) gains nothing from
     // capturing: after a window with mostly misses, plain launches are used for a while.
     cache->window_calls++;
     cache->window_misses++;
+    // ... and a dozen misses in a row (a caller that uploads fresh camera tensors every step: the model mirror) is
+    // answer enough -- a capture costs more than the launches it would have saved
+    if (++cache->miss_run >= 12) { cache->bypass_until = cache->clock + 512; cache->miss_run = 0; }
     if (cache->window_calls >= 64) {
         if (2 * cache->window_misses > cache->window_calls) cache->bypass_until = cache->clock + 512;
         cache->window_calls = cache->window_misses = 0;
     }
-    if (cache->clock < cache->bypass_until) return enqueue(s, (const Fork*)nullptr);
+    // (plain launches, but the side branch still exists: the cache's side stream and events work outside a capture too)
+    if (cache->clock < cache->bypass_until) return enqueue(s, &cache->fork);
     // capture on the private stream (thread-local mode: other host threads keep using the runtime normally)
     hipStream_t cs = cache->capture_stream;
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {
@@ -276,22 +282,49 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
 
 // ---- the whole backward of rasterization(): compositing backward (atomic gradient rows), colour backward,
 // projection backward -- three launches, no memset when the forward left cleared gradient rows behind
-static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_args* b, hipStream_t s) {
+// A graph branch beside the compositing backward (VALU-bound for ~0.5 ms, the memory system idle): the dense output
+// gradients of the per-Gaussian kernels -- 236 bytes per Gaussian, nine tenths of them zeros in a dense scene -- are
+// cleared there by a SMALL grid (a full-size fill takes the machine for 40 us and delays the compositing by as much; 128
+// workgroups trickle along, measured -15 .. -25 us per step at 1 M), and the two kernels then write only the rows that
+// have a gradient.  Needs the row flags (misplat_params.touched), one camera, 16 SH coefficients without Jacobian cache.
+static bool background_fill_ok(const misplat_params* p, const misplat_raster_bwd_args* b) {
+    return p->touched && p->n_cams == 1 && p->n_gauss >= 262144 && b->sh_degree >= 0 && !b->sh_aux && b->K_or_D == 16 &&
+           !b->v_means2d && b->v_means_dir && (b->colors_rest != nullptr) == (b->v_colors_rest != nullptr);
+}
+
+static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_args* b, hipStream_t s, const Fork* fork = nullptr) {
     misplat_stream_t stream = (misplat_stream_t)s;
     misplat_params q = *p;
     q.unit_perm = b->unit_perm;
     q.unit_work = nullptr;
+    bool forked = false;
+    if (fork && background_fill_ok(p, b) && hipEventRecord(fork->forked, s) == hipSuccess &&
+        hipStreamWaitEvent(fork->side, fork->forked, 0) == hipSuccess) {
+        constexpr int kBg = 128;
+        const int64_t n = p->n_gauss;
+        int rf = misplat_internal::zero_fill(b->v_colors, n * (b->colors_rest ? 3 : 48), kBg, fork->side);
+        if (rf == MISPLAT_OK && b->colors_rest) rf = misplat_internal::zero_fill(b->v_colors_rest, n * 45, kBg, fork->side);
+        if (rf == MISPLAT_OK) rf = misplat_internal::zero_fill(b->v_means_dir, n * 3, kBg, fork->side);
+        if (rf == MISPLAT_OK) rf = misplat_internal::zero_fill(b->v_means, n * 3, kBg, fork->side);
+        if (rf == MISPLAT_OK) rf = misplat_internal::zero_fill(b->v_quats, n * 4, kBg, fork->side);
+        if (rf == MISPLAT_OK) rf = misplat_internal::zero_fill(b->v_scales, n * 3, kBg, fork->side);
+        if (rf == MISPLAT_OK) rf = misplat_internal::zero_fill(b->v_opacities, n, kBg, fork->side);
+        if (rf != MISPLAT_OK) return rf;
+        forked = true;
+    }
     int rc = misplat_blend_bwd_atomic(&q, b->color_dim, b->Ks, b->grec, b->flatten_ids, b->offsets, b->n_isects, b->alpha,
                                       b->last_ids, b->median_ids, b->render, b->v_render, b->v_alpha, b->v_exp_depth,
                                       b->v_med_depth, b->v_normal, b->v_grec, b->v_abs, b->zero_flags, stream);
     if (rc != MISPLAT_OK) return rc;
-    rc = misplat_color_bwd(p, b->sh_degree, b->K_or_D, b->n_color, b->per_cam, b->means, b->viewmats, b->colors,
-                           b->colors_rest, b->radii, b->v_grec, b->v_colors, b->v_colors_rest, b->v_means_dir, b->sh_aux,
-                           stream);
+    if (forked && (hipEventRecord(fork->joined, fork->side) != hipSuccess || hipStreamWaitEvent(s, fork->joined, 0) != hipSuccess))
+        return MISPLAT_ELAUNCH;
+    rc = misplat_internal::color_bwd(p, b->sh_degree, b->K_or_D, b->n_color, b->per_cam, b->means, b->viewmats, b->colors,
+                                     b->colors_rest, b->radii, b->v_grec, b->v_colors, b->v_colors_rest, b->v_means_dir,
+                                     b->sh_aux, forked ? 1 : 0, s);
     if (rc != MISPLAT_OK) return rc;
-    return misplat_project_pack_bwd(p, b->depth_slot, b->means, b->quats, b->scales, b->opacities, b->viewmats, b->Ks,
-                                    b->radii, b->compensations, b->v_means2d, b->v_grec, b->v_means_dir, b->v_means,
-                                    b->v_quats, b->v_scales, b->v_opacities, stream);
+    return misplat_internal::project_pack_bwd(p, b->depth_slot, b->means, b->quats, b->scales, b->opacities, b->viewmats, b->Ks,
+                                              b->radii, b->compensations, b->v_means2d, b->v_grec, b->v_means_dir, b->v_means,
+                                              b->v_quats, b->v_scales, b->v_opacities, forked ? 1 : 0, s);
 }
 
 extern "C" int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
@@ -301,7 +334,7 @@ extern "C" int misplat_raster_bwd(const misplat_params* p, const misplat_raster_
     // memset nodes are kept out of graphs (see the note on phase A): only the memset-free form is captured
     const bool memset_free = (b->zero_flags & 1) && (!b->v_abs || (b->zero_flags & 2));
     if (!cache || !memset_free) return enqueue_backward(p, b, s);
-    return run_cached(cache, make_key(0x100, s, p, b), s, [&](hipStream_t st, const Fork*) { return enqueue_backward(p, b, st); });
+    return run_cached(cache, make_key(0x100, s, p, b), s, [&](hipStream_t st, const Fork* f) { return enqueue_backward(p, b, st, f); });
 }
 
 // float4 streaming copy: the measured HBM roof of the box the benchmark runs on (bench.py reports fractions of it
