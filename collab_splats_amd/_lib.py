@@ -49,7 +49,7 @@ class RasterArgs(C.Structure):
                                              "tiles_per_gauss", "rect2", "cellhist", "cell_count", "cell_offs", "order",
                                              "rect_sorted", "counters", "tile_count", "offsets", "payload", "flatten_ids", "scratch")]
                 + [("cap_isects", C.c_int64)]
-                + [(n, C.c_void_p) for n in ("n_isects_host", "reserved1", "render", "alpha", "exp_depth", "med_depth",
+                + [(n, C.c_void_p) for n in ("n_isects_host", "v_abs_zero", "render", "alpha", "exp_depth", "med_depth",
                                              "normal", "last_ids", "median_ids", "unit_perm_in", "unit_work",
                                              "unit_perm_out")])
 
@@ -86,7 +86,7 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
 # name -> (restype, n_args); every symbol include/misplat.h declares
 SYMBOLS = {
     "misplat_project_fwd": (C.c_int, 16), "misplat_project_bwd": (C.c_int, 18),
-    "misplat_project_pack_fwd": (C.c_int, 16), "misplat_color_fwd": (C.c_int, 16),
+    "misplat_project_pack_fwd": (C.c_int, 17), "misplat_color_fwd": (C.c_int, 16),
     "misplat_color_bwd": (C.c_int, 16), "misplat_project_pack_bwd": (C.c_int, 18),
     "misplat_sh_fwd": (C.c_int, 9), "misplat_sh_bwd": (C.c_int, 11),
     "misplat_sort32_workspace_bytes": (C.c_size_t, 2),

@@ -52,7 +52,7 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(INCLUDE, "misplat.h"), os.path.join(CSRC, "sh_eval.h")]
+    headers = [os.path.join(INCLUDE, "misplat.h"), os.path.join(CSRC, "sh_eval.h"), os.path.join(CSRC, "internal.h")]
     jobs = []
     objs = []
     for src, extra in SOURCES.items():

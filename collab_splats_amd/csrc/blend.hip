@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "misplat.h"
+#include "internal.h"
 #include "sh_eval.h"
 
 namespace {
@@ -525,8 +526,24 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
     const float* __restrict__ v_exp_depth, const float* __restrict__ v_med_depth,
     const float* __restrict__ v_normal, float* __restrict__ slab, float* __restrict__ slab_abs,
     uint8_t* __restrict__ valid, const float4* __restrict__ featx = nullptr, float* __restrict__ v_featx = nullptr,
-    int n_channels = CD) {
+    int n_channels = CD, misplat_internal::FillList F = {}) {
     static_assert(NXQ == 0 || ATOMIC, "N-D colours: atomic gradient mode only");
+    // Background role (F.blocks > 0): the last workgroups of the grid -- dispatched when the machine starts to drain --
+    // clear the tensors the per-Gaussian backward kernels write sparsely afterwards: memory-bound waves beside this
+    // kernel's issue-bound ones, no launch, no graph branch.
+    const int fill_b = (int)blockIdx.x - ((int)gridDim.x - F.blocks);
+    if (F.blocks > 0 && fill_b >= 0) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k >= F.count) break;
+            float4* __restrict__ d = (float4*)F.p[k];
+            const int64_t n4 = F.n[k] >> 2;
+            for (int64_t i = (int64_t)fill_b * 64 + threadIdx.x; i < n4; i += (int64_t)F.blocks * 64) d[i] = z;
+            if (fill_b == 0 && (int)threadIdx.x < (int)(F.n[k] & 3)) F.p[k][4 * n4 + threadIdx.x] = 0.f;
+        }
+        return;
+    }
     __shared__ float4 sm[4 * 64 + 4];
     __shared__ int sm_idx[64 + 4];
     __shared__ int sm_slot[64 + 4];
@@ -1530,28 +1547,42 @@ extern "C" int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, con
     return check_launch();
 }
 
-// Same backward, but every (band, Gaussian) row is added straight into v_grec[C*N,16] (and
-// v_abs[C*N,2]) with no-return fp32 atomics -- no slab, no second kernel; the sums then depend on
-// arrival order (not bitwise reproducible).  v_grec / v_abs are zeroed here on `stream`.
-extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks,
-                                        const float* grec, const int32_t* flatten_ids,
-                                        const int32_t* offsets, int64_t n_isects, const float* alpha,
-                                        const int32_t* last_ids, const int32_t* median_ids,
-                                        const float* render, const float* v_render, const float* v_alpha,
-                                        const float* v_exp_depth, const float* v_med_depth,
-                                        const float* v_normal, float* v_grec, float* v_abs,
-                                        int32_t v_grec_is_zero, misplat_stream_t stream) {
+// misplat_blend_bwd_atomic + background fills (internal.h): 512 one-wave workgroups behind the last unit of the grid
+// (placement and count measured: see enqueue_backward in raster.hip).
+constexpr int kFillBlocks = 512;
+int misplat_internal::blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks, const float* grec,
+                                       const int32_t* flatten_ids, const int32_t* offsets, int64_t n_isects,
+                                       const float* alpha, const int32_t* last_ids, const int32_t* median_ids,
+                                       const float* render, const float* v_render, const float* v_alpha,
+                                       const float* v_exp_depth, const float* v_med_depth, const float* v_normal,
+                                       float* v_grec, float* v_abs, int32_t v_grec_is_zero, const FillList* fills,
+                                       hipStream_t s) {
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !v_grec) return MISPLAT_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
     const size_t rows = (size_t)p->n_gauss * p->n_cams;
     if (rows == 0) return MISPLAT_OK;
     // v_grec_is_zero: bit 0 = v_grec, bit 1 = v_abs have been cleared by the caller
     if (!(v_grec_is_zero & 1) && hipMemsetAsync(v_grec, 0, rows * MISPLAT_REC * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
     if (v_abs && !(v_grec_is_zero & 2) && hipMemsetAsync(v_abs, 0, rows * 2 * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
-    if (n_isects == 0) return MISPLAT_OK;
     const int ppl = pick_ppl(p->ppl_bwd, kDefaultPplBwd);
+    FillList F = {};
+    if (fills) {
+        if (fills->count < 0 || fills->count > 8) return MISPLAT_EINVAL;
+        for (int k = 0; k < fills->count; k++)
+            if (!fills->p[k] || (((uintptr_t)fills->p[k]) & 15) || fills->n[k] < 0) return MISPLAT_EINVAL;
+        const bool in_kernel = n_isects > 0 && !(ppl == 2 && p->sub_blocks == 4) && color_dim >= 1 && color_dim <= 4;
+        if (in_kernel) {
+            F = *fills;
+            F.blocks = kFillBlocks;
+        } else {
+            for (int k = 0; k < fills->count; k++) {
+                const int rf = zero_fill(fills->p[k], fills->n[k], 0, s);
+                if (rf != MISPLAT_OK) return rf;
+            }
+        }
+    }
+    if (n_isects == 0) return MISPLAT_OK;
     const int total = p->tile_w * p->tile_h * p->n_cams * (4 / ppl);
-    const int grid = ((total + 7) / 8) * 8;
+    const int grid = ((total + 7) / 8) * 8 + F.blocks;
     if (ppl == 2 && p->sub_blocks == 4 && color_dim >= 1 && color_dim <= 4) {
 #define LAUNCH_BWDQ(CD_)                                                                                       \
         do {                                                                                                   \
@@ -1575,7 +1606,7 @@ extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_d
     hipLaunchKernelGGL((blend_bwd_kernel<CD_, PPL_, ABS_, true>), dim3(grid), dim3(64), 0, s, *p, Ks,          \
                        (const float4*)grec, flatten_ids, (const int32_t*)nullptr, offsets, n_isects, alpha,    \
                        last_ids, median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal,    \
-                       v_grec, v_abs, (uint8_t*)nullptr)
+                       v_grec, v_abs, (uint8_t*)nullptr, (const float4*)nullptr, (float*)nullptr, CD_, F)
 #define DISPATCH_BWDA(CD_)                                                       \
     do {                                                                         \
         if (v_abs) {                                                             \
@@ -1596,6 +1627,22 @@ extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_d
 #undef DISPATCH_BWDA
 #undef LAUNCH_BWDA
     return check_launch();
+}
+
+// Same backward, but every (band, Gaussian) row is added straight into v_grec[C*N,16] (and
+// v_abs[C*N,2]) with no-return fp32 atomics -- no slab, no second kernel; the sums then depend on
+// arrival order (not bitwise reproducible).  v_grec / v_abs are zeroed here on `stream`.
+extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks,
+                                        const float* grec, const int32_t* flatten_ids,
+                                        const int32_t* offsets, int64_t n_isects, const float* alpha,
+                                        const int32_t* last_ids, const int32_t* median_ids,
+                                        const float* render, const float* v_render, const float* v_alpha,
+                                        const float* v_exp_depth, const float* v_med_depth,
+                                        const float* v_normal, float* v_grec, float* v_abs,
+                                        int32_t v_grec_is_zero, misplat_stream_t stream) {
+    return misplat_internal::blend_bwd_atomic(p, color_dim, Ks, grec, flatten_ids, offsets, n_isects, alpha, last_ids,
+                                              median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal,
+                                              v_grec, v_abs, v_grec_is_zero, nullptr, (hipStream_t)stream);
 }
 
 // ---- N-D colours: D' = n_channels in 5..20 composited in ONE pass.

@@ -12,8 +12,24 @@ namespace misplat_internal {
 // machine away from it.
 int zero_fill(float* dst, int64_t n_floats, int max_blocks, hipStream_t s);
 
+// Tensors to clear "in the background" of a compute-bound kernel: the last `blocks` workgroups (64 threads each) of that
+// kernel's grid write the zeros, the others do the kernel's own work.  n[k] floats at p[k] (16-byte aligned).
+struct FillList {
+    float* p[8];
+    int64_t n[8];
+    int count, blocks;
+};
+
+// misplat_blend_bwd_atomic that also clears the tensors of `fills` (or NULL) -- inside the compositing kernel's own grid
+// where its layout allows (a parallel graph branch costs ~10 us at either end), with plain fills ahead of it otherwise.
+int blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks, const float* grec, const int32_t* flatten_ids,
+                     const int32_t* offsets, int64_t n_isects, const float* alpha, const int32_t* last_ids,
+                     const int32_t* median_ids, const float* render, const float* v_render, const float* v_alpha,
+                     const float* v_exp_depth, const float* v_med_depth, const float* v_normal, float* v_grec, float* v_abs,
+                     int32_t v_grec_is_zero, const FillList* fills, hipStream_t s);
+
 // misplat_color_bwd / misplat_project_pack_bwd with one more piece of knowledge: outputs_zero != 0 -- every output
-// gradient tensor has already been cleared (by zero_fill on a side branch), only the rows that have a gradient are
+// gradient tensor has already been cleared (FillList above), only the rows that have a gradient are
 // written.
 int color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color, int32_t per_cam, const float* means,
               const float* viewmats, const float* coeffs_or_colors, const float* coeffs_rest, const int32_t* radii,

@@ -520,7 +520,8 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
     const float* __restrict__ scales, const float* __restrict__ opacities,
     const float* __restrict__ viewmats, const float* __restrict__ Ks, int32_t* __restrict__ radii,
     float* __restrict__ means2d, float* __restrict__ depths, float* __restrict__ comps,
-    float4* __restrict__ grec, uint32_t* __restrict__ zero_words, int n_zero, float4* __restrict__ lazy_rows) {
+    float4* __restrict__ grec, uint32_t* __restrict__ zero_words, int n_zero, float4* __restrict__ lazy_rows,
+    float2* __restrict__ abs_rows) {
     // scratch the NEXT kernels of the stream accumulate into (bucketing counters): cleared here, no memset launch
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0u;
@@ -541,6 +542,7 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
         }
         if (idx >= total) continue;
         if (P.touched) P.touched[idx] = 0;
+        if (abs_rows) abs_rows[idx] = make_float2(0.f, 0.f);      // the |mean2d gradient| rows the backward adds into
         const int cam_i = (int)(idx / P.n_gauss);
         const int g = (int)(idx - (int64_t)cam_i * P.n_gauss);
         const Cam cam = load_cam(viewmats + 16 * cam_i, Ks + 9 * cam_i);
@@ -1428,7 +1430,7 @@ extern "C" int misplat_project_pack_fwd(const misplat_params* p, const float* me
                                         const float* scales, const float* opacities, const float* viewmats,
                                         const float* Ks, int32_t* radii, float* means2d, float* depths,
                                         float* compensations, float* grec, uint32_t* zero_words, int32_t n_zero,
-                                        float* lazy_rows, misplat_stream_t stream) {
+                                        float* lazy_rows, float* abs_rows, misplat_stream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1 || p->width < 1 || p->height < 1) return MISPLAT_EINVAL;
     int64_t total = (int64_t)p->n_gauss * p->n_cams;
     if (n_zero < 0 || (n_zero > 0 && !zero_words)) return MISPLAT_EINVAL;
@@ -1436,7 +1438,7 @@ extern "C" int misplat_project_pack_fwd(const misplat_params* p, const float* me
     if (total > 0 && !opacities) return MISPLAT_EINVAL;
     hipLaunchKernelGGL(project_pack_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                        means, quats, scales, opacities, viewmats, Ks, radii, means2d, depths, compensations,
-                       (float4*)grec, zero_words, n_zero, (float4*)lazy_rows);
+                       (float4*)grec, zero_words, n_zero, (float4*)lazy_rows, (float2*)abs_rows);
     return check_launch();
 }
 

@@ -53,7 +53,7 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         if (!a->cell_count || !a->counters || n_zero < 4 || n_zero > (1 << 20)) return MISPLAT_EINVAL;
         rc = misplat_project_pack_fwd(p, a->means, a->quats, a->scales, a->opacities, a->viewmats, a->Ks, a->radii,
                                       a->means2d, a->depths, a->compensations, a->grec, a->cell_count, (int32_t)n_zero,
-                                      a->lazy_colour ? a->v_grec_zero : nullptr, stream);
+                                      a->lazy_colour ? a->v_grec_zero : nullptr, a->v_abs_zero, stream);
         if (rc != MISPLAT_OK) return rc;
         rc = misplat_bucket_count(p, a->means2d, a->radii, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count,
                                   a->counters, 1, stream);
@@ -282,49 +282,50 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
 
 // ---- the whole backward of rasterization(): compositing backward (atomic gradient rows), colour backward,
 // projection backward -- three launches, no memset when the forward left cleared gradient rows behind
-// A graph branch beside the compositing backward (VALU-bound for ~0.5 ms, the memory system idle): the dense output
+// In the background of the compositing backward (VALU-bound for ~0.5 ms, the memory system idle): the dense output
 // gradients of the per-Gaussian kernels -- 236 bytes per Gaussian, nine tenths of them zeros in a dense scene -- are
-// cleared there by a SMALL grid (a full-size fill takes the machine for 40 us and delays the compositing by as much; 128
-// workgroups trickle along, measured -15 .. -25 us per step at 1 M), and the two kernels then write only the rows that
-// have a gradient.  Needs the row flags (misplat_params.touched), one camera, 16 SH coefficients without Jacobian cache.
+// cleared by 512 extra one-wave workgroups at the END of that kernel's own grid (misplat_internal::FillList: they are
+// dispatched when the machine starts to drain), and the two kernels then write only the rows that have a gradient.
+// Measured on one box, 1 M / 1080p, ms per step, three alternating rounds: a small fill grid on a parallel graph branch
+// 1.092 (the branch's fork and join edges cost ~10 us each on the main branch: kernel timeline), workgroups at the
+// head of the grid 1.100 (512) / 1.085 (128) / 1.106 (2048), at the end 1.075 (512) / 1.077 (128).  Needs the row
+// flags (misplat_params.touched), one camera, 16 SH coefficients without Jacobian cache.
 static bool background_fill_ok(const misplat_params* p, const misplat_raster_bwd_args* b) {
     return p->touched && p->n_cams == 1 && p->n_gauss >= 262144 && b->sh_degree >= 0 && !b->sh_aux && b->K_or_D == 16 &&
            !b->v_means2d && b->v_means_dir && (b->colors_rest != nullptr) == (b->v_colors_rest != nullptr);
 }
 
-static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_args* b, hipStream_t s, const Fork* fork = nullptr) {
-    misplat_stream_t stream = (misplat_stream_t)s;
+static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_args* b, hipStream_t s) {
     misplat_params q = *p;
     q.unit_perm = b->unit_perm;
     q.unit_work = nullptr;
-    bool forked = false;
-    if (fork && background_fill_ok(p, b) && hipEventRecord(fork->forked, s) == hipSuccess &&
-        hipStreamWaitEvent(fork->side, fork->forked, 0) == hipSuccess) {
-        constexpr int kBg = 128;
+    // Dense scenes: the per-Gaussian backward kernels only write the rows that received a gradient (`touched`); the
+    // zeros of all the others are written in the background of the compositing backward (issue-bound, memory idle).
+    const bool background = background_fill_ok(p, b);
+    misplat_internal::FillList F = {};
+    if (background) {
         const int64_t n = p->n_gauss;
-        int rf = misplat_internal::zero_fill(b->v_colors, n * (b->colors_rest ? 3 : 48), kBg, fork->side);
-        if (rf == MISPLAT_OK && b->colors_rest) rf = misplat_internal::zero_fill(b->v_colors_rest, n * 45, kBg, fork->side);
-        if (rf == MISPLAT_OK) rf = misplat_internal::zero_fill(b->v_means_dir, n * 3, kBg, fork->side);
-        if (rf == MISPLAT_OK) rf = misplat_internal::zero_fill(b->v_means, n * 3, kBg, fork->side);
-        if (rf == MISPLAT_OK) rf = misplat_internal::zero_fill(b->v_quats, n * 4, kBg, fork->side);
-        if (rf == MISPLAT_OK) rf = misplat_internal::zero_fill(b->v_scales, n * 3, kBg, fork->side);
-        if (rf == MISPLAT_OK) rf = misplat_internal::zero_fill(b->v_opacities, n, kBg, fork->side);
-        if (rf != MISPLAT_OK) return rf;
-        forked = true;
+        auto add = [&](float* ptr, int64_t count) { F.p[F.count] = ptr; F.n[F.count] = count; F.count++; };
+        add(b->v_colors, n * (b->colors_rest ? 3 : 48));
+        if (b->colors_rest) add(b->v_colors_rest, n * 45);
+        add(b->v_means_dir, n * 3);
+        add(b->v_means, n * 3);
+        add(b->v_quats, n * 4);
+        add(b->v_scales, n * 3);
+        add(b->v_opacities, n);
     }
-    int rc = misplat_blend_bwd_atomic(&q, b->color_dim, b->Ks, b->grec, b->flatten_ids, b->offsets, b->n_isects, b->alpha,
-                                      b->last_ids, b->median_ids, b->render, b->v_render, b->v_alpha, b->v_exp_depth,
-                                      b->v_med_depth, b->v_normal, b->v_grec, b->v_abs, b->zero_flags, stream);
+    int rc = misplat_internal::blend_bwd_atomic(&q, b->color_dim, b->Ks, b->grec, b->flatten_ids, b->offsets, b->n_isects,
+                                                b->alpha, b->last_ids, b->median_ids, b->render, b->v_render, b->v_alpha,
+                                                b->v_exp_depth, b->v_med_depth, b->v_normal, b->v_grec, b->v_abs, b->zero_flags,
+                                                background ? &F : nullptr, s);
     if (rc != MISPLAT_OK) return rc;
-    if (forked && (hipEventRecord(fork->joined, fork->side) != hipSuccess || hipStreamWaitEvent(s, fork->joined, 0) != hipSuccess))
-        return MISPLAT_ELAUNCH;
     rc = misplat_internal::color_bwd(p, b->sh_degree, b->K_or_D, b->n_color, b->per_cam, b->means, b->viewmats, b->colors,
                                      b->colors_rest, b->radii, b->v_grec, b->v_colors, b->v_colors_rest, b->v_means_dir,
-                                     b->sh_aux, forked ? 1 : 0, s);
+                                     b->sh_aux, background ? 1 : 0, s);
     if (rc != MISPLAT_OK) return rc;
     return misplat_internal::project_pack_bwd(p, b->depth_slot, b->means, b->quats, b->scales, b->opacities, b->viewmats, b->Ks,
                                               b->radii, b->compensations, b->v_means2d, b->v_grec, b->v_means_dir, b->v_means,
-                                              b->v_quats, b->v_scales, b->v_opacities, forked ? 1 : 0, s);
+                                              b->v_quats, b->v_scales, b->v_opacities, background ? 1 : 0, s);
 }
 
 extern "C" int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
@@ -334,7 +335,7 @@ extern "C" int misplat_raster_bwd(const misplat_params* p, const misplat_raster_
     // memset nodes are kept out of graphs (see the note on phase A): only the memset-free form is captured
     const bool memset_free = (b->zero_flags & 1) && (!b->v_abs || (b->zero_flags & 2));
     if (!cache || !memset_free) return enqueue_backward(p, b, s);
-    return run_cached(cache, make_key(0x100, s, p, b), s, [&](hipStream_t st, const Fork* f) { return enqueue_backward(p, b, st, f); });
+    return run_cached(cache, make_key(0x100, s, p, b), s, [&](hipStream_t st, const Fork*) { return enqueue_backward(p, b, st); });
 }
 
 // float4 streaming copy: the measured HBM roof of the box the benchmark runs on (bench.py reports fractions of it

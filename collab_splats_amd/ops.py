@@ -689,7 +689,7 @@ def _lazy_colour_ok(P: Params, dev, deg: int, kd: int, n_color: int, want_grad: 
 
 def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg: int, kd: int,
                     n_color: int, per_cam: int, depth_channel: bool, want_aux: bool, want_grad: bool, defer: bool = False,
-                    lazy: bool = False, flags: bool = False):
+                    lazy: bool = False, flags: bool = False, absgrad: bool = False):
     """Allocations + phase A of misplat_raster_fwd (``defer``: phase A is launched together with B, by _raster_phase_b).
     Returns (radii, means2d, depths, comps, grec, sh_aux, state)."""
     lib = _lib.load()
@@ -700,6 +700,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     n_cells, n_blocks = bucket_plan(P)
     means2d, depths, comps, grec, sh_aux = _carve_f(dev, (2 * rows, rows, rows, MISPLAT_REC * rows, 12 * rows if want_aux else 0))
     v_grec_zero = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32) if want_grad else None
+    v_abs_zero = torch.empty(rows, 2, device=dev, dtype=torch.float32) if (want_grad and absgrad) else None
     # (counters directly behind cell_count: the projection kernel clears that contiguous range, no memset launch)
     radii, tiles_per_gauss, rect2, cellhist, cell_count, counters, cell_offs, order, rect_sorted, tile_count, touched = _carve(
         dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, 4, n_cells + 1, rows, 2 * rows, n_tiles + 1,
@@ -718,6 +719,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     a.radii, a.means2d, a.depths, a.compensations, a.grec = _dp(radii), _dp(means2d), _dp(depths), _dp(comps), _dp(grec)
     a.sh_aux = _dp(sh_aux) if want_aux else None
     a.v_grec_zero = _dp(v_grec_zero)
+    a.v_abs_zero = _dp(v_abs_zero)
     a.tiles_per_gauss, a.rect2, a.cellhist, a.cell_count = _dp(tiles_per_gauss), _dp(rect2), _dp(cellhist), _dp(cell_count)
     a.cell_offs, a.order, a.counters, a.tile_count = _dp(cell_offs), _dp(order), _dp(counters), _dp(tile_count)
     a.rect_sorted = _dp(rect_sorted)
@@ -729,7 +731,8 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     if not defer:
         check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
               "misplat_raster_fwd(A)")
-    state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero, deferred=defer,
+    state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero, v_abs_zero=v_abs_zero,
+                 deferred=defer,
                  counters=counters, touched=touched,
                  keep=(rect2, cellhist, cell_count, cell_offs, order, counters, tile_count, radii))
     return (radii.view(Cn, N, 2), means2d.view(Cn, N, 2), depths.view(Cn, N), comps.view(Cn, N), grec.view(rows, MISPLAT_REC),
@@ -805,7 +808,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         if sched.ppl_b == sched.ppl_f:
             sched.perm_bwd = sched.perm
     bins = dict(tiles_per_gauss=state["tiles_per_gauss"], n_isects=cap if static else n_known, depths=state["depths"],
-                tile_ids=None, v_grec_zero=state.get("v_grec_zero"),
+                tile_ids=None, v_grec_zero=state.get("v_grec_zero"), v_abs_zero=state.get("v_abs_zero"),
                 n_isects_dev=state["counters"].view(torch.int64)[0] if static else None,
                 n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:cap if static else n_known],
                 isect_offsets=offsets[:n_tiles + 1], _keep=(scratch, payload))
@@ -848,7 +851,7 @@ class _RasterFused(torch.autograd.Function):
         defer = _STATIC_CAP is not None or (MERGE_PHASES and SPECULATE and _cap_key(P, means.device) in _CAP_HINT)
         radii, means2d, depths, comps, grec, sh_aux, state = _raster_phase_a(
             P, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam, depth_channel,
-            want_aux, want_grad, defer=defer, lazy=lazy, flags=True)
+            want_aux, want_grad, defer=defer, lazy=lazy, flags=True, absgrad=bool(absgrad))
         imgs, bins, sched = _raster_phase_b(P, state, cd)
         render, alpha, exp_depth, med_depth, normal, last_ids, median_ids = imgs
         extra["bins"] = bins
@@ -884,7 +887,9 @@ class _RasterFused(torch.autograd.Function):
             v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
         v_abs = None
         if ctx.absgrad:
-            v_abs = torch.zeros(rows, 2, device=dev, dtype=torch.float32)
+            v_abs = bins.pop("v_abs_zero", None)                # cleared by the forward's projection kernel
+            if v_abs is None:
+                v_abs = torch.zeros(rows, 2, device=dev, dtype=torch.float32)
             flags |= 2
         v_colors = _grad_out(colors)
         v_colors_rest = _grad_out(colors_rest) if colors_rest is not None else None
@@ -1026,7 +1031,7 @@ class _ProjectPack(torch.autograd.Function):
         grec = torch.empty(Cn * N, MISPLAT_REC, device=dev, dtype=torch.float32)
         check(lib.misplat_project_pack_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
                                            ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
-                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), ptr(None), stream_ptr()),
+                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), ptr(None), ptr(None), stream_ptr()),
               "misplat_project_pack_fwd")
         if prebin is not None:                         # count tiles + start the n_isects read-back before the colours
             prebin["pending"] = start_binning(P, means2d, radii)
@@ -1249,7 +1254,7 @@ class _ProjectPackX(torch.autograd.Function):
         featx = torch.empty(Cn * N, 4 * nxq, device=dev, dtype=torch.float32)
         check(lib.misplat_project_pack_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
                                            ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
-                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), ptr(None), stream_ptr()),
+                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), ptr(None), ptr(None), stream_ptr()),
               "misplat_project_pack_fwd")
         D, per_cam = colors.shape[-1], int(colors.dim() == 3)
         check(lib.misplat_color_fwd_x(C.byref(P), C.c_int32(D), C.c_int32(per_cam), C.c_int32(int(depth_channel)),

@@ -131,6 +131,8 @@ int misplat_project_pack_fwd(const misplat_params* p, const float* means, const 
                              successors on the stream (the bucketing counters): saves a memset launch */,
                              float* lazy_rows /* or NULL.  Given (v_grec-shaped, [C*N,16]): on-demand colours -- the colour
                              slots of grec are left UNSET for misplat_blend_fwd_lazy, and these gradient rows are cleared */,
+                             float* abs_rows /* or NULL: v_abs-shaped rows [C*N,2] cleared for the compositing backward
+                             (misplat_blend_bwd_atomic, v_grec_is_zero bit 1): saves that memset launch */,
                              misplat_stream_t stream);
 /* coeffs_rest (SH only, may be NULL): when given, coeffs_or_colors is features_dc[N,3] and
  * coeffs_rest is features_rest[N,K-1,3] -- the reference's two parameter tensors
@@ -433,7 +435,7 @@ typedef struct misplat_raster_args {
     uint32_t* scratch;
     int64_t cap_isects;
     int64_t* n_isects_host; /* pinned host memory, or NULL */
-    void* reserved1;
+    float* v_abs_zero; /* or NULL: |mean2d gradient| rows [C*N,2] cleared by the projection kernel */
     /* images */
     float *render, *alpha, *exp_depth, *med_depth, *normal;
     int32_t *last_ids, *median_ids;
