@@ -46,13 +46,13 @@ struct BandCtx {
 template <int PPL>
 __device__ __forceinline__ bool band_ctx(const misplat_params& P, const float* __restrict__ Ks,
                                          const int32_t* __restrict__ offsets, int64_t n_isects,
-                                         BandCtx& c) {
+                                         BandCtx& c, int first_block = 0) {
     constexpr int WPT = 4 / PPL;
     const int tiles_per_cam = P.tile_w * P.tile_h;
     const int total_tiles = tiles_per_cam * P.n_cams;
     const int total = total_tiles * WPT;
     const int per_xcd = (total + 7) >> 3;
-    const int b = blockIdx.x;
+    const int b = (int)blockIdx.x - first_block;         // (first_block: a multiple of 8, the XCD of a unit stays)
     int unit = (b & 7) * per_xcd + (b >> 3);
     if (P.unit_perm) unit = P.unit_perm[b];      // caller-supplied launch order (longest first); the grid has exactly
                                                  // 8 * ceil(total / 8) workgroups = entries of unit_perm (padding: total)
@@ -529,10 +529,10 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
     int n_channels = CD, misplat_internal::FillList F = {}) {
     static_assert(NXQ == 0 || ATOMIC, "N-D colours: atomic gradient mode only");
     // Background role (F.blocks > 0): the last workgroups of the grid -- dispatched when the machine starts to drain --
-    // clear the tensors the per-Gaussian backward kernels write sparsely afterwards: memory-bound waves beside this
-    // kernel's issue-bound ones, no launch, no graph branch.
-    const int fill_b = (int)blockIdx.x - ((int)gridDim.x - F.blocks);
-    if (F.blocks > 0 && fill_b >= 0) {
+    // or (at_head: fills too large for the tail) the first ones clear the tensors the per-Gaussian backward kernels write
+    // sparsely afterwards: memory-bound waves beside this kernel's issue-bound ones, no launch, no graph branch.
+    const int fill_b = F.at_head ? (int)blockIdx.x : (int)blockIdx.x - ((int)gridDim.x - F.blocks);
+    if (F.blocks > 0 && fill_b >= 0 && fill_b < F.blocks) {
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
         for (int ch = 0; ch < NX; ch++) vcolx[k][ch] = 0.f;
     const size_t rstride = NXQ > 0 ? (size_t)n_channels : (size_t)CD;
     BandCtx c;
-    if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c)) return;
+    if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c, F.at_head ? F.blocks : 0)) return;
     if (c.end <= c.beg) return;
     const int lane = threadIdx.x;
     const int x = c.tx * MISPLAT_TILE + (lane & 15);
@@ -1547,9 +1547,11 @@ extern "C" int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, con
     return check_launch();
 }
 
-// misplat_blend_bwd_atomic + background fills (internal.h): 512 one-wave workgroups behind the last unit of the grid
-// (placement and count measured: see enqueue_backward in raster.hip).
+// misplat_blend_bwd_atomic + background fills (internal.h): 512 one-wave workgroups (a multiple of 8: the unit -> XCD map
+// stays) behind the last unit of the grid, or in front of the first one when the fill is too large to hide in the
+// kernel's tail (placement and count measured: see enqueue_backward in raster.hip).
 constexpr int kFillBlocks = 512;
+constexpr int64_t kFillHeadRows = 2500000;
 int misplat_internal::blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks, const float* grec,
                                        const int32_t* flatten_ids, const int32_t* offsets, int64_t n_isects,
                                        const float* alpha, const int32_t* last_ids, const int32_t* median_ids,
@@ -1573,6 +1575,7 @@ int misplat_internal::blend_bwd_atomic(const misplat_params* p, int32_t color_di
         if (in_kernel) {
             F = *fills;
             F.blocks = kFillBlocks;
+            F.at_head = (int64_t)rows >= kFillHeadRows;
         } else {
             for (int k = 0; k < fills->count; k++) {
                 const int rf = zero_fill(fills->p[k], fills->n[k], 0, s);

@@ -12,12 +12,13 @@ namespace misplat_internal {
 // machine away from it.
 int zero_fill(float* dst, int64_t n_floats, int max_blocks, hipStream_t s);
 
-// Tensors to clear "in the background" of a compute-bound kernel: the last `blocks` workgroups (64 threads each) of that
-// kernel's grid write the zeros, the others do the kernel's own work.  n[k] floats at p[k] (16-byte aligned).
+// Tensors to clear "in the background" of a compute-bound kernel: the last (at_head: the first) `blocks` workgroups (64
+// threads each) of that kernel's grid write the zeros, the others do the kernel's own work.  n[k] floats at p[k]
+// (16-byte aligned).  blocks / at_head are chosen by the kernel's launcher.
 struct FillList {
     float* p[8];
     int64_t n[8];
-    int count, blocks;
+    int count, blocks, at_head;
 };
 
 // misplat_blend_bwd_atomic that also clears the tensors of `fills` (or NULL) -- inside the compositing kernel's own grid

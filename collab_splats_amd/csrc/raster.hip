@@ -288,8 +288,10 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
 // dispatched when the machine starts to drain), and the two kernels then write only the rows that have a gradient.
 // Measured on one box, 1 M / 1080p, ms per step, three alternating rounds: a small fill grid on a parallel graph branch
 // 1.092 (the branch's fork and join edges cost ~10 us each on the main branch: kernel timeline), workgroups at the
-// head of the grid 1.100 (512) / 1.085 (128) / 1.106 (2048), at the end 1.075 (512) / 1.077 (128).  Needs the row
-// flags (misplat_params.touched), one camera, 16 SH coefficients without Jacobian cache.
+// head of the grid 1.100 (512) / 1.085 (128) / 1.106 (2048), at the end 1.075 (512) / 1.077 (128).  At 5 M (1.18 GB
+// of zeros, model step) the tail is too short for them: end 2.478 (512) / 2.492 (2048), head 2.448 (512) -- so the
+// launcher puts them in front from 2.5 M rows.  Needs the row flags (misplat_params.touched), one camera, 16 SH
+// coefficients without Jacobian cache.
 static bool background_fill_ok(const misplat_params* p, const misplat_raster_bwd_args* b) {
     return p->touched && p->n_cams == 1 && p->n_gauss >= 262144 && b->sh_degree >= 0 && !b->sh_aux && b->K_or_D == 16 &&
            !b->v_means2d && b->v_means_dir && (b->colors_rest != nullptr) == (b->v_colors_rest != nullptr);

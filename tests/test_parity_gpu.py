@@ -1273,6 +1273,26 @@ def test_on_demand_colours_equal_the_colour_kernel(dev, N, W, H, scale_mul):
             assert rel_err(a, b) < 2e-5, (k, rel_err(a, b))
 
 
+def test_background_fill_and_sparse_backward_equal_the_dense_backward(dev):
+    """From 262 144 Gaussians the fused node's backward writes only the rows the compositing backward flagged, over
+    zeros that extra workgroups of the compositing kernel's own grid wrote into the (uninitialised) gradient tensors:
+    every row without a gradient must be exactly zero -- the allocator is seeded with NaNs first -- and the others equal
+    the dense per-Gaussian backward of the two-node form (no row flags) up to the order of the atomic sums."""
+    args = _bench_like_scene(dev, 300_000, 640, 360, seed=9, scale_mul=1.5)
+    ref_img, ref_grad, _ = _fwd_bwd(args, FUSED_NODE=False)
+    for rep in range(3):                                       # (capacity hint, merged phases, graph replay; lazy colours once dense)
+        poison = [torch.full((300_000 * 48 + 64 * k,), float("nan"), device=dev) for k in range(4)]
+        del poison                                             # the next allocations of this size come back full of NaNs
+        img, grad, _ = _fwd_bwd(args)
+        for a, b in zip(img, ref_img):
+            assert torch.equal(a, b)
+        for k, (a, b) in enumerate(zip(grad, ref_grad)):
+            assert torch.isfinite(a).all(), (rep, k)
+            assert rel_err(a, b) < 2e-5, (rep, k, rel_err(a, b))
+            dead = b.reshape(b.shape[0], -1).abs().sum(1) == 0
+            assert bool(dead.any()) and float(a.reshape(a.shape[0], -1)[dead].abs().sum()) == 0.0, (rep, k)
+
+
 def test_two_node_form_backpropagates_a_loss_on_projection_outputs(dev, monkeypatch):
     """MISPLAT_FUSED_NODE=0: the projection's own outputs in ``meta`` are differentiable, and a loss on them reaches the
     projection backward WITHOUT passing the compositing kernels -- the `touched` row flags (set by the compositing
