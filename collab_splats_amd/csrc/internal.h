@@ -29,16 +29,12 @@ int blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks
                      const float* v_exp_depth, const float* v_med_depth, const float* v_normal, float* v_grec, float* v_abs,
                      int32_t v_grec_is_zero, const FillList* fills, hipStream_t s);
 
-// misplat_color_bwd / misplat_project_pack_bwd with one more piece of knowledge: outputs_zero != 0 -- every output
-// gradient tensor has already been cleared (FillList above), only the rows that have a gradient are
-// written.
-int color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color, int32_t per_cam, const float* means,
-              const float* viewmats, const float* coeffs_or_colors, const float* coeffs_rest, const int32_t* radii,
-              const float* v_grec, float* v_coeffs_or_colors, float* v_coeffs_rest, float* v_means_dir, const float* sh_aux,
-              int outputs_zero, hipStream_t s);
-int project_pack_bwd(const misplat_params* p, int32_t depth_slot, const float* means, const float* quats, const float* scales,
-                     const float* opacities, const float* viewmats, const float* Ks, const int32_t* radii,
-                     const float* compensations, const float* v_means2d, const float* v_grec, const float* v_means_dir,
-                     float* v_means, float* v_quats, float* v_scales, float* v_opacities, int outputs_zero, hipStream_t s);
+// color_bwd + project_pack_bwd of the rows flagged in misplat_params.touched as ONE launch: one camera, SH colours
+// (16 coefficients, no Jacobian cache), no separate mean2d gradient, every output cleared beforehand (FillList above).
+// The SH direction gradient stays in registers: no v_means_dir.
+int gauss_bwd_sparse(const misplat_params* p, int32_t sh_degree, int32_t depth_slot, const float* means, const float* quats,
+                     const float* scales, const float* opacities, const float* viewmats, const float* Ks, const float* coeffs,
+                     const float* coeffs_rest, const float* compensations, const float* v_grec, float* v_coeffs,
+                     float* v_coeffs_rest, float* v_means, float* v_quats, float* v_scales, float* v_opacities, hipStream_t s);
 
 }  // namespace misplat_internal

@@ -1095,83 +1095,75 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float4* __restrict__ dst
     if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail[threadIdx.x] = 0.f;
 }
 
-// zero_blocks > 0 ([N,16,3] layout with `touched` flags only): the first zero_blocks workgroups clear the rows whose flag
-// is NOT set (and all of v_means_dir's dead rows) while the others compute the flagged rows -- the two halves touch
-// disjoint rows, so they need no order and run side by side instead of one behind the other.
 constexpr int kFlagStep = 512;          // rows a wave of the sparse backward kernels scans per step (8 flag bytes per lane)
+
+// SH backward of one row whose colour gradient is non-zero (no Jacobian cache): coefficients in, the clamp from a
+// re-evaluation, the coefficient gradient row out; dir[3] = the gradient that reaches the mean through the view direction.
+template <bool SPLIT>
+__device__ __forceinline__ void sh_bwd_row(int deg, int g, float ccx, float ccy, float ccz, const float* __restrict__ means,
+                                           const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest,
+                                           const float* __restrict__ v_grec, float* __restrict__ v_coeffs,
+                                           float* __restrict__ v_coeffs_rest, float (&dir)[3]) {
+    const float* vg = v_grec + (size_t)g * MISPLAT_REC + 12;
+    const float vg0 = vg[0], vg1 = vg[1], vg2 = vg[2];
+    const float dx = means[3 * g] - ccx, dy = means[3 * g + 1] - ccy, dz = means[3 * g + 2] - ccz;
+    const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float inv = n > 0.f ? 1.0f / n : 0.f;
+    const float x = dx * inv, y = dy * inv, z = dz * inv;
+    float cf[48];
+    if (!SPLIT) {
+        const float4* s4 = reinterpret_cast<const float4*>(coeffs + (size_t)g * 48);
+#pragma unroll
+        for (int u = 0; u < 12; u++) { const float4 v = s4[u]; cf[4 * u] = v.x; cf[4 * u + 1] = v.y; cf[4 * u + 2] = v.z; cf[4 * u + 3] = v.w; }
+    } else {
+        cf[0] = coeffs[3 * (size_t)g]; cf[1] = coeffs[3 * (size_t)g + 1]; cf[2] = coeffs[3 * (size_t)g + 2];
+        const float* sr = coeffs_rest + (size_t)g * 45;
+#pragma unroll
+        for (int u = 0; u < 45; u++) cf[3 + u] = sr[u];
+    }
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    float J[9];
+    sh_eval<false>(deg, x, y, z, cf, c0, c1, c2, J);
+    const float vc0 = (c0 + 0.5f > 0.f) ? vg0 : 0.f, vc1 = (c1 + 0.5f > 0.f) ? vg1 : 0.f, vc2 = (c2 + 0.5f > 0.f) ? vg2 : 0.f;
+    float vd0 = 0.f, vd1 = 0.f, vd2 = 0.f;
+    misplat_sh::sh_grad<false>(deg, x, y, z, cf, vc0, vc1, vc2, vd0, vd1, vd2, nullptr);
+    const int nb = (deg + 1) * (deg + 1);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (k >= nb) { cf[3 * k] = 0.f; cf[3 * k + 1] = 0.f; cf[3 * k + 2] = 0.f; }       // above the active degree
+    if (!SPLIT) {
+        float4* o4 = reinterpret_cast<float4*>(v_coeffs + (size_t)g * 48);
+#pragma unroll
+        for (int u = 0; u < 12; u++) o4[u] = make_float4(cf[4 * u], cf[4 * u + 1], cf[4 * u + 2], cf[4 * u + 3]);
+    } else {
+        v_coeffs[3 * (size_t)g] = cf[0]; v_coeffs[3 * (size_t)g + 1] = cf[1]; v_coeffs[3 * (size_t)g + 2] = cf[2];
+        float* orr = v_coeffs_rest + (size_t)g * 45;
+#pragma unroll
+        for (int u = 0; u < 45; u++) orr[u] = cf[3 + u];
+    }
+    const float dot = x * vd0 + y * vd1 + z * vd2;
+    dir[0] = (vd0 - x * dot) * inv; dir[1] = (vd1 - y * dot) * inv; dir[2] = (vd2 - z * dot) * inv;
+}
 
 template <bool SPLIT>
 __global__ __launch_bounds__(64) void color_sh_bwd_sparse_kernel(
     misplat_params P, int deg, const float* __restrict__ means, const float* __restrict__ viewmats,
     const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest, const int32_t* __restrict__ radii,
     const float* __restrict__ v_grec, float* __restrict__ v_coeffs, float* __restrict__ v_coeffs_rest,
-    float* __restrict__ v_means_dir, int zero_blocks) {
+    float* __restrict__ v_means_dir) {
     __shared__ int queue[128];
     const int lane = threadIdx.x;
-    // (the live workgroups come first in the grid: they are few and long, the zero workgroups fill the machine around them)
-    const int n_live_blocks = (int)gridDim.x - zero_blocks;
-    if (!SPLIT && (int)blockIdx.x >= n_live_blocks) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4* d4 = reinterpret_cast<float4*>(v_coeffs);
-        const int64_t n4 = (int64_t)P.n_gauss * 12;
-        for (int64_t e4 = (int64_t)((int)blockIdx.x - n_live_blocks) * 64 + lane; e4 < n4; e4 += (int64_t)zero_blocks * 64) {
-            const int64_t row = e4 / 12;
-            if (P.touched[row] == 0) {
-                d4[e4] = z;
-                if (e4 - row * 12 < 3) v_means_dir[3 * row + (int)(e4 - row * 12)] = 0.f;
-            }
-        }
-        return;
-    }
     const int live_block = (int)blockIdx.x;
-    const int live_grid = n_live_blocks;
+    const int live_grid = (int)gridDim.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float* V = viewmats;
     const float ccx = -(V[0] * V[3] + V[4] * V[7] + V[8] * V[11]);
     const float ccy = -(V[1] * V[3] + V[5] * V[7] + V[9] * V[11]);
     const float ccz = -(V[2] * V[3] + V[6] * V[7] + V[10] * V[11]);
-    // the gradient of one row (its colour gradient is non-zero): coefficients in, gradient row out, in place
     auto heavy = [&](int g) {
-        const float* vg = v_grec + (size_t)g * MISPLAT_REC + 12;
-        const float vg0 = vg[0], vg1 = vg[1], vg2 = vg[2];
-        const float dx = means[3 * g] - ccx, dy = means[3 * g + 1] - ccy, dz = means[3 * g + 2] - ccz;
-        const float n = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float inv = n > 0.f ? 1.0f / n : 0.f;
-        const float x = dx * inv, y = dy * inv, z = dz * inv;
-        float cf[48];
-        if (!SPLIT) {
-            const float4* s4 = reinterpret_cast<const float4*>(coeffs + (size_t)g * 48);
-#pragma unroll
-            for (int u = 0; u < 12; u++) { const float4 v = s4[u]; cf[4 * u] = v.x; cf[4 * u + 1] = v.y; cf[4 * u + 2] = v.z; cf[4 * u + 3] = v.w; }
-        } else {
-            cf[0] = coeffs[3 * (size_t)g]; cf[1] = coeffs[3 * (size_t)g + 1]; cf[2] = coeffs[3 * (size_t)g + 2];
-            const float* sr = coeffs_rest + (size_t)g * 45;
-#pragma unroll
-            for (int u = 0; u < 45; u++) cf[3 + u] = sr[u];
-        }
-        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-        float J[9];
-        sh_eval<false>(deg, x, y, z, cf, c0, c1, c2, J);
-        const float vc0 = (c0 + 0.5f > 0.f) ? vg0 : 0.f, vc1 = (c1 + 0.5f > 0.f) ? vg1 : 0.f, vc2 = (c2 + 0.5f > 0.f) ? vg2 : 0.f;
-        float vd0 = 0.f, vd1 = 0.f, vd2 = 0.f;
-        misplat_sh::sh_grad<false>(deg, x, y, z, cf, vc0, vc1, vc2, vd0, vd1, vd2, nullptr);
-        const int nb = (deg + 1) * (deg + 1);
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (k >= nb) { cf[3 * k] = 0.f; cf[3 * k + 1] = 0.f; cf[3 * k + 2] = 0.f; }       // above the active degree
-        if (!SPLIT) {
-            float4* o4 = reinterpret_cast<float4*>(v_coeffs + (size_t)g * 48);
-#pragma unroll
-            for (int u = 0; u < 12; u++) o4[u] = make_float4(cf[4 * u], cf[4 * u + 1], cf[4 * u + 2], cf[4 * u + 3]);
-        } else {
-            v_coeffs[3 * (size_t)g] = cf[0]; v_coeffs[3 * (size_t)g + 1] = cf[1]; v_coeffs[3 * (size_t)g + 2] = cf[2];
-            float* orr = v_coeffs_rest + (size_t)g * 45;
-#pragma unroll
-            for (int u = 0; u < 45; u++) orr[u] = cf[3 + u];
-        }
-        const float dot = x * vd0 + y * vd1 + z * vd2;
-        v_means_dir[3 * g] = (vd0 - x * dot) * inv; v_means_dir[3 * g + 1] = (vd1 - y * dot) * inv;
-        v_means_dir[3 * g + 2] = (vd2 - z * dot) * inv;
+        float dir[3];
+        sh_bwd_row<SPLIT>(deg, g, ccx, ccy, ccz, means, coeffs, coeffs_rest, v_grec, v_coeffs, v_coeffs_rest, dir);
+        v_means_dir[3 * g] = dir[0]; v_means_dir[3 * g + 1] = dir[1]; v_means_dir[3 * g + 2] = dir[2];
     };
     int qn = 0;
     auto push = [&](bool live, int g) {
@@ -1224,6 +1216,41 @@ __global__ __launch_bounds__(64) void color_sh_bwd_sparse_kernel(
     if (lane < qn) heavy(queue[lane]);
 }
 
+// Projection backward of one row from its packed gradient row; dir[3]: what already reached the mean (the SH direction
+// gradient), the start value of the mean's gradient.
+__device__ __forceinline__ void pp_bwd_row(const misplat_params& P, const Cam& cam, int depth_slot, int g,
+                                           const float* __restrict__ means, const float* __restrict__ quats,
+                                           const float* __restrict__ scales, const float* __restrict__ opacities,
+                                           const float* __restrict__ comps, const float* __restrict__ v_means2d,
+                                           const float* __restrict__ v_grec, const float (&dir)[3], float* __restrict__ v_means,
+                                           float* __restrict__ v_quats, float* __restrict__ v_scales,
+                                           float* __restrict__ v_opacities) {
+    float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
+    float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
+    float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
+    const float opac = opacities[g];
+    float o_m[3] = {dir[0], dir[1], dir[2]}, o_q[4] = {0.f, 0.f, 0.f, 0.f}, o_s[3] = {0.f, 0.f, 0.f};
+    float o_op = 0.f;
+    const float4* vg = reinterpret_cast<const float4*>(v_grec + (size_t)g * MISPLAT_REC);
+    const float4 g0 = vg[0], g1 = vg[1], g2 = vg[2], g3 = vg[3];
+    ProjGrads G;
+    G.v_m2d[0] = v_means2d ? v_means2d[2 * g] : g0.x;
+    G.v_m2d[1] = v_means2d ? v_means2d[2 * g + 1] : g0.y;
+    G.v_conic[0] = g0.z; G.v_conic[1] = g0.w; G.v_conic[2] = g1.x;
+    const float v_oeff = g1.y;
+    G.v_rt = g1.z; G.v_rp[0] = g1.w; G.v_rp[1] = g2.x;
+    G.v_nr[0] = g2.y; G.v_nr[1] = g2.z; G.v_nr[2] = g2.w;
+    G.v_depth = depth_slot == 12 ? g3.x : (depth_slot == 13 ? g3.y : (depth_slot == 14 ? g3.z : (depth_slot == 15 ? g3.w : 0.f)));
+    if (P.antialiased) { o_op += v_oeff * comps[g]; G.v_comp = v_oeff * opac; }
+    else { o_op += v_oeff; G.v_comp = 0.f; }
+    project_bwd_one(mean, quat, sc, cam, P, G, o_m, o_q, o_s);
+#pragma unroll
+    for (int k = 0; k < 3; k++) { v_means[3 * g + k] = o_m[k]; v_scales[3 * g + k] = o_s[k]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) v_quats[4 * g + k] = o_q[k];
+    v_opacities[g] = o_op;
+}
+
 // One camera: most rows of a dense scene never receive a gradient -- the compositing stops at the first opaque layers,
 // and the packed gradient row of a Gaussian behind them is still the zeros the forward left (1 M random Gaussians at
 // 1080p: 11 % of the visible rows get one, at 5 M 2 %; scripts/touched_fraction.py).  A zero row in gives a zero row out,
@@ -1236,86 +1263,18 @@ __global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
     const float* __restrict__ viewmats, const float* __restrict__ Ks, const int32_t* __restrict__ radii,
     const float* __restrict__ comps, const float* __restrict__ v_means2d, const float* __restrict__ v_grec,
     const float* __restrict__ v_means_dir, float* __restrict__ v_means, float* __restrict__ v_quats,
-    float* __restrict__ v_scales, float* __restrict__ v_opacities, int zero_blocks) {
+    float* __restrict__ v_scales, float* __restrict__ v_opacities) {
     __shared__ int queue[128];
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     int qn = 0;
-    // zero_blocks > 0 (`touched` flags given, no separate mean2d gradient): the LAST zero_blocks workgroups clear the
-    // outputs of the rows whose flag is not set while the first ones compute the flagged rows (disjoint rows, no order
-    // needed: side by side instead of one scan doing both).  A dead row's SH direction gradient is zero as well.
-    // zero_blocks < 0: the outputs were cleared beforehand (a background fill beside the compositing backward): flagged
-    // rows only, nobody clears anything here.
-    const int n_live_blocks = (int)gridDim.x - (zero_blocks > 0 ? zero_blocks : 0);
-    if ((int)blockIdx.x >= n_live_blocks) {
-        for (int64_t g = (int64_t)((int)blockIdx.x - n_live_blocks) * 64 + lane; g < P.n_gauss; g += (int64_t)zero_blocks * 64) {
-            if (P.touched[g] != 0) continue;
-            v_means[3 * g] = 0.f; v_means[3 * g + 1] = 0.f; v_means[3 * g + 2] = 0.f;
-            v_scales[3 * g] = 0.f; v_scales[3 * g + 1] = 0.f; v_scales[3 * g + 2] = 0.f;
-            *reinterpret_cast<float4*>(v_quats + 4 * (size_t)g) = make_float4(0.f, 0.f, 0.f, 0.f);
-            v_opacities[g] = 0.f;
-        }
-        return;
-    }
     const Cam cam = load_cam(viewmats, Ks);
     auto heavy = [&](int g) {
-        float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
-        float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
-        float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
-        const float opac = opacities[g];
-        float o_m[3] = {0.f, 0.f, 0.f}, o_q[4] = {0.f, 0.f, 0.f, 0.f}, o_s[3] = {0.f, 0.f, 0.f};
-        float o_op = 0.f;
-        if (v_means_dir) { o_m[0] = v_means_dir[3 * g]; o_m[1] = v_means_dir[3 * g + 1]; o_m[2] = v_means_dir[3 * g + 2]; }
-        const float4* vg = reinterpret_cast<const float4*>(v_grec + (size_t)g * MISPLAT_REC);
-        const float4 g0 = vg[0], g1 = vg[1], g2 = vg[2], g3 = vg[3];
-        ProjGrads G;
-        G.v_m2d[0] = v_means2d ? v_means2d[2 * g] : g0.x;
-        G.v_m2d[1] = v_means2d ? v_means2d[2 * g + 1] : g0.y;
-        G.v_conic[0] = g0.z; G.v_conic[1] = g0.w; G.v_conic[2] = g1.x;
-        const float v_oeff = g1.y;
-        G.v_rt = g1.z; G.v_rp[0] = g1.w; G.v_rp[1] = g2.x;
-        G.v_nr[0] = g2.y; G.v_nr[1] = g2.z; G.v_nr[2] = g2.w;
-        G.v_depth = depth_slot == 12 ? g3.x : (depth_slot == 13 ? g3.y : (depth_slot == 14 ? g3.z : (depth_slot == 15 ? g3.w : 0.f)));
-        if (P.antialiased) { o_op += v_oeff * comps[g]; G.v_comp = v_oeff * opac; }
-        else { o_op += v_oeff; G.v_comp = 0.f; }
-        project_bwd_one(mean, quat, sc, cam, P, G, o_m, o_q, o_s);
-#pragma unroll
-        for (int k = 0; k < 3; k++) { v_means[3 * g + k] = o_m[k]; v_scales[3 * g + k] = o_s[k]; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) v_quats[4 * g + k] = o_q[k];
-        v_opacities[g] = o_op;
+        float dir[3] = {0.f, 0.f, 0.f};
+        if (v_means_dir) { dir[0] = v_means_dir[3 * g]; dir[1] = v_means_dir[3 * g + 1]; dir[2] = v_means_dir[3 * g + 2]; }
+        pp_bwd_row(P, cam, depth_slot, g, means, quats, scales, opacities, comps, v_means2d, v_grec, dir, v_means, v_quats, v_scales,
+                   v_opacities);
     };
-    if (zero_blocks != 0) {
-        // flags 8 at a time per lane (one load covers kFlagStep rows of the wave), the ballots run from registers
-        for (int64_t base = (int64_t)blockIdx.x * kFlagStep; base < P.n_gauss; base += (int64_t)n_live_blocks * kFlagStep) {
-            const int64_t r0 = base + 8 * lane;
-            unsigned long long lo = 0ull;
-            if (r0 + 8 <= P.n_gauss) lo = *reinterpret_cast<const unsigned long long*>(P.touched + r0);
-            else
-                for (int b = 0; b < 8; b++)
-                    if (r0 + b < P.n_gauss) lo |= (unsigned long long)P.touched[r0 + b] << (8 * b);
-            if (__ballot(lo != 0ull) == 0ull) continue;
-#pragma unroll 1
-            for (int b = 0; b < 8; b++) {
-                const bool live = (lo & 0xffull) != 0ull;
-                const unsigned long long mask = __ballot(live);
-                if (live) queue[qn + __popcll(mask & lt)] = (int)(r0 + b);
-                qn += __popcll(mask);
-                __builtin_amdgcn_wave_barrier();
-                if (qn >= 64) {
-                    const int gq = queue[lane];
-                    const int keep = lane + 64 < qn ? queue[lane + 64] : 0;
-                    __builtin_amdgcn_wave_barrier();
-                    queue[lane] = keep;
-                    qn -= 64;
-                    heavy(gq);
-                }
-                lo >>= 8;
-            }
-        }
-        if (lane < qn) heavy(queue[lane]);
-        return;
-    }
     for (int base = blockIdx.x * 64; base < P.n_gauss; base += gridDim.x * 64) {
         const int g = base + lane;
         bool live = false;
@@ -1349,6 +1308,61 @@ __global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
             queue[lane] = keep;
             qn -= 64;
             heavy(gq);
+        }
+    }
+    if (lane < qn) heavy(queue[lane]);
+}
+
+// Both per-Gaussian backward stages of the flagged rows in ONE launch (outputs cleared beforehand, one camera, SH colours
+// without Jacobian cache): one scan of the flags, one queue, and a row's SH direction gradient goes from the SH stage to
+// the projection stage in registers (no v_means_dir round trip, one launch and one dependent scan less).
+template <bool SPLIT>
+__global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
+    misplat_params P, int deg, int depth_slot, const float* __restrict__ means, const float* __restrict__ quats,
+    const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ viewmats,
+    const float* __restrict__ Ks, const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest,
+    const float* __restrict__ comps, const float* __restrict__ v_grec, float* __restrict__ v_coeffs,
+    float* __restrict__ v_coeffs_rest, float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
+    float* __restrict__ v_opacities) {
+    __shared__ int queue[128];
+    const int lane = threadIdx.x;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const float* V = viewmats;
+    const float ccx = -(V[0] * V[3] + V[4] * V[7] + V[8] * V[11]);
+    const float ccy = -(V[1] * V[3] + V[5] * V[7] + V[9] * V[11]);
+    const float ccz = -(V[2] * V[3] + V[6] * V[7] + V[10] * V[11]);
+    const Cam cam = load_cam(viewmats, Ks);
+    auto heavy = [&](int g) {
+        float dir[3];
+        sh_bwd_row<SPLIT>(deg, g, ccx, ccy, ccz, means, coeffs, coeffs_rest, v_grec, v_coeffs, v_coeffs_rest, dir);
+        pp_bwd_row(P, cam, depth_slot, g, means, quats, scales, opacities, comps, nullptr, v_grec, dir, v_means, v_quats, v_scales,
+                   v_opacities);
+    };
+    int qn = 0;
+    for (int64_t base = (int64_t)blockIdx.x * kFlagStep; base < P.n_gauss; base += (int64_t)gridDim.x * kFlagStep) {
+        const int64_t r0 = base + 8 * lane;
+        unsigned long long fl = 0ull;
+        if (r0 + 8 <= P.n_gauss) fl = *reinterpret_cast<const unsigned long long*>(P.touched + r0);
+        else
+            for (int b = 0; b < 8; b++)
+                if (r0 + b < P.n_gauss) fl |= (unsigned long long)P.touched[r0 + b] << (8 * b);
+        if (__ballot(fl != 0ull) == 0ull) continue;
+#pragma unroll 1
+        for (int b = 0; b < 8; b++) {
+            const bool live = (fl & 0xffull) != 0ull;
+            const unsigned long long mask = __ballot(live);
+            if (live) queue[qn + __popcll(mask & lt)] = (int)(r0 + b);
+            qn += __popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+            if (qn >= 64) {
+                const int gq = queue[lane];
+                const int keep = lane + 64 < qn ? queue[lane + 64] : 0;
+                __builtin_amdgcn_wave_barrier();
+                queue[lane] = keep;
+                qn -= 64;
+                heavy(gq);
+            }
+            fl >>= 8;
         }
     }
     if (lane < qn) heavy(queue[lane]);
@@ -1487,16 +1501,7 @@ extern "C" int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int
                                  const float* coeffs_or_colors, const float* coeffs_rest, const int32_t* radii,
                                  const float* v_grec, float* v_coeffs_or_colors, float* v_coeffs_rest,
                                  float* v_means_dir, const float* sh_aux, misplat_stream_t stream) {
-    return misplat_internal::color_bwd(p, sh_degree, K_or_D, n_color, per_cam, means, viewmats, coeffs_or_colors, coeffs_rest,
-                                       radii, v_grec, v_coeffs_or_colors, v_coeffs_rest, v_means_dir, sh_aux, 0,
-                                       (hipStream_t)stream);
-}
-
-int misplat_internal::color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color, int32_t per_cam,
-                                const float* means, const float* viewmats, const float* coeffs_or_colors,
-                                const float* coeffs_rest, const int32_t* radii, const float* v_grec,
-                                float* v_coeffs_or_colors, float* v_coeffs_rest, float* v_means_dir, const float* sh_aux,
-                                int outputs_zero, hipStream_t s) {
+    hipStream_t s = (hipStream_t)stream;
     if (!p || p->n_gauss < 0 || p->n_cams < 1 || n_color < 0 || n_color > 4) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
     if (sh_degree >= 0) {
@@ -1516,26 +1521,15 @@ int misplat_internal::color_bwd(const misplat_params* p, int32_t sh_degree, int3
                                    (int)(n_floats - 4 * n4));
             };
             if (((uintptr_t)v_means_dir & 15) != 0) return MISPLAT_EINVAL;
-            // (512 rows per scan step: only when that still leaves enough waves -- a small scene with most rows live would
-            // run its batches one behind the other in a handful of waves)
-            const bool prefilled = outputs_zero != 0;
-            const bool side_by_side = !prefilled && !coeffs_rest && p->touched && (((uintptr_t)p->touched) & 15) == 0 && p->n_gauss >= 262144;
-            if (prefilled) {}
-            else if (coeffs_rest) { zero(v_coeffs_or_colors, (int64_t)p->n_gauss * 3); zero(v_coeffs_rest, (int64_t)p->n_gauss * 45); }
-            else if (!side_by_side) zero(v_coeffs_or_colors, (int64_t)p->n_gauss * 48);
-            if (!side_by_side && !prefilled) zero(v_means_dir, (int64_t)p->n_gauss * 3);
+            if (coeffs_rest) { zero(v_coeffs_or_colors, (int64_t)p->n_gauss * 3); zero(v_coeffs_rest, (int64_t)p->n_gauss * 45); }
+            else zero(v_coeffs_or_colors, (int64_t)p->n_gauss * 48);
+            zero(v_means_dir, (int64_t)p->n_gauss * 3);
             if (coeffs_rest)
                 hipLaunchKernelGGL(color_sh_bwd_sparse_kernel<true>, dim3(grid), dim3(64), 0, s, *p, sh_degree, means, viewmats,
-                                   coeffs_or_colors, coeffs_rest, radii, v_grec, v_coeffs_or_colors, v_coeffs_rest, v_means_dir, 0);
-            else {
-                // (a workgroup of the zero half clears 64 x 16 bytes per step: at least ~16 steps each, at most 8 192 workgroups)
-                const int64_t zwant = ((int64_t)p->n_gauss * 12 + 1023) / 1024;
-                const int zb = side_by_side ? (int)(zwant < 1 ? 1 : (zwant > 8192 ? 8192 : zwant)) : 0;
-                const int lb = (int)(((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep) < 2048 ? (int)(((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep) : 2048;
-                hipLaunchKernelGGL(color_sh_bwd_sparse_kernel<false>, dim3(side_by_side ? zb + lb : grid), dim3(64), 0, s, *p,
-                                   sh_degree, means, viewmats, coeffs_or_colors, coeffs_rest, radii, v_grec, v_coeffs_or_colors,
-                                   v_coeffs_rest, v_means_dir, zb);
-            }
+                                   coeffs_or_colors, coeffs_rest, radii, v_grec, v_coeffs_or_colors, v_coeffs_rest, v_means_dir);
+            else
+                hipLaunchKernelGGL(color_sh_bwd_sparse_kernel<false>, dim3(grid), dim3(64), 0, s, *p, sh_degree, means, viewmats,
+                                   coeffs_or_colors, coeffs_rest, radii, v_grec, v_coeffs_or_colors, v_coeffs_rest, v_means_dir);
             return check_launch();
         }
 #define LAUNCH_SH_BWD(MULTI_, AUX_, KC_, SPLIT_)                                                                     \
@@ -1567,22 +1561,35 @@ int misplat_internal::color_bwd(const misplat_params* p, int32_t sh_degree, int3
     return check_launch();
 }
 
+int misplat_internal::gauss_bwd_sparse(const misplat_params* p, int32_t sh_degree, int32_t depth_slot, const float* means,
+                                       const float* quats, const float* scales, const float* opacities, const float* viewmats,
+                                       const float* Ks, const float* coeffs, const float* coeffs_rest, const float* compensations,
+                                       const float* v_grec, float* v_coeffs, float* v_coeffs_rest, float* v_means, float* v_quats,
+                                       float* v_scales, float* v_opacities, hipStream_t s) {
+    if (!p || p->n_gauss < 1 || p->n_cams != 1 || !p->touched || sh_degree < 0 || sh_degree > 3) return MISPLAT_EINVAL;
+    if (depth_slot != -1 && (depth_slot < 12 || depth_slot > 15)) return MISPLAT_EINVAL;
+    if ((coeffs_rest != nullptr) != (v_coeffs_rest != nullptr)) return MISPLAT_EINVAL;
+    if ((((uintptr_t)p->touched) & 7) || (((uintptr_t)coeffs | (uintptr_t)v_coeffs | (uintptr_t)v_grec | (uintptr_t)v_quats) & 15))
+        return MISPLAT_EINVAL;
+    int64_t waves = ((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep;
+    if (waves > 2048) waves = 2048;
+    if (coeffs_rest)
+        hipLaunchKernelGGL(gauss_bwd_sparse_kernel<true>, dim3((unsigned)waves), dim3(64), 0, s, *p, sh_degree, depth_slot, means,
+                           quats, scales, opacities, viewmats, Ks, coeffs, coeffs_rest, compensations, v_grec, v_coeffs,
+                           v_coeffs_rest, v_means, v_quats, v_scales, v_opacities);
+    else
+        hipLaunchKernelGGL(gauss_bwd_sparse_kernel<false>, dim3((unsigned)waves), dim3(64), 0, s, *p, sh_degree, depth_slot, means,
+                           quats, scales, opacities, viewmats, Ks, coeffs, coeffs_rest, compensations, v_grec, v_coeffs,
+                           v_coeffs_rest, v_means, v_quats, v_scales, v_opacities);
+    return check_launch();
+}
+
 extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_slot, const float* means,
                                         const float* quats, const float* scales, const float* opacities,
                                         const float* viewmats, const float* Ks, const int32_t* radii,
                                         const float* compensations, const float* v_means2d, const float* v_grec,
                                         const float* v_means_dir, float* v_means, float* v_quats,
                                         float* v_scales, float* v_opacities, misplat_stream_t stream) {
-    return misplat_internal::project_pack_bwd(p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii, compensations,
-                                              v_means2d, v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities, 0,
-                                              (hipStream_t)stream);
-}
-
-int misplat_internal::project_pack_bwd(const misplat_params* p, int32_t depth_slot, const float* means, const float* quats,
-                                       const float* scales, const float* opacities, const float* viewmats, const float* Ks,
-                                       const int32_t* radii, const float* compensations, const float* v_means2d,
-                                       const float* v_grec, const float* v_means_dir, float* v_means, float* v_quats,
-                                       float* v_scales, float* v_opacities, int outputs_zero, hipStream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
     if (depth_slot != -1 && (depth_slot < 12 || depth_slot > 15)) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
@@ -1591,16 +1598,9 @@ int misplat_internal::project_pack_bwd(const misplat_params* p, int32_t depth_sl
         // fill batches of live ones
         int64_t waves = ((int64_t)p->n_gauss + 63) / 64;
         if (waves > 2048) waves = 2048;
-        int zero_blocks = 0;
-        if (p->touched && !v_means2d && (((uintptr_t)p->touched) & 15) == 0 && p->n_gauss >= 262144) {
-            waves = ((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep;   // the live half
-            if (waves > 2048) waves = 2048;
-            const int64_t zwant = ((int64_t)p->n_gauss + 1023) / 1024;       // ~16 rows per lane of the zero half, at most 2 048
-            zero_blocks = outputs_zero ? -1 : (int)(zwant < 1 ? 1 : (zwant > 2048 ? 2048 : zwant));
-        }
-        hipLaunchKernelGGL(project_pack_bwd_sparse_kernel, dim3((unsigned)(waves + (zero_blocks > 0 ? zero_blocks : 0))), dim3(64), 0,
-                           (hipStream_t)stream, *p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii,
-                           compensations, v_means2d, v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities, zero_blocks);
+        hipLaunchKernelGGL(project_pack_bwd_sparse_kernel, dim3((unsigned)waves), dim3(64), 0, (hipStream_t)stream, *p, depth_slot,
+                           means, quats, scales, opacities, viewmats, Ks, radii, compensations, v_means2d, v_grec, v_means_dir,
+                           v_means, v_quats, v_scales, v_opacities);
         return check_launch();
     }
     hipLaunchKernelGGL(project_pack_bwd_kernel, dim3(grid_for(p->n_gauss, 256)), dim3(256), 0, (hipStream_t)stream,

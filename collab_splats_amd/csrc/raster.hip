@@ -293,8 +293,12 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
 // launcher puts them in front from 2.5 M rows.  Needs the row flags (misplat_params.touched), one camera, 16 SH
 // coefficients without Jacobian cache.
 static bool background_fill_ok(const misplat_params* p, const misplat_raster_bwd_args* b) {
-    return p->touched && p->n_cams == 1 && p->n_gauss >= 262144 && b->sh_degree >= 0 && !b->sh_aux && b->K_or_D == 16 &&
-           !b->v_means2d && b->v_means_dir && (b->colors_rest != nullptr) == (b->v_colors_rest != nullptr);
+    if (!(p->touched && p->n_cams == 1 && p->n_gauss >= 262144 && b->sh_degree >= 0 && !b->sh_aux && b->K_or_D == 16 &&
+          !b->v_means2d && (b->colors_rest != nullptr) == (b->v_colors_rest != nullptr)))
+        return false;
+    const uintptr_t a16 = (uintptr_t)b->colors | (uintptr_t)b->v_colors | (uintptr_t)b->v_colors_rest | (uintptr_t)b->v_grec |
+                          (uintptr_t)b->v_means | (uintptr_t)b->v_quats | (uintptr_t)b->v_scales | (uintptr_t)b->v_opacities;
+    return (a16 & 15) == 0 && (((uintptr_t)p->touched) & 7) == 0;
 }
 
 static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_args* b, hipStream_t s) {
@@ -310,7 +314,6 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
         auto add = [&](float* ptr, int64_t count) { F.p[F.count] = ptr; F.n[F.count] = count; F.count++; };
         add(b->v_colors, n * (b->colors_rest ? 3 : 48));
         if (b->colors_rest) add(b->v_colors_rest, n * 45);
-        add(b->v_means_dir, n * 3);
         add(b->v_means, n * 3);
         add(b->v_quats, n * 4);
         add(b->v_scales, n * 3);
@@ -321,13 +324,17 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
                                                 b->v_exp_depth, b->v_med_depth, b->v_normal, b->v_grec, b->v_abs, b->zero_flags,
                                                 background ? &F : nullptr, s);
     if (rc != MISPLAT_OK) return rc;
-    rc = misplat_internal::color_bwd(p, b->sh_degree, b->K_or_D, b->n_color, b->per_cam, b->means, b->viewmats, b->colors,
-                                     b->colors_rest, b->radii, b->v_grec, b->v_colors, b->v_colors_rest, b->v_means_dir,
-                                     b->sh_aux, background ? 1 : 0, s);
+    if (background)        // flagged rows only, both per-Gaussian stages in one launch
+        return misplat_internal::gauss_bwd_sparse(p, b->sh_degree, b->depth_slot, b->means, b->quats, b->scales, b->opacities,
+                                                  b->viewmats, b->Ks, b->colors, b->colors_rest, b->compensations, b->v_grec,
+                                                  b->v_colors, b->v_colors_rest, b->v_means, b->v_quats, b->v_scales,
+                                                  b->v_opacities, s);
+    rc = misplat_color_bwd(p, b->sh_degree, b->K_or_D, b->n_color, b->per_cam, b->means, b->viewmats, b->colors, b->colors_rest,
+                           b->radii, b->v_grec, b->v_colors, b->v_colors_rest, b->v_means_dir, b->sh_aux, (misplat_stream_t)s);
     if (rc != MISPLAT_OK) return rc;
-    return misplat_internal::project_pack_bwd(p, b->depth_slot, b->means, b->quats, b->scales, b->opacities, b->viewmats, b->Ks,
-                                              b->radii, b->compensations, b->v_means2d, b->v_grec, b->v_means_dir, b->v_means,
-                                              b->v_quats, b->v_scales, b->v_opacities, background ? 1 : 0, s);
+    return misplat_project_pack_bwd(p, b->depth_slot, b->means, b->quats, b->scales, b->opacities, b->viewmats, b->Ks, b->radii,
+                                    b->compensations, b->v_means2d, b->v_grec, b->v_means_dir, b->v_means, b->v_quats, b->v_scales,
+                                    b->v_opacities, (misplat_stream_t)s);
 }
 
 extern "C" int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
