@@ -114,6 +114,88 @@ inline int grid_for(int64_t n, int block) {
     if (b < 1) b = 1;
     return (int)b;
 }
+// ---- a5 get_loss_dict (rade_gs_model.py:289-307 + the base model's L1 term): three image means and their backward.
+// Forward: kLossBlocks workgroups leave (sum |gt - rgb|, sum err_exp, sum err_med) per workgroup -- fixed grid, fixed
+// tree, so the values are reproducible bit for bit --, one workgroup adds the partial sums in fp64 and writes the two
+// loss values.  Backward: the three constant-magnitude gradient images in one pass.
+constexpr int kLossBlocks = 512;
+
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void loss_partial_kernel(int64_t n_pix, const float* __restrict__ rgb,
+                                                           const float* __restrict__ gt, const float* __restrict__ err_exp,
+                                                           const float* __restrict__ err_med, float* __restrict__ partials) {
+    __shared__ float sm[3][4];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    if (gt) {
+        const int64_t n3 = 3 * n_pix, n4 = n3 >> 2;                       // (both images 16-byte aligned: launcher)
+        const float4* a4 = reinterpret_cast<const float4*>(rgb);
+        const float4* b4 = reinterpret_cast<const float4*>(gt);
+        for (int64_t i = tid; i < n4; i += stride) {
+            const float4 a = a4[i], b = b4[i];
+            s0 += (fabsf(b.x - a.x) + fabsf(b.y - a.y)) + (fabsf(b.z - a.z) + fabsf(b.w - a.w));
+        }
+        if (tid < (n3 & 3)) s0 += fabsf(gt[4 * n4 + tid] - rgb[4 * n4 + tid]);
+    }
+    if (err_exp)
+        for (int64_t i = tid; i < n_pix; i += stride) { s1 += err_exp[i]; s2 += err_med[i]; }
+    s0 = wave_sum_f(s0); s1 = wave_sum_f(s1); s2 = wave_sum_f(s2);
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = s0; sm[1][threadIdx.x >> 6] = s1; sm[2][threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        partials[3 * blockIdx.x + threadIdx.x] = (sm[threadIdx.x][0] + sm[threadIdx.x][1]) + (sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+}
+
+__global__ __launch_bounds__(256) void loss_final_kernel(int n_blocks, const float* __restrict__ partials, double inv_n3, double inv_n,
+                                                         float depth_ratio, float lambda, float* __restrict__ rgb_loss,
+                                                         float* __restrict__ dn_loss) {
+    __shared__ double sm[3][256];
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < n_blocks; b += 256)
+        for (int k = 0; k < 3; k++) s[k] += (double)partials[3 * b + k];
+    for (int k = 0; k < 3; k++) sm[k][threadIdx.x] = s[k];
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w)
+            for (int k = 0; k < 3; k++) sm[k][threadIdx.x] += sm[k][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (rgb_loss) *rgb_loss = (float)(sm[0][0] * inv_n3);
+        if (dn_loss) {
+            const float m_exp = (float)(sm[1][0] * inv_n), m_med = (float)(sm[2][0] * inv_n);
+            *dn_loss = lambda * ((1.0f - depth_ratio) * m_exp + depth_ratio * m_med);
+        }
+    }
+}
+
+// v_rgb = -g_rgb / (3 n) * sign(gt - rgb) (torch's abs backward: sign(0) = 0); v_err_exp = g_dn lambda (1 - r) / n,
+// v_err_med = g_dn lambda r / n.  g_*: device scalars (the upstream gradients of the two loss values), or NULL = 0.
+__global__ __launch_bounds__(256) void loss_bwd_kernel(int64_t n_pix, const float* __restrict__ rgb, const float* __restrict__ gt,
+                                                       const float* __restrict__ g_rgb, const float* __restrict__ g_dn,
+                                                       float inv_n3, float w_exp, float w_med, float* __restrict__ v_rgb,
+                                                       float* __restrict__ v_err_exp, float* __restrict__ v_err_med) {
+    const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, stride = (int64_t)gridDim.x * 256;
+    if (v_rgb) {
+        const float g = g_rgb ? -(*g_rgb) * inv_n3 : 0.f;
+        const int64_t n3 = 3 * n_pix;
+        for (int64_t i = tid; i < n3; i += stride) {
+            const float d = gt[i] - rgb[i];
+            v_rgb[i] = d > 0.f ? g : (d < 0.f ? -g : 0.f);
+        }
+    }
+    if (v_err_exp) {
+        const float gd = g_dn ? *g_dn : 0.f;
+        const float a = gd * w_exp, b = gd * w_med;
+        for (int64_t i = tid; i < n_pix; i += stride) { v_err_exp[i] = a; v_err_med[i] = b; }
+    }
+}
+
 inline int check_launch() { return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH; }
 
 }  // namespace
@@ -149,5 +231,32 @@ extern "C" int misplat_outputs_bwd(int64_t n_pix, int32_t color_dim, const float
                        color_dim, background3_host[0], background3_host[1], background3_host[2], render, alpha, v_rgb,
                        v_depth, v_median_depth, v_normals, v_depth_im, v_render, v_alpha, v_exp_depth, v_med_depth,
                        v_exp_normal);
+    return check_launch();
+}
+
+extern "C" int misplat_loss_fwd(int64_t n_pix, const float* rgb, const float* gt, const float* err_exp, const float* err_med,
+                                float depth_ratio, float depth_normal_lambda, float* partials, float* rgb_loss, float* dn_loss,
+                                misplat_stream_t stream) {
+    if (n_pix < 1 || !partials || (gt && (!rgb || !rgb_loss)) || (err_exp && (!err_med || !dn_loss)) || (!gt && !err_exp))
+        return MISPLAT_EINVAL;
+    if (gt && ((((uintptr_t)rgb) | ((uintptr_t)gt)) & 15)) return MISPLAT_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(loss_partial_kernel, dim3(kLossBlocks), dim3(256), 0, s, n_pix, rgb, gt, err_exp, err_med, partials);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, kLossBlocks, partials, 1.0 / (3.0 * (double)n_pix),
+                       1.0 / (double)n_pix, depth_ratio, depth_normal_lambda, gt ? rgb_loss : nullptr, err_exp ? dn_loss : nullptr);
+    return check_launch();
+}
+
+extern "C" int misplat_loss_bwd(int64_t n_pix, const float* rgb, const float* gt, const float* g_rgb_loss, const float* g_dn_loss,
+                                float depth_ratio, float depth_normal_lambda, float* v_rgb, float* v_err_exp, float* v_err_med,
+                                misplat_stream_t stream) {
+    if (n_pix < 1 || (v_rgb && (!rgb || !gt)) || ((v_err_exp != nullptr) != (v_err_med != nullptr)) || (!v_rgb && !v_err_exp))
+        return MISPLAT_EINVAL;
+    int64_t blocks = (3 * n_pix + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    const float inv_n = (float)(1.0 / (double)n_pix);
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n_pix, rgb, gt, g_rgb_loss,
+                       g_dn_loss, (float)(1.0 / (3.0 * (double)n_pix)), depth_normal_lambda * (1.0f - depth_ratio) * inv_n,
+                       depth_normal_lambda * depth_ratio * inv_n, v_rgb, v_err_exp, v_err_med);
     return check_launch();
 }

@@ -1516,3 +1516,77 @@ def get_outputs_epilogue(render, alpha, exp_depth, med_depth, exp_normal, backgr
     args = [_f32(t, n) for t, n in ((render, "render"), (alpha, "alpha"), (exp_depth, "expected_depths"),
                                     (med_depth, "median_depths"), (exp_normal, "expected_normals"))]
     return _GetOutputs.apply(*args, tuple(float(b) for b in background), bool(want_depth_im), float(fx), float(fy))
+
+
+LOSS_PARTIALS = 3 * 512      # MISPLAT_LOSS_PARTIALS
+
+
+class _MeanLosses(torch.autograd.Function):
+    """a5 (rade_gs_model.py:289-307 + the base model's L1 term) as ONE autograd node: forward = two launches
+    (misplat_loss_fwd), backward = one (misplat_loss_bwd) that writes the gradient images the a3 + a4 node consumes --
+    instead of ~30 elementwise / reduction launches of a few microseconds each.  ``err``: the [2,H,W] tensor whose halves
+    are the two error maps (then e1 / e2 are ignored), or None with e1 / e2 given separately."""
+
+    @staticmethod
+    def forward(ctx, rgb, gt, err, e1, e2, depth_ratio: float, lam: float):
+        lib = _lib.load()
+        with_rgb = rgb is not None and gt is not None
+        if err is not None:
+            e1, e2 = err[0], err[1]
+        with_dn = e1 is not None and e2 is not None
+        require_gpu(*[t for t in (rgb, gt, e1, e2) if t is not None])
+        n_pix = rgb.numel() // 3 if with_rgb else e1.numel()
+        if with_rgb and with_dn and e1.numel() != n_pix:
+            raise ValueError("get_loss_dict: the error maps and the image differ in size")
+        dev = rgb.device if with_rgb else e1.device
+        partials = torch.empty(LOSS_PARTIALS, device=dev, dtype=torch.float32)
+        rgb_loss = torch.empty((), device=dev, dtype=torch.float32) if with_rgb else None
+        dn_loss = torch.empty((), device=dev, dtype=torch.float32) if with_dn else None
+        check(lib.misplat_loss_fwd(C.c_int64(n_pix), ptr(rgb if with_rgb else None), ptr(gt if with_rgb else None),
+                                   ptr(e1 if with_dn else None), ptr(e2 if with_dn else None), C.c_float(depth_ratio),
+                                   C.c_float(lam), ptr(partials), ptr(rgb_loss), ptr(dn_loss), stream_ptr()), "misplat_loss_fwd")
+        ctx.save_for_backward(*(t for t in (rgb, gt) if with_rgb))
+        ctx.with_rgb, ctx.with_dn, ctx.packed, ctx.n_pix = with_rgb, with_dn, err is not None, n_pix
+        ctx.err_shape = tuple(err.shape) if err is not None else (tuple(e1.shape) if with_dn else None)
+        ctx.k = (float(depth_ratio), float(lam))
+        ctx.dev = dev
+        ctx.set_materialize_grads(False)
+        return rgb_loss, dn_loss
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_dn):
+        lib = _lib.load()
+        rgb, gt = ctx.saved_tensors if ctx.with_rgb else (None, None)
+        want_rgb = ctx.with_rgb and ctx.needs_input_grad[0] and g_rgb is not None
+        want_dn = ctx.with_dn and g_dn is not None and (ctx.needs_input_grad[2] if ctx.packed
+                                                       else (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]))
+        v_rgb = torch.empty_like(rgb) if want_rgb else None
+        v_err = v_e1 = v_e2 = None
+        if want_dn:
+            if ctx.packed:
+                v_err = torch.empty(ctx.err_shape, device=ctx.dev, dtype=torch.float32)
+                v_e1, v_e2 = v_err[0], v_err[1]
+            else:
+                v_e1 = torch.empty(ctx.err_shape, device=ctx.dev, dtype=torch.float32)
+                v_e2 = torch.empty(ctx.err_shape, device=ctx.dev, dtype=torch.float32)
+        if want_rgb or want_dn:
+            g1 = g_rgb.to(torch.float32).contiguous() if want_rgb else None
+            g2 = g_dn.to(torch.float32).contiguous() if want_dn else None
+            check(lib.misplat_loss_bwd(C.c_int64(ctx.n_pix), ptr(rgb if want_rgb else None), ptr(gt if want_rgb else None),
+                                       ptr(g1), ptr(g2), C.c_float(ctx.k[0]), C.c_float(ctx.k[1]), ptr(v_rgb), ptr(v_e1),
+                                       ptr(v_e2), stream_ptr()), "misplat_loss_bwd")
+        if ctx.packed:
+            return v_rgb, None, v_err, None, None, None, None
+        return v_rgb, None, None, v_e1, v_e2, None, None
+
+
+def mean_losses(rgb, gt, err=None, e1=None, e2=None, depth_ratio: float = 0.0, depth_normal_lambda: float = 0.0):
+    """(rgb_loss or None, depth_normal_loss or None): mean |gt - rgb| and lambda * ((1 - r) * mean(e1) + r * mean(e2)).
+    Contiguous float32 GPU tensors; ``err`` [2,...] packs e1 / e2 (its gradient then arrives as one tensor)."""
+    def ok(t):
+        return t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous())
+    if not all(ok(t) for t in (rgb, gt, err, e1, e2)):
+        raise ValueError("mean_losses: contiguous float32 GPU tensors only")
+    if rgb is not None and gt is not None and rgb.shape != gt.shape:
+        raise ValueError("mean_losses: image and ground truth differ in shape")
+    return _MeanLosses.apply(rgb, gt, err, e1, e2, float(depth_ratio), float(depth_normal_lambda))

@@ -422,12 +422,35 @@ class RadegsModel(nn.Module):
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
         """rade_gs_model.py:274-309.  The Splatfacto base loss (L1 + SSIM, third-party, absent) is
-        represented by its L1 term only."""
+        represented by its L1 term only.  On the GPU the means and their backward are one autograd node
+        (``ops.mean_losses``: three launches in all instead of ~30 small ones)."""
         loss_dict: Dict[str, Tensor] = {}
-        if batch is not None and "image" in batch:
-            loss_dict["rgb_loss"] = torch.abs(batch["image"].to(outputs["rgb"].device) - outputs["rgb"]).mean()
-        if self.config.use_depth_normal_loss and self.step >= self.config.regularization_from_iter:
-            depth_normal_loss = ((1 - self.config.depth_ratio) * outputs["depth_normal_error_map"].mean()
-                                 + self.config.depth_ratio * outputs["middepth_normal_error_map"].mean())
+        rgb = outputs["rgb"]
+        gt = batch["image"].to(rgb.device) if batch is not None and "image" in batch else None
+        with_dn = self.config.use_depth_normal_loss and self.step >= self.config.regularization_from_iter
+        e1 = outputs["depth_normal_error_map"] if with_dn else None
+        e2 = outputs["middepth_normal_error_map"] if with_dn else None
+
+        def plain(t):
+            return t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous())
+
+        if rgb.is_cuda and plain(rgb) and plain(gt) and plain(e1) and plain(e2) and (gt is None or gt.shape == rgb.shape) \
+                and (gt is not None or with_dn) and (e1 is None or e1.shape == e2.shape):
+            # (the two maps are the halves of the epilogue's [2,H,W] tensor: its gradient then arrives as one tensor too)
+            base = e1._base if with_dn and e1._base is not None and e1._base is e2._base else None
+            packed = (base is not None and base.dim() == 3 and base.shape[0] == 2 and base.is_contiguous()
+                      and e1.data_ptr() == base.data_ptr() and e2.data_ptr() == base[1].data_ptr())
+            rgb_loss, dn_loss = ops.mean_losses(rgb if gt is not None else None, gt, base if packed else None,
+                                                None if packed else e1, None if packed else e2,
+                                                self.config.depth_ratio, self.config.depth_normal_lambda)
+            if gt is not None:
+                loss_dict["rgb_loss"] = rgb_loss
+            if with_dn:
+                loss_dict["depth_normal_loss"] = dn_loss
+            return loss_dict
+        if gt is not None:
+            loss_dict["rgb_loss"] = torch.abs(gt - rgb).mean()
+        if with_dn:
+            depth_normal_loss = ((1 - self.config.depth_ratio) * e1.mean() + self.config.depth_ratio * e2.mean())
             loss_dict["depth_normal_loss"] = self.config.depth_normal_lambda * depth_normal_loss
         return loss_dict

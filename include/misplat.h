@@ -401,6 +401,22 @@ int misplat_outputs_bwd(int64_t n_pix, int32_t color_dim, const float* backgroun
                         float* v_exp_depth, float* v_med_depth, float* v_exp_normal,
                         misplat_stream_t stream);
 
+/* ---- a5 get_loss_dict (rade_gs_model.py:289-307: depth_normal_lambda * ((1 - depth_ratio) * mean(depth_normal_error_map)
+ * + depth_ratio * mean(middepth_normal_error_map)); the base model's L1 term mean |gt - rgb|) in two launches, and
+ * its backward in one.  rgb / gt [n_pix,3] (16-byte aligned), err_exp / err_med [n_pix]; either pair may be NULL (that
+ * loss is then not computed).  partials: 3 * 512 floats of device scratch.  rgb_loss / dn_loss: device scalars.
+ * Reproducible bit for bit (fixed grid and summation tree, fp64 final sums). */
+#define MISPLAT_LOSS_PARTIALS (3 * 512)
+int misplat_loss_fwd(int64_t n_pix, const float* rgb, const float* gt, const float* err_exp, const float* err_med,
+                     float depth_ratio, float depth_normal_lambda, float* partials, float* rgb_loss, float* dn_loss,
+                     misplat_stream_t stream);
+/* g_rgb_loss / g_dn_loss: the upstream gradients of the two loss values as DEVICE scalars (or NULL = 0);
+ * v_rgb[n_pix,3] = -g / (3 n) sign(gt - rgb), v_err_exp / v_err_med[n_pix] = the constant images g lambda (1 - r) / n and
+ * g lambda r / n.  v_rgb or the v_err pair may be NULL. */
+int misplat_loss_bwd(int64_t n_pix, const float* rgb, const float* gt, const float* g_rgb_loss, const float* g_dn_loss,
+                     float depth_ratio, float depth_normal_lambda, float* v_rgb, float* v_err_exp, float* v_err_med,
+                     misplat_stream_t stream);
+
 /* ---- the whole forward of rasterization() (rade_gs_model.py:439-465) as ONE host entry: csrc/raster.hip.
  * Every pointer is a caller-allocated device buffer of the size the per-stage entry points above document
  * (n_isects_host: 8 bytes of PINNED host memory).
@@ -455,7 +471,10 @@ int misplat_raster_fwd(const misplat_params* p, const misplat_raster_args* a, in
                        misplat_graph_cache* cache /* or NULL: plain launches */);
 /* The whole backward of rasterization() as ONE host entry: misplat_blend_bwd_atomic, misplat_color_bwd,
  * misplat_project_pack_bwd back to back (arguments as documented there).  zero_flags: see misplat_blend_bwd_atomic;
- * with a cache the sequence is replayed as a graph when it contains no memset (zero_flags covers v_grec and v_abs). */
+ * with a cache the sequence is replayed as a graph when it contains no memset (zero_flags covers v_grec and v_abs).
+ * With misplat_params.touched, one camera, 16 SH coefficients without sh_aux and >= 262 144 Gaussians the same results
+ * come from two launches: the compositing backward, whose grid also clears the seven output tensors, and ONE kernel for
+ * both per-Gaussian stages that visits only the flagged rows (v_means_dir is then not written). */
 typedef struct misplat_raster_bwd_args {
     /* compositing backward: saved by the forward */
     const float *Ks, *grec;

@@ -1099,6 +1099,53 @@ def test_get_loss_dict_depth_normal_term_vs_reference_goldens(dev, i):
     assert rel_err(nr.grad, g[f"dn{i}_v_nrm"]) < TOL
 
 
+@pytest.mark.parametrize("H,W", [(7, 5), (270, 480), (1080, 1920)])
+def test_fused_loss_node_equals_the_torch_formulas(dev, H, W):
+    """ops.mean_losses (misplat_loss_fwd / misplat_loss_bwd): the L1 term and the depth-normal term of get_loss_dict
+    (rade_gs_model.py:289-307) with their gradients, against the reference's torch expressions; reproducible bit for
+    bit; error maps packed in one [2,H,W] tensor (what get_outputs hands over) or given separately; either term alone."""
+    from collab_splats_amd import ops
+    g = torch.Generator().manual_seed(H * W)
+    rgb0 = torch.rand(H, W, 3, generator=g).to(dev)
+    gt = torch.rand(H, W, 3, generator=g).to(dev)
+    gt[0, 0] = rgb0[0, 0]                                      # sign(0) = 0 in the backward
+    err0 = torch.rand(2, H, W, generator=g).to(dev)
+    r, lam = 0.6, 0.05
+
+    def reference():
+        rgb, err = rgb0.clone().requires_grad_(True), err0.clone().requires_grad_(True)
+        l1 = torch.abs(gt - rgb).mean()
+        dn = lam * ((1 - r) * err[0].unsqueeze(-1).mean() + r * err[1].unsqueeze(-1).mean())
+        (1.7 * l1 + 0.3 * dn).backward()
+        return l1.detach(), dn.detach(), rgb.grad, err.grad
+
+    l1_ref, dn_ref, vrgb_ref, verr_ref = reference()
+    seen = []
+    for packed in (True, False):
+        rgb, err = rgb0.clone().requires_grad_(True), err0.clone().requires_grad_(True)
+        if packed:
+            l1, dn = ops.mean_losses(rgb, gt, err=err, depth_ratio=r, depth_normal_lambda=lam)
+        else:
+            l1, dn = ops.mean_losses(rgb, gt, e1=err[0].unsqueeze(-1), e2=err[1].unsqueeze(-1), depth_ratio=r,
+                                     depth_normal_lambda=lam)
+        (1.7 * l1 + 0.3 * dn).backward()
+        assert abs(float(l1) - float(l1_ref)) <= 2e-6 * float(l1_ref) and abs(float(dn) - float(dn_ref)) <= 2e-6 * float(dn_ref)
+        assert torch.allclose(rgb.grad, vrgb_ref, rtol=1e-6, atol=0) and torch.allclose(err.grad, verr_ref, rtol=1e-6, atol=0)
+        assert float(rgb.grad[0, 0].abs().sum()) == 0.0
+        seen.append((l1.detach().clone(), dn.detach().clone()))
+    assert torch.equal(seen[0][0], seen[1][0]) and torch.equal(seen[0][1], seen[1][1])
+    rgb = rgb0.clone().requires_grad_(True)                    # one term alone
+    l1, none = ops.mean_losses(rgb, gt)
+    assert none is None and torch.equal(l1.detach(), seen[0][0])
+    l1.backward()
+    assert torch.allclose(rgb.grad * 1.7, vrgb_ref, rtol=1e-6, atol=0)
+    err = err0.clone().requires_grad_(True)
+    none, dn = ops.mean_losses(None, None, err=err, depth_ratio=r, depth_normal_lambda=lam)
+    assert none is None and torch.equal(dn.detach(), seen[0][1])
+    dn.backward()
+    assert torch.allclose(err.grad * 0.3, verr_ref, rtol=1e-6, atol=0)
+
+
 def _bench_like_scene(dev, N, W, H, seed, scale_mul=1.0):
     from collab_splats_amd.synthetic import random_scene
     sc = random_scene(N, W, H, seed=seed)
