@@ -36,8 +36,11 @@ python3 bench.py --no-cpu-baseline --dn-loss --gaussians 5000000 > $OUT/bench_5M
 cd /tmp
 rocprofv3 --kernel-trace --output-format csv -d $OUT/t10k -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --gaussians 10000 --width 256 --height 256 --steps 40 > /dev/null 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $OUT/t100k -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --gaussians 100000 --steps 40 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t1M -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 30 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t1Mdn -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --dn-loss --steps 30 > /dev/null 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/t5Mdn -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --dn-loss --gaussians 5000000 --steps 30 > /dev/null 2>&1
 cd $GRAFT_REPO_ROOT
-for t in t10k t100k; do
+for t in t10k t100k t1M t1Mdn t5Mdn; do
   python3 scripts/timeline.py $(find $OUT/$t -name "*kernel_trace.csv" | head -1) > $OUT/timeline_$t.txt 2>&1 || true
   rm -rf $OUT/$t
 done
