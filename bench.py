@@ -28,6 +28,7 @@ N=1 only).
 from __future__ import annotations
 
 import argparse
+import functools
 import json
 import os
 import subprocess
@@ -264,7 +265,7 @@ def main():
                 bucket.attach()
             out = model.get_outputs(cam)
             loss = model.get_loss_dict(out, {"image": target})
-            sum(loss.values()).backward()
+            functools.reduce(torch.add, loss.values()).backward()      # (nerfstudio's trainer sums the dictionary this way)
             if bucket is not None:
                 info["allreduce_ms"].append(bucket.allreduce())
             info["n_isects"], info["n_visible"] = model.info["n_isects"], model.info["radii"]
