@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--render-mode", default="RGB+ED")
     ap.add_argument("--rasterize-mode", default="antialiased")
     ap.add_argument("--shared-grads", action="store_true", help="shared Gaussians: all-reduce the gradients over RCCL")
+    ap.add_argument("--torch-activations", action="store_true",
+                    help="exp(log_scales) / sigmoid(opacity_logits) as torch launches in front of rasterization(), as the "
+                         "reference calls it (default: the scales_are_log / opacities_are_logit extension)")
     ap.add_argument("--dn-loss", action="store_true",
                     help="step = RadegsModel.get_outputs -> L1 + depth-normal consistency loss -> backward (configs[4])")
     ap.add_argument("--graphed", action="store_true",
@@ -282,11 +285,18 @@ def main():
                     p.grad = None
             else:
                 bucket.attach()
-            out = rasterization(params["means"], params["quats"], torch.exp(params["log_scales"]),
-                                torch.sigmoid(params["opacity_logits"]), params["sh"], viewmats, Ks, W, H,
-                                near_plane=0.01, far_plane=1e10, sh_degree=3, packed=False,
-                                render_mode=args.render_mode, sparse_grad=False, absgrad=False,
-                                rasterize_mode=args.rasterize_mode, return_depth_normal=True)
+            if args.torch_activations:             # the reference's call: activations as separate torch launches
+                out = rasterization(params["means"], params["quats"], torch.exp(params["log_scales"]),
+                                    torch.sigmoid(params["opacity_logits"]), params["sh"], viewmats, Ks, W, H,
+                                    near_plane=0.01, far_plane=1e10, sh_degree=3, packed=False,
+                                    render_mode=args.render_mode, sparse_grad=False, absgrad=False,
+                                    rasterize_mode=args.rasterize_mode, return_depth_normal=True)
+            else:                                  # the same step with exp / sigmoid inside the projection kernels
+                out = rasterization(params["means"], params["quats"], params["log_scales"], params["opacity_logits"],
+                                    params["sh"], viewmats, Ks, W, H, near_plane=0.01, far_plane=1e10, sh_degree=3,
+                                    packed=False, render_mode=args.render_mode, sparse_grad=False, absgrad=False,
+                                    rasterize_mode=args.rasterize_mode, return_depth_normal=True,
+                                    scales_are_log=True, opacities_are_logit=True)
             torch.autograd.backward(list(out[:5]), ups)
             if bucket is not None:
                 info["allreduce_ms"].append(bucket.allreduce())
@@ -365,7 +375,9 @@ def main():
                   f"consistency loss -> backward (BASELINE configs[4])")
         else:
             wl = (f"{N} random Gaussians, 1 view {W}x{H} per GPU, SH degree 3, {args.render_mode} "
-                  f"({args.rasterize_mode}), colour+alpha+expected/median depth+normal, fwd+bwd to all six parameter tensors")
+                  f"({args.rasterize_mode}), colour+alpha+expected/median depth+normal, fwd+bwd to all six parameter tensors; "
+                  + ("exp(log_scales) / sigmoid(opacity_logits) as torch launches" if args.torch_activations
+                     else "exp(log_scales) / sigmoid(opacity_logits) inside the projection kernels (scales_are_log / opacities_are_logit)"))
         line = {
             "metric": "Msplats/s fwd+bwd @1080p (1M Gaussians); grad max-rel-err vs reference",
             "value": round(world * N / (dt / args.steps) / 1e6, 3), "unit": "Msplats/s",

@@ -36,7 +36,8 @@ class Params(C.Structure):
                 ("alpha_max", C.c_float), ("alpha_min", C.c_float), ("t_stop", C.c_float),
                 ("median_t", C.c_float), ("jacobian_margin", C.c_float), ("plane_eps", C.c_float),
                 ("ppl_fwd", C.c_int32), ("ppl_bwd", C.c_int32), ("ed_slot", C.c_int32), ("sub_blocks", C.c_int32),
-                ("unit_perm", C.c_void_p), ("unit_work", C.c_void_p), ("touched", C.c_void_p)]
+                ("unit_perm", C.c_void_p), ("unit_work", C.c_void_p), ("touched", C.c_void_p),
+                ("activations", C.c_int32), ("reserved_p", C.c_int32)]
 
 
 class RasterArgs(C.Structure):

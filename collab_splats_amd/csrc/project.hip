@@ -508,6 +508,13 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int n_gauss, int n_cams, in
 }
 
 
+// misplat_params.activations: the caller's parameters are log-scales (bit 0) / opacity logits (bit 1) and the kernels
+// apply exp / sigmoid themselves (rade_gs_model.py:443-444 does it with two torch launches per direction).
+__device__ __forceinline__ void apply_activations(const misplat_params& P, float (&scale)[3], float& opac) {
+    if (P.activations & 1) { scale[0] = expf(scale[0]); scale[1] = expf(scale[1]); scale[2] = expf(scale[2]); }
+    if (P.activations & 2) opac = 1.0f / (1.0f + expf(-opac));
+}
+
 // ================================================================================================
 // Fused per-Gaussian stages (the path rasterization() takes): projection writes the packed blend
 // record directly, the colour kernel (SH + 0.5 clamp, or pass-through) fills its colour slots, and
@@ -549,7 +556,8 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
         float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
         float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
         float scale[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
-        const float opac = opacities[g];
+        float opac = opacities[g];
+        apply_activations(P, scale, opac);
         int32_t rxi = 0, ryi = 0;
         float mx = 0.f, my = 0.f, dep = 0.f, cn0 = 0.f, cn1 = 0.f, cn2 = 0.f, comp = 0.f, rt = 0.f, oeff = 0.f;
         float rp[2] = {0.f, 0.f}, nr[3] = {0.f, 0.f, 0.f};
@@ -1228,7 +1236,8 @@ __device__ __forceinline__ void pp_bwd_row(const misplat_params& P, const Cam& c
     float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
     float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
     float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
-    const float opac = opacities[g];
+    float opac = opacities[g];
+    apply_activations(P, sc, opac);
     float o_m[3] = {dir[0], dir[1], dir[2]}, o_q[4] = {0.f, 0.f, 0.f, 0.f}, o_s[3] = {0.f, 0.f, 0.f};
     float o_op = 0.f;
     const float4* vg = reinterpret_cast<const float4*>(v_grec + (size_t)g * MISPLAT_REC);
@@ -1244,6 +1253,8 @@ __device__ __forceinline__ void pp_bwd_row(const misplat_params& P, const Cam& c
     if (P.antialiased) { o_op += v_oeff * comps[g]; G.v_comp = v_oeff * opac; }
     else { o_op += v_oeff; G.v_comp = 0.f; }
     project_bwd_one(mean, quat, sc, cam, P, G, o_m, o_q, o_s);
+    if (P.activations & 1) { o_s[0] *= sc[0]; o_s[1] *= sc[1]; o_s[2] *= sc[2]; }       // d exp(x) = exp(x) dx
+    if (P.activations & 2) o_op *= opac * (1.0f - opac);                                 // d sigmoid(x) = s (1 - s) dx
 #pragma unroll
     for (int k = 0; k < 3; k++) { v_means[3 * g + k] = o_m[k]; v_scales[3 * g + k] = o_s[k]; }
 #pragma unroll
@@ -1393,7 +1404,7 @@ extern "C" int misplat_project_fwd(const misplat_params* p, const float* means, 
                                    const float* Ks, int32_t* radii, float* means2d, float* depths,
                                    float* conics, float* compensations, float* ray_ts,
                                    float* ray_planes, float* normals, misplat_stream_t stream) {
-    if (!p || p->n_gauss < 0 || p->n_cams < 1 || p->width < 1 || p->height < 1) return MISPLAT_EINVAL;
+    if (!p || p->n_gauss < 0 || p->n_cams < 1 || p->width < 1 || p->height < 1 || p->activations) return MISPLAT_EINVAL;
     int64_t total = (int64_t)p->n_gauss * p->n_cams;
     if (total == 0) return MISPLAT_OK;
     hipLaunchKernelGGL(project_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *p,
@@ -1409,7 +1420,7 @@ extern "C" int misplat_project_bwd(const misplat_params* p, const float* means, 
                                    const float* v_ray_ts, const float* v_ray_planes,
                                    const float* v_normals, float* v_means, float* v_quats,
                                    float* v_scales, misplat_stream_t stream) {
-    if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
+    if (!p || p->n_gauss < 0 || p->n_cams < 1 || p->activations) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
     hipLaunchKernelGGL(project_bwd_kernel, dim3(grid_for(p->n_gauss, 256)), dim3(256), 0, (hipStream_t)stream,
                        *p, means, quats, scales, viewmats, Ks, radii, v_means2d, v_depths, v_conics,
@@ -1590,7 +1601,7 @@ extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_s
                                         const float* compensations, const float* v_means2d, const float* v_grec,
                                         const float* v_means_dir, float* v_means, float* v_quats,
                                         float* v_scales, float* v_opacities, misplat_stream_t stream) {
-    if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
+    if (!p || p->n_gauss < 0 || p->n_cams < 1 || (p->activations && p->n_cams != 1)) return MISPLAT_EINVAL;   // (activations: one camera)
     if (depth_slot != -1 && (depth_slot < 12 || depth_slot > 15)) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
     if (p->n_cams == 1) {

@@ -288,9 +288,10 @@ class RadegsModel(nn.Module):
             means, quats, scales = means[visible_mask], quats[visible_mask], scales[visible_mask]
             opacities = opacities[visible_mask]
             colors = tuple(c[visible_mask] for c in colors) if isinstance(colors, tuple) else colors[visible_mask]
+        # (the activations of rade_gs_model.py:443-444 run inside the projection kernels: see rendering.rasterization)
         return rasterization(
-            means=means, quats=quats, scales=torch.exp(scales),
-            opacities=torch.sigmoid(opacities.squeeze(-1)), colors=colors,
+            means=means, quats=quats, scales=scales, scales_are_log=True,
+            opacities=opacities.squeeze(-1), opacities_are_logit=True, colors=colors,
             viewmats=camera_params["viewmats"], Ks=camera_params["Ks"],
             width=int(camera_params["image_width"]), height=int(camera_params["image_height"]),
             packed=False, near_plane=0.01, far_plane=1e10, render_mode=render_mode,

@@ -64,6 +64,11 @@ def rasterization(
     opacity_aware_radius: bool = True,
     alpha_max: float = 0.999,
     normalise_expected_depth: bool = False,
+    # extension: ``scales`` holds log-scales / ``opacities`` holds logits -- the projection kernels apply exp / sigmoid
+    # themselves and the gradients come back for the raw parameters (the caller's torch.exp / torch.sigmoid of
+    # rade_gs_model.py:443-444 and their backward: four launches per step less).  Same results up to rounding.
+    scales_are_log: bool = False,
+    opacities_are_logit: bool = False,
 ):
     if render_mode not in _RENDER_MODES:
         raise ValueError(f"Unknown render_mode: {render_mode}")
@@ -118,6 +123,13 @@ def rasterization(
                     opacity_aware_radius=opacity_aware_radius, eps2d=eps2d, near_plane=near_plane,
                     far_plane=far_plane, radius_clip=radius_clip, radius_sigma=radius_sigma,
                     alpha_max=alpha_max, ed_slot=n_user if ed_fused else -1)
+    act = (1 if scales_are_log else 0) | (2 if opacities_are_logit else 0)
+    if act and not (fused and ops.fused_node_ok() and N > 0 and Cn == 1):
+        # only the single-node path of one camera carries the activations inside its kernels: elsewhere, as the caller would
+        scales = torch.exp(scales) if scales_are_log else scales
+        opacities = torch.sigmoid(opacities) if opacities_are_logit else opacities
+        act = 0
+    P.activations = act
     if fused and ops.fused_node_ok() and N > 0:
         # ---- the reference's path as ONE autograd node (ops._RasterFused): two C calls forward, one backward
         cin = colors if n_user > 0 else means.new_zeros(N, 1)[:, :0].contiguous()

@@ -79,6 +79,12 @@ typedef struct misplat_params {
      * per-Gaussian backward kernels -- a row that was never set has an all-zero gradient row, which then is not fetched
      * (in a dense scene nine rows in ten; their 64-byte rows were the largest read of both kernels). */
     uint8_t* touched;
+    /* Extension (not in gsplat's interface): bit 0 -- `scales` are log-scales, bit 1 -- `opacities` are logits; the fused
+     * projection kernels (misplat_project_pack_fwd / _bwd, one camera; misplat_raster_fwd / _bwd) apply exp / sigmoid
+     * themselves and return the gradients of the raw parameters -- the four activation launches of
+     * rade_gs_model.py:443-444 and their backward disappear.  0 = activated values, as gsplat takes them. */
+    int32_t activations;
+    int32_t reserved_p;
 } misplat_params;
 
 /* ---- a2.1 projection: fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, ...)

@@ -1340,6 +1340,43 @@ def test_background_fill_and_sparse_backward_equal_the_dense_backward(dev):
             assert bool(dead.any()) and float(a.reshape(a.shape[0], -1)[dead].abs().sum()) == 0.0, (rep, k)
 
 
+@pytest.mark.parametrize("N,W,H,scale_mul,two_cams", [(30_000, 640, 360, 1.0, False), (300_000, 640, 360, 1.5, False),
+                                                     (4_000, 200, 120, 1.0, True)])
+def test_activations_inside_the_projection_kernels_equal_torch_activations(dev, N, W, H, scale_mul, two_cams):
+    """rasterization(..., scales_are_log=True, opacities_are_logit=True): exp / sigmoid (rade_gs_model.py:443-444) run
+    inside the projection kernels and the gradients come back for the raw parameters -- the same images and the same
+    gradients as with torch.exp / torch.sigmoid in front (sparse and one-launch per-Gaussian backward; two cameras fall
+    back to the torch activations)."""
+    from collab_splats_amd import rasterization
+    args = _bench_like_scene(dev, N, W, H, seed=13, scale_mul=scale_mul)
+    raw = [args[0], args[1], torch.log(args[2]), torch.logit(args[3].clamp(1e-4, 1 - 1e-4)), args[4]]
+    viewmats, Ks = args[5], args[6]
+    if two_cams:
+        viewmats, Ks = torch.cat([viewmats, viewmats]), torch.cat([Ks, Ks])
+    kw = dict(sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True, absgrad=True)
+    ups = None
+    results = []
+    for inside in (False, True, True):                          # (third run: capacity hint, graphs, on-demand colours)
+        leaves = [t.clone().requires_grad_(True) for t in raw]
+        if inside:
+            out = rasterization(*leaves, viewmats, Ks, W, H, scales_are_log=True, opacities_are_logit=True, **kw)
+        else:
+            out = rasterization(leaves[0], leaves[1], torch.exp(leaves[2]), torch.sigmoid(leaves[3]), leaves[4], viewmats, Ks,
+                                W, H, **kw)
+        if ups is None:
+            ups = [u.to(dev) for u in upstream([t.shape for t in out[:5]], dtype=torch.float32)]
+        torch.autograd.backward(list(out[:5]), ups)
+        torch.cuda.synchronize()
+        results.append(([t.detach().clone() for t in out[:5]], [l.grad.clone() for l in leaves]))
+    (ref_img, ref_grad) = results[0]
+    for img, grad in results[1:]:
+        for name, a, b in zip(("render", "alpha", "exp_depth", "med_depth", "normal"), img, ref_img):
+            assert_close_flips(a, b, name, tol=1e-5)            # (expf in the kernel vs torch.exp: last-bit differences)
+        for name, a, b in zip(("v_means", "v_quats", "v_log_scales", "v_opacity_logits", "v_sh"), grad, ref_grad):
+            assert torch.isfinite(a).all(), name
+            assert_close_flips(a, b, name, tol=5e-5)
+
+
 def test_two_node_form_backpropagates_a_loss_on_projection_outputs(dev, monkeypatch):
     """MISPLAT_FUSED_NODE=0: the projection's own outputs in ``meta`` are differentiable, and a loss on them reaches the
     projection backward WITHOUT passing the compositing kernels -- the `touched` row flags (set by the compositing
