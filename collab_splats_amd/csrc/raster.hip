@@ -133,7 +133,7 @@ struct misplat_graph_cache {
     std::vector<GraphEntry> entries;
     std::vector<Retired> retired;
     uint64_t clock = 0, hits = 0, captures = 0;
-    uint64_t window_calls = 0, window_misses = 0, bypass_until = 0, miss_run = 0;
+    uint64_t window_calls = 0, window_misses = 0, bypass_until = 0, miss_run = 0, pause_len = 512;
     int max_entries = 16;
     // Sequences are captured on this private stream (the caller's may be the legacy default stream, which cannot be
     // captured) and the resulting graph is launched on the caller's stream.
@@ -198,23 +198,32 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
             e.stamp = cache->clock;
             e.last_stream = s;
             cache->hits++;
-            cache->window_calls++;
             cache->miss_run = 0;
+            if (++cache->window_calls >= 32) {                      // a window closes: a quiet one resets the pause length
+                if (cache->window_misses == 0) cache->pause_len = 512;
+                cache->window_calls = cache->window_misses = 0;
+            }
             return hipGraphLaunch(e.exec, s) == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
         }
-    // A caller whose argument blocks never repeat (addresses or sizes change every call) gains nothing from
-    // capturing: after a window with mostly misses, plain launches are used for a while.
+    // A capture + instantiation costs ~2 ms, a replay saves some tens of microseconds of host time: a caller whose
+    // argument blocks do not repeat (the model mirror: fresh camera tensors, allocator addresses that cycle with a long
+    // period) must not keep capturing.  The first 32 calls are free (start-up: a few distinct phases, addresses that
+    // settle); after that two misses within a window of 32 calls, or a dozen in a row at any time, stop captures for a
+    // while (graphs already captured are still replayed: the lookup above comes first); the pause doubles every time it
+    // is needed again and goes back to 512 calls after a window without a miss.
+    // (plain launches while captures are paused -- the side branch still exists: the cache's side stream and events
+    // work outside a capture too)
+    if (cache->clock < cache->bypass_until) return enqueue(s, &cache->fork);
+    if (cache->window_calls >= 32) cache->window_calls = cache->window_misses = 0;
     cache->window_calls++;
     cache->window_misses++;
-    // ... and a dozen misses in a row (a caller that uploads fresh camera tensors every step: the model mirror) is
-    // answer enough -- a capture costs more than the launches it would have saved
-    if (++cache->miss_run >= 12) { cache->bypass_until = cache->clock + 512; cache->miss_run = 0; }
-    if (cache->window_calls >= 64) {
-        if (2 * cache->window_misses > cache->window_calls) cache->bypass_until = cache->clock + 512;
+    if (++cache->miss_run >= 12 || (cache->clock > 32 && cache->window_misses >= 2)) {
+        cache->bypass_until = cache->clock + cache->pause_len;
+        if (cache->pause_len < 65536) cache->pause_len *= 2;
+        cache->miss_run = 0;
         cache->window_calls = cache->window_misses = 0;
+        return enqueue(s, &cache->fork);
     }
-    // (plain launches, but the side branch still exists: the cache's side stream and events work outside a capture too)
-    if (cache->clock < cache->bypass_until) return enqueue(s, &cache->fork);
     // capture on the private stream (thread-local mode: other host threads keep using the runtime normally)
     hipStream_t cs = cache->capture_stream;
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {

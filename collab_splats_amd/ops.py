@@ -589,6 +589,15 @@ def _graph_cache(dev: torch.device):
     return C.c_void_p(_GRAPH_CACHE[idx])
 
 
+def reset_graph_cache(dev: Optional[torch.device] = None) -> None:
+    """Drop the device's graph cache (waits for the device): the next call starts a fresh one -- captured graphs, hit
+    statistics and a pause of captures after a run of misses (csrc/raster.hip, run_cached) all go."""
+    idx = torch.cuda.current_device() if dev is None or dev.index is None else dev.index
+    h = _GRAPH_CACHE.pop(idx, None)
+    if h:
+        _lib.load().misplat_graph_cache_destroy(C.c_void_p(h))
+
+
 def graph_cache_stats(dev: Optional[torch.device] = None) -> Dict[str, int]:
     """{"hits", "captures"} of the device's graph cache (zeros when graphs are off or unused)."""
     idx = torch.cuda.current_device() if dev is None or dev.index is None else dev.index

@@ -1153,14 +1153,18 @@ def _bench_like_scene(dev, N, W, H, seed, scale_mul=1.0):
             torch.sigmoid(sc["opacity_logits"]).to(dev), sc["sh"].to(dev), sc["viewmats"].to(dev), sc["Ks"].to(dev), W, H]
 
 
-def _fwd_bwd(args, **flags):
-    """One forward + backward under temporary ``ops`` switches; returns (images, gradients, meta)."""
+def _fwd_bwd(args, leaves=None, **flags):
+    """One forward + backward under temporary ``ops`` switches; returns (images, gradients, meta).  ``leaves``: the
+    parameter tensors to use (and reuse: a training loop's addresses repeat, fresh clones' do not)."""
     from collab_splats_amd import ops, rasterization
     old = {k: getattr(ops, k) for k in flags}
     for k, v in flags.items():
         setattr(ops, k, v)
     try:
-        leaves = [t.clone().requires_grad_(True) for t in args[:5]]
+        if leaves is None:
+            leaves = [t.clone().requires_grad_(True) for t in args[:5]]
+        for l in leaves:
+            l.grad = None
         out = rasterization(*leaves, *args[5:], sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased",
                             return_depth_normal=True)
         ups = [u.to(out[0].device) for u in upstream([t.shape for t in out[:5]], dtype=torch.float32)]
@@ -1182,9 +1186,14 @@ def test_one_entry_forward_speculation_and_graph_replay_change_nothing(dev):
                 dict(FUSED_ENTRY=True, SPECULATE=True, GRAPHS=False, UNIT_ORDER=True),
                 dict(FUSED_ENTRY=True, SPECULATE=True, GRAPHS=True, UNIT_ORDER=True),
                 dict(FUSED_ENTRY=False, UNIT_ORDER=True)]
+    from collab_splats_amd import ops
     for flags in variants:
-        for rep in range(3):                               # repeats: capacity hints, cached launch orders and graphs are reused
-            img, grad, meta = _fwd_bwd(args, **flags)
+        leaves = None
+        if flags.get("GRAPHS"):
+            ops.reset_graph_cache()                        # (earlier tests' many shapes may have paused captures)
+            leaves = [t.clone().requires_grad_(True) for t in args[:5]]     # one set of parameters, as a training loop has
+        for rep in range(6 if leaves else 3):              # repeats: capacity hints, cached launch orders and graphs are reused
+            img, grad, meta = _fwd_bwd(args, leaves, **flags)
             for a, b in zip(img, ref_img):
                 assert torch.equal(a, b), (flags, rep)
             assert meta["n_isects"] == ref_meta["n_isects"]
@@ -1192,6 +1201,10 @@ def test_one_entry_forward_speculation_and_graph_replay_change_nothing(dev):
             assert torch.equal(meta["isect_offsets"], ref_meta["isect_offsets"]), (flags, rep)
             for a, b in zip(grad, ref_grad):
                 assert rel_err(a, b) < 1e-5, (flags, rep)
+            del img, grad, meta, a, b                      # (nothing of this repeat stays allocated: the next one sees the same addresses)
+        if flags.get("GRAPHS"):
+            stats = ops.graph_cache_stats()
+            assert stats["captures"] >= 1 and stats["hits"] >= 1, stats     # graphs were captured AND replayed above
 
 
 def test_speculative_capacity_overflow_is_detected_and_redone_exactly(dev):
