@@ -52,7 +52,7 @@ class RasterArgs(C.Structure):
                 + [("cap_isects", C.c_int64)]
                 + [(n, C.c_void_p) for n in ("n_isects_host", "v_abs_zero", "render", "alpha", "exp_depth", "med_depth",
                                              "normal", "last_ids", "median_ids", "unit_perm_in", "unit_work",
-                                             "unit_perm_out")])
+                                             "unit_perm_out", "ev_blend_begin", "ev_blend_end")])
 
 
 class RasterBwdArgs(C.Structure):
@@ -64,7 +64,7 @@ class RasterBwdArgs(C.Structure):
                                             "depth_slot", "reserved")]
                 + [(n, C.c_void_p) for n in ("means", "quats", "scales", "opacities", "colors", "colors_rest", "viewmats",
                                              "radii", "compensations", "sh_aux", "v_means2d", "v_colors", "v_colors_rest",
-                                             "v_means_dir", "v_means", "v_quats", "v_scales", "v_opacities")])
+                                             "v_means_dir", "v_means", "v_quats", "v_scales", "v_opacities", "ev_blend_begin", "ev_blend_end")])
 
 
 def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: int = 16,

@@ -96,6 +96,7 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         misplat_params q = *p;
         q.unit_perm = a->unit_perm_in;
         q.unit_work = a->unit_work;
+        if (a->ev_blend_begin && hipEventRecord((hipEvent_t)a->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
         if (a->lazy_colour)
             rc = misplat_blend_fwd_lazy(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects, a->render,
                                         a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, a->means,
@@ -105,6 +106,7 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
             rc = misplat_blend_fwd(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects, a->render,
                                    a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, stream);
         if (rc != MISPLAT_OK) return rc;
+        if (a->ev_blend_end && hipEventRecord((hipEvent_t)a->ev_blend_end, s) != hipSuccess) return MISPLAT_ELAUNCH;
         if (a->unit_work && a->unit_perm_out) {
             rc = misplat_unit_order(p, p->ppl_fwd, a->unit_work, a->unit_perm_out, stream);
             if (rc != MISPLAT_OK) return rc;
@@ -328,11 +330,13 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
         add(b->v_scales, n * 3);
         add(b->v_opacities, n);
     }
+    if (b->ev_blend_begin && hipEventRecord((hipEvent_t)b->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
     int rc = misplat_internal::blend_bwd_atomic(&q, b->color_dim, b->Ks, b->grec, b->flatten_ids, b->offsets, b->n_isects,
                                                 b->alpha, b->last_ids, b->median_ids, b->render, b->v_render, b->v_alpha,
                                                 b->v_exp_depth, b->v_med_depth, b->v_normal, b->v_grec, b->v_abs, b->zero_flags,
                                                 background ? &F : nullptr, s);
     if (rc != MISPLAT_OK) return rc;
+    if (b->ev_blend_end && hipEventRecord((hipEvent_t)b->ev_blend_end, s) != hipSuccess) return MISPLAT_ELAUNCH;
     if (background)        // flagged rows only, both per-Gaussian stages in one launch
         return misplat_internal::gauss_bwd_sparse(p, b->sh_degree, b->depth_slot, b->means, b->quats, b->scales, b->opacities,
                                                   b->viewmats, b->Ks, b->colors, b->colors_rest, b->compensations, b->v_grec,
@@ -352,7 +356,7 @@ extern "C" int misplat_raster_bwd(const misplat_params* p, const misplat_raster_
     hipStream_t s = (hipStream_t)stream;
     // memset nodes are kept out of graphs (see the note on phase A): only the memset-free form is captured
     const bool memset_free = (b->zero_flags & 1) && (!b->v_abs || (b->zero_flags & 2));
-    if (!cache || !memset_free) return enqueue_backward(p, b, s);
+    if (!cache || !memset_free || b->ev_blend_begin || b->ev_blend_end) return enqueue_backward(p, b, s);
     return run_cached(cache, make_key(0x100, s, p, b), s, [&](hipStream_t st, const Fork*) { return enqueue_backward(p, b, st); });
 }
 

@@ -121,6 +121,15 @@ class _timed:
         return False
 
 
+def _kernel_event_pair():
+    """Two timing events whose raw handles the one-entry C calls record around a compositing kernel (measurement passes:
+    KERNEL_EVENTS is set); a torch event only gets its handle when it is first recorded."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    e1.record()
+    return e0, e1
+
+
 # Independent small kernels (colour vs binning in the forward, colour-backward vs projection-backward)
 # can be overlapped on one side stream per device (MISPLAT_OVERLAP=1).  Measured gain at 1 M / 1080p: <1 %
 # (every kernel already fills the chip), so it is off by default.
@@ -792,9 +801,14 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
     phases = 3 if state.get("deferred") else 2
     while True:
         a.payload, a.flatten_ids, a.scratch, a.cap_isects = _dp(payload), _dp(flatten_ids), _dp(scratch), cap
+        if KERNEL_EVENTS is not None:                                 # a measurement pass: events around the compositing forward
+            ev = _kernel_event_pair()
+            a.ev_blend_begin, a.ev_blend_end = ev[0].cuda_event, ev[1].cuda_event
+            KERNEL_EVENTS.setdefault("blend_fwd", []).append(ev)
         with _timed("raster_fwd_B"):
             check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(phases), stream_ptr(), _graph_cache(dev)),
                   "misplat_raster_fwd(B)")
+        a.ev_blend_begin, a.ev_blend_end = None, None
         phases = 2
         if static:                                                    # nobody waits: the count stays on the device
             _STATIC_SEEN[dev.index if dev.index is not None else torch.cuda.current_device()] = cap
@@ -921,6 +935,10 @@ class _RasterFused(torch.autograd.Function):
             b.compensations, b.sh_aux, b.v_means2d = _dp(comps), _dp(sh_aux), None
             b.v_colors, b.v_colors_rest, b.v_means_dir = _dp(v_colors), _dp(v_colors_rest), _dp(v_means_dir)
             b.v_means, b.v_quats, b.v_scales, b.v_opacities = _dp(v_means), _dp(v_quats), _dp(v_scales), _dp(v_opac)
+            if KERNEL_EVENTS is not None:                             # a measurement pass: events around the compositing backward
+                ev = _kernel_event_pair()
+                b.ev_blend_begin, b.ev_blend_end = ev[0].cuda_event, ev[1].cuda_event
+                KERNEL_EVENTS.setdefault("blend_bwd", []).append(ev)
             with _timed("raster_bwd"):
                 check(lib.misplat_raster_bwd(C.byref(P), C.byref(b), stream_ptr(), _graph_cache(dev)), "misplat_raster_bwd")
         else:

@@ -464,6 +464,9 @@ typedef struct misplat_raster_args {
     /* launch order (speed only): see misplat_params.unit_perm / unit_work */
     const int32_t* unit_perm_in;
     int32_t *unit_work, *unit_perm_out;
+    /* measurement (or NULL): two hipEvent_t recorded on `stream` directly before and after the compositing forward; a
+     * call that carries them is launched plainly (no graph) */
+    void *ev_blend_begin, *ev_blend_end;
 } misplat_raster_args;
 /* Graph cache (optional, caller-owned, thread-safe; the library itself keeps no state): with a cache, the launch
  * sequence of a call is captured into a hipGraph the first time a given (params, args, phases, stream) block is seen
@@ -501,6 +504,9 @@ typedef struct misplat_raster_bwd_args {
     const float *compensations, *sh_aux /* or NULL */;
     const float* v_means2d /* or NULL: the mean2d gradient is columns 0:2 of v_grec */;
     float *v_colors, *v_colors_rest /* or NULL */, *v_means_dir /* or NULL */, *v_means, *v_quats, *v_scales, *v_opacities;
+    /* measurement (or NULL): two hipEvent_t recorded on `stream` directly before and after the compositing backward; a
+     * call that carries them is launched plainly (no graph) */
+    void *ev_blend_begin, *ev_blend_end;
 } misplat_raster_bwd_args;
 int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
                        misplat_graph_cache* cache /* or NULL */);
