@@ -1390,6 +1390,44 @@ def test_activations_inside_the_projection_kernels_equal_torch_activations(dev, 
             assert_close_flips(a, b, name, tol=5e-5)
 
 
+@pytest.mark.parametrize("N", [30_000, 300_000])
+def test_gradient_sink_with_activations_inside_the_kernels(dev, N):
+    """parallel.GradientBuckets (the data-parallel path: the backward kernels write the parameters' gradients straight into
+    ONE flat buffer, stage by stage so that the colour bucket's all-reduce can start early) together with raw log-scales /
+    logits as inputs: every parameter is then a direct input of the rasterizer, so all five gradients land in the buffer
+    without a copy, and they equal the ordinary backward's."""
+    from collab_splats_amd import ops, parallel, rasterization
+    W, H = 640, 360
+    args = _bench_like_scene(dev, N, W, H, seed=17, scale_mul=1.5 if N > 100_000 else 1.0)
+    raw = [args[0], args[1], torch.log(args[2]), torch.logit(args[3].clamp(1e-4, 1 - 1e-4)), args[4]]
+    kw = dict(sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True,
+              scales_are_log=True, opacities_are_logit=True)
+    ups = None
+    grads = []
+    for sink in (False, True, True):
+        leaves = [t.clone().requires_grad_(True) for t in raw]
+        bucket = parallel.GradientBuckets(leaves, geometry=[0, 1, 2, 3], colour=[4]) if sink else None
+        if bucket is not None:
+            bucket.attach()
+        try:
+            out = rasterization(*leaves, args[5], args[6], W, H, **kw)
+            if ups is None:
+                ups = [u.to(dev) for u in upstream([t.shape for t in out[:5]], dtype=torch.float32)]
+            torch.autograd.backward(list(out[:5]), ups)
+        finally:
+            if bucket is not None:
+                bucket.allreduce()
+            assert ops.GRAD_SINK is None
+        if bucket is not None:
+            for l, v in zip(leaves, bucket.views):
+                assert l.grad.data_ptr() == v.data_ptr()                     # the gradients ARE the buffer's slices
+        grads.append([l.grad.clone() for l in leaves])
+    for got in grads[1:]:
+        for name, a, b in zip(("v_means", "v_quats", "v_log_scales", "v_opacity_logits", "v_sh"), got, grads[0]):
+            assert torch.isfinite(a).all(), name
+            assert rel_err(a, b) < 2e-5, (name, rel_err(a, b))
+
+
 def test_two_node_form_backpropagates_a_loss_on_projection_outputs(dev, monkeypatch):
     """MISPLAT_FUSED_NODE=0: the projection's own outputs in ``meta`` are differentiable, and a loss on them reaches the
     projection backward WITHOUT passing the compositing kernels -- the `touched` row flags (set by the compositing
