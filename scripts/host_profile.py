@@ -17,8 +17,9 @@ ups = [torch.rand(s, generator=g).to(dev) for s in ((1, H, W, 4), (1, H, W, 1), 
 def step():
     for p in params.values():
         p.grad = None
-    out = rasterization(params["means"], params["quats"], torch.exp(params["log_scales"]), torch.sigmoid(params["opacity_logits"]),
-                        params["sh"], V, K, W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True)
+    out = rasterization(params["means"], params["quats"], params["log_scales"], params["opacity_logits"],
+                        params["sh"], V, K, W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True,
+                        scales_are_log=True, opacities_are_logit=True)
     torch.autograd.backward(list(out[:5]), ups)
 for _ in range(20): step()
 torch.cuda.synchronize()

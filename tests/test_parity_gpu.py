@@ -1428,6 +1428,29 @@ def test_gradient_sink_with_activations_inside_the_kernels(dev, N):
             assert rel_err(a, b) < 2e-5, (name, rel_err(a, b))
 
 
+def test_large_scene_entirely_out_of_view_gives_zero_gradients(dev):
+    """No intersection at all in a scene large enough for the background-fill path (>= 262 144 Gaussians): the compositing
+    backward has no grid to carry the fill, the zeros are then written by plain fill launches -- every gradient is
+    exactly zero (the allocator is seeded with NaNs first), the images are empty."""
+    from collab_splats_amd import rasterization
+    N, W, H = 300_000, 320, 200
+    args = _bench_like_scene(dev, N, W, H, seed=3)
+    viewmats = args[5].clone()
+    viewmats[:, 2, 3] -= 1.0e4                                  # the whole scene behind the camera
+    for rep in range(2):
+        poison = [torch.full((N * 48 + 64 * k,), float("nan"), device=dev) for k in range(4)]
+        del poison
+        leaves = [t.clone().requires_grad_(True) for t in args[:5]]
+        out = rasterization(*leaves, viewmats, args[6], W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased",
+                            return_depth_normal=True, absgrad=True)
+        assert int(out[5]["n_isects"]) == 0 and float(out[1].detach().abs().sum()) == 0.0
+        ups = [u.to(dev) for u in upstream([t.shape for t in out[:5]], dtype=torch.float32)]
+        torch.autograd.backward(list(out[:5]), ups)
+        for l in leaves:
+            assert l.grad is not None and float(l.grad.abs().sum()) == 0.0
+        assert float(out[5]["means2d"].absgrad.abs().sum()) == 0.0
+
+
 def test_two_node_form_backpropagates_a_loss_on_projection_outputs(dev, monkeypatch):
     """MISPLAT_FUSED_NODE=0: the projection's own outputs in ``meta`` are differentiable, and a loss on them reaches the
     projection backward WITHOUT passing the compositing kernels -- the `touched` row flags (set by the compositing
