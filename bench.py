@@ -6,14 +6,19 @@
           --master-port P bench.py --gpus N --steps K --warmup W; `python bench.py --gpus N` alone starts the
           N ranks itself as child processes)
 
-A "step" is one pass of the hot path over one view of the synthetic scene: activations
-(exp/sigmoid, rade_gs_model.py:443-444) -> rasterization(..., return_depth_normal=True) -> backward
-of all five outputs to the six parameter tensors.  Workload (BASELINE.json configs[2], the one the
-metric is quoted on): 1 M random Gaussians, 1920x1080, SH degree 3, RGB+ED, antialiased.  With N
-GPUs every rank renders its own view of its own replica (configs[3]: independent views, no
-collective, weak scaling).  --shared-grads: all ranks hold the SAME Gaussians, render different views and
-all-reduce the 236 B/Gaussian gradients over RCCL; with --dn-loss the step is the model mirror's
-get_outputs -> L1 + depth-normal consistency loss -> backward (configs[4] exactly; use --gaussians 5000000).
+A "step" is one pass of the hot path over one view of the synthetic scene, exactly as the reference's caller issues it
+(rade_gs_model.py:439-465): torch.exp / torch.sigmoid of the raw parameters (:443-444) -> rasterization(...,
+return_depth_normal=True) -> backward of all five outputs to the six parameter tensors -- and, as in training
+(one camera per step, :94-95), a DIFFERENT camera every step: the eight views of BASELINE configs[3] are cycled.
+Workload (BASELINE.json configs[2], the one the metric is quoted on): 1 M random Gaussians, 1920x1080, SH degree 3, RGB+ED,
+antialiased.  `value` is that drop-in step.  The same line carries `variants`: the 2 x 2 of {torch activations,
+scales_are_log / opacities_are_logit inside the projection kernels (an extension of this build)} x {cycling views,
+one fixed view}, each measured with the same protocol right after the headline (`value_ext` = extension + cycling);
+--ext-activations / --fixed-view make one of the other corners the headline.  With N GPUs every rank renders its own
+views of its own replica (configs[3]: independent views, no collective, weak scaling).  --shared-grads: all ranks hold
+the SAME Gaussians, render different views and all-reduce the 236 B/Gaussian gradients over RCCL; with --dn-loss the step
+is the model mirror's get_outputs -> L1 + depth-normal consistency loss -> backward (configs[4] per GPU minus the SSIM
+term of the Splatfacto base loss, which is third-party and not built; use --gaussians 5000000).
 Inputs are resident in HBM before the timed region.
 
 Protocol: W untimed steps, then EXACTLY K steps between two barrier+synchronize fences,
@@ -55,9 +60,15 @@ def parse():
     ap.add_argument("--render-mode", default="RGB+ED")
     ap.add_argument("--rasterize-mode", default="antialiased")
     ap.add_argument("--shared-grads", action="store_true", help="shared Gaussians: all-reduce the gradients over RCCL")
-    ap.add_argument("--torch-activations", action="store_true",
-                    help="exp(log_scales) / sigmoid(opacity_logits) as torch launches in front of rasterization(), as the "
-                         "reference calls it (default: the scales_are_log / opacities_are_logit extension)")
+    ap.add_argument("--ext-activations", action="store_true",
+                    help="headline = the scales_are_log / opacities_are_logit extension (exp / sigmoid inside the projection "
+                         "kernels); default: torch.exp / torch.sigmoid in front of rasterization(), as the reference calls it")
+    ap.add_argument("--fixed-view", action="store_true",
+                    help="headline = the same camera every step; default: the eight views of configs[3] cycled, one per step")
+    ap.add_argument("--no-variants", action="store_true", help="skip the other three corners of the 2 x 2 (`variants`)")
+    ap.add_argument("--buckets", action="store_true",
+                    help="attach a parallel.GradientBuckets sink even on one GPU (no collective): measures what the "
+                         "data-parallel backward costs on top of the plain one")
     ap.add_argument("--dn-loss", action="store_true",
                     help="step = RadegsModel.get_outputs -> L1 + depth-normal consistency loss -> backward (configs[4])")
     ap.add_argument("--graphed", action="store_true",
@@ -156,49 +167,69 @@ def cpu_baseline(args, seed: int):
     return base, keep
 
 
-def parity(args, sc, scales, op, ups, gr, what: str):
-    """The second half of the metric ("grad max-rel-err vs reference"): HIP gradients against the C port (the checker;
-    the upstream CUDA reference is absent -- parity unpinned).  tensor-inf-norm relative error
-    max|g - g_ref| / max|g_ref|  per parameter."""
-    import numpy as np
+def rasterize_step(params, viewmats, Ks, W, H, args, ext: bool):
+    """THE call of a step -- the timed loop and the parity leg both go through here.  ``ext`` False: the reference's call
+    (torch.exp / torch.sigmoid in front, rade_gs_model.py:443-444); True: the same step with the activations inside the
+    projection kernels (scales_are_log / opacities_are_logit, an extension of this build)."""
     from collab_splats_amd.rendering import rasterization
-    dev = torch.device("cuda", torch.cuda.current_device())
-    leaves = [sc["means"].to(dev).requires_grad_(True), sc["quats"].to(dev).requires_grad_(True),
-              torch.from_numpy(scales).to(dev).requires_grad_(True), torch.from_numpy(op).to(dev).requires_grad_(True),
-              sc["sh"].to(dev).requires_grad_(True)]
-    out = rasterization(*leaves, sc["viewmats"].to(dev), sc["Ks"].to(dev), args.width, args.height, sh_degree=3,
-                        render_mode=args.render_mode, rasterize_mode=args.rasterize_mode, return_depth_normal=True)
-    torch.autograd.backward(list(out[:5]), [torch.from_numpy(u)[None].to(dev) for u in ups])
+    kw = dict(near_plane=0.01, far_plane=1e10, sh_degree=3, packed=False, render_mode=args.render_mode, sparse_grad=False,
+              absgrad=False, rasterize_mode=args.rasterize_mode, return_depth_normal=True)
+    if ext:
+        return rasterization(params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"],
+                             viewmats, Ks, W, H, scales_are_log=True, opacities_are_logit=True, **kw)
+    return rasterization(params["means"], params["quats"], torch.exp(params["log_scales"]),
+                         torch.sigmoid(params["opacity_logits"]), params["sh"], viewmats, Ks, W, H, **kw)
+
+
+def parity(args, params, viewmats, Ks, W, H, ext, ups_dev, gr, act, what: str):
+    """The second half of the metric ("grad max-rel-err vs reference"): the gradients of the step the benchmark times --
+    the same `rasterize_step` call on `params` (the benchmark's own leaves when the full workload is checked) -- against
+    the C port (the checker; the upstream CUDA reference is absent: parity unpinned).
+    tensor-inf-norm relative error  max|g - g_ref| / max|g_ref|  per RAW parameter: the C port's gradients of the activated
+    scales / opacities are chained through exp / sigmoid (`act` = the activated values it was given)."""
+    import numpy as np
+    for p in params.values():
+        p.grad = None
+    out = rasterize_step(params, viewmats, Ks, W, H, args, ext)
+    torch.autograd.backward(list(out[:5]), ups_dev)
+    torch.cuda.synchronize()
+    scales, op = act
+    want = {"means": gr["v_means"], "quats": gr["v_quats"], "log_scales": gr["v_scales"] * scales,
+            "opacity_logits": gr["v_opacities"] * op * (1.0 - op), "sh": gr["v_colors"]}
 
     def rel(a, b):
         a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
         return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
-    names = ("v_means", "v_quats", "v_scales", "v_opacities", "v_colors")
-    errs = {k[2:]: rel(l.grad.cpu().numpy(), gr[k]) for k, l in zip(names, leaves)}
+    errs = {k: rel(params[k].grad.cpu().numpy(), want[k]) for k in want}
     return {"value": float(f"{max(errs.values()):.3e}"), "per_tensor": {k: float(f"{v:.3e}") for k, v in errs.items()},
-            "on": what, "against": "oracle/craster.c (fp32 C port; upstream gsplat-rade absent: parity unpinned)",
-            "target": 1e-4}
+            "on": what, "call": "the timed step's own call (" + ("extension" if ext else "torch") + " activations), raw-parameter gradients",
+            "against": "oracle/craster.c (fp32 C port; upstream gsplat-rade absent: parity unpinned)", "target": 1e-4}
 
 
-def copy_roof(dev) -> float:
-    """GB/s of a float4 streaming copy (read + write bytes) on this box, 512 MiB buffers, best of 5."""
+def copy_roof(dev):
+    """GB/s of a float4 streaming copy (read + write bytes) on this box, 512 MiB buffers: best of 5 for each kernel variant
+    (plain / non-temporal / four loads in flight); returns (best, per-variant list)."""
     import ctypes as C
     from collab_splats_amd import _lib
     lib = _lib.load()
     n4 = (512 << 20) // 16
     src = torch.empty(n4 * 4, device=dev, dtype=torch.float32).normal_()
     dst = torch.empty_like(src)
-    best = 0.0
-    for i in range(7):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _lib.check(lib.misplat_stream_copy(_lib.ptr(src), _lib.ptr(dst), C.c_int64(n4), _lib.stream_ptr()), "misplat_stream_copy")
-        e1.record()
-        e1.synchronize()
-        if i >= 2:
-            best = max(best, 2 * n4 * 16 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-    return best
+    per = []
+    for variant in range(3):
+        best = 0.0
+        for i in range(7):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.misplat_stream_copy(_lib.ptr(src), _lib.ptr(dst), C.c_int64(n4), C.c_int32(variant), _lib.stream_ptr()),
+                       "misplat_stream_copy")
+            e1.record()
+            e1.synchronize()
+            if i >= 2:
+                best = max(best, 2 * n4 * 16 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+        per.append(round(best, 1))
+    return max(per), per
 
 
 def spawn_ranks(args) -> int:
@@ -216,6 +247,22 @@ def spawn_ranks(args) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+GUIDE_COPY_GBS = 6290.0     # MI355X_MICROARCH.md: measured float4 copy
+
+
+def traversed_entries(meta, W, H):
+    """List entries the compositing BACKWARD stages: per band (16 x 8 pixels) everything from the tile's first entry to the
+    band's deepest `last_ids` -- what `64 * I` of SURVEY 8(d) becomes once the early termination is counted."""
+    if W % 16 or H % 8:
+        return None
+    last = meta["last_ids"][0]
+    offs = meta["isect_offsets"][0]
+    bands = last.view(H // 8, 8, W // 16, 16).amax(dim=(1, 3)).long()                     # [H/8, W/16]
+    rows = torch.arange(H // 8, device=last.device) // 2
+    beg = offs[rows].long()                                                               # tile row of every band row
+    return int((bands - beg + 1).clamp(min=0).sum().item())
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -231,33 +278,40 @@ def main():
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     from collab_splats_amd import ops, radegs
-    from collab_splats_amd.rendering import rasterization
     from collab_splats_amd.synthetic import random_scene, view_matrix
 
     N, W, H = args.gaussians, args.width, args.height
     shared = args.shared_grads or args.dn_loss
     seed = 42 if shared else 42 + rank              # shared Gaussians vs independent scenes
     sc = random_scene(N, W, H, seed=seed)
-    viewmats = (view_matrix(rank) if world > 1 else sc["viewmats"]).to(dev)
+    # the eight views of configs[3], resident on the device (the "dataset"); view 0 is the identity view of the generator
+    views = [view_matrix(v).to(dev) for v in range(8)]
     Ks = sc["Ks"].to(dev)
     cd = {"RGB": 3, "RGB+ED": 4, "RGB+D": 4}[args.render_mode]
     g = torch.Generator().manual_seed(7)
-    info = {"allreduce_ms": []}
+    info = {"allreduce_ms": [], "it": 0, "isects": []}
     bucket = None
+    mode = {"ext": bool(args.ext_activations), "fixed": bool(args.fixed_view)}
+
+    def view_index():
+        return rank % 8 if mode["fixed"] else (rank + info["it"]) % 8
 
     if args.dn_loss:
-        # configs[4]: the model mirror (a1 + a2 + a3 + a4 + a5) with the depth-normal consistency loss active
+        # configs[4] per GPU: the model mirror (a1 + a2 + a3 + a4 + a5) with the depth-normal consistency loss active
+        # (its activations are inside the kernels; the base loss is L1 only -- no SSIM)
         cfg = radegs.RadegsModelConfig(rasterize_mode=args.rasterize_mode, regularization_from_iter=0)
         model = radegs.RadegsModel(cfg, sc["means"], sc["log_scales"], sc["quats"], sc["opacity_logits"], sc["sh"][:, 0],
                                    sc["sh"][:, 1:]).to(dev)
         model.train()
         model.step = 20000
-        c2w = torch.linalg.inv(viewmats[0].cpu())[:3, :4].clone()
-        c2w[:, 1:3] *= -1.0                         # OpenCV world->camera back to the OpenGL camera-to-world the model takes
-        cam = radegs.PinholeCamera.make(c2w, float(Ks[0, 0, 0]), float(Ks[0, 1, 1]), W, H)
+        cams = []
+        for v in range(8):
+            c2w = torch.linalg.inv(view_matrix(v)[0])[:3, :4].clone()
+            c2w[:, 1:3] *= -1.0                     # OpenCV world->camera back to the OpenGL camera-to-world the model takes
+            cams.append(radegs.PinholeCamera.make(c2w, float(Ks[0, 0, 0]), float(Ks[0, 1, 1]), W, H))
         target = torch.rand(H, W, 3, generator=g).to(dev)
         leaves = [model.gauss_params[k] for k in parallel.GRAD_KEYS]
-        if shared and world > 1:
+        if (shared and world > 1) or args.buckets:
             bucket = parallel.GradientBuckets(leaves)
 
         def step():
@@ -266,17 +320,19 @@ def main():
                     p.grad = None
             else:
                 bucket.attach()
-            out = model.get_outputs(cam)
+            out = model.get_outputs(cams[view_index()])
             loss = model.get_loss_dict(out, {"image": target})
             functools.reduce(torch.add, loss.values()).backward()      # (nerfstudio's trainer sums the dictionary this way)
             if bucket is not None:
                 info["allreduce_ms"].append(bucket.allreduce())
-            info["n_isects"], info["n_visible"] = model.info["n_isects"], model.info["radii"]
+            info["n_isects"], info["n_visible"], info["meta"] = model.info["n_isects"], model.info["radii"], model.info
+            info["isects"].append(int(model.info["n_isects"]))
+            info["it"] += 1
     else:
         params = {k: sc[k].to(dev).requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
         ups = [torch.rand(s, generator=g).to(dev) for s in ((1, H, W, cd), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3))]
         leaves = list(params.values())
-        if shared and world > 1:
+        if (shared and world > 1) or args.buckets:
             bucket = parallel.GradientBuckets(leaves, geometry=[0, 1, 2, 3], colour=[4])
 
         def step():
@@ -285,81 +341,108 @@ def main():
                     p.grad = None
             else:
                 bucket.attach()
-            if args.torch_activations:             # the reference's call: activations as separate torch launches
-                out = rasterization(params["means"], params["quats"], torch.exp(params["log_scales"]),
-                                    torch.sigmoid(params["opacity_logits"]), params["sh"], viewmats, Ks, W, H,
-                                    near_plane=0.01, far_plane=1e10, sh_degree=3, packed=False,
-                                    render_mode=args.render_mode, sparse_grad=False, absgrad=False,
-                                    rasterize_mode=args.rasterize_mode, return_depth_normal=True)
-            else:                                  # the same step with exp / sigmoid inside the projection kernels
-                out = rasterization(params["means"], params["quats"], params["log_scales"], params["opacity_logits"],
-                                    params["sh"], viewmats, Ks, W, H, near_plane=0.01, far_plane=1e10, sh_degree=3,
-                                    packed=False, render_mode=args.render_mode, sparse_grad=False, absgrad=False,
-                                    rasterize_mode=args.rasterize_mode, return_depth_normal=True,
-                                    scales_are_log=True, opacities_are_logit=True)
+            out = rasterize_step(params, views[view_index()], Ks, W, H, args, mode["ext"])
             torch.autograd.backward(list(out[:5]), ups)
             if bucket is not None:
                 info["allreduce_ms"].append(bucket.allreduce())
-            info["n_isects"], info["n_visible"] = out[5]["n_isects"], out[5]["radii"]
+            info["n_isects"], info["n_visible"], info["meta"] = out[5]["n_isects"], out[5]["radii"], out[5]
+            info["isects"].append(int(out[5]["n_isects"]))
+            info["it"] += 1
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    roof = copy_roof(dev) if rank == 0 else 0.0
+    def timed(run, k, w):
+        """w untimed + exactly k timed steps between two fences: (wall seconds max over ranks, device-event median ms)."""
+        for _ in range(w):
+            run()
+        info["allreduce_ms"].clear()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
+        fence()
+        t0 = time.perf_counter()
+        for e0, e1 in evs:
+            e0.record()
+            run()
+            e1.record()
+        fence()
+        dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+        dev_ms = sorted(a.elapsed_time(b) for a, b in evs)
+        return dt, dev_ms[len(dev_ms) // 2]
+
+    roof, roof_variants = copy_roof(dev) if rank == 0 else (0.0, [])
     eager_step, graphed = step, None
     if args.graphed:
-        if args.dn_loss or shared:
+        if args.dn_loss or shared or args.buckets:
             raise SystemExit("bench.py: --graphed covers the plain rasterization step only")
+        mode["fixed"] = True                       # (a captured graph replays ONE argument block: one camera)
         from collab_splats_amd import graphs
         step()                                     # one eager step: learn the intersection count
         torch.cuda.synchronize()
         capacity = int(int(info["n_isects"]) * 1.5) + 4096
         graphed = graphs.GraphedStep(step, capacity=capacity)
         step = graphed.replay
-    for _ in range(args.warmup):
-        step()
-    info["allreduce_ms"].clear()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    fence()
-    t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record()
-        step()
-        e1.record()
-    fence()
-    dt = time.perf_counter() - t0
-    dt = parallel.max_over_ranks(dt, dev)
-    dev_ms = sorted(a.elapsed_time(b) for a, b in evs)
-    dev_med = dev_ms[len(dev_ms) // 2]
+    stats0 = dict(ops.PATH_STATS)
+    dt, dev_med = timed(step, args.steps, args.warmup)
+    took = {k: ops.PATH_STATS[k] - stats0.get(k, 0) for k in ops.PATH_STATS}
+    headline_mode = dict(mode)
     if graphed is not None:
         graphed.check()                            # the fixed capacity held for every replay
         step = eager_step
         step()                                     # (eager again: info[...] must not point into the graph's pool)
     allreduce_ms = sorted(ev[0].elapsed_time(ev[1]) for ev in info["allreduce_ms"] if ev is not None)
 
+    # ---- the other corners of {torch, extension activations} x {cycling, fixed view}: same protocol, after the headline
+    variants = {}
+
+    def label(m):
+        return ("ext" if m["ext"] else "torch") + "_activations+" + ("fixed_view" if m["fixed"] else "cycling_views")
+
+    ms_head = dt / args.steps * 1e3
+    variants[label(headline_mode)] = {"ms_per_step": round(ms_head, 4), "device_ms_median": round(dev_med, 4),
+                                      "value": round(world * N / (dt / args.steps) / 1e6, 3)}
+    if not args.no_variants and not args.dn_loss and graphed is None:
+        for ext in (False, True):
+            for fixed in (False, True):
+                m = {"ext": ext, "fixed": fixed}
+                if m == headline_mode:
+                    continue
+                mode.update(m)
+                dtv, medv = timed(step, args.steps, args.warmup)
+                variants[label(m)] = {"ms_per_step": round(dtv / args.steps * 1e3, 4), "device_ms_median": round(medv, 4),
+                                      "value": round(world * N / (dtv / args.steps) / 1e6, 3)}
+        mode.update(headline_mode)
+
     # ---- instrumented pass (outside the timed region): HIP events on the launch stream around the compositing kernels
     # (the same path as the timed region: the one-entry C calls record the events themselves, directly before and
     # after the kernel, and launch plainly instead of replaying a graph while they carry events)
     ops.KERNEL_EVENTS = {}
-    for _ in range(7):
+    info["isects"].clear()
+    n_inst = 10
+    trav = []
+    for i in range(n_inst):
         step()
+        if rank == 0 and i >= 2:
+            t = traversed_entries(info["meta"], W, H)
+            if t is not None:
+                trav.append(t)
     torch.cuda.synchronize()
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
 
     if rank == 0:
-        I = int(info["n_isects"])
+        isects = info["isects"][2:] or [int(info["n_isects"])]
+        I = int(sum(isects) / len(isects))         # mean over the instrumented launches (the views differ)
         n_vis = int((info["n_visible"] > 0).any(-1).sum().item())
         ktimes = {}
-        for k, v in events.items():                # ms; the first two instrumented steps are warm-up
-            ts = sorted(a.elapsed_time(b) for a, b in v[2:]) or [0.0]
-            ktimes[k] = ts[len(ts) // 2]
+        for k, v in events.items():                # ms; the first two instrumented steps are warm-up; MEAN duration per launch
+            ts = [a.elapsed_time(b) for a, b in v[2:]] or [0.0]
+            ktimes[k] = sum(ts) / len(ts)
         dom = max((k for k in ktimes if k in ("blend_bwd", "blend_fwd", "slab_reduce")), key=ktimes.get)
         abytes = algorithmic_bytes(dom, N, I, W * H)
         achieved = abytes / (ktimes[dom] * 1e-3) / 1e9
+        I_trav = int(sum(trav) / len(trav)) if trav else None
         step_bytes = algorithmic_bytes("step", N, I, W * H)
-        ms = dt / args.steps * 1e3
         step_gbs = step_bytes / (dev_med * 1e-3) / 1e9
         pmc = {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -369,40 +452,62 @@ def main():
             except Exception:
                 pmc = {}
         vif = pmc.get("valu_issue_frac")
+        view_txt = ("one fixed view" if headline_mode["fixed"] else "8 cycling views (configs[3]'s cameras, one per step)")
         if args.dn_loss:
-            wl = (f"{N} shared Gaussians, 1 view {W}x{H} per GPU, model mirror get_outputs -> L1 + depth-normal "
-                  f"consistency loss -> backward (BASELINE configs[4])")
+            wl = (f"{N} shared Gaussians, {view_txt} {W}x{H} per GPU, model mirror get_outputs -> L1 + depth-normal "
+                  f"consistency loss (no SSIM: the Splatfacto base loss is third-party) -> backward (BASELINE configs[4] per GPU); "
+                  f"activations inside the projection kernels")
         else:
-            wl = (f"{N} random Gaussians, 1 view {W}x{H} per GPU, SH degree 3, {args.render_mode} "
+            wl = (f"{N} random Gaussians, {view_txt} {W}x{H} per GPU, SH degree 3, {args.render_mode} "
                   f"({args.rasterize_mode}), colour+alpha+expected/median depth+normal, fwd+bwd to all six parameter tensors; "
-                  + ("exp(log_scales) / sigmoid(opacity_logits) as torch launches" if args.torch_activations
-                     else "exp(log_scales) / sigmoid(opacity_logits) inside the projection kernels (scales_are_log / opacities_are_logit)"))
+                  + ("exp(log_scales) / sigmoid(opacity_logits) inside the projection kernels (scales_are_log / opacities_are_logit extension)"
+                     if headline_mode["ext"] else "torch activations (torch.exp / torch.sigmoid in front, the reference's call)"))
+        if not shared and bucket is None:
+            par = "independent views, no collective"
+        elif world == 1:
+            par = "one GPU, no collective" + ("; gradients written into a GradientBuckets flat buffer (--buckets)" if bucket is not None else "")
+        else:
+            par = "shared Gaussians, RCCL all-reduce of 236 B/Gaussian grads (colour + geometry bucket, zero-copy flat buffer)"
         line = {
             "metric": "Msplats/s fwd+bwd @1080p (1M Gaussians); grad max-rel-err vs reference",
             "value": round(world * N / (dt / args.steps) / 1e6, 3), "unit": "Msplats/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_head, 4),
             "device_ms_median": round(dev_med, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": wl, "views": world, "n_isects": I, "n_visible": n_vis,
-                       "parallelism": ("independent views, no collective" if not shared
-                                       else "shared Gaussians, RCCL all-reduce of 236 B/Gaussian grads (two buckets, "
-                                            "zero-copy flat buffer)"),
+            "value_ext": variants.get("ext_activations+cycling_views", {}).get("value"),
+            "variants": variants,
+            "config": {"workload": wl, "views": 1 if headline_mode["fixed"] else 8, "n_isects": I, "n_isects_per_view": isects[:8],
+                       "n_visible": n_vis, "parallelism": par,
                        "git_rev": git_rev(), "graph_cache": ops.graph_cache_stats(),
+                       "path": {k: took.get(k, 0) for k in ("forward", "forward_lazy_colour", "forward_merged_phases",
+                                                           "forward_prev_order", "capacity_redo", "backward_one_call",
+                                                           "backward_background_fill", "backward_staged", "backward_sink")},
+                       "path_note": f"counts over the {args.steps + args.warmup} headline steps: on-demand colours, merged "
+                                    "phases, previous-step launch order, capacity misses, one-call backward, background fill",
                        "host": (f"whole step replayed as one hipGraph (graphs.GraphedStep, fixed capacity "
                                 f"{graphed.capacity} intersections, no host synchronisation)" if graphed is not None
                                 else "eager PyTorch step (the reference's training loop is eager)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "frac_of_guide_copy_6290": round(achieved / GUIDE_COPY_GBS, 5),
                          "traffic": pmc.get(dom), "traffic_git_rev": pmc.get("git_rev"),
                          "valu_issue_frac": vif.get(dom) if isinstance(vif, dict) else None,
                          "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
-                         "kernel_ms_note": "HIP events recorded by the C entries directly around the compositing kernels of "
-                                           "the default path, in a separate pass of plain launches after the timed region",
+                         "kernel_ms_note": "mean per launch: HIP events recorded by the C entries directly around the compositing "
+                                           "kernels of the headline path, in a separate pass of plain launches after the timed region",
                          "algorithmic_bytes": abytes,
-                         "copy_roof_GBs": round(roof, 1), "frac_of_copy_roof": round(achieved / max(roof, 1e-9), 5),
+                         "algorithmic_bytes_note": "SURVEY 8(d): 88 P + 64 I + 60 N with I = all intersections (mean over the views)",
+                         "traversed_entries": I_trav,
+                         "achieved_traversed": (round((88.0 * W * H + 64.0 * I_trav + 60.0 * N) / (ktimes[dom] * 1e-3) / 1e9, 2)
+                                                if (I_trav is not None and dom == "blend_bwd") else None),
+                         "traversed_note": "64 I replaced by 64 x the list entries the backward really stages (early termination: "
+                                           "per band, first entry .. deepest last_id); the dense-scene figure to read next to `achieved`",
+                         "copy_roof_GBs": round(roof, 1), "copy_roof_variants_GBs": roof_variants,
+                         "frac_of_copy_roof": round(achieved / max(roof, 1e-9), 5),
                          "step_algorithmic_bytes": step_bytes, "step_GBs": round(step_gbs, 1),
                          "step_frac": round(step_gbs / HBM_PEAK_GBS, 5),
+                         "step_frac_of_guide_copy_6290": round(step_gbs / GUIDE_COPY_GBS, 5),
                          "step_frac_of_copy_roof": round(step_gbs / max(roof, 1e-9), 5),
                          "note": "the compositing kernels are VALU (v_exp/FMA) issue bound, not HBM bound: "
                                  "valu_issue_frac is the share of SIMD issue cycles (PMC, profiles/), see DESIGN.md"},
@@ -410,20 +515,32 @@ def main():
         if allreduce_ms:
             line["allreduce_ms"] = round(allreduce_ms[len(allreduce_ms) // 2], 4)
         if world == 1 and not args.no_cpu_baseline and not args.dn_loss:
+            import numpy as np
+            from oracle.craster import CRaster
             line["cpu_baseline"], keep = cpu_baseline(args, seed)
-            sc_s, scales_s, op_s, ups_s, gr_s = keep
-            what = f"the cpu_baseline sample ({min(args.cpu_sample, N)} Gaussians)"
-            if (os.cpu_count() or 1) >= 32 and N <= 1_000_000 and N > args.cpu_sample:
-                # enough host cores: check the gradients on the FULL workload (one C-port iteration)
-                import numpy as np
-                from oracle.craster import CRaster
-                cr = CRaster(np.float32)
-                scales_f, op_f = torch.exp(sc["log_scales"]).numpy(), torch.sigmoid(sc["opacity_logits"]).numpy()
-                gcpu = torch.Generator().manual_seed(7)
-                ups_f = [torch.rand(s, generator=gcpu).numpy() for s in ((H, W, cd), (H, W, 1), (H, W, 1), (H, W, 1), (H, W, 3))]
-                _, gr_f = _c_port_run(cr, sc, scales_f, op_f, W, H, args, ups_f)
-                sc_s, scales_s, op_s, ups_s, gr_s, what = sc, scales_f, op_f, ups_f, gr_f, f"the full workload ({N} Gaussians)"
-            line["grad_max_rel_err"] = parity(args, sc_s, scales_s, op_s, ups_s, gr_s, what)
+            cr = CRaster(np.float32)
+            full = (os.cpu_count() or 1) >= 32 and args.cpu_sample < N <= 1_000_000
+            mode.update(headline_mode)
+            if full:
+                # enough host cores: the gradients of the FULL workload, on the benchmark's own leaves (one C-port iteration)
+                sc_p, params_p, what = sc, params, f"the full workload ({N} Gaussians), view 0"
+            else:
+                n_s = min(args.cpu_sample, N)
+                sc_p = random_scene(n_s, W, H, seed=seed)
+                params_p = {k: sc_p[k].to(dev).requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+                what = f"the cpu_baseline sample ({n_s} Gaussians), view 0"
+            # the C port activates like the step that is checked: torch's exp / sigmoid for the reference's call, the kernels'
+            # own fixed-sequence exp (cr_activate) for the extension
+            if headline_mode["ext"]:
+                act = cr.activate(sc_p["log_scales"].numpy(), sc_p["opacity_logits"].numpy())
+            else:                                  # (evaluated where the step evaluates them: bit-identical inputs on both sides)
+                act = (torch.exp(params_p["log_scales"]).detach().cpu().numpy(),
+                       torch.sigmoid(params_p["opacity_logits"]).detach().cpu().numpy())
+            gcpu = torch.Generator().manual_seed(7)
+            ups_np = [torch.rand(s, generator=gcpu) for s in ((1, H, W, cd), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3))]
+            _, gr = _c_port_run(cr, sc_p, act[0], act[1], W, H, args, [u[0].numpy() for u in ups_np])
+            line["grad_max_rel_err"] = parity(args, params_p, views[0], Ks, W, H, headline_mode["ext"],
+                                              [u.to(dev) for u in ups_np], gr, act, what)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

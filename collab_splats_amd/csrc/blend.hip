@@ -1371,8 +1371,10 @@ __global__ __launch_bounds__(1024) void unit_order_kernel(int units, int per, co
     __shared__ uint32_t wmax[16];
     const int x = blockIdx.x;
     const int lo = x * per, hi = min(lo + per, units);
+    // (the work counts are a hint from another launch: whatever they hold -- negative, huge, changing while this kernel
+    // reads them -- the result is a permutation of the strip's units and every access stays inside hist[] / perm[])
     int mx = 0;
-    for (int u = lo + threadIdx.x; u < hi; u += 1024) mx = max(mx, work[u]);
+    for (int u = lo + threadIdx.x; u < hi; u += 1024) mx = max(mx, max(work[u], 0));
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) mx = max(mx, __shfl_xor(mx, m));
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = (uint32_t)mx;
@@ -1382,7 +1384,8 @@ __global__ __launch_bounds__(1024) void unit_order_kernel(int units, int per, co
 #pragma unroll
     for (int w = 0; w < 16; w++) top = max(top, wmax[w]);
     const float scale = 255.0f / (float)top;
-    for (int u = lo + threadIdx.x; u < hi; u += 1024) atomicAdd(&hist[255 - (int)((float)work[u] * scale)], 1u);
+    auto cls_of = [&](int w) { return 255 - min(255, (int)((float)min(max(w, 0), (int)top) * scale)); };
+    for (int u = lo + threadIdx.x; u < hi; u += 1024) atomicAdd(&hist[cls_of(work[u])], 1u);
     __syncthreads();
     // exclusive scan of the 256 classes (class 0 = heaviest): waves 0..3, one class per lane
     uint32_t v = 0u, incl = 0u;
@@ -1404,8 +1407,8 @@ __global__ __launch_bounds__(1024) void unit_order_kernel(int units, int per, co
     }
     __syncthreads();
     for (int u = lo + threadIdx.x; u < hi; u += 1024) {
-        const uint32_t rank = atomicAdd(&hist[255 - (int)((float)work[u] * scale)], 1u);
-        perm[rank * 8 + x] = u;
+        const uint32_t rank = atomicAdd(&hist[cls_of(work[u])], 1u);
+        if (rank < (uint32_t)per) perm[rank * 8 + x] = u;
     }
     for (int r = (hi > lo ? hi - lo : 0) + threadIdx.x; r < per; r += 1024) perm[r * 8 + x] = units;   // padding: no unit
 }
@@ -1519,7 +1522,7 @@ extern "C" int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, con
     const int total = p->tile_w * p->tile_h * p->n_cams * planes;
     const int grid = ((total + 7) / 8) * 8;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(slab_valid, 0, (size_t)n_isects * planes, s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (misplat_internal::fill_bytes(slab_valid, (size_t)n_isects * planes, 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
 #define LAUNCH_BWD(CD_, PPL_, ABS_)                                                                          \
     hipLaunchKernelGGL((blend_bwd_kernel<CD_, PPL_, ABS_, false>), dim3(grid), dim3(64), 0, s, *p, Ks,         \
                        (const float4*)grec, flatten_ids, slots_sorted, offsets, n_isects, alpha, last_ids,     \
@@ -1563,8 +1566,8 @@ int misplat_internal::blend_bwd_atomic(const misplat_params* p, int32_t color_di
     const size_t rows = (size_t)p->n_gauss * p->n_cams;
     if (rows == 0) return MISPLAT_OK;
     // v_grec_is_zero: bit 0 = v_grec, bit 1 = v_abs have been cleared by the caller
-    if (!(v_grec_is_zero & 1) && hipMemsetAsync(v_grec, 0, rows * MISPLAT_REC * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
-    if (v_abs && !(v_grec_is_zero & 2) && hipMemsetAsync(v_abs, 0, rows * 2 * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (!(v_grec_is_zero & 1) && fill_bytes(v_grec, rows * MISPLAT_REC * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
+    if (v_abs && !(v_grec_is_zero & 2) && fill_bytes(v_abs, rows * 2 * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     const int ppl = pick_ppl(p->ppl_bwd, kDefaultPplBwd);
     FillList F = {};
     if (fills) {
@@ -1686,9 +1689,9 @@ extern "C" int misplat_blend_bwd_x_atomic(const misplat_params* p, int32_t n_cha
     hipStream_t s = (hipStream_t)stream;
     const size_t rows = (size_t)p->n_gauss * p->n_cams;
     if (rows == 0) return MISPLAT_OK;
-    if (hipMemsetAsync(v_grec, 0, rows * MISPLAT_REC * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
-    if (hipMemsetAsync(v_featx, 0, rows * 4 * nxq * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
-    if (v_abs && hipMemsetAsync(v_abs, 0, rows * 2 * sizeof(float), s) != hipSuccess) return MISPLAT_ELAUNCH;
+    if (misplat_internal::fill_bytes(v_grec, rows * MISPLAT_REC * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
+    if (misplat_internal::fill_bytes(v_featx, rows * 4 * nxq * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
+    if (v_abs && misplat_internal::fill_bytes(v_abs, rows * 2 * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     if (n_isects == 0) return MISPLAT_OK;
     const int total = p->tile_w * p->tile_h * p->n_cams * 2;
     const int grid = ((total + 7) / 8) * 8;

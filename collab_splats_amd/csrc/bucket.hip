@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "misplat.h"
+#include "internal.h"
 
 namespace {
 
@@ -507,8 +508,8 @@ extern "C" int misplat_bucket_count(const misplat_params* p, const float* means2
     hipStream_t s = (hipStream_t)stream;
     // cell counts and the two counters start from zero (already_zero: an earlier kernel of the stream cleared them)
     if (!already_zero) {
-        if (hipMemsetAsync(cell_count, 0, sizeof(uint32_t) * (size_t)g.n_cells, s) != hipSuccess) return MISPLAT_ELAUNCH;
-        if (hipMemsetAsync(counters, 0, 2 * sizeof(int64_t), s) != hipSuccess) return MISPLAT_ELAUNCH;
+        if (misplat_internal::fill_bytes(cell_count, sizeof(uint32_t) * (size_t)g.n_cells, 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
+        if (misplat_internal::fill_bytes(counters, 2 * sizeof(int64_t), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     }
     if (total > 0)
         hipLaunchKernelGGL(bucket_count_kernel, dim3(g.n_blocks), dim3(kCountThreads), 0, s, total, p->n_gauss, p->tile_w,

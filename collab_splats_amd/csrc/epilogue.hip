@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "misplat.h"
+#include "internal.h"
 
 namespace {
 
@@ -209,8 +210,9 @@ extern "C" int misplat_outputs_fwd(int64_t n_pix, int32_t color_dim, const float
     if (depth_im && color_dim < 4) return MISPLAT_EINVAL;
     if (n_pix == 0) return MISPLAT_OK;
     hipStream_t s = (hipStream_t)stream;
-    // seed the four maxima with -FLT_MAX on the device (a memset node: no pageable host buffer, no hidden sync)
-    if (hipMemsetD32Async((hipDeviceptr_t)maxes4, 0xff7fffff, 4, s) != hipSuccess) return MISPLAT_ELAUNCH;
+    // seed the four maxima with -FLT_MAX on the device (a fill KERNEL: no pageable host buffer, no hidden sync, and no
+    // memset node in a graph that captures this call)
+    if (misplat_internal::fill_bytes(maxes4, 4 * sizeof(float), 0xff7fffffu, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     const int max_grid = grid_for(n_pix, 256) < 512 ? grid_for(n_pix, 256) : 512;
     hipLaunchKernelGGL(outputs_max_kernel, dim3(max_grid), dim3(256), 0, s, n_pix, color_dim, render,
                        exp_depth, med_depth, exp_normal, maxes4);

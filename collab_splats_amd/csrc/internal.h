@@ -12,6 +12,12 @@ namespace misplat_internal {
 // machine away from it.
 int zero_fill(float* dst, int64_t n_floats, int max_blocks, hipStream_t s);
 
+// dst[0 .. bytes) = the byte pattern of `word` repeated (word-aligned fills: every 4 bytes hold `word`; a byte fill: pass
+// a word of four equal bytes), by a KERNEL.  The library enqueues no memset at all: a memset node inside a captured
+// hipGraph was observed not to be applied on replay (ROCm 7.2), and both the library's own graph
+// cache and a caller's whole-step capture (graphs.GraphedStep) may record any of these sequences.
+int fill_bytes(void* dst, size_t bytes, uint32_t word, hipStream_t s);
+
 // Tensors to clear "in the background" of a compute-bound kernel: the last (at_head: the first) `blocks` workgroups (64
 // threads each) of that kernel's grid write the zeros, the others do the kernel's own work.  n[k] floats at p[k]
 // (16-byte aligned).  blocks / at_head are chosen by the kernel's launcher.

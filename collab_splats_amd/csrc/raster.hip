@@ -350,6 +350,15 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
                                     b->v_opacities, (misplat_stream_t)s);
 }
 
+// What misplat_raster_bwd will do with these arguments (host only, nothing is enqueued): bit 0 -- the two-launch form
+// (zeros in the background of the compositing backward + one kernel for the flagged rows); bit 1 -- replayable as a
+// graph (memset-free, no measurement events).
+extern "C" int misplat_raster_bwd_plan(const misplat_params* p, const misplat_raster_bwd_args* b) {
+    if (!p || !b) return MISPLAT_EINVAL;
+    const bool memset_free = (b->zero_flags & 1) && (!b->v_abs || (b->zero_flags & 2));
+    return (background_fill_ok(p, b) ? 1 : 0) | ((memset_free && !b->ev_blend_begin && !b->ev_blend_end) ? 2 : 0);
+}
+
 extern "C" int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
                                   misplat_graph_cache* cache) {
     if (!p || !b) return MISPLAT_EINVAL;
@@ -361,26 +370,78 @@ extern "C" int misplat_raster_bwd(const misplat_params* p, const misplat_raster_
 }
 
 // float4 streaming copy: the measured HBM roof of the box the benchmark runs on (bench.py reports fractions of it
-// next to the 8 TB/s specification).
-__global__ __launch_bounds__(256) void stream_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n) {
-    // one 16-byte load + store per lane and iteration (four independent loads per lane measured 9 % SLOWER: 4.51 vs 4.97 TB/s)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+// next to the 8 TB/s specification and the 6.29 TB/s the hardware guide measured).  Variants (bench.py takes the best):
+//   0  one 16-byte load + store per lane and iteration, 2 048 workgroups, grid-stride
+//   1  the same with non-temporal loads and stores (no reuse: keep the lines out of the caches' way)
+//   2  four independent 16-byte loads per lane and iteration, then four non-temporal stores (more bytes in flight per CU)
+typedef float copy_v4 __attribute__((ext_vector_type(4)));       // (the non-temporal builtins take native vector types)
+template <int VARIANT>
+__global__ __launch_bounds__(256) void stream_copy_kernel(const copy_v4* __restrict__ src, copy_v4* __restrict__ dst, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (VARIANT == 0) {
+        for (; i < n; i += stride) dst[i] = src[i];
+    } else if (VARIANT == 1) {
+        for (; i < n; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    } else {
+        for (; i + 3 * stride < n; i += 4 * stride) {
+            const copy_v4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+            const copy_v4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+            __builtin_nontemporal_store(a, dst + i); __builtin_nontemporal_store(b, dst + i + stride);
+            __builtin_nontemporal_store(c, dst + i + 2 * stride); __builtin_nontemporal_store(d, dst + i + 3 * stride);
+        }
+        for (; i < n; i += stride) dst[i] = src[i];
+    }
 }
 
-extern "C" int misplat_stream_copy(const void* src, void* dst, int64_t n_float4, misplat_stream_t stream) {
-    if (n_float4 < 0 || (n_float4 > 0 && (!src || !dst))) return MISPLAT_EINVAL;
+extern "C" int misplat_stream_copy(const void* src, void* dst, int64_t n_float4, int32_t variant, misplat_stream_t stream) {
+    if (n_float4 < 0 || (n_float4 > 0 && (!src || !dst)) || variant < 0 || variant > 2) return MISPLAT_EINVAL;
     if (n_float4 == 0) return MISPLAT_OK;
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst,
-                       n_float4);
+    hipStream_t s = (hipStream_t)stream;
+    if (variant == 0)
+        hipLaunchKernelGGL(stream_copy_kernel<0>, dim3(256 * 8), dim3(256), 0, s, (const copy_v4*)src, (copy_v4*)dst, n_float4);
+    else if (variant == 1)
+        hipLaunchKernelGGL(stream_copy_kernel<1>, dim3(256 * 8), dim3(256), 0, s, (const copy_v4*)src, (copy_v4*)dst, n_float4);
+    else
+        hipLaunchKernelGGL(stream_copy_kernel<2>, dim3(256 * 8), dim3(256), 0, s, (const copy_v4*)src, (copy_v4*)dst, n_float4);
+    return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+}
+
+// Kernel-side fill (see internal.h: no memset node is ever enqueued by this library): bytes before the first 16-byte
+// boundary and behind the last one go one at a time, the body as 16-byte stores.
+__global__ __launch_bounds__(256) void fill_bytes_kernel(uint8_t* __restrict__ dst, size_t bytes, uint32_t word) {
+    const uintptr_t a = (uintptr_t)dst;
+    size_t head = (size_t)((16 - (a & 15)) & 15);
+    if (head > bytes) head = bytes;
+    const size_t n16 = (bytes - head) >> 4;
+    const size_t tail0 = head + (n16 << 4);
+    uint4* body = reinterpret_cast<uint4*>(dst + head);
+    // the pattern is anchored at dst: byte i holds byte (i & 3) of `word`, so the body's words are `word` rotated by head
+    const uint32_t sh = (uint32_t)(head & 3) * 8u;
+    const uint32_t w = sh ? ((word >> sh) | (word << (32u - sh))) : word;
+    const uint4 v = make_uint4(w, w, w, w);
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < n16; i += stride) body[i] = v;
+    if (blockIdx.x == 0) {
+        for (size_t i = threadIdx.x; i < head; i += blockDim.x) dst[i] = (uint8_t)(word >> (8u * (uint32_t)(i & 3)));
+        for (size_t i = tail0 + threadIdx.x; i < bytes; i += blockDim.x) dst[i] = (uint8_t)(word >> (8u * (uint32_t)(i & 3)));
+    }
+}
+
+int misplat_internal::fill_bytes(void* dst, size_t bytes, uint32_t word, hipStream_t s) {
+    if (!dst && bytes) return MISPLAT_EINVAL;
+    if (bytes == 0) return MISPLAT_OK;
+    size_t blocks = ((bytes >> 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fill_bytes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint8_t*)dst, bytes, word);
     return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
 }
 
 // Clears a device buffer on `stream` (the retry of phase B clears tile_count with it: the buffers of one forward are
 // slices of one allocation, so a framework-level in-place clear would invalidate tensors saved for the backward).
 extern "C" int misplat_zero_bytes(void* dst, size_t bytes, misplat_stream_t stream) {
-    if (!dst && bytes) return MISPLAT_EINVAL;
-    if (bytes == 0) return MISPLAT_OK;
-    return hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream) == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+    return misplat_internal::fill_bytes(dst, bytes, 0u, (hipStream_t)stream);
 }
 
 // Host-side wait for the intersection count of phase A: *slot was set to -1 by the caller before the launch and is

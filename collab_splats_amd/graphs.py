@@ -14,7 +14,9 @@ standard PyTorch recipe applies: run the step a few times, capture it once, repl
 
 ``fn`` follows the usual rules of CUDA-graph capture in PyTorch: static input tensors updated in place, and nothing with
 autograd history stashed across calls (return / keep detached tensors: an autograd graph kept alive from the previous
-iteration makes PyTorch run its AccumulateGrad nodes on the wrong stream and the capture fails).
+iteration makes PyTorch run its AccumulateGrad nodes on the wrong stream and the capture crashes the process).  What
+``fn`` RETURNS is checked: a result that carries autograd history raises ``MisplatError`` during the warm-up, before any
+capture has begun.
 
 The reference's trainer (nerfstudio) runs eagerly; this is an extension on the caller's side of the boundary, not part
 of the drop-in surface.  Densification changes tensor shapes: re-create the GraphedStep after a refinement step.
@@ -28,6 +30,25 @@ import torch
 from . import ops
 
 
+def _tensors_with_history(obj, path="result", seen=None):
+    """Paths of the tensors inside ``obj`` (lists / tuples / dicts / objects with __dict__ are walked) that carry autograd
+    history."""
+    seen = set() if seen is None else seen
+    if id(obj) in seen:
+        return []
+    seen.add(id(obj))
+    if isinstance(obj, torch.Tensor):
+        return [path] if obj.grad_fn is not None else []
+    out = []
+    if isinstance(obj, dict):
+        for k, v in obj.items():
+            out += _tensors_with_history(v, f"{path}[{k!r}]", seen)
+    elif isinstance(obj, (list, tuple)):
+        for i, v in enumerate(obj):
+            out += _tensors_with_history(v, f"{path}[{i}]", seen)
+    return out
+
+
 class GraphedStep:
     def __init__(self, fn: Callable[[], object], capacity: int, warmup: int = 3, device: Optional[torch.device] = None):
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
@@ -39,7 +60,18 @@ class GraphedStep:
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side), ops.static_capacity(self.capacity):
             for _ in range(max(warmup, 1)):                   # allocator warm-up, launch-order feedback, lazy initialisation
-                fn()
+                res = fn()
+                bad = _tensors_with_history(res)
+                del res
+                if bad:
+                    # An autograd graph kept alive across calls makes PyTorch run its AccumulateGrad nodes on the stream of
+                    # the PREVIOUS call: inside a capture that is a cross-stream dependency and the process dies in
+                    # capture_end (observed: SIGSEGV).  Refuse before any capture has begun.
+                    torch.cuda.current_stream(self.device).wait_stream(side)
+                    raise ops._lib.MisplatError(
+                        "GraphedStep: fn() returned tensor(s) with autograd history (" + ", ".join(bad[:4])
+                        + ("..." if len(bad) > 4 else "") + "): return detached tensors (t.detach()) or nothing -- "
+                        "a graph of the previous iteration that is still alive cannot be captured")
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         ops.check_static_capacity(self.device)                # too small already: fail before capturing

@@ -8,6 +8,7 @@ rade_features_model.py:430-434).
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
 from typing import Dict, Optional, Tuple
@@ -38,7 +39,19 @@ def set_deterministic(flag: bool) -> None:
 # sweeps, repeated benchmark steps; harmless otherwise: a stale order is just another arbitrary order).
 UNIT_ORDER = os.environ.get("MISPLAT_UNIT_ORDER", "1") == "1"
 UNIT_ORDER_FWD = os.environ.get("MISPLAT_UNIT_ORDER_FWD", "1") == "1"
+# keyed by (device, STREAM, shape): the buffer is written by misplat_unit_order on the stream of the call that produced it,
+# so only a later call on the same stream is ordered behind that write (a forward on another stream -- an evaluation
+# render, a second thread -- starts from the default order instead of reading a half-written permutation)
 _LAST_ORDER: Dict[tuple, Tensor] = {}
+
+# Which variants of the path the calls of this process took (tests and bench.py read it; never reset by the library):
+#   forward / forward_lazy_colour / forward_merged_phases / forward_prev_order / capacity_redo
+#   backward_one_call / backward_background_fill / backward_staged / backward_sink
+PATH_STATS: "collections.Counter" = collections.Counter()
+
+
+def _stream_id() -> int:
+    return int(stream_ptr().value or 0)
 
 
 def _eff_ppl(v: int) -> int:
@@ -55,7 +68,7 @@ class _UnitSchedule:
             return
         self.ppl_f, self.ppl_b = _eff_ppl(P.ppl_fwd), _eff_ppl(P.ppl_bwd)
         self.units = P.tile_w * P.tile_h * P.n_cams * (4 // self.ppl_f)
-        self.key = (dev.index, P.n_cams, P.tile_w, P.tile_h, self.ppl_f)
+        self.key = (dev.index, _stream_id(), P.n_cams, P.tile_w, P.tile_h, self.ppl_f)
         self.work, self.perm = _carve(dev, (self.units, 8 * ((self.units + 7) // 8)))
 
     def before_forward(self, P: Params) -> None:
@@ -560,7 +573,7 @@ CAP_MARGIN = float(os.environ.get("MISPLAT_CAP_MARGIN", "1.25"))
 COLOUR_BRANCH = os.environ.get("MISPLAT_COLOUR_BRANCH", "0") == "1"
 COLOUR_BRANCH_MIN_ROWS = 500_000
 _CAP_HINT: Dict[tuple, int] = {}
-_READBACK: Dict[int, tuple] = {}
+_READBACK: Dict[tuple, Tensor] = {}
 
 
 def _carve_f(dev: torch.device, sizes) -> list:
@@ -572,18 +585,24 @@ def _carve_f(dev: torch.device, sizes) -> list:
     return [buf[o:o + int(n)] for o, n in zip(offs, sizes)]
 
 
-# hipGraph replay of the launch sequences (csrc/raster.hip): one graph per distinct argument block, LRU of 16 per device.
+# hipGraph replay of the launch sequences (csrc/raster.hip): one graph per distinct argument block, LRU per device.
 GRAPHS = os.environ.get("MISPLAT_GRAPH", "1") == "1"
+# one graph per distinct argument block: a trainer that cycles through a few resident camera tensors needs forward +
+# backward graphs for each of them (8 views -> 16 graphs and the first-call variants)
+GRAPH_CACHE_ENTRIES = int(os.environ.get("MISPLAT_GRAPH_ENTRIES", "64"))
 _GRAPH_CACHE: Dict[int, int] = {}
 
 
-def _readback_slot(dev: torch.device) -> Tensor:
-    """Pinned int64[1] of this device that receives the intersection count: every forward waits for its own count
-    before it returns, so one slot per device is enough."""
+def _readback_slot(dev: torch.device, static: bool = False) -> Tensor:
+    """Pinned int64[1] of this device that receives the intersection count.  An eager forward waits for its own count
+    before it returns, so one slot per device serves all of them; fixed-capacity calls (``static_capacity``: nobody
+    waits, a captured graph replays the copy) have a slot of their own, so that a replay queued in front of an eager
+    forward can never be mistaken for that forward's count."""
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if idx not in _READBACK:
-        _READBACK[idx] = torch.zeros(1, dtype=torch.int64, pin_memory=True)
-    return _READBACK[idx]
+    key = (idx, bool(static))
+    if key not in _READBACK:
+        _READBACK[key] = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+    return _READBACK[key]
 
 
 def _graph_cache(dev: torch.device):
@@ -591,7 +610,7 @@ def _graph_cache(dev: torch.device):
         return None                                     # (the caller is capturing the whole step: plain launches)
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     if idx not in _GRAPH_CACHE:
-        h = _lib.load().misplat_graph_cache_create(C.c_int32(16))
+        h = _lib.load().misplat_graph_cache_create(C.c_int32(GRAPH_CACHE_ENTRIES))
         if not h:
             raise _lib.MisplatError("misplat_graph_cache_create failed")
         _GRAPH_CACHE[idx] = h
@@ -675,9 +694,9 @@ def check_static_capacity(dev: Optional[torch.device] = None) -> int:
     """After a synchronisation: the intersection count of the last fixed-capacity forward on this device; raises if it
     did not fit (its images are then incomplete)."""
     idx = torch.cuda.current_device() if dev is None or dev.index is None else dev.index
-    if idx not in _READBACK or idx not in _STATIC_SEEN:
+    if (idx, True) not in _READBACK or idx not in _STATIC_SEEN:
         return 0
-    n = int(_READBACK[idx][0])
+    n = int(_READBACK[(idx, True)][0])
     if n > _STATIC_SEEN[idx]:
         raise _lib.MisplatError(f"{n} tile intersections exceed the fixed capacity {_STATIC_SEEN[idx]}: rerun with a larger one")
     return n
@@ -728,7 +747,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     # gradient rows (the single autograd node): with the two-node form a loss on the projection's own outputs reaches the
     # projection backward without ever passing the compositing kernels.
     P.touched = touched.data_ptr() if (want_grad and flags) else None
-    host = _readback_slot(dev)
+    host = _readback_slot(dev, static=_STATIC_CAP is not None and defer)
     host[0] = -1                                                      # overwritten by the asynchronous copy of phase A
     a = RasterArgs()
     a.means, a.quats, a.scales, a.opacities = _dp(means), _dp(quats), _dp(scales), _dp(opacities)
@@ -795,6 +814,8 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         last = _LAST_ORDER.get(sched.key) if UNIT_ORDER_FWD else None
         if last is not None and _CAPTURE_KEEP is not None:
             _CAPTURE_KEEP.append(last)                                # a captured graph keeps reading this buffer
+        if last is not None:
+            PATH_STATS["forward_prev_order"] += 1
         a.unit_perm_in, a.unit_work, a.unit_perm_out = _dp(last), _dp(sched.work), _dp(sched.perm)
     else:
         a.unit_perm_in, a.unit_work, a.unit_perm_out = None, None, None
@@ -818,6 +839,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         if n_known <= cap:
             break
         cap = n_known                                                 # the guess was too small: exact size, once more
+        PATH_STATS["capacity_redo"] += 1
         a.colour_pending = 0                                          # (the colours were written by the first attempt)
         tc = state["keep"][6]                                         # tile_count: phase B expects it cleared
         check(lib.misplat_zero_bytes(ptr(tc), C.c_size_t(4 * tc.numel()), stream_ptr()), "misplat_zero_bytes")
@@ -825,7 +847,9 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
             raise _lib.MisplatError(f"{cap} tile intersections exceed int32 indexing")
         payload, flatten_ids, scratch = isect_buffers(cap)
     if not static:
-        _CAP_HINT[key] = n_known
+        # a slowly decaying maximum: consecutive training views differ in their counts by tens of percent, and a guess that
+        # falls short costs a second phase B, while a generous one costs nothing but address space (288 GB of HBM)
+        _CAP_HINT[key] = max(n_known, int(0.97 * _CAP_HINT.get(key, 0)))
     if sched.on:
         _LAST_ORDER[sched.key] = sched.perm
         if sched.ppl_b == sched.ppl_f:
@@ -872,6 +896,9 @@ class _RasterFused(torch.autograd.Function):
         lazy = _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd)
         want_aux = SH_AUX and deg >= 0 and want_grad and not lazy
         defer = _STATIC_CAP is not None or (MERGE_PHASES and SPECULATE and _cap_key(P, means.device) in _CAP_HINT)
+        PATH_STATS["forward"] += 1
+        PATH_STATS["forward_lazy_colour"] += int(lazy)
+        PATH_STATS["forward_merged_phases"] += int(bool(defer))
         radii, means2d, depths, comps, grec, sh_aux, state = _raster_phase_a(
             P, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam, depth_channel,
             want_aux, want_grad, defer=defer, lazy=lazy, flags=True, absgrad=bool(absgrad))
@@ -920,7 +947,10 @@ class _RasterFused(torch.autograd.Function):
         v_means, v_quats = _grad_out(means), _grad_out(quats)
         v_scales, v_opac = _grad_out(scales), _grad_out(opacities)
         perm = ctx.sched.perm_bwd if ctx.sched is not None else None
-        simple = GRAD_SINK is None and v_means2d_in is None
+        # (a data-parallel gradient sink only changes where the six outputs are written: the slices of its flat buffer are
+        # plain pointers like any other, so the one-call backward -- graph replay, both per-Gaussian stages in one launch,
+        # zeros written in the background of the compositing backward -- serves it too)
+        simple = v_means2d_in is None
         if simple:
             b = RasterBwdArgs()
             b.Ks, b.grec, b.flatten_ids, b.offsets = _dp(Ks), _dp(grec), _dp(bins["flatten_ids"]), _dp(bins["isect_offsets"])
@@ -941,9 +971,14 @@ class _RasterFused(torch.autograd.Function):
                 KERNEL_EVENTS.setdefault("blend_bwd", []).append(ev)
             with _timed("raster_bwd"):
                 check(lib.misplat_raster_bwd(C.byref(P), C.byref(b), stream_ptr(), _graph_cache(dev)), "misplat_raster_bwd")
+            PATH_STATS["backward_one_call"] += 1
+            PATH_STATS["backward_background_fill"] += int(lib.misplat_raster_bwd_plan(C.byref(P), C.byref(b)) & 1)
+            if GRAD_SINK is not None:
+                PATH_STATS["backward_sink"] += 1
+                GRAD_SINK.rasterizer_done()
         else:
-            # data-parallel gradient sink (the colour bucket's all-reduce starts between the kernels) or a gradient that
-            # reached means2d from another consumer: stage by stage
+            # a gradient that reached means2d from another consumer: stage by stage
+            PATH_STATS["backward_staged"] += 1
             _with_perm = C.c_void_p(perm.data_ptr()) if perm is not None else None
             P.unit_perm = _with_perm
             check(lib.misplat_blend_bwd_atomic(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),

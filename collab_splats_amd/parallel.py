@@ -42,20 +42,31 @@ def shard_views(n_views: int, rank: int, world: int) -> List[int]:
 
 class GradientBuckets:
     """The six parameter gradients of the shared Gaussians in ONE preallocated flat fp32 buffer (59 floats = 236 B per
-    Gaussian at SH degree 3), reduced over the ranks as TWO buckets:
+    Gaussian at SH degree 3), reduced over the ranks with RCCL.
 
-      colour bucket    features_dc / features_rest (or ``sh``): 192 of the 236 B.  The SH backward kernel writes it
-                       STRAIGHT into the buffer (``ops.GRAD_SINK``), and its ``all_reduce(async_op=True)`` is launched as
-                       soon as that kernel has been enqueued -- it travels over xGMI while the projection backward and
-                       the activation backward still run;
-      geometry bucket  means, quats, scales, opacities: launched from ``allreduce()`` after ``backward()``.  means / quats
-                       come out of the projection backward in place; gradients that autograd produced elsewhere (the
-                       log-scale / logit activations of the caller) are copied in (16 B per Gaussian).
+    The slices of the buffer ARE the gradient tensors: ``ops.GRAD_SINK`` hands them to the rasterizer's backward as its
+    output pointers, so the ONE-CALL backward (``misplat_raster_bwd``: graph replay, both per-Gaussian stages in one
+    launch, the zeros written in the background of the compositing backward) writes all 236 B/Gaussian in place -- the
+    data-parallel backward is the same backward as on one GPU.  Two collectives follow it, one per bucket:
 
-    After ``allreduce()`` every ``p.grad`` IS its slice of the buffer: no flatten / unflatten copies (1.18 GB each way
-    at 5 M Gaussians in the first version).  One large collective per bucket suits the point-to-point xGMI links (7 x
-    ~153 GB/s per GPU): RCCL's direct reduce-scatter + all-gather moves 2 x 7/8 of the bucket per rank over 7 links in
-    parallel.  ``NCCL_DEBUG=INFO`` (stderr) shows the algorithm / protocol RCCL picked."""
+      * the colour bucket (features_dc / features_rest or ``sh``: 192 of the 236 B) is complete the moment that call has
+        been enqueued -- nothing but the rasterizer ever writes a colour gradient -- and its
+        ``all_reduce(async_op=True)`` starts right there (``rasterizer_done``), while autograd finishes the step;
+      * the geometry bucket (means, quats, scales, opacities) goes from ``allreduce()`` after ``backward()``: gradients
+        that autograd adds elsewhere (the caller's own ``exp`` / ``sigmoid``, a scale regulariser) are then included --
+        accumulated in place where the slice already is ``p.grad``, copied in (16 B/Gaussian) where it is not.
+
+    One large collective per bucket suits the point-to-point xGMI links (7 x ~153 GB/s per GPU): RCCL's direct
+    reduce-scatter + all-gather moves 2 x 7/8 of the bucket per rank over 7 links in parallel.  ``NCCL_DEBUG=INFO``
+    (stderr) shows the algorithm / protocol RCCL picked.
+
+    A slice is handed out ONCE per parameter and ``attach()``: a second rasterization node on the same parameters in one
+    ``backward()`` (several views per step) gets an ordinary fresh tensor, which autograd then adds into the slice; with
+    more than one view per backward nothing may be reduced before ``allreduce()`` -- say so with
+    ``attach(views_per_backward=k)`` (a second node after an early launch raises instead of corrupting the sum)."""
+
+    ALIGN = 4                                           # floats: every slice starts on a 16-byte boundary (the backward's
+                                                        # background fill stores 16 bytes at a time)
 
     def __init__(self, params: Sequence[torch.Tensor], geometry: Sequence[int] | None = None,
                  colour: Sequence[int] | None = None):
@@ -66,45 +77,71 @@ class GradientBuckets:
             geometry = [i for i in range(len(self.params)) if i not in colour]
         self.colour, self.geometry = list(colour), list(geometry)
         order = self.colour + self.geometry
-        total = sum(self.params[i].numel() for i in order)
+
+        def padded(n):
+            return (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+
+        total = sum(padded(self.params[i].numel()) for i in order)
         dev = self.params[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.views: List[torch.Tensor] = [None] * len(self.params)
         o = 0
-        for i in order:
+        self.n_colour = 0
+        for k, i in enumerate(order):
             n = self.params[i].numel()
             self.views[i] = self.flat[o:o + n].view_as(self.params[i])
-            o += n
-        self.n_colour = sum(self.params[i].numel() for i in self.colour)
-        self._colour_work = None
-        self._colour_launched = False
+            o += padded(n)
+            if k + 1 == len(self.colour):
+                self.n_colour = o                        # the colour bucket is the prefix flat[:n_colour]
+        self.views_per_backward = 1
+        self._work: list = []                            # collectives in flight: (work, host copy or None, slice)
+        self._reduced = 0                                # floats of the buffer (a prefix) whose collective has been launched
         self._by_ptr = {}
+        self._handed: set = set()
+        self._nodes_done = 0
 
     # -- the step
-    def attach(self) -> None:
+    def attach(self, views_per_backward: int = 1) -> None:
         """Call before ``backward()``: gradients start from None and the backward kernels are pointed at the buffer."""
         from . import ops
         for p in self.params:
             p.grad = None
         self._by_ptr = {p.data_ptr(): i for i, p in enumerate(self.params)}
-        self._colour_work, self._colour_launched = None, False
+        self._work, self._reduced, self._nodes_done = [], 0, 0
+        self._handed = set()
+        self.views_per_backward = max(1, int(views_per_backward))
         ops.GRAD_SINK = self
 
     def sink(self, inp: torch.Tensor):
-        """Output buffer for the gradient of ``inp`` if it is one of the parameters themselves (else None).  A FRESH
-        view object every time: autograd adopts an incoming gradient without a copy only if nobody else holds it."""
+        """Output buffer for the gradient of ``inp`` if it is one of the parameters themselves and its slice has not been
+        handed out since ``attach()`` (else None: the caller allocates, autograd accumulates).  A FRESH view object
+        every time: autograd adopts an incoming gradient without a copy only if nobody else holds it."""
         i = self._by_ptr.get(inp.data_ptr())
         if i is None or self.views[i].shape != inp.shape:
             return None
+        if i in self._handed:
+            if self._reduced:
+                from ._lib import MisplatError
+                raise MisplatError("GradientBuckets: a second rasterization node reached the parameters after their all-reduce "
+                                   "had been launched; call attach(views_per_backward=k) for k views per backward()")
+            return None
+        self._handed.add(i)
         return self.views[i].view(inp.shape)
 
-    def colour_ready(self) -> None:
-        """Called by the backward right after the colour kernel has been enqueued."""
-        if self._colour_launched or not self.colour:
+    def rasterizer_done(self) -> None:
+        """Called by the rasterizer's backward right after its one C call has been enqueued: everything it wrote into the
+        buffer is final unless another view follows in the same backward."""
+        self._nodes_done += 1
+        if self.views_per_backward != 1 or self._reduced or _world() <= 1:
             return
-        self._colour_launched = True
-        if all(self._by_ptr.get(self.params[i].data_ptr()) == i for i in self.colour) and _world() > 1:
-            self._colour_work = self._launch(self.flat[:self.n_colour])
+        if self.colour and all(i in self._handed for i in self.colour):
+            self._launch(self.n_colour)
+
+    def colour_ready(self) -> None:
+        """Two-node / stage-by-stage form: called right after the colour backward kernel has been enqueued."""
+        if self.views_per_backward == 1 and not self._reduced and self.colour and _world() > 1 \
+                and all(i in self._handed for i in self.colour):
+            self._launch(self.n_colour)
 
     def allreduce(self, average: bool = False):
         """After ``backward()``: reduce what is still pending, make every ``p.grad`` its slice of the buffer.  Returns a
@@ -115,38 +152,41 @@ class GradientBuckets:
         if self.flat.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        pending_colour = self._colour_work is None
+        n_prefix = self._reduced
         for i, p in enumerate(self.params):
-            if pending_colour or i in self.geometry:
-                g = p.grad
-                if g is None:
-                    self.views[i].zero_()
-                elif g.data_ptr() != self.views[i].data_ptr():
-                    self.views[i].copy_(g)               # produced by autograd outside the rasterizer (activations)
-        works = []
-        if _world() > 1:
-            if pending_colour:
-                works.append(self._launch(self.flat))      # nothing was overlapped: one collective for everything
-            else:
-                works.append(self._launch(self.flat[self.n_colour:]))
-                works.append(self._colour_work)
-        for w in works:
+            start = self.views[i].storage_offset()
+            if start < n_prefix:
+                continue                                 # already travelling (written in place by the kernels)
+            g = p.grad
+            if g is None:
+                self.views[i].zero_()
+            elif g.data_ptr() != self.views[i].data_ptr():
+                self.views[i].copy_(g)                   # produced by autograd outside the rasterizer (activations)
+        if _world() > 1 and self._reduced < self.flat.numel():
+            self._launch(self.flat.numel())
+        for w in self._work:
             self._finish(w)
+        self._work = []
         if average and _world() > 1:
             self.flat /= _world()
         for i, p in enumerate(self.params):
             p.grad = self.views[i].view(p.shape)
-        self._colour_work = None
         if ev is not None:
             ev[1].record()
         return ev
 
     # -- collectives
-    def _launch(self, t: torch.Tensor):
+    def _launch(self, upto: int) -> None:
+        """all_reduce of flat[self._reduced : upto], asynchronously."""
+        t = self.flat[self._reduced:upto]
+        self._reduced = upto
+        if t.numel() == 0:
+            return
         if dist.get_backend() == "gloo" and t.is_cuda:       # CPU rehearsal of the multi-rank path on a GPU box
             host = t.cpu()
-            return (dist.all_reduce(host, op=dist.ReduceOp.SUM, async_op=True), host, t)
-        return (dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), None, t)
+            self._work.append((dist.all_reduce(host, op=dist.ReduceOp.SUM, async_op=True), host, t))
+        else:
+            self._work.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), None, t))
 
     @staticmethod
     def _finish(w) -> None:
@@ -158,41 +198,6 @@ class GradientBuckets:
 
 def _world() -> int:
     return dist.get_world_size() if dist.is_initialized() else 1
-
-
-def flatten_grads(params: Sequence[torch.Tensor]) -> torch.Tensor:
-    """One contiguous fp32 bucket (kept for callers that hold ordinary ``.grad`` tensors; GradientBuckets avoids the copies)."""
-    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-
-
-def unflatten_into_grads(flat: torch.Tensor, params: Sequence[torch.Tensor]) -> None:
-    o = 0
-    for p in params:
-        n = p.numel()
-        p.grad = flat[o:o + n].view_as(p).clone() if p.grad is None else p.grad.copy_(flat[o:o + n].view_as(p))
-        o += n
-
-
-def _reduce_device(t: torch.Tensor) -> torch.Tensor:
-    """gloo (CPU rehearsal of the multi-rank path) cannot reduce device tensors: stage through host."""
-    if dist.get_backend() == "gloo" and t.is_cuda:
-        return t.cpu()
-    return t
-
-
-def allreduce_gradients(params: Sequence[torch.Tensor], average: bool = False) -> torch.Tensor:
-    """Sum (or mean) the gradients of the shared Gaussians over all ranks, in place (simple form: flatten, one
-    all-reduce, copy back; the training path uses GradientBuckets)."""
-    flat = flatten_grads(params)
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        buf = _reduce_device(flat)
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        if buf is not flat:
-            flat.copy_(buf)
-        if average:
-            flat /= dist.get_world_size()
-    unflatten_into_grads(flat, params)
-    return flat
 
 
 def max_over_ranks(value: float, device: torch.device) -> float:

@@ -377,12 +377,17 @@ class RadegsModel(nn.Module):
         accumulation = background.new_zeros(*rgb.shape[:2], 1)
         return {"rgb": rgb, "depth": depth, "accumulation": accumulation, "background": background}
 
+    def set_crop(self, crop_box) -> None:
+        """Splatfacto's ``set_crop``: the box (anything with ``within(points[N,3]) -> bool[N(,1)]``, nerfstudio's
+        ``OrientedBox``) that ``get_outputs`` applies in evaluation (rade_gs_model.py:96-105), or None."""
+        self.crop_box = crop_box
+
     @torch.no_grad()
     def get_outputs_for_camera(self, camera, obb_box=None) -> Dict[str, Union[Tensor, List, None]]:
-        """Splatfacto's no-grad entry used by the meshing loop (mesh.py:1581-1584).  ``obb_box`` cropping is a
-        nerfstudio feature on the other side of the boundary: only ``None`` is accepted."""
-        if obb_box is not None:
-            raise NotImplementedError("obb_box cropping is outside the rasterizer path (SURVEY.md section 8)")
+        """Splatfacto's no-grad entry used by the meshing loop, which passes ``obb_box=crop_box`` (mesh.py:1581-1584):
+        the box becomes the model's crop box (``set_crop``) and ``get_outputs`` renders the Gaussians inside it -- in
+        evaluation mode, as the reference's cropping is (rade_gs_model.py:96-119)."""
+        self.set_crop(obb_box)
         return self.get_outputs(camera.to(self.device) if hasattr(camera, "to") else camera)
 
     @torch.no_grad()

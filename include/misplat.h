@@ -510,6 +510,9 @@ typedef struct misplat_raster_bwd_args {
 } misplat_raster_bwd_args;
 int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
                        misplat_graph_cache* cache /* or NULL */);
+/* Host-only query: what misplat_raster_bwd does with these arguments.  Bit 0: the two-launch form (zeros written in the
+ * background of the compositing backward, one kernel for the flagged rows); bit 1: replayable as a graph.  < 0: error. */
+int misplat_raster_bwd_plan(const misplat_params* p, const misplat_raster_bwd_args* b);
 /* Host-side wait for phase A's count: the caller stores -1 in *n_isects_host before the call; returns the count as
  * soon as the device-to-host copy has landed, or -1 after timeout_us. */
 int64_t misplat_wait_count(const volatile int64_t* n_isects_host, int64_t timeout_us);
@@ -532,8 +535,9 @@ int misplat_adam_step(int32_t n_tensors, float* const* params, const float* cons
                       misplat_stream_t stream);
 
 /* Measurement helper: dst[i] = src[i] over n_float4 16-byte elements (a plain streaming copy; bench.py times it to
- * report the HBM roof of the box it runs on). */
-int misplat_stream_copy(const void* src, void* dst, int64_t n_float4, misplat_stream_t stream);
+ * report the HBM roof of the box it runs on).  variant: 0 plain, 1 non-temporal loads / stores, 2 four loads in flight
+ * per lane + non-temporal stores. */
+int misplat_stream_copy(const void* src, void* dst, int64_t n_float4, int32_t variant, misplat_stream_t stream);
 
 /* Library identification ("misplat <version> gfx950"). */
 const char* misplat_version(void);

@@ -43,8 +43,12 @@ class FlipProof:
     Built from the C restatement's per-pixel margin map (oracle/craster.c::cr_blend_margin: the smallest rounding
     error of the sigma evaluation, in units of the size of its terms, that could move alpha across alpha_min, T'
     across t_stop or T across median_t for any Gaussian the pixel traverses).
-    A pixel may only miss the tolerance if its margin is below MARGIN_TOL; a per-Gaussian gradient row may only
-    miss it if the Gaussian's screen-space box (mean2d +- radii) contains such a pixel."""
+    A pixel may only miss the tolerance if its margin is below MARGIN_TOL.  A per-Gaussian gradient row may only miss
+    it if the Gaussian's screen-space box (mean2d +- radii) contains a pixel that ACTUALLY DIFFERS between the two
+    implementations -- an image value out of tolerance, or unequal ``last_ids`` / ``median_ids`` -- and that pixel has
+    itself been proven to sit on a threshold (``check_pixels`` records every differing pixel it has accepted; call it
+    for the five images and the two index maps BEFORE the gradient tensors).  A box that merely covers some
+    low-margin pixel where nothing flipped explains nothing and fails."""
 
     def __init__(self, margin, means2d=None, radii=None, margin_tol=MARGIN_TOL):
         self.margin = np.asarray(margin, dtype=np.float64)
@@ -52,28 +56,59 @@ class FlipProof:
         self.margin_tol = margin_tol
         self.means2d = None if means2d is None else np.asarray(means2d, dtype=np.float64)
         self.radii = None if radii is None else np.asarray(radii, dtype=np.int64)
-        # summed-area table of the low-margin pixels: box queries in O(1)
-        self.sat = np.zeros((self.low.shape[0] + 1, self.low.shape[1] + 1), dtype=np.int64)
-        self.sat[1:, 1:] = self.low.astype(np.int64).cumsum(0).cumsum(1)
+        self.flipped = np.zeros_like(self.low)           # pixels that differ AND were proven to sit on a threshold
+        self.pixel_checks = 0
+        self.rows_checked = 0                            # out-of-tolerance gradient rows seen / explained by a flip
+        self.rows_loose_only = 0                         # ... that only the old rule (any low-margin pixel) would pass
+
+    @staticmethod
+    def _sat(mask):
+        sat = np.zeros((mask.shape[0] + 1, mask.shape[1] + 1), dtype=np.int64)
+        sat[1:, 1:] = mask.astype(np.int64).cumsum(0).cumsum(1)
+        return sat
 
     def check_pixels(self, bad_mask, name):
-        """bad_mask [H, W] bool: every bad pixel must sit on a threshold."""
+        """bad_mask [H, W] bool (pixels that differ): every one must sit on a threshold; they are remembered as the
+        flips that may explain gradient rows."""
+        self.pixel_checks += 1
         unexplained = bad_mask & ~self.low
         assert not unexplained.any(), (
             f"{name}: {int(unexplained.sum())} pixel(s) miss the tolerance with threshold margin >= {self.margin_tol} "
             f"(first at {tuple(np.argwhere(unexplained)[0])}, margin {self.margin[unexplained].min():.3e}): not a flip")
+        self.flipped |= bad_mask
+
+    def check_ids(self, got_last, ref_last, got_med, ref_med, max_frac=1e-4):
+        """The contributor index maps agree except at proven flips (and those pixels count as differing)."""
+        for key, got, ref in (("last_ids", got_last, ref_last), ("median_ids", got_med, ref_med)):
+            diff = np.asarray(got) != np.asarray(ref)
+            assert diff.sum() <= max(2, max_frac * diff.size), (key, int(diff.sum()))
+            self.check_pixels(diff, key)
+
+    def _box_counts(self, sat, rows):
+        H, W = self.low.shape
+        mx, my = self.means2d[rows, 0], self.means2d[rows, 1]
+        rx, ry = self.radii[rows, 0], self.radii[rows, 1]
+        x0 = np.clip(np.floor(mx - rx - 1), 0, W).astype(np.int64); x1 = np.clip(np.ceil(mx + rx + 1), 0, W).astype(np.int64)
+        y0 = np.clip(np.floor(my - ry - 1), 0, H).astype(np.int64); y1 = np.clip(np.ceil(my + ry + 1), 0, H).astype(np.int64)
+        return sat[y1, x1] - sat[y0, x1] - sat[y1, x0] + sat[y0, x0]
 
     def check_rows(self, bad_rows, name):
         """bad_rows: indices of Gaussians whose gradient misses the tolerance."""
         assert self.means2d is not None, "FlipProof needs means2d/radii for gradient tensors"
-        H, W = self.low.shape
-        for g in np.asarray(bad_rows).reshape(-1):
-            mx, my = self.means2d[g]
-            rx, ry = self.radii[g]
-            x0, x1 = int(np.clip(np.floor(mx - rx - 1), 0, W)), int(np.clip(np.ceil(mx + rx + 1), 0, W))
-            y0, y1 = int(np.clip(np.floor(my - ry - 1), 0, H)), int(np.clip(np.ceil(my + ry + 1), 0, H))
-            n = self.sat[y1, x1] - self.sat[y0, x1] - self.sat[y1, x0] + self.sat[y0, x0]
-            assert n > 0, f"{name}: Gaussian {int(g)} misses the tolerance but covers no threshold pixel: not a flip"
+        assert self.pixel_checks > 0, "FlipProof: check the images / index maps before the gradient rows"
+        rows = np.asarray(bad_rows, dtype=np.int64).reshape(-1)
+        if rows.size == 0:
+            return
+        strict = self._box_counts(self._sat(self.flipped), rows) > 0
+        loose = self._box_counts(self._sat(self.low), rows) > 0
+        self.rows_checked += int(rows.size)
+        self.rows_loose_only += int((loose & ~strict).sum())
+        print(f"[FlipProof] {name}: {rows.size} out-of-tolerance row(s), {int(strict.sum())} cover a pixel that differs, "
+              f"{int((loose & ~strict).sum())} cover only a low-margin pixel where nothing flipped (rejected), "
+              f"{int((~loose).sum())} cover no threshold pixel at all; {int(self.flipped.sum())} differing pixel(s) on record")
+        assert strict.all(), (
+            f"{name}: Gaussian {int(rows[~strict][0])} (+{int((~strict).sum()) - 1} more) misses the tolerance but its screen box "
+            f"covers no pixel that differs between the two implementations: not a flip")
 
 
 def assert_close_flips(got, ref, name="", tol=1e-4, outlier_frac=2e-5, outlier_tol=None, min_outliers=2, proof=None):

@@ -31,18 +31,38 @@ def _view_grad(view, shape):
 
 
 def _worker(rank, world, port, n, n_views, q):
+    """Views sharded over the ranks; every rank plays the rasterizer's backward against a GradientBuckets sink: the colour
+    gradients are written IN PLACE through ``sink()`` and their bucket is launched from ``rasterizer_done()``, the geometry
+    gradients arrive through autograd (fresh tensors) and travel from ``allreduce()``."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     r, w, _ = parallel.init_distributed(backend="gloo")
     assert (r, w) == (rank, world)
     params = [torch.zeros(s, requires_grad=True) for s in _shapes(n).values()]
     mine = parallel.shard_views(n_views, rank, world)
-    for p in params:
-        p.grad = sum((_view_grad(v, p.shape) for v in mine), torch.zeros(p.shape))
-    flat = parallel.allreduce_gradients(params)
-    assert flat.numel() == 59 * n                                      # 236 B per Gaussian
+    bk = parallel.GradientBuckets(params)
+    assert bk.colour == [4, 5] and bk.geometry == [0, 1, 2, 3]
+    assert bk.flat.numel() >= 59 * n and all(v.data_ptr() % 16 == 0 for v in bk.views)     # 236 B per Gaussian, aligned slices
+    bk.attach()
+    local = [sum((_view_grad(v, p.shape) for v in mine), torch.zeros(p.shape)) for p in params]
+    for i in bk.colour:                                                # "the kernels" write the colour bucket in place
+        out = bk.sink(params[i])
+        assert out is not None and out.data_ptr() == bk.views[i].data_ptr()
+        out.copy_(local[i])
+        params[i].grad = out
+    bk.rasterizer_done()
+    early = len(bk._work)                                              # the colour bucket is already travelling
+    try:                                                               # ... so a second node on the same parameters must fail loudly
+        bk.sink(params[4])
+        early = -1
+    except Exception as e:
+        assert "views_per_backward" in str(e)
+    for i in bk.geometry:                                              # autograd's own tensors: copied in by allreduce()
+        params[i].grad = local[i].clone()
+    bk.allreduce()
     expect = [sum((_view_grad(v, p.shape) for v in range(n_views)), torch.zeros(p.shape)) for p in params]
-    ok = all(torch.allclose(p.grad, e, atol=1e-5) for p, e in zip(params, expect))
+    ok = all(torch.allclose(p.grad, e, atol=1e-5) for p, e in zip(params, expect)) and early == 1
+    ok &= all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, bk.views))
     # max-over-ranks timing reduction used by bench.py
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -68,11 +88,28 @@ def test_view_sharded_gradient_allreduce_gloo_ws2():
     assert all(r[3] == 2.0 for r in res)
 
 
-def test_allreduce_is_identity_without_process_group():
-    params = [torch.zeros(4, 3, requires_grad=True), torch.zeros(4, 1, requires_grad=True)]
+def test_gradient_buckets_without_process_group_and_two_views_in_one_backward():
+    """World size 1: no collective, ``p.grad`` ends up as the slices.  A slice is handed out ONCE per ``attach()``: the
+    second rasterization node of one ``backward()`` (two views per step) gets None -- an ordinary tensor that autograd adds
+    in place -- so the sum of both views arrives, not twice the second one."""
+    params = [torch.zeros(4, 3, requires_grad=True), torch.zeros(4, 1, requires_grad=True),
+              torch.zeros(4, 15, 3, requires_grad=True)]
+    bk = parallel.GradientBuckets(params, geometry=[0, 1], colour=[2])
+    bk.attach(views_per_backward=2)
+    g1, g2 = torch.full((4, 15, 3), 1.0), torch.full((4, 15, 3), 10.0)
+    first = bk.sink(params[2])
+    assert first is not None and first.data_ptr() == bk.views[2].data_ptr()
+    first.copy_(g1)
+    params[2].grad = first                                             # AccumulateGrad adopts the first node's output
+    bk.rasterizer_done()
+    assert bk.sink(params[2]) is None                                  # second node: no slice
+    params[2].grad += g2                                               # ... autograd accumulates in place
+    bk.rasterizer_done()
     params[0].grad = torch.ones(4, 3)
-    flat = parallel.allreduce_gradients(params)
-    assert flat.numel() == 16 and torch.equal(params[0].grad, torch.ones(4, 3)) and not params[1].grad.any()
+    bk.allreduce()
+    assert torch.equal(params[2].grad, g1 + g2) and params[2].grad.data_ptr() == bk.views[2].data_ptr()
+    assert torch.equal(params[0].grad, torch.ones(4, 3)) and not params[1].grad.any()
+    assert bk.sink(torch.zeros(4, 3)) is None                          # not a parameter
 
 
 def _bucket_worker(rank, world, port, n, q):
@@ -96,7 +133,7 @@ def _bucket_worker(rank, world, port, n, q):
     expect = [sum((_view_grad(10 * r + i, p.shape) for r in range(world)), torch.zeros(p.shape)) for i, p in enumerate(leaves)]
     ok = all(torch.allclose(p.grad, e, atol=1e-5) for p, e in zip(leaves, expect))
     ok &= all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(leaves, bk.views))      # zero-copy: grads ARE the buffer
-    ok &= bk.flat.numel() == 59 * n
+    ok &= bk.flat.numel() == 59 * n                                       # (n = 64: no padding between the slices)
     # lock-step refinement: per-rank screen-space gradients are summed, every rank refines with the same seeded noise
     optimizers = {k: torch.optim.Adam([v], lr=1e-3) for k, v in params.items()}
     for k, v in params.items():

@@ -350,3 +350,67 @@ def test_camera_upload_on_cpu_is_a_plain_copy():
     vals = torch.arange(28, dtype=torch.float32)
     out = radegs._upload(vals, torch.device("cpu"))
     assert torch.equal(out, vals) and not radegs._PIN_RING
+
+
+def test_flip_proof_rows_need_a_pixel_that_actually_differs():
+    """tests/helpers.FlipProof: a gradient row out of tolerance is only explained by a pixel inside its screen box that
+    DIFFERS between the two implementations (recorded by check_pixels / check_ids), not by any low-margin pixel."""
+    import helpers
+    margin = np.ones((20, 30))
+    margin[5, 5] = margin[10, 10] = 1e-9                            # two pixels on a threshold
+    proof = helpers.FlipProof(margin, np.array([[5.0, 5.0], [10.0, 10.0], [25.0, 15.0]]), np.array([[2, 2], [2, 2], [2, 2]]))
+    with pytest.raises(AssertionError, match="before the gradient rows"):
+        proof.check_rows([0], "g")                                  # images / index maps first
+    differs = np.zeros((20, 30), bool)
+    differs[5, 5] = True
+    proof.check_pixels(differs, "render")                           # (5, 5) differs and sits on a threshold: accepted
+    proof.check_rows([0], "g")                                      # Gaussian 0 covers it
+    with pytest.raises(AssertionError, match="covers no pixel that differs"):
+        proof.check_rows([1], "g")                                  # Gaussian 1 covers only a low-margin pixel where nothing flipped
+    with pytest.raises(AssertionError, match="covers no pixel that differs"):
+        proof.check_rows([2], "g")
+    assert proof.rows_loose_only == 1
+    off = np.zeros((20, 30), bool)
+    off[1, 1] = True
+    with pytest.raises(AssertionError, match="not a flip"):
+        proof.check_pixels(off, "alpha")                            # a differing pixel far from every threshold
+    ids = np.zeros((20, 30), np.int32)
+    ids2 = ids.copy()
+    ids2[10, 10] = 7
+    proof.check_ids(ids2, ids, ids, ids)                            # unequal last_ids at a threshold pixel: now on record
+    proof.check_rows([1], "g")
+
+
+def test_graphed_step_result_check_finds_autograd_history():
+    from collab_splats_amd.graphs import _tensors_with_history
+    a = torch.ones(2, requires_grad=True)
+    b = a * 2
+    assert _tensors_with_history(None) == [] and _tensors_with_history([a, a.detach(), 3, "x"]) == []
+    assert _tensors_with_history({"img": [b.detach(), b], "meta": {"k": (b,)}}) == ["result['img'][1]"]
+    assert _tensors_with_history((a.detach(), {"loss": b.sum()})) == ["result[1]['loss']"]
+
+
+def test_kernel_and_oracle_activations_use_the_same_operation_sequence(craster):
+    """``scales_are_log`` / ``opacities_are_logit``: the projection kernels' exp (csrc/project.hip det_exp) and the C
+    restatement's (cr_activate) must be the same sequence of IEEE operations -- they feed the integer stages.  Checked
+    here without a GPU: the two function bodies hold the same constants in the same order, the C one is within 2 ulp of
+    exp over the parameter range, and sigmoid(0) = 0.5 exactly."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def constants(path, start):
+        text = open(path).read()
+        body = text[text.index(start):]
+        body = body[:body.index("return p *")]
+        return re.findall(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?f", body)
+
+    k = constants(os.path.join(root, "collab_splats_amd", "csrc", "project.hip"), "float det_exp(float x)")
+    c = constants(os.path.join(root, "oracle", "craster.c"), "x = x < -87.0f")
+    assert len(k) == 16 and k == c, (k, c)
+    cr = craster.CRaster(np.float32)
+    x = np.linspace(-14.0, 6.0, 100_001).astype(np.float32)
+    sc, op = cr.activate(np.stack([x, x, x], 1), x)
+    ref = np.exp(x.astype(np.float64))
+    assert np.max(np.abs(sc[:, 0] - ref) / ref) < 2.0 * 2.0 ** -23
+    assert np.array_equal(sc[:, 0], sc[:, 2]) and (np.diff(sc[:, 0]) >= 0).all()
+    assert cr.activate(np.zeros((1, 3), np.float32), np.zeros(1, np.float32))[1][0] == 0.5
