@@ -529,13 +529,10 @@ def main():
                 sc_p = random_scene(n_s, W, H, seed=seed)
                 params_p = {k: sc_p[k].to(dev).requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
                 what = f"the cpu_baseline sample ({n_s} Gaussians), view 0"
-            # the C port activates like the step that is checked: torch's exp / sigmoid for the reference's call, the kernels'
-            # own fixed-sequence exp (cr_activate) for the extension
-            if headline_mode["ext"]:
-                act = cr.activate(sc_p["log_scales"].numpy(), sc_p["opacity_logits"].numpy())
-            else:                                  # (evaluated where the step evaluates them: bit-identical inputs on both sides)
-                act = (torch.exp(params_p["log_scales"]).detach().cpu().numpy(),
-                       torch.sigmoid(params_p["opacity_logits"]).detach().cpu().numpy())
+            # the C port is given the activated values as the DEVICE computes them (the kernels' exp / sigmoid are torch's
+            # device expressions): bit-identical inputs on both sides, whichever form of the call is checked
+            act = (torch.exp(params_p["log_scales"]).detach().cpu().numpy(),
+                   torch.sigmoid(params_p["opacity_logits"]).detach().cpu().numpy())
             gcpu = torch.Generator().manual_seed(7)
             ups_np = [torch.rand(s, generator=gcpu) for s in ((1, H, W, cd), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3))]
             _, gr = _c_port_run(cr, sc_p, act[0], act[1], W, H, args, [u[0].numpy() for u in ups_np])

@@ -235,19 +235,20 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
         nrm[k][0] = nrm[k][1] = nrm[k][2] = 0.f;
     }
     const float amax = P.alpha_max, amin = P.alpha_min, tstop = P.t_stop, tmed = P.median_t;
+    const uint32_t amax_bits = __float_as_uint(amax);
     const float xlo = (float)(c.tx * MISPLAT_TILE) + 0.5f, xhi = xlo + 15.0f;
     const float ylo = (float)c.y0 + 0.5f, yhi = ylo + (float)(4 * PPL - 1);
 
     // pixel pairs (k = 2 kp, 2 kp + 1) as 2-vectors for the packed-math loop (even PPL)
     constexpr int NP = PPL >= 2 ? PPL / 2 : 1;
     constexpr int NXF = NXQ > 0 ? 4 * NXQ : 1;
-    v2f py2[NP], il2[NP], T2[NP], Tfin2[NP], dep2[NP], med2[NP], col2[NP][CD], nrm2[NP][3], colx2[NP][NXF];
+    v2f py2[NP], il2[NP], T2[NP], dep2[NP], med2[NP], col2[NP][CD], nrm2[NP][3], colx2[NP][NXF];
     if constexpr (PPL % 2 == 0) {
 #pragma unroll
         for (int kp = 0; kp < NP; kp++) {
             const int k0 = 2 * kp, k1 = 2 * kp + 1;
             py2[kp] = mk2(py[k0], py[k1]); il2[kp] = mk2(inv_ell[k0], inv_ell[k1]);
-            T2[kp] = mk2(T[k0], T[k1]); Tfin2[kp] = mk2(1.0f, 1.0f);
+            T2[kp] = mk2(T[k0], T[k1]);
             dep2[kp] = mk2(0.f, 0.f); med2[kp] = mk2(0.f, 0.f);
 #pragma unroll
             for (int ch = 0; ch < CD; ch++) col2[kp][ch] = mk2(0.f, 0.f);
@@ -258,19 +259,35 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
         }
     }
 
+    // Packed path (even PPL): the per-pixel control state lives in LANE MASKS (scalar registers), not in vector compares
+    // of the transmittance -- `alive` (not terminated), `above` (T still above the median threshold) -- so that the
+    // trip's decisions are scalar ANDs of three vector compares per pixel (sigma >= 0, alpha >= alpha_min, T' <= t_stop)
+    // instead of six, a finished pixel needs no parking register (its T is kept NEGATED: magnitude = transmittance at
+    // termination, and alpha = 0 for it, so nothing accumulates), and the median bookkeeping is skipped by a wave-uniform
+    // branch once no pixel of the band is above the threshold any more (most trips: T falls below 0.5 early, the
+    // traversal runs on to 1e-4).
+    // (Masks are carried explicitly as 64-bit scalars and turned back into lane predicates with inverse_ballot: a `bool`
+    // carried around the loop would be legalised into a 0/1 vector register, three vector instructions per trip each.)
+    typedef unsigned long long lmask;
+    lmask alive[PPL], above[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; k++) { alive[k] = __ballot(T[k] > 0.f); above[k] = alive[k]; }
+    bool med_live = true;                       // (wave-uniform) some pixel may still take its median from a later Gaussian
+#define MISPLAT_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
+
     int work = 0;                               // staged Gaussians composited by this unit (its measured cost)
     for (int bs = c.beg; bs < c.end; bs += 64) {
-        float tmax;
         if constexpr (PPL % 2 == 0) {
-            tmax = fmaxf(T2[0].x, T2[0].y);
+            lmask any = alive[0];
 #pragma unroll
-            for (int kp = 1; kp < NP; kp++) tmax = fmaxf(tmax, fmaxf(T2[kp].x, T2[kp].y));
+            for (int k = 1; k < PPL; k++) any |= alive[k];
+            if (any == 0ull) break;
         } else {
-            tmax = T[0];
+            float tmax = T[0];
 #pragma unroll
             for (int k = 1; k < PPL; k++) tmax = fmaxf(tmax, T[k]);
+            if (__ballot(tmax > 0.f) == 0ull) break;
         }
-        if (__ballot(tmax > 0.f) == 0ull) break;
         __syncthreads();
         const int n = stage_records<NXQ, LAZY>(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
                                                nullptr, xlo, xhi, ylo, yhi, amin, smx, featx, &lz);
@@ -297,6 +314,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
             if constexpr (PPL % 2 == 0) {
                 // two pixels of the lane per packed instruction (see blend_bwd_kernel)
                 v2f dy_[NP], a_[NP];
+                lmask ok_[PPL];
 #pragma unroll
                 for (int kp = 0; kp < NP; kp++) {
                     const v2f dy = q0.y - py2[kp];
@@ -304,25 +322,34 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
                     v2f vis;
                     vis.x = __builtin_amdgcn_exp2f(e.x); vis.y = __builtin_amdgcn_exp2f(e.y);
                     const v2f ov = q1.y * vis;
-                    const float am0 = fminf(amax, ov.x), am1 = fminf(amax, ov.y);
+                    // min(alpha_max, o vis) on the bit patterns: both are non-negative floats (a NaN sorts above every
+                    // number and fails the `e <= 0` test anyway), so the unsigned integer minimum is the float minimum
+                    // -- without the canonicalisation a float min needs
+                    const float am0 = __uint_as_float(min(amax_bits, __float_as_uint(ov.x)));
+                    const float am1 = __uint_as_float(min(amax_bits, __float_as_uint(ov.y)));
+                    // (one ballot per compare: the compare then writes its lane mask straight into scalar registers)
+                    const lmask ok0 = alive[2 * kp] & __ballot(e.x <= 0.f) & __ballot(am0 >= amin);
+                    const lmask ok1 = alive[2 * kp + 1] & __ballot(e.y <= 0.f) & __ballot(am1 >= amin);
                     v2f a;
-                    a.x = (e.x <= 0.f && am0 >= amin) ? am0 : 0.f; a.y = (e.y <= 0.f && am1 >= amin) ? am1 : 0.f;
-                    dy_[kp] = dy; a_[kp] = a;
+                    a.x = MISPLAT_LANE(ok0) ? am0 : 0.f; a.y = MISPLAT_LANE(ok1) ? am1 : 0.f;
+                    dy_[kp] = dy; a_[kp] = a; ok_[2 * kp] = ok0; ok_[2 * kp + 1] = ok1;
                 }
                 q0 = sm[j + 1]; q1 = sm[64 + j + 1];                   // next Gaussian (array padded)
                 __builtin_amdgcn_sched_barrier(0);
+                lmask any_alive = 0ull;
 #pragma unroll
                 for (int kp = 0; kp < NP; kp++) {
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
                     const v2f dy = dy_[kp], a = a_[kp];
                     const v2f Tk = T2[kp];
-                    v2f w = a * Tk;
+                    v2f w = a * Tk;                                      // (a = 0 for a finished pixel: its T stays as it is)
                     const v2f Tn = Tk - w;
-                    const bool stop0 = (w.x > 0.f) && (Tn.x <= tstop), stop1 = (w.y > 0.f) && (Tn.y <= tstop);
-                    const bool use0 = (w.x > 0.f) && !stop0, use1 = (w.y > 0.f) && !stop1;
-                    Tfin2[kp].x = stop0 ? Tk.x : Tfin2[kp].x; Tfin2[kp].y = stop1 ? Tk.y : Tfin2[kp].y;
-                    const bool med0 = use0 && (Tk.x > tmed), med1 = use1 && (Tk.y > tmed);
-                    T2[kp].x = stop0 ? 0.f : Tn.x; T2[kp].y = stop1 ? 0.f : Tn.y;
-                    w.x = stop0 ? 0.f : w.x; w.y = stop1 ? 0.f : w.y;
+                    const lmask stop0 = ok_[k0] & __ballot(Tn.x <= tstop), stop1 = ok_[k1] & __ballot(Tn.y <= tstop);   // this Gaussian is excluded
+                    const lmask use0 = ok_[k0] & ~stop0, use1 = ok_[k1] & ~stop1;
+                    T2[kp].x = MISPLAT_LANE(stop0) ? -Tk.x : Tn.x; T2[kp].y = MISPLAT_LANE(stop1) ? -Tk.y : Tn.y;
+                    w.x = MISPLAT_LANE(stop0) ? 0.f : w.x; w.y = MISPLAT_LANE(stop1) ? 0.f : w.y;
+                    alive[k0] &= ~stop0; alive[k1] &= ~stop1;
+                    any_alive |= alive[k0] | alive[k1];
                     const v2f zp = (tpx - q2.x * dy) * il2[kp];
                     col2[kp][0] += w * q3.x;
                     if (CD > 1) col2[kp][CD > 1 ? 1 : 0] += w * q3.y;
@@ -335,11 +362,23 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
                     }
                     dep2[kp] += w * zp;
                     nrm2[kp][0] += w * q2.y; nrm2[kp][1] += w * q2.z; nrm2[kp][2] += w * q2.w;
-                    med2[kp].x = med0 ? zp.x : med2[kp].x; med2[kp].y = med1 ? zp.y : med2[kp].y;
-                    medi[2 * kp] = med0 ? i : medi[2 * kp]; medi[2 * kp + 1] = med1 ? i : medi[2 * kp + 1];
-                    last[2 * kp] = use0 ? i : last[2 * kp]; last[2 * kp + 1] = use1 ? i : last[2 * kp + 1];
-                    tm = fmaxf(tm, fmaxf(T2[kp].x, T2[kp].y));
+                    last[k0] = MISPLAT_LANE(use0) ? i : last[k0]; last[k1] = MISPLAT_LANE(use1) ? i : last[k1];
+                    if (med_live) {                                      // wave-uniform
+                        asm volatile("; median bookkeeping" ::);         // (a real branch: not worth speculating on every trip)
+                        const lmask med0 = use0 & above[k0], med1 = use1 & above[k1];        // T BEFORE this Gaussian > median_t
+                        med2[kp].x = MISPLAT_LANE(med0) ? zp.x : med2[kp].x; med2[kp].y = MISPLAT_LANE(med1) ? zp.y : med2[kp].y;
+                        medi[k0] = MISPLAT_LANE(med0) ? i : medi[k0]; medi[k1] = MISPLAT_LANE(med1) ? i : medi[k1];
+                        above[k0] = __ballot(T2[kp].x > tmed); above[k1] = __ballot(T2[kp].y > tmed);   // (a finished pixel's T is negative)
+                    }
                 }
+                if (med_live) {
+                    lmask any_above = above[0];
+#pragma unroll
+                    for (int k = 1; k < PPL; k++) any_above |= above[k];
+                    med_live = any_above != 0ull;
+                }
+                if (any_alive == 0ull) break;
+                continue;
             } else {
 #pragma unroll
                 for (int k = 0; k < PPL; k++) {
@@ -385,7 +424,8 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int k = 2 * kp + h;
-                T[k] = h ? T2[kp].y : T2[kp].x; Tfin[k] = h ? Tfin2[kp].y : Tfin2[kp].x;
+                const float Ts = h ? T2[kp].y : T2[kp].x;               // negative: terminated, magnitude = T at termination
+                T[k] = Ts > 0.f ? Ts : 0.f; Tfin[k] = fabsf(Ts);
                 dep[k] = h ? dep2[kp].y : dep2[kp].x; med[k] = h ? med2[kp].y : med2[kp].x;
 #pragma unroll
                 for (int ch = 0; ch < CD; ch++) col[k][ch] = h ? col2[kp][ch].y : col2[kp][ch].x;
@@ -638,6 +678,8 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
     // per-lane scale undoing the conic pre-multiplication (component = record layout index)
     const float out_scale = (comp == 2 || comp == 4) ? -0.5f * kLog2e : (comp == 3 ? -kLog2e : 1.0f);
     const float amax = P.alpha_max, amin = P.alpha_min;
+    const uint32_t amax_bits = __float_as_uint(amax);
+    const uint32_t comp_off = 4u * (uint32_t)comp;           // byte offset of this lane's component inside a 64-byte row
     const float xlo = (float)(c.tx * MISPLAT_TILE) + 0.5f, xhi = xlo + 15.0f;
     const float ylo = (float)c.y0 + 0.5f, yhi = ylo + (float)(4 * PPL - 1);
     // slab mode: one plane per band; atomic mode: slab IS v_grec[C*N,16] (zeroed by the launcher)
@@ -662,6 +704,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
         // and no copies.
         float4 q0 = sm[n - 1], q1 = sm[64 + n - 1], q2 = sm[128 + n - 1], q3 = sm[192 + n - 1];
         int i = sm_idx[n - 1], islot = sm_slot[n - 1];
+        unsigned long long touched_j = 0ull;       // staged entries of this batch that received a gradient row
         for (int j = n - 1; j >= 0; j--) {
             float4 xq[NXQ > 0 ? NXQ : 1];
 #pragma unroll
@@ -677,8 +720,11 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
             for (int r = 0; r < 16; r++) accx[r] = 0.f;
             float ab0 = 0.f, ab1 = 0.f;
             float amx = 0.f;
+            unsigned long long any_ok = 0ull;      // (packed path) lanes with a contributing pixel
             if constexpr (PPL % 2 == 0) {
                 // Two pixels of the lane at a time in 2-vectors (v_pk_{fma,mul,add}_f32) for the per-pixel chain.
+                // The per-pixel decisions are lane masks in scalar registers (one ballot per vector compare, combined
+                // with scalar ANDs, turned back into select conditions with inverse_ballot): see blend_fwd_kernel.
                 const float dxx = dx * dx, ndx = -dx;
                 const float c1x = 2.0f * q0.z * dx, c1y = q0.w * dx;
 #pragma unroll
@@ -689,11 +735,15 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                     v2f vis;
                     vis.x = __builtin_amdgcn_exp2f(e.x); vis.y = __builtin_amdgcn_exp2f(e.y);
                     const v2f ov = q1.y * vis;
-                    const bool ok0 = (i <= last[k0]) && (e.x <= 0.f) && (fminf(amax, ov.x) >= amin);
-                    const bool ok1 = (i <= last[k1]) && (e.y <= 0.f) && (fminf(amax, ov.y) >= amin);
+                    // min(alpha_max, o vis) as an unsigned minimum of the bit patterns (non-negative floats; a NaN fails e <= 0)
+                    const float am0 = __uint_as_float(min(amax_bits, __float_as_uint(ov.x)));
+                    const float am1 = __uint_as_float(min(amax_bits, __float_as_uint(ov.y)));
+                    const unsigned long long okm0 = __ballot(i <= last[k0]) & __ballot(e.x <= 0.f) & __ballot(am0 >= amin);
+                    const unsigned long long okm1 = __ballot(i <= last[k1]) & __ballot(e.y <= 0.f) & __ballot(am1 >= amin);
+                    any_ok |= okm0 | okm1;
+                    const bool ok0 = __builtin_amdgcn_inverse_ballot_w64(okm0), ok1 = __builtin_amdgcn_inverse_ballot_w64(okm1);
                     v2f a;
-                    a.x = ok0 ? fminf(amax, ov.x) : 0.f; a.y = ok1 ? fminf(amax, ov.y) : 0.f;
-                    amx = fmaxf(amx, fmaxf(a.x, a.y));
+                    a.x = ok0 ? am0 : 0.f; a.y = ok1 ? am1 : 0.f;
                     const v2f om = 1.0f - a;
                     v2f ra;
                     ra.x = __builtin_amdgcn_rcpf(om.x); ra.y = __builtin_amdgcn_rcpf(om.y);
@@ -710,18 +760,21 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                         dot += xq[q].x * vcolx2[kp][4 * q] + xq[q].y * vcolx2[kp][4 * q + 1] +
                                xq[q].z * vcolx2[kp][4 * q + 2] + xq[q].w * vcolx2[kp][4 * q + 3];
                     dot += q2.y * vn2[kp][0] + q2.z * vn2[kp][1] + q2.w * vn2[kp][2] + zp * vd2[kp];
-                    v2f v_a = (tf2[kp] - B2[kp]) * ra + Tk * dot;
-                    v_a.x = ok0 ? v_a.x : 0.f; v_a.y = ok1 ? v_a.y : 0.f;
+                    const v2f v_a = (tf2[kp] - B2[kp]) * ra + Tk * dot;     // (only used through vam below: masked there)
                     B2[kp] += w * dot;
                     v2f vz = w * vd2[kp];
                     if (batch_has_median) {          // wave-uniform: most batches hold no pixel's median Gaussian
+                        asm volatile("; median gradient" ::);               // (a real branch, not a speculated select)
                         v2f vmed;
                         vmed.x = (ok0 && i == medi[k0]) ? vm2[kp].x : 0.f; vmed.y = (ok1 && i == medi[k1]) ? vm2[kp].y : 0.f;
                         vz += vmed;
                     }
                     const v2f vzl = vz * il2[kp];
+                    // d alpha / d (o vis) is 1 below the clamp, 0 at it; and nothing flows through a pixel that skipped
+                    const bool un0 = __builtin_amdgcn_inverse_ballot_w64(okm0 & __ballot(ov.x <= amax));
+                    const bool un1 = __builtin_amdgcn_inverse_ballot_w64(okm1 & __ballot(ov.y <= amax));
                     v2f vam;
-                    vam.x = (ov.x <= amax) ? v_a.x : 0.f; vam.y = (ov.y <= amax) ? v_a.y : 0.f;
+                    vam.x = un0 ? v_a.x : 0.f; vam.y = un1 ? v_a.y : 0.f;
                     const v2f v_e = (kLn2 * ov) * vam;
                     const v2f dyve = dy * v_e;
                     const v2f vmx = (c1x + q0.w * dy) * v_e - vzl * q1.w;
@@ -800,17 +853,19 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                 }
             }
             const size_t slot = (size_t)islot;
+            const uint32_t slot_off = (uint32_t)islot << 6;   // (atomic mode: rows * 64 B < 4 GiB, checked by the launcher)
             {
                 const int jn = j > 0 ? j - 1 : 0;
                 q0 = sm[jn]; q1 = sm[64 + jn]; q2 = sm[128 + jn]; q3 = sm[192 + jn];
                 i = sm_idx[jn]; islot = sm_slot[jn];
             }
-            if (__ballot(amx > 0.f) != 0ull) {
+            const bool contributes = (PPL % 2 == 0) ? (any_ok != 0ull) : (__ballot(amx > 0.f) != 0ull);
+            if (contributes) {
                 const float r = wave_reduce16(acc, lane);
                 if (ATOMIC) {
-                    // one 64-byte contiguous no-return fp32 atomic per (band, Gaussian)
-                    if (writer) atomicAdd(&slab_b[slot * MISPLAT_REC + comp], r * out_scale);
-                    if (P.touched && lane == 1) P.touched[slot] = 1;
+                    // one 64-byte contiguous no-return fp32 atomic per (band, Gaussian): 32-bit byte offset from a uniform base
+                    if (writer) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(slab_b) + (slot_off + comp_off)), r * out_scale);
+                    touched_j |= 1ull << j;        // (flagged once per batch, below)
                     if (NXQ > 0) {
                         const float rx = wave_reduce16(accx, lane);
                         if (writer && comp < NX) atomicAdd(&v_featx[slot * NX + comp], rx);
@@ -827,6 +882,9 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                 }
             }
         }
+        // row flags for the per-Gaussian backward kernels: one store instruction per batch (lane p flags the row of staged
+        // entry p) instead of a predicated store per trip
+        if (ATOMIC && P.touched && ((touched_j >> lane) & 1ull)) P.touched[sm_slot[lane]] = 1;
     }
 }
 
@@ -1565,6 +1623,7 @@ int misplat_internal::blend_bwd_atomic(const misplat_params* p, int32_t color_di
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !v_grec) return MISPLAT_EINVAL;
     const size_t rows = (size_t)p->n_gauss * p->n_cams;
     if (rows == 0) return MISPLAT_OK;
+    if (rows >= ((size_t)1 << 26)) return MISPLAT_EINVAL;   // the kernels address gradient rows with 32-bit byte offsets (64 B each)
     // v_grec_is_zero: bit 0 = v_grec, bit 1 = v_abs have been cleared by the caller
     if (!(v_grec_is_zero & 1) && fill_bytes(v_grec, rows * MISPLAT_REC * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     if (v_abs && !(v_grec_is_zero & 2) && fill_bytes(v_abs, rows * 2 * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
@@ -1689,6 +1748,7 @@ extern "C" int misplat_blend_bwd_x_atomic(const misplat_params* p, int32_t n_cha
     hipStream_t s = (hipStream_t)stream;
     const size_t rows = (size_t)p->n_gauss * p->n_cams;
     if (rows == 0) return MISPLAT_OK;
+    if (rows >= ((size_t)1 << 26)) return MISPLAT_EINVAL;   // (32-bit byte offsets into the gradient rows)
     if (misplat_internal::fill_bytes(v_grec, rows * MISPLAT_REC * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     if (misplat_internal::fill_bytes(v_featx, rows * 4 * nxq * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     if (v_abs && misplat_internal::fill_bytes(v_abs, rows * 2 * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;

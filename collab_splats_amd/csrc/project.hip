@@ -36,26 +36,6 @@ __device__ __forceinline__ float det_log(float x) {
     return (float)e * 0.69314718f + 2.0f * s * p;
 }
 
-__device__ __forceinline__ float det_exp(float x) {
-    // e^x from plain mul/add/floor only, in one fixed order (this file is compiled without FMA contraction): the
-    // activations of misplat_params.activations feed the radii and tile rectangles, so an independent fp32
-    // implementation of the same sequence (the tests' CPU restatement) must reproduce them bit for bit.  x = k ln2 + r,
-    // |r| <= 0.3466, e^r by a degree-7 polynomial (truncation 5e-9), 2^k through the exponent bits; ~1.5 ulp.
-    x = x < -87.0f ? -87.0f : (x > 88.0f ? 88.0f : x);
-    const float k = floorf(x * 1.44269504f + 0.5f);
-    float r = x - k * 0.693145751953125f;          // ln2 split: the high part has 16 significant bits (k * hi is exact)
-    r = r - k * 1.42860677e-06f;
-    float p = 1.98412698e-04f;
-    p = p * r + 1.38888889e-03f;
-    p = p * r + 8.33333377e-03f;
-    p = p * r + 4.16666679e-02f;
-    p = p * r + 1.66666672e-01f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
-    return p * __uint_as_float((uint32_t)((int)k + 127) << 23);
-}
-
 struct ProjState {
     float Rc[9], qn[4], qnorm;
     float mu[3], u, v, tx, ty, limx, limy;
@@ -531,8 +511,10 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int n_gauss, int n_cams, in
 // misplat_params.activations: the caller's parameters are log-scales (bit 0) / opacity logits (bit 1) and the kernels
 // apply exp / sigmoid themselves (rade_gs_model.py:443-444 does it with two torch launches per direction).
 __device__ __forceinline__ void apply_activations(const misplat_params& P, float (&scale)[3], float& opac) {
-    if (P.activations & 1) { scale[0] = det_exp(scale[0]); scale[1] = det_exp(scale[1]); scale[2] = det_exp(scale[2]); }
-    if (P.activations & 2) opac = 1.0f / (1.0f + det_exp(-opac));
+    // (expf / the sigmoid expression of torch's own device kernels: the same bits as torch.exp / torch.sigmoid in front of
+    // the call, so the extension and the reference's call are interchangeable down to the integer stages)
+    if (P.activations & 1) { scale[0] = expf(scale[0]); scale[1] = expf(scale[1]); scale[2] = expf(scale[2]); }
+    if (P.activations & 2) opac = 1.0f / (1.0f + expf(-opac));
 }
 
 // ================================================================================================

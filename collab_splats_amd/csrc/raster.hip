@@ -135,7 +135,8 @@ struct misplat_graph_cache {
     std::vector<GraphEntry> entries;
     std::vector<Retired> retired;
     uint64_t clock = 0, hits = 0, captures = 0;
-    uint64_t window_calls = 0, window_misses = 0, bypass_until = 0, miss_run = 0, pause_len = 512;
+    std::vector<uint64_t> seen;                 // hashes of the last 256 argument blocks that missed (capture on second sighting)
+    uint64_t seen_next = 0, window_start = 0, window_captures = 0;
     int max_entries = 16;
     // Sequences are captured on this private stream (the caller's may be the legacy default stream, which cannot be
     // captured) and the resulting graph is launched on the caller's stream.
@@ -200,32 +201,28 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
             e.stamp = cache->clock;
             e.last_stream = s;
             cache->hits++;
-            cache->miss_run = 0;
-            if (++cache->window_calls >= 32) {                      // a window closes: a quiet one resets the pause length
-                if (cache->window_misses == 0) cache->pause_len = 512;
-                cache->window_calls = cache->window_misses = 0;
-            }
             return hipGraphLaunch(e.exec, s) == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
         }
-    // A capture + instantiation costs ~2 ms, a replay saves some tens of microseconds of host time: a caller whose
-    // argument blocks do not repeat (the model mirror: fresh camera tensors, allocator addresses that cycle with a long
-    // period) must not keep capturing.  The first 32 calls are free (start-up: a few distinct phases, addresses that
-    // settle); after that two misses within a window of 32 calls, or a dozen in a row at any time, stop captures for a
-    // while (graphs already captured are still replayed: the lookup above comes first); the pause doubles every time it
-    // is needed again and goes back to 512 calls after a window without a miss.
-    // (plain launches while captures are paused -- the side branch still exists: the cache's side stream and events
-    // work outside a capture too)
-    if (cache->clock < cache->bypass_until) return enqueue(s, &cache->fork);
-    if (cache->window_calls >= 32) cache->window_calls = cache->window_misses = 0;
-    cache->window_calls++;
-    cache->window_misses++;
-    if (++cache->miss_run >= 12 || (cache->clock > 32 && cache->window_misses >= 2)) {
-        cache->bypass_until = cache->clock + cache->pause_len;
-        if (cache->pause_len < 65536) cache->pause_len *= 2;
-        cache->miss_run = 0;
-        cache->window_calls = cache->window_misses = 0;
+    // A capture + instantiation costs host time (of the order of a millisecond), a replay saves some tens of
+    // microseconds: a caller whose argument blocks do not repeat (fresh camera tensors at addresses that never come back,
+    // intersection capacities that drift) must not capture at all.  So a block is captured when it is seen for the
+    // SECOND time: its first sighting only leaves a 64-bit hash in a ring of the last 256 misses and launches plainly.
+    // A trainer that cycles through a few resident camera tensors pays one plain round, one capturing round and
+    // replays from then on; a caller whose blocks never recur pays nothing.  Safety net for blocks that recur exactly
+    // once (period-2 address patterns that then move on): at most max_entries captures per 256 calls.
+    uint64_t h = 1469598103934665603ull;
+    for (uint8_t bt : key) { h ^= bt; h *= 1099511628211ull; }
+    bool seen = false;
+    for (uint64_t v : cache->seen) seen |= (v == h);
+    if (cache->clock - cache->window_start >= 256) { cache->window_start = cache->clock; cache->window_captures = 0; }
+    if (!seen || cache->window_captures >= (uint64_t)cache->max_entries) {
+        if (!seen) {
+            if (cache->seen.size() < 256) cache->seen.push_back(h);
+            else cache->seen[cache->seen_next++ & 255] = h;
+        }
         return enqueue(s, &cache->fork);
     }
+    cache->window_captures++;
     // capture on the private stream (thread-local mode: other host threads keep using the runtime normally)
     hipStream_t cs = cache->capture_stream;
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {

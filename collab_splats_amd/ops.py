@@ -847,9 +847,11 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
             raise _lib.MisplatError(f"{cap} tile intersections exceed int32 indexing")
         payload, flatten_ids, scratch = isect_buffers(cap)
     if not static:
-        # a slowly decaying maximum: consecutive training views differ in their counts by tens of percent, and a guess that
-        # falls short costs a second phase B, while a generous one costs nothing but address space (288 GB of HBM)
-        _CAP_HINT[key] = max(n_known, int(0.97 * _CAP_HINT.get(key, 0)))
+        # a very slowly decaying maximum: consecutive training views differ in their counts by tens of percent (1 M random
+        # Gaussians, the eight views of configs[3]: 3.8 - 6.4 M), a guess that falls short costs a second phase B, a
+        # generous one costs nothing but address space (288 GB of HBM) -- and a capacity that stays put keeps the buffers'
+        # addresses and with them the graph keys (a change of 1/8 octave needs ~100 calls at this decay)
+        _CAP_HINT[key] = max(n_known, int(0.999 * _CAP_HINT.get(key, 0)))
     if sched.on:
         _LAST_ORDER[sched.key] = sched.perm
         if sched.ppl_b == sched.ppl_f:

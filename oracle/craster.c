@@ -96,41 +96,6 @@ static inline real det_log(real x) {
 #endif
 }
 
-/* Deterministic e^x (float build): the same operation sequence as det_exp in csrc/project.hip -- the activations the
- * projection kernels apply to raw log-scales / logits (misplat_params.activations, an extension of this build; the
- * reference's caller applies torch.exp / torch.sigmoid itself, rade_gs_model.py:443-444). */
-static inline real det_exp(real x) {
-#if defined(REAL_IS_DOUBLE)
-    return exp(x);
-#else
-    x = x < -87.0f ? -87.0f : (x > 88.0f ? 88.0f : x);
-    const float k = floorf(x * 1.44269504f + 0.5f);
-    float r = x - k * 0.693145751953125f;
-    r = r - k * 1.42860677e-06f;
-    float p = 1.98412698e-04f;
-    p = p * r + 1.38888889e-03f;
-    p = p * r + 8.33333377e-03f;
-    p = p * r + 4.16666679e-02f;
-    p = p * r + 1.66666672e-01f;
-    p = p * r + 0.5f;
-    p = p * r + 1.0f;
-    p = p * r + 1.0f;
-    union { float f; uint32_t u; } v;
-    v.u = (uint32_t)((int)k + 127) << 23;
-    return p * v.f;
-#endif
-}
-
-/* scales = exp(log_scales) [N,3], opacities = sigmoid(logits) [N]: what the kernels compute inside when the caller hands
- * them raw parameters. */
-void cr_activate(int N, const real* log_scales, const real* logits, real* scales, real* opacities) {
-#pragma omp parallel for schedule(static)
-    for (int g = 0; g < N; g++) {
-        for (int k = 0; k < 3; k++) scales[3 * g + k] = det_exp(log_scales[3 * g + k]);
-        opacities[g] = R(1) / (R(1) + det_exp(-logits[g]));
-    }
-}
-
 static inline void quat_to_rot(const real* q, real* Rm, real* qn_out, real* norm_out) {
     real n = SQRT(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
     real r = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;

@@ -75,14 +75,6 @@ class CRaster:
                       int(antialiased))
 
     # -- stages
-    def activate(self, log_scales, logits):
-        """(exp(log_scales), sigmoid(logits)) exactly as the projection kernels compute them from raw parameters
-        (``scales_are_log`` / ``opacities_are_logit``): cr_activate / det_exp."""
-        ls, lg = self._a(log_scales), self._a(logits)
-        sc, op = np.zeros_like(ls), np.zeros_like(lg)
-        self.lib.cr_activate(C.c_int(ls.shape[0]), self._p(ls), self._p(lg), self._p(sc), self._p(op))
-        return sc, op
-
     def project_fwd(self, means, quats, scales, opacities, viewmat, P):
         N = means.shape[0]
         dt = self.dtype

@@ -1,4 +1,6 @@
 """Shared test helpers (tests only)."""
+import os
+
 import numpy as np
 import torch
 
@@ -103,9 +105,14 @@ class FlipProof:
         loose = self._box_counts(self._sat(self.low), rows) > 0
         self.rows_checked += int(rows.size)
         self.rows_loose_only += int((loose & ~strict).sum())
-        print(f"[FlipProof] {name}: {rows.size} out-of-tolerance row(s), {int(strict.sum())} cover a pixel that differs, "
-              f"{int((loose & ~strict).sum())} cover only a low-margin pixel where nothing flipped (rejected), "
-              f"{int((~loose).sum())} cover no threshold pixel at all; {int(self.flipped.sum())} differing pixel(s) on record")
+        msg = (f"[FlipProof] {name}: {rows.size} out-of-tolerance row(s), {int(strict.sum())} cover a pixel that differs, "
+               f"{int((loose & ~strict).sum())} cover only a low-margin pixel where nothing flipped (rejected), "
+               f"{int((~loose).sum())} cover no threshold pixel at all; {int(self.flipped.sum())} differing pixel(s) on record, "
+               f"{int(self.low.sum())} low-margin pixel(s) in the image")
+        print(msg)
+        if os.environ.get("FLIPPROOF_LOG"):                  # (pytest swallows the output of passing tests)
+            with open(os.environ["FLIPPROOF_LOG"], "a") as f:
+                f.write(msg + "\n")
         assert strict.all(), (
             f"{name}: Gaussian {int(rows[~strict][0])} (+{int((~strict).sum()) - 1} more) misses the tolerance but its screen box "
             f"covers no pixel that differs between the two implementations: not a flip")
