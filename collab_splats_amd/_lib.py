@@ -47,7 +47,7 @@ class RasterArgs(C.Structure):
                 + [(n, C.c_int32) for n in ("sh_degree", "K_or_D", "n_color", "per_cam", "depth_channel", "color_dim",
                                             "colour_pending", "lazy_colour")]
                 + [(n, C.c_void_p) for n in ("radii", "means2d", "depths", "compensations", "grec", "sh_aux", "v_grec_zero",
-                                             "tiles_per_gauss", "rect2", "cellhist", "cell_count", "cell_offs", "order",
+                                             "tiles_per_gauss", "rect2", "cellhist", "cell_count", "cell_offs", "cell_cursor", "order",
                                              "rect_sorted", "counters", "tile_count", "offsets", "payload", "flatten_ids", "scratch")]
                 + [("cap_isects", C.c_int64)]
                 + [(n, C.c_void_p) for n in ("n_isects_host", "v_abs_zero", "render", "alpha", "exp_depth", "med_depth",
@@ -106,7 +106,7 @@ SYMBOLS = {
     "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 20), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),
     "misplat_depth_normal_bwd": (C.c_int, 14), "misplat_outputs_fwd": (C.c_int, 15), "misplat_outputs_bwd": (C.c_int, 16),
     "misplat_loss_fwd": (C.c_int, 11), "misplat_loss_bwd": (C.c_int, 11),
-    "misplat_bucket_plan": (C.c_int, 3), "misplat_bucket_count": (C.c_int, 10), "misplat_bucket_rows": (C.c_int, 11),
+    "misplat_bucket_plan": (C.c_int, 3), "misplat_bucket_count": (C.c_int, 10), "misplat_bucket_rows": (C.c_int, 14),
     "misplat_bucket_tiles": (C.c_int, 11),
     "misplat_unit_order": (C.c_int, 5), "misplat_raster_fwd": (C.c_int, 5), "misplat_raster_bwd": (C.c_int, 4), "misplat_raster_bwd_plan": (C.c_int, 2), "misplat_graph_cache_create": (C.c_void_p, 1),
     "misplat_graph_cache_destroy": (None, 1), "misplat_graph_cache_stats": (C.c_int, 3), "misplat_wait_count": (C.c_int64, 2), "misplat_zero_bytes": (C.c_int, 3), "misplat_stream_copy": (C.c_int, 5),

@@ -281,18 +281,261 @@ __device__ __forceinline__ int tile_radix_regs(uint32_t (&key)[R], uint32_t (&va
     return passes;
 }
 
+// ---- bin + rank: the fast path of the register classes ---------------------------------------------------------
+// A bucket of n entries whose keys (depth bits) are spread over [kmin, kmax] does not need three stable LSD passes:
+// ONE counting pass on the top B bits of key - kmin (B = log2 of the histogram size = 512 * WAVES >= n bins, so a
+// bin holds about one entry when the depths are spread evenly) puts every entry within a few slots of its final
+// place, and the entry then RANKS itself inside its bin by comparing (key, value) with the bin's other entries --
+// values are unique and ascend with the Gaussian row (rows themselves, or emission slots, which are assigned in row
+// order), so this is exactly the (depth, row) order of the stable / two-sort paths, equal depths included.  Nothing
+// here needs stability, so the histogram is not split per wave and the positions inside a bin come from a returning
+// LDS atomic: 5 barriers per bucket instead of ~13, ~25 instead of ~180 instructions per entry.
+// Crowded bins (depths clustered in a small part of the bucket's range: a wall seen through a few floaters) make the
+// ranking quadratic; a bucket whose fullest bin exceeds kBinRankCap entries is left to the LSD sort (returns false,
+// before anything has been written).
+constexpr int kBinRankCap = 32;
+#ifndef MISPLAT_TS_BINRANK
+#define MISPLAT_TS_BINRANK 1
+#endif
+#ifndef MISPLAT_TS_BINRANK_MASK
+#define MISPLAT_TS_BINRANK_MASK (1 | 2 | 16)   /* bit = WAVES of the classes that take the fast path (see sort_bucket_regs) */
+#endif
+#ifndef MISPLAT_TS_B_BLOCKS
+#define MISPLAT_TS_B_BLOCKS 6                  /* launch bound (workgroups per 4 SIMDs x ...) of the eight-wave class */
+#endif
+template <int WAVES, int R, bool HAS_VALS>
+__device__ __forceinline__ bool tile_bin_rank(const uint32_t (&key)[R], const uint32_t (&val)[R], int n,
+                                              tile_sort_lds<WAVES, R>& L, int beg, const int32_t* __restrict__ isect_gid,
+                                              int32_t* __restrict__ payload, int32_t* __restrict__ flatten_ids) {
+    constexpr int DIG = 512 * WAVES;                               // bins (= words of L.hist2[0])
+    constexpr int LOG_DIG = WAVES == 1 ? 9 : (WAVES == 2 ? 10 : (WAVES == 4 ? 11 : (WAVES == 8 ? 12 : 13)));
+    static_assert((1 << LOG_DIG) == DIG, "WAVES must be 1, 2, 4, 8 or 16");
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint32_t* hist = L.hist2[0];
+    uint32_t mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = wave * 64 * R + r * 64 + lane;
+        if (i < n) { mn = min(mn, key[r]); mx = max(mx, key[r]); }
+    }
+    if (threadIdx.x == 0) { L.kmin = 0xffffffffu; L.kmax = 0u; }
+    reinterpret_cast<uint4*>(hist)[2 * threadIdx.x] = zero4;
+    reinterpret_cast<uint4*>(hist)[2 * threadIdx.x + 1] = zero4;
+    mn = wave_scan_incl(mn, 0xffffffffu, [](uint32_t a, uint32_t b) { return min(a, b); });
+    mx = wave_scan_incl(mx, 0u, [](uint32_t a, uint32_t b) { return max(a, b); });
+    __syncthreads();
+    if (lane == 63 && wave * 64 * R < n) { atomicMin(&L.kmin, mn); atomicMax(&L.kmax, mx); }
+    __syncthreads();
+    const uint32_t kmin = L.kmin;
+    const uint32_t range = L.kmax - kmin;
+    const int bits = range ? 32 - __builtin_clz(range) : 0;
+    const int shift = bits > LOG_DIG ? bits - LOG_DIG : 0;
+    // 1. count
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = wave * 64 * R + r * 64 + lane;
+        if (i < n) atomicAdd(&hist[(key[r] - kmin) >> shift], 1u);
+    }
+    __syncthreads();
+    // 2. flat exclusive scan of the DIG counters (8 consecutive ones per thread) + the fullest bin
+    const uint4 h0 = reinterpret_cast<uint4*>(hist)[2 * threadIdx.x];
+    const uint4 h1 = reinterpret_cast<uint4*>(hist)[2 * threadIdx.x + 1];
+    const uint32_t fullest = max(max(max(h0.x, h0.y), max(h0.z, h0.w)), max(max(h1.x, h1.y), max(h1.z, h1.w)));
+    const uint32_t tot = h0.x + h0.y + h0.z + h0.w + h1.x + h1.y + h1.z + h1.w;
+    const uint32_t incl = wave_scan_incl(tot, 0u, [](uint32_t a, uint32_t b) { return a + b; });
+    if (lane == 63) L.wsum[wave] = incl;
+    if (__syncthreads_or(fullest > (uint32_t)kBinRankCap)) return false;     // (uniform; nothing written yet)
+    uint32_t e = incl - tot;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) e += (w < wave) ? L.wsum[w] : 0u;
+    uint4 e0, e1;
+    e0.x = e; e += h0.x; e0.y = e; e += h0.y; e0.z = e; e += h0.z; e0.w = e; e += h0.w;
+    e1.x = e; e += h1.x; e1.y = e; e += h1.y; e1.z = e; e += h1.z; e1.w = e;
+    reinterpret_cast<uint4*>(hist)[2 * threadIdx.x] = e0;
+    reinterpret_cast<uint4*>(hist)[2 * threadIdx.x + 1] = e1;
+    __syncthreads();
+    // 3. scatter: any order inside a bin (the cursors end up at the bins' ends)
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = wave * 64 * R + r * 64 + lane;
+        if (i < n) {
+            const uint32_t k = key[r] - kmin;
+            const uint32_t pos = atomicAdd(&hist[k >> shift], 1u);
+            L.xk[pos] = k;
+            L.xv[pos] = val[r];
+        }
+    }
+    __syncthreads();
+    // 4. rank inside the bin, write out
+#pragma unroll 1
+    for (int r = 0; r < R; r++) {
+        const int i = wave * 64 * R + r * 64 + lane;
+        if (i >= n) continue;
+        const uint32_t k = L.xk[i], v = L.xv[i];
+        const uint32_t d = k >> shift;
+        const int s0 = d ? (int)hist[d - 1] : 0, s1 = (int)hist[d];
+        int before = 0;
+        for (int j = s0; j < s1; j++) {
+            const uint32_t kj = L.xk[j], vj = L.xv[j];
+            before += (kj < k || (kj == k && vj < v)) ? 1 : 0;
+        }
+        payload[beg + s0 + before] = (int32_t)v;
+        flatten_ids[beg + s0 + before] = HAS_VALS ? isect_gid[v] : (int32_t)v;
+    }
+    return true;
+}
+
 // UNORDERED: the bucket arrives in arbitrary order (filled with atomic cursors, misplat_tile_scatter).  The
 // depth sort alone is then only deterministic when all depths differ, so after it neighbours are compared
 // and a bucket with ties (rare in a real scene) is re-sorted by row and then, stably, by depth again.
+// One bucket [beg, beg + n) of a register class (n <= 64 * WAVES * R), every thread of the workgroup calls it.
+// SHORT_PATH: buckets of at most two entries per thread are rank-sorted (the class that starts at one entry).
+template <int WAVES, int R, bool HAS_VALS, bool UNORDERED, bool SHORT_PATH>
+__device__ __forceinline__ void sort_bucket_regs(tile_sort_lds<WAVES, R>& L, int beg, int n, const float* __restrict__ depths,
+                                                 const int32_t* __restrict__ isect_gid, int32_t* __restrict__ payload,
+                                                 int32_t* __restrict__ flatten_ids) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (SHORT_PATH && n <= 128 * WAVES) {
+        // Short bucket (at most two entries per thread): rank = number of entries that sort before mine, counted
+        // against all n through LDS broadcasts -- n / 2 iterations of a few compares instead of 3 radix passes.
+        // Ties break by row (UNORDERED: the (depth, row) order) or by arrival (stable).
+        constexpr int T = 64 * WAVES;
+        uint32_t v[2], k[2], tb[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int i = threadIdx.x + q * T;
+            v[q] = 0u; k[q] = 0xffffffffu; tb[q] = 0xffffffffu;
+            if (i < n) {
+                v[q] = (uint32_t)payload[beg + i];
+                const int32_t rw = HAS_VALS ? isect_gid[v[q]] : (int32_t)v[q];
+                k[q] = __float_as_uint(depths[rw]);
+                tb[q] = UNORDERED ? (uint32_t)rw : (uint32_t)i;
+            }
+        }
+        uint2* pk = reinterpret_cast<uint2*>(L.xk);                 // (key, tie-break) pairs: 4 T <= CAP words (R >= 4)
+        __syncthreads();                                            // (the previous bucket's readers are done)
+        pk[threadIdx.x] = make_uint2(k[0], tb[0]);
+        pk[threadIdx.x + T] = make_uint2(k[1], tb[1]);
+        __syncthreads();
+        int rank0 = 0, rank1 = 0;
+        const uint4* pk2 = reinterpret_cast<const uint4*>(L.xk);
+        const int n2 = (n + 1) >> 1;                                // the pad entry (0xffffffff, 0xffffffff) never sorts before
+        const bool two = n > T;                                     // (uniform)
+        for (int j = 0; j < n2; j++) {
+            const uint4 p = pk2[j];
+            rank0 += (p.x < k[0] || (p.x == k[0] && p.y < tb[0])) ? 1 : 0;
+            rank0 += (p.z < k[0] || (p.z == k[0] && p.w < tb[0])) ? 1 : 0;
+            if (two) {
+                rank1 += (p.x < k[1] || (p.x == k[1] && p.y < tb[1])) ? 1 : 0;
+                rank1 += (p.z < k[1] || (p.z == k[1] && p.w < tb[1])) ? 1 : 0;
+            }
+        }
+        if ((int)threadIdx.x < n) {
+            payload[beg + rank0] = (int32_t)v[0];
+            flatten_ids[beg + rank0] = HAS_VALS ? isect_gid[v[0]] : (int32_t)v[0];
+        }
+        if ((int)threadIdx.x + T < n) {
+            payload[beg + rank1] = (int32_t)v[1];
+            flatten_ids[beg + rank1] = HAS_VALS ? isect_gid[v[1]] : (int32_t)v[1];
+        }
+        return;
+    }
+    uint32_t key[R], val[R];
+    int32_t row[R];
+    // all loads of one level are issued before the first use (index clamped instead of predicated)
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = wave * 64 * R + r * 64 + lane;
+        val[r] = (uint32_t)payload[beg + (i < n ? i : 0)];
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) row[r] = HAS_VALS ? isect_gid[val[r]] : (int32_t)val[r];
+#pragma unroll
+    for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[row[r]]);
+    // (Classes of up to 1 024 entries only.  Measured at 5 M Gaussians / 1080p, typical bucket 3 900 entries: the
+    // eight-wave class 556 us with bin + rank against 480 with three LSD passes -- 16 returning LDS atomics per thread on
+    // 4 096 random counters and the longer runs of a 12-bit binning cost more than the two passes they replace, and the
+    // extra live registers spill under the class's 80-register bound.)
+    if (MISPLAT_TS_BINRANK && (MISPLAT_TS_BINRANK_MASK & WAVES)) {
+        // (values ascend with the row in both modes -- rows, or emission slots handed out in row order -- so ranking by
+        // (depth, value) is the stable order of the ordered mode and the (depth, row) order of the unordered one)
+        if (tile_bin_rank<WAVES, R, HAS_VALS>(key, val, n, L, beg, isect_gid, payload, flatten_ids)) {
+            __syncthreads();                       // (the LDS image is reused by the next bucket of this workgroup)
+            return;
+        }
+        __syncthreads();
+    }
+    const int passes = tile_radix_regs<WAVES, R>(key, val, n, L);
+    unsigned placed = 0u;                          // bit r: entry r was written by the tie pass below
+    if (UNORDERED) {
+        // Equal depths: with 4 000 entries per bucket (5 M Gaussians at 1080p) a third of the buckets holds a pair of
+        // equal floats, and re-sorting the whole bucket twice for it tripled their cost.  A run of equal keys is
+        // short: every entry of one looks at its run (the sorted keys and values are still in LDS), takes the slot
+        // its row earns inside it and is written there; only a run longer than 8 falls back to the two extra sorts
+        // (which then rewrite everything).  Rolled loop over LDS, not over the register arrays: unrolled it cost
+        // 45 VGPRs and half the occupancy of the common path.
+        bool redo = false;
+        if (passes == 0) redo = n > 1;
+        else {
+#pragma unroll 1
+            for (int r = 0; r < R; r++) {
+                const int i = wave * 64 * R + r * 64 + lane;
+                if (i >= n) continue;
+                const uint32_t k = L.xk[i];
+                const bool tp = i > 0 && L.xk[i - 1] == k, tn = i + 1 < n && L.xk[i + 1] == k;
+                if (!(tp || tn)) continue;
+                int s = i, e = i;
+                while (s > 0 && i - s < 8 && L.xk[s - 1] == k) s--;
+                while (e + 1 < n && e - i < 8 && L.xk[e + 1] == k) e++;
+                if (i - s == 8 || e - i == 8) { redo = true; continue; }
+                const uint32_t v = L.xv[i];
+                const uint32_t mine = HAS_VALS ? (uint32_t)isect_gid[v] : v;
+                int before = 0;
+                for (int j = s; j <= e; j++) {
+                    if (j == i) continue;
+                    const uint32_t vj = L.xv[j];
+                    before += ((HAS_VALS ? (uint32_t)isect_gid[vj] : vj) < mine) ? 1 : 0;
+                }
+                payload[beg + s + before] = (int32_t)v;
+                flatten_ids[beg + s + before] = (int32_t)mine;
+                placed |= 1u << r;
+            }
+        }
+        if (__syncthreads_or(redo)) {
+#pragma unroll
+            for (int r = 0; r < R; r++) key[r] = HAS_VALS ? (uint32_t)isect_gid[val[r]] : val[r];
+            tile_radix_regs<WAVES, R>(key, val, n, L);            // by row
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[key[r]]);
+            tile_radix_regs<WAVES, R>(key, val, n, L);            // stably by depth
+            placed = 0u;
+        }
+    }
+    if (HAS_VALS) {
+#pragma unroll
+        for (int r = 0; r < R; r++) row[r] = isect_gid[val[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = wave * 64 * R + r * 64 + lane;
+        if (i < n && !((placed >> r) & 1u)) {
+            payload[beg + i] = (int32_t)val[r];
+            flatten_ids[beg + i] = HAS_VALS ? row[r] : (int32_t)val[r];
+        }
+    }
+    __syncthreads();
+}
+
 template <int WAVES, int R, bool HAS_VALS, bool UNORDERED>
-__global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? 6 : (WAVES == 1 ? 4 : 1)) void tile_sort_reg_kernel(const int32_t* __restrict__ offsets, int n_tiles,
+__global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? MISPLAT_TS_B_BLOCKS : (WAVES == 1 ? 4 : 1)) void tile_sort_reg_kernel(const int32_t* __restrict__ offsets, int n_tiles,
                                                                    int64_t n_isects, int lo, int hi,
                                                                    const float* __restrict__ depths,
                                                                    const int32_t* __restrict__ isect_gid,
                                                                    int32_t* __restrict__ payload,
                                                                    int32_t* __restrict__ flatten_ids, int has_longest) {
     __shared__ tile_sort_lds<WAVES, R> L;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int t_first, t_last, t_step;
     if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step, has_longest)) return;
     for (int t = t_first; t < t_last; t += t_step) {
@@ -300,123 +543,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? 6 : (WAVES == 
         const int beg = min(offsets[t], end);
         const int n = end - beg;
         if (n <= lo || n > hi) continue;               // uniform over the block (n >= 1 from here)
-        if (lo == 0 && n <= 128 * WAVES) {
-            // Short bucket (at most two entries per thread): rank = number of entries that sort before mine, counted
-            // against all n through LDS broadcasts -- n / 2 iterations of a few compares instead of 3 radix passes.
-            // Ties break by row (UNORDERED: the (depth, row) order) or by arrival (stable).
-            constexpr int T = 64 * WAVES;
-            uint32_t v[2], k[2], tb[2];
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                const int i = threadIdx.x + q * T;
-                v[q] = 0u; k[q] = 0xffffffffu; tb[q] = 0xffffffffu;
-                if (i < n) {
-                    v[q] = (uint32_t)payload[beg + i];
-                    const int32_t rw = HAS_VALS ? isect_gid[v[q]] : (int32_t)v[q];
-                    k[q] = __float_as_uint(depths[rw]);
-                    tb[q] = UNORDERED ? (uint32_t)rw : (uint32_t)i;
-                }
-            }
-            uint2* pk = reinterpret_cast<uint2*>(L.xk);                 // (key, tie-break) pairs: 4 T <= CAP words (R >= 4)
-            __syncthreads();                                            // (the previous bucket's readers are done)
-            pk[threadIdx.x] = make_uint2(k[0], tb[0]);
-            pk[threadIdx.x + T] = make_uint2(k[1], tb[1]);
-            __syncthreads();
-            int rank0 = 0, rank1 = 0;
-            const uint4* pk2 = reinterpret_cast<const uint4*>(L.xk);
-            const int n2 = (n + 1) >> 1;                                // the pad entry (0xffffffff, 0xffffffff) never sorts before
-            const bool two = n > T;                                     // (uniform)
-            for (int j = 0; j < n2; j++) {
-                const uint4 p = pk2[j];
-                rank0 += (p.x < k[0] || (p.x == k[0] && p.y < tb[0])) ? 1 : 0;
-                rank0 += (p.z < k[0] || (p.z == k[0] && p.w < tb[0])) ? 1 : 0;
-                if (two) {
-                    rank1 += (p.x < k[1] || (p.x == k[1] && p.y < tb[1])) ? 1 : 0;
-                    rank1 += (p.z < k[1] || (p.z == k[1] && p.w < tb[1])) ? 1 : 0;
-                }
-            }
-            if ((int)threadIdx.x < n) {
-                payload[beg + rank0] = (int32_t)v[0];
-                flatten_ids[beg + rank0] = HAS_VALS ? isect_gid[v[0]] : (int32_t)v[0];
-            }
-            if ((int)threadIdx.x + T < n) {
-                payload[beg + rank1] = (int32_t)v[1];
-                flatten_ids[beg + rank1] = HAS_VALS ? isect_gid[v[1]] : (int32_t)v[1];
-            }
-            continue;
-        }
-        uint32_t key[R], val[R];
-        int32_t row[R];
-        // all loads of one level are issued before the first use (index clamped instead of predicated)
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int i = wave * 64 * R + r * 64 + lane;
-            val[r] = (uint32_t)payload[beg + (i < n ? i : 0)];
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) row[r] = HAS_VALS ? isect_gid[val[r]] : (int32_t)val[r];
-#pragma unroll
-        for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[row[r]]);
-        const int passes = tile_radix_regs<WAVES, R>(key, val, n, L);
-        unsigned placed = 0u;                          // bit r: entry r was written by the tie pass below
-        if (UNORDERED) {
-            // Equal depths: with 4 000 entries per bucket (5 M Gaussians at 1080p) a third of the buckets holds a pair of
-            // equal floats, and re-sorting the whole bucket twice for it tripled their cost.  A run of equal keys is
-            // short: every entry of one looks at its run (the sorted keys and values are still in LDS), takes the slot
-            // its row earns inside it and is written there; only a run longer than 8 falls back to the two extra sorts
-            // (which then rewrite everything).  Rolled loop over LDS, not over the register arrays: unrolled it cost
-            // 45 VGPRs and half the occupancy of the common path.
-            bool redo = false;
-            if (passes == 0) redo = n > 1;
-            else {
-#pragma unroll 1
-                for (int r = 0; r < R; r++) {
-                    const int i = wave * 64 * R + r * 64 + lane;
-                    if (i >= n) continue;
-                    const uint32_t k = L.xk[i];
-                    const bool tp = i > 0 && L.xk[i - 1] == k, tn = i + 1 < n && L.xk[i + 1] == k;
-                    if (!(tp || tn)) continue;
-                    int s = i, e = i;
-                    while (s > 0 && i - s < 8 && L.xk[s - 1] == k) s--;
-                    while (e + 1 < n && e - i < 8 && L.xk[e + 1] == k) e++;
-                    if (i - s == 8 || e - i == 8) { redo = true; continue; }
-                    const uint32_t v = L.xv[i];
-                    const uint32_t mine = HAS_VALS ? (uint32_t)isect_gid[v] : v;
-                    int before = 0;
-                    for (int j = s; j <= e; j++) {
-                        if (j == i) continue;
-                        const uint32_t vj = L.xv[j];
-                        before += ((HAS_VALS ? (uint32_t)isect_gid[vj] : vj) < mine) ? 1 : 0;
-                    }
-                    payload[beg + s + before] = (int32_t)v;
-                    flatten_ids[beg + s + before] = (int32_t)mine;
-                    placed |= 1u << r;
-                }
-            }
-            if (__syncthreads_or(redo)) {
-#pragma unroll
-                for (int r = 0; r < R; r++) key[r] = HAS_VALS ? (uint32_t)isect_gid[val[r]] : val[r];
-                tile_radix_regs<WAVES, R>(key, val, n, L);            // by row
-                __syncthreads();
-#pragma unroll
-                for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[key[r]]);
-                tile_radix_regs<WAVES, R>(key, val, n, L);            // stably by depth
-                placed = 0u;
-            }
-        }
-        if (HAS_VALS) {
-#pragma unroll
-            for (int r = 0; r < R; r++) row[r] = isect_gid[val[r]];
-        }
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int i = wave * 64 * R + r * 64 + lane;
-            if (i < n && !((placed >> r) & 1u)) {
-                payload[beg + i] = (int32_t)val[r];
-                flatten_ids[beg + i] = HAS_VALS ? row[r] : (int32_t)val[r];
-            }
-        }
-        __syncthreads();
+        if (lo == 0) sort_bucket_regs<WAVES, R, HAS_VALS, UNORDERED, true>(L, beg, n, depths, isect_gid, payload, flatten_ids);
+        else sort_bucket_regs<WAVES, R, HAS_VALS, UNORDERED, false>(L, beg, n, depths, isect_gid, payload, flatten_ids);
     }
 }
 
@@ -424,21 +552,11 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? 6 : (WAVES == 
 // entries walked 64 at a time per wave, ping-pong buffers in global scratch (GLOBAL) or dynamic LDS.
 // UNORDERED: four passes over the row bits come first, so the result is the (depth, row) order whatever
 // the order of arrival.
+// One bucket [beg, beg + n) of any length, ping-pong buffers in global scratch (GLOBAL) or in lds32 behind the histograms.
 template <int CAP, int WAVES, bool HAS_VALS, bool GLOBAL, bool UNORDERED>
-__global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __restrict__ offsets, int n_tiles,
-                                                               int64_t n_isects, int lo, int hi,
-                                                               const float* __restrict__ depths,
-                                                               const int32_t* __restrict__ isect_gid,
-                                                               int32_t* payload, int32_t* flatten_ids,   // (aliased below)
-                                                               uint32_t* scratch, int has_longest) {
-    extern __shared__ uint32_t lds32[];
-    int t_first, t_last, t_step;
-    if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step, has_longest)) return;
-    for (int t = t_first; t < t_last; t += t_step) {
-    const int end = min(offsets[t + 1], (int)n_isects);
-    const int beg = min(offsets[t], end);
-    const int n = end - beg;
-    if (n <= lo || n > hi) continue;                 // another size class (uniform over the block)
+__device__ __forceinline__ void sort_bucket_passes(uint32_t* lds32, int beg, int n, const float* __restrict__ depths,
+                                                   const int32_t* __restrict__ isect_gid, int32_t* payload,
+                                                   int32_t* flatten_ids, uint32_t* scratch) {
     constexpr int THREADS = 64 * WAVES;
     // buffers: keys / values, ping and pong; hist[WAVES][256] always in LDS
     uint32_t* hist = lds32;
@@ -530,6 +648,58 @@ __global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __
         flatten_ids[beg + i] = HAS_VALS ? isect_gid[v] : v;
     }
     __syncthreads();
+}
+
+template <int CAP, int WAVES, bool HAS_VALS, bool GLOBAL, bool UNORDERED>
+__global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __restrict__ offsets, int n_tiles,
+                                                               int64_t n_isects, int lo, int hi,
+                                                               const float* __restrict__ depths,
+                                                               const int32_t* __restrict__ isect_gid,
+                                                               int32_t* payload, int32_t* flatten_ids,   // (aliased below)
+                                                               uint32_t* scratch, int has_longest) {
+    extern __shared__ uint32_t lds32[];
+    int t_first, t_last, t_step;
+    if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step, has_longest)) return;
+    for (int t = t_first; t < t_last; t += t_step) {
+        const int end = min(offsets[t + 1], (int)n_isects);
+        const int beg = min(offsets[t], end);
+        const int n = end - beg;
+        if (n <= lo || n > hi) continue;                 // another size class (uniform over the block)
+        sort_bucket_passes<CAP, WAVES, HAS_VALS, GLOBAL, UNORDERED>(lds32, beg, n, depths, isect_gid, payload, flatten_ids, scratch);
+    }
+}
+
+// Every size class that has no grid of its own in this launch plan, in ONE launch of 1 024-thread workgroups: a
+// workgroup tests its contiguous chunk of tiles in parallel, leaves if none of them is its business, and otherwise sorts
+// the buckets of the uncovered classes one after the other -- up to 8 192 entries in registers (16 waves x 8 per lane,
+// whatever the bucket's own class), longer ones through global scratch.  `covered`: bit c set = class c (<= 1 024,
+// <= 4 096, <= 8 192 entries) is sorted by a launch of its own.  Replaces three near-empty launches of ~5 us each.
+__device__ __forceinline__ int size_class(int n) { return n <= 1024 ? 0 : (n <= 4096 ? 1 : (n <= 8192 ? 2 : 3)); }
+template <bool HAS_VALS, bool UNORDERED>
+__global__ __launch_bounds__(1024) void tile_sort_rest_kernel(const int32_t* __restrict__ offsets, int n_tiles, int64_t n_isects,
+                                                              int covered, const float* __restrict__ depths,
+                                                              const int32_t* __restrict__ isect_gid, int32_t* payload,
+                                                              int32_t* flatten_ids, uint32_t* scratch) {
+    __shared__ tile_sort_lds<16, 8> L;
+    __shared__ uint32_t hist_passes[16 * 256];
+    const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
+    const int t_first = blockIdx.x * per, t_last = min(t_first + per, n_tiles);
+    bool mine = false;
+    for (int t = t_first + threadIdx.x; t < t_last; t += blockDim.x) {
+        const int e1 = min(offsets[t + 1], (int)n_isects);
+        const int n = e1 - min(offsets[t], e1);
+        mine |= n > 0 && !((covered >> size_class(n)) & 1);
+    }
+    if (!__syncthreads_or(mine)) return;
+    for (int t = t_first; t < t_last; t++) {
+        const int end = min(offsets[t + 1], (int)n_isects);
+        const int beg = min(offsets[t], end);
+        const int n = end - beg;
+        if (n <= 0) continue;
+        const int cls = size_class(n);
+        if ((covered >> cls) & 1) continue;              // (uniform over the block)
+        if (cls < 3) sort_bucket_regs<16, 8, HAS_VALS, UNORDERED, false>(L, beg, n, depths, isect_gid, payload, flatten_ids);
+        else sort_bucket_passes<0, 16, HAS_VALS, true, UNORDERED>(hist_passes, beg, n, depths, isect_gid, payload, flatten_ids, scratch);
     }
 }
 
@@ -777,25 +947,37 @@ static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_i
     // all tiles and skips buckets of the other classes.  A class that the typical bucket (n_isects / n_tiles)
     // can reach gets one workgroup per tile; the others get a small grid whose workgroups test their chunk of
     // tiles in parallel first (tile_range), so an unused class costs a few microseconds.
-    const int64_t avg = n_isects / n_tiles;
+    // (n_isects may be the CAPACITY of a speculative launch, about 1.25 x the real count: 4 / 5 of it is the estimate)
+    const int64_t avg = n_isects / n_tiles * 4 / 5;
     const int full = n_tiles < 65536 ? n_tiles : 65536;
     const int few = n_tiles < 256 ? n_tiles : 256;
+    // A class the typical bucket (n_isects / n_tiles) can reach gets a grid of its own, one workgroup per tile; every other
+    // class goes through ONE more launch (tile_sort_rest_kernel): a 1 M scene is two launches (was four), a 5 M one three.
+    int covered = 0;
     // <= 1024 entries.  Sparse scenes (typical bucket under 256 entries: 100 k Gaussians at 1080p): ONE wavefront per
     // bucket, 16 entries per lane, no barrier ever waits for another wave (0.496 -> 0.471 ms per step there); dense ones:
     // two waves, 8 entries per lane (measured at 1 M, typical bucket 800: one wave x 16 +12 us, four waves x 4 +5 us).
-    if (avg < 256)
-        hipLaunchKernelGGL((tile_sort_reg_kernel<1, 16, HAS_VALS, UNORDERED>), dim3(full), dim3(64), 0, s, offsets, n_tiles,
-                           n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
-    else
-        hipLaunchKernelGGL((tile_sort_reg_kernel<2, 8, HAS_VALS, UNORDERED>), dim3(full), dim3(128), 0, s, offsets, n_tiles,
-                           n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
-    hipLaunchKernelGGL((tile_sort_reg_kernel<8, 8, HAS_VALS, UNORDERED>), dim3(avg >= 1024 ? full : few), dim3(512), 0, s,
-                       offsets, n_tiles, n_isects, 1024, 4096, depths, isect_gid, payload, flatten_ids, has_longest);
-    hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS, UNORDERED>), dim3(avg >= 2048 ? full : few), dim3(1024), 0,
-                       s, offsets, n_tiles, n_isects, 4096, 8192, depths, isect_gid, payload, flatten_ids, has_longest);
-    hipLaunchKernelGGL((tile_sort_kernel<0, 16, HAS_VALS, true, UNORDERED>), dim3(avg >= 4096 ? full : (few < 64 ? few : 64)),
-                       dim3(1024), (size_t)16 * 256 * 4, s, offsets, n_tiles, n_isects, 8192, 0x7fffffff, depths,
-                       isect_gid, payload, flatten_ids, scratch, has_longest);
+    if (avg < 2048) {
+        covered |= 1;
+        if (avg < 256)
+            hipLaunchKernelGGL((tile_sort_reg_kernel<1, 16, HAS_VALS, UNORDERED>), dim3(full), dim3(64), 0, s, offsets, n_tiles,
+                               n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
+        else
+            hipLaunchKernelGGL((tile_sort_reg_kernel<2, 8, HAS_VALS, UNORDERED>), dim3(full), dim3(128), 0, s, offsets, n_tiles,
+                               n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
+    }
+    if (avg >= 1024) {
+        covered |= 2;
+        hipLaunchKernelGGL((tile_sort_reg_kernel<8, 8, HAS_VALS, UNORDERED>), dim3(full), dim3(512), 0, s, offsets, n_tiles,
+                           n_isects, 1024, 4096, depths, isect_gid, payload, flatten_ids, has_longest);
+    }
+    if (avg >= 2048) {
+        covered |= 4;
+        hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS, UNORDERED>), dim3(full), dim3(1024), 0, s, offsets, n_tiles,
+                           n_isects, 4096, 8192, depths, isect_gid, payload, flatten_ids, has_longest);
+    }
+    hipLaunchKernelGGL((tile_sort_rest_kernel<HAS_VALS, UNORDERED>), dim3(few), dim3(1024), 0, s, offsets, n_tiles, n_isects,
+                       covered, depths, isect_gid, payload, flatten_ids, scratch);
     return check_launch();
 }
 

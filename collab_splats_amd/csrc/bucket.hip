@@ -144,46 +144,47 @@ __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(
     }
 }
 
-// ---- 2a. one workgroup: cell_offs = exclusive scan of the cell counts (the counts are cleared: they become the
-// cursors of 2b); counters[1] = visible rows; the tile counters are cleared for pass 3 ------------------------
-__global__ __launch_bounds__(1024) void bucket_cell_scan_kernel(int n_cells, uint32_t* __restrict__ cell_count,
-                                                                uint32_t* __restrict__ cell_offs,
-                                                                int64_t* __restrict__ counters,
-                                                                int32_t* __restrict__ tile_count, int n_tiles1) {
-    __shared__ uint32_t wsum[16];
-    for (int i = threadIdx.x; i < n_tiles1; i += 1024) tile_count[i] = 0;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // thread t owns cells 2t, 2t+1 (n_cells <= 2048)
-    const int c0 = 2 * threadIdx.x, c1 = c0 + 1;
-    const uint32_t a = c0 < n_cells ? cell_count[c0] : 0u, b2 = c1 < n_cells ? cell_count[c1] : 0u;
-    if (c0 < n_cells) cell_count[c0] = 0u;
-    if (c1 < n_cells) cell_count[c1] = 0u;
-    const uint32_t incl = wave_scan_add(a + b2);
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t carry = 0u, all = 0u;
-#pragma unroll
-    for (int w = 0; w < 16; w++) { carry += (w < wave) ? wsum[w] : 0u; all += wsum[w]; }
-    const uint32_t e = carry + incl - (a + b2);
-    if (c0 < n_cells) cell_offs[c0] = e;
-    if (c1 < n_cells) cell_offs[c1] = e + a;
-    if (threadIdx.x == 0) {
-        cell_offs[n_cells] = all;
-        counters[1] = (int64_t)all;
-    }
-}
-
-// ---- 2b. visible rows -> cell order (the slices of pass 1 again): every workgroup reserves its range of each cell
-// with one returning atomic, positions inside the range come from an LDS cursor ---------------------------------
+// ---- 2. visible rows -> cell order (the slices of pass 1 again).  Every workgroup scans the (at most 2 048) global cell
+// counts itself -- two per thread, a few hundred instructions, instead of a one-workgroup launch in front of this kernel --,
+// reserves its range of each cell with one returning atomic on a cursor array and takes positions inside the range from an
+// LDS cursor.  Workgroup 0 also publishes what the host and the later kernels need: cell_offs, counters[1] = visible
+// rows, and the intersection count as a system-scope store into the caller's pinned slot (no copy node in the stream).
 __global__ __launch_bounds__(kCountThreads) void bucket_rows_kernel(
     int64_t total, int n_gauss, int shift, int cells_x, int cells_per_cam, int n_cells, int rows_per_block,
     const int32_t* __restrict__ tiles_per_gauss, const uint2* __restrict__ rect2, const uint32_t* __restrict__ cellhist,
-    const uint32_t* __restrict__ cell_offs, uint32_t* __restrict__ cell_cursor, int32_t* __restrict__ order,
-    uint2* __restrict__ rect_sorted) {
+    const uint32_t* __restrict__ cell_count, uint32_t* __restrict__ cell_offs, uint32_t* __restrict__ cell_cursor,
+    int32_t* __restrict__ order, uint2* __restrict__ rect_sorted, int64_t* __restrict__ counters,
+    long long* __restrict__ n_isects_host) {
     __shared__ uint32_t base[MISPLAT_BUCKET_MAX_CELLS];
+    __shared__ uint32_t wsum[kCountThreads / 64];
+    static_assert(2 * kCountThreads >= MISPLAT_BUCKET_MAX_CELLS, "two cells per thread");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        const int c0 = 2 * threadIdx.x, c1 = c0 + 1;
+        const uint32_t a = c0 < n_cells ? cell_count[c0] : 0u, b2 = c1 < n_cells ? cell_count[c1] : 0u;
+        const uint32_t incl = wave_scan_add(a + b2);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t carry = 0u, all = 0u;
+#pragma unroll
+        for (int w = 0; w < kCountThreads / 64; w++) { carry += (w < wave) ? wsum[w] : 0u; all += wsum[w]; }
+        const uint32_t e = carry + incl - (a + b2);
+        if (c0 < n_cells) base[c0] = e;
+        if (c1 < n_cells) base[c1] = e + a;
+        if (blockIdx.x == 0) {
+            if (c0 < n_cells) cell_offs[c0] = e;
+            if (c1 < n_cells) cell_offs[c1] = e + a;
+            if (threadIdx.x == 0) {
+                cell_offs[n_cells] = all;
+                counters[1] = (int64_t)all;
+                if (n_isects_host) __hip_atomic_store(n_isects_host, (long long)counters[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __syncthreads();
+    }
     for (int c = threadIdx.x; c < n_cells; c += kCountThreads) {
         const uint32_t h = cellhist[(size_t)blockIdx.x * n_cells + c];
-        base[c] = h ? cell_offs[c] + atomicAdd(&cell_cursor[c], h) : 0u;
+        base[c] = h ? base[c] + atomicAdd(&cell_cursor[c], h) : 0u;
     }
     __syncthreads();
     const int64_t beg = (int64_t)blockIdx.x * rows_per_block;
@@ -196,6 +197,16 @@ __global__ __launch_bounds__(kCountThreads) void bucket_rows_kernel(
             order[pos] = (int32_t)idx;
             rect_sorted[pos] = r2;                               // the tile passes read rectangles without a gather
         }
+    }
+}
+
+// (no visible row at all, or no Gaussian: the publishing part of bucket_rows_kernel alone)
+__global__ void bucket_rows_empty_kernel(int n_cells, uint32_t* __restrict__ cell_offs, int64_t* __restrict__ counters,
+                                         long long* __restrict__ n_isects_host) {
+    for (int c = threadIdx.x; c <= n_cells; c += blockDim.x) cell_offs[c] = 0u;
+    if (threadIdx.x == 0) {
+        counters[1] = 0;
+        if (n_isects_host) __hip_atomic_store(n_isects_host, (long long)counters[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -519,10 +530,12 @@ extern "C" int misplat_bucket_count(const misplat_params* p, const float* means2
 }
 
 extern "C" int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles_per_gauss, const uint32_t* rect2,
-                                   const uint32_t* cellhist, uint32_t* cell_count, uint32_t* cell_offs, int32_t* order,
-                                   uint32_t* rect_sorted, int64_t* counters, int32_t* tile_count, misplat_stream_t stream) {
+                                   const uint32_t* cellhist, const uint32_t* cell_count, uint32_t* cell_cursor,
+                                   uint32_t* cell_offs, int32_t* order, uint32_t* rect_sorted, int64_t* counters,
+                                   int32_t* tile_count, int64_t* n_isects_host, int32_t already_zero,
+                                   misplat_stream_t stream) {
     int32_t nc, nb;
-    if (misplat_bucket_plan(p, &nc, &nb) != MISPLAT_OK || !cell_count || !cell_offs || !counters || !tile_count)
+    if (misplat_bucket_plan(p, &nc, &nb) != MISPLAT_OK || !cell_count || !cell_cursor || !cell_offs || !counters || !tile_count)
         return MISPLAT_EINVAL;
     const CellGrid g = make_grid(p);
     const int64_t total = (int64_t)p->n_gauss * p->n_cams;
@@ -530,12 +543,19 @@ extern "C" int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles
     const int64_t n_tiles = (int64_t)p->tile_w * p->tile_h * p->n_cams;
     if (n_tiles + 1 > 0x7fffffffLL) return MISPLAT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bucket_cell_scan_kernel, dim3(1), dim3(1024), 0, s, g.n_cells, cell_count, cell_offs, counters,
-                       tile_count, (int)(n_tiles + 1));
+    // the cell cursors and the tile counters of pass 3 start from zero (already_zero: an earlier kernel cleared them)
+    if (!(already_zero & 1) && misplat_internal::fill_bytes(cell_cursor, sizeof(uint32_t) * (size_t)g.n_cells, 0u, s) != MISPLAT_OK)
+        return MISPLAT_ELAUNCH;
+    if (!(already_zero & 2) && misplat_internal::fill_bytes(tile_count, sizeof(int32_t) * (size_t)(n_tiles + 1), 0u, s) != MISPLAT_OK)
+        return MISPLAT_ELAUNCH;
     if (total > 0)
         hipLaunchKernelGGL(bucket_rows_kernel, dim3(g.n_blocks), dim3(kCountThreads), 0, s, total, p->n_gauss, g.shift,
                            g.cells_x, g.cells_x * g.cells_y, g.n_cells, g.rows_per_block, tiles_per_gauss,
-                           (const uint2*)rect2, cellhist, cell_offs, cell_count, order, (uint2*)rect_sorted);
+                           (const uint2*)rect2, cellhist, cell_count, cell_offs, cell_cursor, order, (uint2*)rect_sorted, counters,
+                           (long long*)n_isects_host);
+    else
+        hipLaunchKernelGGL(bucket_rows_empty_kernel, dim3(1), dim3(256), 0, s, g.n_cells, cell_offs, counters,
+                           (long long*)n_isects_host);
     return check_launch();
 }
 

@@ -532,8 +532,9 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
     float4* __restrict__ grec, uint32_t* __restrict__ zero_words, int n_zero, float4* __restrict__ lazy_rows,
     float2* __restrict__ abs_rows) {
     // scratch the NEXT kernels of the stream accumulate into (bucketing counters): cleared here, no memset launch
-    if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < n_zero; i += blockDim.x) zero_words[i] = 0u;
+    // (a few thousand words -- cell counts, cursors, tile counts: spread over the first workgroups of the grid)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * blockDim.x)
+        zero_words[i] = 0u;
     const int64_t total = (int64_t)P.n_cams * P.n_gauss;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + blockDim.x - 1 - (total + blockDim.x - 1) % blockDim.x;
          idx += (int64_t)gridDim.x * blockDim.x) {

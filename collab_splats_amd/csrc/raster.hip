@@ -47,10 +47,16 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
     // the same call it is deferred to B's parallel branch.
     const bool colour_in_b = (phases & 2) && a->colour_pending != 0 && !a->lazy_colour;
     if (phases & 1) {
-        // the projection kernel also clears the cell counts and the two counters (contiguous: cell_count ... counters),
-        // so phase A contains no memset at all
-        const int64_t n_zero = ((const uint32_t*)a->counters + 4) - a->cell_count;
-        if (!a->cell_count || !a->counters || n_zero < 4 || n_zero > (1 << 20)) return MISPLAT_EINVAL;
+        // the projection kernel also clears everything the bucketing accumulates into -- cell counts, cell cursors, the
+        // two counters, the tile counters: ONE contiguous range (cell_count ... tile_count) --, so phase A contains no
+        // memset and no clearing kernel at all
+        const int64_t n_tiles1 = (int64_t)p->tile_w * p->tile_h * p->n_cams + 1;
+        if (!a->cell_count || !a->cell_cursor || !a->counters || !a->tile_count) return MISPLAT_EINVAL;
+        const uint32_t* zend = (const uint32_t*)a->tile_count + n_tiles1;
+        const int64_t n_zero = zend - a->cell_count;
+        if (!(a->cell_count < a->cell_cursor && a->cell_cursor < (const uint32_t*)a->counters &&
+              (const uint32_t*)a->counters + 4 <= (const uint32_t*)a->tile_count) || n_zero < 4 || n_zero > (1 << 22))
+            return MISPLAT_EINVAL;
         rc = misplat_project_pack_fwd(p, a->means, a->quats, a->scales, a->opacities, a->viewmats, a->Ks, a->radii,
                                       a->means2d, a->depths, a->compensations, a->grec, a->cell_count, (int32_t)n_zero,
                                       a->lazy_colour ? a->v_grec_zero : nullptr, a->v_abs_zero, stream);
@@ -58,11 +64,9 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         rc = misplat_bucket_count(p, a->means2d, a->radii, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count,
                                   a->counters, 1, stream);
         if (rc != MISPLAT_OK) return rc;
-        if (a->n_isects_host &&
-            hipMemcpyAsync(a->n_isects_host, a->counters, sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess)
-            return MISPLAT_ELAUNCH;
-        rc = misplat_bucket_rows(p, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count, a->cell_offs, a->order,
-                                 a->rect_sorted, a->counters, a->tile_count, stream);
+        // (the intersection count reaches the caller's pinned slot as a store from bucket_rows: no copy node)
+        rc = misplat_bucket_rows(p, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count, a->cell_cursor, a->cell_offs,
+                                 a->order, a->rect_sorted, a->counters, a->tile_count, a->n_isects_host, 3, stream);
         if (rc != MISPLAT_OK) return rc;
         if (!a->colour_pending && !a->lazy_colour) {
             rc = enqueue_colour(p, a, stream);

@@ -357,16 +357,16 @@ def start_binning(P: Params, means2d: Tensor, radii: Tensor) -> Dict[str, Tensor
     n_tiles = P.tile_w * P.tile_h * P.n_cams
     if ORDERING == "cells":
         n_cells, n_blocks = bucket_plan(P)
-        tiles_per_gauss, rect2, cellhist, cell_count, cell_offs, order, rect_sorted, counters, tile_count = _carve(
-            dev, (total, 2 * total, n_blocks * n_cells, n_cells, n_cells + 1, total, 2 * total, 4, n_tiles + 1))
+        tiles_per_gauss, rect2, cellhist, cell_count, cell_cursor, cell_offs, order, rect_sorted, counters, tile_count = _carve(
+            dev, (total, 2 * total, n_blocks * n_cells, n_cells, n_cells, n_cells + 1, total, 2 * total, 4, n_tiles + 1))
         counters = counters.view(torch.int64)
         check(lib.misplat_bucket_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(rect2),
                                        ptr(cellhist), ptr(cell_count), ptr(counters), C.c_int32(0), stream_ptr()),
               "misplat_bucket_count")
         pend = _read_back(counters[0:1])
         check(lib.misplat_bucket_rows(C.byref(P), ptr(tiles_per_gauss), ptr(rect2), ptr(cellhist), ptr(cell_count),
-                                      ptr(cell_offs), ptr(order), ptr(rect_sorted), ptr(counters), ptr(tile_count),
-                                      stream_ptr()), "misplat_bucket_rows")
+                                      ptr(cell_cursor), ptr(cell_offs), ptr(order), ptr(rect_sorted), ptr(counters),
+                                      ptr(tile_count), ptr(None), C.c_int32(0), stream_ptr()), "misplat_bucket_rows")
         pend.update(tiles_per_gauss=tiles_per_gauss, rect2=rect_sorted, order=order, counters=counters, tile_count=tile_count)
         return pend
     if ORDERING != "pertile":
@@ -738,9 +738,11 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     means2d, depths, comps, grec, sh_aux = _carve_f(dev, (2 * rows, rows, rows, MISPLAT_REC * rows, 12 * rows if want_aux else 0))
     v_grec_zero = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32) if want_grad else None
     v_abs_zero = torch.empty(rows, 2, device=dev, dtype=torch.float32) if (want_grad and absgrad) else None
-    # (counters directly behind cell_count: the projection kernel clears that contiguous range, no memset launch)
-    radii, tiles_per_gauss, rect2, cellhist, cell_count, counters, cell_offs, order, rect_sorted, tile_count, touched = _carve(
-        dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, 4, n_cells + 1, rows, 2 * rows, n_tiles + 1,
+    # (cell_count, cell_cursor, counters, tile_count back to back: the projection kernel clears that contiguous range -- no
+    # memset, no clearing launch)
+    (radii, tiles_per_gauss, rect2, cellhist, cell_count, cell_cursor, counters, tile_count, cell_offs, order, rect_sorted,
+     touched) = _carve(
+        dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, n_cells, 4, n_tiles + 1, n_cells + 1, rows, 2 * rows,
               (rows + 3) // 4 if want_grad else 0))
     # one byte per row: cleared by the projection kernel, set by the compositing backward, read by the per-Gaussian
     # backward kernels (misplat_params.touched).  Only where the compositing backward is the ONLY source of the packed
@@ -759,6 +761,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     a.v_abs_zero = _dp(v_abs_zero)
     a.tiles_per_gauss, a.rect2, a.cellhist, a.cell_count = _dp(tiles_per_gauss), _dp(rect2), _dp(cellhist), _dp(cell_count)
     a.cell_offs, a.order, a.counters, a.tile_count = _dp(cell_offs), _dp(order), _dp(counters), _dp(tile_count)
+    a.cell_cursor = _dp(cell_cursor)
     a.rect_sorted = _dp(rect_sorted)
     a.n_isects_host = host.data_ptr()
     # the colour kernel moves into phase B's parallel graph branch -- worth it only for large scenes (a two-branch
@@ -771,7 +774,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero, v_abs_zero=v_abs_zero,
                  deferred=defer,
                  counters=counters, touched=touched,
-                 keep=(rect2, cellhist, cell_count, cell_offs, order, counters, tile_count, radii))
+                 keep=(rect2, cellhist, cell_count, cell_offs, order, counters, tile_count, radii, cell_cursor))
     return (radii.view(Cn, N, 2), means2d.view(Cn, N, 2), depths.view(Cn, N), comps.view(Cn, N), grec.view(rows, MISPLAT_REC),
             sh_aux.view(rows, 12) if want_aux else None, state)
 

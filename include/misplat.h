@@ -238,7 +238,10 @@ int misplat_tile_offsets16(const uint16_t* tiles_sorted, int64_t n_isects, int32
  *                 (device int64; cell_count and counters[2] are zeroed here on `stream` unless already_zero);
  *   bucket_rows   cell_offs = scan of the cell counts, counters[1] = visible rows, order[0 .. n_vis) = the visible
  *                 rows in cell order and rect_sorted[0 .. n_vis) their rectangles (layout of rect2, capacity C*N);
- *                 tile_count[n_tiles + 1] is cleared;
+ *                 cell_cursor[n_cells] (scratch) and tile_count[n_tiles + 1] must be zero on entry: cleared here unless
+ *                 already_zero says an earlier kernel of the stream did (bit 0: cell_cursor, bit 1: tile_count);
+ *                 n_isects_host (or NULL): 8 bytes of PINNED, device-mapped host memory that receives counters[0] as a
+ *                 system-scope store from the kernel -- the caller polls it (misplat_wait_count), no copy is enqueued;
  *   bucket_tiles  (tile_count must be all zero on entry, as bucket_rows leaves it; it is NOT zero afterwards)
  *                 offsets[0 .. n_tiles + 1] (offsets[n_tiles] = number of intersections, offsets[n_tiles + 1] = the
  *                 longest bucket: n_tiles + 2 entries) and
@@ -256,8 +259,9 @@ int misplat_bucket_count(const misplat_params* p, const float* means2d, const in
                          earlier kernel of the stream (misplat_project_pack_fwd's zero_words): no memset here */,
                          misplat_stream_t stream);
 int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles_per_gauss, const uint32_t* rect2,
-                        const uint32_t* cellhist, uint32_t* cell_count, uint32_t* cell_offs, int32_t* order,
-                        uint32_t* rect_sorted, int64_t* counters, int32_t* tile_count, misplat_stream_t stream);
+                        const uint32_t* cellhist, const uint32_t* cell_count, uint32_t* cell_cursor, uint32_t* cell_offs,
+                        int32_t* order, uint32_t* rect_sorted, int64_t* counters, int32_t* tile_count,
+                        int64_t* n_isects_host /* or NULL */, int32_t already_zero, misplat_stream_t stream);
 int misplat_bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect_sorted,
                          const int64_t* counters, int32_t* tile_count, int32_t* offsets, const int64_t* cum,
                          int64_t cap_isects, int32_t* payload, int32_t* isect_gid, misplat_stream_t stream);
@@ -426,7 +430,7 @@ int misplat_loss_bwd(int64_t n_pix, const float* rgb, const float* gt, const flo
 /* ---- the whole forward of rasterization() (rade_gs_model.py:439-465) as ONE host entry: csrc/raster.hip.
  * Every pointer is a caller-allocated device buffer of the size the per-stage entry points above document
  * (n_isects_host: 8 bytes of PINNED host memory).
- *   phases & 1 (A): project_pack_fwd, bucket_count, copy counters[0] -> *n_isects_host, bucket_rows, color_fwd
+ *   phases & 1 (A): project_pack_fwd, bucket_count, bucket_rows (which stores counters[0] into *n_isects_host), color_fwd
  *   phases & 2 (B): [color_fwd, if colour_pending] || bucket_tiles, tile_sort (unordered); blend_fwd (+ unit_work), unit_order
  * B only reads device-side sizes, so it may be enqueued with a speculative cap_isects before the host knows the count:
  * the result is exact iff the count (misplat_wait_count) is <= cap_isects (else: clear tile_count and call B again
@@ -450,6 +454,8 @@ typedef struct misplat_raster_args {
     /* bucketing workspace + results */
     int32_t* tiles_per_gauss;
     uint32_t *rect2, *cellhist, *cell_count, *cell_offs;
+    uint32_t* cell_cursor;  /* n_cells words of scratch; cell_count, cell_cursor, counters (4 words) and tile_count must be
+                               slices of ONE allocation in this order: the projection kernel clears the whole range */
     int32_t* order;
     uint32_t* rect_sorted;
     int64_t* counters;
