@@ -188,7 +188,10 @@ __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; 
 // channels 4.. in featx[row][NXQ] (float4s, zero padded); n_channels = D' is the render width.
 template <int CD, int PPL, int NXQ = 0, bool LAZY = false>
 #ifndef MISPLAT_FWD_WAVES
-#define MISPLAT_FWD_WAVES 0            /* 0: let the compiler choose (80 VGPRs -> 6 waves/SIMD for PPL 2) */
+#define MISPLAT_FWD_WAVES 6            /* waves per SIMD the PPL-2 forward is compiled for: 80 VGPRs.  The plain kernel needs
+                                          no more anyway; the on-demand-colour variant (98 unbounded) then spills 7 registers
+                                          around the per-BATCH staging / evaluation, none in the trip loop: measured
+                                          0.222 -> 0.212 ms (fixed view), 0.370 -> 0.362 (cycling views) at 1 M / 1080p */
 #endif
 __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0) ? MISPLAT_FWD_WAVES : 1) void blend_fwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* grec,

@@ -42,3 +42,28 @@ for v in list(range(8)) + list(range(8)):
           f"mean {work.mean():.0f} p50 {q[0]:.0f} p90 {q[1]:.0f} p99 {q[2]:.0f} max {work.max():.0f}; "
           f"pixels with alpha < 0.9999: {alive:.3f}; fwd {fwd:.3f} ms bwd {bwd:.3f} ms; "
           f"fwd ns per staged entry {fwd*1e6/work.sum():.2f}", flush=True)
+
+# ---- what predicts a unit's work before the forward runs?  (rank correlation with the same step's bucket length, with the
+# previous view's work, and with the same view's work one step earlier)
+import numpy as np
+
+
+def spearman(a, b):
+    ra, rb = np.argsort(np.argsort(a)), np.argsort(np.argsort(b))
+    return float(np.corrcoef(ra, rb)[0, 1])
+
+
+prev = None
+for v in list(range(8)):
+    V = view_matrix(v).to(dev)
+    out = rasterization(params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"], V, Ks, W, H,
+                        sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True,
+                        scales_are_log=True, opacities_are_logit=True)
+    torch.cuda.synchronize()
+    work = out[0].grad_fn.sched.work.cpu().numpy().astype(np.float64)
+    meta = out[5]
+    cnt = torch.diff(torch.cat([meta["isect_offsets"].reshape(-1), torch.tensor([meta["n_isects"]], device=dev, dtype=torch.int32)])).cpu().numpy()
+    blen = np.repeat(cnt, 2).astype(np.float64)                      # two bands per tile
+    print(f"view {v}: spearman(work, bucket length) {spearman(work, blen):.3f}"
+          + (f", spearman(work, previous view's work) {spearman(work, prev):.3f}" if prev is not None else ""), flush=True)
+    prev = work
