@@ -325,7 +325,8 @@ def main():
             functools.reduce(torch.add, loss.values()).backward()      # (nerfstudio's trainer sums the dictionary this way)
             if bucket is not None:
                 info["allreduce_ms"].append(bucket.allreduce())
-            info["n_isects"], info["n_visible"], info["meta"] = model.info["n_isects"], model.info["radii"], model.info
+            info["n_isects"], info["n_visible"] = model.info["n_isects"], model.info["radii"]
+            info["meta"] = {"last_ids": model.info["last_ids"], "isect_offsets": model.info["isect_offsets"]}
             info["isects"].append(int(model.info["n_isects"]))
             info["it"] += 1
     else:
@@ -345,8 +346,13 @@ def main():
             torch.autograd.backward(list(out[:5]), ups)
             if bucket is not None:
                 info["allreduce_ms"].append(bucket.allreduce())
-            info["n_isects"], info["n_visible"], info["meta"] = out[5]["n_isects"], out[5]["radii"], out[5]
-            info["isects"].append(int(out[5]["n_isects"]))
+            # (only plain tensors are kept between steps: a reference to `out` / its meta would keep this step's autograd
+            # graph alive, which a whole-step capture -- --graphed -- cannot tolerate)
+            m = out[5]
+            info["n_isects"], info["n_visible"] = m["n_isects"], m["radii"]
+            info["meta"] = {"last_ids": m["last_ids"], "isect_offsets": m["isect_offsets"]}
+            if not torch.is_tensor(m["n_isects"]):
+                info["isects"].append(int(m["n_isects"]))
             info["it"] += 1
 
     def fence():

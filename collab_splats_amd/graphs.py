@@ -58,22 +58,39 @@ class GraphedStep:
                                         "MISPLAT_ORDERING=cells, atomic gradient mode)")
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(side), ops.static_capacity(self.capacity):
-            for _ in range(max(warmup, 1)):                   # allocator warm-up, launch-order feedback, lazy initialisation
-                res = fn()
-                bad = _tensors_with_history(res)
-                del res
-                if bad:
-                    # An autograd graph kept alive across calls makes PyTorch run its AccumulateGrad nodes on the stream of
-                    # the PREVIOUS call: inside a capture that is a cross-stream dependency and the process dies in
-                    # capture_end (observed: SIGSEGV).  Refuse before any capture has begun.
-                    torch.cuda.current_stream(self.device).wait_stream(side)
-                    raise ops._lib.MisplatError(
-                        "GraphedStep: fn() returned tensor(s) with autograd history (" + ", ".join(bad[:4])
-                        + ("..." if len(bad) > 4 else "") + "): return detached tensors (t.detach()) or nothing -- "
-                        "a graph of the previous iteration that is still alive cannot be captured")
+        # An autograd graph kept alive across calls (returned by fn, or stashed anywhere else: a dict of "last outputs", a
+        # meta object) makes PyTorch run the parameters' AccumulateGrad nodes on the stream of the call that created
+        # them: inside a capture that is a cross-stream dependency and the process dies in capture_end (observed:
+        # SIGSEGV).  Both forms are refused here, during the warm-up, before any capture has begun: what fn returns is
+        # inspected, and PyTorch's own stream-mismatch warning (made to fire every time for the duration) is an error.
+        import warnings
+        stale = []
+        warn_always = torch.is_warn_always_enabled()
+        torch.set_warn_always(True)
+        try:
+            with warnings.catch_warnings(record=True) as caught, torch.cuda.stream(side), ops.static_capacity(self.capacity):
+                warnings.simplefilter("always")
+                for _ in range(max(warmup, 1)):               # allocator warm-up, launch-order feedback, lazy initialisation
+                    res = fn()
+                    bad = _tensors_with_history(res)
+                    del res
+                    if bad:
+                        torch.cuda.current_stream(self.device).wait_stream(side)
+                        raise ops._lib.MisplatError(
+                            "GraphedStep: fn() returned tensor(s) with autograd history (" + ", ".join(bad[:4])
+                            + ("..." if len(bad) > 4 else "") + "): return detached tensors (t.detach()) or nothing -- "
+                            "a graph of the previous iteration that is still alive cannot be captured")
+                stale = [w for w in caught if "AccumulateGrad node's stream does not match" in str(w.message)]
+        finally:
+            torch.set_warn_always(warn_always)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
+        if stale:
+            raise ops._lib.MisplatError(
+                "GraphedStep: an autograd graph of an EARLIER call on these parameters is still alive (something keeps a "
+                "tensor with autograd history: outputs, a meta dict, a loss) -- PyTorch reported AccumulateGrad nodes on a "
+                "foreign stream during the warm-up, and capturing in that state crashes the process.  Drop or detach those "
+                "references before creating the GraphedStep")
         ops.check_static_capacity(self.device)                # too small already: fail before capturing
         self.graph = torch.cuda.CUDAGraph()
         self._keep: list = []
