@@ -186,6 +186,26 @@ __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; 
 // "skip" is a = 0.  The next record is prefetched from LDS while the current one is consumed.
 // NXQ > 0: N-D colours (rade_features_model.py:441-476, D = 16 / 17): channels 0..3 ride in the record,
 // channels 4.. in featx[row][NXQ] (float4s, zero padded); n_channels = D' is the render width.
+constexpr int kFillBlocks = 512;
+constexpr int64_t kFillHeadRows = 2500000;
+// The background role of a compositing launch (F.blocks > 0): its last workgroups -- dispatched when the machine starts
+// to drain -- or (at_head: fills too large for the tail) its first ones clear the tensors of F: memory-bound waves
+// beside the kernel's issue-bound ones, no launch, no graph branch.  True for a workgroup that had this role.
+__device__ __forceinline__ bool background_fill(const misplat_internal::FillList& F) {
+    const int fill_b = F.at_head ? (int)blockIdx.x : (int)blockIdx.x - ((int)gridDim.x - F.blocks);
+    if (!(F.blocks > 0 && fill_b >= 0 && fill_b < F.blocks)) return false;
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (k >= F.count) break;
+        float4* __restrict__ d = (float4*)F.p[k];
+        const int64_t n4 = F.n[k] >> 2;
+        for (int64_t i = (int64_t)fill_b * 64 + threadIdx.x; i < n4; i += (int64_t)F.blocks * 64) d[i] = z;
+        if (fill_b == 0 && (int)threadIdx.x < (int)(F.n[k] & 3)) F.p[k][4 * n4 + threadIdx.x] = 0.f;
+    }
+    return true;
+}
+
 template <int CD, int PPL, int NXQ = 0, bool LAZY = false>
 #ifndef MISPLAT_FWD_WAVES
 #define MISPLAT_FWD_WAVES 6            /* waves per SIMD the PPL-2 forward is compiled for: 80 VGPRs.  The plain kernel needs
@@ -199,7 +219,8 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
     float* __restrict__ render, float* __restrict__ alpha, float* __restrict__ exp_depth,
     float* __restrict__ med_depth, float* __restrict__ normal, int32_t* __restrict__ last_ids,
     int32_t* __restrict__ median_ids, const float4* __restrict__ featx = nullptr, int n_channels = CD,
-    LazyColour lz = LazyColour()) {
+    LazyColour lz = LazyColour(), misplat_internal::FillList F = {}) {
+    if (LAZY && background_fill(F)) return;
     __shared__ float4 sm[4 * 64 + 4];
     __shared__ int sm_idx[64 + 4];
     __shared__ float4 smx[NXQ > 0 ? NXQ * 64 + 4 : 1];
@@ -209,7 +230,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
 #pragma unroll
         for (int ch = 0; ch < (NXQ > 0 ? 4 * NXQ : 1); ch++) colx[k][ch] = 0.f;
     BandCtx c;
-    if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c)) return;
+    if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c, (LAZY && F.at_head) ? F.blocks : 0)) return;
     if (LAZY) {                                  // camera centre = -R^T t of the tile's camera (as the colour kernel has it)
 #pragma clang fp contract(off)
         const float* V = lz.viewmats + 16 * c.cam;
@@ -574,19 +595,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
     // Background role (F.blocks > 0): the last workgroups of the grid -- dispatched when the machine starts to drain --
     // or (at_head: fills too large for the tail) the first ones clear the tensors the per-Gaussian backward kernels write
     // sparsely afterwards: memory-bound waves beside this kernel's issue-bound ones, no launch, no graph branch.
-    const int fill_b = F.at_head ? (int)blockIdx.x : (int)blockIdx.x - ((int)gridDim.x - F.blocks);
-    if (F.blocks > 0 && fill_b >= 0 && fill_b < F.blocks) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (k >= F.count) break;
-            float4* __restrict__ d = (float4*)F.p[k];
-            const int64_t n4 = F.n[k] >> 2;
-            for (int64_t i = (int64_t)fill_b * 64 + threadIdx.x; i < n4; i += (int64_t)F.blocks * 64) d[i] = z;
-            if (fill_b == 0 && (int)threadIdx.x < (int)(F.n[k] & 3)) F.p[k][4 * n4 + threadIdx.x] = 0.f;
-        }
-        return;
-    }
+    if (background_fill(F)) return;
     __shared__ float4 sm[4 * 64 + 4];
     __shared__ int sm_idx[64 + 4];
     __shared__ int sm_slot[64 + 4];
@@ -1546,25 +1555,44 @@ extern "C" int misplat_blend_fwd_lazy(const misplat_params* p, int32_t color_dim
                                       const float* coeffs, const float* coeffs_rest, int32_t sh_degree,
                                       int32_t depth_channel, const float* depths, float* sh_aux,
                                       misplat_stream_t stream) {
+    return misplat_internal::blend_fwd_lazy(p, color_dim, Ks, grec, flatten_ids, offsets, n_isects, render, alpha, exp_depth,
+                                            med_depth, normal, last_ids, median_ids, means, viewmats, coeffs, coeffs_rest,
+                                            sh_degree, depth_channel, depths, sh_aux, nullptr, (hipStream_t)stream);
+}
+
+int misplat_internal::blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const float* Ks, float* grec,
+                                     const int32_t* flatten_ids, const int32_t* offsets, int64_t n_isects, float* render,
+                                     float* alpha, float* exp_depth, float* med_depth, float* normal, int32_t* last_ids,
+                                     int32_t* median_ids, const float* means, const float* viewmats, const float* coeffs,
+                                     const float* coeffs_rest, int32_t sh_degree, int32_t depth_channel,
+                                     const float* depths, float* sh_aux, const FillList* fills, hipStream_t s) {
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !means || !viewmats || !coeffs || sh_degree < 0 ||
         sh_degree > 3 || (depth_channel && !depths) || color_dim < 3 || color_dim > 4)
         return MISPLAT_EINVAL;
     if (pick_ppl(p->ppl_fwd, kDefaultPplFwd) != 2) return MISPLAT_EINVAL;
     const int total = p->tile_w * p->tile_h * p->n_cams * 2;
-    const int grid = ((total + 7) / 8) * 8;
+    FillList F = {};
+    if (fills) {
+        if (fills->count < 0 || fills->count > 8) return MISPLAT_EINVAL;
+        for (int k = 0; k < fills->count; k++)
+            if (!fills->p[k] || (((uintptr_t)fills->p[k]) & 15) || fills->n[k] < 0) return MISPLAT_EINVAL;
+        F = *fills;
+        F.blocks = kFillBlocks;
+        F.at_head = (int64_t)p->n_gauss * p->n_cams >= kFillHeadRows;
+    }
+    const int grid = ((total + 7) / 8) * 8 + F.blocks;
     LazyColour lz;
     lz.means = means; lz.coeffs = coeffs; lz.coeffs_rest = coeffs_rest; lz.depths = depths; lz.viewmats = viewmats;
     lz.grec_rw = (float4*)grec; lz.sh_aux = sh_aux; lz.ccx = lz.ccy = lz.ccz = 0.f;
     lz.deg = sh_degree; lz.depth_channel = depth_channel; lz.n_gauss = p->n_gauss;
-    hipStream_t s = (hipStream_t)stream;
     if (color_dim == 3)
         hipLaunchKernelGGL((blend_fwd_kernel<3, 2, 0, true>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec, flatten_ids,
                            offsets, n_isects, render, alpha, exp_depth, med_depth, normal, last_ids, median_ids,
-                           (const float4*)nullptr, 3, lz);
+                           (const float4*)nullptr, 3, lz, F);
     else
         hipLaunchKernelGGL((blend_fwd_kernel<4, 2, 0, true>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec, flatten_ids,
                            offsets, n_isects, render, alpha, exp_depth, med_depth, normal, last_ids, median_ids,
-                           (const float4*)nullptr, 4, lz);
+                           (const float4*)nullptr, 4, lz, F);
     return check_launch();
 }
 
@@ -1614,8 +1642,6 @@ extern "C" int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, con
 // misplat_blend_bwd_atomic + background fills (internal.h): 512 one-wave workgroups (a multiple of 8: the unit -> XCD map
 // stays) behind the last unit of the grid, or in front of the first one when the fill is too large to hide in the
 // kernel's tail (placement and count measured: see enqueue_backward in raster.hip).
-constexpr int kFillBlocks = 512;
-constexpr int64_t kFillHeadRows = 2500000;
 int misplat_internal::blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks, const float* grec,
                                        const int32_t* flatten_ids, const int32_t* offsets, int64_t n_isects,
                                        const float* alpha, const int32_t* last_ids, const int32_t* median_ids,

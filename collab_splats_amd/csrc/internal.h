@@ -35,6 +35,21 @@ int blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks
                      const float* v_exp_depth, const float* v_med_depth, const float* v_normal, float* v_grec, float* v_abs,
                      int32_t v_grec_is_zero, const FillList* fills, hipStream_t s);
 
+// misplat_project_pack_fwd whose on-demand-colour mode (lazy_rows != NULL: colour slots start UNSET) clears the gradient
+// rows only when clear_lazy_rows is set -- the one-entry forward leaves that to blend_fwd_lazy's grid (below).
+int project_pack_fwd(const misplat_params* p, const float* means, const float* quats, const float* scales,
+                     const float* opacities, const float* viewmats, const float* Ks, int32_t* radii, float* means2d,
+                     float* depths, float* compensations, float* grec, uint32_t* zero_words, int32_t n_zero,
+                     float* lazy_rows, float* abs_rows, int32_t clear_lazy_rows, hipStream_t s);
+
+// misplat_blend_fwd_lazy that also clears the tensors of `fills` (or NULL) with the last workgroups of its grid:
+// memory-bound waves beside the issue-bound compositing ones (the gradient rows the backward adds into).
+int blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const float* Ks, float* grec, const int32_t* flatten_ids,
+                   const int32_t* offsets, int64_t n_isects, float* render, float* alpha, float* exp_depth, float* med_depth,
+                   float* normal, int32_t* last_ids, int32_t* median_ids, const float* means, const float* viewmats,
+                   const float* coeffs, const float* coeffs_rest, int32_t sh_degree, int32_t depth_channel,
+                   const float* depths, float* sh_aux, const FillList* fills, hipStream_t s);
+
 // color_bwd + project_pack_bwd of the rows flagged in misplat_params.touched as ONE launch: one camera, SH colours
 // (16 coefficients, no Jacobian cache), no separate mean2d gradient, every output cleared beforehand (FillList above).
 // The SH direction gradient stays in registers: no v_means_dir.

@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
     const float* __restrict__ viewmats, const float* __restrict__ Ks, int32_t* __restrict__ radii,
     float* __restrict__ means2d, float* __restrict__ depths, float* __restrict__ comps,
     float4* __restrict__ grec, uint32_t* __restrict__ zero_words, int n_zero, float4* __restrict__ lazy_rows,
-    float2* __restrict__ abs_rows) {
+    float2* __restrict__ abs_rows, int clear_lazy_rows) {
     // scratch the NEXT kernels of the stream accumulate into (bucketing counters): cleared here, no memset launch
     // (a few thousand words -- cell counts, cursors, tile counts: spread over the first workgroups of the grid)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * blockDim.x)
@@ -541,12 +541,14 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
         if (lazy_rows) {
             // on-demand colours (misplat_blend_fwd_lazy): the colour slots start UNSET, and the gradient rows the
             // backward adds into are cleared here, as whole lines (the block's 256 rows are contiguous)
-            const int64_t base = idx - threadIdx.x;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (clear_lazy_rows) {               // (0: the compositing forward clears them inside its own grid)
+                const int64_t base = idx - threadIdx.x;
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int64_t e4 = 4 * base + threadIdx.x + u * (int64_t)blockDim.x;
-                if (e4 < 4 * total) lazy_rows[e4] = z;
+                for (int u = 0; u < 4; u++) {
+                    const int64_t e4 = 4 * base + threadIdx.x + u * (int64_t)blockDim.x;
+                    if (e4 < 4 * total) lazy_rows[e4] = z;
+                }
             }
             if (idx < total) { const float u_ = __uint_as_float(0x7fc0deadu); grec[4 * idx + 3] = make_float4(u_, u_, u_, u_); }
         }
@@ -1489,6 +1491,16 @@ extern "C" int misplat_project_pack_fwd(const misplat_params* p, const float* me
                                         const float* Ks, int32_t* radii, float* means2d, float* depths,
                                         float* compensations, float* grec, uint32_t* zero_words, int32_t n_zero,
                                         float* lazy_rows, float* abs_rows, misplat_stream_t stream) {
+    return misplat_internal::project_pack_fwd(p, means, quats, scales, opacities, viewmats, Ks, radii, means2d, depths,
+                                              compensations, grec, zero_words, n_zero, lazy_rows, abs_rows, 1,
+                                              (hipStream_t)stream);
+}
+
+int misplat_internal::project_pack_fwd(const misplat_params* p, const float* means, const float* quats,
+                                       const float* scales, const float* opacities, const float* viewmats,
+                                       const float* Ks, int32_t* radii, float* means2d, float* depths,
+                                       float* compensations, float* grec, uint32_t* zero_words, int32_t n_zero,
+                                       float* lazy_rows, float* abs_rows, int32_t clear_lazy_rows, hipStream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1 || p->width < 1 || p->height < 1) return MISPLAT_EINVAL;
     int64_t total = (int64_t)p->n_gauss * p->n_cams;
     if (n_zero < 0 || (n_zero > 0 && !zero_words)) return MISPLAT_EINVAL;
@@ -1496,7 +1508,7 @@ extern "C" int misplat_project_pack_fwd(const misplat_params* p, const float* me
     if (total > 0 && !opacities) return MISPLAT_EINVAL;
     hipLaunchKernelGGL(project_pack_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                        means, quats, scales, opacities, viewmats, Ks, radii, means2d, depths, compensations,
-                       (float4*)grec, zero_words, n_zero, (float4*)lazy_rows, (float2*)abs_rows);
+                       (float4*)grec, zero_words, n_zero, (float4*)lazy_rows, (float2*)abs_rows, (int)clear_lazy_rows);
     return check_launch();
 }
 

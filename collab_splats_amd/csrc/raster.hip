@@ -35,6 +35,9 @@ struct Fork {
     hipEvent_t forked, joined;
 };
 
+constexpr int64_t kRowsClearedByBlend = 2500000;
+inline bool cleared_by_blend(const misplat_params* p) { return (int64_t)p->n_gauss * p->n_cams < kRowsClearedByBlend; }
+
 int enqueue_colour(const misplat_params* p, const misplat_raster_args* a, misplat_stream_t stream) {
     return misplat_color_fwd(p, a->sh_degree, a->K_or_D, a->n_color, a->per_cam, a->depth_channel, a->means, a->viewmats,
                              a->colors, a->colors_rest, a->radii, a->depths, a->grec, a->sh_aux, a->v_grec_zero, stream);
@@ -57,9 +60,14 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         if (!(a->cell_count < a->cell_cursor && a->cell_cursor < (const uint32_t*)a->counters &&
               (const uint32_t*)a->counters + 4 <= (const uint32_t*)a->tile_count) || n_zero < 4 || n_zero > (1 << 22))
             return MISPLAT_EINVAL;
-        rc = misplat_project_pack_fwd(p, a->means, a->quats, a->scales, a->opacities, a->viewmats, a->Ks, a->radii,
-                                      a->means2d, a->depths, a->compensations, a->grec, a->cell_count, (int32_t)n_zero,
-                                      a->lazy_colour ? a->v_grec_zero : nullptr, a->v_abs_zero, stream);
+        // (on-demand colours: the colour slots start UNSET; the gradient rows are cleared by the compositing forward's
+        // own grid in phase B, which every lazy forward goes through before its backward -- up to kRowsClearedByBlend
+        // rows: measured -20 us per 1 M step on changing views; at 5 M rows the 320 MB do not hide behind a 190 us
+        // compositing launch (+60 us there against -65 us here), so the projection kernel keeps them)
+        rc = misplat_internal::project_pack_fwd(p, a->means, a->quats, a->scales, a->opacities, a->viewmats, a->Ks, a->radii,
+                                                a->means2d, a->depths, a->compensations, a->grec, a->cell_count,
+                                                (int32_t)n_zero, a->lazy_colour ? a->v_grec_zero : nullptr, a->v_abs_zero,
+                                                cleared_by_blend(p) ? 0 : 1, s);
         if (rc != MISPLAT_OK) return rc;
         rc = misplat_bucket_count(p, a->means2d, a->radii, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count,
                                   a->counters, 1, stream);
@@ -101,12 +109,20 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         q.unit_perm = a->unit_perm_in;
         q.unit_work = a->unit_work;
         if (a->ev_blend_begin && hipEventRecord((hipEvent_t)a->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
-        if (a->lazy_colour)
-            rc = misplat_blend_fwd_lazy(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects, a->render,
-                                        a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, a->means,
-                                        a->viewmats, a->colors, a->colors_rest, a->sh_degree, a->depth_channel, a->depths,
-                                        nullptr, stream);
-        else
+        if (a->lazy_colour) {
+            misplat_internal::FillList F = {};
+            const bool fill = a->v_grec_zero && cleared_by_blend(p);
+            if (fill) {
+                F.p[0] = a->v_grec_zero;
+                F.n[0] = (int64_t)p->n_gauss * p->n_cams * MISPLAT_REC;
+                F.count = 1;
+            }
+            rc = misplat_internal::blend_fwd_lazy(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects,
+                                                  a->render, a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids,
+                                                  a->median_ids, a->means, a->viewmats, a->colors, a->colors_rest,
+                                                  a->sh_degree, a->depth_channel, a->depths, nullptr,
+                                                  fill ? &F : nullptr, s);
+        } else
             rc = misplat_blend_fwd(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects, a->render,
                                    a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, stream);
         if (rc != MISPLAT_OK) return rc;
