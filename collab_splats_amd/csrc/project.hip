@@ -1359,6 +1359,101 @@ __global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
     if (lane < qn) heavy(queue[lane]);
 }
 
+// sh_bwd_row for a whole wave of queued rows, the coefficient rows staged through LDS.  One thread per row reading its
+// own 192 bytes puts 64 different lines into every load and store instruction (and 48 coefficients + 48 gradients into
+// registers); here the wave moves the rows cooperatively -- 5 rows of 12 x 16 B per instruction ([N,16,3]), or one row of
+// 45 + 3 floats (features_rest + features_dc) -- and sh_eval / sh_grad read and overwrite the row in LDS term by term.
+// Row stride 49 words: a thread's word k lands in bank (49 lane + k) mod 64, all different.
+constexpr int kShStageStride = 49;
+template <bool SPLIT>
+__device__ __forceinline__ void sh_bwd_wave(int deg, int g, bool active, int nrows, float ccx, float ccy, float ccz,
+                                            const float* __restrict__ means, const float* __restrict__ coeffs,
+                                            const float* __restrict__ coeffs_rest, const float* __restrict__ v_grec,
+                                            float* __restrict__ v_coeffs, float* __restrict__ v_coeffs_rest,
+                                            float* stage, int* rows, float (&dir)[3]) {
+    const int lane = threadIdx.x;
+    rows[lane] = active ? g : 0;
+    __syncthreads();
+    if (!SPLIT) {
+        const int sub = lane / 12, q = lane - 12 * sub;
+        float4 v[13];
+#pragma unroll
+        for (int it = 0; it < 13; it++) {
+            const int r = it * 5 + sub;
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < 60 && r < nrows) v[it] = reinterpret_cast<const float4*>(coeffs + (size_t)rows[r] * 48)[q];
+        }
+#pragma unroll
+        for (int it = 0; it < 13; it++) {
+            const int r = it * 5 + sub;
+            if (lane < 60 && r < nrows) {
+                float* d = stage + r * kShStageStride + 4 * q;
+                d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
+            }
+        }
+    } else {
+        const int word = lane < 45 ? lane + 3 : lane - 45;                 // lanes 45..47: the three DC coefficients
+#pragma unroll 1
+        for (int r0 = 0; r0 < nrows; r0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                v[u] = 0.f;
+                if (r0 + u < nrows && lane < 48) {
+                    const size_t gr = (size_t)rows[r0 + u];
+                    v[u] = lane < 45 ? coeffs_rest[gr * 45 + lane] : coeffs[gr * 3 + (lane - 45)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (r0 + u < nrows && lane < 48) stage[(r0 + u) * kShStageStride + word] = v[u];
+        }
+    }
+    __syncthreads();
+    float x = 0.f, y = 0.f, z = 0.f, inv = 0.f, vd0 = 0.f, vd1 = 0.f, vd2 = 0.f;
+    if (active) {
+        float* cf = stage + lane * kShStageStride;
+        const float* vg = v_grec + (size_t)g * MISPLAT_REC + 12;
+        const float vg0 = vg[0], vg1 = vg[1], vg2 = vg[2];
+        const float dx = means[3 * g] - ccx, dy = means[3 * g + 1] - ccy, dz = means[3 * g + 2] - ccz;
+        const float n = sqrtf(dx * dx + dy * dy + dz * dz);
+        inv = n > 0.f ? 1.0f / n : 0.f;
+        x = dx * inv; y = dy * inv; z = dz * inv;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        float J[9];
+        sh_eval<false>(deg, x, y, z, cf, c0, c1, c2, J);
+        const float vc0 = (c0 + 0.5f > 0.f) ? vg0 : 0.f, vc1 = (c1 + 0.5f > 0.f) ? vg1 : 0.f, vc2 = (c2 + 0.5f > 0.f) ? vg2 : 0.f;
+        misplat_sh::sh_grad<false>(deg, x, y, z, cf, vc0, vc1, vc2, vd0, vd1, vd2, nullptr);
+        const int nb = (deg + 1) * (deg + 1);
+        for (int k = nb; k < 16; k++) { cf[3 * k] = 0.f; cf[3 * k + 1] = 0.f; cf[3 * k + 2] = 0.f; }   // above the active degree
+    }
+    __syncthreads();
+    if (!SPLIT) {
+        const int sub = lane / 12, q = lane - 12 * sub;
+#pragma unroll
+        for (int it = 0; it < 13; it++) {
+            const int r = it * 5 + sub;
+            if (lane < 60 && r < nrows) {
+                const float* d = stage + r * kShStageStride + 4 * q;
+                reinterpret_cast<float4*>(v_coeffs + (size_t)rows[r] * 48)[q] = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        }
+    } else {
+        const int word = lane < 45 ? lane + 3 : lane - 45;
+#pragma unroll 4
+        for (int r = 0; r < nrows; r++) {
+            if (lane < 48) {
+                const size_t gr = (size_t)rows[r];
+                const float v = stage[r * kShStageStride + word];
+                if (lane < 45) v_coeffs_rest[gr * 45 + lane] = v;
+                else v_coeffs[gr * 3 + (lane - 45)] = v;
+            }
+        }
+    }
+    const float dot = x * vd0 + y * vd1 + z * vd2;
+    dir[0] = (vd0 - x * dot) * inv; dir[1] = (vd1 - y * dot) * inv; dir[2] = (vd2 - z * dot) * inv;
+}
+
 // Both per-Gaussian backward stages of the flagged rows in ONE launch (outputs cleared beforehand, one camera, SH colours
 // without Jacobian cache): one scan of the flags, one queue, and a row's SH direction gradient goes from the SH stage to
 // the projection stage in registers (no v_means_dir round trip, one launch and one dependent scan less).
@@ -1371,6 +1466,8 @@ __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
     float* __restrict__ v_coeffs_rest, float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
     float* __restrict__ v_opacities) {
     __shared__ int queue[128];
+    __shared__ int rows[64];
+    __shared__ float stage[64 * kShStageStride];
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const float* V = viewmats;
@@ -1378,11 +1475,14 @@ __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
     const float ccy = -(V[1] * V[3] + V[5] * V[7] + V[9] * V[11]);
     const float ccz = -(V[2] * V[3] + V[6] * V[7] + V[10] * V[11]);
     const Cam cam = load_cam(viewmats, Ks);
-    auto heavy = [&](int g) {
+    auto heavy = [&](int g, int nrows) {           // called by the whole wave: lanes < nrows hold a row
         float dir[3];
-        sh_bwd_row<SPLIT>(deg, g, ccx, ccy, ccz, means, coeffs, coeffs_rest, v_grec, v_coeffs, v_coeffs_rest, dir);
-        pp_bwd_row(P, cam, depth_slot, g, means, quats, scales, opacities, comps, nullptr, v_grec, dir, v_means, v_quats, v_scales,
-                   v_opacities);
+        const bool active = lane < nrows;
+        sh_bwd_wave<SPLIT>(deg, g, active, nrows, ccx, ccy, ccz, means, coeffs, coeffs_rest, v_grec, v_coeffs, v_coeffs_rest,
+                           stage, rows, dir);
+        if (active)
+            pp_bwd_row(P, cam, depth_slot, g, means, quats, scales, opacities, comps, nullptr, v_grec, dir, v_means, v_quats,
+                       v_scales, v_opacities);
     };
     int qn = 0;
     for (int64_t base = (int64_t)blockIdx.x * kFlagStep; base < P.n_gauss; base += (int64_t)gridDim.x * kFlagStep) {
@@ -1406,12 +1506,12 @@ __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
                 __builtin_amdgcn_wave_barrier();
                 queue[lane] = keep;
                 qn -= 64;
-                heavy(gq);
+                heavy(gq, 64);
             }
             fl >>= 8;
         }
     }
-    if (lane < qn) heavy(queue[lane]);
+    if (qn > 0) heavy(lane < qn ? queue[lane] : 0, qn);
 }
 
 inline int grid_for(int64_t n, int block) {
