@@ -488,7 +488,8 @@ def main():
                        "git_rev": git_rev(), "graph_cache": ops.graph_cache_stats(),
                        "path": {k: took.get(k, 0) for k in ("forward", "forward_lazy_colour", "forward_merged_phases",
                                                            "forward_prev_order", "capacity_redo", "backward_one_call",
-                                                           "backward_background_fill", "backward_staged", "backward_sink")},
+                                                           "backward_background_fill", "backward_staged", "backward_sink",
+                                                           "forward_rows_on_touch", "backward_rows_refilled")},
                        "path_note": f"counts over the {args.steps + args.warmup} headline steps: on-demand colours, merged "
                                     "phases, previous-step launch order, capacity misses, one-call backward, background fill",
                        "host": (f"whole step replayed as one hipGraph (graphs.GraphedStep, fixed capacity "

@@ -64,7 +64,8 @@ class RasterBwdArgs(C.Structure):
                                             "depth_slot", "reserved")]
                 + [(n, C.c_void_p) for n in ("means", "quats", "scales", "opacities", "colors", "colors_rest", "viewmats",
                                              "radii", "compensations", "sh_aux", "v_means2d", "v_colors", "v_colors_rest",
-                                             "v_means_dir", "v_means", "v_quats", "v_scales", "v_opacities", "ev_blend_begin", "ev_blend_end")])
+                                             "v_means_dir", "v_means", "v_quats", "v_scales", "v_opacities", "ev_blend_begin", "ev_blend_end",
+                                             "v_means2d_out")])
 
 
 def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: int = 16,

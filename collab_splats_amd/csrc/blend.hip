@@ -101,6 +101,7 @@ constexpr uint32_t kColourUnset = 0x7fc0dead;      // a NaN no colour can be (co
 struct LazyColour {
     const float* means; const float* coeffs; const float* coeffs_rest; const float* depths; const float* viewmats;
     float4* grec_rw; float* sh_aux;
+    float4* v_rows;                                  // or NULL: gradient rows [C*N,16], a row is cleared when its colour is set
     float ccx, ccy, ccz;                             // camera centre of the workgroup's tile (set in the kernel)
     int deg, depth_channel, n_gauss;
 };
@@ -134,6 +135,14 @@ __device__ __forceinline__ float4 lazy_colour(const LazyColour& lz, int g) {
     const float4 q3 = make_float4(fmaxf(c0 + 0.5f, 0.f), fmaxf(c1 + 0.5f, 0.f), fmaxf(c2 + 0.5f, 0.f),
                                   lz.depth_channel ? lz.depths[g] : 0.f);
     lz.grec_rw[4 * (size_t)g + 3] = q3;
+    if (lz.v_rows) {
+        // The backward adds into the gradient row of a record only where a pixel of the band takes it, and such a band
+        // has staged the record past this same cull in this launch: whoever sets the colour clears the row (64 bytes),
+        // and nothing has to clear the rows of the records no band ever reaches (misplat_raster_args.lazy_colour = 2).
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* r = lz.v_rows + 4 * (size_t)g;
+        r[0] = z; r[1] = z; r[2] = z; r[3] = z;
+    }
     return q3;
 }
 
@@ -219,8 +228,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
     float* __restrict__ render, float* __restrict__ alpha, float* __restrict__ exp_depth,
     float* __restrict__ med_depth, float* __restrict__ normal, int32_t* __restrict__ last_ids,
     int32_t* __restrict__ median_ids, const float4* __restrict__ featx = nullptr, int n_channels = CD,
-    LazyColour lz = LazyColour(), misplat_internal::FillList F = {}) {
-    if (LAZY && background_fill(F)) return;
+    LazyColour lz = LazyColour()) {
     __shared__ float4 sm[4 * 64 + 4];
     __shared__ int sm_idx[64 + 4];
     __shared__ float4 smx[NXQ > 0 ? NXQ * 64 + 4 : 1];
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
 #pragma unroll
         for (int ch = 0; ch < (NXQ > 0 ? 4 * NXQ : 1); ch++) colx[k][ch] = 0.f;
     BandCtx c;
-    if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c, (LAZY && F.at_head) ? F.blocks : 0)) return;
+    if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c)) return;
     if (LAZY) {                                  // camera centre = -R^T t of the tile's camera (as the colour kernel has it)
 #pragma clang fp contract(off)
         const float* V = lz.viewmats + 16 * c.cam;
@@ -1565,34 +1573,26 @@ int misplat_internal::blend_fwd_lazy(const misplat_params* p, int32_t color_dim,
                                      float* alpha, float* exp_depth, float* med_depth, float* normal, int32_t* last_ids,
                                      int32_t* median_ids, const float* means, const float* viewmats, const float* coeffs,
                                      const float* coeffs_rest, int32_t sh_degree, int32_t depth_channel,
-                                     const float* depths, float* sh_aux, const FillList* fills, hipStream_t s) {
+                                     const float* depths, float* sh_aux, float* rows_on_touch, hipStream_t s) {
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !means || !viewmats || !coeffs || sh_degree < 0 ||
         sh_degree > 3 || (depth_channel && !depths) || color_dim < 3 || color_dim > 4)
         return MISPLAT_EINVAL;
     if (pick_ppl(p->ppl_fwd, kDefaultPplFwd) != 2) return MISPLAT_EINVAL;
     const int total = p->tile_w * p->tile_h * p->n_cams * 2;
-    FillList F = {};
-    if (fills) {
-        if (fills->count < 0 || fills->count > 8) return MISPLAT_EINVAL;
-        for (int k = 0; k < fills->count; k++)
-            if (!fills->p[k] || (((uintptr_t)fills->p[k]) & 15) || fills->n[k] < 0) return MISPLAT_EINVAL;
-        F = *fills;
-        F.blocks = kFillBlocks;
-        F.at_head = (int64_t)p->n_gauss * p->n_cams >= kFillHeadRows;
-    }
-    const int grid = ((total + 7) / 8) * 8 + F.blocks;
+    if (((uintptr_t)rows_on_touch) & 15) return MISPLAT_EINVAL;
+    const int grid = ((total + 7) / 8) * 8;
     LazyColour lz;
     lz.means = means; lz.coeffs = coeffs; lz.coeffs_rest = coeffs_rest; lz.depths = depths; lz.viewmats = viewmats;
-    lz.grec_rw = (float4*)grec; lz.sh_aux = sh_aux; lz.ccx = lz.ccy = lz.ccz = 0.f;
+    lz.grec_rw = (float4*)grec; lz.sh_aux = sh_aux; lz.v_rows = (float4*)rows_on_touch; lz.ccx = lz.ccy = lz.ccz = 0.f;
     lz.deg = sh_degree; lz.depth_channel = depth_channel; lz.n_gauss = p->n_gauss;
     if (color_dim == 3)
         hipLaunchKernelGGL((blend_fwd_kernel<3, 2, 0, true>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec, flatten_ids,
                            offsets, n_isects, render, alpha, exp_depth, med_depth, normal, last_ids, median_ids,
-                           (const float4*)nullptr, 3, lz, F);
+                           (const float4*)nullptr, 3, lz);
     else
         hipLaunchKernelGGL((blend_fwd_kernel<4, 2, 0, true>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec, flatten_ids,
                            offsets, n_isects, render, alpha, exp_depth, med_depth, normal, last_ids, median_ids,
-                           (const float4*)nullptr, 4, lz, F);
+                           (const float4*)nullptr, 4, lz);
     return check_launch();
 }
 

@@ -36,19 +36,18 @@ int blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks
                      int32_t v_grec_is_zero, const FillList* fills, hipStream_t s);
 
 // misplat_project_pack_fwd whose on-demand-colour mode (lazy_rows != NULL: colour slots start UNSET) clears the gradient
-// rows only when clear_lazy_rows is set -- the one-entry forward leaves that to blend_fwd_lazy's grid (below).
+// rows only when clear_lazy_rows is set -- otherwise blend_fwd_lazy clears the rows it reaches (below).
 int project_pack_fwd(const misplat_params* p, const float* means, const float* quats, const float* scales,
                      const float* opacities, const float* viewmats, const float* Ks, int32_t* radii, float* means2d,
                      float* depths, float* compensations, float* grec, uint32_t* zero_words, int32_t n_zero,
                      float* lazy_rows, float* abs_rows, int32_t clear_lazy_rows, hipStream_t s);
 
-// misplat_blend_fwd_lazy that also clears the tensors of `fills` (or NULL) with the last workgroups of its grid:
-// memory-bound waves beside the issue-bound compositing ones (the gradient rows the backward adds into).
+// misplat_blend_fwd_lazy that also clears row g of rows_on_touch[C*N,16] (or NULL) when it sets the colour of record g.
 int blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const float* Ks, float* grec, const int32_t* flatten_ids,
                    const int32_t* offsets, int64_t n_isects, float* render, float* alpha, float* exp_depth, float* med_depth,
                    float* normal, int32_t* last_ids, int32_t* median_ids, const float* means, const float* viewmats,
                    const float* coeffs, const float* coeffs_rest, int32_t sh_degree, int32_t depth_channel,
-                   const float* depths, float* sh_aux, const FillList* fills, hipStream_t s);
+                   const float* depths, float* sh_aux, float* rows_on_touch, hipStream_t s);
 
 // color_bwd + project_pack_bwd of the rows flagged in misplat_params.touched as ONE launch: one camera, SH colours
 // (16 coefficients, no Jacobian cache), no separate mean2d gradient, every output cleared beforehand (FillList above).
@@ -56,6 +55,8 @@ int blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const float* Ks, 
 int gauss_bwd_sparse(const misplat_params* p, int32_t sh_degree, int32_t depth_slot, const float* means, const float* quats,
                      const float* scales, const float* opacities, const float* viewmats, const float* Ks, const float* coeffs,
                      const float* coeffs_rest, const float* compensations, const float* v_grec, float* v_coeffs,
-                     float* v_coeffs_rest, float* v_means, float* v_quats, float* v_scales, float* v_opacities, hipStream_t s);
+                     float* v_coeffs_rest, float* v_means, float* v_quats, float* v_scales, float* v_opacities,
+                     float* v_means2d_out /* or NULL: [N,2] (cleared like the others), columns 0:2 of the flagged rows */,
+                     hipStream_t s);
 
 }  // namespace misplat_internal

@@ -1464,7 +1464,7 @@ __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
     const float* __restrict__ Ks, const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest,
     const float* __restrict__ comps, const float* __restrict__ v_grec, float* __restrict__ v_coeffs,
     float* __restrict__ v_coeffs_rest, float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
-    float* __restrict__ v_opacities) {
+    float* __restrict__ v_opacities, float2* __restrict__ v_m2d) {
     __shared__ int queue[128];
     __shared__ int rows[64];
     __shared__ float stage[64 * kShStageStride];
@@ -1480,9 +1480,11 @@ __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
         const bool active = lane < nrows;
         sh_bwd_wave<SPLIT>(deg, g, active, nrows, ccx, ccy, ccz, means, coeffs, coeffs_rest, v_grec, v_coeffs, v_coeffs_rest,
                            stage, rows, dir);
-        if (active)
+        if (active) {
             pp_bwd_row(P, cam, depth_slot, g, means, quats, scales, opacities, comps, nullptr, v_grec, dir, v_means, v_quats,
                        v_scales, v_opacities);
+            if (v_m2d) v_m2d[g] = *reinterpret_cast<const float2*>(v_grec + (size_t)g * MISPLAT_REC);
+        }
     };
     int qn = 0;
     for (int64_t base = (int64_t)blockIdx.x * kFlagStep; base < P.n_gauss; base += (int64_t)gridDim.x * kFlagStep) {
@@ -1721,8 +1723,9 @@ int misplat_internal::gauss_bwd_sparse(const misplat_params* p, int32_t sh_degre
                                        const float* quats, const float* scales, const float* opacities, const float* viewmats,
                                        const float* Ks, const float* coeffs, const float* coeffs_rest, const float* compensations,
                                        const float* v_grec, float* v_coeffs, float* v_coeffs_rest, float* v_means, float* v_quats,
-                                       float* v_scales, float* v_opacities, hipStream_t s) {
+                                       float* v_scales, float* v_opacities, float* v_means2d_out, hipStream_t s) {
     if (!p || p->n_gauss < 1 || p->n_cams != 1 || !p->touched || sh_degree < 0 || sh_degree > 3) return MISPLAT_EINVAL;
+    if (((uintptr_t)v_means2d_out) & 7) return MISPLAT_EINVAL;
     if (depth_slot != -1 && (depth_slot < 12 || depth_slot > 15)) return MISPLAT_EINVAL;
     if ((coeffs_rest != nullptr) != (v_coeffs_rest != nullptr)) return MISPLAT_EINVAL;
     if ((((uintptr_t)p->touched) & 7) || (((uintptr_t)coeffs | (uintptr_t)v_coeffs | (uintptr_t)v_grec | (uintptr_t)v_quats) & 15))
@@ -1732,11 +1735,11 @@ int misplat_internal::gauss_bwd_sparse(const misplat_params* p, int32_t sh_degre
     if (coeffs_rest)
         hipLaunchKernelGGL(gauss_bwd_sparse_kernel<true>, dim3((unsigned)waves), dim3(64), 0, s, *p, sh_degree, depth_slot, means,
                            quats, scales, opacities, viewmats, Ks, coeffs, coeffs_rest, compensations, v_grec, v_coeffs,
-                           v_coeffs_rest, v_means, v_quats, v_scales, v_opacities);
+                           v_coeffs_rest, v_means, v_quats, v_scales, v_opacities, (float2*)v_means2d_out);
     else
         hipLaunchKernelGGL(gauss_bwd_sparse_kernel<false>, dim3((unsigned)waves), dim3(64), 0, s, *p, sh_degree, depth_slot, means,
                            quats, scales, opacities, viewmats, Ks, coeffs, coeffs_rest, compensations, v_grec, v_coeffs,
-                           v_coeffs_rest, v_means, v_quats, v_scales, v_opacities);
+                           v_coeffs_rest, v_means, v_quats, v_scales, v_opacities, (float2*)v_means2d_out);
     return check_launch();
 }
 

@@ -35,9 +35,6 @@ struct Fork {
     hipEvent_t forked, joined;
 };
 
-constexpr int64_t kRowsClearedByBlend = 2500000;
-inline bool cleared_by_blend(const misplat_params* p) { return (int64_t)p->n_gauss * p->n_cams < kRowsClearedByBlend; }
-
 int enqueue_colour(const misplat_params* p, const misplat_raster_args* a, misplat_stream_t stream) {
     return misplat_color_fwd(p, a->sh_degree, a->K_or_D, a->n_color, a->per_cam, a->depth_channel, a->means, a->viewmats,
                              a->colors, a->colors_rest, a->radii, a->depths, a->grec, a->sh_aux, a->v_grec_zero, stream);
@@ -60,14 +57,13 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         if (!(a->cell_count < a->cell_cursor && a->cell_cursor < (const uint32_t*)a->counters &&
               (const uint32_t*)a->counters + 4 <= (const uint32_t*)a->tile_count) || n_zero < 4 || n_zero > (1 << 22))
             return MISPLAT_EINVAL;
-        // (on-demand colours: the colour slots start UNSET; the gradient rows are cleared by the compositing forward's
-        // own grid in phase B, which every lazy forward goes through before its backward -- up to kRowsClearedByBlend
-        // rows: measured -20 us per 1 M step on changing views; at 5 M rows the 320 MB do not hide behind a 190 us
-        // compositing launch (+60 us there against -65 us here), so the projection kernel keeps them)
+        // (on-demand colours: the colour slots start UNSET.  lazy_colour = 2: the compositing forward clears the gradient
+        // row of every record whose colour it sets, and no other row is ever read -- the caller promises the backward
+        // that reads flagged rows only (misplat_raster_bwd_plan bit 0) or clears v_grec itself first)
         rc = misplat_internal::project_pack_fwd(p, a->means, a->quats, a->scales, a->opacities, a->viewmats, a->Ks, a->radii,
                                                 a->means2d, a->depths, a->compensations, a->grec, a->cell_count,
                                                 (int32_t)n_zero, a->lazy_colour ? a->v_grec_zero : nullptr, a->v_abs_zero,
-                                                cleared_by_blend(p) ? 0 : 1, s);
+                                                a->lazy_colour == 2 ? 0 : 1, s);
         if (rc != MISPLAT_OK) return rc;
         rc = misplat_bucket_count(p, a->means2d, a->radii, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count,
                                   a->counters, 1, stream);
@@ -110,18 +106,12 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         q.unit_work = a->unit_work;
         if (a->ev_blend_begin && hipEventRecord((hipEvent_t)a->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
         if (a->lazy_colour) {
-            misplat_internal::FillList F = {};
-            const bool fill = a->v_grec_zero && cleared_by_blend(p);
-            if (fill) {
-                F.p[0] = a->v_grec_zero;
-                F.n[0] = (int64_t)p->n_gauss * p->n_cams * MISPLAT_REC;
-                F.count = 1;
-            }
+            if (a->lazy_colour == 2 && !a->v_grec_zero) return MISPLAT_EINVAL;
             rc = misplat_internal::blend_fwd_lazy(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects,
                                                   a->render, a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids,
                                                   a->median_ids, a->means, a->viewmats, a->colors, a->colors_rest,
                                                   a->sh_degree, a->depth_channel, a->depths, nullptr,
-                                                  fill ? &F : nullptr, s);
+                                                  a->lazy_colour == 2 ? a->v_grec_zero : nullptr, s);
         } else
             rc = misplat_blend_fwd(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects, a->render,
                                    a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, stream);
@@ -325,7 +315,8 @@ static bool background_fill_ok(const misplat_params* p, const misplat_raster_bwd
           !b->v_means2d && (b->colors_rest != nullptr) == (b->v_colors_rest != nullptr)))
         return false;
     const uintptr_t a16 = (uintptr_t)b->colors | (uintptr_t)b->v_colors | (uintptr_t)b->v_colors_rest | (uintptr_t)b->v_grec |
-                          (uintptr_t)b->v_means | (uintptr_t)b->v_quats | (uintptr_t)b->v_scales | (uintptr_t)b->v_opacities;
+                          (uintptr_t)b->v_means | (uintptr_t)b->v_quats | (uintptr_t)b->v_scales | (uintptr_t)b->v_opacities |
+                          (uintptr_t)b->v_means2d_out;
     return (a16 & 15) == 0 && (((uintptr_t)p->touched) & 7) == 0;
 }
 
@@ -346,6 +337,7 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
         add(b->v_quats, n * 4);
         add(b->v_scales, n * 3);
         add(b->v_opacities, n);
+        if (b->v_means2d_out) add(b->v_means2d_out, n * 2);
     }
     if (b->ev_blend_begin && hipEventRecord((hipEvent_t)b->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
     int rc = misplat_internal::blend_bwd_atomic(&q, b->color_dim, b->Ks, b->grec, b->flatten_ids, b->offsets, b->n_isects,
@@ -358,7 +350,7 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
         return misplat_internal::gauss_bwd_sparse(p, b->sh_degree, b->depth_slot, b->means, b->quats, b->scales, b->opacities,
                                                   b->viewmats, b->Ks, b->colors, b->colors_rest, b->compensations, b->v_grec,
                                                   b->v_colors, b->v_colors_rest, b->v_means, b->v_quats, b->v_scales,
-                                                  b->v_opacities, s);
+                                                  b->v_opacities, b->v_means2d_out, s);
     rc = misplat_color_bwd(p, b->sh_degree, b->K_or_D, b->n_color, b->per_cam, b->means, b->viewmats, b->colors, b->colors_rest,
                            b->radii, b->v_grec, b->v_colors, b->v_colors_rest, b->v_means_dir, b->sh_aux, (misplat_stream_t)s);
     if (rc != MISPLAT_OK) return rc;

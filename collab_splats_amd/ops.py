@@ -46,7 +46,7 @@ _LAST_ORDER: Dict[tuple, Tensor] = {}
 
 # Which variants of the path the calls of this process took (tests and bench.py read it; never reset by the library):
 #   forward / forward_lazy_colour / forward_merged_phases / forward_prev_order / capacity_redo
-#   backward_one_call / backward_background_fill / backward_staged / backward_sink
+#   backward_one_call / backward_background_fill / backward_staged / backward_sink / backward_rows_refilled
 PATH_STATS: "collections.Counter" = collections.Counter()
 
 
@@ -709,6 +709,8 @@ def _cap_key(P: Params, dev: torch.device):
 # On-demand SH colours (csrc/blend.hip, LazyColour): no colour kernel -- the compositing forward evaluates the colour of
 # a record when it first stages it.  Pays when most visible Gaussians are never composited (dense scenes: 1 M random
 # Gaussians at 1080p stage a third of the visible ones); "auto" switches it on from the typical bucket length.
+SPARSE_BWD_MIN_ROWS = 262144        # raster.hip: background_fill_ok
+ROWS_ON_TOUCH = os.environ.get("MISPLAT_ROWS_ON_TOUCH", "1") != "0"
 LAZY_SH = os.environ.get("MISPLAT_LAZY_SH", "auto")
 LAZY_SH_MIN_BUCKET = int(os.environ.get("MISPLAT_LAZY_SH_MIN_BUCKET", "450"))   # measured crossover at 1080p: 391 even, 549 ahead
 
@@ -767,12 +769,17 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     # the colour kernel moves into phase B's parallel graph branch -- worth it only for large scenes (a two-branch
     # graph costs ~40 us more host time per launch; gains ~10 us of GPU time at 1 M Gaussians)
     a.colour_pending = int(COLOUR_BRANCH and rows >= COLOUR_BRANCH_MIN_ROWS)
-    a.lazy_colour = int(lazy)
+    # Gradient rows cleared on first touch (lazy_colour = 2) where the backward is going to read flagged rows only -- the
+    # static part of raster.hip's background_fill_ok; the backward checks the actual plan and clears v_grec itself otherwise.
+    rows_on_touch = bool(lazy and want_grad and flags and Cn == 1 and N >= SPARSE_BWD_MIN_ROWS and not want_aux and kd == 16
+                         and ROWS_ON_TOUCH)
+    a.lazy_colour = 2 if rows_on_touch else int(lazy)
+    PATH_STATS["forward_rows_on_touch"] += int(rows_on_touch)
     if not defer:
         check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
               "misplat_raster_fwd(A)")
     state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero, v_abs_zero=v_abs_zero,
-                 deferred=defer,
+                 deferred=defer, rows_on_touch=rows_on_touch,
                  counters=counters, touched=touched,
                  keep=(rect2, cellhist, cell_count, cell_offs, order, counters, tile_count, radii, cell_cursor))
     return (radii.view(Cn, N, 2), means2d.view(Cn, N, 2), depths.view(Cn, N), comps.view(Cn, N), grec.view(rows, MISPLAT_REC),
@@ -861,7 +868,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
             sched.perm_bwd = sched.perm
     bins = dict(tiles_per_gauss=state["tiles_per_gauss"], n_isects=cap if static else n_known, depths=state["depths"],
                 tile_ids=None, v_grec_zero=state.get("v_grec_zero"), v_abs_zero=state.get("v_abs_zero"),
-                n_isects_dev=state["counters"].view(torch.int64)[0] if static else None,
+                rows_on_touch=bool(state.get("rows_on_touch")), n_isects_dev=state["counters"].view(torch.int64)[0] if static else None,
                 n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:cap if static else n_known],
                 isect_offsets=offsets[:n_tiles + 1], _keep=(scratch, payload))
     imgs = (render.view(Cn, H, W, cd), alpha.view(Cn, H, W, 1), exp_depth.view(Cn, H, W, 1), med_depth.view(Cn, H, W, 1),
@@ -938,6 +945,8 @@ class _RasterFused(torch.autograd.Function):
         ups = _upstream(P, cd, dev, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
         v_grec = bins.pop("v_grec_zero", None)
         flags = 1 if v_grec is not None else 0
+        # (rows cleared on first touch by the forward: as good as cleared for a backward that reads flagged rows only)
+        on_touch = bool(bins.get("rows_on_touch")) and v_grec is not None
         if v_grec is None:
             v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
         v_abs = None
@@ -956,6 +965,7 @@ class _RasterFused(torch.autograd.Function):
         # plain pointers like any other, so the one-call backward -- graph replay, both per-Gaussian stages in one launch,
         # zeros written in the background of the compositing backward -- serves it too)
         simple = v_means2d_in is None
+        v_m2d = None
         if simple:
             b = RasterBwdArgs()
             b.Ks, b.grec, b.flatten_ids, b.offsets = _dp(Ks), _dp(grec), _dp(bins["flatten_ids"]), _dp(bins["isect_offsets"])
@@ -974,16 +984,30 @@ class _RasterFused(torch.autograd.Function):
                 ev = _kernel_event_pair()
                 b.ev_blend_begin, b.ev_blend_end = ev[0].cuda_event, ev[1].cuda_event
                 KERNEL_EVENTS.setdefault("blend_bwd", []).append(ev)
+            # meta["means2d"].grad, when someone still holds meta["means2d"]: a tensor of its own in the flagged-rows
+            # backward (v_grec may then be defined in flagged rows only), a slice of v_grec otherwise
+            m2d_alive = ctx.means2d_ref() is not None
+            v_m2d = torch.empty(rows, 2, device=dev, dtype=torch.float32) if m2d_alive else None
+            b.v_means2d_out = _dp(v_m2d)
+            sparse = int(lib.misplat_raster_bwd_plan(C.byref(P), C.byref(b)) & 1)
+            if not sparse:
+                v_m2d, b.v_means2d_out = None, None
+            if on_touch and not sparse:                               # every row is going to be read: clear them all first
+                b.zero_flags = flags & ~1
+                PATH_STATS["backward_rows_refilled"] += 1
             with _timed("raster_bwd"):
                 check(lib.misplat_raster_bwd(C.byref(P), C.byref(b), stream_ptr(), _graph_cache(dev)), "misplat_raster_bwd")
             PATH_STATS["backward_one_call"] += 1
-            PATH_STATS["backward_background_fill"] += int(lib.misplat_raster_bwd_plan(C.byref(P), C.byref(b)) & 1)
+            PATH_STATS["backward_background_fill"] += sparse
             if GRAD_SINK is not None:
                 PATH_STATS["backward_sink"] += 1
                 GRAD_SINK.rasterizer_done()
         else:
             # a gradient that reached means2d from another consumer: stage by stage
             PATH_STATS["backward_staged"] += 1
+            if on_touch:
+                flags &= ~1
+                PATH_STATS["backward_rows_refilled"] += 1
             _with_perm = C.c_void_p(perm.data_ptr()) if perm is not None else None
             P.unit_perm = _with_perm
             check(lib.misplat_blend_bwd_atomic(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
@@ -1009,7 +1033,10 @@ class _RasterFused(torch.autograd.Function):
         # gsplat's contract: the screen-space gradient rides on meta["means2d"]
         m2d = ctx.means2d_ref()
         if m2d is not None:
-            g2d = v_grec.view(P.n_cams, P.n_gauss, MISPLAT_REC)[..., 0:2]
+            if simple and v_m2d is not None:
+                g2d = v_m2d.view(P.n_cams, P.n_gauss, 2)
+            else:
+                g2d = v_grec.view(P.n_cams, P.n_gauss, MISPLAT_REC)[..., 0:2]
             m2d.grad = g2d if v_means2d_in is None else g2d + v_means2d_in
             if ctx.absgrad:
                 m2d.absgrad = v_abs.view(P.n_cams, P.n_gauss, 2)
@@ -1263,7 +1290,7 @@ def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
     if bins["slots"] is None:                      # binned in atomic mode (ops.DETERMINISTIC_BACKWARD was False)
         # the one-entry forward left a cleared gradient buffer behind (written by the colour kernel): first backward only
         v_grec = bins.pop("v_grec_zero", None)
-        prezeroed = v_grec is not None
+        prezeroed = v_grec is not None and not bins.get("rows_on_touch")
         if v_grec is None:
             v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
         v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None

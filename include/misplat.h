@@ -446,7 +446,10 @@ typedef struct misplat_raster_args {
                                goes through a graph cache (two parallel branches) */
     int32_t lazy_colour;    /* != 0 (SH colours with K = 16, one pass, ppl 2/2 only): no colour kernel -- the compositing
                                forward evaluates the colour of a record when it first stages it (misplat_blend_fwd_lazy);
-                               sh_aux is not written */
+                               sh_aux is not written.  2: in addition v_grec_zero is NOT cleared as a whole -- only the
+                               rows of the records whose colour gets set, which are the only rows the compositing backward
+                               adds into: for a backward that reads flagged rows only (misplat_raster_bwd_plan bit 0);
+                               any other backward must clear v_grec first (zero_flags bit 0 unset) */
     /* per (camera, Gaussian) outputs */
     int32_t* radii;
     float *means2d, *depths, *compensations, *grec, *sh_aux /* or NULL */;
@@ -513,6 +516,10 @@ typedef struct misplat_raster_bwd_args {
     /* measurement (or NULL): two hipEvent_t recorded on `stream` directly before and after the compositing backward; a
      * call that carries them is launched plainly (no graph) */
     void *ev_blend_begin, *ev_blend_end;
+    /* or NULL: [N,2], the mean2d gradient as a tensor of its own (zeros where no gradient arrived) -- written by the
+     * two-launch form only (misplat_raster_bwd_plan bit 0), where v_grec may hold defined values in flagged rows only
+     * (misplat_raster_args.lazy_colour = 2) and cannot be sliced for it */
+    float* v_means2d_out;
 } misplat_raster_bwd_args;
 int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
                        misplat_graph_cache* cache /* or NULL */);

@@ -1337,11 +1337,17 @@ def test_background_fill_and_sparse_backward_equal_the_dense_backward(dev):
     zeros that extra workgroups of the compositing kernel's own grid wrote into the (uninitialised) gradient tensors:
     every row without a gradient must be exactly zero -- the allocator is seeded with NaNs first -- and the others equal
     the dense per-Gaussian backward of the two-node form (no row flags) up to the order of the atomic sums."""
+    from collab_splats_amd import ops
     args = _bench_like_scene(dev, 300_000, 640, 360, seed=9, scale_mul=1.5)
     ref_img, ref_grad, _ = _fwd_bwd(args, FUSED_NODE=False)
+    before = dict(ops.PATH_STATS)
     for rep in range(3):                                       # (capacity hint, merged phases, graph replay; lazy colours once dense)
+        # the next allocations of these sizes come back full of NaNs: the output gradients, and the packed gradient rows
+        # [N,16] -- which, with on-demand colours, nothing clears as a whole: the forward clears the row of each record
+        # whose colour it sets (misplat_raster_args.lazy_colour = 2), and those are the only rows the backward reads
         poison = [torch.full((300_000 * 48 + 64 * k,), float("nan"), device=dev) for k in range(4)]
-        del poison                                             # the next allocations of this size come back full of NaNs
+        poison += [torch.full((300_000 * 16,), float("nan"), device=dev) for k in range(3)]
+        del poison
         img, grad, _ = _fwd_bwd(args)
         for a, b in zip(img, ref_img):
             assert torch.equal(a, b)
@@ -1350,6 +1356,47 @@ def test_background_fill_and_sparse_backward_equal_the_dense_backward(dev):
             assert rel_err(a, b) < 2e-5, (rep, k, rel_err(a, b))
             dead = b.reshape(b.shape[0], -1).abs().sum(1) == 0
             assert bool(dead.any()) and float(a.reshape(a.shape[0], -1)[dead].abs().sum()) == 0.0, (rep, k)
+    took = {k: v - before.get(k, 0) for k, v in ops.PATH_STATS.items()}
+    assert took.get("forward_lazy_colour", 0) >= 1 and took.get("forward_rows_on_touch", 0) == took["forward_lazy_colour"], took
+    assert took.get("backward_rows_refilled", 0) == 0, took
+
+
+def test_rows_cleared_on_first_touch_are_refilled_for_a_backward_that_reads_every_row(dev):
+    """A forward that cleared the packed gradient rows only where it set a colour (on-demand colours, >= 262 144
+    Gaussians), followed by a backward that is NOT the flagged-rows one: a loss on ``meta["means2d"]`` sends the call down
+    the stage-by-stage backward, whose per-Gaussian kernels read every visible row -- the rows are then cleared as a
+    whole first (the allocator is seeded with NaNs).  Gradients equal those of the same loss with the scheme switched off."""
+    from collab_splats_amd import ops, rasterization
+    args = _bench_like_scene(dev, 300_000, 640, 360, seed=9, scale_mul=1.5)
+    kw = dict(sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True)
+
+    def run(on_touch):
+        old = ops.ROWS_ON_TOUCH
+        ops.ROWS_ON_TOUCH = on_touch
+        try:
+            res = None
+            for rep in range(3):                               # (on-demand colours start once the capacity hint says "dense")
+                poison = [torch.full((300_000 * 16,), float("nan"), device=dev) for k in range(3)]
+                del poison
+                leaves = [t.clone().requires_grad_(True) for t in args[:5]]
+                out = rasterization(*leaves, *args[5:], **kw)
+                ups = [u.to(dev) for u in upstream([t.shape for t in out[:5]], dtype=torch.float32)]
+                loss = sum((o * u).sum() for o, u in zip(out[:5], ups)) + (out[5]["means2d"] * 1e-3).sum()
+                loss.backward()
+                torch.cuda.synchronize()
+                res = [l.grad.clone() for l in leaves]
+            return res
+        finally:
+            ops.ROWS_ON_TOUCH = old
+
+    before = dict(ops.PATH_STATS)
+    got = run(True)
+    took = {k: v - before.get(k, 0) for k, v in ops.PATH_STATS.items()}
+    assert took.get("forward_rows_on_touch", 0) >= 1 and took.get("backward_rows_refilled", 0) == took["forward_rows_on_touch"], took
+    ref = run(False)
+    for k, (a, b) in enumerate(zip(got, ref)):
+        assert torch.isfinite(a).all(), k
+        assert rel_err(a, b) < 2e-5, (k, rel_err(a, b))
 
 
 @pytest.mark.parametrize("N,W,H,scale_mul,two_cams", [(30_000, 640, 360, 1.0, False), (300_000, 640, 360, 1.5, False),
