@@ -524,6 +524,7 @@ __device__ __forceinline__ void apply_activations(const misplat_params& P, float
 // Record layout (MISPLAT_REC floats): [0:2] mean2d [2:5] conic [5] opacity_eff [6] ray_t
 // [7:9] ray_plane [9:12] normal [12:16] colour channels.
 // ================================================================================================
+constexpr int kRecPlane = 256 + 4;
 __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
     misplat_params P, const float* __restrict__ means, const float* __restrict__ quats,
     const float* __restrict__ scales, const float* __restrict__ opacities,
@@ -550,9 +551,12 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
                     if (e4 < 4 * total) lazy_rows[e4] = z;
                 }
             }
-            if (idx < total) { const float u_ = __uint_as_float(0x7fc0deadu); grec[4 * idx + 3] = make_float4(u_, u_, u_, u_); }
         }
-        if (idx >= total) continue;
+        // the 64-byte records leave through LDS as whole lines (one 16-byte slot per lane, consecutive lanes on consecutive
+        // slots) instead of four 16-byte stores per lane at a stride of 64 bytes; planes of 256 + 4 slots: conflict-free
+        // both ways.  Slot 3 (colours) is written only with on-demand colours, as UNSET.
+        __shared__ float4 rec_sm[4 * kRecPlane];
+        if (idx < total) {
         if (P.touched) P.touched[idx] = 0;
         if (abs_rows) abs_rows[idx] = make_float2(0.f, 0.f);      // the |mean2d gradient| rows the backward adds into
         const int cam_i = (int)(idx / P.n_gauss);
@@ -603,9 +607,22 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
         radii[2 * idx] = rxi; radii[2 * idx + 1] = ryi;
         means2d[2 * idx] = mx; means2d[2 * idx + 1] = my;
         depths[idx] = dep; comps[idx] = comp;
-        grec[4 * idx + 0] = make_float4(mx, my, cn0, cn1);
-        grec[4 * idx + 1] = make_float4(cn2, oeff, rt, rp[0]);
-        grec[4 * idx + 2] = make_float4(rp[1], nr[0], nr[1], nr[2]);
+        const float u_ = __uint_as_float(0x7fc0deadu);
+        rec_sm[threadIdx.x] = make_float4(mx, my, cn0, cn1);
+        rec_sm[kRecPlane + threadIdx.x] = make_float4(cn2, oeff, rt, rp[0]);
+        rec_sm[2 * kRecPlane + threadIdx.x] = make_float4(rp[1], nr[0], nr[1], nr[2]);
+        rec_sm[3 * kRecPlane + threadIdx.x] = make_float4(u_, u_, u_, u_);
+        }
+        __syncthreads();
+        {
+            const int64_t base4 = 4 * (idx - threadIdx.x);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int j = threadIdx.x + u * 256;                   // slot j of the block = (row j / 4, plane j % 4)
+                if (base4 + j < 4 * total && ((j & 3) != 3 || lazy_rows)) grec[base4 + j] = rec_sm[(j & 3) * kRecPlane + (j >> 2)];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1138,6 +1155,12 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float4* __restrict__ dst
     if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail[threadIdx.x] = 0.f;
 }
 
+#ifndef MISPLAT_SPARSE_FPL
+#define MISPLAT_SPARSE_FPL 8
+#endif
+#ifndef MISPLAT_SPARSE_MAXWAVES
+#define MISPLAT_SPARSE_MAXWAVES 2048
+#endif
 constexpr int kFlagStep = 512;          // rows a wave of the sparse backward kernels scans per step (8 flag bytes per lane)
 
 // SH backward of one row whose colour gradient is non-zero (no Jacobian cache): coefficients in, the clamp from a
@@ -1487,16 +1510,19 @@ __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
         }
     };
     int qn = 0;
-    for (int64_t base = (int64_t)blockIdx.x * kFlagStep; base < P.n_gauss; base += (int64_t)gridDim.x * kFlagStep) {
-        const int64_t r0 = base + 8 * lane;
+    constexpr int FPL = MISPLAT_SPARSE_FPL;      // flag bytes per lane and step
+    for (int64_t base = (int64_t)blockIdx.x * (64 * FPL); base < P.n_gauss; base += (int64_t)gridDim.x * (64 * FPL)) {
+        const int64_t r0 = base + FPL * lane;
         unsigned long long fl = 0ull;
-        if (r0 + 8 <= P.n_gauss) fl = *reinterpret_cast<const unsigned long long*>(P.touched + r0);
-        else
-            for (int b = 0; b < 8; b++)
+        if (r0 + FPL <= P.n_gauss) {
+            if (FPL == 8) fl = *reinterpret_cast<const unsigned long long*>(P.touched + r0);
+            else fl = *reinterpret_cast<const uint32_t*>(P.touched + r0);
+        } else
+            for (int b = 0; b < FPL; b++)
                 if (r0 + b < P.n_gauss) fl |= (unsigned long long)P.touched[r0 + b] << (8 * b);
         if (__ballot(fl != 0ull) == 0ull) continue;
 #pragma unroll 1
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < FPL; b++) {
             const bool live = (fl & 0xffull) != 0ull;
             const unsigned long long mask = __ballot(live);
             if (live) queue[qn + __popcll(mask & lt)] = (int)(r0 + b);
@@ -1730,8 +1756,8 @@ int misplat_internal::gauss_bwd_sparse(const misplat_params* p, int32_t sh_degre
     if ((coeffs_rest != nullptr) != (v_coeffs_rest != nullptr)) return MISPLAT_EINVAL;
     if ((((uintptr_t)p->touched) & 7) || (((uintptr_t)coeffs | (uintptr_t)v_coeffs | (uintptr_t)v_grec | (uintptr_t)v_quats) & 15))
         return MISPLAT_EINVAL;
-    int64_t waves = ((int64_t)p->n_gauss + kFlagStep - 1) / kFlagStep;
-    if (waves > 2048) waves = 2048;
+    int64_t waves = ((int64_t)p->n_gauss + 64 * MISPLAT_SPARSE_FPL - 1) / (64 * MISPLAT_SPARSE_FPL);
+    if (waves > MISPLAT_SPARSE_MAXWAVES) waves = MISPLAT_SPARSE_MAXWAVES;
     if (coeffs_rest)
         hipLaunchKernelGGL(gauss_bwd_sparse_kernel<true>, dim3((unsigned)waves), dim3(64), 0, s, *p, sh_degree, depth_slot, means,
                            quats, scales, opacities, viewmats, Ks, coeffs, coeffs_rest, compensations, v_grec, v_coeffs,

@@ -1652,7 +1652,8 @@ def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H
     (log-scales, logits) reused call after call with ``scales_are_log`` / ``opacities_are_logit``, both phases in one
     launch with a speculative capacity, graph replay, the previous step's launch order, on-demand SH colours, ``touched``
     row flags + background fill + the one-launch per-Gaussian backward -- compared DIRECTLY with the C restatement on the
-    SIXTH call (graphs are captured when an argument block is seen a second time and replayed from the third): integer
+    EIGHTH call (graphs are captured when an argument block is seen a second time and replayed from the third; the
+    allocator may alternate between two or three sets of addresses, each an argument block of its own): integer
     stages bit for bit, images and the gradients of the RAW parameters within 1e-4 or a proven
     threshold flip.  The C port is given the activated values as the device computes them (expf / sigmoid: the kernels use
     the expressions of torch's own device kernels, so torch.exp / torch.sigmoid on the GPU yield the same bits); its
@@ -1676,7 +1677,7 @@ def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H
     ops._CAP_HINT.pop(ops._cap_key(ops._lib.make_params(N, 1, W, H), dev), None)
     before = dict(ops.PATH_STATS)
     out = None
-    n_calls = 6
+    n_calls = 8
     for call in range(n_calls):
         for l in leaves:
             l.grad = None
