@@ -17,8 +17,9 @@ one fixed view}, each measured with the same protocol right after the headline (
 --ext-activations / --fixed-view make one of the other corners the headline.  With N GPUs every rank renders its own
 views of its own replica (configs[3]: independent views, no collective, weak scaling).  --shared-grads: all ranks hold
 the SAME Gaussians, render different views and all-reduce the 236 B/Gaussian gradients over RCCL; with --dn-loss the step
-is the model mirror's get_outputs -> L1 + depth-normal consistency loss -> backward (configs[4] per GPU minus the SSIM
-term of the Splatfacto base loss, which is third-party and not built; use --gaussians 5000000).
+is the model mirror's get_outputs -> get_loss_dict (Splatfacto's main_loss = 0.8 L1 + 0.2 (1 - SSIM) + the depth-normal
+consistency loss) -> backward (configs[4] per GPU; use --gaussians 5000000; --no-ssim: the L1 + depth-normal step that
+rounds 1-2 reported).
 Inputs are resident in HBM before the timed region.
 
 Protocol: W untimed steps, then EXACTLY K steps between two barrier+synchronize fences,
@@ -70,7 +71,9 @@ def parse():
                     help="attach a parallel.GradientBuckets sink even on one GPU (no collective): measures what the "
                          "data-parallel backward costs on top of the plain one")
     ap.add_argument("--dn-loss", action="store_true",
-                    help="step = RadegsModel.get_outputs -> L1 + depth-normal consistency loss -> backward (configs[4])")
+                    help="step = RadegsModel.get_outputs -> main_loss (L1 + SSIM) + depth-normal consistency loss -> backward "
+                         "(configs[4])")
+    ap.add_argument("--no-ssim", action="store_true", help="--dn-loss without the SSIM half of main_loss (ssim_lambda = 0)")
     ap.add_argument("--graphed", action="store_true",
                     help="capture the whole step (activations, forward, backward) into ONE hipGraph with a fixed "
                          "intersection capacity (collab_splats_amd.graphs.GraphedStep) and time its replays: the "
@@ -298,8 +301,9 @@ def main():
 
     if args.dn_loss:
         # configs[4] per GPU: the model mirror (a1 + a2 + a3 + a4 + a5) with the depth-normal consistency loss active
-        # (its activations are inside the kernels; the base loss is L1 only -- no SSIM)
-        cfg = radegs.RadegsModelConfig(rasterize_mode=args.rasterize_mode, regularization_from_iter=0)
+        # (its activations are inside the kernels; main_loss = 0.8 L1 + 0.2 (1 - SSIM) as Splatfacto has it)
+        cfg = radegs.RadegsModelConfig(rasterize_mode=args.rasterize_mode, regularization_from_iter=0,
+                                       ssim_lambda=0.0 if args.no_ssim else 0.2)
         model = radegs.RadegsModel(cfg, sc["means"], sc["log_scales"], sc["quats"], sc["opacity_logits"], sc["sh"][:, 0],
                                    sc["sh"][:, 1:]).to(dev)
         model.train()
@@ -460,9 +464,9 @@ def main():
         vif = pmc.get("valu_issue_frac")
         view_txt = ("one fixed view" if headline_mode["fixed"] else "8 cycling views (configs[3]'s cameras, one per step)")
         if args.dn_loss:
-            wl = (f"{N} shared Gaussians, {view_txt} {W}x{H} per GPU, model mirror get_outputs -> L1 + depth-normal "
-                  f"consistency loss (no SSIM: the Splatfacto base loss is third-party) -> backward (BASELINE configs[4] per GPU); "
-                  f"activations inside the projection kernels")
+            img_loss = "L1 (no SSIM: --no-ssim)" if args.no_ssim else "main_loss = 0.8 L1 + 0.2 (1 - SSIM) (Splatfacto's, restated)"
+            wl = (f"{N} shared Gaussians, {view_txt} {W}x{H} per GPU, model mirror get_outputs -> {img_loss} + depth-normal "
+                  f"consistency loss -> backward (BASELINE configs[4] per GPU); activations inside the projection kernels")
         else:
             wl = (f"{N} random Gaussians, {view_txt} {W}x{H} per GPU, SH degree 3, {args.render_mode} "
                   f"({args.rasterize_mode}), colour+alpha+expected/median depth+normal, fwd+bwd to all six parameter tensors; "

@@ -107,6 +107,7 @@ SYMBOLS = {
     "misplat_blend_planes": (C.c_int, 1), "misplat_blend_bwd_atomic": (C.c_int, 20), "misplat_slab_reduce": (C.c_int, 11), "misplat_depth_normal_fwd": (C.c_int, 10),
     "misplat_depth_normal_bwd": (C.c_int, 14), "misplat_outputs_fwd": (C.c_int, 15), "misplat_outputs_bwd": (C.c_int, 16),
     "misplat_loss_fwd": (C.c_int, 11), "misplat_loss_bwd": (C.c_int, 11),
+    "misplat_ssim_scratch_floats": (C.c_int64, 2), "misplat_ssim_fwd": (C.c_int, 10), "misplat_ssim_bwd": (C.c_int, 9),
     "misplat_bucket_plan": (C.c_int, 3), "misplat_bucket_count": (C.c_int, 10), "misplat_bucket_rows": (C.c_int, 14),
     "misplat_bucket_tiles": (C.c_int, 11),
     "misplat_unit_order": (C.c_int, 5), "misplat_raster_fwd": (C.c_int, 5), "misplat_raster_bwd": (C.c_int, 4), "misplat_raster_bwd_plan": (C.c_int, 2), "misplat_graph_cache_create": (C.c_void_p, 1),

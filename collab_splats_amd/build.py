@@ -30,6 +30,7 @@ SOURCES = {
     "raster.hip": [],
     "blend.hip": [],
     "epilogue.hip": [],
+    "ssim.hip": [],
     "sort.hip": [],
     "optim.hip": [],
 }

@@ -1622,7 +1622,7 @@ class _MeanLosses(torch.autograd.Function):
     are the two error maps (then e1 / e2 are ignored), or None with e1 / e2 given separately."""
 
     @staticmethod
-    def forward(ctx, rgb, gt, err, e1, e2, depth_ratio: float, lam: float):
+    def forward(ctx, rgb, gt, err, e1, e2, depth_ratio: float, lam: float, ssim_lambda: float = 0.0):
         lib = _lib.load()
         with_rgb = rgb is not None and gt is not None
         if err is not None:
@@ -1639,6 +1639,22 @@ class _MeanLosses(torch.autograd.Function):
         check(lib.misplat_loss_fwd(C.c_int64(n_pix), ptr(rgb if with_rgb else None), ptr(gt if with_rgb else None),
                                    ptr(e1 if with_dn else None), ptr(e2 if with_dn else None), C.c_float(depth_ratio),
                                    C.c_float(lam), ptr(partials), ptr(rgb_loss), ptr(dn_loss), stream_ptr()), "misplat_loss_fwd")
+        # the base model's image loss (Splatfacto: (1 - l) L1 + l (1 - SSIM)): two more launches that take the L1 mean from
+        # the device scalar above and leave the derivative maps of the SSIM for the backward
+        ctx.ssim = None
+        if with_rgb and ssim_lambda > 0.0:
+            H, W = int(rgb.shape[-3]), int(rgb.shape[-2])
+            if rgb.shape[-1] != 3 or rgb.numel() != 3 * H * W:
+                raise ValueError("mean_losses: the SSIM term takes one [H,W,3] image")
+            n_scratch = int(lib.misplat_ssim_scratch_floats(C.c_int32(H), C.c_int32(W)))
+            if n_scratch < 0:
+                raise ValueError(f"mean_losses: the SSIM window needs an image of at least 11 x 11 pixels (got {H} x {W})")
+            scratch = torch.empty(n_scratch, device=dev, dtype=torch.float32)
+            main = torch.empty((), device=dev, dtype=torch.float32)
+            check(lib.misplat_ssim_fwd(C.c_int32(H), C.c_int32(W), ptr(rgb), ptr(gt), ptr(scratch), ptr(rgb_loss),
+                                       C.c_float(ssim_lambda), None, ptr(main), stream_ptr()), "misplat_ssim_fwd")
+            ctx.ssim = (H, W, scratch, float(ssim_lambda))
+            rgb_loss = main
         ctx.save_for_backward(*(t for t in (rgb, gt) if with_rgb))
         ctx.with_rgb, ctx.with_dn, ctx.packed, ctx.n_pix = with_rgb, with_dn, err is not None, n_pix
         ctx.err_shape = tuple(err.shape) if err is not None else (tuple(e1.shape) if with_dn else None)
@@ -1663,24 +1679,32 @@ class _MeanLosses(torch.autograd.Function):
             else:
                 v_e1 = torch.empty(ctx.err_shape, device=ctx.dev, dtype=torch.float32)
                 v_e2 = torch.empty(ctx.err_shape, device=ctx.dev, dtype=torch.float32)
-        if want_rgb or want_dn:
-            g1 = g_rgb.to(torch.float32).contiguous() if want_rgb else None
-            g2 = g_dn.to(torch.float32).contiguous() if want_dn else None
-            check(lib.misplat_loss_bwd(C.c_int64(ctx.n_pix), ptr(rgb if want_rgb else None), ptr(gt if want_rgb else None),
-                                       ptr(g1), ptr(g2), C.c_float(ctx.k[0]), C.c_float(ctx.k[1]), ptr(v_rgb), ptr(v_e1),
-                                       ptr(v_e2), stream_ptr()), "misplat_loss_bwd")
+        g1 = g_rgb.to(torch.float32).contiguous() if want_rgb else None
+        g2 = g_dn.to(torch.float32).contiguous() if want_dn else None
+        l1_here = want_rgb and ctx.ssim is None
+        if want_rgb and ctx.ssim is not None:                         # both halves of the image term in one launch
+            H, W, scratch, ssim_lambda = ctx.ssim
+            check(lib.misplat_ssim_bwd(C.c_int32(H), C.c_int32(W), ptr(rgb), ptr(gt), ptr(scratch), ptr(g1),
+                                       C.c_float(ssim_lambda), ptr(v_rgb), stream_ptr()), "misplat_ssim_bwd")
+        if l1_here or want_dn:
+            check(lib.misplat_loss_bwd(C.c_int64(ctx.n_pix), ptr(rgb if l1_here else None), ptr(gt if l1_here else None),
+                                       ptr(g1 if l1_here else None), ptr(g2), C.c_float(ctx.k[0]), C.c_float(ctx.k[1]),
+                                       ptr(v_rgb if l1_here else None), ptr(v_e1), ptr(v_e2), stream_ptr()), "misplat_loss_bwd")
         if ctx.packed:
-            return v_rgb, None, v_err, None, None, None, None
-        return v_rgb, None, None, v_e1, v_e2, None, None
+            return v_rgb, None, v_err, None, None, None, None, None
+        return v_rgb, None, None, v_e1, v_e2, None, None, None
 
 
-def mean_losses(rgb, gt, err=None, e1=None, e2=None, depth_ratio: float = 0.0, depth_normal_lambda: float = 0.0):
+def mean_losses(rgb, gt, err=None, e1=None, e2=None, depth_ratio: float = 0.0, depth_normal_lambda: float = 0.0,
+                ssim_lambda: float = 0.0):
     """(rgb_loss or None, depth_normal_loss or None): mean |gt - rgb| and lambda * ((1 - r) * mean(e1) + r * mean(e2)).
-    Contiguous float32 GPU tensors; ``err`` [2,...] packs e1 / e2 (its gradient then arrives as one tensor)."""
+    Contiguous float32 GPU tensors; ``err`` [2,...] packs e1 / e2 (its gradient then arrives as one tensor).
+    ``ssim_lambda`` > 0: the first value is the base model's ``main_loss`` = (1 - l) mean |gt - rgb| + l (1 - SSIM(gt, rgb))
+    of one [H,W,3] image (misplat_ssim_fwd / misplat_ssim_bwd)."""
     def ok(t):
         return t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous())
     if not all(ok(t) for t in (rgb, gt, err, e1, e2)):
         raise ValueError("mean_losses: contiguous float32 GPU tensors only")
     if rgb is not None and gt is not None and rgb.shape != gt.shape:
         raise ValueError("mean_losses: image and ground truth differ in shape")
-    return _MeanLosses.apply(rgb, gt, err, e1, e2, float(depth_ratio), float(depth_normal_lambda))
+    return _MeanLosses.apply(rgb, gt, err, e1, e2, float(depth_ratio), float(depth_normal_lambda), float(ssim_lambda))

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from torch import Tensor, nn
 
 from . import ops
-from ._lib import make_params
+from ._lib import MisplatError, make_params
 from .rendering import rasterization
 from .strategy import DefaultStrategy
 
@@ -208,6 +208,11 @@ class RadegsModelConfig:
     output_depth_during_training: bool = False
     background_color: str = "black"
     absgrad: bool = False
+    # Splatfacto's image loss [UNVERIFIED-UPSTREAM]: main_loss = (1 - ssim_lambda) L1 + ssim_lambda (1 - SSIM); scale
+    # regularisation (PhysGaussian) off by default, applied every 10th step when on
+    ssim_lambda: float = 0.2
+    use_scale_regularization: bool = False
+    max_gauss_ratio: float = 10.0
 
 
 class RadegsModel(nn.Module):
@@ -426,10 +431,24 @@ class RadegsModel(nn.Module):
                 out["normals"].append(ep[3]); out["accumulation"].append(alpha[sl])
         return {k: torch.cat(v, dim=0) for k, v in out.items()}
 
+    def _scale_reg(self, dev) -> Tensor:
+        """Splatfacto's scale regularisation: 0.1 * mean(max(max(s) / min(s), max_gauss_ratio) - max_gauss_ratio) of the
+        activated scales, every 10th step; 0 otherwise [UNVERIFIED-UPSTREAM]."""
+        if self.config.use_scale_regularization and self.step % 10 == 0:
+            scale_exp = torch.exp(self.scales)
+            ratio = scale_exp.amax(dim=-1) / scale_exp.amin(dim=-1)
+            cap = torch.tensor(self.config.max_gauss_ratio, device=ratio.device, dtype=ratio.dtype)
+            return 0.1 * (torch.maximum(ratio, cap) - self.config.max_gauss_ratio).mean()
+        zero = self.__dict__.get("_zero_scalar")                       # (one device scalar, not a host-to-device copy per step)
+        if zero is None or zero.device != torch.device(dev):
+            zero = self.__dict__["_zero_scalar"] = torch.zeros((), device=dev)
+        return zero
+
     def get_loss_dict(self, outputs, batch, metrics_dict=None) -> Dict[str, Tensor]:
-        """rade_gs_model.py:274-309.  The Splatfacto base loss (L1 + SSIM, third-party, absent) is
-        represented by its L1 term only.  On the GPU the means and their backward are one autograd node
-        (``ops.mean_losses``: three launches in all instead of ~30 small ones)."""
+        """rade_gs_model.py:274-309.  ``super().get_loss_dict`` (:289) is nerfstudio's Splatfacto (third-party, absent from
+        the reference tree) [UNVERIFIED-UPSTREAM]: ``main_loss`` = (1 - ssim_lambda) * mean |gt - rgb| + ssim_lambda *
+        (1 - SSIM(gt, rgb)) and ``scale_reg``; the depth-normal term (:291-307) is added to it.  On the GPU the means, the
+        SSIM and their backward are one autograd node (``ops.mean_losses``: a handful of launches instead of ~60)."""
         loss_dict: Dict[str, Tensor] = {}
         rgb = outputs["rgb"]
         gt = batch["image"].to(rgb.device) if batch is not None and "image" in batch else None
@@ -446,16 +465,22 @@ class RadegsModel(nn.Module):
             base = e1._base if with_dn and e1._base is not None and e1._base is e2._base else None
             packed = (base is not None and base.dim() == 3 and base.shape[0] == 2 and base.is_contiguous()
                       and e1.data_ptr() == base.data_ptr() and e2.data_ptr() == base[1].data_ptr())
-            rgb_loss, dn_loss = ops.mean_losses(rgb if gt is not None else None, gt, base if packed else None,
-                                                None if packed else e1, None if packed else e2,
-                                                self.config.depth_ratio, self.config.depth_normal_lambda)
+            main_loss, dn_loss = ops.mean_losses(rgb if gt is not None else None, gt, base if packed else None,
+                                                 None if packed else e1, None if packed else e2,
+                                                 self.config.depth_ratio, self.config.depth_normal_lambda,
+                                                 ssim_lambda=self.config.ssim_lambda if gt is not None else 0.0)
             if gt is not None:
-                loss_dict["rgb_loss"] = rgb_loss
+                loss_dict["main_loss"] = main_loss
+                loss_dict["scale_reg"] = self._scale_reg(rgb.device)
             if with_dn:
                 loss_dict["depth_normal_loss"] = dn_loss
             return loss_dict
         if gt is not None:
-            loss_dict["rgb_loss"] = torch.abs(gt - rgb).mean()
+            if self.config.ssim_lambda > 0:
+                raise MisplatError("get_loss_dict: the SSIM term of main_loss runs on the GPU only (contiguous float32 CUDA "
+                                   "images of equal shape); there is no CPU fallback")
+            loss_dict["main_loss"] = torch.abs(gt - rgb).mean()
+            loss_dict["scale_reg"] = self._scale_reg(rgb.device)
         if with_dn:
             depth_normal_loss = ((1 - self.config.depth_ratio) * e1.mean() + self.config.depth_ratio * e2.mean())
             loss_dict["depth_normal_loss"] = self.config.depth_normal_lambda * depth_normal_loss

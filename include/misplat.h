@@ -427,6 +427,23 @@ int misplat_loss_bwd(int64_t n_pix, const float* rgb, const float* gt, const flo
                      float depth_ratio, float depth_normal_lambda, float* v_rgb, float* v_err_exp, float* v_err_med,
                      misplat_stream_t stream);
 
+/* ---- the image term of the loss the model inherits (rade_gs_model.py:289 `super().get_loss_dict`: nerfstudio Splatfacto,
+ * third-party and absent from the reference tree) [UNVERIFIED-UPSTREAM]:
+ *   main_loss = (1 - ssim_lambda) * mean |gt - rgb| + ssim_lambda * (1 - SSIM(gt, rgb)),
+ * SSIM as pytorch_msssim.SSIM(data_range=1.0, size_average=True, channel=3): 11-tap gaussian window (sigma 1.5), valid
+ * region (H - 10) x (W - 10), K = (0.01, 0.03), mean over positions and channels.  rgb / gt: [H,W,3]; H, W >= 11.
+ * scratch: misplat_ssim_scratch_floats(H, W) floats, written by the forward (three derivative maps + tile sums) and read
+ * by the backward.  l1_loss: DEVICE scalar mean |gt - rgb| (misplat_loss_fwd's rgb_loss) or NULL = 0; ssim / main_loss:
+ * device scalars (either may be NULL).  Two launches; reproducible bit for bit (fixed tiles, fp64 final sum). */
+int64_t misplat_ssim_scratch_floats(int32_t height, int32_t width);
+int misplat_ssim_fwd(int32_t height, int32_t width, const float* rgb, const float* gt, float* scratch,
+                     const float* l1_loss /* or NULL */, float ssim_lambda, float* ssim /* or NULL */,
+                     float* main_loss /* or NULL */, misplat_stream_t stream);
+/* v_rgb[H,W,3] = g_main * d main_loss / d rgb (both terms: the L1 sign gradient and the transposed window filter of the
+ * forward's maps); g_main: DEVICE scalar (or NULL = 0).  One launch, no atomics. */
+int misplat_ssim_bwd(int32_t height, int32_t width, const float* rgb, const float* gt, const float* scratch,
+                     const float* g_main, float ssim_lambda, float* v_rgb, misplat_stream_t stream);
+
 /* ---- the whole forward of rasterization() (rade_gs_model.py:439-465) as ONE host entry: csrc/raster.hip.
  * Every pointer is a caller-allocated device buffer of the size the per-stage entry points above document
  * (n_isects_host: 8 bytes of PINNED host memory).

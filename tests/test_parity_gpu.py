@@ -620,7 +620,7 @@ def test_model_get_outputs_and_loss(dev):
     empty = acc[..., 0] == 0
     assert empty.any() and torch.all(out["depth"][..., 0][empty] == out["depth"].max())   # where(alpha>0, x, max)
     loss = model.get_loss_dict(out, {"image": torch.rand(H, W, 3)})
-    assert set(loss) == {"rgb_loss", "depth_normal_loss"}
+    assert set(loss) == {"main_loss", "scale_reg", "depth_normal_loss"}       # Splatfacto's keys + the depth-normal term
     sum(loss.values()).backward()
     for k, p in model.gauss_params.items():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
@@ -1043,7 +1043,7 @@ def test_config5_five_million_model_step_with_depth_normal_loss(dev):
             p.grad = None
         out = model.get_outputs(cam)
         loss = model.get_loss_dict(out, {"image": target})
-        assert set(loss) == {"rgb_loss", "depth_normal_loss"}
+        assert set(loss) == {"main_loss", "scale_reg", "depth_normal_loss"}
         (scale * sum(loss.values())).backward()
         return {k: float(v) for k, v in loss.items()}, {k: p.grad.clone() for k, p in model.gauss_params.items()}
 
@@ -1056,7 +1056,7 @@ def test_config5_five_million_model_step_with_depth_normal_loss(dev):
     finally:
         ops.set_deterministic(old)
     assert model.info["n_isects"] > 25_000_000
-    assert l1 == l1b and 0 < l1["depth_normal_loss"] < 0.05 and 0 < l1["rgb_loss"] < 1
+    assert l1 == l1b and 0 < l1["depth_normal_loss"] < 0.05 and 0 < l1["main_loss"] < 1
     assert set(g1) == {"means", "scales", "quats", "opacities", "features_dc", "features_rest"}
     for k in g1:
         assert bool(torch.isfinite(g1[k]).all()) and float(g1[k].abs().max()) > 0, k
@@ -1143,6 +1143,59 @@ def test_fused_loss_node_equals_the_torch_formulas(dev, H, W):
     assert none is None and torch.equal(dn.detach(), seen[0][1])
     dn.backward()
     assert torch.allclose(err.grad * 0.3, verr_ref, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("H,W", [(11, 11), (37, 53), (120, 200), (1080, 1920)])
+def test_main_loss_l1_plus_ssim_vs_the_pytorch_msssim_restatement(dev, H, W):
+    """The image term the model inherits from Splatfacto (rade_gs_model.py:289 -> nerfstudio, third-party)
+    [UNVERIFIED-UPSTREAM]: main_loss = 0.8 L1 + 0.2 (1 - SSIM), SSIM as pytorch_msssim computes it (11-tap gaussian,
+    valid region).  ``ops.mean_losses(..., ssim_lambda=...)`` (misplat_loss_fwd + misplat_ssim_fwd / misplat_ssim_bwd)
+    against oracle/ssim_oracle.py in fp64 with autograd: value within 2e-6, gradient image within 1e-4 of its own
+    scale; twice the same bits; the gradient scales with the upstream gradient; identical images give exactly 0 loss
+    and 0 gradient... up to rounding of 1 - SSIM; the depth-normal half of the node is unchanged by the SSIM half."""
+    from collab_splats_amd import ops
+    from oracle import ssim_oracle
+    g = torch.Generator().manual_seed(H * 7 + W)
+    gt = torch.rand(H, W, 3, generator=g)
+    # a prediction correlated with the target (a training image, not noise): SSIM well inside (0, 1)
+    pred = (gt + 0.15 * torch.randn(H, W, 3, generator=g)).clamp(0, 1)
+    lam = 0.2
+    p64 = pred.double().requires_grad_(True)
+    ref = ssim_oracle.main_loss(p64, gt.double(), lam)
+    ref.backward()
+    rgb = pred.to(dev).requires_grad_(True)
+    gtd = gt.to(dev)
+    main, none = ops.mean_losses(rgb, gtd, ssim_lambda=lam)
+    assert none is None
+    (3.0 * main).backward()
+    assert abs(float(main) - float(ref)) < 2e-6, (float(main), float(ref))
+    got = rgb.grad.cpu().double() / 3.0
+    scale = float(p64.grad.abs().max())
+    assert float((got - p64.grad).abs().max()) < 1e-4 * scale, float((got - p64.grad).abs().max()) / scale
+    rgb2 = pred.to(dev).requires_grad_(True)
+    main2, _ = ops.mean_losses(rgb2, gtd, ssim_lambda=lam)
+    (3.0 * main2).backward()
+    assert torch.equal(main2, main) and torch.equal(rgb2.grad, rgb.grad)
+    # with the depth-normal maps in the same node
+    err = torch.rand(2, H, W, generator=g).to(dev).requires_grad_(True)
+    main3, dn = ops.mean_losses(rgb2.detach().requires_grad_(True), gtd, err=err, depth_ratio=0.6, depth_normal_lambda=0.05,
+                                ssim_lambda=lam)
+    _, dn_ref = ops.mean_losses(None, None, err=err.detach().requires_grad_(True), depth_ratio=0.6, depth_normal_lambda=0.05)
+    assert torch.equal(main3, main) and torch.equal(dn, dn_ref)
+    # identical images
+    same = gtd.clone().requires_grad_(True)
+    zero, _ = ops.mean_losses(same, gtd, ssim_lambda=lam)
+    zero.backward()
+    assert abs(float(zero)) < 1e-6 and float(same.grad.abs().max()) < 1e-6 * float(rgb.grad.abs().max())
+
+
+def test_main_loss_rejects_images_smaller_than_the_ssim_window(dev):
+    from collab_splats_amd import ops
+    rgb, gt = torch.rand(10, 40, 3, device=dev), torch.rand(10, 40, 3, device=dev)
+    with pytest.raises(ValueError, match="11 x 11"):
+        ops.mean_losses(rgb, gt, ssim_lambda=0.2)
+    l1, _ = ops.mean_losses(rgb, gt)                                   # the L1 term alone has no such limit
+    assert abs(float(l1) - float((gt - rgb).abs().mean())) < 1e-6
 
 
 def _bench_like_scene(dev, N, W, H, seed, scale_mul=1.0):
