@@ -53,8 +53,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=24, help="timed steps (default: three passes over the eight views)")
+    ap.add_argument("--warmup", type=int, default=8, help="untimed steps (default: one pass over the eight views)")
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -491,7 +491,7 @@ def main():
                        "n_visible": n_vis, "parallelism": par,
                        "git_rev": git_rev(), "graph_cache": ops.graph_cache_stats(),
                        "path": {k: took.get(k, 0) for k in ("forward", "forward_lazy_colour", "forward_merged_phases",
-                                                           "forward_prev_order", "capacity_redo", "backward_one_call",
+                                                           "forward_view_order", "forward_prev_order", "capacity_redo", "backward_one_call",
                                                            "backward_background_fill", "backward_staged", "backward_sink",
                                                            "forward_rows_on_touch", "backward_rows_refilled")},
                        "path_note": f"counts over the {args.steps + args.warmup} headline steps: on-demand colours, merged "

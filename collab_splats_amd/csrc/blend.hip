@@ -54,8 +54,13 @@ __device__ __forceinline__ bool band_ctx(const misplat_params& P, const float* _
     const int per_xcd = (total + 7) >> 3;
     const int b = (int)blockIdx.x - first_block;         // (first_block: a multiple of 8, the XCD of a unit stays)
     int unit = (b & 7) * per_xcd + (b >> 3);
-    if (P.unit_perm) unit = P.unit_perm[b];      // caller-supplied launch order (longest first); the grid has exactly
-                                                 // 8 * ceil(total / 8) workgroups = entries of unit_perm (padding: total)
+    // caller-supplied launch order (longest first); the grid has exactly 8 * ceil(total / 8) workgroups = entries of a
+    // permutation (padding: total).  unit_sel: unit_perm is a table of records, {slot, valid} chosen on the device from
+    // the call's cameras (misplat_params.unit_sel); no valid record = the default map.
+    if (P.unit_perm) {
+        if (!P.unit_sel) unit = P.unit_perm[b];
+        else if (P.unit_sel[1]) unit = P.unit_perm[(size_t)P.unit_sel[0] * P.unit_stride + MISPLAT_ORDER_HEADER + b];
+    }
     if ((unsigned)unit >= (unsigned)total) return false;
     c.unit = unit;
     c.tile = unit / WPT;
@@ -1443,11 +1448,19 @@ __global__ __launch_bounds__(kDnTX * kDnTY) void depth_normal_bwd_tiled_kernel(
 // workgroup b runs on XCD b & 7 (round-robin dispatch), so strip x = units [x * per, (x + 1) * per) keeps its XCD
 // (its Gaussian records stay in that L2) and is ordered by descending work inside: perm[rank * 8 + x] = unit.
 // Counting sort on 256 work classes -- an approximate order is all a greedy scheduler needs.
+// sel (or NULL): perm is a table of records of `stride` words; the permutation goes into record sel[0], whose header takes
+// the tag sel[2..3] and becomes valid -- for the launches after this one (the backward of the same call) and for the next
+// call with the same cameras.
 __global__ __launch_bounds__(1024) void unit_order_kernel(int units, int per, const int32_t* __restrict__ work,
-                                                          int32_t* __restrict__ perm) {
+                                                          int32_t* __restrict__ perm, int32_t* __restrict__ sel, int stride) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wmax[16];
     const int x = blockIdx.x;
+    if (sel) {
+        int32_t* rec = perm + (size_t)sel[0] * stride;
+        perm = rec + MISPLAT_ORDER_HEADER;
+        if (x == 0 && threadIdx.x == 0) { rec[0] = sel[2]; rec[1] = sel[3]; rec[2] = 1; }
+    }
     const int lo = x * per, hi = min(lo + per, units);
     // (the work counts are a hint from another launch: whatever they hold -- negative, huge, changing while this kernel
     // reads them -- the result is a permutation of the strip's units and every access stays inside hist[] / perm[])
@@ -1489,6 +1502,10 @@ __global__ __launch_bounds__(1024) void unit_order_kernel(int units, int per, co
         if (rank < (uint32_t)per) perm[rank * 8 + x] = u;
     }
     for (int r = (hi > lo ? hi - lo : 0) + threadIdx.x; r < per; r += 1024) perm[r * 8 + x] = units;   // padding: no unit
+    if (sel && x == 0) {                        // (the record is complete when every strip is: the flag is only read by
+        __syncthreads();                        //  LATER launches, which see all of this kernel's stores)
+        if (threadIdx.x == 0) sel[1] = 1;
+    }
 }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH; }
@@ -1519,7 +1536,19 @@ extern "C" int misplat_unit_order(const misplat_params* p, int32_t ppl, const in
     const int q = pick_ppl(ppl, kDefaultPplFwd);
     const int units = p->tile_w * p->tile_h * p->n_cams * (4 / q);
     const int per = (units + 7) >> 3;
-    hipLaunchKernelGGL(unit_order_kernel, dim3(8), dim3(1024), 0, (hipStream_t)stream, units, per, unit_work, unit_perm);
+    hipLaunchKernelGGL(unit_order_kernel, dim3(8), dim3(1024), 0, (hipStream_t)stream, units, per, unit_work, unit_perm,
+                       (int32_t*)nullptr, 0);
+    return check_launch();
+}
+
+int misplat_internal::unit_order_table(const misplat_params* p, int32_t ppl, const int32_t* unit_work, int32_t* table,
+                                       int32_t* sel, int32_t stride, hipStream_t s) {
+    if (!params_ok(p) || !unit_work || !table || !sel) return MISPLAT_EINVAL;
+    const int q = pick_ppl(ppl, kDefaultPplFwd);
+    const int units = p->tile_w * p->tile_h * p->n_cams * (4 / q);
+    const int per = (units + 7) >> 3;
+    if (stride < MISPLAT_ORDER_HEADER + 8 * per) return MISPLAT_EINVAL;
+    hipLaunchKernelGGL(unit_order_kernel, dim3(8), dim3(1024), 0, s, units, per, unit_work, table, sel, (int)stride);
     return check_launch();
 }
 

@@ -36,11 +36,17 @@ int blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks
                      int32_t v_grec_is_zero, const FillList* fills, hipStream_t s);
 
 // misplat_project_pack_fwd whose on-demand-colour mode (lazy_rows != NULL: colour slots start UNSET) clears the gradient
-// rows only when clear_lazy_rows is set -- otherwise blend_fwd_lazy clears the rows it reaches (below).
+// rows only when clear_lazy_rows is set -- otherwise blend_fwd_lazy clears the rows it reaches (below).  order_table /
+// order_sel (or NULL): the kernel also picks the launch-order record of the call's cameras (misplat_params.unit_sel).
 int project_pack_fwd(const misplat_params* p, const float* means, const float* quats, const float* scales,
                      const float* opacities, const float* viewmats, const float* Ks, int32_t* radii, float* means2d,
                      float* depths, float* compensations, float* grec, uint32_t* zero_words, int32_t n_zero,
-                     float* lazy_rows, float* abs_rows, int32_t clear_lazy_rows, hipStream_t s);
+                     float* lazy_rows, float* abs_rows, int32_t clear_lazy_rows, const int32_t* order_table,
+                     int32_t* order_sel, int32_t order_slots, int32_t order_stride, hipStream_t s);
+
+// misplat_unit_order into the record of a view-keyed table that `sel` names (misplat_params.unit_sel).
+int unit_order_table(const misplat_params* p, int32_t ppl, const int32_t* unit_work, int32_t* table, int32_t* sel,
+                     int32_t stride, hipStream_t s);
 
 // misplat_blend_fwd_lazy that also clears row g of rows_on_touch[C*N,16] (or NULL) when it sets the colour of record g.
 int blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const float* Ks, float* grec, const int32_t* flatten_ids,

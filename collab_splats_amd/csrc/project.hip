@@ -531,11 +531,34 @@ __global__ __launch_bounds__(256) void project_pack_fwd_kernel(
     const float* __restrict__ viewmats, const float* __restrict__ Ks, int32_t* __restrict__ radii,
     float* __restrict__ means2d, float* __restrict__ depths, float* __restrict__ comps,
     float4* __restrict__ grec, uint32_t* __restrict__ zero_words, int n_zero, float4* __restrict__ lazy_rows,
-    float2* __restrict__ abs_rows, int clear_lazy_rows) {
+    float2* __restrict__ abs_rows, int clear_lazy_rows, const int32_t* __restrict__ order_table,
+    int32_t* __restrict__ order_sel, int order_slots, int order_stride) {
     // scratch the NEXT kernels of the stream accumulate into (bucketing counters): cleared here, no memset launch
     // (a few thousand words -- cell counts, cursors, tile counts: spread over the first workgroups of the grid)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_zero; i += (int64_t)gridDim.x * blockDim.x)
         zero_words[i] = 0u;
+    // View-keyed launch orders (misplat_params.unit_sel): one thread hashes the cameras of the call (FNV-1a over the
+    // bit patterns of viewmats and Ks) and looks for a record with that tag in four consecutive slots; a miss takes the
+    // first empty one of them, or evicts the home slot.  {slot, found, tag} go to order_sel for the compositing launches.
+    if (order_sel && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        unsigned long long h = 1469598103934665603ull;
+        for (int i = 0; i < 16 * P.n_cams; i++) h = (h ^ (unsigned long long)__float_as_uint(viewmats[i])) * 1099511628211ull;
+        for (int i = 0; i < 9 * P.n_cams; i++) h = (h ^ (unsigned long long)__float_as_uint(Ks[i])) * 1099511628211ull;
+        // (FNV leaves differences of high input bits -- a sign flip -- out of its low bits: cameras that mirror each other
+        // would share a home slot; murmur3's finaliser spreads them)
+        h ^= h >> 33; h *= 0xff51afd7ed558ccdull; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ull; h ^= h >> 33;
+        if (h == 0ull) h = 1ull;
+        const int32_t lo = (int32_t)(uint32_t)h, hi = (int32_t)(uint32_t)(h >> 32);
+        int found = -1, empty = -1;
+        for (int i = 0; i < 4; i++) {
+            const int sidx = (int)((h + (unsigned long long)i) % (unsigned long long)order_slots);
+            const int32_t* hd = order_table + (size_t)sidx * order_stride;
+            if (hd[2] != 0 && hd[0] == lo && hd[1] == hi) { found = sidx; break; }
+            if (hd[2] == 0 && empty < 0) empty = sidx;
+        }
+        const int slot = found >= 0 ? found : (empty >= 0 ? empty : (int)(h % (unsigned long long)order_slots));
+        order_sel[0] = slot; order_sel[1] = found >= 0 ? 1 : 0; order_sel[2] = lo; order_sel[3] = hi;
+    }
     const int64_t total = (int64_t)P.n_cams * P.n_gauss;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total + blockDim.x - 1 - (total + blockDim.x - 1) % blockDim.x;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -1620,15 +1643,18 @@ extern "C" int misplat_project_pack_fwd(const misplat_params* p, const float* me
                                         float* compensations, float* grec, uint32_t* zero_words, int32_t n_zero,
                                         float* lazy_rows, float* abs_rows, misplat_stream_t stream) {
     return misplat_internal::project_pack_fwd(p, means, quats, scales, opacities, viewmats, Ks, radii, means2d, depths,
-                                              compensations, grec, zero_words, n_zero, lazy_rows, abs_rows, 1,
-                                              (hipStream_t)stream);
+                                              compensations, grec, zero_words, n_zero, lazy_rows, abs_rows, 1, nullptr,
+                                              nullptr, 0, 0, (hipStream_t)stream);
 }
 
 int misplat_internal::project_pack_fwd(const misplat_params* p, const float* means, const float* quats,
                                        const float* scales, const float* opacities, const float* viewmats,
                                        const float* Ks, int32_t* radii, float* means2d, float* depths,
                                        float* compensations, float* grec, uint32_t* zero_words, int32_t n_zero,
-                                       float* lazy_rows, float* abs_rows, int32_t clear_lazy_rows, hipStream_t stream) {
+                                       float* lazy_rows, float* abs_rows, int32_t clear_lazy_rows,
+                                       const int32_t* order_table, int32_t* order_sel, int32_t order_slots,
+                                       int32_t order_stride, hipStream_t stream) {
+    if (order_sel && (!order_table || order_slots < 1 || order_stride < MISPLAT_ORDER_HEADER)) return MISPLAT_EINVAL;
     if (!p || p->n_gauss < 0 || p->n_cams < 1 || p->width < 1 || p->height < 1) return MISPLAT_EINVAL;
     int64_t total = (int64_t)p->n_gauss * p->n_cams;
     if (n_zero < 0 || (n_zero > 0 && !zero_words)) return MISPLAT_EINVAL;
@@ -1636,7 +1662,8 @@ int misplat_internal::project_pack_fwd(const misplat_params* p, const float* mea
     if (total > 0 && !opacities) return MISPLAT_EINVAL;
     hipLaunchKernelGGL(project_pack_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, *p,
                        means, quats, scales, opacities, viewmats, Ks, radii, means2d, depths, compensations,
-                       (float4*)grec, zero_words, n_zero, (float4*)lazy_rows, (float2*)abs_rows, (int)clear_lazy_rows);
+                       (float4*)grec, zero_words, n_zero, (float4*)lazy_rows, (float2*)abs_rows, (int)clear_lazy_rows,
+                       order_table, order_sel, (int)order_slots, (int)order_stride);
     return check_launch();
 }
 

@@ -63,7 +63,8 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         rc = misplat_internal::project_pack_fwd(p, a->means, a->quats, a->scales, a->opacities, a->viewmats, a->Ks, a->radii,
                                                 a->means2d, a->depths, a->compensations, a->grec, a->cell_count,
                                                 (int32_t)n_zero, a->lazy_colour ? a->v_grec_zero : nullptr, a->v_abs_zero,
-                                                a->lazy_colour == 2 ? 0 : 1, s);
+                                                a->lazy_colour == 2 ? 0 : 1, a->order_table, a->order_table ? a->order_sel : nullptr,
+                                                a->order_slots, a->order_stride, s);
         if (rc != MISPLAT_OK) return rc;
         rc = misplat_bucket_count(p, a->means2d, a->radii, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count,
                                   a->counters, 1, stream);
@@ -102,7 +103,10 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         if (forked && (hipEventRecord(fork->joined, fork->side) != hipSuccess || hipStreamWaitEvent(s, fork->joined, 0) != hipSuccess))
             return MISPLAT_ELAUNCH;
         misplat_params q = *p;
-        q.unit_perm = a->unit_perm_in;
+        const bool by_view = a->order_table && a->order_sel && a->unit_work;
+        q.unit_perm = by_view ? a->order_table : a->unit_perm_in;
+        q.unit_sel = by_view ? a->order_sel : nullptr;
+        q.unit_stride = by_view ? a->order_stride : 0;
         q.unit_work = a->unit_work;
         if (a->ev_blend_begin && hipEventRecord((hipEvent_t)a->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
         if (a->lazy_colour) {
@@ -117,7 +121,10 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
                                    a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, stream);
         if (rc != MISPLAT_OK) return rc;
         if (a->ev_blend_end && hipEventRecord((hipEvent_t)a->ev_blend_end, s) != hipSuccess) return MISPLAT_ELAUNCH;
-        if (a->unit_work && a->unit_perm_out) {
+        if (by_view) {
+            rc = misplat_internal::unit_order_table(p, p->ppl_fwd, a->unit_work, a->order_table, a->order_sel, a->order_stride, s);
+            if (rc != MISPLAT_OK) return rc;
+        } else if (a->unit_work && a->unit_perm_out) {
             rc = misplat_unit_order(p, p->ppl_fwd, a->unit_work, a->unit_perm_out, stream);
             if (rc != MISPLAT_OK) return rc;
         }
@@ -323,6 +330,8 @@ static bool background_fill_ok(const misplat_params* p, const misplat_raster_bwd
 static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_args* b, hipStream_t s) {
     misplat_params q = *p;
     q.unit_perm = b->unit_perm;
+    q.unit_sel = b->unit_perm ? b->unit_sel : nullptr;
+    q.unit_stride = b->unit_stride;
     q.unit_work = nullptr;
     // Dense scenes: the per-Gaussian backward kernels only write the rows that received a gradient (`touched`); the
     // zeros of all the others are written in the background of the compositing backward (issue-bound, memory idle).

@@ -13,7 +13,13 @@
 // of PIXELS: the transposed filter of the three maps (the same separable passes, from LDS) combined with the pixel's own
 // x and y, plus the L1 term's sign gradient -- the whole d main_loss / d rgb in one pass, nothing accumulated atomically
 // (reproducible bit for bit).  HBM traffic at 1080p: forward 2 x 25 MB in + 74 MB of maps out, backward the reverse
-// + 25 MB of gradient: ~0.25 GB per step, streaming.
+// + 25 MB of gradient: ~0.25 GB per step (~60 us at the copy roof) -- but the kernels are bound by vector issue, not by
+// memory: 71 / 80 us at 1080p, 22.5 M / 24.2 M wave instructions of 4 cycles each on 1 024 SIMDs (37 / 39 us at full
+// issue; SQ counters of this round), and with every global access removed the forward still takes 66 us.  What cut
+// instructions: four outputs per thread and pass from 14 values read once, the window folded around its centre
+// (5 adds + 6 multiply-adds per plane and output instead of 11 multiply-adds), two reciprocals instead of six IEEE
+// divisions, row / column of the loads computed once.  What did not matter (each measured): one workgroup per channel
+// or per tile, all loads in flight at once, an XCD-contiguous tile order, leaving out the stores (-20 / -7 us).
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdint>
@@ -63,17 +69,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int Wd, const floa
     __shared__ float sx[kPatch][kRowS], sy[kPatch][kRowS];
     __shared__ float hz[3][5][kPatch][kHzS];
     __shared__ float red[4];
-#ifdef SSIM_EXP_XCD
-    // consecutive tiles to the same XCD (workgroup b runs on XCD b % 8): each XCD gets a band of whole tile rows
-    const int nb = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
-    const int per = (nb + 7) >> 3;
-    const int tile_id = (lin & 7) * per + (lin >> 3);
-    if (tile_id >= nb) { if (threadIdx.x == 0) partials[lin] = 0.f; return; }
-    const int bx = tile_id % gridDim.x, by = tile_id / gridDim.x;
-    const int ox = bx * kTile, oy = by * kTile;
-#else
     const int ox = blockIdx.x * kTile, oy = blockIdx.y * kTile;
-#endif
     const int OW = Wd - (kWin - 1), OH = H - (kWin - 1);
     const int row_floats = 3 * Wd;
     {
@@ -88,14 +84,10 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int Wd, const floa
         for (int i = 0; i < kRounds; i++) {
             const int r = r0 + kRowsPer * i, y = oy + r;
             va[i] = 0.f; vb[i] = 0.f;
-#ifdef SSIM_EXP_NOLOAD
-            if (lane_ok && r < kPatch && y < H) { va[i] = 0.25f + 0.001f * (float)(q & 63); vb[i] = 0.3f; }
-#else
             if (lane_ok && r < kPatch && y < H) {
                 const size_t o = (size_t)y * row_floats + xf;
                 va[i] = rgb[o]; vb[i] = gt[o];
             }
-#endif
         }
 #pragma unroll
         for (int i = 0; i < kRounds; i++) {
@@ -168,15 +160,9 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int Wd, const floa
                 const float dlum_dm = 2.0f * (m2 - m1 * lum) * r1;
                 const float dcs_dm = 2.0f * (m1 * cs - m2) * r2;
                 const size_t o = (size_t)c * plane + (size_t)py * OW + px;
-#ifdef SSIM_EXP_NOWRITE
-                if (s == 123.456f) {
-#endif
                 maps[o] = cs * dlum_dm + lum * dcs_dm;
                 maps[3 * plane + o] = -lum * cs * r2;
                 maps[6 * plane + o] = 2.0f * lum * r2;
-#ifdef SSIM_EXP_NOWRITE
-                }
-#endif
             }
         }
     }
@@ -303,11 +289,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(int H, int Wd, const floa
     for (int t = threadIdx.x; t < kTile * 3 * kTile; t += 256) {
         const int r = t / (3 * kTile), q = t - r * (3 * kTile);
         const int y = iy0 + r, xf = 3 * ix0 + q;
-#ifdef SSIM_EXP_NOWRITE
-        if (y < H && xf < row_floats && outs[r][q] == 123.456f) v_rgb[(size_t)y * row_floats + xf] = outs[r][q];
-#else
         if (y < H && xf < row_floats) v_rgb[(size_t)y * row_floats + xf] = outs[r][q];
-#endif
     }
 }
 

@@ -45,7 +45,7 @@ UNIT_ORDER_FWD = os.environ.get("MISPLAT_UNIT_ORDER_FWD", "1") == "1"
 _LAST_ORDER: Dict[tuple, Tensor] = {}
 
 # Which variants of the path the calls of this process took (tests and bench.py read it; never reset by the library):
-#   forward / forward_lazy_colour / forward_merged_phases / forward_prev_order / capacity_redo
+#   forward / forward_lazy_colour / forward_merged_phases / forward_view_order (or forward_prev_order) / capacity_redo
 #   backward_one_call / backward_background_fill / backward_staged / backward_sink / backward_rows_refilled
 PATH_STATS: "collections.Counter" = collections.Counter()
 
@@ -58,18 +58,48 @@ def _eff_ppl(v: int) -> int:
     return v if v in (1, 2, 4) else 2
 
 
+# View-keyed launch orders (the one-entry forward): per (device, stream, image shape) a persistent device table of
+# ORDER_SLOTS records {tag, valid, permutation} and four selector words.  The projection kernel hashes the call's cameras
+# and picks the record, the compositing forward runs in that record's order and leaves the order it measured there
+# (include/misplat.h: misplat_params.unit_sel) -- a training loop revisits its cameras every epoch, so every view finds
+# the order of its own last visit, where a single "previous call" order belongs to some other view (measured on the
+# bench's 8 cycling views: as good as no order).  16 336 words per record at 1080p: 16.7 MB for 256 slots.
+ORDER_BY_VIEW = os.environ.get("MISPLAT_ORDER_BY_VIEW", "1") == "1"
+ORDER_SLOTS = int(os.environ.get("MISPLAT_ORDER_SLOTS", "256"))
+ORDER_HEADER = 16                     # MISPLAT_ORDER_HEADER
+_ORDER_TABLES: Dict[tuple, tuple] = {}
+
+
+def _order_table(P: Params, dev: torch.device):
+    """(table, sel, stride) of this device / stream / shape, or None when view-keyed orders are off."""
+    if not (UNIT_ORDER and UNIT_ORDER_FWD and ORDER_BY_VIEW and ORDER_SLOTS > 0):
+        return None
+    ppl_f = _eff_ppl(P.ppl_fwd)
+    if _eff_ppl(P.ppl_bwd) != ppl_f:
+        return None
+    units = P.tile_w * P.tile_h * P.n_cams * (4 // ppl_f)
+    key = (dev.index, _stream_id(), P.n_cams, P.tile_w, P.tile_h, ppl_f, ORDER_SLOTS)
+    got = _ORDER_TABLES.get(key)
+    if got is None:
+        stride = ORDER_HEADER + 8 * ((units + 7) // 8)
+        got = _ORDER_TABLES[key] = (torch.zeros(ORDER_SLOTS * stride, device=dev, dtype=torch.int32),
+                                    torch.zeros(4, device=dev, dtype=torch.int32), stride)
+    return got
+
+
 class _UnitSchedule:
     """Per-call launch-order state of one compositing forward/backward pair."""
 
-    def __init__(self, P: Params, dev: torch.device):
+    def __init__(self, P: Params, dev: torch.device, by_view=None):
         self.on = UNIT_ORDER
         self.perm_bwd = None
+        self.by_view = by_view if self.on else None        # (table, sel, stride): the order lives in a view-keyed record
         if not self.on:
             return
         self.ppl_f, self.ppl_b = _eff_ppl(P.ppl_fwd), _eff_ppl(P.ppl_bwd)
         self.units = P.tile_w * P.tile_h * P.n_cams * (4 // self.ppl_f)
         self.key = (dev.index, _stream_id(), P.n_cams, P.tile_w, P.tile_h, self.ppl_f)
-        self.work, self.perm = _carve(dev, (self.units, 8 * ((self.units + 7) // 8)))
+        self.work, self.perm = _carve(dev, (self.units, 8 * ((self.units + 7) // 8) if self.by_view is None else 0))
 
     def before_forward(self, P: Params) -> None:
         if not self.on:
@@ -90,12 +120,16 @@ class _UnitSchedule:
             self.perm_bwd = self.perm
 
     def before_backward(self, P: Params) -> None:
-        P.unit_perm = self.perm_bwd.data_ptr() if self.perm_bwd is not None else None
+        if self.by_view is not None:
+            table, sel, stride = self.by_view
+            P.unit_perm, P.unit_sel, P.unit_stride = table.data_ptr(), sel.data_ptr(), stride
+        else:
+            P.unit_perm = self.perm_bwd.data_ptr() if self.perm_bwd is not None else None
         P.unit_work = None
 
     @staticmethod
     def done(P: Params) -> None:
-        P.unit_perm, P.unit_work = None, None
+        P.unit_perm, P.unit_work, P.unit_sel, P.unit_stride = None, None, None, 0
 
 
 # Data-parallel training: a parallel.GradientBuckets object (or None).  While set, the backward of the per-Gaussian
@@ -774,12 +808,15 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     rows_on_touch = bool(lazy and want_grad and flags and Cn == 1 and N >= SPARSE_BWD_MIN_ROWS and not want_aux and kd == 16
                          and ROWS_ON_TOUCH)
     a.lazy_colour = 2 if rows_on_touch else int(lazy)
+    order = _order_table(P, dev)
+    if order is not None:
+        a.order_table, a.order_sel, a.order_slots, a.order_stride = _dp(order[0]), _dp(order[1]), ORDER_SLOTS, order[2]
     PATH_STATS["forward_rows_on_touch"] += int(rows_on_touch)
     if not defer:
         check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
               "misplat_raster_fwd(A)")
     state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero, v_abs_zero=v_abs_zero,
-                 deferred=defer, rows_on_touch=rows_on_touch,
+                 deferred=defer, rows_on_touch=rows_on_touch, order=order,
                  counters=counters, touched=touched,
                  keep=(rect2, cellhist, cell_count, cell_offs, order, counters, tile_count, radii, cell_cursor))
     return (radii.view(Cn, N, 2), means2d.view(Cn, N, 2), depths.view(Cn, N), comps.view(Cn, N), grec.view(rows, MISPLAT_REC),
@@ -809,7 +846,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
     if cap >= 2 ** 31:
         raise _lib.MisplatError(f"{cap} tile intersections exceed int32 indexing")
     render, alpha, exp_depth, med_depth, normal = _carve_f(dev, (cd * n_pix, n_pix, n_pix, n_pix, 3 * n_pix))
-    sched = _UnitSchedule(P, dev)
+    sched = _UnitSchedule(P, dev, by_view=state.get("order"))
     last_ids, median_ids, offsets = _carve(dev, (n_pix, n_pix, n_tiles + 2))
 
     def isect_buffers(c):
@@ -820,7 +857,11 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
     a.offsets, a.render, a.alpha, a.exp_depth, a.med_depth, a.normal = (_dp(offsets), _dp(render), _dp(alpha), _dp(exp_depth),
                                                                         _dp(med_depth), _dp(normal))
     a.last_ids, a.median_ids = _dp(last_ids), _dp(median_ids)
-    if sched.on:
+    if sched.on and sched.by_view is not None:
+        PATH_STATS["forward_view_order"] += 1
+        a.unit_perm_in, a.unit_work, a.unit_perm_out = None, _dp(sched.work), None
+    elif sched.on:
+        a.order_table, a.order_sel = None, None
         last = _LAST_ORDER.get(sched.key) if UNIT_ORDER_FWD else None
         if last is not None and _CAPTURE_KEEP is not None:
             _CAPTURE_KEEP.append(last)                                # a captured graph keeps reading this buffer
@@ -862,7 +903,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         # generous one costs nothing but address space (288 GB of HBM) -- and a capacity that stays put keeps the buffers'
         # addresses and with them the graph keys (a change of 1/8 octave needs ~100 calls at this decay)
         _CAP_HINT[key] = max(n_known, int(0.999 * _CAP_HINT.get(key, 0)))
-    if sched.on:
+    if sched.on and sched.by_view is None:
         _LAST_ORDER[sched.key] = sched.perm
         if sched.ppl_b == sched.ppl_f:
             sched.perm_bwd = sched.perm
@@ -961,6 +1002,7 @@ class _RasterFused(torch.autograd.Function):
         v_means, v_quats = _grad_out(means), _grad_out(quats)
         v_scales, v_opac = _grad_out(scales), _grad_out(opacities)
         perm = ctx.sched.perm_bwd if ctx.sched is not None else None
+        by_view = ctx.sched.by_view if ctx.sched is not None else None
         # (a data-parallel gradient sink only changes where the six outputs are written: the slices of its flat buffer are
         # plain pointers like any other, so the one-call backward -- graph replay, both per-Gaussian stages in one launch,
         # zeros written in the background of the compositing backward -- serves it too)
@@ -973,6 +1015,8 @@ class _RasterFused(torch.autograd.Function):
             b.alpha, b.last_ids, b.median_ids, b.render = _dp(alpha), _dp(last_ids), _dp(median_ids), _dp(render)
             b.v_render, b.v_alpha, b.v_exp_depth, b.v_med_depth, b.v_normal = [_dp(t) for t in ups]
             b.v_grec, b.v_abs, b.unit_perm = _dp(v_grec), _dp(v_abs), _dp(perm)
+            if by_view is not None:
+                b.unit_perm, b.unit_sel, b.unit_stride = _dp(by_view[0]), _dp(by_view[1]), by_view[2]
             b.color_dim, b.zero_flags = cd, flags
             b.sh_degree, b.K_or_D, b.n_color, b.per_cam, b.depth_slot = deg, kd, n_color, per_cam, ctx.depth_slot
             b.means, b.quats, b.scales, b.opacities = _dp(means), _dp(quats), _dp(scales), _dp(opacities)
@@ -1010,12 +1054,14 @@ class _RasterFused(torch.autograd.Function):
                 PATH_STATS["backward_rows_refilled"] += 1
             _with_perm = C.c_void_p(perm.data_ptr()) if perm is not None else None
             P.unit_perm = _with_perm
+            if by_view is not None:
+                P.unit_perm, P.unit_sel, P.unit_stride = by_view[0].data_ptr(), by_view[1].data_ptr(), by_view[2]
             check(lib.misplat_blend_bwd_atomic(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
                                                ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(alpha),
                                                ptr(last_ids), ptr(median_ids), ptr(render), *[ptr(t) for t in ups],
                                                ptr(v_grec), ptr(v_abs), C.c_int32(flags), stream_ptr()),
                   "misplat_blend_bwd_atomic")
-            P.unit_perm = None
+            P.unit_perm, P.unit_sel, P.unit_stride = None, None, 0
             check(lib.misplat_color_bwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
                                         C.c_int32(per_cam), ptr(means), ptr(viewmats), ptr(colors), ptr(colors_rest),
                                         ptr(radii), ptr(v_grec), ptr(v_colors), ptr(v_colors_rest), ptr(v_means_dir),

@@ -71,7 +71,7 @@ def train(steps=300, n=20000, W=320, H=200, n_views=8, refine_every=50, seed=0, 
         loss.backward()
         fused_adam_step_all(model.optimizers)
         counts = model.strategy.step_post_backward(model.gauss_params, model.optimizers, model.strategy_state, it + 1, model.info)
-        log.append((losses["rgb_loss"].item(), model.means.shape[0], counts))
+        log.append((losses["main_loss"].item(), model.means.shape[0], counts))
         if verbose and (it % 50 == 0 or it == steps - 1):
             extra = "".join(f"  {k} {v.item():.5f}" for k, v in losses.items())
             print(f"step {it:4d}{extra}  gaussians {model.means.shape[0]}  dup/split/prune {counts}")

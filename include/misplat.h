@@ -74,6 +74,13 @@ typedef struct misplat_params {
      * processes unit unit_perm[b] instead of the default XCD-strip map (misplat_unit_order builds it, longest first). */
     const int32_t* unit_perm;
     int32_t* unit_work;
+    /* View-keyed orders (unit_sel != NULL): unit_perm is then the base of a TABLE of records of unit_stride int32 each --
+     * MISPLAT_ORDER_HEADER header words {tag lo, tag hi, valid, ...} followed by a permutation -- and unit_sel points to
+     * four device words {slot, valid, tag lo, tag hi} that misplat_raster_fwd's projection kernel writes from a hash
+     * of the call's cameras (viewmats, Ks): a compositing launch uses the permutation of record `slot` if `valid`, the
+     * default map otherwise; the forward's order kernel stores the new permutation (and the tag) into that record.  A
+     * training loop revisits its cameras every epoch: each view finds the order its own last visit measured. */
+#define MISPLAT_ORDER_HEADER 16
     /* (or NULL) one byte per (camera, Gaussian) row, a speed hint that never changes a result: cleared by
      * misplat_project_pack_fwd, set by the ATOMIC compositing backward for every row it adds a gradient to, read by the
      * per-Gaussian backward kernels -- a row that was never set has an all-zero gradient row, which then is not fetched
@@ -84,7 +91,8 @@ typedef struct misplat_params {
      * themselves and return the gradients of the raw parameters -- the four activation launches of
      * rade_gs_model.py:443-444 and their backward disappear.  0 = activated values, as gsplat takes them. */
     int32_t activations;
-    int32_t reserved_p;
+    int32_t unit_stride;     /* see unit_sel */
+    const int32_t* unit_sel; /* or NULL */
 } misplat_params;
 
 /* ---- a2.1 projection: fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, ...)
@@ -493,6 +501,12 @@ typedef struct misplat_raster_args {
     /* measurement (or NULL): two hipEvent_t recorded on `stream` directly before and after the compositing forward; a
      * call that carries them is launched plainly (no graph) */
     void *ev_blend_begin, *ev_blend_end;
+    /* view-keyed launch orders (misplat_params.unit_sel), or NULL: order_table[order_slots][order_stride] int32 --
+     * zero-initialised by the caller once and kept between calls --, order_sel[4].  Phase A selects the record of the
+     * call's cameras, phase B composites in that record's order (if it holds one) and stores the order it measured.
+     * unit_perm_in / unit_perm_out are ignored then; unit_work is still needed. */
+    int32_t *order_table, *order_sel;
+    int32_t order_slots, order_stride;
 } misplat_raster_args;
 /* Graph cache (optional, caller-owned, thread-safe; the library itself keeps no state): with a cache, the launch
  * sequence of a call is captured into a hipGraph the first time a given (params, args, phases, stream) block is seen
@@ -537,6 +551,9 @@ typedef struct misplat_raster_bwd_args {
      * two-launch form only (misplat_raster_bwd_plan bit 0), where v_grec may hold defined values in flagged rows only
      * (misplat_raster_args.lazy_colour = 2) and cannot be sliced for it */
     float* v_means2d_out;
+    /* view-keyed launch order: unit_perm is the table base, see misplat_params.unit_sel (or NULL / 0) */
+    const int32_t* unit_sel;
+    int32_t unit_stride, reserved2;
 } misplat_raster_bwd_args;
 int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
                        misplat_graph_cache* cache /* or NULL */);

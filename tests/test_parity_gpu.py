@@ -1743,7 +1743,7 @@ def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H
     # ---- the machinery was ON for the call that is compared
     assert took.get("forward") == n_calls and took.get("backward_one_call") == n_calls and took.get("backward_staged", 0) == 0
     assert took.get("forward_merged_phases", 0) == n_calls - 1      # from the second call on
-    assert took.get("forward_prev_order", 0) >= n_calls - 1         # (an earlier test may have left an order for this shape)
+    assert took.get("forward_view_order", 0) == n_calls             # the launch order comes from the record of this view
     assert took.get("capacity_redo", 0) == 0
     gs = ops.graph_cache_stats(dev)
     assert gs["hits"] >= 1 and gs["captures"] >= 1, gs
@@ -1829,6 +1829,62 @@ def test_cycling_views_reuse_graphs_without_capacity_redo(dev):
     assert took.get("capacity_redo", 0) == 0 and took.get("forward_merged_phases", 0) == 16, took
     print(f"[cycling views] graph cache before rounds 3-4 {g0}, after {g1}")         # (replays need repeating addresses:
     # whether the allocator hands them out again is the caller's allocation pattern, not a property to assert here)
+    # ---- every view found its own launch order: eight valid records with eight different tags in the view-keyed table,
+    # each one a permutation of the units (padding entries = units), and from the second round on the selector said "found"
+    assert took.get("forward_view_order", 0) == 16, took
+    tables = [v for k, v in ops._ORDER_TABLES.items() if k[3:5] == ((W + 15) // 16, (H + 15) // 16) and k[0] == torch.device(dev).index]
+    assert len(tables) == 1
+    table, sel, stride = tables[0]
+    units = ((W + 15) // 16) * ((H + 15) // 16) * 2
+    recs = table.view(-1, stride).cpu()
+    valid = recs[recs[:, 2] != 0]
+    assert valid.shape[0] == 8 and len({(int(r[0]), int(r[1])) for r in valid}) == 8
+    for r in valid:
+        perm = r[ops.ORDER_HEADER:]
+        assert torch.equal(torch.sort(perm[perm < units]).values, torch.arange(units, dtype=torch.int32))
+        assert int((perm == units).sum()) == perm.numel() - units
+    assert int(sel.cpu()[1]) == 1
+
+
+def test_view_keyed_orders_survive_eviction_and_collisions(dev, monkeypatch):
+    """Two slots for five views: every call evicts somebody's record.  The order is a speed hint -- the images stay
+    bitwise those of a run without any launch order, the gradients equal up to the order of the atomic sums, and
+    whatever the table holds is a valid permutation under its tag."""
+    from collab_splats_amd import ops, rasterization
+    from collab_splats_amd.synthetic import random_scene, view_matrix
+    N, W, H = 30_000, 320, 208
+    sc = random_scene(N, W, H, seed=3)
+    leaves = [sc[k].to(dev).requires_grad_(True) for k in ("means", "quats", "log_scales", "opacity_logits", "sh")]
+    views = [view_matrix(v).to(dev) for v in range(5)]
+    K = sc["Ks"].to(dev)
+    ups = [u.to(dev) for u in upstream([(1, H, W, 4), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3)], dtype=torch.float32)]
+    kw = dict(sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True)
+
+    def call(v):
+        for l in leaves:
+            l.grad = None
+        out = rasterization(leaves[0], leaves[1], torch.exp(leaves[2]), torch.sigmoid(leaves[3]), leaves[4], views[v], K, W, H, **kw)
+        torch.autograd.backward(list(out[:5]), ups)
+        return [t.detach().clone() for t in out[:5]], [l.grad.clone() for l in leaves]
+
+    monkeypatch.setattr(ops, "UNIT_ORDER", False)
+    ref = [call(v) for v in range(5)]
+    monkeypatch.setattr(ops, "UNIT_ORDER", True)
+    monkeypatch.setattr(ops, "ORDER_SLOTS", 2)
+    for rnd in range(3):
+        for v in range(5):
+            img, grad = call(v)
+            for x, y in zip(img, ref[v][0]):
+                assert torch.equal(x, y), (rnd, v)
+            for x, y in zip(grad, ref[v][1]):
+                assert rel_err(x, y) < 2e-5, (rnd, v)
+    (table, sel, stride), = [v for k, v in ops._ORDER_TABLES.items() if k[-1] == 2 and k[3:5] == ((W + 15) // 16, (H + 15) // 16)]
+    units = ((W + 15) // 16) * ((H + 15) // 16) * 2
+    recs = table.view(-1, stride).cpu()
+    assert recs.shape[0] == 2 and bool((recs[:, 2] != 0).all())
+    for r in recs:
+        perm = r[ops.ORDER_HEADER:]
+        assert torch.equal(torch.sort(perm[perm < units]).values, torch.arange(units, dtype=torch.int32))
 
 
 # ---------------------------------------------------------------- f3 / f4 on the device, against their oracles
