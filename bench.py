@@ -54,7 +54,9 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=24, help="timed steps (default: three passes over the eight views)")
-    ap.add_argument("--warmup", type=int, default=8, help="untimed steps (default: one pass over the eight views)")
+    ap.add_argument("--warmup", type=int, default=16,
+                    help="untimed steps (default: two passes over the eight views -- a graph is captured when an argument block "
+                         "is seen the second time, a view's launch order exists after its first visit)")
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
