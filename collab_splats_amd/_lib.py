@@ -37,7 +37,8 @@ class Params(C.Structure):
                 ("median_t", C.c_float), ("jacobian_margin", C.c_float), ("plane_eps", C.c_float),
                 ("ppl_fwd", C.c_int32), ("ppl_bwd", C.c_int32), ("ed_slot", C.c_int32), ("sub_blocks", C.c_int32),
                 ("unit_perm", C.c_void_p), ("unit_work", C.c_void_p), ("touched", C.c_void_p),
-                ("activations", C.c_int32), ("unit_stride", C.c_int32), ("unit_sel", C.c_void_p)]
+                ("activations", C.c_int32), ("unit_stride", C.c_int32), ("unit_sel", C.c_void_p),
+                ("unit_slots", C.c_int32), ("reserved_p", C.c_int32)]
 
 
 class RasterArgs(C.Structure):
@@ -67,7 +68,7 @@ class RasterBwdArgs(C.Structure):
                                              "radii", "compensations", "sh_aux", "v_means2d", "v_colors", "v_colors_rest",
                                              "v_means_dir", "v_means", "v_quats", "v_scales", "v_opacities", "ev_blend_begin", "ev_blend_end",
                                              "v_means2d_out", "unit_sel")]
-                + [("unit_stride", C.c_int32), ("reserved2", C.c_int32)])
+                + [("unit_stride", C.c_int32), ("unit_slots", C.c_int32)])
 
 
 def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: int = 16,

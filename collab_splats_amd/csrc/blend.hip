@@ -59,7 +59,8 @@ __device__ __forceinline__ bool band_ctx(const misplat_params& P, const float* _
     // the call's cameras (misplat_params.unit_sel); no valid record = the default map.
     if (P.unit_perm) {
         if (!P.unit_sel) unit = P.unit_perm[b];
-        else if (P.unit_sel[1]) unit = P.unit_perm[(size_t)P.unit_sel[0] * P.unit_stride + MISPLAT_ORDER_HEADER + b];
+        else if (P.unit_sel[1] && (unsigned)P.unit_sel[0] < (unsigned)P.unit_slots)
+            unit = P.unit_perm[(size_t)P.unit_sel[0] * P.unit_stride + MISPLAT_ORDER_HEADER + b];
     }
     if ((unsigned)unit >= (unsigned)total) return false;
     c.unit = unit;
@@ -1452,11 +1453,13 @@ __global__ __launch_bounds__(kDnTX * kDnTY) void depth_normal_bwd_tiled_kernel(
 // the tag sel[2..3] and becomes valid -- for the launches after this one (the backward of the same call) and for the next
 // call with the same cameras.
 __global__ __launch_bounds__(1024) void unit_order_kernel(int units, int per, const int32_t* __restrict__ work,
-                                                          int32_t* __restrict__ perm, int32_t* __restrict__ sel, int stride) {
+                                                          int32_t* __restrict__ perm, int32_t* __restrict__ sel, int stride,
+                                                          int slots) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wmax[16];
     const int x = blockIdx.x;
     if (sel) {
+        if ((unsigned)sel[0] >= (unsigned)slots) return;       // (a selector nobody wrote: leave the table alone)
         int32_t* rec = perm + (size_t)sel[0] * stride;
         perm = rec + MISPLAT_ORDER_HEADER;
         if (x == 0 && threadIdx.x == 0) { rec[0] = sel[2]; rec[1] = sel[3]; rec[2] = 1; }
@@ -1537,18 +1540,18 @@ extern "C" int misplat_unit_order(const misplat_params* p, int32_t ppl, const in
     const int units = p->tile_w * p->tile_h * p->n_cams * (4 / q);
     const int per = (units + 7) >> 3;
     hipLaunchKernelGGL(unit_order_kernel, dim3(8), dim3(1024), 0, (hipStream_t)stream, units, per, unit_work, unit_perm,
-                       (int32_t*)nullptr, 0);
+                       (int32_t*)nullptr, 0, 0);
     return check_launch();
 }
 
 int misplat_internal::unit_order_table(const misplat_params* p, int32_t ppl, const int32_t* unit_work, int32_t* table,
-                                       int32_t* sel, int32_t stride, hipStream_t s) {
-    if (!params_ok(p) || !unit_work || !table || !sel) return MISPLAT_EINVAL;
+                                       int32_t* sel, int32_t stride, int32_t slots, hipStream_t s) {
+    if (!params_ok(p) || !unit_work || !table || !sel || slots < 1) return MISPLAT_EINVAL;
     const int q = pick_ppl(ppl, kDefaultPplFwd);
     const int units = p->tile_w * p->tile_h * p->n_cams * (4 / q);
     const int per = (units + 7) >> 3;
     if (stride < MISPLAT_ORDER_HEADER + 8 * per) return MISPLAT_EINVAL;
-    hipLaunchKernelGGL(unit_order_kernel, dim3(8), dim3(1024), 0, s, units, per, unit_work, table, sel, (int)stride);
+    hipLaunchKernelGGL(unit_order_kernel, dim3(8), dim3(1024), 0, s, units, per, unit_work, table, sel, (int)stride, (int)slots);
     return check_launch();
 }
 

@@ -46,7 +46,7 @@ int project_pack_fwd(const misplat_params* p, const float* means, const float* q
 
 // misplat_unit_order into the record of a view-keyed table that `sel` names (misplat_params.unit_sel).
 int unit_order_table(const misplat_params* p, int32_t ppl, const int32_t* unit_work, int32_t* table, int32_t* sel,
-                     int32_t stride, hipStream_t s);
+                     int32_t stride, int32_t slots, hipStream_t s);
 
 // misplat_blend_fwd_lazy that also clears row g of rows_on_touch[C*N,16] (or NULL) when it sets the colour of record g.
 int blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const float* Ks, float* grec, const int32_t* flatten_ids,

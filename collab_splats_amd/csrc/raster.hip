@@ -104,9 +104,15 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
             return MISPLAT_ELAUNCH;
         misplat_params q = *p;
         const bool by_view = a->order_table && a->order_sel && a->unit_work;
+        if (by_view) {          // (a record must hold a whole permutation: the compositing launch indexes it by workgroup)
+            const int ppl_f = (p->ppl_fwd == 1 || p->ppl_fwd == 2 || p->ppl_fwd == 4) ? p->ppl_fwd : 2;
+            const int64_t units = (int64_t)p->tile_w * p->tile_h * p->n_cams * (4 / ppl_f);
+            if (a->order_slots < 1 || a->order_stride < MISPLAT_ORDER_HEADER + 8 * ((units + 7) / 8)) return MISPLAT_EINVAL;
+        }
         q.unit_perm = by_view ? a->order_table : a->unit_perm_in;
         q.unit_sel = by_view ? a->order_sel : nullptr;
         q.unit_stride = by_view ? a->order_stride : 0;
+        q.unit_slots = by_view ? a->order_slots : 0;
         q.unit_work = a->unit_work;
         if (a->ev_blend_begin && hipEventRecord((hipEvent_t)a->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
         if (a->lazy_colour) {
@@ -122,7 +128,8 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         if (rc != MISPLAT_OK) return rc;
         if (a->ev_blend_end && hipEventRecord((hipEvent_t)a->ev_blend_end, s) != hipSuccess) return MISPLAT_ELAUNCH;
         if (by_view) {
-            rc = misplat_internal::unit_order_table(p, p->ppl_fwd, a->unit_work, a->order_table, a->order_sel, a->order_stride, s);
+            rc = misplat_internal::unit_order_table(p, p->ppl_fwd, a->unit_work, a->order_table, a->order_sel, a->order_stride,
+                                                    a->order_slots, s);
             if (rc != MISPLAT_OK) return rc;
         } else if (a->unit_work && a->unit_perm_out) {
             rc = misplat_unit_order(p, p->ppl_fwd, a->unit_work, a->unit_perm_out, stream);
@@ -332,6 +339,7 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
     q.unit_perm = b->unit_perm;
     q.unit_sel = b->unit_perm ? b->unit_sel : nullptr;
     q.unit_stride = b->unit_stride;
+    q.unit_slots = b->unit_slots;
     q.unit_work = nullptr;
     // Dense scenes: the per-Gaussian backward kernels only write the rows that received a gradient (`touched`); the
     // zeros of all the others are written in the background of the compositing backward (issue-bound, memory idle).

@@ -70,6 +70,10 @@ ORDER_HEADER = 16                     # MISPLAT_ORDER_HEADER
 _ORDER_TABLES: Dict[tuple, tuple] = {}
 
 
+def _order_slots(table: Tensor, stride: int) -> int:
+    return table.numel() // stride
+
+
 def _order_table(P: Params, dev: torch.device):
     """(table, sel, stride) of this device / stream / shape, or None when view-keyed orders are off."""
     if not (UNIT_ORDER and UNIT_ORDER_FWD and ORDER_BY_VIEW and ORDER_SLOTS > 0):
@@ -122,14 +126,14 @@ class _UnitSchedule:
     def before_backward(self, P: Params) -> None:
         if self.by_view is not None:
             table, sel, stride = self.by_view
-            P.unit_perm, P.unit_sel, P.unit_stride = table.data_ptr(), sel.data_ptr(), stride
+            P.unit_perm, P.unit_sel, P.unit_stride, P.unit_slots = table.data_ptr(), sel.data_ptr(), stride, _order_slots(table, stride)
         else:
             P.unit_perm = self.perm_bwd.data_ptr() if self.perm_bwd is not None else None
         P.unit_work = None
 
     @staticmethod
     def done(P: Params) -> None:
-        P.unit_perm, P.unit_work, P.unit_sel, P.unit_stride = None, None, None, 0
+        P.unit_perm, P.unit_work, P.unit_sel, P.unit_stride, P.unit_slots = None, None, None, 0, 0
 
 
 # Data-parallel training: a parallel.GradientBuckets object (or None).  While set, the backward of the per-Gaussian
@@ -810,7 +814,8 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     a.lazy_colour = 2 if rows_on_touch else int(lazy)
     order = _order_table(P, dev)
     if order is not None:
-        a.order_table, a.order_sel, a.order_slots, a.order_stride = _dp(order[0]), _dp(order[1]), ORDER_SLOTS, order[2]
+        a.order_table, a.order_sel, a.order_slots, a.order_stride = (_dp(order[0]), _dp(order[1]),
+                                                                     _order_slots(order[0], order[2]), order[2])
     PATH_STATS["forward_rows_on_touch"] += int(rows_on_touch)
     if not defer:
         check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
@@ -1017,6 +1022,7 @@ class _RasterFused(torch.autograd.Function):
             b.v_grec, b.v_abs, b.unit_perm = _dp(v_grec), _dp(v_abs), _dp(perm)
             if by_view is not None:
                 b.unit_perm, b.unit_sel, b.unit_stride = _dp(by_view[0]), _dp(by_view[1]), by_view[2]
+                b.unit_slots = _order_slots(by_view[0], by_view[2])
             b.color_dim, b.zero_flags = cd, flags
             b.sh_degree, b.K_or_D, b.n_color, b.per_cam, b.depth_slot = deg, kd, n_color, per_cam, ctx.depth_slot
             b.means, b.quats, b.scales, b.opacities = _dp(means), _dp(quats), _dp(scales), _dp(opacities)
@@ -1056,12 +1062,13 @@ class _RasterFused(torch.autograd.Function):
             P.unit_perm = _with_perm
             if by_view is not None:
                 P.unit_perm, P.unit_sel, P.unit_stride = by_view[0].data_ptr(), by_view[1].data_ptr(), by_view[2]
+                P.unit_slots = _order_slots(by_view[0], by_view[2])
             check(lib.misplat_blend_bwd_atomic(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
                                                ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(alpha),
                                                ptr(last_ids), ptr(median_ids), ptr(render), *[ptr(t) for t in ups],
                                                ptr(v_grec), ptr(v_abs), C.c_int32(flags), stream_ptr()),
                   "misplat_blend_bwd_atomic")
-            P.unit_perm, P.unit_sel, P.unit_stride = None, None, 0
+            P.unit_perm, P.unit_sel, P.unit_stride, P.unit_slots = None, None, 0, 0
             check(lib.misplat_color_bwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
                                         C.c_int32(per_cam), ptr(means), ptr(viewmats), ptr(colors), ptr(colors_rest),
                                         ptr(radii), ptr(v_grec), ptr(v_colors), ptr(v_colors_rest), ptr(v_means_dir),

@@ -93,6 +93,8 @@ typedef struct misplat_params {
     int32_t activations;
     int32_t unit_stride;     /* see unit_sel */
     const int32_t* unit_sel; /* or NULL */
+    int32_t unit_slots;      /* records in the table: a selector outside [0, unit_slots) counts as "no record" */
+    int32_t reserved_p;
 } misplat_params;
 
 /* ---- a2.1 projection: fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, ...)
@@ -553,7 +555,7 @@ typedef struct misplat_raster_bwd_args {
     float* v_means2d_out;
     /* view-keyed launch order: unit_perm is the table base, see misplat_params.unit_sel (or NULL / 0) */
     const int32_t* unit_sel;
-    int32_t unit_stride, reserved2;
+    int32_t unit_stride, unit_slots;
 } misplat_raster_bwd_args;
 int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
                        misplat_graph_cache* cache /* or NULL */);
