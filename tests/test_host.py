@@ -193,6 +193,31 @@ def test_get_loss_dict_value_vs_reference_goldens():
         model.config.use_depth_normal_loss = True
 
 
+def test_image_loss_on_cpu_tensors_fails_loudly_and_scale_reg_follows_splatfacto():
+    """``main_loss`` (L1 + SSIM, Splatfacto's, [UNVERIFIED-UPSTREAM]) has no CPU path: CPU images with ``ssim_lambda`` > 0
+    raise; with ``ssim_lambda`` = 0 the plain L1 mean is a host expression.  ``scale_reg`` (off by default): 0.1 * mean(
+    max(max(s) / min(s), 10) - 10) of the activated scales on every tenth step, 0 otherwise."""
+    import math
+    from collab_splats_amd import radegs
+    from collab_splats_amd._lib import MisplatError
+    log_s = torch.log(torch.tensor([[1.0, 1.0, 1.0], [20.0, 1.0, 2.0], [0.5, 0.01, 0.1]]))
+    model = radegs.RadegsModel(radegs.RadegsModelConfig(use_depth_normal_loss=False), torch.zeros(3, 3), log_s,
+                               torch.ones(3, 4), torch.zeros(3), torch.zeros(3, 3), torch.zeros(3, 15, 3))
+    rgb, gt = torch.rand(12, 14, 3), torch.rand(12, 14, 3)
+    with pytest.raises(MisplatError, match="no CPU fallback"):
+        model.get_loss_dict({"rgb": rgb}, {"image": gt})
+    model.config.ssim_lambda = 0.0
+    loss = model.get_loss_dict({"rgb": rgb}, {"image": gt})
+    assert set(loss) == {"main_loss", "scale_reg"} and float(loss["scale_reg"]) == 0.0
+    assert abs(float(loss["main_loss"]) - float((gt - rgb).abs().mean())) < 1e-7
+    model.config.use_scale_regularization = True
+    model.step = 20
+    want = 0.1 * ((1.0 - 1.0) * 0 + (max(20.0, 10.0) - 10.0) + (max(50.0, 10.0) - 10.0)) / 3.0
+    assert math.isclose(float(model.get_loss_dict({"rgb": rgb}, {"image": gt})["scale_reg"].detach()), want, rel_tol=1e-5)
+    model.step = 21
+    assert float(model.get_loss_dict({"rgb": rgb}, {"image": gt})["scale_reg"]) == 0.0
+
+
 def _np_refine(P, grad2d_avg, noise, step, cfg):
     """Second, independent restatement (numpy fp64) of one 3DGS refinement step -- clone small high-gradient
     Gaussians, split large ones into two samples with scales / 1.6, prune transparent (and, after the first opacity
