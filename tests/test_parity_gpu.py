@@ -1414,6 +1414,39 @@ def test_background_fill_and_sparse_backward_equal_the_dense_backward(dev):
     assert took.get("backward_rows_refilled", 0) == 0, took
 
 
+def test_scene_above_2_5M_rows_head_fill_and_rows_on_touch_equal_the_dense_backward(dev):
+    """From 2.5 M rows the zeros of the sparse backward are written by the FIRST workgroups of the compositing backward's
+    grid (the tail is too short for 0.6 GB), the launch order table, the on-touch row clears and the flagged-rows
+    backward all run at a size the rest of the suite does not reach: 2.6 M Gaussians at 640 x 360.  Images bitwise and
+    gradients (to the order of the atomic sums) those of the two-node form with its dense per-Gaussian backward; rows
+    without a gradient exactly zero over a NaN-seeded allocator; two identical steady-state calls give identical images."""
+    from collab_splats_amd import ops
+    N = 2_600_000
+    args = _bench_like_scene(dev, N, 640, 360, seed=21, scale_mul=0.6)
+    ref_img, ref_grad, _ = _fwd_bwd(args, FUSED_NODE=False)
+    before = dict(ops.PATH_STATS)
+    leaves = [t.clone().requires_grad_(True) for t in args[:5]]
+    imgs = []
+    for rep in range(3):
+        poison = [torch.full((N * 48 + 64 * k,), float("nan"), device=dev) for k in range(2)]
+        poison += [torch.full((N * 16,), float("nan"), device=dev) for k in range(2)]
+        del poison
+        img, grad, meta = _fwd_bwd(args, leaves)
+        imgs.append(img)
+        for a, b in zip(img, ref_img):
+            assert torch.equal(a, b), rep
+        for k, (a, b) in enumerate(zip(grad, ref_grad)):
+            assert torch.isfinite(a).all(), (rep, k)
+            assert rel_err(a, b) < 2e-5, (rep, k, rel_err(a, b))
+            dead = b.reshape(b.shape[0], -1).abs().sum(1) == 0
+            assert bool(dead.any()) and float(a.reshape(a.shape[0], -1)[dead].abs().sum()) == 0.0, (rep, k)
+    took = {k: v - before.get(k, 0) for k, v in ops.PATH_STATS.items()}
+    assert took.get("backward_background_fill", 0) == 3 and took.get("forward_view_order", 0) == 3, took
+    assert took.get("forward_lazy_colour", 0) >= 2 and took.get("forward_rows_on_touch", 0) == took["forward_lazy_colour"], took
+    keys = meta["isect_ids"]
+    assert bool((keys[1:] >= keys[:-1]).all()) and meta["n_isects"] == int(meta["tiles_per_gauss"].sum())
+
+
 def test_rows_cleared_on_first_touch_are_refilled_for_a_backward_that_reads_every_row(dev):
     """A forward that cleared the packed gradient rows only where it set a colour (on-demand colours, >= 262 144
     Gaussians), followed by a backward that is NOT the flagged-rows one: a loss on ``meta["means2d"]`` sends the call down
