@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int Wd, const floa
                                                        float* __restrict__ partials) {
     __shared__ float sx[kPatch][kRowS], sy[kPatch][kRowS];
     __shared__ float hz[3][5][kPatch][kHzS];
-    __shared__ float red[4];
+    __shared__ float red[2][4];
     const int ox = blockIdx.x * kTile, oy = blockIdx.y * kTile;
     const int OW = Wd - (kWin - 1), OH = H - (kWin - 1);
     const int row_floats = 3 * Wd;
@@ -96,6 +96,14 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int Wd, const floa
         }
     }
     __syncthreads();
+    // ---- the L1 term's sum over the tile's own 16 x 16 pixels (the patch's first 16 rows and columns), all channels
+    float l1 = 0.f;
+    {
+        const int lx = threadIdx.x & (kTile - 1), ly = threadIdx.x >> 4;
+        if (ox + lx < Wd && oy + ly < H)
+            l1 = (fabsf(sx[ly][3 * lx] - sy[ly][3 * lx]) + fabsf(sx[ly][3 * lx + 1] - sy[ly][3 * lx + 1])) +
+                 fabsf(sx[ly][3 * lx + 2] - sy[ly][3 * lx + 2]);
+    }
     // ---- row pass: item = (channel, patch row, quad of output columns)
     for (int t = threadIdx.x; t < 3 * kPatch * kQuads; t += 256) {
         const int quad = t % kQuads, cr = t / kQuads;
@@ -167,27 +175,34 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(int H, int Wd, const floa
         }
     }
     s = wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    l1 = wave_sum(l1);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s; red[1][threadIdx.x >> 6] = l1; }
     __syncthreads();
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x < 2) {
+        const size_t b = (size_t)blockIdx.y * gridDim.x + blockIdx.x, nb = (size_t)gridDim.x * gridDim.y;
+        partials[threadIdx.x * nb + b] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
 }
 
+// partials: n SSIM tile sums, then n L1 tile sums.  l1_loss (or NULL): the L1 mean from elsewhere (misplat_loss_fwd);
+// NULL = the kernel's own sum.
 __global__ __launch_bounds__(1024) void ssim_final_kernel(int n, const float* __restrict__ partials, double inv_count,
-                                                          const float* __restrict__ l1_loss, float lambda,
+                                                          double inv_n3, const float* __restrict__ l1_loss, float lambda,
                                                           float* __restrict__ ssim_out, float* __restrict__ main_out) {
-    __shared__ double sm[1024];
-    double s = 0.0;
-    for (int b = threadIdx.x; b < n; b += 1024) s += (double)partials[b];
-    sm[threadIdx.x] = s;
+    __shared__ double sm[2][1024];
+    double s = 0.0, a = 0.0;
+    for (int b = threadIdx.x; b < n; b += 1024) { s += (double)partials[b]; a += (double)partials[n + b]; }
+    sm[0][threadIdx.x] = s; sm[1][threadIdx.x] = a;
     __syncthreads();
     for (int w = 512; w >= 1; w >>= 1) {
-        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        if ((int)threadIdx.x < w) { sm[0][threadIdx.x] += sm[0][threadIdx.x + w]; sm[1][threadIdx.x] += sm[1][threadIdx.x + w]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const float ssim = (float)(sm[0] * inv_count);
+        const float ssim = (float)(sm[0][0] * inv_count);
+        const float l1 = l1_loss ? *l1_loss : (float)(sm[1][0] * inv_n3);
         if (ssim_out) *ssim_out = ssim;
-        if (main_out) *main_out = (1.0f - lambda) * (l1_loss ? *l1_loss : 0.f) + lambda * (1.0f - ssim);
+        if (main_out) *main_out = (1.0f - lambda) * l1 + lambda * (1.0f - ssim);
     }
 }
 
@@ -301,7 +316,7 @@ inline bool shape_ok(int32_t h, int32_t w) { return h >= kWin && w >= kWin && (i
 extern "C" int64_t misplat_ssim_scratch_floats(int32_t height, int32_t width) {
     if (!shape_ok(height, width)) return -1;
     const int64_t gx = (width + kTile - 1) / kTile, gy = (height + kTile - 1) / kTile;
-    return 9 * (int64_t)(height - (kWin - 1)) * (width - (kWin - 1)) + gx * gy;
+    return 9 * (int64_t)(height - (kWin - 1)) * (width - (kWin - 1)) + 2 * gx * gy;
 }
 
 extern "C" int misplat_ssim_fwd(int32_t height, int32_t width, const float* rgb, const float* gt, float* scratch,
@@ -317,7 +332,8 @@ extern "C" int misplat_ssim_fwd(int32_t height, int32_t width, const float* rgb,
     hipLaunchKernelGGL(ssim_fwd_kernel, grid, dim3(256), 0, s, (int)height, (int)width, rgb, gt, make_window(), 0.01f * 0.01f,
                        0.03f * 0.03f, maps, partials);
     hipLaunchKernelGGL(ssim_final_kernel, dim3(1), dim3(1024), 0, s, (int)(grid.x * grid.y), partials,
-                       1.0 / (3.0 * (double)OH * (double)OW), l1_loss, ssim_lambda, ssim, main_loss);
+                       1.0 / (3.0 * (double)OH * (double)OW), 1.0 / (3.0 * (double)height * (double)width), l1_loss,
+                       ssim_lambda, ssim, main_loss);
     return check_launch();
 }
 

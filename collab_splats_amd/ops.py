@@ -1686,16 +1686,19 @@ class _MeanLosses(torch.autograd.Function):
         if with_rgb and with_dn and e1.numel() != n_pix:
             raise ValueError("get_loss_dict: the error maps and the image differ in size")
         dev = rgb.device if with_rgb else e1.device
-        partials = torch.empty(LOSS_PARTIALS, device=dev, dtype=torch.float32)
-        rgb_loss = torch.empty((), device=dev, dtype=torch.float32) if with_rgb else None
+        with_ssim = with_rgb and ssim_lambda > 0.0               # (the SSIM forward then sums the L1 term too: its tiles hold both images)
+        l1_here = with_rgb and not with_ssim
+        rgb_loss = torch.empty((), device=dev, dtype=torch.float32) if l1_here else None
         dn_loss = torch.empty((), device=dev, dtype=torch.float32) if with_dn else None
-        check(lib.misplat_loss_fwd(C.c_int64(n_pix), ptr(rgb if with_rgb else None), ptr(gt if with_rgb else None),
-                                   ptr(e1 if with_dn else None), ptr(e2 if with_dn else None), C.c_float(depth_ratio),
-                                   C.c_float(lam), ptr(partials), ptr(rgb_loss), ptr(dn_loss), stream_ptr()), "misplat_loss_fwd")
-        # the base model's image loss (Splatfacto: (1 - l) L1 + l (1 - SSIM)): two more launches that take the L1 mean from
-        # the device scalar above and leave the derivative maps of the SSIM for the backward
+        if l1_here or with_dn:
+            partials = torch.empty(LOSS_PARTIALS, device=dev, dtype=torch.float32)
+            check(lib.misplat_loss_fwd(C.c_int64(n_pix), ptr(rgb if l1_here else None), ptr(gt if l1_here else None),
+                                       ptr(e1 if with_dn else None), ptr(e2 if with_dn else None), C.c_float(depth_ratio),
+                                       C.c_float(lam), ptr(partials), ptr(rgb_loss), ptr(dn_loss), stream_ptr()), "misplat_loss_fwd")
+        # the base model's image loss (Splatfacto: (1 - l) L1 + l (1 - SSIM)): two launches that sum both terms tile by tile
+        # and leave the derivative maps of the SSIM for the backward
         ctx.ssim = None
-        if with_rgb and ssim_lambda > 0.0:
+        if with_ssim:
             H, W = int(rgb.shape[-3]), int(rgb.shape[-2])
             if rgb.shape[-1] != 3 or rgb.numel() != 3 * H * W:
                 raise ValueError("mean_losses: the SSIM term takes one [H,W,3] image")
@@ -1704,7 +1707,7 @@ class _MeanLosses(torch.autograd.Function):
                 raise ValueError(f"mean_losses: the SSIM window needs an image of at least 11 x 11 pixels (got {H} x {W})")
             scratch = torch.empty(n_scratch, device=dev, dtype=torch.float32)
             main = torch.empty((), device=dev, dtype=torch.float32)
-            check(lib.misplat_ssim_fwd(C.c_int32(H), C.c_int32(W), ptr(rgb), ptr(gt), ptr(scratch), ptr(rgb_loss),
+            check(lib.misplat_ssim_fwd(C.c_int32(H), C.c_int32(W), ptr(rgb), ptr(gt), ptr(scratch), None,
                                        C.c_float(ssim_lambda), None, ptr(main), stream_ptr()), "misplat_ssim_fwd")
             ctx.ssim = (H, W, scratch, float(ssim_lambda))
             rgb_loss = main

@@ -443,8 +443,9 @@ int misplat_loss_bwd(int64_t n_pix, const float* rgb, const float* gt, const flo
  * SSIM as pytorch_msssim.SSIM(data_range=1.0, size_average=True, channel=3): 11-tap gaussian window (sigma 1.5), valid
  * region (H - 10) x (W - 10), K = (0.01, 0.03), mean over positions and channels.  rgb / gt: [H,W,3]; H, W >= 11.
  * scratch: misplat_ssim_scratch_floats(H, W) floats, written by the forward (three derivative maps + tile sums) and read
- * by the backward.  l1_loss: DEVICE scalar mean |gt - rgb| (misplat_loss_fwd's rgb_loss) or NULL = 0; ssim / main_loss:
- * device scalars (either may be NULL).  Two launches; reproducible bit for bit (fixed tiles, fp64 final sum). */
+ * by the backward.  l1_loss: DEVICE scalar mean |gt - rgb| computed elsewhere (misplat_loss_fwd's rgb_loss), or NULL =
+ * the forward sums it itself (its tiles hold both images anyway: fixed tile sums, fp64 final sum); ssim / main_loss:
+ * device scalars (either may be NULL).  Two launches; reproducible bit for bit. */
 int64_t misplat_ssim_scratch_floats(int32_t height, int32_t width);
 int misplat_ssim_fwd(int32_t height, int32_t width, const float* rgb, const float* gt, float* scratch,
                      const float* l1_loss /* or NULL */, float ssim_lambda, float* ssim /* or NULL */,
