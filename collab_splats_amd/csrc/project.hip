@@ -1178,12 +1178,6 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float4* __restrict__ dst
     if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail[threadIdx.x] = 0.f;
 }
 
-#ifndef MISPLAT_SPARSE_FPL
-#define MISPLAT_SPARSE_FPL 8
-#endif
-#ifndef MISPLAT_SPARSE_MAXWAVES
-#define MISPLAT_SPARSE_MAXWAVES 2048
-#endif
 constexpr int kFlagStep = 512;          // rows a wave of the sparse backward kernels scans per step (8 flag bytes per lane)
 
 // SH backward of one row whose colour gradient is non-zero (no Jacobian cache): coefficients in, the clamp from a
@@ -1503,7 +1497,8 @@ __device__ __forceinline__ void sh_bwd_wave(int deg, int g, bool active, int nro
 // Both per-Gaussian backward stages of the flagged rows in ONE launch (outputs cleared beforehand, one camera, SH colours
 // without Jacobian cache): one scan of the flags, one queue, and a row's SH direction gradient goes from the SH stage to
 // the projection stage in registers (no v_means_dir round trip, one launch and one dependent scan less).
-template <bool SPLIT>
+// FPL: flag bytes a lane scans per step (a wave covers 64 * FPL rows per step).
+template <bool SPLIT, int FPL>
 __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
     misplat_params P, int deg, int depth_slot, const float* __restrict__ means, const float* __restrict__ quats,
     const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ viewmats,
@@ -1533,7 +1528,6 @@ __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
         }
     };
     int qn = 0;
-    constexpr int FPL = MISPLAT_SPARSE_FPL;      // flag bytes per lane and step
     for (int64_t base = (int64_t)blockIdx.x * (64 * FPL); base < P.n_gauss; base += (int64_t)gridDim.x * (64 * FPL)) {
         const int64_t r0 = base + FPL * lane;
         unsigned long long fl = 0ull;
@@ -1783,16 +1777,21 @@ int misplat_internal::gauss_bwd_sparse(const misplat_params* p, int32_t sh_degre
     if ((coeffs_rest != nullptr) != (v_coeffs_rest != nullptr)) return MISPLAT_EINVAL;
     if ((((uintptr_t)p->touched) & 7) || (((uintptr_t)coeffs | (uintptr_t)v_coeffs | (uintptr_t)v_grec | (uintptr_t)v_quats) & 15))
         return MISPLAT_EINVAL;
-    int64_t waves = ((int64_t)p->n_gauss + 64 * MISPLAT_SPARSE_FPL - 1) / (64 * MISPLAT_SPARSE_FPL);
-    if (waves > MISPLAT_SPARSE_MAXWAVES) waves = MISPLAT_SPARSE_MAXWAVES;
-    if (coeffs_rest)
-        hipLaunchKernelGGL(gauss_bwd_sparse_kernel<true>, dim3((unsigned)waves), dim3(64), 0, s, *p, sh_degree, depth_slot, means,
-                           quats, scales, opacities, viewmats, Ks, coeffs, coeffs_rest, compensations, v_grec, v_coeffs,
-                           v_coeffs_rest, v_means, v_quats, v_scales, v_opacities, (float2*)v_means2d_out);
-    else
-        hipLaunchKernelGGL(gauss_bwd_sparse_kernel<false>, dim3((unsigned)waves), dim3(64), 0, s, *p, sh_degree, depth_slot, means,
-                           quats, scales, opacities, viewmats, Ks, coeffs, coeffs_rest, compensations, v_grec, v_coeffs,
-                           v_coeffs_rest, v_means, v_quats, v_scales, v_opacities, (float2*)v_means2d_out);
+    // One wave per 256 rows (4 flag bytes per lane) up to 2.5 M rows, per 512 rows (8 bytes) above, at most 4 096 / 2 048
+    // waves: measured on one box, 1 M: 88 -> 83 us with the finer split (twice the waves for the same three per SIMD the
+    // LDS stage allows), 5 M: 66 -> 73 us with it (its rows are sparse: the wider step skips more per load).
+    const bool fine = p->n_gauss < 2500000;
+    const int step = fine ? 256 : 512;
+    int64_t waves = ((int64_t)p->n_gauss + step - 1) / step;
+    const int64_t cap = fine ? 4096 : 2048;
+    if (waves > cap) waves = cap;
+#define LAUNCH_SPARSE(SPLIT_, FPL_)                                                                                          \
+    hipLaunchKernelGGL((gauss_bwd_sparse_kernel<SPLIT_, FPL_>), dim3((unsigned)waves), dim3(64), 0, s, *p, sh_degree, depth_slot, \
+                       means, quats, scales, opacities, viewmats, Ks, coeffs, coeffs_rest, compensations, v_grec, v_coeffs,  \
+                       v_coeffs_rest, v_means, v_quats, v_scales, v_opacities, (float2*)v_means2d_out)
+    if (coeffs_rest) { if (fine) LAUNCH_SPARSE(true, 4); else LAUNCH_SPARSE(true, 8); }
+    else { if (fine) LAUNCH_SPARSE(false, 4); else LAUNCH_SPARSE(false, 8); }
+#undef LAUNCH_SPARSE
     return check_launch();
 }
 
