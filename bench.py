@@ -497,7 +497,7 @@ def main():
                                                            "backward_background_fill", "backward_staged", "backward_sink",
                                                            "forward_rows_on_touch", "backward_rows_refilled")},
                        "path_note": f"counts over the {args.steps + args.warmup} headline steps: on-demand colours, merged "
-                                    "phases, previous-step launch order, capacity misses, one-call backward, background fill",
+                                    "phases, view-keyed launch order, capacity misses, one-call backward, background fill, gradient rows cleared on touch",
                        "host": (f"whole step replayed as one hipGraph (graphs.GraphedStep, fixed capacity "
                                 f"{graphed.capacity} intersections, no host synchronisation)" if graphed is not None
                                 else "eager PyTorch step (the reference's training loop is eager)")},
