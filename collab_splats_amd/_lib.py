@@ -92,7 +92,7 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
 SYMBOLS = {
     "misplat_project_fwd": (C.c_int, 16), "misplat_project_bwd": (C.c_int, 18),
     "misplat_project_pack_fwd": (C.c_int, 17), "misplat_color_fwd": (C.c_int, 16),
-    "misplat_color_bwd": (C.c_int, 16), "misplat_project_pack_bwd": (C.c_int, 18),
+    "misplat_color_bwd": (C.c_int, 16), "misplat_project_pack_bwd": (C.c_int, 20),
     "misplat_sh_fwd": (C.c_int, 9), "misplat_sh_bwd": (C.c_int, 11),
     "misplat_sort32_workspace_bytes": (C.c_size_t, 2),
     "misplat_sort32_pairs": (C.c_int, 9), "misplat_tile_offsets32": (C.c_int, 5),

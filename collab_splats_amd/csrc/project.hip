@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(256) void project_pack_bwd_kernel(
     const float* __restrict__ viewmats, const float* __restrict__ Ks, const int32_t* __restrict__ radii,
     const float* __restrict__ comps, const float* __restrict__ v_means2d, const float* __restrict__ v_grec,
     const float* __restrict__ v_means_dir, float* __restrict__ v_means, float* __restrict__ v_quats,
-    float* __restrict__ v_scales, float* __restrict__ v_opacities) {
+    float* __restrict__ v_scales, float* __restrict__ v_opacities, const float* __restrict__ v_depth_rows, int v_depth_stride) {
     for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P.n_gauss; g += gridDim.x * blockDim.x) {
         float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
         float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
@@ -1152,6 +1152,7 @@ __global__ __launch_bounds__(256) void project_pack_bwd_kernel(
             G.v_rt = g1.z; G.v_rp[0] = g1.w; G.v_rp[1] = g2.x;
             G.v_nr[0] = g2.y; G.v_nr[1] = g2.z; G.v_nr[2] = g2.w;
             G.v_depth = depth_slot == 12 ? g3.x : (depth_slot == 13 ? g3.y : (depth_slot == 14 ? g3.z : (depth_slot == 15 ? g3.w : 0.f)));
+            if (v_depth_rows) G.v_depth = v_depth_rows[(size_t)idx * v_depth_stride];      // (the depth channel lives outside the record)
             if (P.antialiased) { o_op += v_oeff * comps[idx]; G.v_comp = v_oeff * opac; }
             else { o_op += v_oeff; G.v_comp = 0.f; }
             project_bwd_one(mean, quat, sc, cam, P, G, o_m, o_q, o_s);
@@ -1307,7 +1308,8 @@ __device__ __forceinline__ void pp_bwd_row(const misplat_params& P, const Cam& c
                                            const float* __restrict__ comps, const float* __restrict__ v_means2d,
                                            const float* __restrict__ v_grec, const float (&dir)[3], float* __restrict__ v_means,
                                            float* __restrict__ v_quats, float* __restrict__ v_scales,
-                                           float* __restrict__ v_opacities) {
+                                           float* __restrict__ v_opacities, const float* __restrict__ v_depth_rows = nullptr,
+                                           int v_depth_stride = 0) {
     float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
     float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
     float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
@@ -1325,6 +1327,7 @@ __device__ __forceinline__ void pp_bwd_row(const misplat_params& P, const Cam& c
     G.v_rt = g1.z; G.v_rp[0] = g1.w; G.v_rp[1] = g2.x;
     G.v_nr[0] = g2.y; G.v_nr[1] = g2.z; G.v_nr[2] = g2.w;
     G.v_depth = depth_slot == 12 ? g3.x : (depth_slot == 13 ? g3.y : (depth_slot == 14 ? g3.z : (depth_slot == 15 ? g3.w : 0.f)));
+    if (v_depth_rows) G.v_depth = v_depth_rows[(size_t)g * v_depth_stride];
     if (P.antialiased) { o_op += v_oeff * comps[g]; G.v_comp = v_oeff * opac; }
     else { o_op += v_oeff; G.v_comp = 0.f; }
     project_bwd_one(mean, quat, sc, cam, P, G, o_m, o_q, o_s);
@@ -1349,7 +1352,7 @@ __global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
     const float* __restrict__ viewmats, const float* __restrict__ Ks, const int32_t* __restrict__ radii,
     const float* __restrict__ comps, const float* __restrict__ v_means2d, const float* __restrict__ v_grec,
     const float* __restrict__ v_means_dir, float* __restrict__ v_means, float* __restrict__ v_quats,
-    float* __restrict__ v_scales, float* __restrict__ v_opacities) {
+    float* __restrict__ v_scales, float* __restrict__ v_opacities, const float* __restrict__ v_depth_rows, int v_depth_stride) {
     __shared__ int queue[128];
     const int lane = threadIdx.x;
     const unsigned long long lt = (1ull << lane) - 1ull;
@@ -1359,7 +1362,7 @@ __global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
         float dir[3] = {0.f, 0.f, 0.f};
         if (v_means_dir) { dir[0] = v_means_dir[3 * g]; dir[1] = v_means_dir[3 * g + 1]; dir[2] = v_means_dir[3 * g + 2]; }
         pp_bwd_row(P, cam, depth_slot, g, means, quats, scales, opacities, comps, v_means2d, v_grec, dir, v_means, v_quats, v_scales,
-                   v_opacities);
+                   v_opacities, v_depth_rows, v_depth_stride);
     };
     for (int base = blockIdx.x * 64; base < P.n_gauss; base += gridDim.x * 64) {
         const int g = base + lane;
@@ -1373,6 +1376,7 @@ __global__ __launch_bounds__(64) void project_pack_bwd_sparse_kernel(
                        g1.w != 0.f || g2.x != 0.f || g2.y != 0.f || g2.z != 0.f || g2.w != 0.f || g3.x != 0.f || g3.y != 0.f ||
                        g3.z != 0.f || g3.w != 0.f;
                 if (v_means2d) live = live || v_means2d[2 * g] != 0.f || v_means2d[2 * g + 1] != 0.f;
+                if (v_depth_rows) live = live || v_depth_rows[(size_t)g * v_depth_stride] != 0.f;
             }
             if (!live) {
                 float m0 = 0.f, m1 = 0.f, m2 = 0.f;
@@ -1800,9 +1804,11 @@ extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_s
                                         const float* viewmats, const float* Ks, const int32_t* radii,
                                         const float* compensations, const float* v_means2d, const float* v_grec,
                                         const float* v_means_dir, float* v_means, float* v_quats,
-                                        float* v_scales, float* v_opacities, misplat_stream_t stream) {
+                                        float* v_scales, float* v_opacities, const float* v_depth_rows,
+                                        int32_t v_depth_stride, misplat_stream_t stream) {
     if (!p || p->n_gauss < 0 || p->n_cams < 1 || (p->activations && p->n_cams != 1)) return MISPLAT_EINVAL;   // (activations: one camera)
     if (depth_slot != -1 && (depth_slot < 12 || depth_slot > 15)) return MISPLAT_EINVAL;
+    if (v_depth_rows && (v_depth_stride < 1 || depth_slot != -1)) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
     if (p->n_cams == 1) {
         // one wave per workgroup, at most 2 048 of them (the kernel's 2 waves per SIMD): every wave scans enough rows to
@@ -1811,12 +1817,12 @@ extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_s
         if (waves > 2048) waves = 2048;
         hipLaunchKernelGGL(project_pack_bwd_sparse_kernel, dim3((unsigned)waves), dim3(64), 0, (hipStream_t)stream, *p, depth_slot,
                            means, quats, scales, opacities, viewmats, Ks, radii, compensations, v_means2d, v_grec, v_means_dir,
-                           v_means, v_quats, v_scales, v_opacities);
+                           v_means, v_quats, v_scales, v_opacities, v_depth_rows, (int)v_depth_stride);
         return check_launch();
     }
     hipLaunchKernelGGL(project_pack_bwd_kernel, dim3(grid_for(p->n_gauss, 256)), dim3(256), 0, (hipStream_t)stream,
                        *p, depth_slot, means, quats, scales, opacities, viewmats, Ks, radii, compensations, v_means2d,
-                       v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities);
+                       v_grec, v_means_dir, v_means, v_quats, v_scales, v_opacities, v_depth_rows, (int)v_depth_stride);
     return check_launch();
 }
 

@@ -373,7 +373,7 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
     if (rc != MISPLAT_OK) return rc;
     return misplat_project_pack_bwd(p, b->depth_slot, b->means, b->quats, b->scales, b->opacities, b->viewmats, b->Ks, b->radii,
                                     b->compensations, b->v_means2d, b->v_grec, b->v_means_dir, b->v_means, b->v_quats, b->v_scales,
-                                    b->v_opacities, (misplat_stream_t)s);
+                                    b->v_opacities, nullptr, 0, (misplat_stream_t)s);
 }
 
 // What misplat_raster_bwd will do with these arguments (host only, nothing is enqueued): bit 0 -- the two-launch form

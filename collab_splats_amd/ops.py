@@ -1081,7 +1081,7 @@ class _RasterFused(torch.autograd.Function):
             check(lib.misplat_project_pack_bwd(C.byref(P), C.c_int32(ctx.depth_slot), ptr(means), ptr(quats),
                                                ptr(scales), ptr(opacities), ptr(viewmats), ptr(Ks), ptr(radii),
                                                ptr(comps), ptr(vm2d), ptr(v_grec), ptr(v_means_dir), ptr(v_means),
-                                               ptr(v_quats), ptr(v_scales), ptr(v_opac), stream_ptr()),
+                                               ptr(v_quats), ptr(v_scales), ptr(v_opac), None, C.c_int32(0), stream_ptr()),
                   "misplat_project_pack_bwd")
         # gsplat's contract: the screen-space gradient rides on meta["means2d"]
         m2d = ctx.means2d_ref()
@@ -1245,7 +1245,7 @@ class _ProjectPack(torch.autograd.Function):
         check(lib.misplat_project_pack_bwd(C.byref(P), C.c_int32(ctx.depth_slot), ptr(means), ptr(quats),
                                            ptr(scales), ptr(opacities), ptr(viewmats), ptr(Ks), ptr(radii),
                                            ptr(comps), ptr(v_means2d), ptr(v_grec), ptr(fused_dir), ptr(v_means),
-                                           ptr(v_quats), ptr(v_scales), ptr(v_opac), stream_ptr()),
+                                           ptr(v_quats), ptr(v_scales), ptr(v_opac), None, C.c_int32(0), stream_ptr()),
               "misplat_project_pack_bwd")
         if side is not cur:
             cur.wait_stream(side)
@@ -1423,20 +1423,21 @@ class _ProjectPackX(torch.autograd.Function):
         v_colors = torch.empty_like(colors)
         check(lib.misplat_color_bwd_x(C.byref(P), C.c_int32(D), C.c_int32(ctx.per_cam), C.c_int32(nxq), ptr(radii),
                                       ptr(v_grec), ptr(v_featx), ptr(v_colors), stream_ptr()), "misplat_color_bwd_x")
-        depth_slot = -1
+        depth_slot, v_depth_rows, v_depth_stride = -1, None, 0
         if ctx.depth_channel:                       # channel D carries the depth
             if D < 4:
                 depth_slot = 12 + D
-            else:                                   # it lives in featx: park its gradient in the (consumed) slot 15
-                v_grec = v_grec.clone()
-                v_grec[:, 15] = v_featx[:, D - 4]
-                depth_slot = 15
+            else:                                   # it lives in featx: the projection backward reads it from there (float D - 4
+                #                                     of every v_featx row) -- no copy of the 64-byte gradient rows to park it in
+                v_depth_rows = C.c_void_p(v_featx.data_ptr() + 4 * (D - 4))
+                v_depth_stride = 4 * nxq
         v_means, v_quats = torch.empty_like(means), torch.empty_like(quats)
         v_scales, v_opac = torch.empty_like(scales), torch.empty_like(opacities)
         check(lib.misplat_project_pack_bwd(C.byref(P), C.c_int32(depth_slot), ptr(means), ptr(quats), ptr(scales),
                                            ptr(opacities), ptr(viewmats), ptr(Ks), ptr(radii), ptr(comps),
                                            ptr(v_means2d), ptr(v_grec), ptr(None), ptr(v_means), ptr(v_quats),
-                                           ptr(v_scales), ptr(v_opac), stream_ptr()), "misplat_project_pack_bwd")
+                                           ptr(v_scales), ptr(v_opac), v_depth_rows, C.c_int32(v_depth_stride), stream_ptr()),
+              "misplat_project_pack_bwd")
         return v_means, v_quats, v_scales, v_opac, v_colors, None, None, None, None, None
 
 

@@ -172,13 +172,16 @@ int misplat_color_bwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D
                       float* v_means_dir /*[N,3], SH only*/, const float* sh_aux /* or NULL */,
                       misplat_stream_t stream);
 /* depth_slot: 12..15 = record slot carrying the depth channel, -1 = none.  v_means_dir may be
- * NULL.  Outputs v_means[N,3] v_quats[N,4] v_scales[N,3] v_opacities[N], summed over cameras. */
+ * NULL.  v_depth_rows (or NULL; then depth_slot must be -1): the depth channel's gradient lives OUTSIDE the record -- row
+ * g's value is v_depth_rows[g * v_depth_stride] (the N-D colour path keeps channels >= 4 in featx: pass a pointer into
+ * v_featx).  Outputs v_means[N,3] v_quats[N,4] v_scales[N,3] v_opacities[N], summed over cameras. */
 int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_slot, const float* means,
                              const float* quats, const float* scales, const float* opacities,
                              const float* viewmats, const float* Ks, const int32_t* radii,
                              const float* compensations, const float* v_means2d, const float* v_grec,
                              const float* v_means_dir, float* v_means, float* v_quats,
-                             float* v_scales, float* v_opacities, misplat_stream_t stream);
+                             float* v_scales, float* v_opacities, const float* v_depth_rows,
+                             int32_t v_depth_stride, misplat_stream_t stream);
 
 /* ---- a2.3 binning: for every tile the Gaussian rows whose rectangle mean2d +- radii touches it, in
  * (depth, row) order -- the order of gsplat's 64-bit (tile | depth) key sort, without the keys.  Two routes to the
