@@ -223,10 +223,13 @@ __device__ __forceinline__ bool background_fill(const misplat_internal::FillList
 
 template <int CD, int PPL, int NXQ = 0, bool LAZY = false>
 #ifndef MISPLAT_FWD_WAVES
-#define MISPLAT_FWD_WAVES 6            /* waves per SIMD the PPL-2 forward is compiled for: 80 VGPRs.  The plain kernel needs
-                                          no more anyway; the on-demand-colour variant (98 unbounded) then spills 7 registers
-                                          around the per-BATCH staging / evaluation, none in the trip loop: measured
-                                          0.222 -> 0.212 ms (fixed view), 0.370 -> 0.362 (cycling views) at 1 M / 1080p */
+#define MISPLAT_FWD_WAVES 5            /* waves per SIMD the PPL-2 forward is compiled for (5: <= 102 VGPRs, 6: 80).  The plain
+                                          kernel needs 80 anyway; the on-demand-colour variant (98 unbounded) bounded to six
+                                          waves spills around the per-BATCH staging / evaluation -- 7 registers when this was
+                                          first measured (0.222 -> 0.212 ms fixed view, 0.370 -> 0.362 cycling, 1 M / 1080p),
+                                          10 since the evaluation also clears the record's gradient row.  Re-measured at the
+                                          end of round 3 (view-keyed orders on): five waves, no spill, 0.339 -> 0.323 ms on the
+                                          cycling views, 0.217 -> 0.213 fixed, 5 M and 100 k unchanged; four waves 0.344 */
 #endif
 __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0) ? MISPLAT_FWD_WAVES : 1) void blend_fwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* grec,
