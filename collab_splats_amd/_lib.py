@@ -35,10 +35,11 @@ class Params(C.Structure):
                 ("far_plane", C.c_float), ("radius_clip", C.c_float), ("radius_sigma", C.c_float),
                 ("alpha_max", C.c_float), ("alpha_min", C.c_float), ("t_stop", C.c_float),
                 ("median_t", C.c_float), ("jacobian_margin", C.c_float), ("plane_eps", C.c_float),
-                ("ppl_fwd", C.c_int32), ("ppl_bwd", C.c_int32), ("ed_slot", C.c_int32), ("sub_blocks", C.c_int32),
+                ("ed_slot", C.c_int32), ("reserved_q", C.c_int32),
                 ("unit_perm", C.c_void_p), ("unit_work", C.c_void_p), ("touched", C.c_void_p),
                 ("activations", C.c_int32), ("unit_stride", C.c_int32), ("unit_sel", C.c_void_p),
-                ("unit_slots", C.c_int32), ("reserved_p", C.c_int32)]
+                ("unit_slots", C.c_int32), ("front_pass", C.c_int32), ("front_n", C.c_void_p), ("tile_flag", C.c_void_p),
+                ("unit_reach", C.c_void_p), ("front_depths", C.c_void_p)]
 
 
 class RasterArgs(C.Structure):
@@ -46,7 +47,7 @@ class RasterArgs(C.Structure):
     _P = C.c_void_p
     _fields_ = ([(n, C.c_void_p) for n in ("means", "quats", "scales", "opacities", "colors", "colors_rest", "viewmats", "Ks")]
                 + [(n, C.c_int32) for n in ("sh_degree", "K_or_D", "n_color", "per_cam", "depth_channel", "color_dim",
-                                            "colour_pending", "lazy_colour")]
+                                            "reserved_c", "lazy_colour")]
                 + [(n, C.c_void_p) for n in ("radii", "means2d", "depths", "compensations", "grec", "sh_aux", "v_grec_zero",
                                              "tiles_per_gauss", "rect2", "cellhist", "cell_count", "cell_offs", "cell_cursor", "order",
                                              "rect_sorted", "counters", "tile_count", "offsets", "payload", "flatten_ids", "scratch")]
@@ -54,7 +55,9 @@ class RasterArgs(C.Structure):
                 + [(n, C.c_void_p) for n in ("n_isects_host", "v_abs_zero", "render", "alpha", "exp_depth", "med_depth",
                                              "normal", "last_ids", "median_ids", "unit_perm_in", "unit_work",
                                              "unit_perm_out", "ev_blend_begin", "ev_blend_end", "order_table", "order_sel")]
-                + [("order_slots", C.c_int32), ("order_stride", C.c_int32)])
+                + [("order_slots", C.c_int32), ("order_stride", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("unit_reach", "front_n", "tile_flag")]
+                + [("front_margin", C.c_float), ("front_min_bucket", C.c_int32)])
 
 
 class RasterBwdArgs(C.Structure):
@@ -76,7 +79,7 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
                 near_plane: float = 0.01, far_plane: float = 1e10, radius_clip: float = 0.0,
                 radius_sigma: float = 3.33, alpha_max: float = 0.999, alpha_min: float = 1.0 / 255.0,
                 t_stop: float = 1e-4, median_t: float = 0.5, jacobian_margin: float = 0.3,
-                plane_eps: float = 1e-6, ppl_fwd: int = 0, ppl_bwd: int = 0, ed_slot: int = -1) -> Params:
+                plane_eps: float = 1e-6, ed_slot: int = -1) -> Params:
     if tile_size != MISPLAT_TILE:
         raise ValueError(f"tile_size must be {MISPLAT_TILE} (got {tile_size})")
     tw = (width + tile_size - 1) // tile_size
@@ -84,8 +87,7 @@ def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: i
     return Params(n_gauss, n_cams, width, height, tile_size, tw, th, int(antialiased),
                   int(opacity_aware_radius), eps2d, near_plane, far_plane, radius_clip, radius_sigma,
                   alpha_max, alpha_min, t_stop, median_t, jacobian_margin, plane_eps,
-                  int(os.environ.get("MISPLAT_PPL_FWD", ppl_fwd)), int(os.environ.get("MISPLAT_PPL_BWD", ppl_bwd)), int(ed_slot),
-                  int(os.environ.get("MISPLAT_SUB_BLOCKS", 0)), None, None, None)
+                  int(ed_slot), 0, None, None, None)
 
 
 # name -> (restype, n_args); every symbol include/misplat.h declares
@@ -94,16 +96,8 @@ SYMBOLS = {
     "misplat_project_pack_fwd": (C.c_int, 17), "misplat_color_fwd": (C.c_int, 16),
     "misplat_color_bwd": (C.c_int, 16), "misplat_project_pack_bwd": (C.c_int, 20),
     "misplat_sh_fwd": (C.c_int, 9), "misplat_sh_bwd": (C.c_int, 11),
-    "misplat_sort32_workspace_bytes": (C.c_size_t, 2),
-    "misplat_sort32_pairs": (C.c_int, 9), "misplat_tile_offsets32": (C.c_int, 5),
     "misplat_isect_ids": (C.c_int, 6), "misplat_tile_sort": (C.c_int, 10),
-    "misplat_tile_count_blocks": (C.c_int, 8),
-    "misplat_tile_emit_blocks": (C.c_int, 10),
-    "misplat_sort16_workspace_bytes": (C.c_size_t, 2),
-    "misplat_sort16_pairs": (C.c_int, 9),
-    "misplat_tile_offsets16": (C.c_int, 5),
-    "misplat_adam_step": (C.c_int, 12),
-    "misplat_radix_workspace_bytes": (C.c_size_t, 4), "misplat_radix_sort_pairs": (C.c_int, 11), "misplat_pack": (C.c_int, 11),
+    "misplat_adam_step": (C.c_int, 12), "misplat_pack": (C.c_int, 11),
     "misplat_blend_fwd": (C.c_int, 15), "misplat_blend_fwd_lazy": (C.c_int, 23), "misplat_blend_bwd": (C.c_int, 21),
     "misplat_color_fwd_x": (C.c_int, 11), "misplat_color_bwd_x": (C.c_int, 9),
     "misplat_blend_fwd_x": (C.c_int, 17), "misplat_blend_bwd_x_atomic": (C.c_int, 22),
@@ -113,7 +107,7 @@ SYMBOLS = {
     "misplat_ssim_scratch_floats": (C.c_int64, 2), "misplat_ssim_fwd": (C.c_int, 10), "misplat_ssim_bwd": (C.c_int, 9),
     "misplat_bucket_plan": (C.c_int, 3), "misplat_bucket_count": (C.c_int, 10), "misplat_bucket_rows": (C.c_int, 14),
     "misplat_bucket_tiles": (C.c_int, 11),
-    "misplat_unit_order": (C.c_int, 5), "misplat_raster_fwd": (C.c_int, 5), "misplat_raster_bwd": (C.c_int, 4), "misplat_raster_bwd_plan": (C.c_int, 2), "misplat_graph_cache_create": (C.c_void_p, 1),
+    "misplat_unit_order": (C.c_int, 4), "misplat_raster_fwd": (C.c_int, 5), "misplat_raster_bwd": (C.c_int, 4), "misplat_raster_bwd_plan": (C.c_int, 2), "misplat_graph_cache_create": (C.c_void_p, 1),
     "misplat_graph_cache_destroy": (None, 1), "misplat_graph_cache_stats": (C.c_int, 3), "misplat_wait_count": (C.c_int64, 2), "misplat_zero_bytes": (C.c_int, 3), "misplat_stream_copy": (C.c_int, 5),
     "misplat_version": (C.c_char_p, 0),
 }

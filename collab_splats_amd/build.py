@@ -31,7 +31,6 @@ SOURCES = {
     "blend.hip": [],
     "epilogue.hip": [],
     "ssim.hip": [],
-    "sort.hip": [],
     "optim.hip": [],
 }
 

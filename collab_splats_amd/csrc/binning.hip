@@ -1,5 +1,5 @@
-// binning.hip -- the per-tile depth sort (one workgroup per tile, register-resident LDS radix), the
-// "pertile" pair emission + tile-bit radix sort (rocPRIM) + per-tile offsets, record packing.
+// binning.hip -- the per-tile depth sort (one workgroup per tile: bin + rank, or a register-resident LDS radix),
+// gsplat's isect_ids on demand, record packing.
 // gfx950 only.  SURVEY.md section 8 row a2.3 (inside gsplat-rade's rasterization(), called at
 // /root/reference/collab_splats/models/rade_gs_model.py:439-465).  Integer stage: results are
 // bit-exact against the CPU restatement (tests/test_parity_gpu.py).  The default bucketing is in
@@ -9,9 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 #include <stdint.h>
 #include "misplat.h"
+#include "internal.h"
 
 namespace {
 
@@ -70,30 +70,6 @@ __global__ __launch_bounds__(256) void pack_kernel(int64_t n_rows, int cd,
 
 
 
-// offsets[t] = first sorted position whose tile id is >= t.  Four positions per thread, all loads
-// issued before any use.
-template <typename KT>
-__global__ __launch_bounds__(256) void tile_offsets32_kernel(const KT* __restrict__ tiles, int64_t n,
-                                                             int n_tiles, int32_t* __restrict__ offsets) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 <= n; i0 += 4 * stride) {
-        int64_t cur[4], prev[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int64_t i = i0 + u * stride;
-            cur[u] = (i < n) ? (int64_t)tiles[i] : (int64_t)n_tiles - 1;
-            prev[u] = (i > 0 && i <= n) ? (int64_t)tiles[i - 1] : -1;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int64_t i = i0 + u * stride;
-            if (i > n) continue;
-            const int64_t hi = (i == n) ? (int64_t)n_tiles - 1 : cur[u];
-            for (int64_t t = prev[u] + 1; t <= hi; t++) offsets[t] = (int32_t)i;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void isect_ids_kernel(const uint32_t* __restrict__ tiles,
                                                         const int32_t* __restrict__ flatten_ids,
                                                         const float* __restrict__ depths, int64_t n,
@@ -111,7 +87,7 @@ __global__ __launch_bounds__(256) void isect_ids_kernel(const uint32_t* __restri
 // launch-latency-bound kernels of a global 32-bit depth sort of the rows.
 // Per pass: per-wave digit histograms (LDS atomics) -> exclusive scan over (digit, wave) -> every wave
 // walks its contiguous chunk 64 entries at a time in order, peers found with one __ballot per digit
-// bit, rank = popcount of the lower peers (the scheme of csrc/sort.hip at workgroup scope).
+// bit, rank = popcount of the lower peers (one ballot per digit bit).
 // GLOBAL = true: the ping-pong buffers live in global scratch (lists longer than the largest LDS class).
 // Register-resident classes: a bucket of n <= 64*WAVES*R entries; wave w owns the contiguous entries
 // [w*64R, (w+1)*64R) and lane l holds entries w*64R + r*64 + l (r < R) in registers for the whole sort.
@@ -125,8 +101,18 @@ __global__ __launch_bounds__(256) void isect_ids_kernel(const uint32_t* __restri
 // Tiles a workgroup of a size class walks.  A grid as large as n_tiles: one tile each.  A smaller grid (the
 // rare classes): a contiguous chunk per workgroup, first tested in parallel (one tile per thread) so that
 // workgroups without a bucket of the class leave after one round of loads instead of a serial walk.
+// Which tiles a sort launch looks at (front-only ordering, below): mode 0 -- all; mode 1 -- those the front kernel left
+// undone (state = front_n: < 0); mode 2 -- those the compositing flagged (state = tile_flag: != 0).
+struct TileSel {
+    const int32_t* state;
+    int mode;
+    __device__ __forceinline__ bool wants(int t) const {
+        return mode == 0 || (mode == 1 ? state[t] < 0 : state[t] != 0);
+    }
+};
+
 __device__ __forceinline__ bool tile_range(const int32_t* __restrict__ offsets, int n_tiles, int64_t n_isects, int lo,
-                                           int hi, int& t_first, int& t_last, int& t_step, int has_longest) {
+                                           int hi, int& t_first, int& t_last, int& t_step, int has_longest, TileSel sel) {
     // offsets[n_tiles + 1] (when present) is the longest bucket: a size class above it has nothing to do
     if (has_longest && offsets[n_tiles + 1] <= lo) return false;
     if ((int)gridDim.x >= n_tiles) {
@@ -141,7 +127,7 @@ __device__ __forceinline__ bool tile_range(const int32_t* __restrict__ offsets, 
     for (int t = t_first + threadIdx.x; t < t_last; t += blockDim.x) {
         const int e1 = min(offsets[t + 1], (int)n_isects);
         const int n = e1 - min(offsets[t], e1);
-        mine |= (n > lo && n <= hi);
+        mine |= (n > lo && n <= hi) && sel.wants(t);
     }
     return __syncthreads_or(mine) != 0;
 }
@@ -380,7 +366,7 @@ __device__ __forceinline__ bool tile_bin_rank(const uint32_t (&key)[R], const ui
             const uint32_t kj = L.xk[j], vj = L.xv[j];
             before += (kj < k || (kj == k && vj < v)) ? 1 : 0;
         }
-        payload[beg + s0 + before] = (int32_t)v;
+        if (payload) payload[beg + s0 + before] = (int32_t)v;
         flatten_ids[beg + s0 + before] = HAS_VALS ? isect_gid[v] : (int32_t)v;
     }
     return true;
@@ -534,15 +520,16 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? MISPLAT_TS_B_B
                                                                    const float* __restrict__ depths,
                                                                    const int32_t* __restrict__ isect_gid,
                                                                    int32_t* __restrict__ payload,
-                                                                   int32_t* __restrict__ flatten_ids, int has_longest) {
+                                                                   int32_t* __restrict__ flatten_ids, int has_longest,
+                                                                   TileSel sel) {
     __shared__ tile_sort_lds<WAVES, R> L;
     int t_first, t_last, t_step;
-    if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step, has_longest)) return;
+    if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step, has_longest, sel)) return;
     for (int t = t_first; t < t_last; t += t_step) {
         const int end = min(offsets[t + 1], (int)n_isects);     // offsets: n_tiles + 1 entries; n_isects: buffer capacity
         const int beg = min(offsets[t], end);
         const int n = end - beg;
-        if (n <= lo || n > hi) continue;               // uniform over the block (n >= 1 from here)
+        if (n <= lo || n > hi || !sel.wants(t)) continue;      // uniform over the block (n >= 1 from here)
         if (lo == 0) sort_bucket_regs<WAVES, R, HAS_VALS, UNORDERED, true>(L, beg, n, depths, isect_gid, payload, flatten_ids);
         else sort_bucket_regs<WAVES, R, HAS_VALS, UNORDERED, false>(L, beg, n, depths, isect_gid, payload, flatten_ids);
     }
@@ -650,25 +637,6 @@ __device__ __forceinline__ void sort_bucket_passes(uint32_t* lds32, int beg, int
     __syncthreads();
 }
 
-template <int CAP, int WAVES, bool HAS_VALS, bool GLOBAL, bool UNORDERED>
-__global__ __launch_bounds__(64 * WAVES) void tile_sort_kernel(const int32_t* __restrict__ offsets, int n_tiles,
-                                                               int64_t n_isects, int lo, int hi,
-                                                               const float* __restrict__ depths,
-                                                               const int32_t* __restrict__ isect_gid,
-                                                               int32_t* payload, int32_t* flatten_ids,   // (aliased below)
-                                                               uint32_t* scratch, int has_longest) {
-    extern __shared__ uint32_t lds32[];
-    int t_first, t_last, t_step;
-    if (!tile_range(offsets, n_tiles, n_isects, lo, hi, t_first, t_last, t_step, has_longest)) return;
-    for (int t = t_first; t < t_last; t += t_step) {
-        const int end = min(offsets[t + 1], (int)n_isects);
-        const int beg = min(offsets[t], end);
-        const int n = end - beg;
-        if (n <= lo || n > hi) continue;                 // another size class (uniform over the block)
-        sort_bucket_passes<CAP, WAVES, HAS_VALS, GLOBAL, UNORDERED>(lds32, beg, n, depths, isect_gid, payload, flatten_ids, scratch);
-    }
-}
-
 // Every size class that has no grid of its own in this launch plan, in ONE launch of 1 024-thread workgroups: a
 // workgroup tests its contiguous chunk of tiles in parallel, leaves if none of them is its business, and otherwise sorts
 // the buckets of the uncovered classes one after the other -- up to 8 192 entries in registers (16 waves x 8 per lane,
@@ -679,7 +647,7 @@ template <bool HAS_VALS, bool UNORDERED>
 __global__ __launch_bounds__(1024) void tile_sort_rest_kernel(const int32_t* __restrict__ offsets, int n_tiles, int64_t n_isects,
                                                               int covered, const float* __restrict__ depths,
                                                               const int32_t* __restrict__ isect_gid, int32_t* payload,
-                                                              int32_t* flatten_ids, uint32_t* scratch) {
+                                                              int32_t* flatten_ids, uint32_t* scratch, TileSel sel) {
     __shared__ tile_sort_lds<16, 8> L;
     __shared__ uint32_t hist_passes[16 * 256];
     const int per = (n_tiles + gridDim.x - 1) / gridDim.x;
@@ -688,7 +656,7 @@ __global__ __launch_bounds__(1024) void tile_sort_rest_kernel(const int32_t* __r
     for (int t = t_first + threadIdx.x; t < t_last; t += blockDim.x) {
         const int e1 = min(offsets[t + 1], (int)n_isects);
         const int n = e1 - min(offsets[t], e1);
-        mine |= n > 0 && !((covered >> size_class(n)) & 1);
+        mine |= n > 0 && !((covered >> size_class(n)) & 1) && sel.wants(t);
     }
     if (!__syncthreads_or(mine)) return;
     for (int t = t_first; t < t_last; t++) {
@@ -697,137 +665,11 @@ __global__ __launch_bounds__(1024) void tile_sort_rest_kernel(const int32_t* __r
         const int n = end - beg;
         if (n <= 0) continue;
         const int cls = size_class(n);
-        if ((covered >> cls) & 1) continue;              // (uniform over the block)
+        if (((covered >> cls) & 1) || !sel.wants(t)) continue;      // (uniform over the block)
         if (cls < 3) sort_bucket_regs<16, 8, HAS_VALS, UNORDERED, false>(L, beg, n, depths, isect_gid, payload, flatten_ids);
         else sort_bucket_passes<0, 16, HAS_VALS, true, UNORDERED>(hist_passes, beg, n, depths, isect_gid, payload, flatten_ids, scratch);
     }
 }
-
-// ---- row-order emission without a global scan array ("pertile" ordering): rows are cut into blocks of
-// MISPLAT_COUNT_BLOCK; tile_count_blocks writes the per-row counts and one sum per block, a single
-// workgroup scans the block sums (and produces the grand total the host needs), and the emission kernel
-// redoes the cheap in-block scan itself.  Replaces count + int64 cast + device scan + subtraction.
-__global__ __launch_bounds__(MISPLAT_COUNT_BLOCK) void tile_count_blocks_kernel(int64_t total, int tw, int th,
-                                                                                const float* __restrict__ means2d,
-                                                                                const int32_t* __restrict__ radii,
-                                                                                int32_t* __restrict__ tiles_per_gauss,
-                                                                                int32_t* __restrict__ block_sums) {
-    __shared__ uint32_t wsum[MISPLAT_COUNT_BLOCK / 64];
-    const int64_t idx = (int64_t)blockIdx.x * MISPLAT_COUNT_BLOCK + threadIdx.x;
-    int n = 0;
-    if (idx < total) {
-        const int rx = radii[2 * idx], ry = radii[2 * idx + 1];
-        if (rx > 0 || ry > 0) {
-            int x0, x1, y0, y1;
-            tile_rect(means2d[2 * idx], means2d[2 * idx + 1], rx, ry, tw, th, x0, x1, y0, y1);
-            n = (x1 - x0) * (y1 - y0);
-        }
-        tiles_per_gauss[idx] = n;
-    }
-    const uint32_t incl = wave_scan_incl((uint32_t)n, 0u, [](uint32_t a, uint32_t b) { return a + b; });
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-#pragma unroll
-        for (int w = 0; w < MISPLAT_COUNT_BLOCK / 64; w++) t += wsum[w];
-        block_sums[blockIdx.x] = (int32_t)t;
-    }
-}
-
-// one workgroup: block_offs = exclusive scan (int64) of block_sums, *n_isects = grand total
-__global__ __launch_bounds__(1024) void tile_block_scan_kernel(int n_blocks, const int32_t* __restrict__ block_sums,
-                                                               int64_t* __restrict__ block_offs,
-                                                               int64_t* __restrict__ n_isects) {
-    __shared__ unsigned long long wsum[16];
-    const int per = (n_blocks + 1023) / 1024;
-    const int b = min(threadIdx.x * per, n_blocks), e = min(b + per, n_blocks);
-    unsigned long long tot = 0;
-    for (int i = b; i < e; i++) tot += (unsigned long long)(uint32_t)block_sums[i];
-    unsigned long long incl = tot;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long up = __shfl_up(incl, off);
-        if (lane >= off) incl += up;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    unsigned long long carry = 0;
-    for (int w = 0; w < wave; w++) carry += wsum[w];
-    unsigned long long run = carry + incl - tot;
-    for (int i = b; i < e; i++) {
-        block_offs[i] = (int64_t)run;
-        run += (unsigned long long)(uint32_t)block_sums[i];
-    }
-    if (threadIdx.x == 1023) *n_isects = (int64_t)(carry + incl);
-}
-
-template <typename KT>
-__global__ __launch_bounds__(MISPLAT_COUNT_BLOCK) void tile_emit_blocks_kernel(int64_t total, int n_gauss, int tw, int th,
-                                                                               const float* __restrict__ means2d,
-                                                                               const int32_t* __restrict__ radii,
-                                                                               const int32_t* __restrict__ tiles_per_gauss,
-                                                                               const int64_t* __restrict__ block_offs,
-                                                                               KT* __restrict__ tile_ids,
-                                                                               int32_t* __restrict__ slot_ids,
-                                                                               int32_t* __restrict__ isect_gid) {
-    // slot_ids == NULL: only the Gaussian row is emitted (it is then the sort payload).
-    // Cooperative expansion: the block's rows publish (exclusive offset, tile rectangle) in LDS; thread t then
-    // produces outputs t, t + 256, ... of the block -- it finds the owning row with an 8-step binary search and
-    // decodes the tile from the offset inside the row -- so every store instruction writes 64 consecutive
-    // elements and no lane idles while a neighbour walks a large rectangle.
-    __shared__ uint32_t wsum[MISPLAT_COUNT_BLOCK / 64];
-    __shared__ uint32_t s_excl[MISPLAT_COUNT_BLOCK];
-    __shared__ uint32_t s_xy[MISPLAT_COUNT_BLOCK];        // x0 | y0 << 16
-    __shared__ uint32_t s_base[MISPLAT_COUNT_BLOCK];      // camera * tiles_per_camera
-    __shared__ float s_rw[MISPLAT_COUNT_BLOCK];           // 1 / rectangle width
-    __shared__ uint32_t s_w[MISPLAT_COUNT_BLOCK];
-    const int64_t idx = (int64_t)blockIdx.x * MISPLAT_COUNT_BLOCK + threadIdx.x;
-    const uint32_t n = idx < total ? (uint32_t)tiles_per_gauss[idx] : 0u;
-    const uint32_t incl = wave_scan_incl(n, 0u, [](uint32_t a, uint32_t b) { return a + b; });
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) wsum[wave] = incl;
-    uint32_t xy = 0u, w = 1u, cbase = 0u;
-    if (n != 0u) {
-        int x0, x1, y0, y1;
-        tile_rect(means2d[2 * idx], means2d[2 * idx + 1], radii[2 * idx], radii[2 * idx + 1], tw, th, x0, x1, y0, y1);
-        xy = (uint32_t)x0 | ((uint32_t)y0 << 16);
-        w = (uint32_t)(x1 - x0);
-        cbase = (uint32_t)(idx / n_gauss) * (uint32_t)(tw * th);
-    }
-    __syncthreads();
-    uint32_t before = incl - n, block_total = 0u;
-#pragma unroll
-    for (int k = 0; k < MISPLAT_COUNT_BLOCK / 64; k++) { before += (k < wave) ? wsum[k] : 0u; block_total += wsum[k]; }
-    s_excl[threadIdx.x] = before; s_xy[threadIdx.x] = xy; s_base[threadIdx.x] = cbase;
-    s_w[threadIdx.x] = w; s_rw[threadIdx.x] = 1.0f / (float)w;
-    __syncthreads();
-    const int64_t j0 = block_offs[blockIdx.x];
-    const int64_t row0 = (int64_t)blockIdx.x * MISPLAT_COUNT_BLOCK;
-    for (uint32_t o = threadIdx.x; o < block_total; o += MISPLAT_COUNT_BLOCK) {
-        int lo = 0, hi = MISPLAT_COUNT_BLOCK - 1;            // largest r with s_excl[r] <= o (rows with n = 0 never win)
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (s_excl[mid] <= o) lo = mid; else hi = mid - 1;
-        }
-        const uint32_t q = o - s_excl[lo];
-        const uint32_t rw_i = s_w[lo];
-        // (q + 0.5) / w is at least 0.5 / w away from an integer: the float quotient truncates exactly
-        const uint32_t ty = (uint32_t)(((float)q + 0.5f) * s_rw[lo]);
-        const uint32_t tx = q - ty * rw_i;
-        const uint32_t pxy = s_xy[lo];
-        const uint32_t tile = s_base[lo] + ((pxy >> 16) + ty) * (uint32_t)tw + (pxy & 0xffffu) + tx;
-        const int64_t j = j0 + (int64_t)o;
-        tile_ids[j] = (KT)tile;
-        if (slot_ids) slot_ids[j] = (int32_t)j;
-        isect_gid[j] = (int32_t)(row0 + lo);
-    }
-}
-
-
-
 
 inline int grid_for(int64_t n, int block) {
     int64_t b = (n + block - 1) / block;
@@ -858,74 +700,6 @@ extern "C" int misplat_pack(int64_t n_rows, int32_t color_dim, const float* mean
 
 
 
-extern "C" size_t misplat_sort32_workspace_bytes(int64_t n, int32_t end_bit) {
-    size_t bytes = 0;
-    if (n <= 0) return 16;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr,
-                                             (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u,
-                                             (unsigned)end_bit, (hipStream_t) nullptr);
-    if (e != hipSuccess) return 0;
-    return bytes < 16 ? 16 : bytes;
-}
-
-extern "C" int misplat_sort32_pairs(void* workspace, size_t workspace_bytes, const uint32_t* keys_in,
-                                    uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
-                                    int32_t end_bit, misplat_stream_t stream) {
-    if (n < 0 || end_bit < 1 || end_bit > 32) return MISPLAT_EINVAL;
-    if (n == 0) return MISPLAT_OK;
-    size_t need = 0;
-    if (rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                  (unsigned)end_bit, (hipStream_t)stream) != hipSuccess)
-        return MISPLAT_ELAUNCH;
-    if (need > workspace_bytes) return MISPLAT_EWORKSPACE;
-    hipError_t e = rocprim::radix_sort_pairs(workspace, workspace_bytes, keys_in, keys_out, vals_in, vals_out,
-                                             (size_t)n, 0u, (unsigned)end_bit, (hipStream_t)stream);
-    return e == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
-}
-
-extern "C" int misplat_tile_offsets32(const uint32_t* tiles_sorted, int64_t n_isects, int32_t n_tiles_total,
-                                      int32_t* offsets, misplat_stream_t stream) {
-    if (n_isects < 0 || n_tiles_total < 1) return MISPLAT_EINVAL;
-    hipLaunchKernelGGL(tile_offsets32_kernel<uint32_t>, dim3(grid_for((n_isects + 4) / 4, 256)), dim3(256), 0,
-                       (hipStream_t)stream, tiles_sorted, n_isects, n_tiles_total, offsets);
-    return check_launch();
-}
-
-extern "C" int misplat_tile_offsets16(const uint16_t* tiles_sorted, int64_t n_isects, int32_t n_tiles_total,
-                                      int32_t* offsets, misplat_stream_t stream) {
-    if (n_isects < 0 || n_tiles_total < 1 || n_tiles_total > 65537) return MISPLAT_EINVAL;
-    hipLaunchKernelGGL(tile_offsets32_kernel<uint16_t>, dim3(grid_for((n_isects + 4) / 4, 256)), dim3(256), 0,
-                       (hipStream_t)stream, tiles_sorted, n_isects, n_tiles_total, offsets);
-    return check_launch();
-}
-
-// 16-bit tile keys (C * tiles <= 65536, i.e. everything up to 4K single views): 12 instead of 16 bytes
-// of traffic per pair and pass.
-extern "C" size_t misplat_sort16_workspace_bytes(int64_t n, int32_t end_bit) {
-    size_t bytes = 0;
-    if (n <= 0) return 16;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, (const uint16_t*)nullptr, (uint16_t*)nullptr,
-                                             (const int32_t*)nullptr, (int32_t*)nullptr, (size_t)n, 0u,
-                                             (unsigned)end_bit, (hipStream_t) nullptr);
-    if (e != hipSuccess) return 0;
-    return bytes < 16 ? 16 : bytes;
-}
-
-extern "C" int misplat_sort16_pairs(void* workspace, size_t workspace_bytes, const uint16_t* keys_in,
-                                    uint16_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
-                                    int32_t end_bit, misplat_stream_t stream) {
-    if (n < 0 || end_bit < 1 || end_bit > 16) return MISPLAT_EINVAL;
-    if (n == 0) return MISPLAT_OK;
-    size_t need = 0;
-    if (rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u,
-                                  (unsigned)end_bit, (hipStream_t)stream) != hipSuccess)
-        return MISPLAT_ELAUNCH;
-    if (need > workspace_bytes) return MISPLAT_EWORKSPACE;
-    hipError_t e = rocprim::radix_sort_pairs(workspace, workspace_bytes, keys_in, keys_out, vals_in, vals_out,
-                                             (size_t)n, 0u, (unsigned)end_bit, (hipStream_t)stream);
-    return e == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
-}
-
 extern "C" int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, const float* depths,
                                  int64_t n_isects, uint64_t* isect_ids, misplat_stream_t stream) {
     if (n_isects < 0) return MISPLAT_EINVAL;
@@ -936,13 +710,97 @@ extern "C" int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* fl
 }
 
 
-// Sort every tile's bucket (ascending row order on entry) by the depth bits, stably.  payload: in/out
+// ---- front-only ordering (dense scenes) --------------------------------------------------------------------------------
+// A dense scene is mostly a hidden scene: at 5 M Gaussians / 1080p the compositing traverses 9 % of the 32 M bucket
+// entries the per-tile sort orders (the rest lies behind the depth at which every pixel of the tile has saturated).  A
+// training loop revisits its cameras, so the view-keyed record that holds a view's launch order (misplat_params.unit_sel)
+// also holds, per tile, the DEPTH its last visit reached (the deepest list entry a band looked at; +inf when a band ran
+// through its whole list).  This kernel reads a tile's bucket once, keeps the entries at or in front of that pivot (x a
+// margin) -- ONE compare per entry: no histogram, no LDS atomic, no barrier for the nine entries in ten behind it --,
+// sorts the survivors (bin + rank: exactly the (depth, row) order, they are the first nf entries of the fully sorted list)
+// and writes them to the head of the tile's range of flatten_ids; front_n[tile] = nf.  payload is NOT touched: it stays a
+// permutation of the bucket, from which a later launch can sort the whole tile -- the compositing forward flags a tile
+// whose pixels are still alive at the end of a truncated list (tile_flag), the flagged tiles are sorted in full and
+// composited again, and meta["flatten_ids"] is completed the same way when someone asks for it.  Exact results always;
+// the pivot only decides how much is sorted.
+// A tile the kernel does not take (no record for these cameras yet, a short bucket, an infinite pivot, more survivors
+// than the 2 048 it holds, depths too clustered for bin + rank) gets front_n = -1: the regular size-class kernels, which
+// skip the tiles that are done, sort it in full.
+constexpr int kFrontWaves = 4, kFrontR = 8, kFrontCap = 64 * kFrontWaves * kFrontR;
+__global__ __launch_bounds__(64 * kFrontWaves) void tile_sort_front_kernel(
+    const int32_t* __restrict__ offsets, int n_tiles, int64_t n_isects, const float* __restrict__ depths,
+    const int32_t* __restrict__ payload, int32_t* __restrict__ flatten_ids, misplat_internal::FrontSort F) {
+    __shared__ tile_sort_lds<kFrontWaves, kFrontR> L;
+    __shared__ int s_nf;
+    constexpr int T = 64 * kFrontWaves;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int32_t* rec = nullptr;
+    if (F.order_sel[1] != 0 && (unsigned)F.order_sel[0] < (unsigned)F.order_slots) {
+        rec = F.order_table + (size_t)F.order_sel[0] * F.order_stride;
+        if (rec[3] != 1) rec = nullptr;                          // (a record written without pivots)
+    }
+    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const int end = min(offsets[t + 1], (int)n_isects);
+        const int beg = min(offsets[t], end);
+        const int n = end - beg;
+        float pivot = 0.f;
+        bool take = rec != nullptr && n >= F.min_bucket;
+        if (take) {
+            pivot = __int_as_float(rec[F.pivot_off + t]) * F.margin;
+            take = pivot < __builtin_inff() && pivot == pivot;   // (+inf: the last visit needed the whole list)
+        }
+        if (!take) {                                             // (uniform over the block)
+            if (threadIdx.x == 0) { F.front_n[t] = -1; F.tile_flag[t] = 0; }
+            continue;
+        }
+        if (threadIdx.x == 0) s_nf = 0;
+        __syncthreads();
+        for (int base = 0; base < n; base += 4 * T) {
+            int32_t v[4];
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = base + u * T + (int)threadIdx.x; v[u] = payload[beg + (i < n ? i : 0)]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) d[u] = depths[v[u]];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = base + u * T + (int)threadIdx.x;
+                const bool keep = i < n && d[u] <= pivot;
+                const unsigned long long m = __ballot(keep);
+                if (m == 0ull) continue;                         // (uniform over the wave)
+                int pos0 = 0;
+                if (lane == 0) pos0 = atomicAdd(&s_nf, __popcll(m));
+                pos0 = __shfl(pos0, 0);
+                const int pos = pos0 + __popcll(m & ((1ull << lane) - 1ull));
+                if (keep && pos < kFrontCap) { L.xk[pos] = __float_as_uint(d[u]); L.xv[pos] = (uint32_t)v[u]; }
+            }
+        }
+        __syncthreads();
+        const int nf = s_nf;
+        bool done = nf <= kFrontCap;
+        if (done && nf > 0) {
+            uint32_t key[kFrontR], val[kFrontR];
+#pragma unroll
+            for (int r = 0; r < kFrontR; r++) {
+                const int i = wave * 64 * kFrontR + r * 64 + lane;
+                key[r] = i < nf ? L.xk[i] : 0u; val[r] = i < nf ? L.xv[i] : 0u;
+            }
+            __syncthreads();                                     // (bin + rank reuses xk / xv)
+            done = tile_bin_rank<kFrontWaves, kFrontR, false>(key, val, nf, L, beg, nullptr, nullptr, flatten_ids);
+        }
+        __syncthreads();                                         // (the LDS image is reused by the next tile)
+        if (threadIdx.x == 0) { F.front_n[t] = done ? nf : -1; F.tile_flag[t] = 0; }
+    }
+}
+
+// Sort every tile's bucket (arbitrary order on entry) into (depth, row) order.  payload: in/out
 // (rows, or emission slots when isect_gid != NULL); flatten_ids: out (rows in final order);
 // scratch: 2 * n_isects uint32, only touched by tiles longer than the largest LDS class (8192 entries).
+// sel: which tiles (TileSel); rest_only: everything through the one launch of tile_sort_rest_kernel (few tiles expected).
 template <bool HAS_VALS, bool UNORDERED>
 static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
                             const int32_t* isect_gid, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,
-                            int has_longest, hipStream_t s) {
+                            int has_longest, hipStream_t s, TileSel sel = TileSel{nullptr, 0}, bool rest_only = false) {
     // size classes (entries per bucket): <=1024 | <=4096 | <=8192 | longer (global scratch).  Every class walks
     // all tiles and skips buckets of the other classes.  A class that the typical bucket (n_isects / n_tiles)
     // can reach gets one workgroup per tile; the others get a small grid whose workgroups test their chunk of
@@ -957,28 +815,53 @@ static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_i
     // <= 1024 entries.  Sparse scenes (typical bucket under 256 entries: 100 k Gaussians at 1080p): ONE wavefront per
     // bucket, 16 entries per lane, no barrier ever waits for another wave (0.496 -> 0.471 ms per step there); dense ones:
     // two waves, 8 entries per lane (measured at 1 M, typical bucket 800: one wave x 16 +12 us, four waves x 4 +5 us).
-    if (avg < 2048) {
+    if (avg < 2048 && !rest_only) {
         covered |= 1;
         if (avg < 256)
             hipLaunchKernelGGL((tile_sort_reg_kernel<1, 16, HAS_VALS, UNORDERED>), dim3(full), dim3(64), 0, s, offsets, n_tiles,
-                               n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
+                               n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest, sel);
         else
             hipLaunchKernelGGL((tile_sort_reg_kernel<2, 8, HAS_VALS, UNORDERED>), dim3(full), dim3(128), 0, s, offsets, n_tiles,
-                               n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest);
+                               n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest, sel);
     }
-    if (avg >= 1024) {
+    if (avg >= 1024 && !rest_only) {
         covered |= 2;
         hipLaunchKernelGGL((tile_sort_reg_kernel<8, 8, HAS_VALS, UNORDERED>), dim3(full), dim3(512), 0, s, offsets, n_tiles,
-                           n_isects, 1024, 4096, depths, isect_gid, payload, flatten_ids, has_longest);
+                           n_isects, 1024, 4096, depths, isect_gid, payload, flatten_ids, has_longest, sel);
     }
-    if (avg >= 2048) {
+    if (avg >= 2048 && !rest_only) {
         covered |= 4;
         hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS, UNORDERED>), dim3(full), dim3(1024), 0, s, offsets, n_tiles,
-                           n_isects, 4096, 8192, depths, isect_gid, payload, flatten_ids, has_longest);
+                           n_isects, 4096, 8192, depths, isect_gid, payload, flatten_ids, has_longest, sel);
     }
     hipLaunchKernelGGL((tile_sort_rest_kernel<HAS_VALS, UNORDERED>), dim3(few), dim3(1024), 0, s, offsets, n_tiles, n_isects,
-                       covered, depths, isect_gid, payload, flatten_ids, scratch);
+                       covered, depths, isect_gid, payload, flatten_ids, scratch, sel);
     return check_launch();
+}
+
+// Front-only ordering, first part: the front kernel, then the regular size classes for the tiles it left undone.
+int misplat_internal::tile_sort_front(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
+                                      int32_t* payload, int32_t* flatten_ids, uint32_t* scratch, const FrontSort& F,
+                                      hipStream_t s) {
+    if (n_isects < 0 || n_tiles < 1 || n_isects > 0x7fffffffLL || !scratch || !F.order_table || !F.order_sel || !F.front_n ||
+        !F.tile_flag || F.order_slots < 1 || F.pivot_off < MISPLAT_ORDER_HEADER || F.order_stride < F.pivot_off + n_tiles)
+        return MISPLAT_EINVAL;
+    const int grid = n_tiles < 65536 ? n_tiles : 65536;
+    hipLaunchKernelGGL(tile_sort_front_kernel, dim3(grid), dim3(64 * kFrontWaves), 0, s, offsets, n_tiles, n_isects, depths,
+                       (const int32_t*)payload, flatten_ids, F);
+    if (n_isects == 0) return check_launch();
+    return launch_tile_sort<false, true>(offsets, n_tiles, n_isects, depths, nullptr, payload, flatten_ids, scratch, 1, s,
+                                         TileSel{F.front_n, 1});
+}
+
+// Second part: the tiles whose flag the compositing forward set, in full (one launch; few tiles are expected).
+int misplat_internal::tile_sort_flagged(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
+                                        int32_t* payload, int32_t* flatten_ids, uint32_t* scratch, const int32_t* tile_flag,
+                                        hipStream_t s) {
+    if (n_isects < 0 || n_tiles < 1 || n_isects > 0x7fffffffLL || !scratch || !tile_flag) return MISPLAT_EINVAL;
+    if (n_isects == 0) return MISPLAT_OK;
+    return launch_tile_sort<false, true>(offsets, n_tiles, n_isects, depths, nullptr, payload, flatten_ids, scratch, 1, s,
+                                         TileSel{tile_flag, 2}, true);
 }
 
 extern "C" int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
@@ -988,50 +871,10 @@ extern "C" int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, 
     if (n_isects < 0 || n_tiles_total < 1 || n_isects > 0x7fffffffLL || !scratch || (flags & ~3)) return MISPLAT_EINVAL;
     if (n_isects == 0) return MISPLAT_OK;
     hipStream_t s = (hipStream_t)stream;
-    const int unordered = flags & 1, has_longest = (flags >> 1) & 1;
+    const int has_longest = (flags >> 1) & 1;      // (bit 0, "unordered", is what every bucket is now: accepted, ignored)
     if (isect_gid)
-        return unordered ? launch_tile_sort<true, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
-                                                        flatten_ids, scratch, has_longest, s)
-                         : launch_tile_sort<true, false>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
-                                                         flatten_ids, scratch, has_longest, s);
-    return unordered ? launch_tile_sort<false, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
-                                                     flatten_ids, scratch, has_longest, s)
-                     : launch_tile_sort<false, false>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload,
-                                                      flatten_ids, scratch, has_longest, s);
-}
-
-extern "C" int misplat_tile_count_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
-                                         int32_t* tiles_per_gauss, int32_t* block_sums, int64_t* block_offs,
-                                         int64_t* n_isects, misplat_stream_t stream) {
-    if (!p || p->tile_size != MISPLAT_TILE || !block_sums || !block_offs || !n_isects) return MISPLAT_EINVAL;
-    const int64_t total = (int64_t)p->n_gauss * p->n_cams;
-    const int64_t n_blocks = (total + MISPLAT_COUNT_BLOCK - 1) / MISPLAT_COUNT_BLOCK;
-    if (n_blocks > 0x7fffffffLL) return MISPLAT_EINVAL;
-    hipStream_t s = (hipStream_t)stream;
-    if (total > 0)
-        hipLaunchKernelGGL(tile_count_blocks_kernel, dim3((unsigned)n_blocks), dim3(MISPLAT_COUNT_BLOCK), 0, s, total,
-                           p->tile_w, p->tile_h, means2d, radii, tiles_per_gauss, block_sums);
-    hipLaunchKernelGGL(tile_block_scan_kernel, dim3(1), dim3(1024), 0, s, (int)n_blocks, block_sums, block_offs,
-                       n_isects);
-    return check_launch();
-}
-
-extern "C" int misplat_tile_emit_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
-                                        const int32_t* tiles_per_gauss, const int64_t* block_offs, void* tile_ids,
-                                        int32_t key_bytes, int32_t* slot_ids, int32_t* isect_gid,
-                                        misplat_stream_t stream) {
-    if (!p || p->tile_size != MISPLAT_TILE || (key_bytes != 2 && key_bytes != 4)) return MISPLAT_EINVAL;
-    if (key_bytes == 2 && (int64_t)p->tile_w * p->tile_h * p->n_cams > 65536) return MISPLAT_EINVAL;
-    const int64_t total = (int64_t)p->n_gauss * p->n_cams;
-    if (total == 0) return MISPLAT_OK;
-    const int64_t n_blocks = (total + MISPLAT_COUNT_BLOCK - 1) / MISPLAT_COUNT_BLOCK;
-    if (key_bytes == 2)
-        hipLaunchKernelGGL(tile_emit_blocks_kernel<uint16_t>, dim3((unsigned)n_blocks), dim3(MISPLAT_COUNT_BLOCK), 0,
-                           (hipStream_t)stream, total, p->n_gauss, p->tile_w, p->tile_h, means2d, radii,
-                           tiles_per_gauss, block_offs, (uint16_t*)tile_ids, slot_ids, isect_gid);
-    else
-        hipLaunchKernelGGL(tile_emit_blocks_kernel<uint32_t>, dim3((unsigned)n_blocks), dim3(MISPLAT_COUNT_BLOCK), 0,
-                           (hipStream_t)stream, total, p->n_gauss, p->tile_w, p->tile_h, means2d, radii,
-                           tiles_per_gauss, block_offs, (uint32_t*)tile_ids, slot_ids, isect_gid);
-    return check_launch();
+        return launch_tile_sort<true, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
+                                            has_longest, s);
+    return launch_tile_sort<false, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
+                                         has_longest, s);
 }

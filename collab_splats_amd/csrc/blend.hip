@@ -39,6 +39,7 @@ constexpr float kLn2 = 0.6931471805599453f;
 struct BandCtx {
     int tile, cam, band, tx, ty, y0, beg, end, unit;
     float fx, fy, cx, cy;
+    bool trunc;                  // front-only ordering: the list ends at its sorted head, more entries follow unsorted
 };
 
 // XCD-aware block -> work map: blocks are dealt round-robin over the 8 XCDs, so every XCD gets a
@@ -73,12 +74,24 @@ __device__ __forceinline__ bool band_ctx(const misplat_params& P, const float* _
     c.y0 = c.ty * MISPLAT_TILE + c.band * 4 * PPL;
     if (c.y0 >= P.height) {                      // band below the image: nothing to do (and it costs nothing)
         if (P.unit_work && threadIdx.x == 0) P.unit_work[unit] = 0;
+        if (P.unit_reach && threadIdx.x == 0) P.unit_reach[unit] = 0.f;
         return false;
     }
     // offsets has C*tiles + 1 entries (the last one = number of intersections); n_isects is the capacity of
     // flatten_ids: a speculative launch whose capacity turned out too small must stay inside its buffers
     c.end = min(offsets[c.tile + 1], (int)n_isects);
     c.beg = min(offsets[c.tile], c.end);
+    // Front-only ordering (the forward of misplat_raster_fwd; csrc/binning.hip): front_n[tile] >= 0 -- only that many
+    // entries at the head of the tile's list are there (sorted); the second pass composites the flagged tiles again, in full.
+    c.trunc = false;
+    if (P.front_n) {
+        if (P.front_pass) {
+            if (P.tile_flag[c.tile] == 0) return false;
+        } else {
+            const int fn = P.front_n[c.tile];
+            if (fn >= 0 && fn < c.end - c.beg) { c.end = c.beg + fn; c.trunc = true; }
+        }
+    }
     c.fx = Ks[9 * c.cam]; c.fy = Ks[9 * c.cam + 4]; c.cx = Ks[9 * c.cam + 2]; c.cy = Ks[9 * c.cam + 5];
     return true;
 }
@@ -201,6 +214,7 @@ __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; 
 // "skip" is a = 0.  The next record is prefetched from LDS while the current one is consumed.
 // NXQ > 0: N-D colours (rade_features_model.py:441-476, D = 16 / 17): channels 0..3 ride in the record,
 // channels 4.. in featx[row][NXQ] (float4s, zero padded); n_channels = D' is the render width.
+constexpr int kBandsPerTile = MISPLAT_BANDS;
 constexpr int kFillBlocks = 512;
 constexpr int64_t kFillHeadRows = 2500000;
 // The background role of a compositing launch (F.blocks > 0): its last workgroups -- dispatched when the machine starts
@@ -281,10 +295,11 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
     const float ylo = (float)c.y0 + 0.5f, yhi = ylo + (float)(4 * PPL - 1);
 
     // pixel pairs (k = 2 kp, 2 kp + 1) as 2-vectors for the packed-math loop (even PPL)
-    constexpr int NP = PPL >= 2 ? PPL / 2 : 1;
+    static_assert(PPL % 2 == 0, "the compositing loops work on pixel pairs");
+    constexpr int NP = PPL / 2;
     constexpr int NXF = NXQ > 0 ? 4 * NXQ : 1;
     v2f py2[NP], il2[NP], T2[NP], dep2[NP], med2[NP], col2[NP][CD], nrm2[NP][3], colx2[NP][NXF];
-    if constexpr (PPL % 2 == 0) {
+    {
 #pragma unroll
         for (int kp = 0; kp < NP; kp++) {
             const int k0 = 2 * kp, k1 = 2 * kp + 1;
@@ -317,22 +332,19 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
 #define MISPLAT_LANE(m) __builtin_amdgcn_inverse_ballot_w64(m)
 
     int work = 0;                               // staged Gaussians composited by this unit (its measured cost)
+    int reach_end = c.beg;                      // end of the last batch of list entries the band looked at
     for (int bs = c.beg; bs < c.end; bs += 64) {
-        if constexpr (PPL % 2 == 0) {
+        {
             lmask any = alive[0];
 #pragma unroll
             for (int k = 1; k < PPL; k++) any |= alive[k];
             if (any == 0ull) break;
-        } else {
-            float tmax = T[0];
-#pragma unroll
-            for (int k = 1; k < PPL; k++) tmax = fmaxf(tmax, T[k]);
-            if (__ballot(tmax > 0.f) == 0ull) break;
         }
         __syncthreads();
         const int n = stage_records<NXQ, LAZY>(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
                                                nullptr, xlo, xhi, ylo, yhi, amin, smx, featx, &lz);
         __syncthreads();
+        reach_end = min(bs + 64, c.end);
         if (n == 0) continue;
         work += n;
         // LDS latency is hidden without a second register set: the half of the record consumed late (q2, q3 =
@@ -351,8 +363,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
             const float dx = q0.x - px;
             const float ea = q0.z * dx * dx, eb = q0.w * dx;
             const float tpx = q1.z - q1.w * dx;
-            float tm = 0.f;
-            if constexpr (PPL % 2 == 0) {
+            {
                 // two pixels of the lane per packed instruction (see blend_bwd_kernel)
                 v2f dy_[NP], a_[NP];
                 lmask ok_[PPL];
@@ -419,47 +430,27 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
                     med_live = any_above != 0ull;
                 }
                 if (any_alive == 0ull) break;
-                continue;
-            } else {
-#pragma unroll
-                for (int k = 0; k < PPL; k++) {
-                    const float dy = q0.y - py[k];
-                    const float e = ea + (q1.x * dy + eb) * dy;
-                    const float vis = __builtin_amdgcn_exp2f(e);
-                    float a = fminf(amax, q1.y * vis);
-                    a = (e <= 0.f && a >= amin) ? a : 0.f;
-                    float w = a * T[k];
-                    const float Tn = T[k] - w;
-                    const bool stop = (w > 0.f) && (Tn <= tstop);       // this Gaussian is excluded
-                    const bool use = (w > 0.f) && !stop;
-                    Tfin[k] = stop ? T[k] : Tfin[k];
-                    const bool is_med = use && (T[k] > tmed);
-                    T[k] = stop ? 0.f : Tn;
-                    w = stop ? 0.f : w;
-                    const float zp = (tpx - q2.x * dy) * inv_ell[k];
-                    col[k][0] += w * q3.x;
-                    if (CD > 1) col[k][CD > 1 ? 1 : 0] += w * q3.y;
-                    if (CD > 2) col[k][CD > 2 ? 2 : 0] += w * q3.z;
-                    if (CD > 3) col[k][CD > 3 ? 3 : 0] += w * q3.w;
-#pragma unroll
-                    for (int q = 0; q < NXQ; q++) {
-                        colx[k][4 * q + 0] += w * xq[q].x; colx[k][4 * q + 1] += w * xq[q].y;
-                        colx[k][4 * q + 2] += w * xq[q].z; colx[k][4 * q + 3] += w * xq[q].w;
-                    }
-                    dep[k] += w * zp;
-                    nrm[k][0] += w * q2.y; nrm[k][1] += w * q2.z; nrm[k][2] += w * q2.w;
-                    med[k] = is_med ? zp : med[k];
-                    medi[k] = is_med ? i : medi[k];
-                    last[k] = use ? i : last[k];
-                    tm = fmaxf(tm, T[k]);
-                }
-                q0 = sm[j + 1]; q1 = sm[64 + j + 1];                   // next Gaussian (array padded)
             }
-            if (__ballot(tm > 0.f) == 0ull) break;
         }
     }
     if (P.unit_work && lane == 0) P.unit_work[c.unit] = work;
-    if constexpr (PPL % 2 == 0) {
+    if (P.unit_reach) {
+        // How deep this visit went -- the pivot of the view's next visit (front-only ordering): the depth of the last list
+        // entry of the last batch the band staged; +inf when pixels are still alive at the end of the list (the whole list
+        // was needed) -- and if that list was only the sorted head of a longer one, the tile is flagged: it is sorted in
+        // full and composited again by the second pass.
+        lmask any = alive[0];
+#pragma unroll
+        for (int k = 1; k < PPL; k++) any |= alive[k];
+        float reach = 0.f;
+        if (any != 0ull) {
+            reach = __builtin_inff();
+            if (c.trunc && lane == 0) P.tile_flag[c.tile] = 1;
+        } else if (reach_end > c.beg)
+            reach = P.front_depths[flatten_ids[reach_end - 1]];
+        if (lane == 0) P.unit_reach[c.unit] = reach;
+    }
+    {
 #pragma unroll
         for (int kp = 0; kp < NP; kp++) {
 #pragma unroll
@@ -685,9 +676,10 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
     const int maxlast = wave_max(mymax);
     if (maxlast < c.beg) return;
     // pixel pairs (k = 2 kp, 2 kp + 1) as 2-vectors for the packed-math loop (even PPL)
-    constexpr int NP = PPL >= 2 ? PPL / 2 : 1;
+    static_assert(PPL % 2 == 0, "the compositing loops work on pixel pairs");
+    constexpr int NP = PPL / 2;
     v2f py2[NP], il2[NP], T2[NP], B2[NP], tf2[NP], vd2[NP], vm2[NP], vcol2[NP][CD], vn2[NP][3], vcolx2[NP][NX];
-    if constexpr (PPL % 2 == 0) {
+    {
 #pragma unroll
         for (int kp = 0; kp < NP; kp++) {
             const int k0 = 2 * kp, k1 = 2 * kp + 1;
@@ -748,9 +740,8 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
 #pragma unroll
             for (int r = 0; r < 16; r++) accx[r] = 0.f;
             float ab0 = 0.f, ab1 = 0.f;
-            float amx = 0.f;
-            unsigned long long any_ok = 0ull;      // (packed path) lanes with a contributing pixel
-            if constexpr (PPL % 2 == 0) {
+            unsigned long long any_ok = 0ull;      // lanes with a contributing pixel
+            {
                 // Two pixels of the lane at a time in 2-vectors (v_pk_{fma,mul,add}_f32) for the per-pixel chain.
                 // The per-pixel decisions are lane masks in scalar registers (one ballot per vector compare, combined
                 // with scalar ANDs, turned back into select conditions with inverse_ballot): see blend_fwd_kernel.
@@ -834,52 +825,6 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
 #undef MISPLAT_ADD1
                     if (ABS) { ab0 += fabsf(vmx.x) + fabsf(vmx.y); ab1 += fabsf(vmy.x) + fabsf(vmy.y); }
                 }
-            } else {
-#pragma unroll
-                for (int k = 0; k < PPL; k++) {
-                    const float dy = q0.y - py[k];
-                    const float e = ea + (q1.x * dy + eb) * dy;
-                    const float vis = __builtin_amdgcn_exp2f(e);
-                    const float ov = q1.y * vis;
-                    float a = fminf(amax, ov);
-                    const bool ok = (i <= last[k]) && (e <= 0.f) && (a >= amin);
-                    a = ok ? a : 0.f;
-                    amx = fmaxf(amx, a);
-                    const float ra = __builtin_amdgcn_rcpf(1.0f - a);
-                    T[k] *= ra;
-                    const float w = a * T[k];
-                    const float zp = (tpx - q2.x * dy) * inv_ell[k];
-                    float dot = q3.x * vcol[k][0];
-                    if (CD > 1) dot += q3.y * vcol[k][CD > 1 ? 1 : 0];
-                    if (CD > 2) dot += q3.z * vcol[k][CD > 2 ? 2 : 0];
-                    if (CD > 3) dot += q3.w * vcol[k][CD > 3 ? 3 : 0];
-#pragma unroll
-                    for (int q = 0; q < NXQ; q++)
-                        dot += xq[q].x * vcolx[k][4 * q] + xq[q].y * vcolx[k][4 * q + 1] + xq[q].z * vcolx[k][4 * q + 2] +
-                               xq[q].w * vcolx[k][4 * q + 3];
-                    dot += q2.y * vn[k][0] + q2.z * vn[k][1] + q2.w * vn[k][2] + zp * vd[k];
-                    float v_a = (tfva[k] - B[k]) * ra + T[k] * dot;
-                    v_a = ok ? v_a : 0.f;
-                    B[k] += w * dot;
-                    acc[12] += w * vcol[k][0];
-                    if (CD > 1) acc[13] += w * vcol[k][CD > 1 ? 1 : 0];
-                    if (CD > 2) acc[14] += w * vcol[k][CD > 2 ? 2 : 0];
-                    if (CD > 3) acc[15] += w * vcol[k][CD > 3 ? 3 : 0];
-#pragma unroll
-                    for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) accx[ch] += w * vcolx[k][ch];
-                    acc[9] += w * vn[k][0]; acc[10] += w * vn[k][1]; acc[11] += w * vn[k][2];
-                    float vz = w * vd[k];
-                    vz += (ok && i == medi[k]) ? vm[k] : 0.f;
-                    const float vzl = vz * inv_ell[k];
-                    acc[6] += vzl; acc[7] -= vzl * dx; acc[8] -= vzl * dy;
-                    const float v_e = (ov <= amax) ? kLn2 * ov * v_a : 0.f;
-                    acc[5] += vis * ((ov <= amax) ? v_a : 0.f);
-                    acc[2] += dx * dx * v_e; acc[3] += dx * dy * v_e; acc[4] += dy * dy * v_e;
-                    const float vmx = (2.0f * q0.z * dx + q0.w * dy) * v_e - vzl * q1.w;
-                    const float vmy = (2.0f * q1.x * dy + q0.w * dx) * v_e - vzl * q2.x;
-                    acc[0] += vmx; acc[1] += vmy;
-                    if (ABS) { ab0 += fabsf(vmx); ab1 += fabsf(vmy); }
-                }
             }
             const size_t slot = (size_t)islot;
             const uint32_t slot_off = (uint32_t)islot << 6;   // (atomic mode: rows * 64 B < 4 GiB, checked by the launcher)
@@ -888,7 +833,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                 q0 = sm[jn]; q1 = sm[64 + jn]; q2 = sm[128 + jn]; q3 = sm[192 + jn];
                 i = sm_idx[jn]; islot = sm_slot[jn];
             }
-            const bool contributes = (PPL % 2 == 0) ? (any_ok != 0ull) : (__ballot(amx > 0.f) != 0ull);
+            const bool contributes = any_ok != 0ull;
             if (contributes) {
                 const float r = wave_reduce16(acc, lane);
                 if (ATOMIC) {
@@ -914,314 +859,6 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
         // row flags for the per-Gaussian backward kernels: one store instruction per batch (lane p flags the row of staged
         // entry p) instead of a predicated store per trip
         if (ATOMIC && P.touched && ((touched_j >> lane) & 1ull)) P.touched[sm_slot[lane]] = 1;
-    }
-}
-
-// ---- backward, four sub-blocks per wave ("quad") --------------------------------------------------
-// The band kernel above walks ONE culled list per 16 x 8 band, and a Gaussian that survives the band's cull touches on
-// average under half of the band's pixels (scripts/work_stats.py: lane use 0.49).  Here the band is split into four
-// 8 x 4 SUB-BLOCKS, each owned by 16 lanes and each with its own culled list: in one loop trip the four lane groups
-// work on four DIFFERENT Gaussians of the staged batch (a group that has run out of entries idles on a null record).
-// 1 M / 1080p: 1.78 M band units -> 5.01 M sub-block units in 1.47 M trips (-17 %), exact counts from the CPU
-// restatement.  The per-Gaussian gradient rows of a batch are accumulated in LDS (ds_add_f32, one per lane and trip)
-// and leave as global atomics once per batch, so the number of global atomics does not grow with the finer split.
-//
-// MEASURED (1 M / 1080p, MI355X): 0.649 ms against 0.478 ms of the band kernel -- NOT the default (misplat_params.
-// sub_blocks = 4 selects it).  The loop executes the same 148 vector instructions per trip as the band kernel and
-// 17 % fewer trips, but ds_add_f32 is serialised in the LDS (SQ_LDS_IDX_ACTIVE 8.5x the band kernel's: the LDS is busy
-// 85 % of the kernel, 220 array cycles per trip against 22).  Bounds on any repair, measured with the same kernel: a
-// plain (racy, so wrong) read-add-write in place of the atomic: 0.448 ms, i.e. -7 % at best before the ~10 instructions
-// per trip that detecting two groups on the same slot would cost; one global atomic per sub-block unit instead of the
-// LDS rows (5.0 M x 64 B instead of 1.8 M): 1.43 ms, the memory-side atomic units saturate.  The per-batch overhead
-// (four box tests, list building, flush: ~600 instructions x 57 k batches) eats the rest of the 17 %.
-//
-// Lane map: the sub-block of lane l is s = (l & 3) ^ ((l & 4) ? 3 : 0), its pixel slot m = l >> 2: the four lanes of
-// a DPP quad belong to the four sub-blocks.  The reduction over a sub-block's 16 lanes is then a reduction over lane
-// bits 2..5 -- exactly the cheap stages of wave_reduce16 (bank-masked DPP for bits 2 and 3: row_half_mirror pairs l
-// with l ^ 7, which is why s is mirrored in the odd banks; v_permlane{16,32}_swap for bits 4 and 5) -- and the two
-// quad stages are simply left out: lane l ends with component (l >> 2) & 15 of ITS sub-block's Gaussian.
-__device__ __forceinline__ float sub_reduce16(float (&v)[16]) {
-#define MISPLAT_XU(k, n, ctrl, m_hi, m_lo)                                                            \
-    "v_add_f32_dpp %" #k ", %" #k ", %" #k " " ctrl " row_mask:0xf bank_mask:" m_hi "\n\t"            \
-    "v_add_f32_dpp %" #k ", %" #n ", %" #n " " ctrl " row_mask:0xf bank_mask:" m_lo "\n\t"
-    asm("s_nop 1\n\t"
-        MISPLAT_XU(0, 8, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(1, 9, "row_half_mirror", "0xa", "0x5")
-        MISPLAT_XU(2, 10, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(3, 11, "row_half_mirror", "0xa", "0x5")
-        MISPLAT_XU(4, 12, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(5, 13, "row_half_mirror", "0xa", "0x5")
-        MISPLAT_XU(6, 14, "row_half_mirror", "0xa", "0x5") MISPLAT_XU(7, 15, "row_half_mirror", "0xa", "0x5")
-        : "+v"(v[1]), "+v"(v[3]), "+v"(v[5]), "+v"(v[7]), "+v"(v[9]), "+v"(v[11]), "+v"(v[13]), "+v"(v[15])
-        : "v"(v[0]), "v"(v[2]), "v"(v[4]), "v"(v[6]), "v"(v[8]), "v"(v[10]), "v"(v[12]), "v"(v[14]));
-    asm("s_nop 1\n\t"
-        MISPLAT_XU(0, 4, "row_ror:8", "0xc", "0x3") MISPLAT_XU(1, 5, "row_ror:8", "0xc", "0x3")
-        MISPLAT_XU(2, 6, "row_ror:8", "0xc", "0x3") MISPLAT_XU(3, 7, "row_ror:8", "0xc", "0x3")
-        : "+v"(v[3]), "+v"(v[7]), "+v"(v[11]), "+v"(v[15])
-        : "v"(v[1]), "v"(v[5]), "v"(v[9]), "v"(v[13]));
-#undef MISPLAT_XU
-    asm("s_nop 1\n\t"
-        "v_permlane16_swap_b32 %0, %1\n\t"
-        "v_permlane16_swap_b32 %2, %3"
-        : "+v"(v[3]), "+v"(v[7]), "+v"(v[11]), "+v"(v[15]));
-    float lo = v[3] + v[7], hi = v[11] + v[15];
-    asm("s_nop 1\n\t"
-        "v_permlane32_swap_b32 %0, %1"
-        : "+v"(lo), "+v"(hi));
-    return lo + hi;
-}
-__device__ __forceinline__ float sub_sum(float v) {            // sum over the 16 lanes of the caller's sub-block
-    v += dpp_mov<kDppHalfMirror>(v);
-    v += dpp_mov<kDppRor8>(v);
-    return cross_row_sum(v);
-}
-
-constexpr int kQS = 65;                // slots per staged batch + the null slot (64)
-
-template <int CD, bool ABS>
-#ifndef MISPLAT_BWDQ_WAVES
-#define MISPLAT_BWDQ_WAVES 4
-#endif
-__global__ __launch_bounds__(64, MISPLAT_BWDQ_WAVES) void blend_bwd_quad_kernel(
-    misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
-    const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ offsets, int64_t n_isects,
-    const float* __restrict__ alpha, const int32_t* __restrict__ last_ids, const int32_t* __restrict__ median_ids,
-    const float* __restrict__ render, const float* __restrict__ v_render, const float* __restrict__ v_alpha,
-    const float* __restrict__ v_exp_depth, const float* __restrict__ v_med_depth,
-    const float* __restrict__ v_normal, float* __restrict__ v_grec, float* __restrict__ v_abs) {
-    __shared__ float4 sm[4 * kQS];                 // component c of slot p: sm[c * kQS + p]; slot 64 = null record
-    __shared__ int sm_idx[kQS];                    // list position of the slot's Gaussian ([64] = INT_MAX)
-    __shared__ int sm_row[64];                     // its row of v_grec
-    __shared__ float gacc[kQS * MISPLAT_REC];      // gradient rows of the batch (row 64 collects the idle groups' zeros)
-    __shared__ float gabs[ABS ? kQS * 2 : 2];
-    __shared__ uint8_t lst[4][64];                 // per sub-block: the slots it has to visit, ascending
-    BandCtx c;
-    if (!band_ctx<2>(P, Ks, offsets, n_isects, c)) return;
-    if (c.end <= c.beg) return;
-    const int lane = threadIdx.x;
-    const int sub = (lane & 3) ^ ((lane & 4) ? 3 : 0);
-    const int m = lane >> 2;
-    const int x = c.tx * MISPLAT_TILE + (sub & 1) * 8 + (m & 7);
-    const int ybase = c.y0 + (sub >> 1) * 4 + (m >> 3);
-    const float px = (float)x + 0.5f;
-    const float rxn = (px - c.cx) / c.fx;
-    float T[2], tfva[2], vd[2], vm[2], vcol[2][CD], vn[2][3], py[2], inv_ell[2];
-    int last[2], medi[2];
-    int mymax = -1;
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int y = ybase + 2 * k;
-        py[k] = (float)y + 0.5f;
-        const float ryn = (py[k] - c.cy) / c.fy;
-        inv_ell[k] = 1.0f / sqrtf(rxn * rxn + ryn * ryn + 1.0f);
-        last[k] = -1; medi[k] = -1; T[k] = 1.f; tfva[k] = 0.f; vd[k] = 0.f; vm[k] = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < CD; ch++) vcol[k][ch] = 0.f;
-        vn[k][0] = vn[k][1] = vn[k][2] = 0.f;
-        if (x < P.width && y < P.height) {
-            const size_t pid = ((size_t)c.cam * P.height + y) * P.width + x;
-            last[k] = last_ids[pid];
-            medi[k] = median_ids[pid];
-            const float al = alpha[pid];
-            const float Tf = 1.0f - al;
-            T[k] = Tf;
-            float va = v_alpha[pid];
-#pragma unroll
-            for (int ch = 0; ch < CD; ch++) {
-                float g = v_render[pid * CD + ch];
-                if (ch == P.ed_slot) {         // out = raw / max(alpha, 1e-10)
-                    const float inv_al = 1.0f / fmaxf(al, 1e-10f);
-                    g *= inv_al;
-                    if (al > 1e-10f) va -= g * render[pid * CD + ch];
-                }
-                vcol[k][ch] = g;
-            }
-            tfva[k] = Tf * va;
-            vn[k][0] = v_normal[pid * 3]; vn[k][1] = v_normal[pid * 3 + 1]; vn[k][2] = v_normal[pid * 3 + 2];
-            vd[k] = v_exp_depth[pid];
-            vm[k] = v_med_depth[pid];
-        }
-        mymax = max(mymax, last[k]);
-    }
-    const int maxlast = wave_max(mymax);
-    if (maxlast < c.beg) return;
-    // largest last_id of each sub-block: a sub-block skips the entries behind it
-    int sl = mymax;
-    sl = max(sl, __shfl_xor(sl, 7)); sl = max(sl, __shfl_xor(sl, 8));
-    sl = max(sl, __shfl_xor(sl, 16)); sl = max(sl, __shfl_xor(sl, 32));
-    const int sl0 = __builtin_amdgcn_readlane(sl, 0), sl1 = __builtin_amdgcn_readlane(sl, 1);
-    const int sl2 = __builtin_amdgcn_readlane(sl, 2), sl3 = __builtin_amdgcn_readlane(sl, 3);
-    const v2f py2 = mk2(py[0], py[1]), il2 = mk2(inv_ell[0], inv_ell[1]), tf2 = mk2(tfva[0], tfva[1]);
-    const v2f vd2 = mk2(vd[0], vd[1]), vm2 = mk2(vm[0], vm[1]);
-    v2f T2 = mk2(T[0], T[1]), B2 = mk2(0.f, 0.f), vcol2[CD], vn2[3];
-#pragma unroll
-    for (int ch = 0; ch < CD; ch++) vcol2[ch] = mk2(vcol[0][ch], vcol[1][ch]);
-#pragma unroll
-    for (int ch = 0; ch < 3; ch++) vn2[ch] = mk2(vn[0][ch], vn[1][ch]);
-    const int comp = (lane >> 2) & 15;
-    const float amax = P.alpha_max, amin = P.alpha_min;
-    const float bx0 = (float)(c.tx * MISPLAT_TILE) + 0.5f, by0 = (float)c.y0 + 0.5f;
-    // LDS: accumulators start (and are left by every flush) at zero; the null record has opacity 0
-    for (int k = lane; k < kQS * MISPLAT_REC; k += 64) gacc[k] = 0.f;
-    if (ABS) for (int k = lane; k < kQS * 2; k += 64) gabs[k] = 0.f;
-    if (lane < 4) sm[lane * kQS + 64] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane == 0) sm_idx[64] = 0x7fffffff;
-    const uint8_t* my_list = lst[sub];
-    const int fl_comp = lane & 15;                 // component this lane flushes
-    const float fl_scale = (fl_comp == 2 || fl_comp == 4) ? -0.5f * kLog2e : (fl_comp == 3 ? -kLog2e : 1.0f);
-
-    for (int b = (maxlast - c.beg) >> 6; b >= 0; b--) {
-        const int bs = c.beg + (b << 6);
-        __syncthreads();
-        // ---- stage: one list entry per lane, culled against each of the four sub-blocks
-        int n, n0, n1, n2, n3;
-        {
-            const int ii = bs + lane;
-            bool k0 = false, k1 = false, k2 = false, k3 = false;
-            float4 q0, q1, q2, q3;
-            int g = 0;
-            if (ii <= maxlast) {
-                g = flatten_ids[ii];
-                q0 = grec[4 * (size_t)g + 0]; q1 = grec[4 * (size_t)g + 1];
-                q2 = grec[4 * (size_t)g + 2]; q3 = grec[4 * (size_t)g + 3];
-                const float dxa = q0.x - bx0, dya = q0.y - by0;         // mean - centre of the band's first pixel
-                const float thr = amin / (q1.y * 1.002f);
-                const float s0 = sigma_min_box(q0.z, q0.w, q1.x, dxa - 7.f, dxa, dya - 3.f, dya);
-                const float s1 = sigma_min_box(q0.z, q0.w, q1.x, dxa - 15.f, dxa - 8.f, dya - 3.f, dya);
-                const float s2 = sigma_min_box(q0.z, q0.w, q1.x, dxa - 7.f, dxa, dya - 7.f, dya - 4.f);
-                const float s3 = sigma_min_box(q0.z, q0.w, q1.x, dxa - 15.f, dxa - 8.f, dya - 7.f, dya - 4.f);
-                k0 = ii <= sl0 && __builtin_amdgcn_exp2f(-s0 * kLog2e) >= thr;
-                k1 = ii <= sl1 && __builtin_amdgcn_exp2f(-s1 * kLog2e) >= thr;
-                k2 = ii <= sl2 && __builtin_amdgcn_exp2f(-s2 * kLog2e) >= thr;
-                k3 = ii <= sl3 && __builtin_amdgcn_exp2f(-s3 * kLog2e) >= thr;
-            }
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const unsigned long long mk = __ballot(k0 || k1 || k2 || k3);
-            const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1), m2 = __ballot(k2), m3 = __ballot(k3);
-            n = __popcll(mk); n0 = __popcll(m0); n1 = __popcll(m1); n2 = __popcll(m2); n3 = __popcll(m3);
-            if (k0 || k1 || k2 || k3) {
-                const int pos = __popcll(mk & lt);
-                q0.z *= -0.5f * kLog2e; q0.w *= -kLog2e; q1.x *= -0.5f * kLog2e;
-                sm[pos] = q0; sm[kQS + pos] = q1; sm[2 * kQS + pos] = q2; sm[3 * kQS + pos] = q3;
-                sm_idx[pos] = ii;
-                sm_row[pos] = g;
-                if (k0) lst[0][__popcll(m0 & lt)] = (uint8_t)pos;
-                if (k1) lst[1][__popcll(m1 & lt)] = (uint8_t)pos;
-                if (k2) lst[2][__popcll(m2 & lt)] = (uint8_t)pos;
-                if (k3) lst[3][__popcll(m3 & lt)] = (uint8_t)pos;
-            }
-        }
-        __syncthreads();
-        if (n == 0) continue;
-        const int trips = max(max(n0, n1), max(n2, n3));
-        bool mine_med = (unsigned)(medi[0] - bs) < 64u || (unsigned)(medi[1] - bs) < 64u;
-        const bool batch_has_median = __ballot(mine_med) != 0ull;
-        const int my_n = sub == 0 ? n0 : (sub == 1 ? n1 : (sub == 2 ? n2 : n3));
-        // walk the sub-block's list back to front; the slot of the trip after next and the record of the next trip are
-        // fetched ahead
-        int t = my_n - 1;
-        int pos = t >= 0 ? (int)my_list[t] : 64;
-        int pos_nx = t >= 1 ? (int)my_list[t - 1] : 64;
-        float4 q0 = sm[pos], q1 = sm[kQS + pos], q2 = sm[2 * kQS + pos], q3 = sm[3 * kQS + pos];
-        int i = sm_idx[pos];
-        // LDS returns in order: the accumulate of trip k is issued at the top of trip k + 1, ahead of that trip's
-        // record reads, so that no wait in the loop ever sits right behind it
-        float r_pend = 0.f, a0_pend = 0.f;
-        int addr_pend = 64 * MISPLAT_REC + comp, aaddr_pend = 64 * 2;
-        for (int step = 0; step < trips; step++) {
-            atomicAdd(&gacc[addr_pend], r_pend);                          // ds_add_f32, every lane its own address
-            if (ABS) { if (m < 2) atomicAdd(&gabs[aaddr_pend], a0_pend); }
-            const float dx = q0.x - px;
-            const float ea = q0.z * dx * dx, eb = q0.w * dx;
-            const float tpx = q1.z - q1.w * dx;
-            float acc[16];
-            float ab0 = 0.f, ab1 = 0.f;
-            const float dxx = dx * dx, ndx = -dx;
-            const float c1x = 2.0f * q0.z * dx, c1y = q0.w * dx;
-            const v2f dy = q0.y - py2;
-            const v2f e = ea + (q1.x * dy + eb) * dy;
-            v2f vis;
-            vis.x = __builtin_amdgcn_exp2f(e.x); vis.y = __builtin_amdgcn_exp2f(e.y);
-            const v2f ov = q1.y * vis;
-            const bool ok0 = (i <= last[0]) && (e.x <= 0.f) && (fminf(amax, ov.x) >= amin);
-            const bool ok1 = (i <= last[1]) && (e.y <= 0.f) && (fminf(amax, ov.y) >= amin);
-            v2f a;
-            a.x = ok0 ? fminf(amax, ov.x) : 0.f; a.y = ok1 ? fminf(amax, ov.y) : 0.f;
-            const float amx = fmaxf(a.x, a.y);
-            const v2f om = 1.0f - a;
-            v2f ra;
-            ra.x = __builtin_amdgcn_rcpf(om.x); ra.y = __builtin_amdgcn_rcpf(om.y);
-            T2 *= ra;
-            const v2f Tk = T2;
-            const v2f w = a * Tk;
-            const v2f zp = (tpx - q2.x * dy) * il2;
-            v2f dot = q3.x * vcol2[0];
-            if (CD > 1) dot += q3.y * vcol2[CD > 1 ? 1 : 0];
-            if (CD > 2) dot += q3.z * vcol2[CD > 2 ? 2 : 0];
-            if (CD > 3) dot += q3.w * vcol2[CD > 3 ? 3 : 0];
-            dot += q2.y * vn2[0] + q2.z * vn2[1] + q2.w * vn2[2] + zp * vd2;
-            v2f v_a = (tf2 - B2) * ra + Tk * dot;
-            v_a.x = ok0 ? v_a.x : 0.f; v_a.y = ok1 ? v_a.y : 0.f;
-            B2 += w * dot;
-            v2f vz = w * vd2;
-            if (batch_has_median) {
-                v2f vmed;
-                vmed.x = (ok0 && i == medi[0]) ? vm2.x : 0.f; vmed.y = (ok1 && i == medi[1]) ? vm2.y : 0.f;
-                vz += vmed;
-            }
-            const v2f vzl = vz * il2;
-            v2f vam;
-            vam.x = (ov.x <= amax) ? v_a.x : 0.f; vam.y = (ov.y <= amax) ? v_a.y : 0.f;
-            const v2f v_e = (kLn2 * ov) * vam;
-            const v2f dyve = dy * v_e;
-            const v2f vmx = (c1x + q0.w * dy) * v_e - vzl * q1.w;
-            const v2f vmy = (2.0f * q1.x * dy + c1y) * v_e - vzl * q2.x;
-            const float s_ve = v_e.x + v_e.y, s_dyve = dyve.x + dyve.y, s_vzl = vzl.x + vzl.y;
-            acc[0] = vmx.x + vmx.y; acc[1] = vmy.x + vmy.y;
-            acc[2] = dxx * s_ve; acc[3] = dx * s_dyve; acc[4] = fmaf(dy.y, dyve.y, dy.x * dyve.x);
-            acc[5] = fmaf(vis.y, vam.y, vis.x * vam.x);
-            acc[6] = s_vzl; acc[7] = ndx * s_vzl; acc[8] = -fmaf(vzl.y, dy.y, vzl.x * dy.x);
-            acc[9] = fmaf(w.y, vn2[0].y, w.x * vn2[0].x); acc[10] = fmaf(w.y, vn2[1].y, w.x * vn2[1].x);
-            acc[11] = fmaf(w.y, vn2[2].y, w.x * vn2[2].x);
-            acc[12] = fmaf(w.y, vcol2[0].y, w.x * vcol2[0].x);
-            acc[13] = CD > 1 ? fmaf(w.y, vcol2[CD > 1 ? 1 : 0].y, w.x * vcol2[CD > 1 ? 1 : 0].x) : 0.f;
-            acc[14] = CD > 2 ? fmaf(w.y, vcol2[CD > 2 ? 2 : 0].y, w.x * vcol2[CD > 2 ? 2 : 0].x) : 0.f;
-            acc[15] = CD > 3 ? fmaf(w.y, vcol2[CD > 3 ? 3 : 0].y, w.x * vcol2[CD > 3 ? 3 : 0].x) : 0.f;
-            if (ABS) { ab0 = fabsf(vmx.x) + fabsf(vmx.y); ab1 = fabsf(vmy.x) + fabsf(vmy.y); }
-            const int pos_cur = pos;
-            {   // next trip's record, the slot of the one after
-                pos = pos_nx;
-                q0 = sm[pos]; q1 = sm[kQS + pos]; q2 = sm[2 * kQS + pos]; q3 = sm[3 * kQS + pos];
-                i = sm_idx[pos];
-                t--;
-                pos_nx = t >= 1 ? (int)my_list[t - 1] : 64;
-            }
-            r_pend = 0.f;
-            if (__ballot(amx > 0.f) != 0ull) {
-                r_pend = sub_reduce16(acc);
-                addr_pend = pos_cur * MISPLAT_REC + comp;
-                if (ABS) {
-                    ab0 = sub_sum(ab0); ab1 = sub_sum(ab1);
-                    a0_pend = m == 0 ? ab0 : ab1;
-                    aaddr_pend = pos_cur * 2 + (m & 1);
-                }
-            } else if (ABS) a0_pend = 0.f;
-        }
-        atomicAdd(&gacc[addr_pend], r_pend);
-        if (ABS) { if (m < 2) atomicAdd(&gabs[aaddr_pend], a0_pend); }
-        __syncthreads();
-        // ---- flush the batch: one no-return global atomic per (slot, component), accumulators back to zero
-        for (int k = lane; k < n * MISPLAT_REC; k += 64) {
-            const float val = gacc[k];
-            gacc[k] = 0.f;
-            const size_t row = (size_t)sm_row[k >> 4];
-            if (val != 0.f) atomicAdd(&v_grec[row * MISPLAT_REC + fl_comp], val * fl_scale);
-            if (P.touched && val != 0.f) P.touched[row] = 1;
-        }
-        if (ABS) {
-            for (int k = lane; k < n * 2; k += 64) {
-                const float val = gabs[k];
-                gabs[k] = 0.f;
-                if (val != 0.f) atomicAdd(&v_abs[(size_t)sm_row[k >> 1] * 2 + (k & 1)], val);
-            }
-        }
     }
 }
 
@@ -1457,7 +1094,8 @@ __global__ __launch_bounds__(kDnTX * kDnTY) void depth_normal_bwd_tiled_kernel(
 // call with the same cameras.
 __global__ __launch_bounds__(1024) void unit_order_kernel(int units, int per, const int32_t* __restrict__ work,
                                                           int32_t* __restrict__ perm, int32_t* __restrict__ sel, int stride,
-                                                          int slots) {
+                                                          int slots, const float* __restrict__ reach = nullptr,
+                                                          int n_tiles = 0, int pivot_off = 0) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t wmax[16];
     const int x = blockIdx.x;
@@ -1465,7 +1103,16 @@ __global__ __launch_bounds__(1024) void unit_order_kernel(int units, int per, co
         if ((unsigned)sel[0] >= (unsigned)slots) return;       // (a selector nobody wrote: leave the table alone)
         int32_t* rec = perm + (size_t)sel[0] * stride;
         perm = rec + MISPLAT_ORDER_HEADER;
-        if (x == 0 && threadIdx.x == 0) { rec[0] = sel[2]; rec[1] = sel[3]; rec[2] = 1; }
+        if (x == 0 && threadIdx.x == 0) { rec[0] = sel[2]; rec[1] = sel[3]; rec[2] = 1; rec[3] = reach ? 1 : 0; }
+        // per-tile depth pivots for the view's next visit (front-only ordering, csrc/binning.hip): the deeper of the two
+        // bands' reach
+        if (reach)
+            for (int t = x * 1024 + (int)threadIdx.x; t < n_tiles; t += 8 * 1024) {
+                float pv = 0.f;
+#pragma unroll
+                for (int b = 0; b < kBandsPerTile; b++) pv = fmaxf(pv, reach[t * kBandsPerTile + b]);
+                rec[pivot_off + t] = __float_as_int(pv);
+            }
     }
     const int lo = x * per, hi = min(lo + per, units);
     // (the work counts are a hint from another launch: whatever they hold -- negative, huge, changing while this kernel
@@ -1530,31 +1177,32 @@ inline bool params_ok(const misplat_params* p) {
 
 }  // namespace
 
-// pixels-per-lane selection: params field (0 = default)
-inline int pick_ppl(int requested, int dflt) { return (requested == 1 || requested == 2 || requested == 4) ? requested : dflt; }
-constexpr int kDefaultPplFwd = 2, kDefaultPplBwd = 2;
+// A tile is covered by two independent wavefronts ("bands" of 16 x 8 pixels, two pixels per lane): measured against one
+// (16 x 16, four pixels per lane: 0.513 against 0.481 ms backward) and four (0.605) bands per tile, DESIGN.md section 6.
+constexpr int kPpl = 2, kBands = 4 / kPpl;
 
-extern "C" int misplat_blend_planes(const misplat_params* p) { return p ? 4 / pick_ppl(p->ppl_bwd, kDefaultPplBwd) : 0; }
+extern "C" int misplat_blend_planes(const misplat_params* p) { return p ? kBands : 0; }
 
-extern "C" int misplat_unit_order(const misplat_params* p, int32_t ppl, const int32_t* unit_work, int32_t* unit_perm,
+extern "C" int misplat_unit_order(const misplat_params* p, const int32_t* unit_work, int32_t* unit_perm,
                                   misplat_stream_t stream) {
     if (!params_ok(p) || !unit_work || !unit_perm) return MISPLAT_EINVAL;
-    const int q = pick_ppl(ppl, kDefaultPplFwd);
-    const int units = p->tile_w * p->tile_h * p->n_cams * (4 / q);
+    const int units = p->tile_w * p->tile_h * p->n_cams * kBands;
     const int per = (units + 7) >> 3;
     hipLaunchKernelGGL(unit_order_kernel, dim3(8), dim3(1024), 0, (hipStream_t)stream, units, per, unit_work, unit_perm,
                        (int32_t*)nullptr, 0, 0);
     return check_launch();
 }
 
-int misplat_internal::unit_order_table(const misplat_params* p, int32_t ppl, const int32_t* unit_work, int32_t* table,
-                                       int32_t* sel, int32_t stride, int32_t slots, hipStream_t s) {
+int misplat_internal::unit_order_table(const misplat_params* p, const int32_t* unit_work, int32_t* table,
+                                       int32_t* sel, int32_t stride, int32_t slots, const float* unit_reach, hipStream_t s) {
     if (!params_ok(p) || !unit_work || !table || !sel || slots < 1) return MISPLAT_EINVAL;
-    const int q = pick_ppl(ppl, kDefaultPplFwd);
-    const int units = p->tile_w * p->tile_h * p->n_cams * (4 / q);
+    const int n_tiles = p->tile_w * p->tile_h * p->n_cams;
+    const int units = n_tiles * kBands;
     const int per = (units + 7) >> 3;
-    if (stride < MISPLAT_ORDER_HEADER + 8 * per) return MISPLAT_EINVAL;
-    hipLaunchKernelGGL(unit_order_kernel, dim3(8), dim3(1024), 0, s, units, per, unit_work, table, sel, (int)stride, (int)slots);
+    const int pivot_off = MISPLAT_ORDER_HEADER + 8 * per;
+    if (stride < pivot_off + (unit_reach ? n_tiles : 0)) return MISPLAT_EINVAL;
+    hipLaunchKernelGGL(unit_order_kernel, dim3(8), dim3(1024), 0, s, units, per, unit_work, table, sel, (int)stride, (int)slots,
+                       unit_reach, n_tiles, pivot_off);
     return check_launch();
 }
 
@@ -1564,26 +1212,18 @@ extern "C" int misplat_blend_fwd(const misplat_params* p, int32_t color_dim, con
                                  float* med_depth, float* normal, int32_t* last_ids,
                                  int32_t* median_ids, misplat_stream_t stream) {
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL) return MISPLAT_EINVAL;
-    const int ppl = pick_ppl(p->ppl_fwd, kDefaultPplFwd);
-    const int total = p->tile_w * p->tile_h * p->n_cams * (4 / ppl);
+    const int total = p->tile_w * p->tile_h * p->n_cams * kBands;
     const int grid = ((total + 7) / 8) * 8;
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_FWD(CD_, PPL_)                                                                              \
-    hipLaunchKernelGGL((blend_fwd_kernel<CD_, PPL_>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec, \
+#define LAUNCH_FWD(CD_)                                                                                    \
+    hipLaunchKernelGGL((blend_fwd_kernel<CD_, kPpl>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec, \
                        flatten_ids, offsets, n_isects, render, alpha, exp_depth, med_depth, normal, last_ids,  \
                        median_ids)
-#define DISPATCH_FWD(CD_)                                  \
-    do {                                                   \
-        if (ppl == 1) LAUNCH_FWD(CD_, 1);                  \
-        else if (ppl == 2) LAUNCH_FWD(CD_, 2);             \
-        else LAUNCH_FWD(CD_, 4);                           \
-    } while (0)
-    if (color_dim == 1) DISPATCH_FWD(1);
-    else if (color_dim == 2) DISPATCH_FWD(2);
-    else if (color_dim == 3) DISPATCH_FWD(3);
-    else if (color_dim == 4) DISPATCH_FWD(4);
+    if (color_dim == 1) LAUNCH_FWD(1);
+    else if (color_dim == 2) LAUNCH_FWD(2);
+    else if (color_dim == 3) LAUNCH_FWD(3);
+    else if (color_dim == 4) LAUNCH_FWD(4);
     else return MISPLAT_EINVAL;
-#undef DISPATCH_FWD
 #undef LAUNCH_FWD
     return check_launch();
 }
@@ -1612,8 +1252,7 @@ int misplat_internal::blend_fwd_lazy(const misplat_params* p, int32_t color_dim,
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !means || !viewmats || !coeffs || sh_degree < 0 ||
         sh_degree > 3 || (depth_channel && !depths) || color_dim < 3 || color_dim > 4)
         return MISPLAT_EINVAL;
-    if (pick_ppl(p->ppl_fwd, kDefaultPplFwd) != 2) return MISPLAT_EINVAL;
-    const int total = p->tile_w * p->tile_h * p->n_cams * 2;
+    const int total = p->tile_w * p->tile_h * p->n_cams * kBands;
     if (((uintptr_t)rows_on_touch) & 15) return MISPLAT_EINVAL;
     const int grid = ((total + 7) / 8) * 8;
     LazyColour lz;
@@ -1641,29 +1280,17 @@ extern "C" int misplat_blend_bwd(const misplat_params* p, int32_t color_dim, con
                                  float* slab_abs, uint8_t* slab_valid, misplat_stream_t stream) {
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !slab_valid) return MISPLAT_EINVAL;
     if (n_isects == 0) return MISPLAT_OK;
-    const int ppl = pick_ppl(p->ppl_bwd, kDefaultPplBwd);
-    const int planes = 4 / ppl;
+    const int planes = kBands;
     const int total = p->tile_w * p->tile_h * p->n_cams * planes;
     const int grid = ((total + 7) / 8) * 8;
     hipStream_t s = (hipStream_t)stream;
     if (misplat_internal::fill_bytes(slab_valid, (size_t)n_isects * planes, 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
-#define LAUNCH_BWD(CD_, PPL_, ABS_)                                                                          \
-    hipLaunchKernelGGL((blend_bwd_kernel<CD_, PPL_, ABS_, false>), dim3(grid), dim3(64), 0, s, *p, Ks,         \
+#define LAUNCH_BWD(CD_, ABS_)                                                                                \
+    hipLaunchKernelGGL((blend_bwd_kernel<CD_, kPpl, ABS_, false>), dim3(grid), dim3(64), 0, s, *p, Ks,         \
                        (const float4*)grec, flatten_ids, slots_sorted, offsets, n_isects, alpha, last_ids,     \
                        median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, slab,        \
                        slab_abs, slab_valid)
-#define DISPATCH_BWD(CD_)                                                        \
-    do {                                                                         \
-        if (slab_abs) {                                                          \
-            if (ppl == 1) LAUNCH_BWD(CD_, 1, true);                              \
-            else if (ppl == 2) LAUNCH_BWD(CD_, 2, true);                         \
-            else LAUNCH_BWD(CD_, 4, true);                                       \
-        } else {                                                                 \
-            if (ppl == 1) LAUNCH_BWD(CD_, 1, false);                             \
-            else if (ppl == 2) LAUNCH_BWD(CD_, 2, false);                        \
-            else LAUNCH_BWD(CD_, 4, false);                                      \
-        }                                                                        \
-    } while (0)
+#define DISPATCH_BWD(CD_) do { if (slab_abs) LAUNCH_BWD(CD_, true); else LAUNCH_BWD(CD_, false); } while (0)
     if (color_dim == 1) DISPATCH_BWD(1);
     else if (color_dim == 2) DISPATCH_BWD(2);
     else if (color_dim == 3) DISPATCH_BWD(3);
@@ -1691,13 +1318,12 @@ int misplat_internal::blend_bwd_atomic(const misplat_params* p, int32_t color_di
     // v_grec_is_zero: bit 0 = v_grec, bit 1 = v_abs have been cleared by the caller
     if (!(v_grec_is_zero & 1) && fill_bytes(v_grec, rows * MISPLAT_REC * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     if (v_abs && !(v_grec_is_zero & 2) && fill_bytes(v_abs, rows * 2 * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
-    const int ppl = pick_ppl(p->ppl_bwd, kDefaultPplBwd);
     FillList F = {};
     if (fills) {
         if (fills->count < 0 || fills->count > 8) return MISPLAT_EINVAL;
         for (int k = 0; k < fills->count; k++)
             if (!fills->p[k] || (((uintptr_t)fills->p[k]) & 15) || fills->n[k] < 0) return MISPLAT_EINVAL;
-        const bool in_kernel = n_isects > 0 && !(ppl == 2 && p->sub_blocks == 4) && color_dim >= 1 && color_dim <= 4;
+        const bool in_kernel = n_isects > 0 && color_dim >= 1 && color_dim <= 4;
         if (in_kernel) {
             F = *fills;
             F.blocks = kFillBlocks;
@@ -1710,44 +1336,14 @@ int misplat_internal::blend_bwd_atomic(const misplat_params* p, int32_t color_di
         }
     }
     if (n_isects == 0) return MISPLAT_OK;
-    const int total = p->tile_w * p->tile_h * p->n_cams * (4 / ppl);
+    const int total = p->tile_w * p->tile_h * p->n_cams * kBands;
     const int grid = ((total + 7) / 8) * 8 + F.blocks;
-    if (ppl == 2 && p->sub_blocks == 4 && color_dim >= 1 && color_dim <= 4) {
-#define LAUNCH_BWDQ(CD_)                                                                                       \
-        do {                                                                                                   \
-            if (v_abs) hipLaunchKernelGGL((blend_bwd_quad_kernel<CD_, true>), dim3(grid), dim3(64), 0, s, *p, Ks, \
-                                          (const float4*)grec, flatten_ids, offsets, n_isects, alpha, last_ids, \
-                                          median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth,     \
-                                          v_normal, v_grec, v_abs);                                            \
-            else hipLaunchKernelGGL((blend_bwd_quad_kernel<CD_, false>), dim3(grid), dim3(64), 0, s, *p, Ks,   \
-                                    (const float4*)grec, flatten_ids, offsets, n_isects, alpha, last_ids,      \
-                                    median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, \
-                                    v_grec, v_abs);                                                            \
-        } while (0)
-        if (color_dim == 1) LAUNCH_BWDQ(1);
-        else if (color_dim == 2) LAUNCH_BWDQ(2);
-        else if (color_dim == 3) LAUNCH_BWDQ(3);
-        else LAUNCH_BWDQ(4);
-#undef LAUNCH_BWDQ
-        return check_launch();
-    }
-#define LAUNCH_BWDA(CD_, PPL_, ABS_)                                                                         \
-    hipLaunchKernelGGL((blend_bwd_kernel<CD_, PPL_, ABS_, true>), dim3(grid), dim3(64), 0, s, *p, Ks,          \
+#define LAUNCH_BWDA(CD_, ABS_)                                                                               \
+    hipLaunchKernelGGL((blend_bwd_kernel<CD_, kPpl, ABS_, true>), dim3(grid), dim3(64), 0, s, *p, Ks,          \
                        (const float4*)grec, flatten_ids, (const int32_t*)nullptr, offsets, n_isects, alpha,    \
                        last_ids, median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal,    \
                        v_grec, v_abs, (uint8_t*)nullptr, (const float4*)nullptr, (float*)nullptr, CD_, F)
-#define DISPATCH_BWDA(CD_)                                                       \
-    do {                                                                         \
-        if (v_abs) {                                                             \
-            if (ppl == 1) LAUNCH_BWDA(CD_, 1, true);                             \
-            else if (ppl == 2) LAUNCH_BWDA(CD_, 2, true);                        \
-            else LAUNCH_BWDA(CD_, 4, true);                                      \
-        } else {                                                                 \
-            if (ppl == 1) LAUNCH_BWDA(CD_, 1, false);                            \
-            else if (ppl == 2) LAUNCH_BWDA(CD_, 2, false);                       \
-            else LAUNCH_BWDA(CD_, 4, false);                                     \
-        }                                                                        \
-    } while (0)
+#define DISPATCH_BWDA(CD_) do { if (v_abs) LAUNCH_BWDA(CD_, true); else LAUNCH_BWDA(CD_, false); } while (0)
     if (color_dim == 1) DISPATCH_BWDA(1);
     else if (color_dim == 2) DISPATCH_BWDA(2);
     else if (color_dim == 3) DISPATCH_BWDA(3);
@@ -1784,7 +1380,7 @@ extern "C" int misplat_blend_fwd_x(const misplat_params* p, int32_t n_channels, 
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || nxq < 1 || nxq > 4 || n_channels < 5 ||
         n_channels > 4 + 4 * nxq || !featx)
         return MISPLAT_EINVAL;
-    const int total = p->tile_w * p->tile_h * p->n_cams * 2;
+    const int total = p->tile_w * p->tile_h * p->n_cams * kBands;
     const int grid = ((total + 7) / 8) * 8;
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_FWDX(NXQ_)                                                                                   \
@@ -1817,7 +1413,7 @@ extern "C" int misplat_blend_bwd_x_atomic(const misplat_params* p, int32_t n_cha
     if (misplat_internal::fill_bytes(v_featx, rows * 4 * nxq * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     if (v_abs && misplat_internal::fill_bytes(v_abs, rows * 2 * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     if (n_isects == 0) return MISPLAT_OK;
-    const int total = p->tile_w * p->tile_h * p->n_cams * 2;
+    const int total = p->tile_w * p->tile_h * p->n_cams * kBands;
     const int grid = ((total + 7) / 8) * 8;
 #define LAUNCH_BWDX(NXQ_, ABS_)                                                                              \
     hipLaunchKernelGGL((blend_bwd_kernel<4, 2, ABS_, true, NXQ_>), dim3(grid), dim3(64), 0, s, *p, Ks,          \
@@ -1844,18 +1440,9 @@ extern "C" int misplat_slab_reduce(const misplat_params* p, int64_t n_rows, int6
                                    float* v_abs, misplat_stream_t stream) {
     if (!p || n_rows < 0 || n_isects < 0 || (slab_abs != nullptr) != (v_abs != nullptr)) return MISPLAT_EINVAL;
     if (n_rows == 0) return MISPLAT_OK;
-    const int planes = 4 / pick_ppl(p->ppl_bwd, kDefaultPplBwd);
     const dim3 grid(grid_for(n_rows * 16, 256)), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    if (planes == 1)
-        hipLaunchKernelGGL(slab_reduce_kernel<1>, grid, block, 0, s, n_rows, n_isects, cum, tiles_per_gauss, slab,
-                           slab_abs, slab_valid, v_grec, v_abs);
-    else if (planes == 2)
-        hipLaunchKernelGGL(slab_reduce_kernel<2>, grid, block, 0, s, n_rows, n_isects, cum, tiles_per_gauss, slab,
-                           slab_abs, slab_valid, v_grec, v_abs);
-    else
-        hipLaunchKernelGGL(slab_reduce_kernel<4>, grid, block, 0, s, n_rows, n_isects, cum, tiles_per_gauss, slab,
-                           slab_abs, slab_valid, v_grec, v_abs);
+    hipLaunchKernelGGL(slab_reduce_kernel<kBands>, grid, block, 0, (hipStream_t)stream, n_rows, n_isects, cum, tiles_per_gauss,
+                       slab, slab_abs, slab_valid, v_grec, v_abs);
     return check_launch();
 }
 

@@ -45,8 +45,10 @@ int project_pack_fwd(const misplat_params* p, const float* means, const float* q
                      int32_t* order_sel, int32_t order_slots, int32_t order_stride, hipStream_t s);
 
 // misplat_unit_order into the record of a view-keyed table that `sel` names (misplat_params.unit_sel).
-int unit_order_table(const misplat_params* p, int32_t ppl, const int32_t* unit_work, int32_t* table, int32_t* sel,
-                     int32_t stride, int32_t slots, hipStream_t s);
+// unit_reach (or NULL): [units] depths the forward reached -- the record also gets its per-tile pivots (front-only ordering)
+// at word MISPLAT_ORDER_HEADER + 8 * ceil(units / 8); stride must cover them.
+int unit_order_table(const misplat_params* p, const int32_t* unit_work, int32_t* table, int32_t* sel,
+                     int32_t stride, int32_t slots, const float* unit_reach, hipStream_t s);
 
 // misplat_blend_fwd_lazy that also clears row g of rows_on_touch[C*N,16] (or NULL) when it sets the colour of record g.
 int blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const float* Ks, float* grec, const int32_t* flatten_ids,
@@ -64,5 +66,21 @@ int gauss_bwd_sparse(const misplat_params* p, int32_t sh_degree, int32_t depth_s
                      float* v_coeffs_rest, float* v_means, float* v_quats, float* v_scales, float* v_opacities,
                      float* v_means2d_out /* or NULL: [N,2] (cleared like the others), columns 0:2 of the flagged rows */,
                      hipStream_t s);
+
+// Front-only ordering (csrc/binning.hip, tile_sort_front_kernel): the view-keyed table of misplat_params.unit_sel, whose
+// records hold per-tile depth pivots at word pivot_off; front_n[n_tiles] / tile_flag[n_tiles] are written for every tile.
+struct FrontSort {
+    const int32_t* order_table;
+    const int32_t* order_sel;
+    int32_t order_slots, order_stride, pivot_off;
+    float margin;
+    int32_t min_bucket;
+    int32_t* front_n;
+    int32_t* tile_flag;
+};
+int tile_sort_front(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths, int32_t* payload,
+                    int32_t* flatten_ids, uint32_t* scratch, const FrontSort& F, hipStream_t s);
+int tile_sort_flagged(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths, int32_t* payload,
+                      int32_t* flatten_ids, uint32_t* scratch, const int32_t* tile_flag, hipStream_t s);
 
 }  // namespace misplat_internal

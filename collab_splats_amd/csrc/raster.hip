@@ -27,25 +27,14 @@
 
 namespace {
 
-// `fork`: a second stream + two events owned by the graph cache, or NULL.  With it the colour kernel (memory-latency
-// bound, ~100 us at 1 M Gaussians) runs BESIDE the bucketing kernels and the per-tile sort (latency bound, ~170 us) and
-// joins in front of the compositing: captured into a graph this becomes two parallel branches.
-struct Fork {
-    hipStream_t side;
-    hipEvent_t forked, joined;
-};
-
 int enqueue_colour(const misplat_params* p, const misplat_raster_args* a, misplat_stream_t stream) {
     return misplat_color_fwd(p, a->sh_degree, a->K_or_D, a->n_color, a->per_cam, a->depth_channel, a->means, a->viewmats,
                              a->colors, a->colors_rest, a->radii, a->depths, a->grec, a->sh_aux, a->v_grec_zero, stream);
 }
 
-int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32_t phases, hipStream_t s, const Fork* fork) {
+int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32_t phases, hipStream_t s) {
     misplat_stream_t stream = (misplat_stream_t)s;
     int rc;
-    // The colour kernel belongs to phase A, but nothing before the compositing reads its output: when phase B follows in
-    // the same call it is deferred to B's parallel branch.
-    const bool colour_in_b = (phases & 2) && a->colour_pending != 0 && !a->lazy_colour;
     if (phases & 1) {
         // the projection kernel also clears everything the bucketing accumulates into -- cell counts, cell cursors, the
         // two counters, the tile counters: ONE contiguous range (cell_count ... tile_count) --, so phase A contains no
@@ -73,66 +62,83 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         rc = misplat_bucket_rows(p, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count, a->cell_cursor, a->cell_offs,
                                  a->order, a->rect_sorted, a->counters, a->tile_count, a->n_isects_host, 3, stream);
         if (rc != MISPLAT_OK) return rc;
-        if (!a->colour_pending && !a->lazy_colour) {
+        if (!a->lazy_colour) {
             rc = enqueue_colour(p, a, stream);
             if (rc != MISPLAT_OK) return rc;
         }
     }
     if (phases & 2) {
         if (a->cap_isects < 0 || a->cap_isects > 0x7fffffffLL) return MISPLAT_EINVAL;
-        bool forked = false;
-        if (colour_in_b) {
-            if (fork && hipEventRecord(fork->forked, s) == hipSuccess && hipStreamWaitEvent(fork->side, fork->forked, 0) == hipSuccess) {
-                rc = enqueue_colour(p, a, (misplat_stream_t)fork->side);
-                if (rc != MISPLAT_OK) return rc;
-                forked = true;
-            } else {
-                (void)hipGetLastError();
-                rc = enqueue_colour(p, a, stream);
-                if (rc != MISPLAT_OK) return rc;
-            }
-        }
         rc = misplat_bucket_tiles(p, a->order, a->rect_sorted, a->counters, a->tile_count, a->offsets, nullptr, a->cap_isects,
                                   a->payload, nullptr, stream);
         if (rc != MISPLAT_OK) return rc;
-        if (a->cap_isects > 0) {
-            rc = misplat_tile_sort(a->offsets, p->tile_w * p->tile_h * p->n_cams, a->cap_isects, a->depths, nullptr,
-                                   a->payload, a->flatten_ids, a->scratch, 3, stream);
-            if (rc != MISPLAT_OK) return rc;
-        }
-        if (forked && (hipEventRecord(fork->joined, fork->side) != hipSuccess || hipStreamWaitEvent(s, fork->joined, 0) != hipSuccess))
-            return MISPLAT_ELAUNCH;
-        misplat_params q = *p;
+        const int n_tiles = p->tile_w * p->tile_h * p->n_cams;
+        const int64_t units = (int64_t)n_tiles * MISPLAT_BANDS;
+        const int pivot_off = (int)(MISPLAT_ORDER_HEADER + 8 * ((units + 7) / 8));
         const bool by_view = a->order_table && a->order_sel && a->unit_work;
         if (by_view) {          // (a record must hold a whole permutation: the compositing launch indexes it by workgroup)
-            const int ppl_f = (p->ppl_fwd == 1 || p->ppl_fwd == 2 || p->ppl_fwd == 4) ? p->ppl_fwd : 2;
-            const int64_t units = (int64_t)p->tile_w * p->tile_h * p->n_cams * (4 / ppl_f);
-            if (a->order_slots < 1 || a->order_stride < MISPLAT_ORDER_HEADER + 8 * ((units + 7) / 8)) return MISPLAT_EINVAL;
+            if (a->order_slots < 1 || a->order_stride < pivot_off + (a->unit_reach ? n_tiles : 0)) return MISPLAT_EINVAL;
         }
+        // front-only ordering: only with the view-keyed records (they carry the pivots) and the reach output that feeds them
+        const bool front = by_view && a->unit_reach && a->front_n && a->tile_flag;
+        if ((a->front_n != nullptr) != (a->tile_flag != nullptr) || (a->front_n && !front)) return MISPLAT_EINVAL;
+        if (front) {
+            misplat_internal::FrontSort F;
+            F.order_table = a->order_table; F.order_sel = a->order_sel; F.order_slots = a->order_slots;
+            F.order_stride = a->order_stride; F.pivot_off = pivot_off;
+            F.margin = a->front_margin >= 1.0f ? a->front_margin : 1.0f;
+            F.min_bucket = a->front_min_bucket > 0 ? a->front_min_bucket : 1;
+            F.front_n = a->front_n; F.tile_flag = a->tile_flag;
+            rc = misplat_internal::tile_sort_front(a->offsets, n_tiles, a->cap_isects, a->depths, a->payload, a->flatten_ids,
+                                                   a->scratch, F, s);
+            if (rc != MISPLAT_OK) return rc;
+        } else if (a->cap_isects > 0) {
+            rc = misplat_tile_sort(a->offsets, n_tiles, a->cap_isects, a->depths, nullptr, a->payload, a->flatten_ids,
+                                   a->scratch, 3, stream);
+            if (rc != MISPLAT_OK) return rc;
+        }
+        misplat_params q = *p;
         q.unit_perm = by_view ? a->order_table : a->unit_perm_in;
         q.unit_sel = by_view ? a->order_sel : nullptr;
         q.unit_stride = by_view ? a->order_stride : 0;
         q.unit_slots = by_view ? a->order_slots : 0;
         q.unit_work = a->unit_work;
+        q.unit_reach = by_view ? a->unit_reach : nullptr;
+        q.front_depths = a->depths;
+        q.front_n = front ? a->front_n : nullptr;
+        q.tile_flag = front ? a->tile_flag : nullptr;
+        q.front_pass = 0;
         if (a->ev_blend_begin && hipEventRecord((hipEvent_t)a->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
+        if (a->lazy_colour == 2 && !a->v_grec_zero) return MISPLAT_EINVAL;
+        auto composite = [&]() -> int {
         if (a->lazy_colour) {
-            if (a->lazy_colour == 2 && !a->v_grec_zero) return MISPLAT_EINVAL;
-            rc = misplat_internal::blend_fwd_lazy(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects,
+            return misplat_internal::blend_fwd_lazy(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects,
                                                   a->render, a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids,
                                                   a->median_ids, a->means, a->viewmats, a->colors, a->colors_rest,
                                                   a->sh_degree, a->depth_channel, a->depths, nullptr,
                                                   a->lazy_colour == 2 ? a->v_grec_zero : nullptr, s);
-        } else
-            rc = misplat_blend_fwd(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects, a->render,
-                                   a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, stream);
+        }
+        return misplat_blend_fwd(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects, a->render,
+                                 a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids, a->median_ids, stream);
+        };
+        rc = composite();
         if (rc != MISPLAT_OK) return rc;
+        if (front) {
+            // the tiles whose pixels were still alive at the end of their truncated list: sorted in full, composited again
+            rc = misplat_internal::tile_sort_flagged(a->offsets, n_tiles, a->cap_isects, a->depths, a->payload, a->flatten_ids,
+                                                     a->scratch, a->tile_flag, s);
+            if (rc != MISPLAT_OK) return rc;
+            q.front_pass = 1;
+            rc = composite();
+            if (rc != MISPLAT_OK) return rc;
+        }
         if (a->ev_blend_end && hipEventRecord((hipEvent_t)a->ev_blend_end, s) != hipSuccess) return MISPLAT_ELAUNCH;
         if (by_view) {
-            rc = misplat_internal::unit_order_table(p, p->ppl_fwd, a->unit_work, a->order_table, a->order_sel, a->order_stride,
-                                                    a->order_slots, s);
+            rc = misplat_internal::unit_order_table(p, a->unit_work, a->order_table, a->order_sel, a->order_stride,
+                                                    a->order_slots, a->unit_reach, s);
             if (rc != MISPLAT_OK) return rc;
         } else if (a->unit_work && a->unit_perm_out) {
-            rc = misplat_unit_order(p, p->ppl_fwd, a->unit_work, a->unit_perm_out, stream);
+            rc = misplat_unit_order(p, a->unit_work, a->unit_perm_out, stream);
             if (rc != MISPLAT_OK) return rc;
         }
     }
@@ -165,17 +171,13 @@ struct misplat_graph_cache {
     // Sequences are captured on this private stream (the caller's may be the legacy default stream, which cannot be
     // captured) and the resulting graph is launched on the caller's stream.
     hipStream_t capture_stream = nullptr;
-    Fork fork{nullptr, nullptr, nullptr};       // the parallel branch of a sequence (captured, or eager when captures are bypassed)
 };
 
 extern "C" misplat_graph_cache* misplat_graph_cache_create(int32_t max_entries) {
     misplat_graph_cache* c = new (std::nothrow) misplat_graph_cache();
     if (!c) return nullptr;
     if (max_entries > 0) c->max_entries = max_entries;
-    if (hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->fork.side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&c->fork.forked, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->fork.joined, hipEventDisableTiming) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->capture_stream, hipStreamNonBlocking) != hipSuccess) {
         (void)hipGetLastError();
         misplat_graph_cache_destroy(c);
         return nullptr;
@@ -189,9 +191,6 @@ extern "C" void misplat_graph_cache_destroy(misplat_graph_cache* c) {
     for (auto& e : c->entries) { (void)hipGraphExecDestroy(e.exec); (void)hipGraphDestroy(e.graph); }
     for (auto& r : c->retired) { (void)hipGraphExecDestroy(r.exec); (void)hipGraphDestroy(r.graph); (void)hipEventDestroy(r.done); }
     if (c->capture_stream) (void)hipStreamDestroy(c->capture_stream);
-    if (c->fork.side) (void)hipStreamDestroy(c->fork.side);
-    if (c->fork.forked) (void)hipEventDestroy(c->fork.forked);
-    if (c->fork.joined) (void)hipEventDestroy(c->fork.joined);
     delete c;
 }
 
@@ -203,7 +202,7 @@ extern "C" int misplat_graph_cache_stats(misplat_graph_cache* c, int64_t* hits, 
     return MISPLAT_OK;
 }
 
-// Run `enqueue(stream, fork)` through the cache: replay the graph captured for `key`, or capture it now.
+// Run `enqueue(stream)` through the cache: replay the graph captured for `key`, or capture it now.
 template <class Enqueue>
 static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hipStream_t s, Enqueue enqueue) {
     std::lock_guard<std::mutex> g(cache->mu);
@@ -244,29 +243,29 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
             if (cache->seen.size() < 256) cache->seen.push_back(h);
             else cache->seen[cache->seen_next++ & 255] = h;
         }
-        return enqueue(s, &cache->fork);
+        return enqueue(s);
     }
     cache->window_captures++;
     // capture on the private stream (thread-local mode: other host threads keep using the runtime normally)
     hipStream_t cs = cache->capture_stream;
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
-        return enqueue(s, (const Fork*)nullptr);
+        return enqueue(s);
     }
-    const int rc = enqueue(cs, &cache->fork);
+    const int rc = enqueue(cs);
     hipGraph_t graph = nullptr;
     const hipError_t ec = hipStreamEndCapture(cs, &graph);
     if (rc != MISPLAT_OK || ec != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        return rc != MISPLAT_OK ? rc : enqueue(s, (const Fork*)nullptr);
+        return rc != MISPLAT_OK ? rc : enqueue(s);
     }
     hipGraphExec_t exec = nullptr;
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (ei != hipSuccess || !exec) {
         (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        return enqueue(s, (const Fork*)nullptr);
+        return enqueue(s);
     }
     if ((int)cache->entries.size() >= cache->max_entries) {       // evict the least recently used graph
         size_t victim = 0;
@@ -307,9 +306,8 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
                                   misplat_stream_t stream, misplat_graph_cache* cache) {
     if (!p || !a || (phases & ~3) != 0 || phases == 0) return MISPLAT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (!cache) return enqueue_forward(p, a, phases, s, nullptr);
-    return run_cached(cache, make_key(phases, s, p, a), s,
-                      [&](hipStream_t st, const Fork* f) { return enqueue_forward(p, a, phases, st, f); });
+    if (!cache) return enqueue_forward(p, a, phases, s);
+    return run_cached(cache, make_key(phases, s, p, a), s, [&](hipStream_t st) { return enqueue_forward(p, a, phases, st); });
 }
 
 // ---- the whole backward of rasterization(): compositing backward (atomic gradient rows), colour backward,
@@ -392,7 +390,7 @@ extern "C" int misplat_raster_bwd(const misplat_params* p, const misplat_raster_
     // memset nodes are kept out of graphs (see the note on phase A): only the memset-free form is captured
     const bool memset_free = (b->zero_flags & 1) && (!b->v_abs || (b->zero_flags & 2));
     if (!cache || !memset_free || b->ev_blend_begin || b->ev_blend_end) return enqueue_backward(p, b, s);
-    return run_cached(cache, make_key(0x100, s, p, b), s, [&](hipStream_t st, const Fork*) { return enqueue_backward(p, b, st); });
+    return run_cached(cache, make_key(0x100, s, p, b), s, [&](hipStream_t st) { return enqueue_backward(p, b, st); });
 }
 
 // float4 streaming copy: the measured HBM roof of the box the benchmark runs on (bench.py reports fractions of it

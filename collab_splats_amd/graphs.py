@@ -55,7 +55,7 @@ class GraphedStep:
         self.capacity = int(capacity)
         if not ops.fused_node_ok():
             raise ops._lib.MisplatError("GraphedStep needs the default single-node path (MISPLAT_FUSED / MISPLAT_FUSED_NODE / "
-                                        "MISPLAT_ORDERING=cells, atomic gradient mode)")
+                                        "atomic gradient mode)")
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         # An autograd graph kept alive across calls (returned by fn, or stashed anywhere else: a dict of "last outputs", a

@@ -54,8 +54,7 @@ def _stream_id() -> int:
     return int(stream_ptr().value or 0)
 
 
-def _eff_ppl(v: int) -> int:
-    return v if v in (1, 2, 4) else 2
+BANDS = 2                              # MISPLAT_BANDS: wavefronts (16 x 8 pixel bands) per tile
 
 
 # View-keyed launch orders (the one-entry forward): per (device, stream, image shape) a persistent device table of
@@ -78,14 +77,13 @@ def _order_table(P: Params, dev: torch.device):
     """(table, sel, stride) of this device / stream / shape, or None when view-keyed orders are off."""
     if not (UNIT_ORDER and UNIT_ORDER_FWD and ORDER_BY_VIEW and ORDER_SLOTS > 0):
         return None
-    ppl_f = _eff_ppl(P.ppl_fwd)
-    if _eff_ppl(P.ppl_bwd) != ppl_f:
-        return None
-    units = P.tile_w * P.tile_h * P.n_cams * (4 // ppl_f)
-    key = (dev.index, _stream_id(), P.n_cams, P.tile_w, P.tile_h, ppl_f, ORDER_SLOTS)
+    units = P.tile_w * P.tile_h * P.n_cams * BANDS
+    key = (dev.index, _stream_id(), P.n_cams, P.tile_w, P.tile_h, ORDER_SLOTS)
     got = _ORDER_TABLES.get(key)
     if got is None:
-        stride = ORDER_HEADER + 8 * ((units + 7) // 8)
+        # a record: header, the launch order of the view's units, the per-tile depth pivots of front-only ordering
+        n_tiles = P.tile_w * P.tile_h * P.n_cams
+        stride = ORDER_HEADER + 8 * ((units + 7) // 8) + 8 * ((n_tiles + 7) // 8)
         got = _ORDER_TABLES[key] = (torch.zeros(ORDER_SLOTS * stride, device=dev, dtype=torch.int32),
                                     torch.zeros(4, device=dev, dtype=torch.int32), stride)
     return got
@@ -100,9 +98,8 @@ class _UnitSchedule:
         self.by_view = by_view if self.on else None        # (table, sel, stride): the order lives in a view-keyed record
         if not self.on:
             return
-        self.ppl_f, self.ppl_b = _eff_ppl(P.ppl_fwd), _eff_ppl(P.ppl_bwd)
-        self.units = P.tile_w * P.tile_h * P.n_cams * (4 // self.ppl_f)
-        self.key = (dev.index, _stream_id(), P.n_cams, P.tile_w, P.tile_h, self.ppl_f)
+        self.units = P.tile_w * P.tile_h * P.n_cams * BANDS
+        self.key = (dev.index, _stream_id(), P.n_cams, P.tile_w, P.tile_h)
         self.work, self.perm = _carve(dev, (self.units, 8 * ((self.units + 7) // 8) if self.by_view is None else 0))
 
     def before_forward(self, P: Params) -> None:
@@ -117,11 +114,9 @@ class _UnitSchedule:
         P.unit_perm, P.unit_work = None, None
         if not self.on:
             return
-        check(_lib.load().misplat_unit_order(C.byref(P), C.c_int32(self.ppl_f), ptr(self.work), ptr(self.perm),
-                                             stream_ptr()), "misplat_unit_order")
+        check(_lib.load().misplat_unit_order(C.byref(P), ptr(self.work), ptr(self.perm), stream_ptr()), "misplat_unit_order")
         _LAST_ORDER[self.key] = self.perm
-        if self.ppl_b == self.ppl_f:
-            self.perm_bwd = self.perm
+        self.perm_bwd = self.perm
 
     def before_backward(self, P: Params) -> None:
         if self.by_view is not None:
@@ -181,22 +176,8 @@ def _kernel_event_pair():
     return e0, e1
 
 
-# Independent small kernels (colour vs binning in the forward, colour-backward vs projection-backward)
-# can be overlapped on one side stream per device (MISPLAT_OVERLAP=1).  Measured gain at 1 M / 1080p: <1 %
-# (every kernel already fills the chip), so it is off by default.
-OVERLAP = os.environ.get("MISPLAT_OVERLAP", "0") == "1"
 # SH colours: the forward keeps the Jacobian d rgb / d dir for the backward (see misplat_color_fwd)
 SH_AUX = os.environ.get("MISPLAT_SH_AUX", "1") == "1"
-_SIDE: Dict[int, "torch.cuda.Stream"] = {}
-
-
-def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
-    idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    if idx not in _SIDE:
-        _SIDE[idx] = torch.cuda.Stream(device=idx)
-    return _SIDE[idx]
-
-
 def _c(t: Optional[Tensor]) -> Optional[Tensor]:
     return None if t is None else t.contiguous()
 
@@ -302,22 +283,12 @@ def spherical_harmonics_raw(degree: int, dirs: Tensor, coeffs: Tensor, radii: Op
 
 # ----------------------------------------------------------------------------- binning
 
-# Ordering scheme; both give exactly the (tile, depth, Gaussian id) order of a one-shot 64-bit key sort:
-#   "cells"   = (default, hand-written, csrc/bucket.hip) rows are put into coarse screen-cell order, a workgroup of
-#               1024 neighbouring rows counts / fills its intersections per tile through an LDS window with one
-#               global atomic per (workgroup, tile): every intersection is written once (its row, 4 bytes) and no
-#               tile-id array exists; one workgroup per tile then sorts its bucket by (depth, row).  All sizes live
-#               on the device.
-#   "pertile" = (round-1 path, kept as a tested alternative) emit (tile, row) pairs in row order, stable radix sort
-#               on the tile bits (SORT_BACKEND "rocprim" = rocPRIM's radix_sort_pairs, "misplat" = the hand-written
-#               spin-free radix sort of csrc/sort.hip), per-tile offsets, per-tile depth sort.
-ORDERING = os.environ.get("MISPLAT_ORDERING", "cells")
-SORT_BACKEND = os.environ.get("MISPLAT_SORT", "rocprim")
-SORT_BITS_TILE = int(os.environ.get("MISPLAT_SORT_BITS_TILE", "7"))
-
-_WS_CACHE: Dict[tuple, int] = {}
+# Ordering (csrc/bucket.hip + csrc/binning.hip; gives exactly the (tile, depth, Gaussian id) order of a one-shot 64-bit key
+# sort): rows are put into coarse screen-cell order, a workgroup of 1024 neighbouring rows counts / fills its intersections
+# per tile through an LDS window with one global atomic per (workgroup, tile): every intersection is written once (its row,
+# 4 bytes) and no tile-id array exists; one workgroup per tile then sorts its bucket by (depth, row).  All sizes live on
+# the device.
 _PLAN_CACHE: Dict[tuple, Tuple[int, int]] = {}
-COUNT_BLOCK = 256                                     # MISPLAT_COUNT_BLOCK (include/misplat.h)
 
 
 def _carve(dev: torch.device, sizes) -> list:
@@ -329,39 +300,6 @@ def _carve(dev: torch.device, sizes) -> list:
         tot += (int(n) + 63) // 64 * 64
     buf = torch.empty(max(tot, 64), device=dev, dtype=torch.int32)
     return [buf[o:o + int(n)] for o, n in zip(offs, sizes)]
-
-
-def _sort32(lib, keys_in, keys_out, vals_in, vals_out, n: int, end_bit: int, bits_per_pass: int) -> None:
-    """Stable sort of (u32 key, i32 value) pairs on key bits [0, end_bit)."""
-    dev = keys_in.device
-    if SORT_BACKEND == "rocprim":
-        ws_bytes = _sort_ws_bytes(lib, "u32", n, end_bit)
-        ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-        check(lib.misplat_sort32_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(keys_in), ptr(keys_out), ptr(vals_in),
-                                       ptr(vals_out), C.c_int64(n), C.c_int32(end_bit), stream_ptr()),
-              "misplat_sort32_pairs")
-        return
-    end_bit = max(end_bit, 2)                       # the hand-written sort needs >= 2 bits per pass; the extra key bits are zero
-    bpp = min(bits_per_pass, end_bit)
-    ws_bytes = int(lib.misplat_radix_workspace_bytes(C.c_int64(n), C.c_int32(0), C.c_int32(end_bit), C.c_int32(bpp)))
-    if ws_bytes == 0:
-        raise _lib.MisplatError("misplat_radix_workspace_bytes failed")
-    ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-    check(lib.misplat_radix_sort_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(keys_in), ptr(keys_out), ptr(vals_in),
-                                       ptr(vals_out), C.c_int64(n), C.c_int32(0), C.c_int32(end_bit), C.c_int32(bpp),
-                                       stream_ptr()), "misplat_radix_sort_pairs")
-
-
-def _sort_ws_bytes(lib, kind: str, n: int, end_bit: int) -> int:
-    """rocPRIM temp-storage size; depends only on (n, end_bit), so cache it (host-side query)."""
-    key = (kind, n, end_bit)
-    if key not in _WS_CACHE:
-        fn = {"u32": lib.misplat_sort32_workspace_bytes, "u16": lib.misplat_sort16_workspace_bytes}[kind]
-        b = int(fn(C.c_int64(n), C.c_int32(end_bit)))
-        if b == 0:
-            raise _lib.MisplatError("sort workspace query failed")
-        _WS_CACHE[key] = b
-    return _WS_CACHE[key]
 
 
 def bucket_plan(P: Params) -> Tuple[int, int]:
@@ -386,36 +324,25 @@ def _read_back(n_dev: Tensor) -> Dict:
 @torch.no_grad()
 def start_binning(P: Params, means2d: Tensor, radii: Tensor) -> Dict[str, Tensor]:
     """First half of ``bin_tiles``: everything that does not need the number of intersections on the host (tile
-    counts; "cells": also the cell ordering of the rows), and an ASYNCHRONOUS read-back of that number.  Called right
+    counts, the cell ordering of the rows), and an ASYNCHRONOUS read-back of that number.  Called right
     after the projection kernel, before the colour kernel is launched, so that the host's wait for n_isects -- the one
     sync of the step -- and the launches that follow it are hidden behind the colour kernel instead of idling the GPU."""
     lib = _lib.load()
     dev = means2d.device
     total = P.n_gauss * P.n_cams
     n_tiles = P.tile_w * P.tile_h * P.n_cams
-    if ORDERING == "cells":
-        n_cells, n_blocks = bucket_plan(P)
-        tiles_per_gauss, rect2, cellhist, cell_count, cell_cursor, cell_offs, order, rect_sorted, counters, tile_count = _carve(
-            dev, (total, 2 * total, n_blocks * n_cells, n_cells, n_cells, n_cells + 1, total, 2 * total, 4, n_tiles + 1))
-        counters = counters.view(torch.int64)
-        check(lib.misplat_bucket_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(rect2),
-                                       ptr(cellhist), ptr(cell_count), ptr(counters), C.c_int32(0), stream_ptr()),
-              "misplat_bucket_count")
-        pend = _read_back(counters[0:1])
-        check(lib.misplat_bucket_rows(C.byref(P), ptr(tiles_per_gauss), ptr(rect2), ptr(cellhist), ptr(cell_count),
-                                      ptr(cell_cursor), ptr(cell_offs), ptr(order), ptr(rect_sorted), ptr(counters),
-                                      ptr(tile_count), ptr(None), C.c_int32(0), stream_ptr()), "misplat_bucket_rows")
-        pend.update(tiles_per_gauss=tiles_per_gauss, rect2=rect_sorted, order=order, counters=counters, tile_count=tile_count)
-        return pend
-    if ORDERING != "pertile":
-        raise ValueError(f"unknown MISPLAT_ORDERING {ORDERING!r}")
-    n_blocks = (total + COUNT_BLOCK - 1) // COUNT_BLOCK
-    tiles_per_gauss, block_sums, block_offs, n_dev = _carve(dev, (total, max(n_blocks, 1), 2 * max(n_blocks, 1), 2))
-    block_offs, n_dev = block_offs.view(torch.int64), n_dev.view(torch.int64)
-    check(lib.misplat_tile_count_blocks(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(block_sums),
-                                        ptr(block_offs), ptr(n_dev), stream_ptr()), "misplat_tile_count_blocks")
-    pend = _read_back(n_dev)
-    pend.update(tiles_per_gauss=tiles_per_gauss, block_offs=block_offs)
+    n_cells, n_blocks = bucket_plan(P)
+    tiles_per_gauss, rect2, cellhist, cell_count, cell_cursor, cell_offs, order, rect_sorted, counters, tile_count = _carve(
+        dev, (total, 2 * total, n_blocks * n_cells, n_cells, n_cells, n_cells + 1, total, 2 * total, 4, n_tiles + 1))
+    counters = counters.view(torch.int64)
+    check(lib.misplat_bucket_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(rect2),
+                                   ptr(cellhist), ptr(cell_count), ptr(counters), C.c_int32(0), stream_ptr()),
+          "misplat_bucket_count")
+    pend = _read_back(counters[0:1])
+    check(lib.misplat_bucket_rows(C.byref(P), ptr(tiles_per_gauss), ptr(rect2), ptr(cellhist), ptr(cell_count),
+                                  ptr(cell_cursor), ptr(cell_offs), ptr(order), ptr(rect_sorted), ptr(counters),
+                                  ptr(tile_count), ptr(None), C.c_int32(0), stream_ptr()), "misplat_bucket_rows")
+    pend.update(tiles_per_gauss=tiles_per_gauss, rect2=rect_sorted, order=order, counters=counters, tile_count=tile_count)
     return pend
 
 
@@ -440,66 +367,48 @@ def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor,
         raise _lib.MisplatError(f"{n_isects} tile intersections exceed int32 indexing")
     depths = depths.contiguous()
     out = dict(tiles_per_gauss=tiles_per_gauss, n_isects=n_isects, depths=depths, tile_ids=None, n_tiles=n_tiles)
-    if ORDERING == "cells":
-        offsets, payload, flatten_ids, scratch, isect_gid = _carve(
-            dev, (n_tiles + 2, n_isects, n_isects, 2 * n_isects, n_isects if deterministic else 0))
-        cum = None
-        if deterministic:                                         # emission slots index the gradient slab
-            cum = (torch.cumsum(tiles_per_gauss, dim=0, dtype=torch.int64) - tiles_per_gauss).contiguous()
-            out["cum"] = cum
-        else:
-            isect_gid = None
-        check(lib.misplat_bucket_tiles(C.byref(P), ptr(pend["order"]), ptr(pend["rect2"]), ptr(pend["counters"]),
-                                       ptr(pend["tile_count"]), ptr(offsets), ptr(cum), C.c_int64(n_isects), ptr(payload),
-                                       ptr(isect_gid), stream_ptr()), "misplat_bucket_tiles")
-        if n_isects > 0:
-            check(lib.misplat_tile_sort(ptr(offsets), C.c_int32(n_tiles), C.c_int64(n_isects), ptr(depths), ptr(isect_gid),
-                                        ptr(payload), ptr(flatten_ids), ptr(scratch), C.c_int32(3), stream_ptr()),
-                  "misplat_tile_sort")
-        out.update(slots=payload if deterministic else None, flatten_ids=flatten_ids, isect_offsets=offsets[:n_tiles + 1])
-        return out
-    # ---- "pertile": (tile, row) pairs in row order -> stable radix sort on the tile bits -> offsets -> per-tile sort
-    key16 = SORT_BACKEND == "rocprim" and n_tiles < 65536         # 12 instead of 16 B per pair and pass
-    i32 = dict(device=dev, dtype=torch.int32)
-    tile_ids = torch.empty(n_isects, device=dev, dtype=torch.int16 if key16 else torch.int32)
-    tile_ids_s = torch.empty_like(tile_ids)
-    isect_gid, payload_s, flatten_ids, scratch, offsets, slots = _carve(
-        dev, (n_isects, n_isects, n_isects, 2 * n_isects, n_tiles + 1, n_isects if deterministic else 0))
-    if not deterministic:
-        slots = None
-    tile_bits = max(1, (n_tiles - 1).bit_length())
+    offsets, payload, flatten_ids, scratch, isect_gid = _carve(
+        dev, (n_tiles + 2, n_isects, n_isects, 2 * n_isects, n_isects if deterministic else 0))
+    cum = None
+    if deterministic:                                         # emission slots index the gradient slab
+        cum = (torch.cumsum(tiles_per_gauss, dim=0, dtype=torch.int64) - tiles_per_gauss).contiguous()
+        out["cum"] = cum
+    else:
+        isect_gid = None
+    check(lib.misplat_bucket_tiles(C.byref(P), ptr(pend["order"]), ptr(pend["rect2"]), ptr(pend["counters"]),
+                                   ptr(pend["tile_count"]), ptr(offsets), ptr(cum), C.c_int64(n_isects), ptr(payload),
+                                   ptr(isect_gid), stream_ptr()), "misplat_bucket_tiles")
     if n_isects > 0:
-        check(lib.misplat_tile_emit_blocks(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss),
-                                           ptr(pend["block_offs"]), ptr(tile_ids), C.c_int32(2 if key16 else 4), ptr(slots),
-                                           ptr(isect_gid), stream_ptr()), "misplat_tile_emit_blocks")
-        if key16:
-            ws_bytes = _sort_ws_bytes(lib, "u16", n_isects, tile_bits)
-            ws = torch.empty(ws_bytes, device=dev, dtype=torch.uint8)
-            check(lib.misplat_sort16_pairs(ptr(ws), C.c_size_t(ws_bytes), ptr(tile_ids), ptr(tile_ids_s),
-                                           ptr(slots if deterministic else isect_gid), ptr(payload_s),
-                                           C.c_int64(n_isects), C.c_int32(tile_bits), stream_ptr()),
-                  "misplat_sort16_pairs")
-        else:
-            _sort32(lib, tile_ids, tile_ids_s, slots if deterministic else isect_gid, payload_s, n_isects, tile_bits,
-                    SORT_BITS_TILE)
-    # n_tiles + 1 "tiles": the extra entry receives n_isects
-    fn = lib.misplat_tile_offsets16 if key16 else lib.misplat_tile_offsets32
-    check(fn(ptr(tile_ids_s), C.c_int64(n_isects), C.c_int32(n_tiles + 1), ptr(offsets), stream_ptr()),
-          "misplat_tile_offsets")
-    if n_isects > 0:
-        # every tile's bucket -> (depth, row) order, one workgroup per tile, in LDS
-        check(lib.misplat_tile_sort(ptr(offsets), C.c_int32(n_tiles), C.c_int64(n_isects), ptr(depths),
-                                    ptr(isect_gid if deterministic else None), ptr(payload_s), ptr(flatten_ids),
-                                    ptr(scratch), C.c_int32(0), stream_ptr()), "misplat_tile_sort")
-    out.update(slots=payload_s if deterministic else None, flatten_ids=flatten_ids, isect_offsets=offsets,
-               tile_ids=None if key16 else tile_ids_s)
+        check(lib.misplat_tile_sort(ptr(offsets), C.c_int32(n_tiles), C.c_int64(n_isects), ptr(depths), ptr(isect_gid),
+                                    ptr(payload), ptr(flatten_ids), ptr(scratch), C.c_int32(3), stream_ptr()),
+              "misplat_tile_sort")
+    out.update(slots=payload if deterministic else None, flatten_ids=flatten_ids, isect_offsets=offsets[:n_tiles + 1])
     return out
+
+
+@torch.no_grad()
+def complete_bins(bins: Dict[str, Tensor]) -> Tensor:
+    """``flatten_ids`` with every tile's list sorted to its end.  After a front-only forward only the head of each list
+    is there (the part the compositing and the backward read); this sorts every bucket in full from ``payload``, which is
+    still a permutation of it -- the heads come out as they were (they are the first entries of the sorted lists), so it may
+    run before or after the backward."""
+    part = bins.get("partial")
+    if part is not None:
+        n_tiles = bins["n_tiles"]
+        if part["cap"] > 0:
+            check(_lib.load().misplat_tile_sort(ptr(part["offsets"]), C.c_int32(n_tiles), C.c_int64(part["cap"]), ptr(bins["depths"]),
+                                                ptr(None), ptr(part["payload"]), ptr(part["flatten_ids"]), ptr(part["scratch"]),
+                                                C.c_int32(3), stream_ptr()), "misplat_tile_sort")
+        bins["partial"] = None
+        PATH_STATS["bins_completed"] += 1
+    return bins["flatten_ids"]
 
 
 @torch.no_grad()
 def isect_ids(bins: Dict[str, Tensor]) -> Tensor:
     """gsplat's ``meta["isect_ids"]``: the sorted 64-bit keys (tile << 32 | depth bits), on demand."""
     lib = _lib.load()
+    complete_bins(bins)
     n = bins["n_isects"]
     out = torch.empty(n, device=bins["flatten_ids"].device, dtype=torch.int64)
     if bins["tile_ids"] is None:                       # no sorted tile-id array exists: rebuild it from the offsets
@@ -606,10 +515,6 @@ def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Par
 FUSED_ENTRY = os.environ.get("MISPLAT_FUSED", "1") == "1"
 SPECULATE = os.environ.get("MISPLAT_SPECULATE", "1") == "1"
 CAP_MARGIN = float(os.environ.get("MISPLAT_CAP_MARGIN", "1.25"))
-# colour kernel beside the bucketing as a parallel graph branch: measured +-1 % at 1 M Gaussians (both branches are
-# latency-bound but share the memory system) and +40 us of host time per launch, so it is off by default
-COLOUR_BRANCH = os.environ.get("MISPLAT_COLOUR_BRANCH", "0") == "1"
-COLOUR_BRANCH_MIN_ROWS = 500_000
 _CAP_HINT: Dict[tuple, int] = {}
 _READBACK: Dict[tuple, Tensor] = {}
 
@@ -690,7 +595,7 @@ def _quantise_cap(x: int) -> int:
 
 
 def fused_entry_ok() -> bool:
-    return FUSED_ENTRY and ORDERING == "cells" and not DETERMINISTIC_BACKWARD and not OVERLAP
+    return FUSED_ENTRY and not DETERMINISTIC_BACKWARD
 
 
 def _dp(t: Optional[Tensor]):
@@ -751,12 +656,19 @@ SPARSE_BWD_MIN_ROWS = 262144        # raster.hip: background_fill_ok
 ROWS_ON_TOUCH = os.environ.get("MISPLAT_ROWS_ON_TOUCH", "1") != "0"
 LAZY_SH = os.environ.get("MISPLAT_LAZY_SH", "auto")
 LAZY_SH_MIN_BUCKET = int(os.environ.get("MISPLAT_LAZY_SH_MIN_BUCKET", "450"))   # measured crossover at 1080p: 391 even, 549 ahead
+# Front-only ordering (csrc/binning.hip, tile_sort_front_kernel): in a dense scene the compositing stops long before the end of
+# a tile's list, so only the part of every bucket in front of the depth the view's LAST visit reached (x a margin; the
+# pivots live in the view-keyed launch-order records) is sorted; a tile whose pixels outlive its sorted part is sorted in
+# full and composited again (exact images either way), and meta["flatten_ids"] / ["isect_ids"] are completed on access.
+# "auto": from a typical bucket of FRONT_MIN_AVG entries (the hint of the previous call of the shape); "1": always; "0": off.
+FRONT_ONLY = os.environ.get("MISPLAT_FRONT_ONLY", "auto")
+FRONT_MIN_AVG = int(os.environ.get("MISPLAT_FRONT_MIN_AVG", "1024"))
+FRONT_MIN_BUCKET = int(os.environ.get("MISPLAT_FRONT_MIN_BUCKET", "256"))
+FRONT_MARGIN = float(os.environ.get("MISPLAT_FRONT_MARGIN", "1.05"))
 
 
 def _lazy_colour_ok(P: Params, dev, deg: int, kd: int, n_color: int, want_grad: bool, cd: int) -> bool:
     if LAZY_SH == "0" or deg < 0 or kd != 16 or n_color != 3 or not want_grad or cd not in (3, 4):
-        return False
-    if _eff_ppl(P.ppl_fwd) != 2 or _eff_ppl(P.ppl_bwd) != 2:
         return False
     if LAZY_SH == "1":
         return True
@@ -804,9 +716,6 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     a.cell_cursor = _dp(cell_cursor)
     a.rect_sorted = _dp(rect_sorted)
     a.n_isects_host = host.data_ptr()
-    # the colour kernel moves into phase B's parallel graph branch -- worth it only for large scenes (a two-branch
-    # graph costs ~40 us more host time per launch; gains ~10 us of GPU time at 1 M Gaussians)
-    a.colour_pending = int(COLOUR_BRANCH and rows >= COLOUR_BRANCH_MIN_ROWS)
     # Gradient rows cleared on first touch (lazy_colour = 2) where the backward is going to read flagged rows only -- the
     # static part of raster.hip's background_fill_ok; the backward checks the actual plan and clears v_grec itself otherwise.
     rows_on_touch = bool(lazy and want_grad and flags and Cn == 1 and N >= SPARSE_BWD_MIN_ROWS and not want_aux and kd == 16
@@ -852,7 +761,15 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         raise _lib.MisplatError(f"{cap} tile intersections exceed int32 indexing")
     render, alpha, exp_depth, med_depth, normal = _carve_f(dev, (cd * n_pix, n_pix, n_pix, n_pix, 3 * n_pix))
     sched = _UnitSchedule(P, dev, by_view=state.get("order"))
-    last_ids, median_ids, offsets = _carve(dev, (n_pix, n_pix, n_tiles + 2))
+    by_view = sched.on and sched.by_view is not None
+    front = bool(by_view and not static and hint is not None and FRONT_ONLY != "0"
+                 and (FRONT_ONLY == "1" or hint >= FRONT_MIN_AVG * n_tiles))
+    last_ids, median_ids, offsets, reach, front_n, tile_flag = _carve(
+        dev, (n_pix, n_pix, n_tiles + 2, n_tiles * BANDS if by_view else 0, n_tiles if front else 0, n_tiles if front else 0))
+    a.unit_reach = _dp(reach) if by_view else None
+    a.front_n, a.tile_flag = (_dp(front_n), _dp(tile_flag)) if front else (None, None)
+    a.front_margin, a.front_min_bucket = FRONT_MARGIN, FRONT_MIN_BUCKET
+    PATH_STATS["forward_front_only"] += int(front)
 
     def isect_buffers(c):
         return _carve(dev, (c, c, 2 * c))
@@ -896,7 +813,6 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
             break
         cap = n_known                                                 # the guess was too small: exact size, once more
         PATH_STATS["capacity_redo"] += 1
-        a.colour_pending = 0                                          # (the colours were written by the first attempt)
         tc = state["keep"][6]                                         # tile_count: phase B expects it cleared
         check(lib.misplat_zero_bytes(ptr(tc), C.c_size_t(4 * tc.numel()), stream_ptr()), "misplat_zero_bytes")
         if cap >= 2 ** 31:
@@ -910,13 +826,16 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         _CAP_HINT[key] = max(n_known, int(0.999 * _CAP_HINT.get(key, 0)))
     if sched.on and sched.by_view is None:
         _LAST_ORDER[sched.key] = sched.perm
-        if sched.ppl_b == sched.ppl_f:
-            sched.perm_bwd = sched.perm
+        sched.perm_bwd = sched.perm
     bins = dict(tiles_per_gauss=state["tiles_per_gauss"], n_isects=cap if static else n_known, depths=state["depths"],
                 tile_ids=None, v_grec_zero=state.get("v_grec_zero"), v_abs_zero=state.get("v_abs_zero"),
                 rows_on_touch=bool(state.get("rows_on_touch")), n_isects_dev=state["counters"].view(torch.int64)[0] if static else None,
                 n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:cap if static else n_known],
-                isect_offsets=offsets[:n_tiles + 1], _keep=(scratch, payload))
+                isect_offsets=offsets[:n_tiles + 1], _keep=(scratch, payload, reach),
+                # front-only ordering: flatten_ids holds the sorted head of every list (all the compositing and the
+                # backward read); complete_bins() sorts the rest when someone wants the whole lists
+                partial=(dict(cap=cap, offsets=offsets, payload=payload, scratch=scratch, flatten_ids=flatten_ids,
+                              front_n=front_n, tile_flag=tile_flag) if front else None))
     imgs = (render.view(Cn, H, W, cd), alpha.view(Cn, H, W, 1), exp_depth.view(Cn, H, W, 1), med_depth.view(Cn, H, W, 1),
             normal.view(Cn, H, W, 3), last_ids.view(Cn, H, W), median_ids.view(Cn, H, W))
     return imgs, bins, sched
@@ -1182,24 +1101,15 @@ class _ProjectPack(torch.autograd.Function):
               "misplat_project_pack_fwd")
         if prebin is not None:                         # count tiles + start the n_isects read-back before the colours
             prebin["pending"] = start_binning(P, means2d, radii)
-        # the colour slots of grec are only needed by the compositing kernels: launch on the side
-        # stream so the kernel overlaps the binning chain; blend_packed() joins it
-        cur = torch.cuda.current_stream()
-        side = _side_stream(dev) if OVERLAP else cur
-        if side is not cur:
-            side.wait_stream(cur)
-            for t in (grec, means, viewmats, colors, radii, depths):
-                t.record_stream(side)
         # SH + a backward to come: keep d rgb / d dir (48 B per (camera, Gaussian)) so that the backward does not
         # read the coefficients (192 B at degree 3) again
         sh_aux = None
         if SH_AUX and deg >= 0 and any(ctx.needs_input_grad[:6]):
             sh_aux = torch.empty(Cn * N, 12, device=dev, dtype=torch.float32)
-        with torch.cuda.stream(side):
-            check(lib.misplat_color_fwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
-                                        C.c_int32(per_cam), C.c_int32(int(depth_channel)), ptr(means), ptr(viewmats),
-                                        ptr(colors), ptr(colors_rest), ptr(radii), ptr(depths), ptr(grec), ptr(sh_aux),
-                                        ptr(None), stream_ptr()), "misplat_color_fwd")
+        check(lib.misplat_color_fwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
+                                    C.c_int32(per_cam), C.c_int32(int(depth_channel)), ptr(means), ptr(viewmats),
+                                    ptr(colors), ptr(colors_rest), ptr(radii), ptr(depths), ptr(grec), ptr(sh_aux),
+                                    ptr(None), stream_ptr()), "misplat_color_fwd")
         ctx.P, ctx.color_args = P, (deg, kd, n_color, per_cam)
         ctx.depth_slot = 12 + n_color if depth_channel else -1
         ctx.has_rest = colors_rest is not None
@@ -1225,32 +1135,19 @@ class _ProjectPack(torch.autograd.Function):
         v_colors = _grad_out(colors)
         v_colors_rest = _grad_out(colors_rest) if colors_rest is not None else None
         v_means_dir = torch.empty_like(means) if deg >= 0 else None
-        cur = torch.cuda.current_stream()
-        side = _side_stream(means.device) if OVERLAP else cur
-        if side is not cur:
-            side.wait_stream(cur)
-            for t in (v_grec, v_colors, v_colors_rest, v_means_dir, means, viewmats, colors, colors_rest, radii):
-                if t is not None:
-                    t.record_stream(side)
-        with torch.cuda.stream(side):
-            check(lib.misplat_color_bwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
-                                        C.c_int32(per_cam), ptr(means), ptr(viewmats), ptr(colors), ptr(colors_rest),
-                                        ptr(radii), ptr(v_grec), ptr(v_colors), ptr(v_colors_rest), ptr(v_means_dir),
-                                        ptr(sh_aux), stream_ptr()), "misplat_color_bwd")
-        if GRAD_SINK is not None and side is cur:
+        check(lib.misplat_color_bwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
+                                    C.c_int32(per_cam), ptr(means), ptr(viewmats), ptr(colors), ptr(colors_rest),
+                                    ptr(radii), ptr(v_grec), ptr(v_colors), ptr(v_colors_rest), ptr(v_means_dir),
+                                    ptr(sh_aux), stream_ptr()), "misplat_color_bwd")
+        if GRAD_SINK is not None:
             GRAD_SINK.colour_ready()                   # the colour bucket's all-reduce starts now, overlapped with the rest
         v_means, v_quats = _grad_out(means), _grad_out(quats)
         v_scales, v_opac = _grad_out(scales), _grad_out(opacities)
-        fused_dir = v_means_dir if side is cur else None        # overlapped: add the SH direction term afterwards
         check(lib.misplat_project_pack_bwd(C.byref(P), C.c_int32(ctx.depth_slot), ptr(means), ptr(quats),
                                            ptr(scales), ptr(opacities), ptr(viewmats), ptr(Ks), ptr(radii),
-                                           ptr(comps), ptr(v_means2d), ptr(v_grec), ptr(fused_dir), ptr(v_means),
+                                           ptr(comps), ptr(v_means2d), ptr(v_grec), ptr(v_means_dir), ptr(v_means),
                                            ptr(v_quats), ptr(v_scales), ptr(v_opac), None, C.c_int32(0), stream_ptr()),
               "misplat_project_pack_bwd")
-        if side is not cur:
-            cur.wait_stream(side)
-            if v_means_dir is not None:
-                v_means.add_(v_means_dir)
         return v_means, v_quats, v_scales, v_opac, v_colors, v_colors_rest, None, None, None, None, None, None
 
 
@@ -1376,8 +1273,6 @@ def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
 def blend_packed(means2d, grec, Ks, P: Params, bins, absgrad: bool, cd: int):
     if not 1 <= cd <= 4:
         raise ValueError("blend_packed() takes 1..4 colour channels")
-    if OVERLAP:
-        torch.cuda.current_stream().wait_stream(_side_stream(grec.device))   # colour slots of grec
     return _BlendPacked.apply(means2d, grec, _f32(Ks, "Ks"), P, bins, bool(absgrad), int(cd))
 
 

@@ -29,6 +29,9 @@ class _Meta(dict):
         if key == "isect_ids":
             self[key] = ops.isect_ids(self["_bins"])
             return self[key]
+        if key == "flatten_ids":                       # (absent after a front-only forward: only the heads are sorted)
+            self[key] = ops.complete_bins(self["_bins"])
+            return self[key]
         raise KeyError(key)
 
 
@@ -210,11 +213,12 @@ def rasterization(
         "radii": radii, "means2d": means2d, "depths": depths, "conics": conics, "opacities": opac,
         "compensations": comps, "ray_ts": ray_ts, "ray_planes": ray_planes, "normals": normals,
         "tile_width": P.tile_w, "tile_height": P.tile_h, "tiles_per_gauss": bins["tiles_per_gauss"].view(Cn, N),
-        "flatten_ids": bins["flatten_ids"],
         "isect_offsets": bins["isect_offsets"][:-1].view(Cn, P.tile_h, P.tile_w),
         "n_isects": bins["n_isects"] if bins.get("n_isects_dev") is None else bins["n_isects_dev"], "last_ids": first[5], "median_ids": first[6],
         "width": width, "height": height, "tile_size": tile_size, "n_cameras": Cn,
     })
+    if bins.get("partial") is None:
+        meta["flatten_ids"] = bins["flatten_ids"]      # (else completed on first access: _Meta.__missing__)
     if return_depth_normal:
         return render, alpha, exp_depth, med_depth, exp_normal, meta
     return render, alpha, meta

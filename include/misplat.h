@@ -41,6 +41,7 @@ typedef struct ihipStream_t* misplat_stream_t; /* == hipStream_t */
 
 #define MISPLAT_TILE 16          /* pixels per tile side (gsplat default tile_size)          */
 #define MISPLAT_REC 16           /* floats per packed Gaussian record / per gradient row      */
+#define MISPLAT_BANDS 2          /* wavefronts (bands of 16 x 8 pixels) that composite one tile */
 
 /* Scalar configuration of one call (host memory, passed by pointer, copied at launch). */
 typedef struct misplat_params {
@@ -62,14 +63,12 @@ typedef struct misplat_params {
     float median_t;       /* 0.5 */
     float jacobian_margin;/* 0.3 */
     float plane_eps;      /* 1e-6 */
-    int32_t ppl_fwd;      /* pixels per lane of the compositing kernels: 1, 2 or 4 (0 = default); */
-    int32_t ppl_bwd;      /* a tile is covered by 4/ppl independent wavefronts ("bands")          */
     int32_t ed_slot;      /* colour channel (0..3) the compositing kernels divide by max(alpha,1e-10)
                              (the "ED" of render_mode RGB+ED / ED, rade_gs_model.py:237), or -1     */
-    int32_t sub_blocks;   /* atomic backward, ppl_bwd 2, <= 4 channels: 4 = split every band into four 8x4 sub-blocks
-                             with their own culled lists (fewer idle pixel slots); 0 / 1 = one list per band        */
-    /* Launch order of the compositing kernels (speed only; results never depend on it).  A "unit" is one band of
-     * one tile: unit = tile * (4 / ppl) + band.  unit_work (or NULL): the forward writes the number of staged
+    int32_t reserved_q;
+    /* Launch order of the compositing kernels (speed only; results never depend on it).  A tile is covered by
+     * MISPLAT_BANDS independent wavefronts ("bands" of 16 x 8 pixels, two pixels per lane); a "unit" is one band of
+     * one tile: unit = tile * MISPLAT_BANDS + band.  unit_work (or NULL): the forward writes the number of staged
      * Gaussians each unit composited -- its measured cost; unit_perm (or NULL): workgroup b of a compositing launch
      * processes unit unit_perm[b] instead of the default XCD-strip map (misplat_unit_order builds it, longest first). */
     const int32_t* unit_perm;
@@ -94,7 +93,18 @@ typedef struct misplat_params {
     int32_t unit_stride;     /* see unit_sel */
     const int32_t* unit_sel; /* or NULL */
     int32_t unit_slots;      /* records in the table: a selector outside [0, unit_slots) counts as "no record" */
-    int32_t reserved_p;
+    int32_t front_pass;      /* see front_n */
+    /* Front-only ordering (set by misplat_raster_fwd for its compositing forward; NULL / 0 everywhere else -- the
+     * backward never reads behind the entries the forward used).  unit_reach (or NULL) [units]: the forward writes the
+     * DEPTH of the deepest list entry each unit looked at (front_depths[row]; +inf: pixels were still alive at the end of
+     * its list, 0: nothing looked at) -- the pivot of the view's next visit.  front_n (or NULL) [C*tiles]: >= 0 -- only
+     * that many entries at the head of the tile's list exist (the sorted front part, misplat_raster_args.front_n); a unit
+     * that reaches their end with pixels alive sets tile_flag[tile].  front_pass 1: the launch composites the flagged
+     * tiles only, over their whole (by then fully sorted) lists. */
+    const int32_t* front_n;
+    int32_t* tile_flag;
+    float* unit_reach;
+    const float* front_depths;
 } misplat_params;
 
 /* ---- a2.1 projection: fully_fused_projection(means, None, quats, scales, viewmats, Ks, W, H, ...)
@@ -184,65 +194,28 @@ int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_slot, const 
                              int32_t v_depth_stride, misplat_stream_t stream);
 
 /* ---- a2.3 binning: for every tile the Gaussian rows whose rectangle mean2d +- radii touches it, in
- * (depth, row) order -- the order of gsplat's 64-bit (tile | depth) key sort, without the keys.  Two routes to the
- * per-tile buckets: the cell-ordered bucketing (bucket_*, the default, below) or (tile, row) pairs emitted in row
- * order and stably radix-sorted on the tile bits (tile_count_blocks / tile_emit_blocks / sort16|32_pairs /
- * tile_offsets16|32; the round-1 path, kept as an alternative); then misplat_tile_sort orders every bucket by depth.
- * offsets arrays have C*tiles + 1 entries: the last one is the number of intersections. */
-size_t misplat_sort32_workspace_bytes(int64_t n, int32_t end_bit);
-/* Stable ascending radix sort (rocPRIM) of (key, value) pairs on key bits [0, end_bit). */
-int misplat_sort32_pairs(void* workspace, size_t workspace_bytes, const uint32_t* keys_in,
-                         uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
-                         int32_t end_bit, misplat_stream_t stream);
-/* offsets[t] = first sorted position whose tile id is >= t, t < n_tiles_total; pass C*tiles + 1 so that the
- * extra entry receives n_isects. */
-int misplat_tile_offsets32(const uint32_t* tiles_sorted, int64_t n_isects, int32_t n_tiles_total,
-                           int32_t* offsets, misplat_stream_t stream);
+ * (depth, row) order -- the order of gsplat's 64-bit (tile | depth) key sort, without the keys: the cell-ordered
+ * bucketing (bucket_*, below) fills every tile's bucket in arbitrary order, then misplat_tile_sort orders every bucket by
+ * (depth, row).  offsets arrays have C*tiles + 1 entries: the last one is the number of intersections. */
 /* gsplat's meta["isect_ids"] on demand: (tile << 32) | bits(depth[flatten_ids[i]]). */
 int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* flatten_ids, const float* depths,
                       int64_t n_isects, uint64_t* isect_ids, misplat_stream_t stream);
 
-/* Per-tile ordering: once the intersections have been bucketed by tile, one workgroup per tile sorts
- * its bucket by the 32 depth bits with a stable LSD radix sort whose entries stay in registers (exchange
- * through LDS), which is exactly the (tile, depth, id) order -- no global depth sort at all.
- *   unordered = 0: every bucket arrives in ascending row order (stable sort16/sort32_pairs on the tile bits
- *                  of pairs emitted in row order: ordering "pertile");
- *   unordered = 1: buckets arrive in arbitrary order (misplat_bucket_tiles, ordering "cells", the default);
- *                  buckets with equal depths are re-sorted by (row, then depth).
+/* Per-tile ordering: once the intersections have been bucketed by tile, one workgroup per tile sorts its bucket --
+ * entries in registers, exchange through LDS: one counting pass on the bucket's own depth range + ranking inside the
+ * bins, or stable LSD radix passes -- into the (depth, row) order, equal depths included: exactly the (tile, depth, id)
+ * order of a global 64-bit key sort, without one.  Buckets arrive in arbitrary order (misplat_bucket_tiles).
  * offsets: n_tiles_total + 1 entries; n_isects: the number of intersections or an upper bound of it (only used to
  * size the grids of the size classes); payload (in/out): rows, or emission slots when isect_gid != NULL
  * (row = isect_gid[slot]); flatten_ids (out): rows in final order; scratch[2 * n_isects] backs the rare tiles
  * longer than 8192 entries. */
 int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
                       const float* depths, const int32_t* isect_gid, int32_t* payload,
-                      int32_t* flatten_ids, uint32_t* scratch, int32_t flags /* bit 0: unordered; bit 1:
+                      int32_t* flatten_ids, uint32_t* scratch, int32_t flags /* bit 1:
                       offsets[n_tiles_total + 1] holds the longest bucket (misplat_bucket_tiles writes it), so the
                       launches of unused size classes return at once */, misplat_stream_t stream);
 
-/* Row-order emission without a global scan array (ordering "pertile"; replaces gsplat's cumsum between
- * its projection and isect_tiles): rows are cut into blocks of MISPLAT_COUNT_BLOCK.
- *   tile_count_blocks  tiles_per_gauss[C*N], block_sums[n_blocks] (scratch), block_offs[n_blocks] = exclusive
- *                      int64 scan of the block sums, *n_isects = grand total (device; the host reads it);
- *   tile_emit_blocks   (tile id, row) pairs in row order: row r of block b starts at
- *                      block_offs[b] + (sum of tiles_per_gauss over the rows of b before r).
- * n_blocks = ceil(C*N / MISPLAT_COUNT_BLOCK). */
-#define MISPLAT_COUNT_BLOCK 256
-int misplat_tile_count_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
-                              int32_t* tiles_per_gauss, int32_t* block_sums, int64_t* block_offs,
-                              int64_t* n_isects, misplat_stream_t stream);
-int misplat_tile_emit_blocks(const misplat_params* p, const float* means2d, const int32_t* radii,
-                             const int32_t* tiles_per_gauss, const int64_t* block_offs, void* tile_ids,
-                             int32_t key_bytes, int32_t* slot_ids, int32_t* isect_gid, misplat_stream_t stream);
-/* key_bytes = 2: uint16 tile keys (C * tiles <= 65536), sorted with sort16_pairs and scanned with
- * tile_offsets16 -- 12 instead of 16 bytes of traffic per pair and radix pass; key_bytes = 4: uint32. */
-size_t misplat_sort16_workspace_bytes(int64_t n, int32_t end_bit);
-int misplat_sort16_pairs(void* workspace, size_t workspace_bytes, const uint16_t* keys_in,
-                         uint16_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
-                         int32_t end_bit, misplat_stream_t stream);
-int misplat_tile_offsets16(const uint16_t* tiles_sorted, int64_t n_isects, int32_t n_tiles_total,
-                           int32_t* offsets, misplat_stream_t stream);
-
-/* ---- Cell-ordered bucketing (ordering "cells", the default; csrc/bucket.hip).  Replaces gsplat's isect_tiles +
+/* ---- Cell-ordered bucketing (csrc/bucket.hip).  Replaces gsplat's isect_tiles +
  * radix sort + isect_offset_encode: every intersection is written once (its row) and no tile-id array exists.
  *   bucket_plan   (host only) number of screen cells and of counting workgroups for this configuration:
  *                 cellhist holds n_blocks * n_cells uint32, cell_count n_cells, cell_offs n_cells + 1;
@@ -259,7 +232,7 @@ int misplat_tile_offsets16(const uint16_t* tiles_sorted, int64_t n_isects, int32
  *                 offsets[0 .. n_tiles + 1] (offsets[n_tiles] = number of intersections, offsets[n_tiles + 1] = the
  *                 longest bucket: n_tiles + 2 entries) and
  *                 payload[offsets[t] .. offsets[t + 1]) = the rows touching tile t, in arbitrary order
- *                 (misplat_tile_sort(unordered = 1) follows).  cum != NULL (deterministic backward): the payload
+ *                 (misplat_tile_sort follows).  cum != NULL (deterministic backward): the payload
  *                 is the emission slot cum[row] + k and isect_gid[slot] = row.  Writes beyond cap_isects entries
  *                 are dropped: the caller compares counters[0] with cap_isects afterwards.
  * Nothing here needs a host read-back: all sizes live in `counters` on the device. */
@@ -279,18 +252,6 @@ int misplat_bucket_tiles(const misplat_params* p, const int32_t* order, const ui
                          const int64_t* counters, int32_t* tile_count, int32_t* offsets, const int64_t* cum,
                          int64_t cap_isects, int32_t* payload, int32_t* isect_gid, misplat_stream_t stream);
 
-/* Hand-written stable LSD radix sort of (uint32 key, int32 value) pairs on key bits
- * [begin_bit, end_bit), bits_per_pass (1..11) bits per pass, three launches per pass, no
- * inter-workgroup waiting (csrc/sort.hip).  keys_in / vals_in are not modified; the result is in
- * keys_out / vals_out; workspace holds one ping-pong pair and the per-chunk digit counts.
- * Precondition: a pass is at least 2 bits wide, so when (end_bit - begin_bit) leaves a last pass of 1 bit that pass
- * also looks at bit `end_bit`: the key bits at and above end_bit must be zero (they are for tile ids). */
-size_t misplat_radix_workspace_bytes(int64_t n, int32_t begin_bit, int32_t end_bit, int32_t bits_per_pass);
-int misplat_radix_sort_pairs(void* workspace, size_t workspace_bytes, const uint32_t* keys_in,
-                             uint32_t* keys_out, const int32_t* vals_in, int32_t* vals_out, int64_t n,
-                             int32_t begin_bit, int32_t end_bit, int32_t bits_per_pass,
-                             misplat_stream_t stream);
-
 /* ---- a2.4 / a2.5 compositing.  Packed record per (camera, Gaussian), MISPLAT_REC floats:
  *   [0:2] mean2d  [2:5] conic  [5] opacity_eff  [6] ray_t  [7:9] ray_plane  [9:12] normal
  *   [12:16] colour channels 0..3 (unused channels zero).                         */
@@ -298,7 +259,7 @@ int misplat_pack(int64_t n_rows, int32_t color_dim, const float* means2d, const 
                  const float* opacities_eff, const float* ray_ts, const float* ray_planes,
                  const float* normals, const float* colors, float* grec, misplat_stream_t stream);
 
-/* Forward: one wavefront per band of 16 x (4*ppl) pixels of a tile (ppl pixels per lane).
+/* Forward: one wavefront per band of 16 x 8 pixels of a tile (two pixels per lane).
  * offsets: C*tiles + 1 entries (tile t owns flatten_ids[offsets[t] .. offsets[t+1])); n_isects: the number of
  * intersections or an upper bound (the backward's slab stride).
  * Outputs [C,H,W,...]: render[.,color_dim], alpha[.], exp_depth[.] (sum w*z, un-normalised),
@@ -312,7 +273,7 @@ int misplat_blend_fwd(const misplat_params* p, int32_t color_dim, const float* K
 /* The same forward with ON-DEMAND SH colours: the colour slots of grec hold the "unset" pattern left by
  * misplat_project_pack_fwd(lazy_rows != NULL) and are filled here (grec is read AND written) for the records that are
  * staged past their cull -- in a dense scene most visible Gaussians never are.  16 coefficients per Gaussian: coeffs
- * [N,16,3], or features_dc [N,3] + coeffs_rest [N,15,3].  pixels-per-lane 2 only. */
+ * [N,16,3], or features_dc [N,3] + coeffs_rest [N,15,3]. */
 int misplat_blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const float* Ks, float* grec,
                            const int32_t* flatten_ids, const int32_t* offsets, int64_t n_isects, float* render,
                            float* alpha, float* exp_depth, float* med_depth, float* normal, int32_t* last_ids,
@@ -323,10 +284,10 @@ int misplat_blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const flo
 
 /* Launch order for the compositing kernels (speed only): unit_perm[8 * ceil(units / 8)] from the per-unit cost
  * unit_work[units] the forward measured (misplat_params.unit_work), longest first inside every XCD strip;
- * units = C * tiles * (4 / ppl), ppl = pixels per lane of the launch that will use it (0 = default).  Padding
- * entries hold `units` (no unit).  Pass the result as misplat_params.unit_perm to any later compositing launch of
- * the same ppl -- the backward of the same step, or the next forward of the same view. */
-int misplat_unit_order(const misplat_params* p, int32_t ppl, const int32_t* unit_work, int32_t* unit_perm,
+ * units = C * tiles * MISPLAT_BANDS.  Padding entries hold `units` (no unit).  Pass the result as
+ * misplat_params.unit_perm to any later compositing launch -- the backward of the same step, or the next forward of the
+ * same view. */
+int misplat_unit_order(const misplat_params* p, const int32_t* unit_work, int32_t* unit_perm,
                        misplat_stream_t stream);
 
 /* Number of gradient planes (= bands per tile) the backward of this configuration writes. */
@@ -462,7 +423,7 @@ int misplat_ssim_bwd(int32_t height, int32_t width, const float* rgb, const floa
  * Every pointer is a caller-allocated device buffer of the size the per-stage entry points above document
  * (n_isects_host: 8 bytes of PINNED host memory).
  *   phases & 1 (A): project_pack_fwd, bucket_count, bucket_rows (which stores counters[0] into *n_isects_host), color_fwd
- *   phases & 2 (B): [color_fwd, if colour_pending] || bucket_tiles, tile_sort (unordered); blend_fwd (+ unit_work), unit_order
+ *   phases & 2 (B): bucket_tiles, tile_sort; blend_fwd (+ unit_work), unit_order
  * B only reads device-side sizes, so it may be enqueued with a speculative cap_isects before the host knows the count:
  * the result is exact iff the count (misplat_wait_count) is <= cap_isects (else: clear tile_count and call B again
  * with the exact size).  Atomic gradient mode only (the deterministic slab needs the emission-slot scan between A and B). */
@@ -472,10 +433,8 @@ typedef struct misplat_raster_args {
     int32_t sh_degree;      /* -1: pass-through colours */
     int32_t K_or_D, n_color, per_cam, depth_channel;
     int32_t color_dim;      /* channels the compositing kernels carry (1..4) */
-    int32_t colour_pending; /* != 0: the colour kernel is left out of phase A and runs at the start of phase B instead
-                               (nothing before the compositing reads it) -- beside the bucketing kernels when the call
-                               goes through a graph cache (two parallel branches) */
-    int32_t lazy_colour;    /* != 0 (SH colours with K = 16, one pass, ppl 2/2 only): no colour kernel -- the compositing
+    int32_t reserved_c;
+    int32_t lazy_colour;    /* != 0 (SH colours with K = 16, one pass): no colour kernel -- the compositing
                                forward evaluates the colour of a record when it first stages it (misplat_blend_fwd_lazy);
                                sh_aux is not written.  2: in addition v_grec_zero is NOT cleared as a whole -- only the
                                rows of the records whose colour gets set, which are the only rows the compositing backward
@@ -513,6 +472,19 @@ typedef struct misplat_raster_args {
      * unit_perm_in / unit_perm_out are ignored then; unit_work is still needed. */
     int32_t *order_table, *order_sel;
     int32_t order_slots, order_stride;
+    /* Front-only ordering for dense scenes (needs the view-keyed table; csrc/binning.hip).  unit_reach (or NULL) [units]:
+     * the compositing forward's reach per unit; the order kernel turns it into per-tile depth pivots stored behind the
+     * permutation of the view's record (order_stride >= MISPLAT_ORDER_HEADER + 8 * ceil(units / 8) + C * tiles).
+     * front_n / tile_flag (both or neither) [C*tiles]: with them, phase B sorts only the part of every bucket at or in
+     * front of front_margin x the pivot of the view's last visit (buckets of >= front_min_bucket entries; everything else,
+     * and every tile of a view without a record, is sorted in full), composites, sorts the tiles whose pixels were still
+     * alive at the end of their truncated list in full and composites those again: exact images either way.  flatten_ids
+     * is then complete only for the tiles with front_n < 0 or tile_flag != 0; misplat_tile_sort over `payload` (which stays
+     * a permutation of every bucket) completes it. */
+    float* unit_reach;
+    int32_t *front_n, *tile_flag;
+    float front_margin;
+    int32_t front_min_bucket;
 } misplat_raster_args;
 /* Graph cache (optional, caller-owned, thread-safe; the library itself keeps no state): with a cache, the launch
  * sequence of a call is captured into a hipGraph the first time a given (params, args, phases, stream) block is seen

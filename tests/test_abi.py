@@ -74,14 +74,6 @@ def test_raster_args_struct_layout_matches_c(built_lib, cname, pyname):
     assert vals[1:] == [getattr(RasterArgs, f).offset for f in fields]
 
 
-@pytest.mark.gpu
-def test_sort_workspace_query(built_lib):
-    from collab_splats_amd import _lib
-    lib = _lib.load()
-    n = lib.misplat_sort32_workspace_bytes(C.c_int64(1 << 20), C.c_int32(13))
-    assert n >= 16                      # rocPRIM's temporary storage for 1 M (u32, i32) pairs
-
-
 def test_no_cpu_fallback():
     import collab_splats_amd as m
     z = torch.zeros
