@@ -57,7 +57,7 @@ class RasterArgs(C.Structure):
                                              "unit_perm_out", "ev_blend_begin", "ev_blend_end", "order_table", "order_sel")]
                 + [("order_slots", C.c_int32), ("order_stride", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("unit_reach", "front_n", "tile_flag")]
-                + [("front_margin", C.c_float), ("front_min_bucket", C.c_int32)])
+                + [("front_margin", C.c_float), ("front_min_bucket", C.c_int32), ("depth_sorted", C.c_void_p)])
 
 
 class RasterBwdArgs(C.Structure):

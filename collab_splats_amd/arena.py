@@ -1,0 +1,162 @@
+"""Per-call device buffers from a small ring of persistent arenas (plumbing; no kernels here).
+
+One ``rasterization()`` call needs ~25 scratch / output arrays (packed records, bucketing workspace, images, per-tile lists).
+Taken from PyTorch's caching allocator they land wherever it has room: the launch arguments of two identical steps then
+differ in a dozen pointers (a hipGraph captured for one step is useless for the next: DESIGN.md section 8), and the 64-byte
+record gathers of the compositing kernels run 10 - 15 % slower in some placements than in others (section 13.7).  So the
+arrays of a call are carved from ONE persistent slot of a ring kept per (device, stream, shape): the same call gets the same
+addresses every time, every array of >= 1 MiB starts on a 2 MiB boundary of a 2 MiB-aligned slot.
+
+Ownership: the tensors handed out are views of the slot's storage, and a slot is handed out again only when NOTHING refers to
+its storage any more (``torch._C._storage_Use_Count``: outputs the caller still holds, tensors saved for a backward that has not
+run, a ``meta`` dict kept for later all count) -- a call that finds every slot of its ring in use gets a new slot (up to
+``MAX_SLOTS``) or plain allocator memory.  Reuse needs no event: a ring belongs to one stream, and later work on a stream is
+ordered behind earlier work on it, exactly the rule by which the caching allocator itself hands a freed block out again.
+"""
+from __future__ import annotations
+
+import collections
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import Tensor
+
+ENABLED = os.environ.get("MISPLAT_ARENA", "1") == "1"
+MAX_SLOTS = int(os.environ.get("MISPLAT_ARENA_SLOTS", "4"))
+MAX_RINGS = int(os.environ.get("MISPLAT_ARENA_RINGS", "12"))      # distinct (stream, shape, role) keys kept; LRU beyond
+BIG = 1 << 20                     # arrays from this size on start on a 2 MiB boundary
+ALIGN_BIG = 2 << 20
+ALIGN_SMALL = 256
+STATS: "collections.Counter" = collections.Counter()             # slots_created / slot_hits / fallbacks / regrown
+
+_use_count = getattr(torch._C, "_storage_Use_Count", None)
+_ESIZE = {torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8, torch.int16: 2, torch.float64: 8}
+
+
+class Slot:
+    """One arena: a 2 MiB-aligned byte range carved front to back by ``take``; ``demand`` records what a call wanted."""
+
+    def __init__(self, dev: torch.device, nbytes: int):
+        self.size = int(nbytes)
+        self.raw = torch.empty(self.size + ALIGN_BIG, device=dev, dtype=torch.uint8)
+        shift = (-self.raw.data_ptr()) % ALIGN_BIG
+        self.base = self.raw[shift:shift + self.size]
+        self.storage = self.raw.untyped_storage()                 # (kept: the use count below then has a fixed floor)
+        self.floor = self._count()                                # raw + base + the storage wrapper
+        self.off = 0
+        self.demand = 0
+
+    def _count(self) -> int:
+        return int(_use_count(self.storage._cdata))
+
+    def free(self) -> bool:
+        return self._count() <= self.floor
+
+    def begin(self) -> None:
+        self.off = 0
+        self.demand = 0
+
+    def take(self, count: int, dtype: torch.dtype) -> Optional[Tensor]:
+        """``count`` elements of ``dtype`` from the slot, or None when it is full (the caller then asks the allocator)."""
+        nbytes = int(count) * _ESIZE[dtype]
+        align = ALIGN_BIG if nbytes >= BIG else ALIGN_SMALL
+        start = (self.off + align - 1) // align * align
+        self.demand = start + nbytes                                        # (what a slot must hold to serve this call)
+        if start + nbytes > self.size:
+            self.off = start + nbytes                                       # keep counting: the demand of the whole call
+            return None
+        self.off = start + nbytes
+        return self.base[start:start + nbytes].view(dtype)
+
+
+class Ring:
+    def __init__(self, dev: torch.device):
+        self.dev = dev
+        self.slots: List[Slot] = []
+        self.want = 0                                             # bytes the largest call so far asked for
+
+    def acquire(self) -> Optional[Slot]:
+        """A slot nothing refers to (regrown first if the last call did not fit), a new one, or None."""
+        for i, s in enumerate(self.slots):
+            if not s.free():
+                continue
+            if s.size < self.want:                                # the shape's demand grew (a larger capacity class)
+                self.slots[i] = s = Slot(self.dev, self._padded(self.want))
+                STATS["regrown"] += 1
+            else:
+                STATS["slot_hits"] += 1
+            s.begin()
+            return s
+        if self.want > 0 and len(self.slots) < MAX_SLOTS:
+            s = Slot(self.dev, self._padded(self.want))
+            self.slots.append(s)
+            STATS["slots_created"] += 1
+            s.begin()
+            return s
+        return None
+
+    @staticmethod
+    def _padded(n: int) -> int:
+        return (int(n * 1.10) + ALIGN_BIG - 1) // ALIGN_BIG * ALIGN_BIG   # head room: capacities drift by a few percent
+
+    def release(self, slot: Optional[Slot], demand: int) -> None:
+        """What the call asked for in total (also when it had no slot): the next slot of this ring is sized for it."""
+        self.want = max(self.want, int(demand))
+
+
+_RINGS: "collections.OrderedDict[tuple, Ring]" = collections.OrderedDict()
+
+
+def ring(key: tuple, dev: torch.device) -> Optional[Ring]:
+    """The ring of this key (LRU over ``MAX_RINGS`` keys), or None when arenas are off or a graph is being captured (memory
+    allocated during a capture belongs to that graph's private pool and must not outlive it in a ring)."""
+    if not ENABLED or _use_count is None or torch.cuda.is_current_stream_capturing():
+        return None
+    r = _RINGS.get(key)
+    if r is None:
+        r = _RINGS[key] = Ring(dev)
+        while len(_RINGS) > MAX_RINGS:
+            _RINGS.popitem(last=False)                            # (its slots live on while views of them do)
+    else:
+        _RINGS.move_to_end(key)
+    return r
+
+
+class Carver:
+    """The allocations of one call: from a ring slot where one is free and large enough, from the allocator otherwise.
+    ``done()`` tells the ring how much the call wanted, so that the next call of the shape finds a slot that fits."""
+
+    def __init__(self, key: tuple, dev: torch.device):
+        self.dev = dev
+        self.ring = ring(key, dev)
+        self.slot = self.ring.acquire() if self.ring is not None else None
+        self.shadow = 0                                           # demand counted when there is no slot
+
+    def take(self, count: int, dtype: torch.dtype) -> Tensor:
+        count = int(count)
+        if self.slot is not None:
+            t = self.slot.take(count, dtype)
+            if t is not None:
+                return t
+            STATS["fallbacks"] += 1
+        elif self.ring is not None:
+            nbytes = count * _ESIZE[dtype]
+            align = ALIGN_BIG if nbytes >= BIG else ALIGN_SMALL
+            self.shadow = (self.shadow + align - 1) // align * align + nbytes
+        return torch.empty(max(count, 0), device=self.dev, dtype=dtype)
+
+    def carve(self, sizes: Sequence[int], dtype: torch.dtype) -> list:
+        return [self.take(n, dtype) for n in sizes]
+
+    def done(self) -> None:
+        if self.ring is not None:
+            self.ring.release(self.slot, self.slot.demand if self.slot is not None else self.shadow)
+
+    @property
+    def slot_id(self) -> int:
+        return -1 if self.slot is None else self.ring.slots.index(self.slot)
+
+
+def reset() -> None:
+    _RINGS.clear()

@@ -279,6 +279,10 @@ __device__ __forceinline__ int tile_radix_regs(uint32_t (&key)[R], uint32_t (&va
 // Crowded bins (depths clustered in a small part of the bucket's range: a wall seen through a few floaters) make the
 // ranking quadratic; a bucket whose fullest bin exceeds kBinRankCap entries is left to the LSD sort (returns false,
 // before anything has been written).
+// MAP (how a bucket entry's VALUE relates to its Gaussian row): 0 -- the value is the row; 1 -- an emission slot of the
+// deterministic backward, row = isect_gid[value], slots ascend with the row inside a bucket; 2 -- the row's position in the
+// cell-ordered row list (bucket_tile_fill_kernel<., IDX>), row = isect_gid[value] with isect_gid = order[], and `depths` is
+// indexed by the VALUE (depth_sorted): the gather stays local.  The result is the (depth, row) order in every case.
 constexpr int kBinRankCap = 32;
 #ifndef MISPLAT_TS_BINRANK
 #define MISPLAT_TS_BINRANK 1
@@ -289,7 +293,7 @@ constexpr int kBinRankCap = 32;
 #ifndef MISPLAT_TS_B_BLOCKS
 #define MISPLAT_TS_B_BLOCKS 6                  /* launch bound (workgroups per 4 SIMDs x ...) of the eight-wave class */
 #endif
-template <int WAVES, int R, bool HAS_VALS>
+template <int WAVES, int R, int MAP>
 __device__ __forceinline__ bool tile_bin_rank(const uint32_t (&key)[R], const uint32_t (&val)[R], int n,
                                               tile_sort_lds<WAVES, R>& L, int beg, const int32_t* __restrict__ isect_gid,
                                               int32_t* __restrict__ payload, int32_t* __restrict__ flatten_ids) {
@@ -364,10 +368,10 @@ __device__ __forceinline__ bool tile_bin_rank(const uint32_t (&key)[R], const ui
         int before = 0;
         for (int j = s0; j < s1; j++) {
             const uint32_t kj = L.xk[j], vj = L.xv[j];
-            before += (kj < k || (kj == k && vj < v)) ? 1 : 0;
+            before += (kj < k || (kj == k && (MAP == 2 ? isect_gid[vj] < isect_gid[v] : vj < v))) ? 1 : 0;
         }
         if (payload) payload[beg + s0 + before] = (int32_t)v;
-        flatten_ids[beg + s0 + before] = HAS_VALS ? isect_gid[v] : (int32_t)v;
+        flatten_ids[beg + s0 + before] = MAP ? isect_gid[v] : (int32_t)v;
     }
     return true;
 }
@@ -377,7 +381,7 @@ __device__ __forceinline__ bool tile_bin_rank(const uint32_t (&key)[R], const ui
 // and a bucket with ties (rare in a real scene) is re-sorted by row and then, stably, by depth again.
 // One bucket [beg, beg + n) of a register class (n <= 64 * WAVES * R), every thread of the workgroup calls it.
 // SHORT_PATH: buckets of at most two entries per thread are rank-sorted (the class that starts at one entry).
-template <int WAVES, int R, bool HAS_VALS, bool UNORDERED, bool SHORT_PATH>
+template <int WAVES, int R, int MAP, bool UNORDERED, bool SHORT_PATH>
 __device__ __forceinline__ void sort_bucket_regs(tile_sort_lds<WAVES, R>& L, int beg, int n, const float* __restrict__ depths,
                                                  const int32_t* __restrict__ isect_gid, int32_t* __restrict__ payload,
                                                  int32_t* __restrict__ flatten_ids) {
@@ -394,8 +398,8 @@ __device__ __forceinline__ void sort_bucket_regs(tile_sort_lds<WAVES, R>& L, int
             v[q] = 0u; k[q] = 0xffffffffu; tb[q] = 0xffffffffu;
             if (i < n) {
                 v[q] = (uint32_t)payload[beg + i];
-                const int32_t rw = HAS_VALS ? isect_gid[v[q]] : (int32_t)v[q];
-                k[q] = __float_as_uint(depths[rw]);
+                const int32_t rw = MAP ? isect_gid[v[q]] : (int32_t)v[q];
+                k[q] = __float_as_uint(depths[MAP == 2 ? (int32_t)v[q] : rw]);
                 tb[q] = UNORDERED ? (uint32_t)rw : (uint32_t)i;
             }
         }
@@ -419,11 +423,11 @@ __device__ __forceinline__ void sort_bucket_regs(tile_sort_lds<WAVES, R>& L, int
         }
         if ((int)threadIdx.x < n) {
             payload[beg + rank0] = (int32_t)v[0];
-            flatten_ids[beg + rank0] = HAS_VALS ? isect_gid[v[0]] : (int32_t)v[0];
+            flatten_ids[beg + rank0] = MAP ? isect_gid[v[0]] : (int32_t)v[0];
         }
         if ((int)threadIdx.x + T < n) {
             payload[beg + rank1] = (int32_t)v[1];
-            flatten_ids[beg + rank1] = HAS_VALS ? isect_gid[v[1]] : (int32_t)v[1];
+            flatten_ids[beg + rank1] = MAP ? isect_gid[v[1]] : (int32_t)v[1];
         }
         return;
     }
@@ -436,7 +440,7 @@ __device__ __forceinline__ void sort_bucket_regs(tile_sort_lds<WAVES, R>& L, int
         val[r] = (uint32_t)payload[beg + (i < n ? i : 0)];
     }
 #pragma unroll
-    for (int r = 0; r < R; r++) row[r] = HAS_VALS ? isect_gid[val[r]] : (int32_t)val[r];
+    for (int r = 0; r < R; r++) row[r] = MAP == 1 ? isect_gid[val[r]] : (int32_t)val[r];      // (what indexes `depths`)
 #pragma unroll
     for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[row[r]]);
     // (Classes of up to 1 024 entries only.  Measured at 5 M Gaussians / 1080p, typical bucket 3 900 entries: the
@@ -446,7 +450,7 @@ __device__ __forceinline__ void sort_bucket_regs(tile_sort_lds<WAVES, R>& L, int
     if (MISPLAT_TS_BINRANK && (MISPLAT_TS_BINRANK_MASK & WAVES)) {
         // (values ascend with the row in both modes -- rows, or emission slots handed out in row order -- so ranking by
         // (depth, value) is the stable order of the ordered mode and the (depth, row) order of the unordered one)
-        if (tile_bin_rank<WAVES, R, HAS_VALS>(key, val, n, L, beg, isect_gid, payload, flatten_ids)) {
+        if (tile_bin_rank<WAVES, R, MAP>(key, val, n, L, beg, isect_gid, payload, flatten_ids)) {
             __syncthreads();                       // (the LDS image is reused by the next bucket of this workgroup)
             return;
         }
@@ -476,12 +480,12 @@ __device__ __forceinline__ void sort_bucket_regs(tile_sort_lds<WAVES, R>& L, int
                 while (e + 1 < n && e - i < 8 && L.xk[e + 1] == k) e++;
                 if (i - s == 8 || e - i == 8) { redo = true; continue; }
                 const uint32_t v = L.xv[i];
-                const uint32_t mine = HAS_VALS ? (uint32_t)isect_gid[v] : v;
+                const uint32_t mine = MAP ? (uint32_t)isect_gid[v] : v;
                 int before = 0;
                 for (int j = s; j <= e; j++) {
                     if (j == i) continue;
                     const uint32_t vj = L.xv[j];
-                    before += ((HAS_VALS ? (uint32_t)isect_gid[vj] : vj) < mine) ? 1 : 0;
+                    before += ((MAP ? (uint32_t)isect_gid[vj] : vj) < mine) ? 1 : 0;
                 }
                 payload[beg + s + before] = (int32_t)v;
                 flatten_ids[beg + s + before] = (int32_t)mine;
@@ -490,16 +494,16 @@ __device__ __forceinline__ void sort_bucket_regs(tile_sort_lds<WAVES, R>& L, int
         }
         if (__syncthreads_or(redo)) {
 #pragma unroll
-            for (int r = 0; r < R; r++) key[r] = HAS_VALS ? (uint32_t)isect_gid[val[r]] : val[r];
+            for (int r = 0; r < R; r++) key[r] = MAP ? (uint32_t)isect_gid[val[r]] : val[r];
             tile_radix_regs<WAVES, R>(key, val, n, L);            // by row
             __syncthreads();
 #pragma unroll
-            for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[key[r]]);
+            for (int r = 0; r < R; r++) key[r] = __float_as_uint(depths[MAP == 2 ? val[r] : key[r]]);
             tile_radix_regs<WAVES, R>(key, val, n, L);            // stably by depth
             placed = 0u;
         }
     }
-    if (HAS_VALS) {
+    if (MAP) {
 #pragma unroll
         for (int r = 0; r < R; r++) row[r] = isect_gid[val[r]];
     }
@@ -508,13 +512,13 @@ __device__ __forceinline__ void sort_bucket_regs(tile_sort_lds<WAVES, R>& L, int
         const int i = wave * 64 * R + r * 64 + lane;
         if (i < n && !((placed >> r) & 1u)) {
             payload[beg + i] = (int32_t)val[r];
-            flatten_ids[beg + i] = HAS_VALS ? row[r] : (int32_t)val[r];
+            flatten_ids[beg + i] = MAP ? row[r] : (int32_t)val[r];
         }
     }
     __syncthreads();
 }
 
-template <int WAVES, int R, bool HAS_VALS, bool UNORDERED>
+template <int WAVES, int R, int MAP, bool UNORDERED>
 __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? MISPLAT_TS_B_BLOCKS : (WAVES == 1 ? 4 : 1)) void tile_sort_reg_kernel(const int32_t* __restrict__ offsets, int n_tiles,
                                                                    int64_t n_isects, int lo, int hi,
                                                                    const float* __restrict__ depths,
@@ -530,8 +534,8 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? MISPLAT_TS_B_B
         const int beg = min(offsets[t], end);
         const int n = end - beg;
         if (n <= lo || n > hi || !sel.wants(t)) continue;      // uniform over the block (n >= 1 from here)
-        if (lo == 0) sort_bucket_regs<WAVES, R, HAS_VALS, UNORDERED, true>(L, beg, n, depths, isect_gid, payload, flatten_ids);
-        else sort_bucket_regs<WAVES, R, HAS_VALS, UNORDERED, false>(L, beg, n, depths, isect_gid, payload, flatten_ids);
+        if (lo == 0) sort_bucket_regs<WAVES, R, MAP, UNORDERED, true>(L, beg, n, depths, isect_gid, payload, flatten_ids);
+        else sort_bucket_regs<WAVES, R, MAP, UNORDERED, false>(L, beg, n, depths, isect_gid, payload, flatten_ids);
     }
 }
 
@@ -540,7 +544,7 @@ __global__ __launch_bounds__(64 * WAVES, (WAVES == 8 && R == 8) ? MISPLAT_TS_B_B
 // UNORDERED: four passes over the row bits come first, so the result is the (depth, row) order whatever
 // the order of arrival.
 // One bucket [beg, beg + n) of any length, ping-pong buffers in global scratch (GLOBAL) or in lds32 behind the histograms.
-template <int CAP, int WAVES, bool HAS_VALS, bool GLOBAL, bool UNORDERED>
+template <int CAP, int WAVES, int MAP, bool GLOBAL, bool UNORDERED>
 __device__ __forceinline__ void sort_bucket_passes(uint32_t* lds32, int beg, int n, const float* __restrict__ depths,
                                                    const int32_t* __restrict__ isect_gid, int32_t* payload,
                                                    int32_t* flatten_ids, uint32_t* scratch) {
@@ -558,7 +562,7 @@ __device__ __forceinline__ void sort_bucket_passes(uint32_t* lds32, int beg, int
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < n; i += THREADS) {
         const int32_t v = payload[beg + i];
-        const int32_t row = isect_gid ? isect_gid[v] : v;
+        const int32_t row = MAP == 1 ? isect_gid[v] : v;             // (what indexes `depths`)
         k0[i] = __float_as_uint(depths[row]);
         v0[i] = (uint32_t)v;
     }
@@ -570,7 +574,7 @@ __device__ __forceinline__ void sort_bucket_passes(uint32_t* lds32, int beg, int
         const bool by_row = UNORDERED && pass < 4;
         const int shift = 8 * (pass & 3);
         auto digit_of = [&](uint32_t k, uint32_t v) -> uint32_t {
-            const uint32_t src = by_row ? (HAS_VALS ? (uint32_t)isect_gid[v] : v) : k;
+            const uint32_t src = by_row ? (MAP ? (uint32_t)isect_gid[v] : v) : k;
             return (src >> shift) & 255u;
         };
         for (int b = threadIdx.x; b < WAVES * 256; b += THREADS) hist[b] = 0u;
@@ -632,7 +636,7 @@ __device__ __forceinline__ void sort_bucket_passes(uint32_t* lds32, int beg, int
     for (int i = threadIdx.x; i < n; i += THREADS) {
         const int32_t v = (int32_t)vin[i];
         payload[beg + i] = v;
-        flatten_ids[beg + i] = HAS_VALS ? isect_gid[v] : v;
+        flatten_ids[beg + i] = MAP ? isect_gid[v] : v;
     }
     __syncthreads();
 }
@@ -643,7 +647,7 @@ __device__ __forceinline__ void sort_bucket_passes(uint32_t* lds32, int beg, int
 // whatever the bucket's own class), longer ones through global scratch.  `covered`: bit c set = class c (<= 1 024,
 // <= 4 096, <= 8 192 entries) is sorted by a launch of its own.  Replaces three near-empty launches of ~5 us each.
 __device__ __forceinline__ int size_class(int n) { return n <= 1024 ? 0 : (n <= 4096 ? 1 : (n <= 8192 ? 2 : 3)); }
-template <bool HAS_VALS, bool UNORDERED>
+template <int MAP, bool UNORDERED>
 __global__ __launch_bounds__(1024) void tile_sort_rest_kernel(const int32_t* __restrict__ offsets, int n_tiles, int64_t n_isects,
                                                               int covered, const float* __restrict__ depths,
                                                               const int32_t* __restrict__ isect_gid, int32_t* payload,
@@ -666,8 +670,8 @@ __global__ __launch_bounds__(1024) void tile_sort_rest_kernel(const int32_t* __r
         if (n <= 0) continue;
         const int cls = size_class(n);
         if (((covered >> cls) & 1) || !sel.wants(t)) continue;      // (uniform over the block)
-        if (cls < 3) sort_bucket_regs<16, 8, HAS_VALS, UNORDERED, false>(L, beg, n, depths, isect_gid, payload, flatten_ids);
-        else sort_bucket_passes<0, 16, HAS_VALS, true, UNORDERED>(hist_passes, beg, n, depths, isect_gid, payload, flatten_ids, scratch);
+        if (cls < 3) sort_bucket_regs<16, 8, MAP, UNORDERED, false>(L, beg, n, depths, isect_gid, payload, flatten_ids);
+        else sort_bucket_passes<0, 16, MAP, true, UNORDERED>(hist_passes, beg, n, depths, isect_gid, payload, flatten_ids, scratch);
     }
 }
 
@@ -718,7 +722,8 @@ extern "C" int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* fl
 // through its whole list).  This kernel reads a tile's bucket once, keeps the entries at or in front of that pivot (x a
 // margin) -- ONE compare per entry: no histogram, no LDS atomic, no barrier for the nine entries in ten behind it --,
 // sorts the survivors (bin + rank: exactly the (depth, row) order, they are the first nf entries of the fully sorted list)
-// and writes them to the head of the tile's range of flatten_ids; front_n[tile] = nf.  payload is NOT touched: it stays a
+// and writes them (their rows) to the head of the tile's range of flatten_ids; front_n[tile] = nf.  Entries are positions in
+// the cell-ordered row list (MAP 2: depths indexed by the entry, row = row_map[entry]).  payload is NOT touched: it stays a
 // permutation of the bucket, from which a later launch can sort the whole tile -- the compositing forward flags a tile
 // whose pixels are still alive at the end of a truncated list (tile_flag), the flagged tiles are sorted in full and
 // composited again, and meta["flatten_ids"] is completed the same way when someone asks for it.  Exact results always;
@@ -727,9 +732,11 @@ extern "C" int misplat_isect_ids(const uint32_t* tiles_sorted, const int32_t* fl
 // than the 2 048 it holds, depths too clustered for bin + rank) gets front_n = -1: the regular size-class kernels, which
 // skip the tiles that are done, sort it in full.
 constexpr int kFrontWaves = 4, kFrontR = 8, kFrontCap = 64 * kFrontWaves * kFrontR;
+constexpr int kFrontU = 8;             // bucket entries per thread and round of the scan: all their loads in flight together
 __global__ __launch_bounds__(64 * kFrontWaves) void tile_sort_front_kernel(
     const int32_t* __restrict__ offsets, int n_tiles, int64_t n_isects, const float* __restrict__ depths,
-    const int32_t* __restrict__ payload, int32_t* __restrict__ flatten_ids, misplat_internal::FrontSort F) {
+    const int32_t* __restrict__ row_map, const int32_t* __restrict__ payload, int32_t* __restrict__ flatten_ids,
+    misplat_internal::FrontSort F) {
     __shared__ tile_sort_lds<kFrontWaves, kFrontR> L;
     __shared__ int s_nf;
     constexpr int T = 64 * kFrontWaves;
@@ -755,15 +762,15 @@ __global__ __launch_bounds__(64 * kFrontWaves) void tile_sort_front_kernel(
         }
         if (threadIdx.x == 0) s_nf = 0;
         __syncthreads();
-        for (int base = 0; base < n; base += 4 * T) {
-            int32_t v[4];
-            float d[4];
+        for (int base = 0; base < n; base += kFrontU * T) {
+            int32_t v[kFrontU];
+            float d[kFrontU];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = base + u * T + (int)threadIdx.x; v[u] = payload[beg + (i < n ? i : 0)]; }
+            for (int u = 0; u < kFrontU; u++) { const int i = base + u * T + (int)threadIdx.x; v[u] = payload[beg + (i < n ? i : 0)]; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) d[u] = depths[v[u]];
+            for (int u = 0; u < kFrontU; u++) d[u] = depths[v[u]];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < kFrontU; u++) {
                 const int i = base + u * T + (int)threadIdx.x;
                 const bool keep = i < n && d[u] <= pivot;
                 const unsigned long long m = __ballot(keep);
@@ -786,7 +793,7 @@ __global__ __launch_bounds__(64 * kFrontWaves) void tile_sort_front_kernel(
                 key[r] = i < nf ? L.xk[i] : 0u; val[r] = i < nf ? L.xv[i] : 0u;
             }
             __syncthreads();                                     // (bin + rank reuses xk / xv)
-            done = tile_bin_rank<kFrontWaves, kFrontR, false>(key, val, nf, L, beg, nullptr, nullptr, flatten_ids);
+            done = tile_bin_rank<kFrontWaves, kFrontR, 2>(key, val, nf, L, beg, row_map, nullptr, flatten_ids);
         }
         __syncthreads();                                         // (the LDS image is reused by the next tile)
         if (threadIdx.x == 0) { F.front_n[t] = done ? nf : -1; F.tile_flag[t] = 0; }
@@ -797,7 +804,7 @@ __global__ __launch_bounds__(64 * kFrontWaves) void tile_sort_front_kernel(
 // (rows, or emission slots when isect_gid != NULL); flatten_ids: out (rows in final order);
 // scratch: 2 * n_isects uint32, only touched by tiles longer than the largest LDS class (8192 entries).
 // sel: which tiles (TileSel); rest_only: everything through the one launch of tile_sort_rest_kernel (few tiles expected).
-template <bool HAS_VALS, bool UNORDERED>
+template <int MAP, bool UNORDERED>
 static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
                             const int32_t* isect_gid, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,
                             int has_longest, hipStream_t s, TileSel sel = TileSel{nullptr, 0}, bool rest_only = false) {
@@ -818,63 +825,67 @@ static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_i
     if (avg < 2048 && !rest_only) {
         covered |= 1;
         if (avg < 256)
-            hipLaunchKernelGGL((tile_sort_reg_kernel<1, 16, HAS_VALS, UNORDERED>), dim3(full), dim3(64), 0, s, offsets, n_tiles,
+            hipLaunchKernelGGL((tile_sort_reg_kernel<1, 16, MAP, UNORDERED>), dim3(full), dim3(64), 0, s, offsets, n_tiles,
                                n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest, sel);
         else
-            hipLaunchKernelGGL((tile_sort_reg_kernel<2, 8, HAS_VALS, UNORDERED>), dim3(full), dim3(128), 0, s, offsets, n_tiles,
+            hipLaunchKernelGGL((tile_sort_reg_kernel<2, 8, MAP, UNORDERED>), dim3(full), dim3(128), 0, s, offsets, n_tiles,
                                n_isects, 0, 1024, depths, isect_gid, payload, flatten_ids, has_longest, sel);
     }
     if (avg >= 1024 && !rest_only) {
         covered |= 2;
-        hipLaunchKernelGGL((tile_sort_reg_kernel<8, 8, HAS_VALS, UNORDERED>), dim3(full), dim3(512), 0, s, offsets, n_tiles,
+        hipLaunchKernelGGL((tile_sort_reg_kernel<8, 8, MAP, UNORDERED>), dim3(full), dim3(512), 0, s, offsets, n_tiles,
                            n_isects, 1024, 4096, depths, isect_gid, payload, flatten_ids, has_longest, sel);
     }
     if (avg >= 2048 && !rest_only) {
         covered |= 4;
-        hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, HAS_VALS, UNORDERED>), dim3(full), dim3(1024), 0, s, offsets, n_tiles,
+        hipLaunchKernelGGL((tile_sort_reg_kernel<16, 8, MAP, UNORDERED>), dim3(full), dim3(1024), 0, s, offsets, n_tiles,
                            n_isects, 4096, 8192, depths, isect_gid, payload, flatten_ids, has_longest, sel);
     }
-    hipLaunchKernelGGL((tile_sort_rest_kernel<HAS_VALS, UNORDERED>), dim3(few), dim3(1024), 0, s, offsets, n_tiles, n_isects,
+    hipLaunchKernelGGL((tile_sort_rest_kernel<MAP, UNORDERED>), dim3(few), dim3(1024), 0, s, offsets, n_tiles, n_isects,
                        covered, depths, isect_gid, payload, flatten_ids, scratch, sel);
     return check_launch();
 }
 
 // Front-only ordering, first part: the front kernel, then the regular size classes for the tiles it left undone.
 int misplat_internal::tile_sort_front(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
-                                      int32_t* payload, int32_t* flatten_ids, uint32_t* scratch, const FrontSort& F,
-                                      hipStream_t s) {
-    if (n_isects < 0 || n_tiles < 1 || n_isects > 0x7fffffffLL || !scratch || !F.order_table || !F.order_sel || !F.front_n ||
+                                      const int32_t* row_map, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,
+                                      const FrontSort& F, hipStream_t s) {
+    if (n_isects < 0 || n_tiles < 1 || n_isects > 0x7fffffffLL || !scratch || !row_map || !F.order_table || !F.order_sel || !F.front_n ||
         !F.tile_flag || F.order_slots < 1 || F.pivot_off < MISPLAT_ORDER_HEADER || F.order_stride < F.pivot_off + n_tiles)
         return MISPLAT_EINVAL;
     const int grid = n_tiles < 65536 ? n_tiles : 65536;
     hipLaunchKernelGGL(tile_sort_front_kernel, dim3(grid), dim3(64 * kFrontWaves), 0, s, offsets, n_tiles, n_isects, depths,
-                       (const int32_t*)payload, flatten_ids, F);
+                       row_map, (const int32_t*)payload, flatten_ids, F);
     if (n_isects == 0) return check_launch();
-    return launch_tile_sort<false, true>(offsets, n_tiles, n_isects, depths, nullptr, payload, flatten_ids, scratch, 1, s,
-                                         TileSel{F.front_n, 1});
+    return launch_tile_sort<2, true>(offsets, n_tiles, n_isects, depths, row_map, payload, flatten_ids, scratch, 1, s,
+                                     TileSel{F.front_n, 1});
 }
 
 // Second part: the tiles whose flag the compositing forward set, in full (one launch; few tiles are expected).
 int misplat_internal::tile_sort_flagged(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
-                                        int32_t* payload, int32_t* flatten_ids, uint32_t* scratch, const int32_t* tile_flag,
-                                        hipStream_t s) {
-    if (n_isects < 0 || n_tiles < 1 || n_isects > 0x7fffffffLL || !scratch || !tile_flag) return MISPLAT_EINVAL;
+                                        const int32_t* row_map, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,
+                                        const int32_t* tile_flag, hipStream_t s) {
+    if (n_isects < 0 || n_tiles < 1 || n_isects > 0x7fffffffLL || !scratch || !tile_flag || !row_map) return MISPLAT_EINVAL;
     if (n_isects == 0) return MISPLAT_OK;
-    return launch_tile_sort<false, true>(offsets, n_tiles, n_isects, depths, nullptr, payload, flatten_ids, scratch, 1, s,
-                                         TileSel{tile_flag, 2}, true);
+    return launch_tile_sort<2, true>(offsets, n_tiles, n_isects, depths, row_map, payload, flatten_ids, scratch, 1, s,
+                                     TileSel{tile_flag, 2}, true);
 }
 
 extern "C" int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects,
                                  const float* depths, const int32_t* isect_gid, int32_t* payload,
                                  int32_t* flatten_ids, uint32_t* scratch, int32_t flags,
                                  misplat_stream_t stream) {
-    if (n_isects < 0 || n_tiles_total < 1 || n_isects > 0x7fffffffLL || !scratch || (flags & ~3)) return MISPLAT_EINVAL;
+    if (n_isects < 0 || n_tiles_total < 1 || n_isects > 0x7fffffffLL || !scratch || (flags & ~7) || ((flags & 4) && !isect_gid))
+        return MISPLAT_EINVAL;
     if (n_isects == 0) return MISPLAT_OK;
     hipStream_t s = (hipStream_t)stream;
     const int has_longest = (flags >> 1) & 1;      // (bit 0, "unordered", is what every bucket is now: accepted, ignored)
-    if (isect_gid)
-        return launch_tile_sort<true, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
-                                            has_longest, s);
-    return launch_tile_sort<false, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
+    if (flags & 4)                                 // entries are positions in the cell-ordered row list (see MAP)
+        return launch_tile_sort<2, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
                                          has_longest, s);
+    if (isect_gid)
+        return launch_tile_sort<1, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
+                                            has_longest, s);
+    return launch_tile_sort<0, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
+                                     has_longest, s);
 }

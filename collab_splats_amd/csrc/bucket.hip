@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kCountThreads) void bucket_rows_kernel(
     const int32_t* __restrict__ tiles_per_gauss, const uint2* __restrict__ rect2, const uint32_t* __restrict__ cellhist,
     const uint32_t* __restrict__ cell_count, uint32_t* __restrict__ cell_offs, uint32_t* __restrict__ cell_cursor,
     int32_t* __restrict__ order, uint2* __restrict__ rect_sorted, int64_t* __restrict__ counters,
-    long long* __restrict__ n_isects_host) {
+    long long* __restrict__ n_isects_host, const float* __restrict__ depths, float* __restrict__ depth_sorted) {
     __shared__ uint32_t base[MISPLAT_BUCKET_MAX_CELLS];
     __shared__ uint32_t wsum[kCountThreads / 64];
     static_assert(2 * kCountThreads >= MISPLAT_BUCKET_MAX_CELLS, "two cells per thread");
@@ -196,6 +196,8 @@ __global__ __launch_bounds__(kCountThreads) void bucket_rows_kernel(
             const uint32_t pos = atomicAdd(&base[c], 1u);        // LDS cursor: any order inside a cell will do
             order[pos] = (int32_t)idx;
             rect_sorted[pos] = r2;                               // the tile passes read rectangles without a gather
+            // (and the per-tile sort its depth keys: bucket entries are positions in order[] then -- bucket_tile_fill_kernel)
+            if (depth_sorted) depth_sorted[pos] = depths[idx];
         }
     }
 }
@@ -401,8 +403,12 @@ __global__ __launch_bounds__(1024) void bucket_tile_scan_kernel(int n_tiles, int
     }
 }
 
-// fill: payload[offsets[tile] + k] = row (DET: the emission slot cum[row] + q, and isect_gid[slot] = row)
-template <bool DET>
+// fill: payload[offsets[tile] + k] = row (DET: the emission slot cum[row] + q, and isect_gid[slot] = row).
+// IDX: payload = the row's POSITION in order[] instead (bucket_rows has written depth_sorted[position] = depths[row]): the
+// rows of one tile are neighbours in order[] (cell order), so the per-tile sort's gather of its entries' depths stays inside
+// a few hundred KB of depth_sorted -- by row it fetches one cache line per entry from all over depths[] (20 MB at 5 M
+// Gaussians: the gather, not the sorting, was what the sort's time went into); row = order[position] where one is needed.
+template <bool DET, bool IDX>
 __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_fill_kernel(
     int n_gauss, int tw, int tiles_per_cam, const int64_t* __restrict__ counters, const int32_t* __restrict__ order,
     const uint2* __restrict__ rect2, const int32_t* __restrict__ offsets, int32_t* __restrict__ cursors,
@@ -417,6 +423,7 @@ __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_fill_kernel(
     uint2 r2_;
     bool in_;
     tile_wg_prologue<true>(L, n_vis, n_gauss, order, rect2, cam0, wx0, wy0, ww, wh, r_, r2_, in_);
+    const int64_t first_pos = (int64_t)blockIdx.x * rows_per_wg(n_vis);
     const uint32_t total = L.total;
     const int stride = ww + 1;
     // one returning atomic per (workgroup, tile): a contiguous range of the tile's bucket; tab becomes the cursors
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_fill_kernel(
                     payload[slot] = (int32_t)es;
                     if (es < cap) isect_gid[es] = r;
                 } else {
-                    payload[slot] = r;
+                    payload[slot] = IDX ? (int32_t)(first_pos + e) : r;
                 }
             }
         }
@@ -534,6 +541,16 @@ extern "C" int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles
                                    uint32_t* cell_offs, int32_t* order, uint32_t* rect_sorted, int64_t* counters,
                                    int32_t* tile_count, int64_t* n_isects_host, int32_t already_zero,
                                    misplat_stream_t stream) {
+    return misplat_internal::bucket_rows(p, tiles_per_gauss, rect2, cellhist, cell_count, cell_cursor, cell_offs, order, rect_sorted,
+                                         counters, tile_count, n_isects_host, already_zero, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int misplat_internal::bucket_rows(const misplat_params* p, const int32_t* tiles_per_gauss, const uint32_t* rect2,
+                                  const uint32_t* cellhist, const uint32_t* cell_count, uint32_t* cell_cursor,
+                                  uint32_t* cell_offs, int32_t* order, uint32_t* rect_sorted, int64_t* counters,
+                                  int32_t* tile_count, int64_t* n_isects_host, int32_t already_zero, const float* depths,
+                                  float* depth_sorted, hipStream_t stream) {
+    if (depth_sorted && !depths) return MISPLAT_EINVAL;
     int32_t nc, nb;
     if (misplat_bucket_plan(p, &nc, &nb) != MISPLAT_OK || !cell_count || !cell_cursor || !cell_offs || !counters || !tile_count)
         return MISPLAT_EINVAL;
@@ -552,7 +569,7 @@ extern "C" int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles
         hipLaunchKernelGGL(bucket_rows_kernel, dim3(g.n_blocks), dim3(kCountThreads), 0, s, total, p->n_gauss, g.shift,
                            g.cells_x, g.cells_x * g.cells_y, g.n_cells, g.rows_per_block, tiles_per_gauss,
                            (const uint2*)rect2, cellhist, cell_count, cell_offs, cell_cursor, order, (uint2*)rect_sorted, counters,
-                           (long long*)n_isects_host);
+                           (long long*)n_isects_host, depths, depth_sorted);
     else
         hipLaunchKernelGGL(bucket_rows_empty_kernel, dim3(1), dim3(256), 0, s, g.n_cells, cell_offs, counters,
                            (long long*)n_isects_host);
@@ -562,8 +579,16 @@ extern "C" int misplat_bucket_rows(const misplat_params* p, const int32_t* tiles
 extern "C" int misplat_bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect_sorted,
                                     const int64_t* counters, int32_t* tile_count, int32_t* offsets, const int64_t* cum,
                                     int64_t cap_isects, int32_t* payload, int32_t* isect_gid, misplat_stream_t stream) {
+    return misplat_internal::bucket_tiles(p, order, rect_sorted, counters, tile_count, offsets, cum, cap_isects, payload, isect_gid,
+                                          false, (hipStream_t)stream);
+}
+
+int misplat_internal::bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect_sorted,
+                                   const int64_t* counters, int32_t* tile_count, int32_t* offsets, const int64_t* cum,
+                                   int64_t cap_isects, int32_t* payload, int32_t* isect_gid, bool indexed,
+                                   hipStream_t stream) {
     if (!p || p->tile_size != MISPLAT_TILE || !counters || !tile_count || !offsets || cap_isects < 0 ||
-        cap_isects > 0x7fffffffLL || (cum && !isect_gid && cap_isects > 0))
+        cap_isects > 0x7fffffffLL || (cum && !isect_gid && cap_isects > 0) || (indexed && cum))
         return MISPLAT_EINVAL;
     const int64_t total = (int64_t)p->n_gauss * p->n_cams;
     if (total > 0 && (!order || !rect_sorted)) return MISPLAT_EINVAL;
@@ -577,11 +602,15 @@ extern "C" int misplat_bucket_tiles(const misplat_params* p, const int32_t* orde
     hipLaunchKernelGGL(bucket_tile_scan_kernel, dim3(1), dim3(1024), 0, s, (int)n_tiles, tile_count, offsets);
     if (grid > 0 && cap_isects > 0 && payload) {
         if (cum)
-            hipLaunchKernelGGL(bucket_tile_fill_kernel<true>, dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
+            hipLaunchKernelGGL((bucket_tile_fill_kernel<true, false>), dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
+                               tiles_per_cam, counters, order, (const uint2*)rect_sorted, offsets, tile_count, cum, cap_isects,
+                               payload, isect_gid);
+        else if (indexed)
+            hipLaunchKernelGGL((bucket_tile_fill_kernel<false, true>), dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
                                tiles_per_cam, counters, order, (const uint2*)rect_sorted, offsets, tile_count, cum, cap_isects,
                                payload, isect_gid);
         else
-            hipLaunchKernelGGL(bucket_tile_fill_kernel<false>, dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
+            hipLaunchKernelGGL((bucket_tile_fill_kernel<false, false>), dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
                                tiles_per_cam, counters, order, (const uint2*)rect_sorted, offsets, tile_count, cum, cap_isects,
                                payload, isect_gid);
     }

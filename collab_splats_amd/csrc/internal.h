@@ -78,9 +78,22 @@ struct FrontSort {
     int32_t* front_n;
     int32_t* tile_flag;
 };
-int tile_sort_front(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths, int32_t* payload,
-                    int32_t* flatten_ids, uint32_t* scratch, const FrontSort& F, hipStream_t s);
-int tile_sort_flagged(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths, int32_t* payload,
-                      int32_t* flatten_ids, uint32_t* scratch, const int32_t* tile_flag, hipStream_t s);
+// (bucket entries are positions in the cell-ordered row list: depths = depth_sorted, row_map = order -- bucket_tiles below)
+int tile_sort_front(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths, const int32_t* row_map,
+                    int32_t* payload, int32_t* flatten_ids, uint32_t* scratch, const FrontSort& F, hipStream_t s);
+int tile_sort_flagged(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths, const int32_t* row_map,
+                      int32_t* payload, int32_t* flatten_ids, uint32_t* scratch, const int32_t* tile_flag, hipStream_t s);
+
+// misplat_bucket_rows that also writes depth_sorted[position] = depths[row] (both or neither), and misplat_bucket_tiles whose
+// payload (indexed; atomic gradient mode only) holds every row's POSITION in order[] instead of the row:
+// misplat_tile_sort(flags | 4, isect_gid = order, depths = depth_sorted) then gathers its keys from a few hundred KB around
+// the tile instead of from all over depths[].
+int bucket_rows(const misplat_params* p, const int32_t* tiles_per_gauss, const uint32_t* rect2, const uint32_t* cellhist,
+                const uint32_t* cell_count, uint32_t* cell_cursor, uint32_t* cell_offs, int32_t* order, uint32_t* rect_sorted,
+                int64_t* counters, int32_t* tile_count, int64_t* n_isects_host, int32_t already_zero, const float* depths,
+                float* depth_sorted, hipStream_t stream);
+int bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect_sorted, const int64_t* counters,
+                 int32_t* tile_count, int32_t* offsets, const int64_t* cum, int64_t cap_isects, int32_t* payload,
+                 int32_t* isect_gid, bool indexed, hipStream_t stream);
 
 }  // namespace misplat_internal

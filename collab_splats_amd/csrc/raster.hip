@@ -59,8 +59,9 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
                                   a->counters, 1, stream);
         if (rc != MISPLAT_OK) return rc;
         // (the intersection count reaches the caller's pinned slot as a store from bucket_rows: no copy node)
-        rc = misplat_bucket_rows(p, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count, a->cell_cursor, a->cell_offs,
-                                 a->order, a->rect_sorted, a->counters, a->tile_count, a->n_isects_host, 3, stream);
+        rc = misplat_internal::bucket_rows(p, a->tiles_per_gauss, a->rect2, a->cellhist, a->cell_count, a->cell_cursor,
+                                           a->cell_offs, a->order, a->rect_sorted, a->counters, a->tile_count, a->n_isects_host,
+                                           3, a->depth_sorted ? a->depths : nullptr, a->depth_sorted, s);
         if (rc != MISPLAT_OK) return rc;
         if (!a->lazy_colour) {
             rc = enqueue_colour(p, a, stream);
@@ -69,9 +70,13 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
     }
     if (phases & 2) {
         if (a->cap_isects < 0 || a->cap_isects > 0x7fffffffLL) return MISPLAT_EINVAL;
-        rc = misplat_bucket_tiles(p, a->order, a->rect_sorted, a->counters, a->tile_count, a->offsets, nullptr, a->cap_isects,
-                                  a->payload, nullptr, stream);
+        // (depth_sorted given: bucket entries are positions in the cell-ordered row list, the sort's depth gather stays local)
+        rc = misplat_internal::bucket_tiles(p, a->order, a->rect_sorted, a->counters, a->tile_count, a->offsets, nullptr,
+                                            a->cap_isects, a->payload, nullptr, a->depth_sorted != nullptr, s);
         if (rc != MISPLAT_OK) return rc;
+        const float* sort_depths = a->depth_sorted ? a->depth_sorted : a->depths;
+        const int32_t* sort_map = a->depth_sorted ? a->order : nullptr;
+        const int sort_flags = a->depth_sorted ? 7 : 3;
         const int n_tiles = p->tile_w * p->tile_h * p->n_cams;
         const int64_t units = (int64_t)n_tiles * MISPLAT_BANDS;
         const int pivot_off = (int)(MISPLAT_ORDER_HEADER + 8 * ((units + 7) / 8));
@@ -80,21 +85,21 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
             if (a->order_slots < 1 || a->order_stride < pivot_off + (a->unit_reach ? n_tiles : 0)) return MISPLAT_EINVAL;
         }
         // front-only ordering: only with the view-keyed records (they carry the pivots) and the reach output that feeds them
-        const bool front = by_view && a->unit_reach && a->front_n && a->tile_flag;
+        const bool front = by_view && a->unit_reach && a->front_n && a->tile_flag && a->depth_sorted;
         if ((a->front_n != nullptr) != (a->tile_flag != nullptr) || (a->front_n && !front)) return MISPLAT_EINVAL;
         if (front) {
             misplat_internal::FrontSort F;
             F.order_table = a->order_table; F.order_sel = a->order_sel; F.order_slots = a->order_slots;
             F.order_stride = a->order_stride; F.pivot_off = pivot_off;
-            F.margin = a->front_margin >= 1.0f ? a->front_margin : 1.0f;
+            F.margin = a->front_margin > 0.f ? a->front_margin : 1.0f;      // (< 1: a pivot that is too shallow -- tests force the flag path with it)
             F.min_bucket = a->front_min_bucket > 0 ? a->front_min_bucket : 1;
             F.front_n = a->front_n; F.tile_flag = a->tile_flag;
-            rc = misplat_internal::tile_sort_front(a->offsets, n_tiles, a->cap_isects, a->depths, a->payload, a->flatten_ids,
-                                                   a->scratch, F, s);
+            rc = misplat_internal::tile_sort_front(a->offsets, n_tiles, a->cap_isects, sort_depths, sort_map, a->payload,
+                                                   a->flatten_ids, a->scratch, F, s);
             if (rc != MISPLAT_OK) return rc;
         } else if (a->cap_isects > 0) {
-            rc = misplat_tile_sort(a->offsets, n_tiles, a->cap_isects, a->depths, nullptr, a->payload, a->flatten_ids,
-                                   a->scratch, 3, stream);
+            rc = misplat_tile_sort(a->offsets, n_tiles, a->cap_isects, sort_depths, sort_map, a->payload, a->flatten_ids,
+                                   a->scratch, sort_flags, stream);
             if (rc != MISPLAT_OK) return rc;
         }
         misplat_params q = *p;
@@ -125,8 +130,8 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         if (rc != MISPLAT_OK) return rc;
         if (front) {
             // the tiles whose pixels were still alive at the end of their truncated list: sorted in full, composited again
-            rc = misplat_internal::tile_sort_flagged(a->offsets, n_tiles, a->cap_isects, a->depths, a->payload, a->flatten_ids,
-                                                     a->scratch, a->tile_flag, s);
+            rc = misplat_internal::tile_sort_flagged(a->offsets, n_tiles, a->cap_isects, sort_depths, sort_map, a->payload,
+                                                     a->flatten_ids, a->scratch, a->tile_flag, s);
             if (rc != MISPLAT_OK) return rc;
             q.front_pass = 1;
             rc = composite();

@@ -27,7 +27,14 @@ from typing import Callable, Optional
 
 import torch
 
+import types
+
 from . import ops
+
+
+# (the text of PyTorch's warning for an AccumulateGrad node that runs on a stream other than the one its graph was built on;
+# tests/test_host.py checks that the installed torch still says this -- the secondary net behind _tensors_with_history)
+STALE_GRAPH_WARNING = "AccumulateGrad node's stream does not match"
 
 
 def _tensors_with_history(obj, path="result", seen=None):
@@ -43,9 +50,12 @@ def _tensors_with_history(obj, path="result", seen=None):
     if isinstance(obj, dict):
         for k, v in obj.items():
             out += _tensors_with_history(v, f"{path}[{k!r}]", seen)
-    elif isinstance(obj, (list, tuple)):
+    elif isinstance(obj, (list, tuple, set, frozenset)):
         for i, v in enumerate(obj):
             out += _tensors_with_history(v, f"{path}[{i}]", seen)
+    elif hasattr(obj, "__dict__") and not isinstance(obj, (type, types.ModuleType, types.FunctionType, types.MethodType)):
+        for k, v in vars(obj).items():                       # plain objects, dataclasses, SimpleNamespace: a `meta` holder
+            out += _tensors_with_history(v, f"{path}.{k}", seen)
     return out
 
 
@@ -80,7 +90,7 @@ class GraphedStep:
                             "GraphedStep: fn() returned tensor(s) with autograd history (" + ", ".join(bad[:4])
                             + ("..." if len(bad) > 4 else "") + "): return detached tensors (t.detach()) or nothing -- "
                             "a graph of the previous iteration that is still alive cannot be captured")
-                stale = [w for w in caught if "AccumulateGrad node's stream does not match" in str(w.message)]
+                stale = [w for w in caught if STALE_GRAPH_WARNING in str(w.message)]
         finally:
             torch.set_warn_always(warn_always)
         torch.cuda.current_stream(self.device).wait_stream(side)

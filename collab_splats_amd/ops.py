@@ -16,7 +16,7 @@ from typing import Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
-from . import _lib
+from . import _lib, arena
 from ._lib import MISPLAT_REC, Params, RasterArgs, RasterBwdArgs, check, ptr, require_gpu, stream_ptr
 
 
@@ -66,7 +66,8 @@ BANDS = 2                              # MISPLAT_BANDS: wavefronts (16 x 8 pixel
 ORDER_BY_VIEW = os.environ.get("MISPLAT_ORDER_BY_VIEW", "1") == "1"
 ORDER_SLOTS = int(os.environ.get("MISPLAT_ORDER_SLOTS", "256"))
 ORDER_HEADER = 16                     # MISPLAT_ORDER_HEADER
-_ORDER_TABLES: Dict[tuple, tuple] = {}
+ORDER_TABLES_MAX = int(os.environ.get("MISPLAT_ORDER_TABLES", "8"))     # (device, stream, shape) keys kept, least recently used beyond
+_ORDER_TABLES: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
 
 
 def _order_slots(table: Tensor, stride: int) -> int:
@@ -80,19 +81,37 @@ def _order_table(P: Params, dev: torch.device):
     units = P.tile_w * P.tile_h * P.n_cams * BANDS
     key = (dev.index, _stream_id(), P.n_cams, P.tile_w, P.tile_h, ORDER_SLOTS)
     got = _ORDER_TABLES.get(key)
+    if got is not None:
+        _ORDER_TABLES.move_to_end(key)
+    elif torch.cuda.is_current_stream_capturing():
+        # A whole-step capture (graphs.GraphedStep) runs on a stream of its own, which has no table yet -- and creating one
+        # now would put its zero-fill INTO the captured graph: every replay would wipe the table in front of the projection
+        # kernel's lookup, and the launch-order feedback of the warm-up would be lost.  The warm-up of the same shape ran
+        # on another stream of this device and has finished: its table serves the capture (kept alive with the graph).
+        for k2, v in _ORDER_TABLES.items():
+            if k2[0] == key[0] and k2[2:] == key[2:]:
+                got = v
+                break
+        if got is None:
+            return None
+        if _CAPTURE_KEEP is not None:
+            _CAPTURE_KEEP.extend([got[0], got[1]])
+        PATH_STATS["capture_reused_order_table"] += 1
     if got is None:
         # a record: header, the launch order of the view's units, the per-tile depth pivots of front-only ordering
         n_tiles = P.tile_w * P.tile_h * P.n_cams
         stride = ORDER_HEADER + 8 * ((units + 7) // 8) + 8 * ((n_tiles + 7) // 8)
         got = _ORDER_TABLES[key] = (torch.zeros(ORDER_SLOTS * stride, device=dev, dtype=torch.int32),
                                     torch.zeros(4, device=dev, dtype=torch.int32), stride)
+        while len(_ORDER_TABLES) > ORDER_TABLES_MAX:            # (a dropped table lives on while a call still refers to it)
+            _ORDER_TABLES.popitem(last=False)
     return got
 
 
 class _UnitSchedule:
     """Per-call launch-order state of one compositing forward/backward pair."""
 
-    def __init__(self, P: Params, dev: torch.device, by_view=None):
+    def __init__(self, P: Params, dev: torch.device, by_view=None, cv=None):
         self.on = UNIT_ORDER
         self.perm_bwd = None
         self.by_view = by_view if self.on else None        # (table, sel, stride): the order lives in a view-keyed record
@@ -100,7 +119,9 @@ class _UnitSchedule:
             return
         self.units = P.tile_w * P.tile_h * P.n_cams * BANDS
         self.key = (dev.index, _stream_id(), P.n_cams, P.tile_w, P.tile_h)
-        self.work, self.perm = _carve(dev, (self.units, 8 * ((self.units + 7) // 8) if self.by_view is None else 0))
+        # (the host-keyed previous-call order outlives the call in _LAST_ORDER: not from the call's arena slot)
+        self.work, self.perm = _carve(dev, (self.units, 8 * ((self.units + 7) // 8) if self.by_view is None else 0),
+                                      cv if self.by_view is not None else None)
 
     def before_forward(self, P: Params) -> None:
         if not self.on:
@@ -136,11 +157,13 @@ class _UnitSchedule:
 GRAD_SINK = None
 
 
-def _grad_out(inp: Tensor) -> Tensor:
+def _grad_out(inp: Tensor, cv: "Optional[arena.Carver]" = None) -> Tensor:
     if GRAD_SINK is not None:
         v = GRAD_SINK.sink(inp)
         if v is not None:
             return v
+    if cv is not None:
+        return cv.take(inp.numel(), inp.dtype).view(inp.shape)
     return torch.empty_like(inp)
 
 
@@ -291,14 +314,14 @@ def spherical_harmonics_raw(degree: int, dirs: Tensor, coeffs: Tensor, radii: Op
 _PLAN_CACHE: Dict[tuple, Tuple[int, int]] = {}
 
 
-def _carve(dev: torch.device, sizes) -> list:
-    """One int32 allocation cut into views of the given element counts (each 256-byte aligned): a single trip
-    through the caching allocator instead of one per scratch array."""
+def _carve(dev: torch.device, sizes, cv: "Optional[arena.Carver]" = None, dtype=torch.int32) -> list:
+    """One allocation cut into views of the given element counts (each 256-byte aligned): a single trip through the
+    caching allocator -- or one contiguous piece of the call's arena slot (``cv``) -- instead of one per scratch array."""
     offs, tot = [], 0
     for n in sizes:
         offs.append(tot)
         tot += (int(n) + 63) // 64 * 64
-    buf = torch.empty(max(tot, 64), device=dev, dtype=torch.int32)
+    buf = cv.take(max(tot, 64), dtype) if cv is not None else torch.empty(max(tot, 64), device=dev, dtype=dtype)
     return [buf[o:o + int(n)] for o, n in zip(offs, sizes)]
 
 
@@ -396,9 +419,11 @@ def complete_bins(bins: Dict[str, Tensor]) -> Tensor:
     if part is not None:
         n_tiles = bins["n_tiles"]
         if part["cap"] > 0:
-            check(_lib.load().misplat_tile_sort(ptr(part["offsets"]), C.c_int32(n_tiles), C.c_int64(part["cap"]), ptr(bins["depths"]),
-                                                ptr(None), ptr(part["payload"]), ptr(part["flatten_ids"]), ptr(part["scratch"]),
-                                                C.c_int32(3), stream_ptr()), "misplat_tile_sort")
+            # (the bucket entries are positions in the cell-ordered row list: flags bit 2)
+            check(_lib.load().misplat_tile_sort(ptr(part["offsets"]), C.c_int32(n_tiles), C.c_int64(part["cap"]),
+                                                ptr(part["depth_sorted"]), ptr(part["row_map"]), ptr(part["payload"]),
+                                                ptr(part["flatten_ids"]), ptr(part["scratch"]), C.c_int32(7), stream_ptr()),
+                  "misplat_tile_sort")
         bins["partial"] = None
         PATH_STATS["bins_completed"] += 1
     return bins["flatten_ids"]
@@ -519,13 +544,8 @@ _CAP_HINT: Dict[tuple, int] = {}
 _READBACK: Dict[tuple, Tensor] = {}
 
 
-def _carve_f(dev: torch.device, sizes) -> list:
-    offs, tot = [], 0
-    for n in sizes:
-        offs.append(tot)
-        tot += (int(n) + 63) // 64 * 64
-    buf = torch.empty(max(tot, 64), device=dev, dtype=torch.float32)
-    return [buf[o:o + int(n)] for o, n in zip(offs, sizes)]
+def _carve_f(dev: torch.device, sizes, cv: "Optional[arena.Carver]" = None) -> list:
+    return _carve(dev, sizes, cv, torch.float32)
 
 
 # hipGraph replay of the launch sequences (csrc/raster.hip): one graph per distinct argument block, LRU per device.
@@ -661,6 +681,7 @@ LAZY_SH_MIN_BUCKET = int(os.environ.get("MISPLAT_LAZY_SH_MIN_BUCKET", "450"))   
 # pivots live in the view-keyed launch-order records) is sorted; a tile whose pixels outlive its sorted part is sorted in
 # full and composited again (exact images either way), and meta["flatten_ids"] / ["isect_ids"] are completed on access.
 # "auto": from a typical bucket of FRONT_MIN_AVG entries (the hint of the previous call of the shape); "1": always; "0": off.
+INDEXED_BUCKETS = os.environ.get("MISPLAT_INDEXED_BUCKETS", "1") == "1"   # (one-entry path: see misplat_raster_args.depth_sorted)
 FRONT_ONLY = os.environ.get("MISPLAT_FRONT_ONLY", "auto")
 FRONT_MIN_AVG = int(os.environ.get("MISPLAT_FRONT_MIN_AVG", "1024"))
 FRONT_MIN_BUCKET = int(os.environ.get("MISPLAT_FRONT_MIN_BUCKET", "256"))
@@ -687,15 +708,21 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     rows = Cn * N
     n_tiles = P.tile_w * P.tile_h * Cn
     n_cells, n_blocks = bucket_plan(P)
-    means2d, depths, comps, grec, sh_aux = _carve_f(dev, (2 * rows, rows, rows, MISPLAT_REC * rows, 12 * rows if want_aux else 0))
-    v_grec_zero = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32) if want_grad else None
-    v_abs_zero = torch.empty(rows, 2, device=dev, dtype=torch.float32) if (want_grad and absgrad) else None
+    # Every array of the call from ONE slot of a persistent ring (arena.py): the same call finds the same addresses every
+    # step -- an argument block recurs whenever its camera tensor does, so its hipGraph is replayed --, and the gather targets
+    # (records, lists) start on 2 MiB boundaries.  A slot is handed out again only when nothing refers to its storage.
+    cv = arena.Carver(("fwd", dev.index, _stream_id(), N, Cn, P.width, P.height, kd, int(want_grad), int(want_aux), int(absgrad),
+                       int(depth_channel)), dev)
+    means2d, depths, comps, sh_aux = _carve_f(dev, (2 * rows, rows, rows, 12 * rows if want_aux else 0), cv)
+    grec = cv.take(MISPLAT_REC * rows, torch.float32)
+    v_grec_zero = cv.take(MISPLAT_REC * rows, torch.float32).view(rows, MISPLAT_REC) if want_grad else None
+    v_abs_zero = cv.take(2 * rows, torch.float32).view(rows, 2) if (want_grad and absgrad) else None
     # (cell_count, cell_cursor, counters, tile_count back to back: the projection kernel clears that contiguous range -- no
     # memset, no clearing launch)
     (radii, tiles_per_gauss, rect2, cellhist, cell_count, cell_cursor, counters, tile_count, cell_offs, order, rect_sorted,
-     touched) = _carve(
+     touched, depth_sorted) = _carve(
         dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, n_cells, 4, n_tiles + 1, n_cells + 1, rows, 2 * rows,
-              (rows + 3) // 4 if want_grad else 0))
+              (rows + 3) // 4 if want_grad else 0, rows if INDEXED_BUCKETS else 0), cv)
     # one byte per row: cleared by the projection kernel, set by the compositing backward, read by the per-Gaussian
     # backward kernels (misplat_params.touched).  Only where the compositing backward is the ONLY source of the packed
     # gradient rows (the single autograd node): with the two-node form a loss on the projection's own outputs reaches the
@@ -715,12 +742,15 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     a.cell_offs, a.order, a.counters, a.tile_count = _dp(cell_offs), _dp(order), _dp(counters), _dp(tile_count)
     a.cell_cursor = _dp(cell_cursor)
     a.rect_sorted = _dp(rect_sorted)
+    # bucket entries = positions in the cell-ordered row list (the per-tile sort then gathers its depth keys locally)
+    a.depth_sorted = depth_sorted.view(torch.float32).data_ptr() if INDEXED_BUCKETS else None
     a.n_isects_host = host.data_ptr()
     # Gradient rows cleared on first touch (lazy_colour = 2) where the backward is going to read flagged rows only -- the
     # static part of raster.hip's background_fill_ok; the backward checks the actual plan and clears v_grec itself otherwise.
     rows_on_touch = bool(lazy and want_grad and flags and Cn == 1 and N >= SPARSE_BWD_MIN_ROWS and not want_aux and kd == 16
                          and ROWS_ON_TOUCH)
     a.lazy_colour = 2 if rows_on_touch else int(lazy)
+    row_order = order                                                 # (the cell-ordered row list; `order` below: the launch-order table)
     order = _order_table(P, dev)
     if order is not None:
         a.order_table, a.order_sel, a.order_slots, a.order_stride = (_dp(order[0]), _dp(order[1]),
@@ -730,9 +760,10 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
         check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
               "misplat_raster_fwd(A)")
     state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero, v_abs_zero=v_abs_zero,
-                 deferred=defer, rows_on_touch=rows_on_touch, order=order,
+                 deferred=defer, rows_on_touch=rows_on_touch, order=order, carver=cv,
                  counters=counters, touched=touched,
-                 keep=(rect2, cellhist, cell_count, cell_offs, order, counters, tile_count, radii, cell_cursor))
+                 keep=(rect2, cellhist, cell_count, cell_offs, row_order, counters, tile_count, radii, cell_cursor, depth_sorted),
+                 row_map=row_order, depth_sorted=depth_sorted.view(torch.float32) if INDEXED_BUCKETS else None)
     return (radii.view(Cn, N, 2), means2d.view(Cn, N, 2), depths.view(Cn, N), comps.view(Cn, N), grec.view(rows, MISPLAT_REC),
             sh_aux.view(rows, 12) if want_aux else None, state)
 
@@ -759,20 +790,23 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         cap = _quantise_cap(int(hint * CAP_MARGIN))
     if cap >= 2 ** 31:
         raise _lib.MisplatError(f"{cap} tile intersections exceed int32 indexing")
-    render, alpha, exp_depth, med_depth, normal = _carve_f(dev, (cd * n_pix, n_pix, n_pix, n_pix, 3 * n_pix))
-    sched = _UnitSchedule(P, dev, by_view=state.get("order"))
+    cv = state.get("carver")
+    render, alpha, exp_depth, med_depth, normal = _carve_f(dev, (cd * n_pix, n_pix, n_pix, n_pix, 3 * n_pix), cv)
+    sched = _UnitSchedule(P, dev, by_view=state.get("order"), cv=cv)
     by_view = sched.on and sched.by_view is not None
-    front = bool(by_view and not static and hint is not None and FRONT_ONLY != "0"
+    front = bool(by_view and not static and hint is not None and FRONT_ONLY != "0" and state.get("depth_sorted") is not None
                  and (FRONT_ONLY == "1" or hint >= FRONT_MIN_AVG * n_tiles))
     last_ids, median_ids, offsets, reach, front_n, tile_flag = _carve(
-        dev, (n_pix, n_pix, n_tiles + 2, n_tiles * BANDS if by_view else 0, n_tiles if front else 0, n_tiles if front else 0))
+        dev, (n_pix, n_pix, n_tiles + 2, n_tiles * BANDS if by_view else 0, n_tiles if front else 0, n_tiles if front else 0), cv)
     a.unit_reach = _dp(reach) if by_view else None
     a.front_n, a.tile_flag = (_dp(front_n), _dp(tile_flag)) if front else (None, None)
     a.front_margin, a.front_min_bucket = FRONT_MARGIN, FRONT_MIN_BUCKET
     PATH_STATS["forward_front_only"] += int(front)
 
     def isect_buffers(c):
-        return _carve(dev, (c, c, 2 * c))
+        if cv is None:
+            return _carve(dev, (c, c, 2 * c))
+        return cv.take(c, torch.int32), cv.take(c, torch.int32), cv.take(2 * c, torch.int32)
 
     payload, flatten_ids, scratch = isect_buffers(cap)
     a.color_dim = cd
@@ -827,6 +861,9 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
     if sched.on and sched.by_view is None:
         _LAST_ORDER[sched.key] = sched.perm
         sched.perm_bwd = sched.perm
+    if cv is not None:
+        cv.done()
+        PATH_STATS["forward_arena_slot"] += int(cv.slot is not None)
     bins = dict(tiles_per_gauss=state["tiles_per_gauss"], n_isects=cap if static else n_known, depths=state["depths"],
                 tile_ids=None, v_grec_zero=state.get("v_grec_zero"), v_abs_zero=state.get("v_abs_zero"),
                 rows_on_touch=bool(state.get("rows_on_touch")), n_isects_dev=state["counters"].view(torch.int64)[0] if static else None,
@@ -835,7 +872,8 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
                 # front-only ordering: flatten_ids holds the sorted head of every list (all the compositing and the
                 # backward read); complete_bins() sorts the rest when someone wants the whole lists
                 partial=(dict(cap=cap, offsets=offsets, payload=payload, scratch=scratch, flatten_ids=flatten_ids,
-                              front_n=front_n, tile_flag=tile_flag) if front else None))
+                              front_n=front_n, tile_flag=tile_flag, row_map=state["row_map"],
+                              depth_sorted=state["depth_sorted"]) if front else None))
     imgs = (render.view(Cn, H, W, cd), alpha.view(Cn, H, W, 1), exp_depth.view(Cn, H, W, 1), med_depth.view(Cn, H, W, 1),
             normal.view(Cn, H, W, 3), last_ids.view(Cn, H, W), median_ids.view(Cn, H, W))
     return imgs, bins, sched
@@ -908,23 +946,26 @@ class _RasterFused(torch.autograd.Function):
         dev = grec.device
         rows = P.n_cams * P.n_gauss
         ups = _upstream(P, cd, dev, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
+        # the gradients this call hands to autograd, from the backward's own arena ring (they may live on as `.grad` of the
+        # caller's parameters: the slot is reused when nothing refers to it any more -- arena.py)
+        cvb = arena.Carver(("bwd", dev.index, _stream_id(), P.n_gauss, P.n_cams, kd, int(colors_rest is not None), deg), dev)
         v_grec = bins.pop("v_grec_zero", None)
         flags = 1 if v_grec is not None else 0
         # (rows cleared on first touch by the forward: as good as cleared for a backward that reads flagged rows only)
         on_touch = bool(bins.get("rows_on_touch")) and v_grec is not None
         if v_grec is None:
-            v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
+            v_grec = cvb.take(rows * MISPLAT_REC, torch.float32).view(rows, MISPLAT_REC)
         v_abs = None
         if ctx.absgrad:
             v_abs = bins.pop("v_abs_zero", None)                # cleared by the forward's projection kernel
             if v_abs is None:
                 v_abs = torch.zeros(rows, 2, device=dev, dtype=torch.float32)
             flags |= 2
-        v_colors = _grad_out(colors)
-        v_colors_rest = _grad_out(colors_rest) if colors_rest is not None else None
-        v_means_dir = torch.empty_like(means) if deg >= 0 else None
-        v_means, v_quats = _grad_out(means), _grad_out(quats)
-        v_scales, v_opac = _grad_out(scales), _grad_out(opacities)
+        v_colors = _grad_out(colors, cvb)
+        v_colors_rest = _grad_out(colors_rest, cvb) if colors_rest is not None else None
+        v_means_dir = cvb.take(means.numel(), torch.float32).view(means.shape) if deg >= 0 else None
+        v_means, v_quats = _grad_out(means, cvb), _grad_out(quats, cvb)
+        v_scales, v_opac = _grad_out(scales, cvb), _grad_out(opacities, cvb)
         perm = ctx.sched.perm_bwd if ctx.sched is not None else None
         by_view = ctx.sched.by_view if ctx.sched is not None else None
         # (a data-parallel gradient sink only changes where the six outputs are written: the slices of its flat buffer are
@@ -956,7 +997,7 @@ class _RasterFused(torch.autograd.Function):
             # meta["means2d"].grad, when someone still holds meta["means2d"]: a tensor of its own in the flagged-rows
             # backward (v_grec may then be defined in flagged rows only), a slice of v_grec otherwise
             m2d_alive = ctx.means2d_ref() is not None
-            v_m2d = torch.empty(rows, 2, device=dev, dtype=torch.float32) if m2d_alive else None
+            v_m2d = cvb.take(rows * 2, torch.float32).view(rows, 2) if m2d_alive else None
             b.v_means2d_out = _dp(v_m2d)
             sparse = int(lib.misplat_raster_bwd_plan(C.byref(P), C.byref(b)) & 1)
             if not sparse:
@@ -1002,6 +1043,7 @@ class _RasterFused(torch.autograd.Function):
                                                ptr(comps), ptr(vm2d), ptr(v_grec), ptr(v_means_dir), ptr(v_means),
                                                ptr(v_quats), ptr(v_scales), ptr(v_opac), None, C.c_int32(0), stream_ptr()),
                   "misplat_project_pack_bwd")
+        cvb.done()
         # gsplat's contract: the screen-space gradient rides on meta["means2d"]
         m2d = ctx.means2d_ref()
         if m2d is not None:

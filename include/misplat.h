@@ -213,7 +213,9 @@ int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_i
                       const float* depths, const int32_t* isect_gid, int32_t* payload,
                       int32_t* flatten_ids, uint32_t* scratch, int32_t flags /* bit 1:
                       offsets[n_tiles_total + 1] holds the longest bucket (misplat_bucket_tiles writes it), so the
-                      launches of unused size classes return at once */, misplat_stream_t stream);
+                      launches of unused size classes return at once; bit 2: the payload holds positions in the cell-ordered
+                      row list (misplat_raster_args.depth_sorted): isect_gid = that list (row = isect_gid[entry], equal depths
+                      come out in ROW order), depths is indexed by the entry */, misplat_stream_t stream);
 
 /* ---- Cell-ordered bucketing (csrc/bucket.hip).  Replaces gsplat's isect_tiles +
  * radix sort + isect_offset_encode: every intersection is written once (its row) and no tile-id array exists.
@@ -485,6 +487,12 @@ typedef struct misplat_raster_args {
     int32_t *front_n, *tile_flag;
     float front_margin;
     int32_t front_min_bucket;
+    /* (or NULL) [C*N] floats: the bucket entries (payload) are then each row's POSITION in `order` (the cell-ordered row
+     * list) instead of the row, and depth_sorted[position] = depths[row] -- the per-tile sort gathers its keys from a few
+     * hundred KB around the tile instead of from all over depths[] (at 5 M Gaussians that gather was most of the sort's time).
+     * flatten_ids holds rows either way.  Sorting such a payload by hand: misplat_tile_sort(flags | 4, depths = depth_sorted,
+     * isect_gid = order).  Required by front_n. */
+    float* depth_sorted;
 } misplat_raster_args;
 /* Graph cache (optional, caller-owned, thread-safe; the library itself keeps no state): with a cache, the launch
  * sequence of a call is captured into a hipGraph the first time a given (params, args, phases, stream) block is seen
