@@ -81,6 +81,7 @@ def parse():
                          "intersection capacity (collab_splats_amd.graphs.GraphedStep) and time its replays: the "
                          "host-bound small configurations; not the default protocol")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-view", type=int, default=3, help="the rotated view the gradient check runs on besides view 0")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="Gaussians in the CPU-baseline sample")
     return ap.parse_args()
 
@@ -186,28 +187,76 @@ def rasterize_step(params, viewmats, Ks, W, H, args, ext: bool):
                          torch.sigmoid(params["opacity_logits"]), params["sh"], viewmats, Ks, W, H, **kw)
 
 
-def parity(args, params, viewmats, Ks, W, H, ext, ups_dev, gr, act, what: str):
+def parity(args, params, viewmats, Ks, W, H, ext, ups_dev, st, gr, act, what: str, cr, deterministic: bool = False):
     """The second half of the metric ("grad max-rel-err vs reference"): the gradients of the step the benchmark times --
     the same `rasterize_step` call on `params` (the benchmark's own leaves when the full workload is checked) -- against
     the C port (the checker; the upstream CUDA reference is absent: parity unpinned).
-    tensor-inf-norm relative error  max|g - g_ref| / max|g_ref|  per RAW parameter: the C port's gradients of the activated
-    scales / opacities are chained through exp / sigmoid (`act` = the activated values it was given)."""
+    Per RAW parameter (the C port's gradients of the activated scales / opacities are chained through exp / sigmoid, `act` =
+    the activated values it was given):
+      max_rel_err        tensor-inf-norm relative error  max|g - g_ref| / max|g_ref|  (first metric) over ALL rows
+      elementwise        max |d| / (|g_ref| + 1e-3 max|g_ref|)  (second metric) over the rows no flip touches
+      max_rel_err_clean  the first metric over the rows whose screen box covers no pixel that differs between the two
+                         implementations (a threshold flip: alpha = 1/255, T' = 1e-4, T = 0.5 -- tests/helpers.FlipProof)
+      rows_over / rows_flip   rows above 1e-4, and how many of those a proven flip explains (the rest would be a failure)
+    The five images and the two index maps are compared first: their differing pixels are the flips on record."""
     import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    from helpers import FlipProof                                  # (post-timing leg only: test infrastructure, like oracle/)
+    from collab_splats_amd import ops
     for p in params.values():
         p.grad = None
-    out = rasterize_step(params, viewmats, Ks, W, H, args, ext)
-    torch.autograd.backward(list(out[:5]), ups_dev)
-    torch.cuda.synchronize()
+    old_det = ops.DETERMINISTIC_BACKWARD
+    ops.set_deterministic(deterministic)
+    try:
+        out = rasterize_step(params, viewmats, Ks, W, H, args, ext)
+        torch.autograd.backward(list(out[:5]), ups_dev)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_deterministic(old_det)
     scales, op = act
     want = {"means": gr["v_means"], "quats": gr["v_quats"], "log_scales": gr["v_scales"] * scales,
             "opacity_logits": gr["v_opacities"] * op * (1.0 - op), "sh": gr["v_colors"]}
-
-    def rel(a, b):
-        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-        return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
-
-    errs = {k: rel(params[k].grad.cpu().numpy(), want[k]) for k in want}
-    return {"value": float(f"{max(errs.values()):.3e}"), "per_tensor": {k: float(f"{v:.3e}") for k, v in errs.items()},
+    proof = FlipProof(cr.blend_margin(st), st["proj"]["means2d"], st["proj"]["radii"])
+    fw, meta = st["fwd"], out[5]
+    flips = np.zeros(proof.low.shape, bool)
+    unexplained_px = 0
+    images = {}
+    for name, got, ref in (("render", out[0], st["render"]), ("alpha", out[1], fw["alpha"]), ("exp_depth", out[2], fw["exp_depth"]),
+                           ("med_depth", out[3], fw["med_depth"]), ("normal", out[4], fw["normal"])):
+        a, b = got[0].detach().cpu().numpy().astype(np.float64), np.asarray(ref, np.float64)
+        d = np.abs(a - b) / max(np.abs(b).max(), 1e-30)
+        bad = (d > 1e-4).reshape(d.shape[0], d.shape[1], -1).any(-1)
+        flips |= bad
+        unexplained_px += int((bad & ~proof.low).sum())
+        clean = d.reshape(d.shape[0], d.shape[1], -1).max(-1)[~bad]
+        images[name] = {"max_rel_err": float(f"{d.max():.3e}"), "pixels_over": int(bad.sum()),
+                        "max_rel_err_clean": float(f"{(clean.max() if clean.size else 0.0):.3e}")}
+    for key, got, ref in (("last_ids", meta["last_ids"], fw["last_ids"]), ("median_ids", meta["median_ids"], fw["median_ids"])):
+        diff = got[0].cpu().numpy() != np.asarray(ref)
+        flips |= diff
+        unexplained_px += int((diff & ~proof.low).sum())
+        images[key] = {"pixels_differ": int(diff.sum())}
+    proof.flipped |= flips
+    proof.pixel_checks += 1
+    n_rows = want["means"].shape[0]
+    touched = proof._box_counts(proof._sat(proof.flipped), np.arange(n_rows)) > 0          # rows whose box covers a flip
+    per, worst = {}, 0.0
+    for k, ref in want.items():
+        g = params[k].grad.cpu().numpy().astype(np.float64).reshape(n_rows, -1)
+        r = np.asarray(ref, np.float64).reshape(n_rows, -1)
+        scale = max(np.abs(r).max(), 1e-30)
+        d = np.abs(g - r)
+        row = d.max(1) / scale
+        over = row > 1e-4
+        clean = row[~touched]
+        elem = (d / (np.abs(r) + 1e-3 * scale))[~touched]
+        per[k] = {"max_rel_err": float(f"{row.max():.3e}"), "max_rel_err_clean": float(f"{(clean.max() if clean.size else 0.0):.3e}"),
+                  "elementwise": float(f"{(elem.max() if elem.size else 0.0):.3e}"), "rows_over": int(over.sum()),
+                  "rows_flip": int((over & touched).sum())}
+        worst = max(worst, row.max())
+    return {"value": float(f"{worst:.3e}"), "per_tensor": per, "images": images, "flip_pixels": int(flips.sum()),
+            "pixels_unexplained": unexplained_px, "rows_covering_a_flip": int(touched.sum()),
+            "gradient_mode": "deterministic (slab + fixed-order reduce)" if deterministic else "atomic (the timed mode)",
             "on": what, "call": "the timed step's own call (" + ("extension" if ext else "torch") + " activations), raw-parameter gradients",
             "against": "oracle/craster.c (fp32 C port; upstream gsplat-rade absent: parity unpinned)", "target": 1e-4}
 
@@ -373,6 +422,7 @@ def main():
         info["allreduce_ms"].clear()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
         fence()
+        info["graph0"] = ops.graph_cache_stats()                 # (host-side counters: no device work)
         t0 = time.perf_counter()
         for e0, e1 in evs:
             e0.record()
@@ -380,6 +430,7 @@ def main():
             e1.record()
         fence()
         dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+        info["graph1"] = ops.graph_cache_stats()
         dev_ms = sorted(a.elapsed_time(b) for a, b in evs)
         return dt, dev_ms[len(dev_ms) // 2]
 
@@ -398,6 +449,11 @@ def main():
     stats0 = dict(ops.PATH_STATS)
     dt, dev_med = timed(step, args.steps, args.warmup)
     took = {k: ops.PATH_STATS[k] - stats0.get(k, 0) for k in ops.PATH_STATS}
+    # graph replays inside the TIMED region of the headline (after the warm-up): a step goes through the cache twice (one
+    # merged forward call, one backward call)
+    g0, g1 = info["graph0"], info["graph1"]
+    graph_timed = {"hits": g1["hits"] - g0["hits"], "captures": g1["captures"] - g0["captures"], "calls": 2 * args.steps}
+    graph_timed["hit_rate"] = round(graph_timed["hits"] / max(graph_timed["calls"], 1), 4)
     headline_mode = dict(mode)
     if graphed is not None:
         graphed.check()                            # the fixed capacity held for every replay
@@ -491,11 +547,13 @@ def main():
             "variants": variants,
             "config": {"workload": wl, "views": 1 if headline_mode["fixed"] else 8, "n_isects": I, "n_isects_per_view": isects[:8],
                        "n_visible": n_vis, "parallelism": par,
-                       "git_rev": git_rev(), "graph_cache": ops.graph_cache_stats(),
+                       "git_rev": git_rev(), "graph_cache": ops.graph_cache_stats(), "graph_cache_timed": graph_timed,
+                       "graph_hit_rate": graph_timed["hit_rate"], "arena": dict(__import__("collab_splats_amd.arena", fromlist=["STATS"]).STATS),
                        "path": {k: took.get(k, 0) for k in ("forward", "forward_lazy_colour", "forward_merged_phases",
                                                            "forward_view_order", "forward_prev_order", "capacity_redo", "backward_one_call",
                                                            "backward_background_fill", "backward_staged", "backward_sink",
-                                                           "forward_rows_on_touch", "backward_rows_refilled")},
+                                                           "forward_rows_on_touch", "backward_rows_refilled", "forward_front_only",
+                                                           "forward_arena_slot")},
                        "path_note": f"counts over the {args.steps + args.warmup} headline steps: on-demand colours, merged "
                                     "phases, view-keyed launch order, capacity misses, one-call backward, background fill, gradient rows cleared on touch",
                        "host": (f"whole step replayed as one hipGraph (graphs.GraphedStep, fixed capacity "
@@ -548,9 +606,23 @@ def main():
                    torch.sigmoid(params_p["opacity_logits"]).detach().cpu().numpy())
             gcpu = torch.Generator().manual_seed(7)
             ups_np = [torch.rand(s, generator=gcpu) for s in ((1, H, W, cd), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3))]
-            _, gr = _c_port_run(cr, sc_p, act[0], act[1], W, H, args, [u[0].numpy() for u in ups_np])
-            line["grad_max_rel_err"] = parity(args, params_p, views[0], Ks, W, H, headline_mode["ext"],
-                                              [u.to(dev) for u in ups_np], gr, act, what)
+            ups_d = [u.to(dev) for u in ups_np]
+            # view 0 (the generator's identity view) AND the heaviest of the rotated views the headline cycles through
+            # (seven of its eight views are rotated; view 3 stages ~40 % more entries per band than view 0)
+            per_view = {}
+            for v in (0, args.parity_view):
+                sc_v = dict(sc_p, viewmats=view_matrix(v))
+                st, gr = _c_port_run(cr, sc_v, act[0], act[1], W, H, args, [u[0].numpy() for u in ups_np])
+                per_view[f"view{v}"] = parity(args, params_p, views[v], Ks, W, H, headline_mode["ext"], ups_d, st, gr, act,
+                                              what.replace("view 0", f"view {v}"), cr)
+                if v == 0:
+                    # what the largest figure (means) is made of: the same call with the bitwise-reproducible backward (slab +
+                    # fixed-order reduce) -- if the error stays, it is not the order of the atomic sums
+                    det = parity(args, params_p, views[v], Ks, W, H, headline_mode["ext"], ups_d, st, gr, act, what, cr, deterministic=True)
+                    per_view["view0_deterministic"] = {k: det[k] for k in ("value", "per_tensor", "gradient_mode")}
+            head = per_view["view0"]
+            line["grad_max_rel_err"] = dict(head, views=per_view,
+                                            value=float(f"{max(pv['value'] for k, pv in per_view.items() if not k.endswith('deterministic')):.3e}"))
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

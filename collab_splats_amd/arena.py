@@ -5,7 +5,7 @@ Taken from PyTorch's caching allocator they land wherever it has room: the launc
 differ in a dozen pointers (a hipGraph captured for one step is useless for the next: DESIGN.md section 8), and the 64-byte
 record gathers of the compositing kernels run 10 - 15 % slower in some placements than in others (section 13.7).  So the
 arrays of a call are carved from ONE persistent slot of a ring kept per (device, stream, shape): the same call gets the same
-addresses every time, every array of >= 1 MiB starts on a 2 MiB boundary of a 2 MiB-aligned slot.
+addresses every time (the placement of the arrays inside a slot: see ALIGN_BIG below -- measured, not assumed).
 
 Ownership: the tensors handed out are views of the slot's storage, and a slot is handed out again only when NOTHING refers to
 its storage any more (``torch._C._storage_Use_Count``: outputs the caller still holds, tensors saved for a backward that has not
@@ -25,8 +25,15 @@ from torch import Tensor
 ENABLED = os.environ.get("MISPLAT_ARENA", "1") == "1"
 MAX_SLOTS = int(os.environ.get("MISPLAT_ARENA_SLOTS", "4"))
 MAX_RINGS = int(os.environ.get("MISPLAT_ARENA_RINGS", "12"))      # distinct (stream, shape, role) keys kept; LRU beyond
-BIG = 1 << 20                     # arrays from this size on start on a 2 MiB boundary
-ALIGN_BIG = 2 << 20
+# Placement inside a slot.  Measured (5 M Gaussians / 1080p, one box): with every array of >= 1 MiB on a 2 MiB boundary
+# the kernels that write several arrays at the same element offset (bucket_rows: order / rect_sorted / depth_sorted at
+# [pos]) ran 2 x slower (74 -> 182 us; their streams then map to the same memory channels) and the step lost 0.1 ms; the
+# 1 M step lost 4 %.  So arrays are packed at 256-byte granularity, as a one-allocation carve always was -- what the arena
+# contributes is that the addresses REPEAT (graph replay), not where they are.  MISPLAT_ARENA_ALIGN_MB > 0 restores the
+# aligned placement of big arrays for an A/B.
+BIG = 1 << 20
+ALIGN_SLOT = 2 << 20              # the slot itself starts on a 2 MiB boundary
+ALIGN_BIG = int(float(os.environ.get("MISPLAT_ARENA_ALIGN_MB", "0")) * (1 << 20)) or 256
 ALIGN_SMALL = 256
 STATS: "collections.Counter" = collections.Counter()             # slots_created / slot_hits / fallbacks / regrown
 
@@ -39,8 +46,8 @@ class Slot:
 
     def __init__(self, dev: torch.device, nbytes: int):
         self.size = int(nbytes)
-        self.raw = torch.empty(self.size + ALIGN_BIG, device=dev, dtype=torch.uint8)
-        shift = (-self.raw.data_ptr()) % ALIGN_BIG
+        self.raw = torch.empty(self.size + ALIGN_SLOT, device=dev, dtype=torch.uint8)
+        shift = (-self.raw.data_ptr()) % ALIGN_SLOT
         self.base = self.raw[shift:shift + self.size]
         self.storage = self.raw.untyped_storage()                 # (kept: the use count below then has a fixed floor)
         self.floor = self._count()                                # raw + base + the storage wrapper
@@ -98,7 +105,7 @@ class Ring:
 
     @staticmethod
     def _padded(n: int) -> int:
-        return (int(n * 1.10) + ALIGN_BIG - 1) // ALIGN_BIG * ALIGN_BIG   # head room: capacities drift by a few percent
+        return (int(n * 1.10) + ALIGN_SLOT - 1) // ALIGN_SLOT * ALIGN_SLOT   # head room: capacities drift by a few percent
 
     def release(self, slot: Optional[Slot], demand: int) -> None:
         """What the call asked for in total (also when it had no slot): the next slot of this ring is sized for it."""

@@ -814,7 +814,10 @@ static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_i
     // tiles in parallel first (tile_range), so an unused class costs a few microseconds.
     // (n_isects may be the CAPACITY of a speculative launch, about 1.25 x the real count: 4 / 5 of it is the estimate)
     const int64_t avg = n_isects / n_tiles * 4 / 5;
-    const int full = n_tiles < 65536 ? n_tiles : 65536;
+    // (behind the front kernel most tiles are done: a workgroup per tile would be ~8 000 workgroups of up to 1 024 threads
+    // and 64 KB of LDS that start, read two words and leave -- 16 dispatch rounds, 31 us at 5 M Gaussians; 1 024 workgroups
+    // test their 8 tiles in parallel and leave at once, or sort the few that are left; a view's first visit, when ALL are left, runs ~1.5 x slower here)
+    const int full = sel.mode == 1 ? (n_tiles < 1024 ? n_tiles : 1024) : (n_tiles < 65536 ? n_tiles : 65536);
     const int few = n_tiles < 256 ? n_tiles : 256;
     // A class the typical bucket (n_isects / n_tiles) can reach gets a grid of its own, one workgroup per tile; every other
     // class goes through ONE more launch (tile_sort_rest_kernel): a 1 M scene is two launches (was four), a 5 M one three.

@@ -145,22 +145,34 @@ __global__ __launch_bounds__(kCountThreads) void bucket_count_kernel(
 }
 
 // ---- 2. visible rows -> cell order (the slices of pass 1 again).  Every workgroup scans the (at most 2 048) global cell
-// counts itself -- two per thread, a few hundred instructions, instead of a one-workgroup launch in front of this kernel --,
-// reserves its range of each cell with one returning atomic on a cursor array and takes positions inside the range from an
-// LDS cursor.  Workgroup 0 also publishes what the host and the later kernels need: cell_offs, counters[1] = visible
-// rows, and the intersection count as a system-scope store into the caller's pinned slot (no copy node in the stream).
+// counts itself -- two per thread, a few hundred instructions, instead of a one-workgroup launch in front of this kernel --
+// and reserves its range of each cell with one returning atomic on a cursor array.  Workgroup 0 also publishes what the
+// host and the later kernels need: cell_offs, counters[1] = visible rows, and the intersection count as a system-scope
+// store into the caller's pinned slot (no copy node in the stream).
+// Round 4: the rows leave through LDS IN CELL ORDER.  A thread used to store its row at the next free position of its
+// cell as it met it: a wave's 64 stores went to ~64 different cache lines, three partial-line streams (order, rect_sorted,
+// depth_sorted) of 4 - 8 bytes each -- measured at 5 M Gaussians, every such scattered 4-byte stream costs ~100 us (a
+// random gather of the same elements costs the same: the fabric moves whole lines).  Now a workgroup takes its rows in
+// chunks of 16 384: ranks them inside (chunk, cell) with an LDS counter, scans the chunk's cell counts, lays the chunk out
+// by cell in LDS, and writes it from there -- consecutive threads write consecutive positions of a cell's range.
+constexpr int kRowsChunk = 16 * kCountThreads;
+constexpr uint32_t kRowNone = 0xffffffffu;
 __global__ __launch_bounds__(kCountThreads) void bucket_rows_kernel(
     int64_t total, int n_gauss, int shift, int cells_x, int cells_per_cam, int n_cells, int rows_per_block,
     const int32_t* __restrict__ tiles_per_gauss, const uint2* __restrict__ rect2, const uint32_t* __restrict__ cellhist,
     const uint32_t* __restrict__ cell_count, uint32_t* __restrict__ cell_offs, uint32_t* __restrict__ cell_cursor,
     int32_t* __restrict__ order, uint2* __restrict__ rect_sorted, int64_t* __restrict__ counters,
     long long* __restrict__ n_isects_host, const float* __restrict__ depths, float* __restrict__ depth_sorted) {
-    __shared__ uint32_t base[MISPLAT_BUCKET_MAX_CELLS];
+    __shared__ uint32_t base[MISPLAT_BUCKET_MAX_CELLS];          // global position of this workgroup's next row of the cell
+    __shared__ uint32_t cnt[MISPLAT_BUCKET_MAX_CELLS];           // rows of the cell in the current chunk
+    __shared__ uint32_t start[MISPLAT_BUCKET_MAX_CELLS];         // their first slot in sorted[]
+    __shared__ uint32_t sorted[kRowsChunk];                      // the chunk in cell order: row in chunk | cell << 14
     __shared__ uint32_t wsum[kCountThreads / 64];
     static_assert(2 * kCountThreads >= MISPLAT_BUCKET_MAX_CELLS, "two cells per thread");
+    static_assert(kRowsChunk <= (1 << 14) && MISPLAT_BUCKET_MAX_CELLS <= (1 << 11), "packing of sorted[]");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c0 = 2 * threadIdx.x, c1 = c0 + 1;
     {
-        const int c0 = 2 * threadIdx.x, c1 = c0 + 1;
         const uint32_t a = c0 < n_cells ? cell_count[c0] : 0u, b2 = c1 < n_cells ? cell_count[c1] : 0u;
         const uint32_t incl = wave_scan_add(a + b2);
         if (lane == 63) wsum[wave] = incl;
@@ -186,19 +198,66 @@ __global__ __launch_bounds__(kCountThreads) void bucket_rows_kernel(
         const uint32_t h = cellhist[(size_t)blockIdx.x * n_cells + c];
         base[c] = h ? base[c] + atomicAdd(&cell_cursor[c], h) : 0u;
     }
-    __syncthreads();
     const int64_t beg = (int64_t)blockIdx.x * rows_per_block;
     const int64_t end = beg + rows_per_block < total ? beg + rows_per_block : total;
-    for (int64_t idx = beg + threadIdx.x; idx < end; idx += kCountThreads) {
-        if (tiles_per_gauss[idx] > 0) {
-            const uint2 r2 = rect2[idx];
-            const int c = cell_of(r2.x, r2.y, (int)(idx / n_gauss), shift, cells_x, cells_per_cam);
-            const uint32_t pos = atomicAdd(&base[c], 1u);        // LDS cursor: any order inside a cell will do
+    for (int64_t cb = beg; cb < end; cb += kRowsChunk) {
+        for (int c = threadIdx.x; c < n_cells; c += kCountThreads) cnt[c] = 0u;
+        __syncthreads();                                         // (also: base[] of the prologue / the previous chunk)
+        // rank of every visible row inside its (chunk, cell)
+        uint32_t pk[kRowsChunk / kCountThreads];                 // cell | rank << 11, or none
+        int32_t tpg[kRowsChunk / kCountThreads];
+#pragma unroll
+        for (int u = 0; u < kRowsChunk / kCountThreads; u++) {
+            const int64_t idx = cb + u * kCountThreads + threadIdx.x;
+            tpg[u] = idx < end ? tiles_per_gauss[idx] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kRowsChunk / kCountThreads; u++) {
+            pk[u] = kRowNone;
+            if (tpg[u] > 0) {
+                const int64_t idx = cb + u * kCountThreads + threadIdx.x;
+                const uint2 r2 = rect2[idx];
+                const int c = cell_of(r2.x, r2.y, (int)(idx / n_gauss), shift, cells_x, cells_per_cam);
+                pk[u] = (uint32_t)c | (atomicAdd(&cnt[c], 1u) << 11);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the chunk's cell counts (two cells per thread)
+        uint32_t n_chunk;
+        {
+            const uint32_t a = c0 < n_cells ? cnt[c0] : 0u, b2 = c1 < n_cells ? cnt[c1] : 0u;
+            const uint32_t incl = wave_scan_add(a + b2);
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t carry = 0u;
+            n_chunk = 0u;
+#pragma unroll
+            for (int w = 0; w < kCountThreads / 64; w++) { carry += (w < wave) ? wsum[w] : 0u; n_chunk += wsum[w]; }
+            const uint32_t e = carry + incl - (a + b2);
+            if (c0 < n_cells) start[c0] = e;
+            if (c1 < n_cells) start[c1] = e + a;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kRowsChunk / kCountThreads; u++)
+            if (pk[u] != kRowNone) {
+                const uint32_t c = pk[u] & 2047u;
+                sorted[start[c] + (pk[u] >> 11)] = (uint32_t)(u * kCountThreads + threadIdx.x) | (c << 14);
+            }
+        __syncthreads();
+        // out, in cell order: consecutive threads write consecutive positions of a cell's range
+        for (uint32_t k = threadIdx.x; k < n_chunk; k += kCountThreads) {
+            const uint32_t e = sorted[k];
+            const uint32_t c = e >> 14;
+            const int64_t idx = cb + (int64_t)(e & 16383u);
+            const uint32_t pos = base[c] + (k - start[c]);
             order[pos] = (int32_t)idx;
-            rect_sorted[pos] = r2;                               // the tile passes read rectangles without a gather
+            rect_sorted[pos] = rect2[idx];                       // the tile passes read rectangles without a gather
             // (and the per-tile sort its depth keys: bucket entries are positions in order[] then -- bucket_tile_fill_kernel)
             if (depth_sorted) depth_sorted[pos] = depths[idx];
         }
+        __syncthreads();
+        for (int c = threadIdx.x; c < n_cells; c += kCountThreads) base[c] += cnt[c];
     }
 }
 

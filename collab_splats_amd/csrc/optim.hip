@@ -112,3 +112,167 @@ extern "C" int misplat_adam_step(int32_t n_tensors, float* const* params, const 
                        (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps);
     return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
 }
+
+// ---- shared-Gaussian gradient reduce that moves only the rows that HAVE a gradient (parallel.GradientBuckets; SURVEY.md
+// section 8(e) "sparse alternative") -------------------------------------------------------------------------------------
+// Data-parallel training sums 236 B per Gaussian over the ranks (the gradient set of
+// /root/reference/collab_splats/configs/rade_gs_method.py:44-71), but a view's backward reaches few of them: 11 % of the
+// rows of the 1 M scene, 2 % at 5 M (the compositing stops at the first opaque layers), and the compositing backward already
+// flags them (misplat_params.touched).  So: every rank turns its flags into a bitmap (N / 8 bytes), the bitmaps are
+// all-gathered and OR-ed, the union's row ids are listed once (the same list on every rank), the rows are packed into
+// [|union|, W] floats, reduced, and scattered back.  All streaming; the host reads one number (|union|).
+namespace {
+
+constexpr int kBitsBlock = 256;                           // bitmap bytes per workgroup = 2 048 rows
+
+__global__ __launch_bounds__(256) void touched_bits_kernel(const uint8_t* __restrict__ flags, int64_t n, uint8_t* __restrict__ bits,
+                                                           int64_t nbytes) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nbytes) return;
+    const int64_t r0 = b * 8;
+    uint32_t v = 0u;
+    if (r0 + 8 <= n) {
+        const uint2 w = *reinterpret_cast<const uint2*>(flags + r0);       // 8 flags (the flag array is 8-byte aligned)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v |= ((w.x >> (8 * k)) & 0xffu) ? (1u << k) : 0u;
+            v |= ((w.y >> (8 * k)) & 0xffu) ? (1u << (4 + k)) : 0u;
+        }
+    } else {
+        for (int k = 0; k < 8; k++)
+            if (r0 + k < n && flags[r0 + k]) v |= 1u << k;
+    }
+    bits[b] = (uint8_t)v;
+}
+
+__device__ __forceinline__ uint32_t union_byte(const uint8_t* __restrict__ gathered, int world, int64_t nbytes, int64_t b) {
+    uint32_t v = 0u;
+    if (b < nbytes)
+        for (int w = 0; w < world; w++) v |= gathered[(int64_t)w * nbytes + b];
+    return v;
+}
+
+__device__ __forceinline__ uint32_t block_scan_excl(uint32_t x, uint32_t* wsum, uint32_t& total) {   // 256 threads
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = x;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0u;
+    total = 0u;
+#pragma unroll
+    for (int w = 0; w < 4; w++) { before += (w < wave) ? wsum[w] : 0u; total += wsum[w]; }
+    return before + incl - x;
+}
+
+__global__ __launch_bounds__(256) void union_count_kernel(const uint8_t* __restrict__ gathered, int world, int64_t nbytes,
+                                                          int32_t* __restrict__ block_counts) {
+    __shared__ uint32_t wsum[4];
+    const uint32_t v = union_byte(gathered, world, nbytes, (int64_t)blockIdx.x * kBitsBlock + threadIdx.x);
+    uint32_t total;
+    (void)block_scan_excl((uint32_t)__popc(v), wsum, total);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = (int32_t)total;
+}
+
+__global__ __launch_bounds__(256) void union_ids_kernel(const uint8_t* __restrict__ gathered, int world, int64_t nbytes,
+                                                        const int64_t* __restrict__ block_offsets, int32_t* __restrict__ ids) {
+    __shared__ uint32_t wsum[4];
+    const int64_t b = (int64_t)blockIdx.x * kBitsBlock + threadIdx.x;
+    uint32_t v = union_byte(gathered, world, nbytes, b);
+    uint32_t total;
+    int64_t pos = block_offsets[blockIdx.x] + (int64_t)block_scan_excl((uint32_t)__popc(v), wsum, total);
+    while (v) {
+        const int k = __ffs((int)v) - 1;
+        ids[pos++] = (int32_t)(b * 8 + k);
+        v &= v - 1u;
+    }
+}
+
+struct RowTable {
+    float* p[MISPLAT_ROWS_MAX_TENSORS];
+    int32_t width[MISPLAT_ROWS_MAX_TENSORS];
+    int32_t first[MISPLAT_ROWS_MAX_TENSORS + 1];          // column range of every tensor inside a packed row
+    int32_t count, W;
+};
+
+template <bool PACK>
+__global__ __launch_bounds__(256) void rows_move_kernel(RowTable T, const int32_t* __restrict__ ids, int64_t n_ids,
+                                                        float* __restrict__ packed) {
+    const int64_t total = n_ids * T.W;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t u = i / T.W;
+        const int c = (int)(i - u * T.W);
+        int t = 0;
+#pragma unroll
+        for (int k = 1; k < MISPLAT_ROWS_MAX_TENSORS; k++)
+            if (k < T.count && c >= T.first[k]) t = k;
+        float* q = T.p[t] + (int64_t)ids[u] * T.width[t] + (c - T.first[t]);
+        if (PACK) packed[i] = *q;
+        else *q = packed[i];
+    }
+}
+
+int rows_move(bool pack, int32_t n_tensors, float* const* tensors, const int32_t* widths, const int32_t* ids, int64_t n_ids,
+              float* packed, hipStream_t s) {
+    if (n_tensors < 1 || n_tensors > MISPLAT_ROWS_MAX_TENSORS || !tensors || !widths || n_ids < 0) return MISPLAT_EINVAL;
+    if (n_ids == 0) return MISPLAT_OK;
+    if (!ids || !packed) return MISPLAT_EINVAL;
+    RowTable T;
+    int W = 0;
+    for (int i = 0; i < n_tensors; i++) {
+        if (!tensors[i] || widths[i] < 1) return MISPLAT_EINVAL;
+        T.p[i] = tensors[i]; T.width[i] = widths[i]; T.first[i] = W;
+        W += widths[i];
+    }
+    for (int i = n_tensors; i <= MISPLAT_ROWS_MAX_TENSORS; i++) T.first[i] = W;
+    for (int i = n_tensors; i < MISPLAT_ROWS_MAX_TENSORS; i++) { T.p[i] = nullptr; T.width[i] = 0; }
+    T.count = n_tensors; T.W = W;
+    int64_t blocks = (n_ids * W + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    if (pack) hipLaunchKernelGGL(rows_move_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, T, ids, n_ids, packed);
+    else hipLaunchKernelGGL(rows_move_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, T, ids, n_ids, packed);
+    return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" int misplat_touched_bits(const uint8_t* flags, int64_t n_rows, uint8_t* bits, misplat_stream_t stream) {
+    if (n_rows < 0 || (n_rows > 0 && (!flags || !bits)) || (((uintptr_t)flags) & 7)) return MISPLAT_EINVAL;
+    const int64_t nbytes = (n_rows + 7) / 8;
+    if (nbytes == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(touched_bits_kernel, dim3((unsigned)((nbytes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, flags, n_rows,
+                       bits, nbytes);
+    return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+}
+
+extern "C" int misplat_union_count(const uint8_t* gathered, int32_t world, int64_t nbytes, int32_t* block_counts,
+                                   misplat_stream_t stream) {
+    if (world < 1 || nbytes < 0 || (nbytes > 0 && (!gathered || !block_counts))) return MISPLAT_EINVAL;
+    if (nbytes == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(union_count_kernel, dim3((unsigned)((nbytes + kBitsBlock - 1) / kBitsBlock)), dim3(256), 0,
+                       (hipStream_t)stream, gathered, (int)world, nbytes, block_counts);
+    return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+}
+
+extern "C" int misplat_union_ids(const uint8_t* gathered, int32_t world, int64_t nbytes, const int64_t* block_offsets,
+                                 int32_t* ids, misplat_stream_t stream) {
+    if (world < 1 || nbytes < 0 || (nbytes > 0 && (!gathered || !block_offsets || !ids))) return MISPLAT_EINVAL;
+    if (nbytes == 0) return MISPLAT_OK;
+    hipLaunchKernelGGL(union_ids_kernel, dim3((unsigned)((nbytes + kBitsBlock - 1) / kBitsBlock)), dim3(256), 0,
+                       (hipStream_t)stream, gathered, (int)world, nbytes, block_offsets, ids);
+    return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+}
+
+extern "C" int misplat_rows_pack(int32_t n_tensors, const float* const* srcs, const int32_t* widths, const int32_t* ids,
+                                 int64_t n_ids, float* packed, misplat_stream_t stream) {
+    return rows_move(true, n_tensors, (float* const*)srcs, widths, ids, n_ids, packed, (hipStream_t)stream);
+}
+
+extern "C" int misplat_rows_unpack(int32_t n_tensors, float* const* dsts, const int32_t* widths, const int32_t* ids,
+                                   int64_t n_ids, const float* packed, misplat_stream_t stream) {
+    return rows_move(false, n_tensors, dsts, widths, ids, n_ids, (float*)packed, (hipStream_t)stream);
+}

@@ -697,6 +697,15 @@ def _lazy_colour_ok(P: Params, dev, deg: int, kd: int, n_color: int, want_grad: 
     return hint is not None and hint >= LAZY_SH_MIN_BUCKET * P.tile_w * P.tile_h * P.n_cams
 
 
+def _front_only_wanted(P: Params, dev) -> bool:
+    """Front-only ordering for this call?  Needs the view-keyed records (pivots), a capacity hint (the typical bucket) and
+    an eager, non-static call; decided before phase A, which then also lays the buckets out for it (INDEXED_BUCKETS)."""
+    if FRONT_ONLY == "0" or _STATIC_CAP is not None or not (SPECULATE and UNIT_ORDER and UNIT_ORDER_FWD and ORDER_BY_VIEW):
+        return False
+    hint = _CAP_HINT.get(_cap_key(P, dev))
+    return hint is not None and (FRONT_ONLY == "1" or hint >= FRONT_MIN_AVG * P.tile_w * P.tile_h * P.n_cams)
+
+
 def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg: int, kd: int,
                     n_color: int, per_cam: int, depth_channel: bool, want_aux: bool, want_grad: bool, defer: bool = False,
                     lazy: bool = False, flags: bool = False, absgrad: bool = False):
@@ -711,8 +720,11 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     # Every array of the call from ONE slot of a persistent ring (arena.py): the same call finds the same addresses every
     # step -- an argument block recurs whenever its camera tensor does, so its hipGraph is replayed --, and the gather targets
     # (records, lists) start on 2 MiB boundaries.  A slot is handed out again only when nothing refers to its storage.
+    # (bucket entries as positions in the cell-ordered row list: pays where the per-tile sort's depth gather misses the L2 --
+    # dense scenes, i.e. together with front-only ordering; at 1 M Gaussians it costs the sort a second gather: 55 -> 86 us)
+    indexed = INDEXED_BUCKETS and _front_only_wanted(P, dev)
     cv = arena.Carver(("fwd", dev.index, _stream_id(), N, Cn, P.width, P.height, kd, int(want_grad), int(want_aux), int(absgrad),
-                       int(depth_channel)), dev)
+                       int(depth_channel), int(indexed)), dev)
     means2d, depths, comps, sh_aux = _carve_f(dev, (2 * rows, rows, rows, 12 * rows if want_aux else 0), cv)
     grec = cv.take(MISPLAT_REC * rows, torch.float32)
     v_grec_zero = cv.take(MISPLAT_REC * rows, torch.float32).view(rows, MISPLAT_REC) if want_grad else None
@@ -722,7 +734,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     (radii, tiles_per_gauss, rect2, cellhist, cell_count, cell_cursor, counters, tile_count, cell_offs, order, rect_sorted,
      touched, depth_sorted) = _carve(
         dev, (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, n_cells, 4, n_tiles + 1, n_cells + 1, rows, 2 * rows,
-              (rows + 3) // 4 if want_grad else 0, rows if INDEXED_BUCKETS else 0), cv)
+              (rows + 3) // 4 if want_grad else 0, rows if indexed else 0), cv)
     # one byte per row: cleared by the projection kernel, set by the compositing backward, read by the per-Gaussian
     # backward kernels (misplat_params.touched).  Only where the compositing backward is the ONLY source of the packed
     # gradient rows (the single autograd node): with the two-node form a loss on the projection's own outputs reaches the
@@ -743,7 +755,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     a.cell_cursor = _dp(cell_cursor)
     a.rect_sorted = _dp(rect_sorted)
     # bucket entries = positions in the cell-ordered row list (the per-tile sort then gathers its depth keys locally)
-    a.depth_sorted = depth_sorted.view(torch.float32).data_ptr() if INDEXED_BUCKETS else None
+    a.depth_sorted = depth_sorted.view(torch.float32).data_ptr() if indexed else None
     a.n_isects_host = host.data_ptr()
     # Gradient rows cleared on first touch (lazy_colour = 2) where the backward is going to read flagged rows only -- the
     # static part of raster.hip's background_fill_ok; the backward checks the actual plan and clears v_grec itself otherwise.
@@ -763,7 +775,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
                  deferred=defer, rows_on_touch=rows_on_touch, order=order, carver=cv,
                  counters=counters, touched=touched,
                  keep=(rect2, cellhist, cell_count, cell_offs, row_order, counters, tile_count, radii, cell_cursor, depth_sorted),
-                 row_map=row_order, depth_sorted=depth_sorted.view(torch.float32) if INDEXED_BUCKETS else None)
+                 row_map=row_order, depth_sorted=depth_sorted.view(torch.float32) if indexed else None)
     return (radii.view(Cn, N, 2), means2d.view(Cn, N, 2), depths.view(Cn, N), comps.view(Cn, N), grec.view(rows, MISPLAT_REC),
             sh_aux.view(rows, 12) if want_aux else None, state)
 
@@ -794,8 +806,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
     render, alpha, exp_depth, med_depth, normal = _carve_f(dev, (cd * n_pix, n_pix, n_pix, n_pix, 3 * n_pix), cv)
     sched = _UnitSchedule(P, dev, by_view=state.get("order"), cv=cv)
     by_view = sched.on and sched.by_view is not None
-    front = bool(by_view and not static and hint is not None and FRONT_ONLY != "0" and state.get("depth_sorted") is not None
-                 and (FRONT_ONLY == "1" or hint >= FRONT_MIN_AVG * n_tiles))
+    front = bool(by_view and not static and hint is not None and state.get("depth_sorted") is not None)   # (_front_only_wanted)
     last_ids, median_ids, offsets, reach, front_n, tile_flag = _carve(
         dev, (n_pix, n_pix, n_tiles + 2, n_tiles * BANDS if by_view else 0, n_tiles if front else 0, n_tiles if front else 0), cv)
     a.unit_reach = _dp(reach) if by_view else None
@@ -869,6 +880,8 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
                 rows_on_touch=bool(state.get("rows_on_touch")), n_isects_dev=state["counters"].view(torch.int64)[0] if static else None,
                 n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:cap if static else n_known],
                 isect_offsets=offsets[:n_tiles + 1], _keep=(scratch, payload, reach),
+                # one byte per row, set by the atomic compositing backward for the rows it adds a gradient to
+                touched=(state["touched"].view(torch.uint8)[:P.n_gauss * Cn] if P.touched else None),
                 # front-only ordering: flatten_ids holds the sorted head of every list (all the compositing and the
                 # backward read); complete_bins() sorts the rest when someone wants the whole lists
                 partial=(dict(cap=cap, offsets=offsets, payload=payload, scratch=scratch, flatten_ids=flatten_ids,
@@ -1011,7 +1024,8 @@ class _RasterFused(torch.autograd.Function):
             PATH_STATS["backward_background_fill"] += sparse
             if GRAD_SINK is not None:
                 PATH_STATS["backward_sink"] += 1
-                GRAD_SINK.rasterizer_done()
+                # (the row flags let the data-parallel reduce move only the rows that have a gradient: parallel.py)
+                GRAD_SINK.rasterizer_done(bins.get("touched") if P.n_cams == 1 else None)
         else:
             # a gradient that reached means2d from another consumer: stage by stage
             PATH_STATS["backward_staged"] += 1

@@ -40,6 +40,52 @@ def shard_views(n_views: int, rank: int, world: int) -> List[int]:
     return list(range(start, start + base + (1 if rank < rem else 0)))
 
 
+# How the shared-Gaussian gradients travel.
+#   MISPLAT_SPARSE_REDUCE  "auto" (default): when the rasterizer's row flags are there and the union of the ranks' touched
+#                          rows is at most SPARSE_MAX_FRACTION of the Gaussians, only those rows are reduced (236 B x |union|
+#                          instead of 236 B x N: a view's backward reaches 2 % of the rows at 5 M, 11 % at 1 M); "1": whenever
+#                          the flags are there; "0": always the dense buffer.
+#   MISPLAT_ALLREDUCE      "auto": one ``all_reduce`` per bucket, algorithm left to RCCL; "rs_ag": an explicit
+#                          ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` -- every rank exchanges 1/world of the
+#                          buffer with every peer at once, the pattern that uses all 7 xGMI links of a GPU (~1.9 ms for
+#                          1.18 GB where a per-link-bound ring takes ~13.5 ms) -- for the case RCCL picks a ring.
+SPARSE = os.environ.get("MISPLAT_SPARSE_REDUCE", "auto")
+SPARSE_MAX_FRACTION = float(os.environ.get("MISPLAT_SPARSE_MAX_FRACTION", "0.35"))
+ALLREDUCE = os.environ.get("MISPLAT_ALLREDUCE", "auto")
+# One-GPU rehearsal (bench.py --buckets): run the flags -> bitmap -> union -> pack -> [no collective] -> unpack path with a
+# world of one, to measure what the sparse reduce costs on the device besides the bytes it saves on the links.
+REHEARSE = os.environ.get("MISPLAT_SPARSE_REHEARSE", "0") == "1"
+STATS: dict = {"dense": 0, "sparse": 0, "rows_reduced": 0, "rows_total": 0}
+
+
+class _Done:
+    def wait(self):
+        return True
+
+
+def _gather_bits(gathered: torch.Tensor, bits: torch.Tensor) -> None:
+    if _world() > 1:
+        dist.all_gather_into_tensor(gathered, bits)
+    else:
+        gathered.copy_(bits)
+
+
+def _backend() -> str:
+    return dist.get_backend() if dist.is_initialized() else "none"
+
+
+def _reduce(t: torch.Tensor, async_op: bool):
+    """Sum ``t`` (flat fp32, a multiple of the world size long in rs_ag mode) over the ranks, in place."""
+    if _world() <= 1:
+        return _Done()
+    if ALLREDUCE == "rs_ag" and t.numel() % _world() == 0 and t.numel() > 0:
+        chunk = t.numel() // _world()
+        mine = torch.empty(chunk, device=t.device, dtype=t.dtype)
+        dist.reduce_scatter_tensor(mine, t, op=dist.ReduceOp.SUM)
+        return dist.all_gather_into_tensor(t, mine, async_op=async_op)
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=async_op)
+
+
 class GradientBuckets:
     """The six parameter gradients of the shared Gaussians in ONE preallocated flat fp32 buffer (59 floats = 236 B per
     Gaussian at SH degree 3), reduced over the ranks with RCCL.
@@ -50,15 +96,25 @@ class GradientBuckets:
     data-parallel backward is the same backward as on one GPU.  Two collectives follow it, one per bucket:
 
       * the colour bucket (features_dc / features_rest or ``sh``: 192 of the 236 B) is complete the moment that call has
-        been enqueued -- nothing but the rasterizer ever writes a colour gradient -- and its
-        ``all_reduce(async_op=True)`` starts right there (``rasterizer_done``), while autograd finishes the step;
+        been enqueued and its collective starts right there (``rasterizer_done``), while autograd finishes the step.  This
+        assumes that nothing but the rasterizer writes a colour gradient in this backward: the colour slices have a version
+        counter of their own, and ``allreduce()`` raises if anything was added to them after the launch (an SH regulariser,
+        a second loss path: use ``attach(early_colour=False)`` then);
       * the geometry bucket (means, quats, scales, opacities) goes from ``allreduce()`` after ``backward()``: gradients
         that autograd adds elsewhere (the caller's own ``exp`` / ``sigmoid``, a scale regulariser) are then included --
         accumulated in place where the slice already is ``p.grad``, copied in (16 B/Gaussian) where it is not.
 
+    **Only the rows that have a gradient travel** when the rasterizer's row flags are available (``rasterizer_done(touched)``:
+    one byte per Gaussian, set by the compositing backward): the ranks all-gather their bitmaps (N / 8 bytes), OR them, list
+    the union's rows (the same list everywhere), pack 236 B x |union| from the buffer, reduce that and scatter it back
+    (``misplat_touched_bits`` / ``union_*`` / ``rows_pack`` / ``rows_unpack``; torch indexing for CPU rehearsals).  The
+    geometry bucket goes sparse only when the rasterizer wrote every one of its slices in place and nothing else touched
+    them (the activations inside the kernels, no regulariser), or when the caller vouches for it (``allreduce(sparse=True)``:
+    rows outside the flags carry no gradient); above ``SPARSE_MAX_FRACTION`` the dense buffer is cheaper.
+
     One large collective per bucket suits the point-to-point xGMI links (7 x ~153 GB/s per GPU): RCCL's direct
-    reduce-scatter + all-gather moves 2 x 7/8 of the bucket per rank over 7 links in parallel.  ``NCCL_DEBUG=INFO``
-    (stderr) shows the algorithm / protocol RCCL picked.
+    reduce-scatter + all-gather moves 2 x 7/8 of the bucket per rank over 7 links in parallel; ``MISPLAT_ALLREDUCE=rs_ag``
+    issues exactly that pair.  ``NCCL_DEBUG=INFO`` (stderr) shows the algorithm / protocol RCCL picked.
 
     A slice is handed out ONCE per parameter and ``attach()``: a second rasterization node on the same parameters in one
     ``backward()`` (several views per step) gets an ordinary fresh tensor, which autograd then adds into the slice; with
@@ -85,31 +141,49 @@ class GradientBuckets:
         dev = self.params[0].device
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         self.views: List[torch.Tensor] = [None] * len(self.params)
+        starts = {}
         o = 0
         self.n_colour = 0
         for k, i in enumerate(order):
-            n = self.params[i].numel()
-            self.views[i] = self.flat[o:o + n].view_as(self.params[i])
-            o += padded(n)
+            starts[i] = o
+            o += padded(self.params[i].numel())
             if k + 1 == len(self.colour):
                 self.n_colour = o                        # the colour bucket is the prefix flat[:n_colour]
+        # The colour prefix as a tensor of its OWN over the same memory (not a view of ``flat``): its version counter then
+        # counts what autograd does to the colour slices alone -- the guard of the early launch.
+        self._colour_alias = torch.empty(0, device=dev, dtype=torch.float32).set_(self.flat.untyped_storage(), 0, (self.n_colour,))
+        for i in order:
+            n = self.params[i].numel()
+            base = self._colour_alias if i in self.colour else self.flat
+            self.views[i] = base[starts[i]:starts[i] + n].view_as(self.params[i])
+        self._starts = starts
+        self.n_rows = int(self.params[0].shape[0])
+        self.row_params = all(p.dim() >= 1 and p.shape[0] == self.n_rows for p in self.params)   # (else: never sparse)
         self.views_per_backward = 1
-        self._work: list = []                            # collectives in flight: (work, host copy or None, slice)
+        self.early_colour = True
+        self._work: list = []                            # collectives in flight
         self._reduced = 0                                # floats of the buffer (a prefix) whose collective has been launched
         self._by_ptr = {}
         self._handed: set = set()
         self._nodes_done = 0
+        self._touched = None
+        self._union = None
+        self._colour_version = None
 
     # -- the step
-    def attach(self, views_per_backward: int = 1) -> None:
-        """Call before ``backward()``: gradients start from None and the backward kernels are pointed at the buffer."""
+    def attach(self, views_per_backward: int = 1, early_colour: bool = True) -> None:
+        """Call before ``backward()``: gradients start from None and the backward kernels are pointed at the buffer.
+        ``early_colour=False``: the colour bucket waits for ``allreduce()`` like the geometry bucket (needed when anything
+        besides the rasterizer contributes a colour gradient)."""
         from . import ops
         for p in self.params:
             p.grad = None
         self._by_ptr = {p.data_ptr(): i for i, p in enumerate(self.params)}
         self._work, self._reduced, self._nodes_done = [], 0, 0
         self._handed = set()
+        self._touched, self._union, self._colour_version = None, None, None
         self.views_per_backward = max(1, int(views_per_backward))
+        self.early_colour = bool(early_colour)
         ops.GRAD_SINK = self
 
     def sink(self, inp: torch.Tensor):
@@ -128,42 +202,61 @@ class GradientBuckets:
         self._handed.add(i)
         return self.views[i].view(inp.shape)
 
-    def rasterizer_done(self) -> None:
+    def rasterizer_done(self, touched: "torch.Tensor | None" = None) -> None:
         """Called by the rasterizer's backward right after its one C call has been enqueued: everything it wrote into the
-        buffer is final unless another view follows in the same backward."""
+        buffer is final unless another view follows in the same backward.  ``touched`` (or None): uint8 [N], non-zero for
+        the rows that received a gradient in this backward (``misplat_params.touched``)."""
         self._nodes_done += 1
-        if self.views_per_backward != 1 or self._reduced or _world() <= 1:
+        self._touched = touched if (self._nodes_done == 1 and touched is not None and touched.numel() == self.n_rows) else None
+        if self.views_per_backward != 1 or self._reduced or (_world() <= 1 and not REHEARSE) or not self.early_colour:
             return
         if self.colour and all(i in self._handed for i in self.colour):
+            self._colour_version = self._colour_alias._version
             self._launch(self.n_colour)
 
     def colour_ready(self) -> None:
         """Two-node / stage-by-stage form: called right after the colour backward kernel has been enqueued."""
-        if self.views_per_backward == 1 and not self._reduced and self.colour and _world() > 1 \
+        if self.views_per_backward == 1 and not self._reduced and self.colour and _world() > 1 and self.early_colour \
                 and all(i in self._handed for i in self.colour):
+            self._colour_version = self._colour_alias._version
             self._launch(self.n_colour)
 
-    def allreduce(self, average: bool = False):
+    def allreduce(self, average: bool = False, sparse: "bool | None" = None):
         """After ``backward()``: reduce what is still pending, make every ``p.grad`` its slice of the buffer.  Returns a
-        (start, end) pair of device events around the collectives on a GPU, else None."""
+        (start, end) pair of device events around the collectives on a GPU, else None.  ``sparse``: True -- the caller
+        vouches that rows outside the rasterizer's flags carry no gradient (no regulariser on the geometry parameters);
+        False -- dense; None -- decided here (class docstring)."""
         from . import ops
+        from ._lib import MisplatError
         ops.GRAD_SINK = None
         ev = None
         if self.flat.is_cuda:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         n_prefix = self._reduced
+        if n_prefix and self._colour_version is not None:
+            # the colour bucket left early: nothing may have been added to it since (its slices have their own version counter)
+            changed = self._colour_alias._version != self._colour_version
+            foreign = [i for i in self.colour if self.params[i].grad is not None
+                       and self.params[i].grad.data_ptr() != self.views[i].data_ptr()]
+            if changed or foreign:
+                raise MisplatError("GradientBuckets: a gradient reached the colour parameters AFTER their all-reduce had been "
+                                   "launched from the rasterizer's backward (an SH regulariser, a second loss path?) -- the sum "
+                                   "that travelled does not contain it.  Use attach(early_colour=False)")
+        in_place = True                                   # every pending slice was written by the rasterizer, nothing else
         for i, p in enumerate(self.params):
-            start = self.views[i].storage_offset()
+            start = self._starts[i]
             if start < n_prefix:
                 continue                                 # already travelling (written in place by the kernels)
             g = p.grad
             if g is None:
                 self.views[i].zero_()
+                in_place = False
             elif g.data_ptr() != self.views[i].data_ptr():
                 self.views[i].copy_(g)                   # produced by autograd outside the rasterizer (activations)
-        if _world() > 1 and self._reduced < self.flat.numel():
-            self._launch(self.flat.numel())
+                in_place = False
+        if (_world() > 1 or REHEARSE) and self._reduced < self.flat.numel():
+            self._launch(self.flat.numel(), sparse=(in_place if sparse is None else bool(sparse)))
         for w in self._work:
             self._finish(w)
         self._work = []
@@ -176,24 +269,118 @@ class GradientBuckets:
         return ev
 
     # -- collectives
-    def _launch(self, upto: int) -> None:
-        """all_reduce of flat[self._reduced : upto], asynchronously."""
-        t = self.flat[self._reduced:upto]
-        self._reduced = upto
-        if t.numel() == 0:
-            return
-        if dist.get_backend() == "gloo" and t.is_cuda:       # CPU rehearsal of the multi-rank path on a GPU box
-            host = t.cpu()
-            self._work.append((dist.all_reduce(host, op=dist.ReduceOp.SUM, async_op=True), host, t))
-        else:
-            self._work.append((dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True), None, t))
+    def _union_rows(self):
+        """Row ids of the union of the ranks' touched rows (ascending int32, the same on every rank), or None when the
+        flags are missing or the union is too large a part of the scene for packing to pay.  One small collective and one
+        host read (the union's size) per step."""
+        if self._union is not None:
+            return self._union if self._union is not False else None
+        self._union = False
+        if SPARSE == "0" or self._touched is None or not self.row_params:
+            return None
+        n, world, t = self.n_rows, _world(), self._touched
+        nbytes = (n + 7) // 8
+        if t.is_cuda and _backend() != "gloo":
+            import ctypes as C
+            from . import _lib
+            lib = _lib.load()
+            bits = torch.empty(nbytes, device=t.device, dtype=torch.uint8)
+            _lib.check(lib.misplat_touched_bits(_lib.ptr(t), C.c_int64(n), _lib.ptr(bits), _lib.stream_ptr()), "misplat_touched_bits")
+            gathered = torch.empty(world * nbytes, device=t.device, dtype=torch.uint8)
+            _gather_bits(gathered, bits)
+            n_blocks = (nbytes + 255) // 256
+            counts = torch.empty(n_blocks, device=t.device, dtype=torch.int32)
+            _lib.check(lib.misplat_union_count(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr(counts),
+                                               _lib.stream_ptr()), "misplat_union_count")
+            incl = torch.cumsum(counts, dim=0, dtype=torch.int64)
+            total = int(incl[-1].item())                                   # the step's one host read
+            if SPARSE != "1" and total > SPARSE_MAX_FRACTION * n:
+                return None
+            offs = (incl - counts).contiguous()
+            ids = torch.empty(max(total, 1), device=t.device, dtype=torch.int32)
+            _lib.check(lib.misplat_union_ids(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr(offs), _lib.ptr(ids),
+                                             _lib.stream_ptr()), "misplat_union_ids")
+            ids = ids[:total]
+        else:                                             # CPU rehearsal (gloo): the same steps with numpy / torch
+            import numpy as np
+            host = (t.detach().cpu().numpy() != 0)
+            bits = torch.from_numpy(np.packbits(host, bitorder="little"))
+            gathered = torch.empty(world * nbytes, dtype=torch.uint8)
+            _gather_bits(gathered, bits)
+            union = np.bitwise_or.reduce(gathered.numpy().reshape(world, nbytes), axis=0)
+            rows = np.flatnonzero(np.unpackbits(union, bitorder="little")[:n])
+            if SPARSE != "1" and rows.size > SPARSE_MAX_FRACTION * n:
+                return None
+            ids = torch.from_numpy(rows.astype(np.int32)).to(t.device)
+        self._union = ids
+        return ids
 
-    @staticmethod
-    def _finish(w) -> None:
-        work, host, t = w
-        work.wait()
-        if host is not None:
-            t.copy_(host)
+    def _launch(self, upto: int, sparse: bool = True) -> None:
+        """Sum of flat[self._reduced : upto] over the ranks, asynchronously (the rows of the union only when ``sparse``)."""
+        a, b = self._reduced, upto
+        self._reduced = upto
+        if b <= a:
+            return
+        ids = self._union_rows() if sparse else None
+        STATS["rows_total"] += self.n_rows
+        if ids is None:
+            STATS["dense"] += 1
+            STATS["rows_reduced"] += self.n_rows
+            t = self.flat[a:b]
+            if _backend() == "gloo" and t.is_cuda:       # CPU rehearsal of the multi-rank path on a GPU box
+                host = t.cpu()
+                self._work.append(dict(work=_reduce(host, True), host=host, dst=t))
+            else:
+                self._work.append(dict(work=_reduce(t, True), host=None, dst=t))
+            return
+        STATS["sparse"] += 1
+        STATS["rows_reduced"] += int(ids.numel())
+        members = [i for i in range(len(self.params)) if a <= self._starts[i] < b]
+        widths = [self.params[i].numel() // self.n_rows for i in members]
+        W, world = sum(widths), _world()
+        n_pack = int(ids.numel()) * W
+        n_pad = (n_pack + world - 1) // world * world                      # (rs_ag wants a multiple of the world size)
+        dev = self.flat.device
+        packed = torch.zeros(n_pad, device=dev, dtype=torch.float32) if n_pad != n_pack else torch.empty(n_pad, device=dev, dtype=torch.float32)
+        self._rows_move(True, members, widths, ids, packed)
+        if _backend() == "gloo" and packed.is_cuda:
+            host = packed.cpu()
+            self._work.append(dict(work=_reduce(host, True), host=host, dst=packed, unpack=(members, widths, ids)))
+        else:
+            self._work.append(dict(work=_reduce(packed, True), host=None, dst=packed, unpack=(members, widths, ids)))
+
+    def _rows_move(self, pack: bool, members, widths, ids, packed) -> None:
+        """packed[u, :] <-> the rows ids[u] of the member slices, side by side."""
+        if ids.numel() == 0:
+            return
+        tensors = [self.views[i].reshape(self.n_rows, w) for i, w in zip(members, widths)]
+        if packed.is_cuda:
+            import ctypes as C
+            from . import _lib
+            lib = _lib.load()
+            ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+            wid = (C.c_int32 * len(widths))(*widths)
+            fn = lib.misplat_rows_pack if pack else lib.misplat_rows_unpack
+            _lib.check(fn(C.c_int32(len(tensors)), ptrs, wid, _lib.ptr(ids), C.c_int64(ids.numel()), _lib.ptr(packed),
+                          _lib.stream_ptr()), "misplat_rows_pack" if pack else "misplat_rows_unpack")
+            return
+        rows = ids.long()
+        view = packed[:ids.numel() * sum(widths)].view(ids.numel(), sum(widths))
+        c = 0
+        for t, w in zip(tensors, widths):
+            if pack:
+                view[:, c:c + w] = t[rows]
+            else:
+                t[rows] = view[:, c:c + w]
+            c += w
+
+    def _finish(self, w) -> None:
+        w["work"].wait()
+        if w["host"] is not None:
+            w["dst"].copy_(w["host"])
+        if "unpack" in w:
+            members, widths, ids = w["unpack"]
+            self._rows_move(False, members, widths, ids, w["dst"])
 
 
 def _world() -> int:

@@ -213,6 +213,11 @@ class RadegsModelConfig:
     ssim_lambda: float = 0.2
     use_scale_regularization: bool = False
     max_gauss_ratio: float = 10.0
+    # Splatfacto's training-time resolution schedule [UNVERIFIED-UPSTREAM]: the camera is rendered at 1 / 2^k of its
+    # resolution, k = max(num_downscales - step // resolution_schedule, 0) (rade_gs_model.py:132-133 rescales the camera by
+    # the factor ``_get_downscale_factor()`` returns and back, :223)
+    num_downscales: int = 0
+    resolution_schedule: int = 3000
 
 
 class RadegsModel(nn.Module):
@@ -269,6 +274,13 @@ class RadegsModel(nn.Module):
     def _get_camera_parameters(self, camera) -> Dict:
         return camera_parameters(camera, self.device)
 
+    def _get_downscale_factor(self) -> int:
+        """Splatfacto's resolution schedule [UNVERIFIED-UPSTREAM]: 2^max(num_downscales - step // resolution_schedule, 0)
+        while training, 1 in evaluation -- the factor rade_gs_model.py:132 asks for."""
+        if self.training:
+            return 2 ** max(self.config.num_downscales - self.step // max(self.config.resolution_schedule, 1), 0)
+        return 1
+
     def _prefilter_voxel(self, camera_params: Dict) -> Tensor:
         """rade_gs_model.py:348-399: visibility mask from projection radii."""
         from .wrapper import fully_fused_projection
@@ -322,9 +334,23 @@ class RadegsModel(nn.Module):
         # the reference concatenates the two colour parameters every step (rade_gs_model.py:128-130:
         # a 192 B/Gaussian copy + its backward split); the colour kernels read them in place instead
         colors_crop = (pick(self.features_dc), pick(self.features_rest))
-        W, H = int(camera.width.item()), int(camera.height.item())
-        self.last_size = (H, W)
-        camera_params = self._get_camera_parameters(camera)
+        # rade_gs_model.py:132-136: the camera is rescaled by 1 / the schedule's factor for this call -- and back (:223).  The
+        # reference undoes it in straight-line code, so an exception in between leaves the caller's camera shrunk (SURVEY
+        # A.5); here the camera's intrinsics and size are restored exactly, whatever happens
+        camera_scale_fac = self._get_downscale_factor()
+        saved = None
+        if camera_scale_fac != 1 and hasattr(camera, "rescale_output_resolution"):
+            saved = {k: (v.clone() if isinstance(v, Tensor) else v) for k, v in
+                     ((k, getattr(camera, k)) for k in ("fx", "fy", "cx", "cy", "width", "height") if hasattr(camera, k))}
+            camera.rescale_output_resolution(1 / camera_scale_fac)
+        try:
+            W, H = int(camera.width.item()), int(camera.height.item())
+            self.last_size = (H, W)
+            camera_params = self._get_camera_parameters(camera)
+        finally:
+            if saved is not None:
+                for k, v in saved.items():
+                    setattr(camera, k, v)
         voxel_visible_mask = self._prefilter_voxel(camera_params) if (self.config.prefilter_voxel and crop_ids is None) else None
         if self.config.rasterize_mode not in ["antialiased", "classic"]:
             raise ValueError("Unknown rasterize_mode: %s", self.config.rasterize_mode)
@@ -452,6 +478,13 @@ class RadegsModel(nn.Module):
         loss_dict: Dict[str, Tensor] = {}
         rgb = outputs["rgb"]
         gt = batch["image"].to(rgb.device) if batch is not None and "image" in batch else None
+        # (Splatfacto takes whatever the data manager hands it -- a sliced, permuted, uint8 or float64 batch image: normalise
+        # first; uint8 images are 0..255 [UNVERIFIED-UPSTREAM: nerfstudio scales them to 0..1 in its data pipeline])
+        if gt is not None and rgb.is_cuda:
+            if gt.dtype == torch.uint8:
+                gt = gt.to(torch.float32) / 255.0
+            gt = gt.to(rgb.dtype).contiguous()
+            rgb = rgb.contiguous()
         with_dn = self.config.use_depth_normal_loss and self.step >= self.config.regularization_from_iter
         e1 = outputs["depth_normal_error_map"] if with_dn else None
         e2 = outputs["middepth_normal_error_map"] if with_dn else None
@@ -477,8 +510,9 @@ class RadegsModel(nn.Module):
             return loss_dict
         if gt is not None:
             if self.config.ssim_lambda > 0:
-                raise MisplatError("get_loss_dict: the SSIM term of main_loss runs on the GPU only (contiguous float32 CUDA "
-                                   "images of equal shape); there is no CPU fallback")
+                raise MisplatError(f"get_loss_dict: main_loss (L1 + SSIM) takes float32 images of equal shape on the GPU; got "
+                                   f"rgb {tuple(rgb.shape)} {rgb.dtype} on {rgb.device} and gt {tuple(gt.shape)} {gt.dtype} on "
+                                   f"{gt.device} (there is no CPU fallback in the product: oracle/ is test infrastructure)")
             loss_dict["main_loss"] = torch.abs(gt - rgb).mean()
             loss_dict["scale_reg"] = self._scale_reg(rgb.device)
         if with_dn:

@@ -567,6 +567,26 @@ int misplat_adam_step(int32_t n_tensors, float* const* params, const float* cons
                       const float* lr, const int64_t* step, double beta1, double beta2, double eps,
                       misplat_stream_t stream);
 
+/* ---- shared-Gaussian gradient reduce that moves only the rows that have a gradient (the gradient
+ * set of collab_splats/configs/rade_gs_method.py:44-71; csrc/optim.hip, driven by collab_splats_amd/parallel.py).
+ *   touched_bits  bits[ceil(n_rows / 8)]: bit (r & 7) of byte r >> 3 = flags[r] != 0 (flags: misplat_params.touched, 8-byte
+ *                 aligned) -- the bitmap a rank contributes to the all-gather;
+ *   union_count   gathered[world][nbytes] = the ranks' bitmaps; block_counts[ceil(nbytes / 256)] = rows set in the OR of
+ *                 them, per block of 2 048 rows (the caller scans them: block_offsets, and reads the total);
+ *   union_ids     ids[block_offsets[b] ...] = the set rows of block b, ascending: the same list on every rank;
+ *   rows_pack     packed[u][W] = the rows ids[u] of n_tensors (<= 8) row-major tensors of `widths` floats per row, side by
+ *                 side (W = sum of the widths); rows_unpack: the inverse (rows outside `ids` are not touched). */
+#define MISPLAT_ROWS_MAX_TENSORS 8
+int misplat_touched_bits(const uint8_t* flags, int64_t n_rows, uint8_t* bits, misplat_stream_t stream);
+int misplat_union_count(const uint8_t* gathered, int32_t world, int64_t nbytes, int32_t* block_counts,
+                        misplat_stream_t stream);
+int misplat_union_ids(const uint8_t* gathered, int32_t world, int64_t nbytes, const int64_t* block_offsets, int32_t* ids,
+                      misplat_stream_t stream);
+int misplat_rows_pack(int32_t n_tensors, const float* const* srcs, const int32_t* widths, const int32_t* ids, int64_t n_ids,
+                      float* packed, misplat_stream_t stream);
+int misplat_rows_unpack(int32_t n_tensors, float* const* dsts, const int32_t* widths, const int32_t* ids, int64_t n_ids,
+                        const float* packed, misplat_stream_t stream);
+
 /* Measurement helper: dst[i] = src[i] over n_float4 16-byte elements (a plain streaming copy; bench.py times it to
  * report the HBM roof of the box it runs on).  variant: 0 plain, 1 non-temporal loads / stores, 2 four loads in flight
  * per lane + non-temporal stores. */

@@ -172,3 +172,100 @@ def test_gradient_buckets_and_lockstep_densification_gloo_ws2():
     assert all(r[2] for r in res), "replicas diverged after the seeded refinement step"
     assert res[0][3] == res[1][3] and sum(res[0][3][:2]) > 0        # something was actually duplicated / split
     assert res[0][4] == res[1][4] != 64
+
+
+def _sparse_worker(rank, world, port, n, case, mode, q):
+    """The rasterizer's backward played against a GradientBuckets sink, with row flags: every rank touches a subset of the
+    rows (``case``: disjoint / overlapping / nearly all), writes gradients into those rows of ALL six slices in place and
+    leaves the others zero -- as the kernels do.  The sparse reduce (bitmaps all-gathered and OR-ed, the union's rows packed,
+    reduced, scattered back) must equal the dense all-reduce of the same buffers BIT FOR BIT."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_distributed(backend="gloo")
+    parallel.ALLREDUCE = mode
+    g = torch.Generator().manual_seed(50 + rank)
+    rows = {"disjoint": torch.arange(n)[rank::world][: n // 8],
+            "overlap": torch.randperm(n, generator=torch.Generator().manual_seed(7))[: n // 5][rank * 3:],
+            "most": torch.randperm(n, generator=g)[: (9 * n) // 10]}[case]
+    touched = torch.zeros(n, dtype=torch.uint8)
+    touched[rows] = 1
+    results = []
+    for sparse_env in ("0", "auto"):
+        parallel.SPARSE = sparse_env
+        for k in parallel.STATS:
+            parallel.STATS[k] = 0
+        params = [torch.zeros(s, requires_grad=True) for s in _shapes(n).values()]
+        bk = parallel.GradientBuckets(params)
+        bk.attach()
+        for i, p in enumerate(params):                                # "the kernels": in place, touched rows only
+            out = bk.sink(p)
+            out.zero_()
+            out[rows] = _view_grad(100 * rank + i, p.shape)[rows]
+            p.grad = out
+        bk.rasterizer_done(touched)
+        early = len(bk._work)
+        bk.allreduce()
+        results.append(([p.grad.clone() for p in params], dict(parallel.STATS), early))
+    (dense, st_d, _), (sparse, st_s, early) = results
+    same = all(torch.equal(a, b) for a, b in zip(dense, sparse))
+    untouched_zero = True
+    union = torch.zeros(n, dtype=torch.uint8)
+    union[rows] = 1
+    dist.all_reduce(union, op=dist.ReduceOp.MAX)
+    for t in sparse:
+        untouched_zero &= not bool(t[union == 0].any())
+    q.put((rank, same, untouched_zero, st_d, st_s, early, int(union.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("case,mode", [("disjoint", "auto"), ("overlap", "auto"), ("most", "auto"), ("overlap", "rs_ag")])
+def test_sparse_row_reduce_equals_dense_bit_for_bit_gloo_ws2(case, mode):
+    n = 1003                                                             # (not a multiple of 8: the bitmap's last byte is partial)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, 2, port, n, case, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, same, untouched_zero, st_d, st_s, early, n_union in res:
+        assert same, f"rank {rank}: sparse and dense sums differ ({case}, {mode})"
+        assert untouched_zero and early == 1                              # the colour bucket left from rasterizer_done()
+        assert st_d["dense"] == 2 and st_d["sparse"] == 0
+        if case == "most":                                                # union above 35 % of the rows: the dense buffer is cheaper
+            assert st_s["sparse"] == 0 and st_s["dense"] == 2
+        else:
+            assert st_s["sparse"] == 2 and st_s["dense"] == 0 and st_s["rows_reduced"] == 2 * n_union < 2 * 0.35 * n
+
+
+def test_colour_gradient_added_after_the_early_launch_is_refused(monkeypatch):
+    """the colour bucket's all-reduce starts from inside backward(); if anything else adds a colour gradient later
+    in the same backward (an SH regulariser), the sum that travelled does not contain it.  The colour slices have a version
+    counter of their own: ``allreduce()`` raises instead of returning a silently wrong gradient; ``early_colour=False`` is
+    the way to run such a step."""
+    from collab_splats_amd._lib import MisplatError
+    monkeypatch.setattr(parallel, "_world", lambda: 2)                    # (no process group: _launch is stubbed below)
+    params = [torch.zeros(6, 3, requires_grad=True), torch.zeros(6, 15, 3, requires_grad=True)]
+    launched = []
+    for early_colour in (True, False):
+        bk = parallel.GradientBuckets(params, geometry=[0], colour=[1])
+        monkeypatch.setattr(bk, "_launch", lambda upto, sparse=True, bk=bk: (launched.append(upto), setattr(bk, "_reduced", upto)))
+        bk.attach(early_colour=early_colour)
+        out = bk.sink(params[1])
+        out.fill_(1.0)
+        params[1].grad = out
+        bk.rasterizer_done()
+        assert bool(bk._reduced) == early_colour
+        params[1].grad += 2.0                                             # autograd accumulates a second colour gradient in place
+        params[0].grad = torch.ones(6, 3)
+        if early_colour:
+            with pytest.raises(MisplatError, match="early_colour=False"):
+                bk.allreduce()
+        else:
+            bk.allreduce()
+            assert torch.equal(params[1].grad, torch.full((6, 15, 3), 3.0))

@@ -411,3 +411,52 @@ def test_graphed_step_result_check_finds_autograd_history():
     assert _tensors_with_history(None) == [] and _tensors_with_history([a, a.detach(), 3, "x"]) == []
     assert _tensors_with_history({"img": [b.detach(), b], "meta": {"k": (b,)}}) == ["result['img'][1]"]
     assert _tensors_with_history((a.detach(), {"loss": b.sum()})) == ["result[1]['loss']"]
+
+
+def test_graphed_step_result_check_walks_plain_objects_and_knows_torchs_warning_text():
+    """A returned dataclass / namespace that holds a tensor with history is found structurally; the secondary net -- the
+    text of PyTorch's stream-mismatch warning -- still exists in the installed torch (it lives in libtorch_cpu)."""
+    import dataclasses, glob, mmap, types
+    from collab_splats_amd import graphs
+
+    @dataclasses.dataclass
+    class Holder:
+        meta: object
+
+    a = torch.ones(2, requires_grad=True)
+    b = a * 2
+    assert graphs._tensors_with_history(Holder({"means2d": b})) == ["result.meta['means2d']"]
+    assert graphs._tensors_with_history(types.SimpleNamespace(x=[b.detach()], y=Holder(None))) == []
+    libs = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "libtorch_cpu.so"))
+    assert libs, "libtorch_cpu.so not found next to the torch package"
+    with open(libs[0], "rb") as f, mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_READ) as mm:
+        assert mm.find(graphs.STALE_GRAPH_WARNING.encode()) >= 0, "PyTorch changed the text of its AccumulateGrad stream warning"
+
+
+def test_resolution_schedule_rescales_the_camera_and_restores_it_even_on_error(monkeypatch):
+    """rade_gs_model.py:132-136, 223: training renders at 1 / 2^k of the camera's resolution, k = max(num_downscales - step //
+    resolution_schedule, 0) [UNVERIFIED-UPSTREAM: Splatfacto's schedule]; the camera comes back exactly as it was, also when the
+    call fails in between (the reference's straight-line undo does not)."""
+    cfg = radegs.RadegsModelConfig(num_downscales=2, resolution_schedule=100)
+    m = radegs.RadegsModel(cfg, torch.zeros(1, 3), torch.zeros(1, 3), torch.ones(1, 4), torch.zeros(1, 1), torch.zeros(1, 3),
+                           torch.zeros(1, 15, 3))
+    m.train()
+    for step, fac in ((0, 4), (99, 4), (100, 2), (199, 2), (200, 1), (5000, 1)):
+        m.step = step
+        assert m._get_downscale_factor() == fac
+    m.eval()
+    m.step = 0
+    assert m._get_downscale_factor() == 1                                  # evaluation renders at full resolution
+    m.train()
+    cam = radegs.PinholeCamera.make(torch.eye(4)[:3], 500.0, 480.0, 640, 360)
+    seen = {}
+
+    def fake_params(camera):
+        seen.update(W=int(camera.width.item()), H=int(camera.height.item()), fx=camera.fx, cx=camera.cx)
+        raise RuntimeError("stop here")
+
+    monkeypatch.setattr(m, "_get_camera_parameters", fake_params)
+    with pytest.raises(RuntimeError, match="stop here"):
+        m.get_outputs(cam)
+    assert seen == dict(W=160, H=90, fx=125.0, cx=80.0)                   # the call saw the camera at 1/4 resolution
+    assert (int(cam.width.item()), int(cam.height.item()), cam.fx, cam.fy, cam.cx, cam.cy) == (640, 360, 500.0, 480.0, 320.0, 180.0)

@@ -617,6 +617,36 @@ def test_model_get_outputs_and_loss(dev):
     assert mask.shape == (n_now,) and mask.dtype == torch.bool and 0 < int(mask.sum()) < n_now
 
 
+def test_resolution_schedule_renders_the_downscaled_camera(dev):
+    """rade_gs_model.py:132-136, 223 at a downscale factor of 2: a training step under the schedule renders what a camera of
+    half the resolution renders (same intrinsics / 2), bit for bit, and the caller's camera is untouched afterwards."""
+    from collab_splats_amd import radegs
+    from collab_splats_amd.synthetic import random_scene
+    W, H, N = 256, 144, 5000
+    sc = random_scene(N, W, H, seed=6)
+    c2w = torch.tensor([[1.0, 0, 0, 0], [0, -1.0, 0, 0], [0, 0, -1.0, 0]])
+
+    def model(**kw):
+        cfg = radegs.RadegsModelConfig(rasterize_mode="antialiased", regularization_from_iter=0, **kw)
+        m = radegs.RadegsModel(cfg, sc["means"], sc["log_scales"], sc["quats"], sc["opacity_logits"], sc["sh"][:, 0],
+                               sc["sh"][:, 1:]).to(dev)
+        m.train()
+        m.step = 4000
+        return m
+
+    full = radegs.PinholeCamera.make(c2w, 0.9 * W, 0.9 * W, W, H)
+    half = radegs.PinholeCamera.make(c2w, 0.45 * W, 0.45 * W, W // 2, H // 2)
+    m1 = model(num_downscales=3, resolution_schedule=2000)                      # 2^(3 - 4000 // 2000) = 2
+    a = m1.get_outputs(full)
+    b = model().get_outputs(half)
+    assert a["rgb"].shape == (H // 2, W // 2, 3)
+    for k in ("rgb", "depth", "median_depth", "accumulation", "normals", "depth_normal_error_map"):
+        assert torch.equal(a[k], b[k]), k
+    assert (int(full.width.item()), int(full.height.item()), full.fx, full.cx) == (W, H, 0.9 * W, W / 2.0)
+    sum(m1.get_loss_dict(a, {"image": torch.rand(H // 2, W // 2, 3)}).values()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m1.gauss_params.values())
+
+
 def test_crop_box_renders_exactly_the_cropped_subset(dev):
     """rade_gs_model.py:96-119 (evaluation only): a crop box selects Gaussians by ``within(means)``; the outputs are those
     of a model that holds only the selected ones, and an empty crop returns ``get_empty_outputs``."""
@@ -1724,6 +1754,8 @@ def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H
     assert n_lazy == (n_calls if lazy == "1" else (n_calls - 1 if dense else 0)), took   # "auto": from the second call of a dense scene
     if dense:                                                   # background fill + one-launch per-Gaussian backward
         assert took.get("backward_background_fill", 0) == n_lazy, took
+    r, a, ed, md, n, meta = out
+    if dense:
         # front-only ordering (forced on above): from the second call (the first one has no capacity hint), with the view's
         # own pivots from the third; meta["flatten_ids"] below is completed on access
         assert took.get("forward_front_only", 0) == n_calls - 1, took
@@ -1731,7 +1763,6 @@ def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H
         fn = meta["_bins"]["partial"]["front_n"].cpu().numpy()
         cnt = np.diff(np.concatenate([meta["isect_offsets"].reshape(-1).cpu().numpy(), [meta["n_isects"]]]))
         assert ((fn >= 0) & (fn < cnt)).sum() > 0.5 * fn.size, "most tiles should have been sorted in front only"
-    r, a, ed, md, n, meta = out
     # ---- the C restatement on the same raw parameters
     cr = craster.CRaster(np.float32)
     scales_np = torch.exp(leaves[2].detach()).cpu().numpy()
@@ -1864,8 +1895,8 @@ def test_cycling_views_reuse_graphs_without_capacity_redo(dev):
     assert max(counts) > 1.05 * min(counts)                       # the views really differ in their intersection counts
     ops.reset_graph_cache(dev)
     ops._CAP_HINT.pop(ops._cap_key(ops._lib.make_params(N, 1, W, H), dev), None)
-    for rnd in range(4):
-        if rnd == 2:
+    for rnd in range(5):
+        if rnd == 3:
             before, g0 = dict(ops.PATH_STATS), ops.graph_cache_stats(dev)
         for v in range(8):
             img, grad, n_is = call(v)
@@ -1877,8 +1908,10 @@ def test_cycling_views_reuse_graphs_without_capacity_redo(dev):
     took = {k: ops.PATH_STATS[k] - before.get(k, 0) for k in ops.PATH_STATS}
     g1 = ops.graph_cache_stats(dev)
     assert took.get("capacity_redo", 0) == 0 and took.get("forward_merged_phases", 0) == 16, took
-    # every argument block of rounds 3 - 4 has been seen twice before: the call's own arrays come from its arena slot (same
-    # addresses every time a view comes back), so all 16 forwards and 16 backwards replay their graphs and nothing is captured
+    # Rounds 4 - 5 (the capacity hint has seen the largest view in round 1, the arena slot its final size in round 2, every
+    # steady-state argument block has been sighted twice by the end of round 3): the call's own arrays come from its arena
+    # slot -- the same addresses every time a view comes back --, so all 16 forwards and 16 backwards replay their graphs
+    # and nothing is captured any more
     assert g1["captures"] == g0["captures"] and g1["hits"] - g0["hits"] >= 32, (g0, g1)
     assert took.get("forward_arena_slot", 0) == 16, took
     # ---- every view found its own launch order: eight valid records with eight different tags in the view-keyed table,
@@ -1943,6 +1976,52 @@ def test_arena_slots_are_not_recycled_under_tensors_that_are_still_held(dev):
     again = call()
     assert again[0].data_ptr() in (ptr0, others[0])
     assert arena.STATS["slots_created"] - before.get("slots_created", 0) <= 2
+
+
+def test_sparse_reduce_kernels_bitmaps_union_pack_unpack(dev):
+    """csrc/optim.hip, the device half of the sparse shared-Gaussian reduce (parallel.GradientBuckets): flags -> bitmap,
+    OR of several ranks' bitmaps -> ascending row ids, rows packed side by side and scattered back -- against numpy."""
+    from collab_splats_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    for n, world in ((5, 1), (2051, 3), (1_000_003, 8)):
+        flags = (rng.random((world, n)) < 0.04).astype(np.uint8) * rng.integers(1, 255, (world, n), dtype=np.uint8)
+        nbytes = (n + 7) // 8
+        gathered = torch.empty(world, nbytes, dtype=torch.uint8, device=dev)
+        for w in range(world):
+            f = torch.zeros((n + 7) // 8 * 8, dtype=torch.uint8, device=dev)         # (8-byte aligned, like the forward's carve)
+            f[:n] = torch.from_numpy(flags[w]).to(dev)
+            _lib.check(lib.misplat_touched_bits(_lib.ptr(f), C.c_int64(n), C.c_void_p(gathered[w].data_ptr()), _lib.stream_ptr()), "bits")
+        want_bits = np.stack([np.packbits(flags[w] != 0, bitorder="little") for w in range(world)])
+        assert np.array_equal(gathered.cpu().numpy(), want_bits)
+        n_blocks = (nbytes + 255) // 256
+        counts = torch.empty(n_blocks, dtype=torch.int32, device=dev)
+        _lib.check(lib.misplat_union_count(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr(counts), _lib.stream_ptr()), "count")
+        rows = np.flatnonzero((flags != 0).any(0))
+        incl = torch.cumsum(counts, 0, dtype=torch.int64)
+        assert int(incl[-1]) == rows.size
+        ids = torch.empty(max(rows.size, 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.misplat_union_ids(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr((incl - counts).contiguous()),
+                                         _lib.ptr(ids), _lib.stream_ptr()), "ids")
+        assert np.array_equal(ids[:rows.size].cpu().numpy(), rows.astype(np.int32))
+        widths = [3, 45, 3, 3, 4, 1]
+        tens = [torch.randn(n, w, device=dev) for w in widths]
+        W = sum(widths)
+        packed = torch.empty(rows.size * W, device=dev)
+        ptrs = (C.c_void_p * 6)(*[t.data_ptr() for t in tens])
+        wid = (C.c_int32 * 6)(*widths)
+        idt = ids[:rows.size].contiguous()
+        _lib.check(lib.misplat_rows_pack(C.c_int32(6), ptrs, wid, _lib.ptr(idt), C.c_int64(rows.size), _lib.ptr(packed), _lib.stream_ptr()), "pack")
+        want = torch.cat([t[idt.long()] for t in tens], dim=1)
+        assert torch.equal(packed.view(rows.size, W), want)
+        outs = [torch.full_like(t, 7.0) for t in tens]
+        optrs = (C.c_void_p * 6)(*[t.data_ptr() for t in outs])
+        _lib.check(lib.misplat_rows_unpack(C.c_int32(6), optrs, wid, _lib.ptr(idt), C.c_int64(rows.size), _lib.ptr(packed * 2), _lib.stream_ptr()), "unpack")
+        torch.cuda.synchronize()
+        keep = np.ones(n, bool)
+        keep[rows] = False
+        for o, t in zip(outs, tens):
+            assert torch.equal(o[idt.long()], 2 * t[idt.long()]) and bool((o[torch.from_numpy(keep).to(dev)] == 7.0).all())
 
 
 def test_view_keyed_orders_survive_eviction_and_collisions(dev, monkeypatch):
