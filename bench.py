@@ -80,22 +80,34 @@ def parse():
                     help="capture the whole step (activations, forward, backward) into ONE hipGraph with a fixed "
                          "intersection capacity (collab_splats_amd.graphs.GraphedStep) and time its replays: the "
                          "host-bound small configurations; not the default protocol")
+    ap.add_argument("--features", type=int, default=0, metavar="F",
+                    help="the features model's call (rade_features_model.py:427-476): F feature channels behind the SH colours "
+                         "(13 in the reference), SH + clamp + fuse + rasterize as ONE entry, fwd+bwd to coefficients AND features; "
+                         "`variants` then also times the reference's own composition (spherical_harmonics, clamp_min, cat, "
+                         "rasterization(sh_degree=None)) through the same library")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-view", type=int, default=3, help="the rotated view the gradient check runs on besides view 0")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="Gaussians in the CPU-baseline sample")
     return ap.parse_args()
 
 
-def algorithmic_bytes(kernel: str, N: int, I: int, P: int) -> float:
-    """SURVEY.md section 8(d) per-unit figures (fp32, SH3, D=3)."""
+def algorithmic_bytes(kernel: str, N: int, I: int, P: int, n_feat: int = 0, n_channels: int = 3) -> float:
+    """SURVEY.md section 8(d) per-unit figures (fp32, SH3, D=3).  The features model (``n_feat`` > 0 feature channels behind
+    the SH colours, ``n_channels`` = D' composited channels): "for D != 3 replace 12 by 4 D in the colour terms" -- per pixel
+    4 (D' - 3) more bytes in every image-shaped stream, per intersection the 16-byte groups of the extra channels (16 nxq),
+    per Gaussian 4 (D' - 3) more bytes in the 2-D gradient row and 4 n_feat per pass over the feature parameters."""
+    x = 4.0 * max(n_channels - 3, 0) if n_feat else 0.0               # extra bytes per colour-shaped item
+    gx = 16.0 * ((max(n_channels - 4, 0) + 3) // 4) if n_feat else 0.0  # extra gathered bytes per (tile, Gaussian)
     if kernel == "blend_bwd":
-        return 88.0 * P + 64.0 * I + 60.0 * N     # saved outputs + upstream grads, re-gather, 2-D grads
+        return (88.0 + 2 * x) * P + (64.0 + gx) * I + (60.0 + x) * N     # saved outputs + upstream grads, re-gather, 2-D grads
     if kernel == "blend_fwd":
-        return 64.0 * I + 48.0 * P                 # record gather, pixel outputs incl. saved indices
+        return (64.0 + gx) * I + (48.0 + x) * P                 # record gather, pixel outputs incl. saved indices
     if kernel == "slab_reduce":
         return 64.0 * I + 64.0 * N                 # one gradient row per intersection in, one per Gaussian out
     if kernel == "step":
-        return 972.0 * N + 164.0 * I + 136.0 * P   # whole fwd+bwd call (SURVEY.md 8(d) total A)
+        # whole fwd+bwd call (SURVEY.md 8(d) total A = 972 N + 164 I + 136 P); features: read in the forward and the backward,
+        # gradient written once (3 x 4 n_feat), the colour terms of the three 72 / 60-byte per-Gaussian rows widened by x
+        return (972.0 + 12.0 * n_feat + 3 * x) * N + (164.0 + 2 * gx) * I + (136.0 + 3 * x) * P
     raise KeyError(kernel)
 
 
@@ -173,13 +185,25 @@ def cpu_baseline(args, seed: int):
     return base, keep
 
 
-def rasterize_step(params, viewmats, Ks, W, H, args, ext: bool):
+def rasterize_step(params, viewmats, Ks, W, H, args, ext: bool, composed: bool = False):
     """THE call of a step -- the timed loop and the parity leg both go through here.  ``ext`` False: the reference's call
     (torch.exp / torch.sigmoid in front, rade_gs_model.py:443-444); True: the same step with the activations inside the
     projection kernels (scales_are_log / opacities_are_logit, an extension of this build)."""
     from collab_splats_amd.rendering import rasterization
     kw = dict(near_plane=0.01, far_plane=1e10, sh_degree=3, packed=False, render_mode=args.render_mode, sparse_grad=False,
               absgrad=False, rasterize_mode=args.rasterize_mode, return_depth_normal=True)
+    if "features" in params and composed:
+        # the reference's own lines, through this library's drop-ins: rade_features_model.py:427-441 + :450-476
+        from collab_splats_amd import spherical_harmonics
+        cam_c = -(viewmats[0, :3, :3].T @ viewmats[0, :3, 3])
+        colors = spherical_harmonics(3, params["means"] - cam_c, params["sh"])
+        colors = torch.clamp_min(colors + 0.5, 0.0)
+        fused = torch.cat((colors, params["features"]), dim=-1)
+        kw["sh_degree"] = None
+        return rasterization(params["means"], params["quats"], torch.exp(params["log_scales"]),
+                             torch.sigmoid(params["opacity_logits"]), fused, viewmats, Ks, W, H, **kw)
+    if "features" in params:
+        kw["features"] = params["features"]
     if ext:
         return rasterization(params["means"], params["quats"], params["log_scales"], params["opacity_logits"], params["sh"],
                              viewmats, Ks, W, H, scales_are_log=True, opacities_are_logit=True, **kw)
@@ -386,6 +410,9 @@ def main():
             info["it"] += 1
     else:
         params = {k: sc[k].to(dev).requires_grad_(True) for k in ("means", "log_scales", "quats", "opacity_logits", "sh")}
+        if args.features > 0:
+            params["features"] = torch.rand(N, args.features, generator=g).to(dev).requires_grad_(True)
+            cd += args.features
         ups = [torch.rand(s, generator=g).to(dev) for s in ((1, H, W, cd), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3))]
         leaves = list(params.values())
         if (shared and world > 1) or args.buckets:
@@ -397,7 +424,7 @@ def main():
                     p.grad = None
             else:
                 bucket.attach()
-            out = rasterize_step(params, views[view_index()], Ks, W, H, args, mode["ext"])
+            out = rasterize_step(params, views[view_index()], Ks, W, H, args, mode["ext"], composed=mode.get("composed", False))
             torch.autograd.backward(list(out[:5]), ups)
             if bucket is not None:
                 info["allreduce_ms"].append(bucket.allreduce())
@@ -481,6 +508,14 @@ def main():
                 variants[label(m)] = {"ms_per_step": round(dtv / args.steps * 1e3, 4), "device_ms_median": round(medv, 4),
                                       "value": round(world * N / (dtv / args.steps) / 1e6, 3)}
         mode.update(headline_mode)
+    if args.features > 0 and not args.no_variants and graphed is None:
+        # the reference's own composition (spherical_harmonics -> clamp_min -> cat -> rasterization(sh_degree=None)), same views
+        mode.update(headline_mode, composed=True)
+        dtv, medv = timed(step, args.steps, args.warmup)
+        variants["composed_as_the_reference_writes_it+" + ("fixed_view" if headline_mode["fixed"] else "cycling_views")] = {
+            "ms_per_step": round(dtv / args.steps * 1e3, 4), "device_ms_median": round(medv, 4),
+            "value": round(world * N / (dtv / args.steps) / 1e6, 3)}
+        mode.update(headline_mode, composed=False)
 
     # ---- instrumented pass (outside the timed region): HIP events on the launch stream around the compositing kernels
     # (the same path as the timed region: the one-entry C calls record the events themselves, directly before and
@@ -507,10 +542,10 @@ def main():
             ts = [a.elapsed_time(b) for a, b in v[2:]] or [0.0]
             ktimes[k] = sum(ts) / len(ts)
         dom = max((k for k in ktimes if k in ("blend_bwd", "blend_fwd", "slab_reduce")), key=ktimes.get)
-        abytes = algorithmic_bytes(dom, N, I, W * H)
+        abytes = algorithmic_bytes(dom, N, I, W * H, args.features, cd)
         achieved = abytes / (ktimes[dom] * 1e-3) / 1e9
         I_trav = int(sum(trav) / len(trav)) if trav else None
-        step_bytes = algorithmic_bytes("step", N, I, W * H)
+        step_bytes = algorithmic_bytes("step", N, I, W * H, args.features, cd)
         step_gbs = step_bytes / (dev_med * 1e-3) / 1e9
         pmc = {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -570,7 +605,7 @@ def main():
                          "algorithmic_bytes": abytes,
                          "algorithmic_bytes_note": "SURVEY 8(d): 88 P + 64 I + 60 N with I = all intersections (mean over the views)",
                          "traversed_entries": I_trav,
-                         "achieved_traversed": (round((88.0 * W * H + 64.0 * I_trav + 60.0 * N) / (ktimes[dom] * 1e-3) / 1e9, 2)
+                         "achieved_traversed": (round(algorithmic_bytes("blend_bwd", N, I_trav, W * H, args.features, cd) / (ktimes[dom] * 1e-3) / 1e9, 2)
                                                 if (I_trav is not None and dom == "blend_bwd") else None),
                          "traversed_note": "64 I replaced by 64 x the list entries the backward really stages (early termination: "
                                            "per band, first entry .. deepest last_id); the dense-scene figure to read next to `achieved`",
@@ -585,7 +620,15 @@ def main():
         }
         if allreduce_ms:
             line["allreduce_ms"] = round(allreduce_ms[len(allreduce_ms) // 2], 4)
-        if world == 1 and not args.no_cpu_baseline and not args.dn_loss:
+        if args.features > 0:
+            line["config"]["workload"] = (f"the features model's call (rade_features_model.py:427-476): {N} random Gaussians, {view_txt} "
+                                          f"{W}x{H}, SH degree 3 -> clamp_min(c + 0.5, 0) fused with {args.features} feature channels "
+                                          f"-> {cd} composited channels ({args.render_mode}), fwd+bwd to means / quats / scales / "
+                                          f"opacities / SH coefficients AND features; one entry (rasterization(..., features=...))")
+            line["roofline"]["algorithmic_bytes_note"] = ("SURVEY 8(d) with 4 D' substituted in the colour terms (D' = "
+                                                          f"{cd}): see bench.algorithmic_bytes")
+            line["cpu_baseline_note"] = "not timed for this leg (the default run carries cpu_baseline and the gradient check)"
+        if world == 1 and not args.no_cpu_baseline and not args.dn_loss and args.features == 0:
             import numpy as np
             from oracle.craster import CRaster
             line["cpu_baseline"], keep = cpu_baseline(args, seed)

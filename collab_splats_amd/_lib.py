@@ -57,7 +57,8 @@ class RasterArgs(C.Structure):
                                              "unit_perm_out", "ev_blend_begin", "ev_blend_end", "order_table", "order_sel")]
                 + [("order_slots", C.c_int32), ("order_stride", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("unit_reach", "front_n", "tile_flag")]
-                + [("front_margin", C.c_float), ("front_min_bucket", C.c_int32), ("depth_sorted", C.c_void_p)])
+                + [("front_margin", C.c_float), ("front_min_bucket", C.c_int32), ("depth_sorted", C.c_void_p)]
+                + [(n, C.c_void_p) for n in ("features", "featx", "v_featx_zero")] + [("n_feat", C.c_int32), ("nxq", C.c_int32)])
 
 
 class RasterBwdArgs(C.Structure):
@@ -71,7 +72,9 @@ class RasterBwdArgs(C.Structure):
                                              "radii", "compensations", "sh_aux", "v_means2d", "v_colors", "v_colors_rest",
                                              "v_means_dir", "v_means", "v_quats", "v_scales", "v_opacities", "ev_blend_begin", "ev_blend_end",
                                              "v_means2d_out", "unit_sel")]
-                + [("unit_stride", C.c_int32), ("unit_slots", C.c_int32)])
+                + [("unit_stride", C.c_int32), ("unit_slots", C.c_int32)]
+                + [(n, C.c_void_p) for n in ("featx", "features", "v_featx", "v_features")]
+                + [(n, C.c_int32) for n in ("n_feat", "nxq", "depth_channel", "reserved_x")])
 
 
 def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: int = 16,

@@ -397,7 +397,7 @@ __device__ __forceinline__ void sort_bucket_regs(tile_sort_lds<WAVES, R>& L, int
             const int i = threadIdx.x + q * T;
             v[q] = 0u; k[q] = 0xffffffffu; tb[q] = 0xffffffffu;
             if (i < n) {
-                v[q] = (uint32_t)payload[beg + i];
+                v[q] = (uint32_t)payload[beg + i] & (MAP == 2 ? misplat_internal::kIdxMask : 0xffffffffu);
                 const int32_t rw = MAP ? isect_gid[v[q]] : (int32_t)v[q];
                 k[q] = __float_as_uint(depths[MAP == 2 ? (int32_t)v[q] : rw]);
                 tb[q] = UNORDERED ? (uint32_t)rw : (uint32_t)i;
@@ -437,7 +437,7 @@ __device__ __forceinline__ void sort_bucket_regs(tile_sort_lds<WAVES, R>& L, int
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int i = wave * 64 * R + r * 64 + lane;
-        val[r] = (uint32_t)payload[beg + (i < n ? i : 0)];
+        val[r] = (uint32_t)payload[beg + (i < n ? i : 0)] & (MAP == 2 ? misplat_internal::kIdxMask : 0xffffffffu);
     }
 #pragma unroll
     for (int r = 0; r < R; r++) row[r] = MAP == 1 ? isect_gid[val[r]] : (int32_t)val[r];      // (what indexes `depths`)
@@ -561,7 +561,7 @@ __device__ __forceinline__ void sort_bucket_passes(uint32_t* lds32, int beg, int
     uint32_t* v1 = GLOBAL ? buf + cap : buf + 3 * cap;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int i = threadIdx.x; i < n; i += THREADS) {
-        const int32_t v = payload[beg + i];
+        const int32_t v = (int32_t)((uint32_t)payload[beg + i] & (MAP == 2 ? misplat_internal::kIdxMask : 0xffffffffu));
         const int32_t row = MAP == 1 ? isect_gid[v] : v;             // (what indexes `depths`)
         k0[i] = __float_as_uint(depths[row]);
         v0[i] = (uint32_t)v;
@@ -756,6 +756,7 @@ __global__ __launch_bounds__(64 * kFrontWaves) void tile_sort_front_kernel(
             pivot = __int_as_float(rec[F.pivot_off + t]) * F.margin;
             take = pivot < __builtin_inff() && pivot == pivot;   // (+inf: the last visit needed the whole list)
         }
+        const uint32_t qp = misplat_internal::depth_code9(pivot);   // (monotone: d <= pivot implies code(d) <= code(pivot))
         if (!take) {                                             // (uniform over the block)
             if (threadIdx.x == 0) { F.front_n[t] = -1; F.tile_flag[t] = 0; }
             continue;
@@ -767,12 +768,17 @@ __global__ __launch_bounds__(64 * kFrontWaves) void tile_sort_front_kernel(
             float d[kFrontU];
 #pragma unroll
             for (int u = 0; u < kFrontU; u++) { const int i = base + u * T + (int)threadIdx.x; v[u] = payload[beg + (i < n ? i : 0)]; }
-#pragma unroll
-            for (int u = 0; u < kFrontU; u++) d[u] = depths[v[u]];
+            // an entry whose depth code is above the pivot's lies behind it: dropped without fetching its depth (nine in ten)
 #pragma unroll
             for (int u = 0; u < kFrontU; u++) {
                 const int i = base + u * T + (int)threadIdx.x;
-                const bool keep = i < n && d[u] <= pivot;
+                const bool cand = i < n && ((uint32_t)v[u] >> misplat_internal::kIdxBits) <= qp;
+                v[u] = (int32_t)((uint32_t)v[u] & misplat_internal::kIdxMask);
+                d[u] = cand ? depths[v[u]] : __builtin_inff();
+            }
+#pragma unroll
+            for (int u = 0; u < kFrontU; u++) {
+                const bool keep = d[u] <= pivot;
                 const unsigned long long m = __ballot(keep);
                 if (m == 0ull) continue;                         // (uniform over the wave)
                 int pos0 = 0;

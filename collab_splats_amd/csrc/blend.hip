@@ -1402,6 +1402,18 @@ extern "C" int misplat_blend_bwd_x_atomic(const misplat_params* p, int32_t n_cha
                                           const float* v_render, const float* v_alpha, const float* v_exp_depth,
                                           const float* v_med_depth, const float* v_normal, float* v_grec,
                                           float* v_featx, float* v_abs, misplat_stream_t stream) {
+    return misplat_internal::blend_bwd_x_atomic(p, n_channels, nxq, Ks, grec, featx, flatten_ids, offsets, n_isects, alpha, last_ids,
+                                                median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, v_grec,
+                                                v_featx, v_abs, 0, (hipStream_t)stream);
+}
+
+int misplat_internal::blend_bwd_x_atomic(const misplat_params* p, int32_t n_channels, int32_t nxq, const float* Ks,
+                                         const float* grec, const float* featx, const int32_t* flatten_ids,
+                                         const int32_t* offsets, int64_t n_isects, const float* alpha,
+                                         const int32_t* last_ids, const int32_t* median_ids, const float* render,
+                                         const float* v_render, const float* v_alpha, const float* v_exp_depth,
+                                         const float* v_med_depth, const float* v_normal, float* v_grec,
+                                         float* v_featx, float* v_abs, int32_t zero_flags, hipStream_t stream) {
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || nxq < 1 || nxq > 4 || n_channels < 5 ||
         n_channels > 4 + 4 * nxq || !featx || !v_grec || !v_featx)
         return MISPLAT_EINVAL;
@@ -1409,9 +1421,9 @@ extern "C" int misplat_blend_bwd_x_atomic(const misplat_params* p, int32_t n_cha
     const size_t rows = (size_t)p->n_gauss * p->n_cams;
     if (rows == 0) return MISPLAT_OK;
     if (rows >= ((size_t)1 << 26)) return MISPLAT_EINVAL;   // (32-bit byte offsets into the gradient rows)
-    if (misplat_internal::fill_bytes(v_grec, rows * MISPLAT_REC * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
-    if (misplat_internal::fill_bytes(v_featx, rows * 4 * nxq * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
-    if (v_abs && misplat_internal::fill_bytes(v_abs, rows * 2 * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
+    if (!(zero_flags & 1) && misplat_internal::fill_bytes(v_grec, rows * MISPLAT_REC * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
+    if (!(zero_flags & 4) && misplat_internal::fill_bytes(v_featx, rows * 4 * nxq * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
+    if (v_abs && !(zero_flags & 2) && misplat_internal::fill_bytes(v_abs, rows * 2 * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     if (n_isects == 0) return MISPLAT_OK;
     const int total = p->tile_w * p->tile_h * p->n_cams * kBands;
     const int grid = ((total + 7) / 8) * 8;

@@ -283,6 +283,7 @@ struct TileWg {
     uint4 info[kRowsPerWg];         // (fill pass) per row: exclusive scan of the tile counts | x0 | y0 << 16 |
                                     //   rectangle width | in_window << 31 | bits of 1 / width
     int32_t row[kRowsPerWg];
+    uint16_t dcode[kRowsPerWg];     // (fill pass, index mode) 9-bit depth code of the row (misplat_internal::depth_code9)
     int32_t tab[kWinMax];           // difference array -> counts (stride ww + 1) -> (fill pass) cursors
     uint32_t wsum[kRowsPerWg / 64];
     int bb[4];                      // min x, min y, max x, max y of the small rectangles
@@ -471,7 +472,8 @@ template <bool DET, bool IDX>
 __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_fill_kernel(
     int n_gauss, int tw, int tiles_per_cam, const int64_t* __restrict__ counters, const int32_t* __restrict__ order,
     const uint2* __restrict__ rect2, const int32_t* __restrict__ offsets, int32_t* __restrict__ cursors,
-    const int64_t* __restrict__ cum, int64_t cap, int32_t* __restrict__ payload, int32_t* __restrict__ isect_gid) {
+    const int64_t* __restrict__ cum, int64_t cap, int32_t* __restrict__ payload, int32_t* __restrict__ isect_gid,
+    const float* __restrict__ depth_sorted) {
     __shared__ TileWg L;
     __shared__ uint32_t tbase[kWinMax];
     __shared__ __attribute__((aligned(16))) uint16_t owner[kOwnerChunk];
@@ -483,6 +485,9 @@ __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_fill_kernel(
     bool in_;
     tile_wg_prologue<true>(L, n_vis, n_gauss, order, rect2, cam0, wx0, wy0, ww, wh, r_, r2_, in_);
     const int64_t first_pos = (int64_t)blockIdx.x * rows_per_wg(n_vis);
+    // (index mode: the row's depth code rides in the entry's top bits -- the front kernel of the per-tile sort drops the
+    // entries behind its pivot by the code alone; depth_sorted[position] is a coalesced read here)
+    if (IDX) L.dcode[threadIdx.x] = r_ >= 0 ? (uint16_t)misplat_internal::depth_code9(depth_sorted[first_pos + threadIdx.x]) : 0;
     const uint32_t total = L.total;
     const int stride = ww + 1;
     // one returning atomic per (workgroup, tile): a contiguous range of the tile's bucket; tab becomes the cursors
@@ -551,7 +556,7 @@ __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_fill_kernel(
                     payload[slot] = (int32_t)es;
                     if (es < cap) isect_gid[es] = r;
                 } else {
-                    payload[slot] = IDX ? (int32_t)(first_pos + e) : r;
+                    payload[slot] = IDX ? (int32_t)((uint32_t)(first_pos + e) | ((uint32_t)L.dcode[e] << misplat_internal::kIdxBits)) : r;
                 }
             }
         }
@@ -639,15 +644,17 @@ extern "C" int misplat_bucket_tiles(const misplat_params* p, const int32_t* orde
                                     const int64_t* counters, int32_t* tile_count, int32_t* offsets, const int64_t* cum,
                                     int64_t cap_isects, int32_t* payload, int32_t* isect_gid, misplat_stream_t stream) {
     return misplat_internal::bucket_tiles(p, order, rect_sorted, counters, tile_count, offsets, cum, cap_isects, payload, isect_gid,
-                                          false, (hipStream_t)stream);
+                                          nullptr, (hipStream_t)stream);
 }
 
 int misplat_internal::bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect_sorted,
                                    const int64_t* counters, int32_t* tile_count, int32_t* offsets, const int64_t* cum,
-                                   int64_t cap_isects, int32_t* payload, int32_t* isect_gid, bool indexed,
+                                   int64_t cap_isects, int32_t* payload, int32_t* isect_gid, const float* depth_sorted,
                                    hipStream_t stream) {
+    const bool indexed = depth_sorted != nullptr;
     if (!p || p->tile_size != MISPLAT_TILE || !counters || !tile_count || !offsets || cap_isects < 0 ||
-        cap_isects > 0x7fffffffLL || (cum && !isect_gid && cap_isects > 0) || (indexed && cum))
+        cap_isects > 0x7fffffffLL || (cum && !isect_gid && cap_isects > 0) ||
+        (indexed && (cum || (int64_t)p->n_gauss * p->n_cams > (int64_t)misplat_internal::kIdxMask)))
         return MISPLAT_EINVAL;
     const int64_t total = (int64_t)p->n_gauss * p->n_cams;
     if (total > 0 && (!order || !rect_sorted)) return MISPLAT_EINVAL;
@@ -663,15 +670,15 @@ int misplat_internal::bucket_tiles(const misplat_params* p, const int32_t* order
         if (cum)
             hipLaunchKernelGGL((bucket_tile_fill_kernel<true, false>), dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
                                tiles_per_cam, counters, order, (const uint2*)rect_sorted, offsets, tile_count, cum, cap_isects,
-                               payload, isect_gid);
+                               payload, isect_gid, depth_sorted);
         else if (indexed)
             hipLaunchKernelGGL((bucket_tile_fill_kernel<false, true>), dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
                                tiles_per_cam, counters, order, (const uint2*)rect_sorted, offsets, tile_count, cum, cap_isects,
-                               payload, isect_gid);
+                               payload, isect_gid, depth_sorted);
         else
             hipLaunchKernelGGL((bucket_tile_fill_kernel<false, false>), dim3(grid), dim3(kRowsPerWg), 0, s, p->n_gauss, p->tile_w,
                                tiles_per_cam, counters, order, (const uint2*)rect_sorted, offsets, tile_count, cum, cap_isects,
-                               payload, isect_gid);
+                               payload, isect_gid, depth_sorted);
     }
     return check_launch();
 }

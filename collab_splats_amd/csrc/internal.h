@@ -67,6 +67,21 @@ int gauss_bwd_sparse(const misplat_params* p, int32_t sh_degree, int32_t depth_s
                      float* v_means2d_out /* or NULL: [N,2] (cleared like the others), columns 0:2 of the flagged rows */,
                      hipStream_t s);
 
+// Bucket entries in index mode (bucket_tiles(indexed)): position in the cell-ordered row list in the low 23 bits, a 9-bit
+// MONOTONE code of the row's depth above them (6 bits of the float's exponent from 2^-7 up, 3 bits of mantissa: buckets 9 %
+// wide).  The front kernel drops an entry whose code is above the pivot's without touching its depth; everything else masks
+// the code off.  Index mode therefore serves up to 2^23 (8.4 M) rows per call.
+constexpr uint32_t kIdxBits = 23, kIdxMask = (1u << kIdxBits) - 1u;
+__host__ __device__ inline uint32_t depth_code9(float d) {
+    uint32_t b;
+    __builtin_memcpy(&b, &d, 4);
+    if (d != d || (b >> 31)) return 0u;                           // (NaN / negative: never produced for a visible row)
+    const int e = (int)(b >> 23) - 120;
+    if (e < 0) return 0u;
+    if (e > 63) return 511u;
+    return ((uint32_t)e << 3) | ((b >> 20) & 7u);
+}
+
 // Front-only ordering (csrc/binning.hip, tile_sort_front_kernel): the view-keyed table of misplat_params.unit_sel, whose
 // records hold per-tile depth pivots at word pivot_off; front_n[n_tiles] / tile_flag[n_tiles] are written for every tile.
 struct FrontSort {
@@ -94,6 +109,27 @@ int bucket_rows(const misplat_params* p, const int32_t* tiles_per_gauss, const u
                 float* depth_sorted, hipStream_t stream);
 int bucket_tiles(const misplat_params* p, const int32_t* order, const uint32_t* rect_sorted, const int64_t* counters,
                  int32_t* tile_count, int32_t* offsets, const int64_t* cum, int64_t cap_isects, int32_t* payload,
-                 int32_t* isect_gid, bool indexed, hipStream_t stream);
+                 int32_t* isect_gid, const float* depth_sorted /* indexed mode, or NULL */, hipStream_t stream);
+
+// The colour stage with N-D channels (rade_features_model.py:427-476: SH colours + F distilled features, 16 fused channels,
+// 17 with RGB+ED).  color_fwd = misplat_color_fwd whose record slot 3 takes slot3[g * slot3_stride] (SH colours only: the
+// first feature channel rides in the record); color_fwd_x / color_bwd_x = misplat_color_fwd_x / _bwd_x for a source
+// [(C,)N,D] that supplies the fused channels FROM n_pre ON (n_pre = 3 behind SH colours: group 0 is then the colour
+// kernel's), clearing the gradient rows the compositing backward will add into (zero_grec [C*N,16], zero_featx [C*N,4 nxq]).
+int color_fwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color, int32_t per_cam, int32_t depth_channel,
+              const float* means, const float* viewmats, const float* coeffs_or_colors, const float* coeffs_rest,
+              const int32_t* radii, const float* depths, float* grec, float* sh_aux, float* zero_rows, const float* slot3,
+              int32_t slot3_stride, hipStream_t stream);
+int color_fwd_x(const misplat_params* p, int32_t D, int32_t n_pre, int32_t per_cam, int32_t depth_channel, int32_t nxq,
+                const float* colors, const int32_t* radii, const float* depths, float* grec, float* featx, float* zero_grec,
+                float* zero_featx, hipStream_t stream);
+int color_bwd_x(const misplat_params* p, int32_t D, int32_t n_pre, int32_t per_cam, int32_t nxq, const int32_t* radii,
+                const float* v_grec, const float* v_featx, float* v_colors, hipStream_t stream);
+// misplat_blend_bwd_x_atomic whose fills are skipped for what the forward cleared: zero_flags bit 0 v_grec, 1 v_abs, 2 v_featx.
+int blend_bwd_x_atomic(const misplat_params* p, int32_t n_channels, int32_t nxq, const float* Ks, const float* grec,
+                       const float* featx, const int32_t* flatten_ids, const int32_t* offsets, int64_t n_isects,
+                       const float* alpha, const int32_t* last_ids, const int32_t* median_ids, const float* render,
+                       const float* v_render, const float* v_alpha, const float* v_exp_depth, const float* v_med_depth,
+                       const float* v_normal, float* v_grec, float* v_featx, float* v_abs, int32_t zero_flags, hipStream_t s);
 
 }  // namespace misplat_internal

@@ -677,7 +677,10 @@ __global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : 
     const float* __restrict__ viewmats, const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest,
     const int32_t* __restrict__ radii, const float* __restrict__ depths, float* __restrict__ grec,
     const float* __restrict__ v_grec, float* __restrict__ v_coeffs, float* __restrict__ v_coeffs_rest,
-    float* __restrict__ v_means_dir, float* __restrict__ sh_aux = nullptr, float4* __restrict__ zero_rows = nullptr) {
+    float* __restrict__ v_means_dir, float* __restrict__ sh_aux = nullptr, float4* __restrict__ zero_rows = nullptr,
+    const float* __restrict__ slot3 = nullptr, int slot3_stride = 0) {
+    // slot3 (forward, or NULL): the record's fourth colour slot takes slot3[g * slot3_stride] -- the first of the feature
+    // channels the features model composites behind its SH colours (rade_features_model.py:441) -- instead of the depth / 0
     // coeffs_rest == NULL: coeffs is [N,K,3]; else coeffs is features_dc [N,3] and coeffs_rest is
     // features_rest [N,K-1,3] (the two parameter tensors of rade_gs_model.py:119-120, read in place
     // instead of through the per-step torch.cat of :128-130)
@@ -700,7 +703,8 @@ __global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : 
             const int gp = g0 + threadIdx.x;
             pr0 = radii[2 * (int64_t)gp]; pr1 = radii[2 * (int64_t)gp + 1];
             pm0 = means[3 * gp]; pm1 = means[3 * gp + 1]; pm2 = means[3 * gp + 2];
-            if (depth_channel) pdep = depths[gp];
+            if (slot3) pdep = slot3[(size_t)gp * slot3_stride];
+            else if (depth_channel) pdep = depths[gp];
         }
         constexpr bool USE_VIS = KC && BWD && !AUX;
         float pv0 = 0.f, pv1 = 0.f, pv2 = 0.f;      // (USE_VIS) camera 0: the row's colour gradient, fetched with the radii
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(BLOCK, (!BWD && KC == 16) ? MISPLAT_SH_FWD_WAVES : 
                 if (!BWD) {
                     float* o = grec + (size_t)idx * MISPLAT_REC + 12;
                     float4 c = make_float4(fmaxf(c0 + 0.5f, 0.f), fmaxf(c1 + 0.5f, 0.f), fmaxf(c2 + 0.5f, 0.f),
-                                           depth_channel ? (first ? pdep : depths[idx]) : 0.f);
+                                           slot3 ? pdep : (depth_channel ? (first ? pdep : depths[idx]) : 0.f));
                     if (!vis) c = make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(o) = c;
                     if (zero_rows && !KC) {          // the gradient row the backward's atomics will add into: no memset later
@@ -1049,21 +1053,31 @@ __global__ __launch_bounds__(256) void color_copy_bwd_kernel(misplat_params P, i
 // read consecutive 16-byte pieces of the colour rows (a whole 64-byte row of 16 channels per four threads) instead of one
 // thread walking its row channel by channel through 64-byte strides -- the first version took 230 us for 144 MB at 1 M
 // Gaussians, 20x the streaming time.
-__global__ __launch_bounds__(256) void color_copy_x_kernel(misplat_params P, int D, int per_cam, int depth_channel,
+// n_pre: the fused row's first n_pre channels come from elsewhere (3: the SH colours the colour kernel writes, together with
+// channel 3 = colors[., 0], into the record): source channel j is fused channel n_pre + j, and group 0 is not written here.
+// zero_grec / zero_featx (or NULL): the gradient rows [C*N,16] / [C*N,4 nxq] the compositing backward adds into are cleared
+// in passing (no fill launch in the backward).
+__global__ __launch_bounds__(256) void color_copy_x_kernel(misplat_params P, int D, int n_pre, int per_cam, int depth_channel,
                                                            int nxq, const float* __restrict__ colors,
                                                            const int32_t* __restrict__ radii,
                                                            const float* __restrict__ depths, float* __restrict__ grec,
-                                                           float* __restrict__ featx) {
+                                                           float* __restrict__ featx, float4* __restrict__ zero_grec,
+                                                           float4* __restrict__ zero_featx) {
     const int64_t total = (int64_t)P.n_cams * P.n_gauss;
     const int groups = 1 + nxq;
-    const bool vec = (D & 3) == 0 && ((uintptr_t)colors & 15) == 0;
+    const bool vec = n_pre == 0 && (D & 3) == 0 && ((uintptr_t)colors & 15) == 0;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total * groups; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t idx = t / groups;
         const int q = (int)(t - idx * groups);
+        if (q == 0) {
+            if (zero_grec) { float4* zr = zero_grec + 4 * idx; zr[0] = z4; zr[1] = z4; zr[2] = z4; zr[3] = z4; }
+            if (n_pre > 0) continue;                              // (the record's colour slots are the colour kernel's)
+        } else if (zero_featx) zero_featx[idx * nxq + (q - 1)] = z4;
         const int64_t src = per_cam ? idx : idx % P.n_gauss;
         const int2 rd = reinterpret_cast<const int2*>(radii)[idx];
         const bool vis = rd.x > 0 || rd.y > 0;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 v = z4;
         if (vis) {
             const int c0 = 4 * q;
             if (vec && c0 + 4 <= D) {
@@ -1072,8 +1086,8 @@ __global__ __launch_bounds__(256) void color_copy_x_kernel(misplat_params P, int
                 float e[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const int c = c0 + k;
-                    e[k] = c < D ? colors[(size_t)src * D + c] : ((c == D && depth_channel) ? depths[idx] : 0.f);
+                    const int j = c0 + k - n_pre;
+                    e[k] = j < D ? colors[(size_t)src * D + j] : ((j == D && depth_channel) ? depths[idx] : 0.f);
                 }
                 v = make_float4(e[0], e[1], e[2], e[3]);
             }
@@ -1083,7 +1097,7 @@ __global__ __launch_bounds__(256) void color_copy_x_kernel(misplat_params P, int
     }
 }
 
-__global__ __launch_bounds__(256) void color_copy_x_bwd_kernel(misplat_params P, int D, int per_cam, int nxq,
+__global__ __launch_bounds__(256) void color_copy_x_bwd_kernel(misplat_params P, int D, int n_pre, int per_cam, int nxq,
                                                                const int32_t* __restrict__ radii,
                                                                const float* __restrict__ v_grec,
                                                                const float* __restrict__ v_featx,
@@ -1091,7 +1105,33 @@ __global__ __launch_bounds__(256) void color_copy_x_bwd_kernel(misplat_params P,
     const int64_t rows = per_cam ? (int64_t)P.n_cams * P.n_gauss : P.n_gauss;
     const int nx = 4 * nxq;
     const int groups = (D + 3) >> 2;                             // 16-byte groups of an output row
-    const bool vec = (D & 3) == 0 && ((uintptr_t)v_colors & 15) == 0;
+    const bool vec = n_pre == 0 && (D & 3) == 0 && ((uintptr_t)v_colors & 15) == 0;
+    if (n_pre > 0) {
+        // source channel j is fused channel n_pre + j: the groups of the output row do not line up with those of the fused
+        // row -- four scalar picks per thread (slot 12 + c of the record row for c < 4, featx beyond)
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < rows * groups; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t r = t / groups;
+            const int q = (int)(t - r * groups);
+            const int c_lo = per_cam ? (int)(r / P.n_gauss) : 0, c_hi = per_cam ? c_lo + 1 : P.n_cams;
+            const int g = (int)(r % P.n_gauss);
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int ci = c_lo; ci < c_hi; ci++) {
+                const int64_t idx = (int64_t)ci * P.n_gauss + g;
+                const int2 rd = reinterpret_cast<const int2*>(radii)[idx];
+                if (rd.x > 0 || rd.y > 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int c = n_pre + 4 * q + k;
+                        if (4 * q + k < D) acc[k] += c < 4 ? v_grec[(size_t)idx * MISPLAT_REC + 12 + c] : v_featx[(size_t)idx * nx + c - 4];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (4 * q + k < D) v_colors[(size_t)r * D + 4 * q + k] = acc[k];
+        }
+        return;
+    }
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < rows * groups; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = t / groups;
         const int q = (int)(t - r * groups);
@@ -1670,7 +1710,15 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
                                  const float* viewmats, const float* coeffs_or_colors, const float* coeffs_rest,
                                  const int32_t* radii, const float* depths, float* grec, float* sh_aux,
                                  float* zero_rows, misplat_stream_t stream) {
-    if (!p || p->n_gauss < 0 || p->n_cams < 1) return MISPLAT_EINVAL;
+    return misplat_internal::color_fwd(p, sh_degree, K_or_D, n_color, per_cam, depth_channel, means, viewmats, coeffs_or_colors,
+                                       coeffs_rest, radii, depths, grec, sh_aux, zero_rows, nullptr, 0, (hipStream_t)stream);
+}
+
+int misplat_internal::color_fwd(const misplat_params* p, int32_t sh_degree, int32_t K_or_D, int32_t n_color, int32_t per_cam,
+                                int32_t depth_channel, const float* means, const float* viewmats, const float* coeffs_or_colors,
+                                const float* coeffs_rest, const int32_t* radii, const float* depths, float* grec, float* sh_aux,
+                                float* zero_rows, const float* slot3, int32_t slot3_stride, hipStream_t stream) {
+    if (!p || p->n_gauss < 0 || p->n_cams < 1 || (slot3 && (sh_degree < 0 || depth_channel))) return MISPLAT_EINVAL;
     if (n_color < 0 || n_color + (depth_channel ? 1 : 0) > 4) return MISPLAT_EINVAL;
     if (p->n_gauss == 0) return MISPLAT_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -1686,7 +1734,7 @@ extern "C" int misplat_color_fwd(const misplat_params* p, int32_t sh_degree, int
                        dim3(n_blocks < 16384 ? n_blocks : 16384),                                                   \
                        dim3(BLK), lds, s, *p, K_or_D, sh_degree, depth_channel, means, viewmats, coeffs_or_colors, \
                        coeffs_rest, radii, depths, grec, (const float*)nullptr, (float*)nullptr, (float*)nullptr,  \
-                       (float*)nullptr, sh_aux, (float4*)zero_rows)
+                       (float*)nullptr, sh_aux, (float4*)zero_rows, slot3, (int)slot3_stride)
 #define LAUNCH_SH_FWD_K(AUX_)                                                                                      \
     do {                                                                                                           \
         if (!k16) LAUNCH_SH_FWD(AUX_, 0, -1);                                                                      \
@@ -1829,22 +1877,36 @@ extern "C" int misplat_project_pack_bwd(const misplat_params* p, int32_t depth_s
 extern "C" int misplat_color_fwd_x(const misplat_params* p, int32_t D, int32_t per_cam, int32_t depth_channel,
                                    int32_t nxq, const float* colors, const int32_t* radii, const float* depths,
                                    float* grec, float* featx, misplat_stream_t stream) {
-    if (!p || p->n_gauss < 0 || p->n_cams < 1 || nxq < 1 || nxq > 4 || D < 1 || D + (depth_channel ? 1 : 0) > 4 + 4 * nxq)
+    return misplat_internal::color_fwd_x(p, D, 0, per_cam, depth_channel, nxq, colors, radii, depths, grec, featx, nullptr, nullptr,
+                                         (hipStream_t)stream);
+}
+
+int misplat_internal::color_fwd_x(const misplat_params* p, int32_t D, int32_t n_pre, int32_t per_cam, int32_t depth_channel,
+                                  int32_t nxq, const float* colors, const int32_t* radii, const float* depths, float* grec,
+                                  float* featx, float* zero_grec, float* zero_featx, hipStream_t stream) {
+    if (!p || p->n_gauss < 0 || p->n_cams < 1 || nxq < 1 || nxq > 4 || D < 1 || n_pre < 0 || n_pre > 3 ||
+        n_pre + D + (depth_channel ? 1 : 0) > 4 + 4 * nxq || (((uintptr_t)zero_grec | (uintptr_t)zero_featx | (uintptr_t)featx) & 15))
         return MISPLAT_EINVAL;
     int64_t total = (int64_t)p->n_gauss * p->n_cams;
     if (total == 0) return MISPLAT_OK;
-    hipLaunchKernelGGL(color_copy_x_kernel, dim3(grid_for(total * (1 + nxq), 256)), dim3(256), 0, (hipStream_t)stream, *p, D,
-                       per_cam, depth_channel, nxq, colors, radii, depths, grec, featx);
+    hipLaunchKernelGGL(color_copy_x_kernel, dim3(grid_for(total * (1 + nxq), 256)), dim3(256), 0, stream, *p, D, (int)n_pre,
+                       per_cam, depth_channel, nxq, colors, radii, depths, grec, featx, (float4*)zero_grec, (float4*)zero_featx);
     return check_launch();
 }
 
 extern "C" int misplat_color_bwd_x(const misplat_params* p, int32_t D, int32_t per_cam, int32_t nxq,
                                    const int32_t* radii, const float* v_grec, const float* v_featx,
                                    float* v_colors, misplat_stream_t stream) {
-    if (!p || p->n_gauss < 0 || p->n_cams < 1 || nxq < 1 || nxq > 4 || D < 1) return MISPLAT_EINVAL;
+    return misplat_internal::color_bwd_x(p, D, 0, per_cam, nxq, radii, v_grec, v_featx, v_colors, (hipStream_t)stream);
+}
+
+int misplat_internal::color_bwd_x(const misplat_params* p, int32_t D, int32_t n_pre, int32_t per_cam, int32_t nxq,
+                                  const int32_t* radii, const float* v_grec, const float* v_featx, float* v_colors,
+                                  hipStream_t stream) {
+    if (!p || p->n_gauss < 0 || p->n_cams < 1 || nxq < 1 || nxq > 4 || D < 1 || n_pre < 0 || n_pre > 3) return MISPLAT_EINVAL;
     int64_t rows = per_cam ? (int64_t)p->n_gauss * p->n_cams : p->n_gauss;
     if (rows == 0) return MISPLAT_OK;
-    hipLaunchKernelGGL(color_copy_x_bwd_kernel, dim3(grid_for(rows * ((D + 3) / 4), 256)), dim3(256), 0, (hipStream_t)stream, *p,
-                       D, per_cam, nxq, radii, v_grec, v_featx, v_colors);
+    hipLaunchKernelGGL(color_copy_x_bwd_kernel, dim3(grid_for(rows * ((D + 3) / 4), 256)), dim3(256), 0, stream, *p,
+                       D, (int)n_pre, per_cam, nxq, radii, v_grec, v_featx, v_colors);
     return check_launch();
 }

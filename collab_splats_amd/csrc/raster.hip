@@ -63,7 +63,22 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
                                            a->cell_offs, a->order, a->rect_sorted, a->counters, a->tile_count, a->n_isects_host,
                                            3, a->depth_sorted ? a->depths : nullptr, a->depth_sorted, s);
         if (rc != MISPLAT_OK) return rc;
-        if (!a->lazy_colour) {
+        if (a->nxq > 0) {
+            // N-D channels (the features model): SH colours + feature channels written side by side, or pass-through
+            if (a->lazy_colour || !a->featx || a->nxq > 4) return MISPLAT_EINVAL;
+            if (a->sh_degree >= 0) {
+                if (!a->features || a->n_feat < 1) return MISPLAT_EINVAL;
+                rc = misplat_internal::color_fwd(p, a->sh_degree, a->K_or_D, 3, 0, 0, a->means, a->viewmats, a->colors,
+                                                 a->colors_rest, a->radii, a->depths, a->grec, a->sh_aux, a->v_grec_zero,
+                                                 a->features, a->n_feat, s);
+                if (rc != MISPLAT_OK) return rc;
+                rc = misplat_internal::color_fwd_x(p, a->n_feat, 3, 0, a->depth_channel, a->nxq, a->features, a->radii, a->depths,
+                                                   a->grec, a->featx, nullptr, a->v_featx_zero, s);
+            } else
+                rc = misplat_internal::color_fwd_x(p, a->K_or_D, 0, a->per_cam, a->depth_channel, a->nxq, a->colors, a->radii,
+                                                   a->depths, a->grec, a->featx, a->v_grec_zero, a->v_featx_zero, s);
+            if (rc != MISPLAT_OK) return rc;
+        } else if (!a->lazy_colour) {
             rc = enqueue_colour(p, a, stream);
             if (rc != MISPLAT_OK) return rc;
         }
@@ -72,7 +87,7 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         if (a->cap_isects < 0 || a->cap_isects > 0x7fffffffLL) return MISPLAT_EINVAL;
         // (depth_sorted given: bucket entries are positions in the cell-ordered row list, the sort's depth gather stays local)
         rc = misplat_internal::bucket_tiles(p, a->order, a->rect_sorted, a->counters, a->tile_count, a->offsets, nullptr,
-                                            a->cap_isects, a->payload, nullptr, a->depth_sorted != nullptr, s);
+                                            a->cap_isects, a->payload, nullptr, a->depth_sorted, s);
         if (rc != MISPLAT_OK) return rc;
         const float* sort_depths = a->depth_sorted ? a->depth_sorted : a->depths;
         const int32_t* sort_map = a->depth_sorted ? a->order : nullptr;
@@ -116,6 +131,10 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         if (a->ev_blend_begin && hipEventRecord((hipEvent_t)a->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
         if (a->lazy_colour == 2 && !a->v_grec_zero) return MISPLAT_EINVAL;
         auto composite = [&]() -> int {
+        if (a->nxq > 0)
+            return misplat_blend_fwd_x(&q, a->color_dim, a->nxq, a->Ks, a->grec, a->featx, a->flatten_ids, a->offsets,
+                                       a->cap_isects, a->render, a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids,
+                                       a->median_ids, stream);
         if (a->lazy_colour) {
             return misplat_internal::blend_fwd_lazy(&q, a->color_dim, a->Ks, a->grec, a->flatten_ids, a->offsets, a->cap_isects,
                                                   a->render, a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids,
@@ -328,7 +347,7 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
 // launcher puts them in front from 2.5 M rows.  Needs the row flags (misplat_params.touched), one camera, 16 SH
 // coefficients without Jacobian cache.
 static bool background_fill_ok(const misplat_params* p, const misplat_raster_bwd_args* b) {
-    if (!(p->touched && p->n_cams == 1 && p->n_gauss >= 262144 && b->sh_degree >= 0 && !b->sh_aux && b->K_or_D == 16 &&
+    if (!(p->touched && p->n_cams == 1 && p->n_gauss >= 262144 && b->sh_degree >= 0 && !b->sh_aux && b->K_or_D == 16 && b->nxq == 0 &&
           !b->v_means2d && (b->colors_rest != nullptr) == (b->v_colors_rest != nullptr)))
         return false;
     const uintptr_t a16 = (uintptr_t)b->colors | (uintptr_t)b->v_colors | (uintptr_t)b->v_colors_rest | (uintptr_t)b->v_grec |
@@ -359,6 +378,37 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
         add(b->v_opacities, n);
         if (b->v_means2d_out) add(b->v_means2d_out, n * 2);
     }
+    if (b->nxq > 0) {
+        // N-D channels: compositing backward over record + featx rows, then the colour stage's backward, then the projection's
+        if (!b->featx || !b->v_featx || b->nxq > 4) return MISPLAT_EINVAL;
+        if (b->ev_blend_begin && hipEventRecord((hipEvent_t)b->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
+        int rx = misplat_internal::blend_bwd_x_atomic(&q, b->color_dim, b->nxq, b->Ks, b->grec, b->featx, b->flatten_ids, b->offsets,
+                                                      b->n_isects, b->alpha, b->last_ids, b->median_ids, b->render, b->v_render,
+                                                      b->v_alpha, b->v_exp_depth, b->v_med_depth, b->v_normal, b->v_grec,
+                                                      b->v_featx, b->v_abs, b->zero_flags, s);
+        if (rx != MISPLAT_OK) return rx;
+        if (b->ev_blend_end && hipEventRecord((hipEvent_t)b->ev_blend_end, s) != hipSuccess) return MISPLAT_ELAUNCH;
+        const int n_pre = b->sh_degree >= 0 ? 3 : 0, d_src = b->sh_degree >= 0 ? b->n_feat : b->K_or_D;
+        if (b->sh_degree >= 0) {
+            if (!b->v_features || !b->v_means_dir) return MISPLAT_EINVAL;
+            rx = misplat_color_bwd(p, b->sh_degree, b->K_or_D, 3, 0, b->means, b->viewmats, b->colors, b->colors_rest, b->radii,
+                                   b->v_grec, b->v_colors, b->v_colors_rest, b->v_means_dir, b->sh_aux, (misplat_stream_t)s);
+            if (rx != MISPLAT_OK) return rx;
+            rx = misplat_internal::color_bwd_x(p, d_src, 3, 0, b->nxq, b->radii, b->v_grec, b->v_featx, b->v_features, s);
+        } else
+            rx = misplat_internal::color_bwd_x(p, d_src, 0, b->per_cam, b->nxq, b->radii, b->v_grec, b->v_featx, b->v_colors, s);
+        if (rx != MISPLAT_OK) return rx;
+        int depth_slot = -1, stride = 0;
+        const float* v_depth_rows = nullptr;
+        if (b->depth_channel) {
+            const int c = n_pre + d_src;                               // the depth rides behind the user channels
+            if (c < 4) depth_slot = 12 + c;
+            else { v_depth_rows = b->v_featx + (c - 4); stride = 4 * b->nxq; }
+        }
+        return misplat_project_pack_bwd(p, depth_slot, b->means, b->quats, b->scales, b->opacities, b->viewmats, b->Ks, b->radii,
+                                        b->compensations, b->v_means2d, b->v_grec, b->sh_degree >= 0 ? b->v_means_dir : nullptr,
+                                        b->v_means, b->v_quats, b->v_scales, b->v_opacities, v_depth_rows, stride, (misplat_stream_t)s);
+    }
     if (b->ev_blend_begin && hipEventRecord((hipEvent_t)b->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
     int rc = misplat_internal::blend_bwd_atomic(&q, b->color_dim, b->Ks, b->grec, b->flatten_ids, b->offsets, b->n_isects,
                                                 b->alpha, b->last_ids, b->median_ids, b->render, b->v_render, b->v_alpha,
@@ -384,7 +434,7 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
 // graph (memset-free, no measurement events).
 extern "C" int misplat_raster_bwd_plan(const misplat_params* p, const misplat_raster_bwd_args* b) {
     if (!p || !b) return MISPLAT_EINVAL;
-    const bool memset_free = (b->zero_flags & 1) && (!b->v_abs || (b->zero_flags & 2));
+    const bool memset_free = (b->zero_flags & 1) && (!b->v_abs || (b->zero_flags & 2)) && (b->nxq == 0 || (b->zero_flags & 4));
     return (background_fill_ok(p, b) ? 1 : 0) | ((memset_free && !b->ev_blend_begin && !b->ev_blend_end) ? 2 : 0);
 }
 
@@ -393,7 +443,7 @@ extern "C" int misplat_raster_bwd(const misplat_params* p, const misplat_raster_
     if (!p || !b) return MISPLAT_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     // memset nodes are kept out of graphs (see the note on phase A): only the memset-free form is captured
-    const bool memset_free = (b->zero_flags & 1) && (!b->v_abs || (b->zero_flags & 2));
+    const bool memset_free = (b->zero_flags & 1) && (!b->v_abs || (b->zero_flags & 2)) && (b->nxq == 0 || (b->zero_flags & 4));
     if (!cache || !memset_free || b->ev_blend_begin || b->ev_blend_end) return enqueue_backward(p, b, s);
     return run_cached(cache, make_key(0x100, s, p, b), s, [&](hipStream_t st) { return enqueue_backward(p, b, st); });
 }

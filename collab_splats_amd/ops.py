@@ -708,7 +708,7 @@ def _front_only_wanted(P: Params, dev) -> bool:
 
 def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg: int, kd: int,
                     n_color: int, per_cam: int, depth_channel: bool, want_aux: bool, want_grad: bool, defer: bool = False,
-                    lazy: bool = False, flags: bool = False, absgrad: bool = False):
+                    lazy: bool = False, flags: bool = False, absgrad: bool = False, nxq: int = 0, features=None):
     """Allocations + phase A of misplat_raster_fwd (``defer``: phase A is launched together with B, by _raster_phase_b).
     Returns (radii, means2d, depths, comps, grec, sh_aux, state)."""
     lib = _lib.load()
@@ -722,13 +722,16 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     # (records, lists) start on 2 MiB boundaries.  A slot is handed out again only when nothing refers to its storage.
     # (bucket entries as positions in the cell-ordered row list: pays where the per-tile sort's depth gather misses the L2 --
     # dense scenes, i.e. together with front-only ordering; at 1 M Gaussians it costs the sort a second gather: 55 -> 86 us)
-    indexed = INDEXED_BUCKETS and _front_only_wanted(P, dev)
+    indexed = INDEXED_BUCKETS and _front_only_wanted(P, dev) and rows < (1 << 23)     # (23 index bits + 9 bits of depth code)
     cv = arena.Carver(("fwd", dev.index, _stream_id(), N, Cn, P.width, P.height, kd, int(want_grad), int(want_aux), int(absgrad),
-                       int(depth_channel), int(indexed)), dev)
+                       int(depth_channel), int(indexed), int(nxq)), dev)
     means2d, depths, comps, sh_aux = _carve_f(dev, (2 * rows, rows, rows, 12 * rows if want_aux else 0), cv)
     grec = cv.take(MISPLAT_REC * rows, torch.float32)
     v_grec_zero = cv.take(MISPLAT_REC * rows, torch.float32).view(rows, MISPLAT_REC) if want_grad else None
     v_abs_zero = cv.take(2 * rows, torch.float32).view(rows, 2) if (want_grad and absgrad) else None
+    # N-D colours (the features model, nxq > 0): channels 4.. of every row, and their gradient rows
+    featx = cv.take(4 * nxq * rows, torch.float32).view(rows, 4 * nxq) if nxq > 0 else None
+    v_featx_zero = cv.take(4 * nxq * rows, torch.float32).view(rows, 4 * nxq) if (nxq > 0 and want_grad) else None
     # (cell_count, cell_cursor, counters, tile_count back to back: the projection kernel clears that contiguous range -- no
     # memset, no clearing launch)
     (radii, tiles_per_gauss, rect2, cellhist, cell_count, cell_cursor, counters, tile_count, cell_offs, order, rect_sorted,
@@ -750,6 +753,8 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     a.sh_aux = _dp(sh_aux) if want_aux else None
     a.v_grec_zero = _dp(v_grec_zero)
     a.v_abs_zero = _dp(v_abs_zero)
+    a.nxq, a.featx, a.v_featx_zero = int(nxq), _dp(featx), _dp(v_featx_zero)
+    a.features, a.n_feat = _dp(features), (int(features.shape[-1]) if features is not None else 0)
     a.tiles_per_gauss, a.rect2, a.cellhist, a.cell_count = _dp(tiles_per_gauss), _dp(rect2), _dp(cellhist), _dp(cell_count)
     a.cell_offs, a.order, a.counters, a.tile_count = _dp(cell_offs), _dp(order), _dp(counters), _dp(tile_count)
     a.cell_cursor = _dp(cell_cursor)
@@ -772,7 +777,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
         check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(1), stream_ptr(), _graph_cache(dev)),
               "misplat_raster_fwd(A)")
     state = dict(args=a, host=host, tiles_per_gauss=tiles_per_gauss, depths=depths, v_grec_zero=v_grec_zero, v_abs_zero=v_abs_zero,
-                 deferred=defer, rows_on_touch=rows_on_touch, order=order, carver=cv,
+                 deferred=defer, rows_on_touch=rows_on_touch, order=order, carver=cv, featx=featx, v_featx_zero=v_featx_zero,
                  counters=counters, touched=touched,
                  keep=(rect2, cellhist, cell_count, cell_offs, row_order, counters, tile_count, radii, cell_cursor, depth_sorted),
                  row_map=row_order, depth_sorted=depth_sorted.view(torch.float32) if indexed else None)
@@ -877,6 +882,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         PATH_STATS["forward_arena_slot"] += int(cv.slot is not None)
     bins = dict(tiles_per_gauss=state["tiles_per_gauss"], n_isects=cap if static else n_known, depths=state["depths"],
                 tile_ids=None, v_grec_zero=state.get("v_grec_zero"), v_abs_zero=state.get("v_abs_zero"),
+                featx=state.get("featx"), v_featx_zero=state.get("v_featx_zero"),
                 rows_on_touch=bool(state.get("rows_on_touch")), n_isects_dev=state["counters"].view(torch.int64)[0] if static else None,
                 n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:cap if static else n_known],
                 isect_offsets=offsets[:n_tiles + 1], _keep=(scratch, payload, reach),
@@ -910,18 +916,20 @@ def fused_node_ok() -> bool:
 
 class _RasterFused(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, P: Params, sh_degree,
+    def forward(ctx, means, quats, scales, opacities, colors, colors_rest, features, viewmats, Ks, P: Params, sh_degree,
                 depth_channel: bool, cd: int, absgrad: bool, extra: dict):
         import weakref
-        require_gpu(means, quats, scales, opacities, colors, viewmats, Ks)
+        require_gpu(means, quats, scales, opacities, colors, viewmats, Ks, features)
         if sh_degree is not None:
             kd = colors.shape[1] if colors_rest is None else 1 + colors_rest.shape[1]
             deg, n_color, per_cam = int(sh_degree), 3, 0
         else:
             deg, kd, per_cam = -1, colors.shape[-1], int(colors.dim() == 3)
             n_color = kd
-        want_grad = any(ctx.needs_input_grad[:6])
-        lazy = _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd)
+        want_grad = any(ctx.needs_input_grad[:7])
+        # N-D colours in one pass (a8, rade_features_model.py:427-476): cd = D' composited channels, 4 in the record + 4 nxq
+        nxq = (cd - 4 + 3) // 4 if cd > 4 else 0
+        lazy = nxq == 0 and _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd)
         want_aux = SH_AUX and deg >= 0 and want_grad and not lazy
         defer = _STATIC_CAP is not None or (MERGE_PHASES and SPECULATE and _cap_key(P, means.device) in _CAP_HINT)
         PATH_STATS["forward"] += 1
@@ -929,18 +937,21 @@ class _RasterFused(torch.autograd.Function):
         PATH_STATS["forward_merged_phases"] += int(bool(defer))
         radii, means2d, depths, comps, grec, sh_aux, state = _raster_phase_a(
             P, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam, depth_channel,
-            want_aux, want_grad, defer=defer, lazy=lazy, flags=True, absgrad=bool(absgrad))
+            want_aux, want_grad, defer=defer, lazy=lazy, flags=True, absgrad=bool(absgrad), nxq=nxq, features=features)
+        PATH_STATS["forward_nd"] += int(nxq > 0)
         imgs, bins, sched = _raster_phase_b(P, state, cd)
         render, alpha, exp_depth, med_depth, normal, last_ids, median_ids = imgs
         extra["bins"] = bins
         ctx.P, ctx.bins, ctx.sched, ctx.cd, ctx.absgrad = P, bins, sched, cd, absgrad
         ctx.color_args = (deg, kd, n_color, per_cam)
-        ctx.depth_slot = 12 + n_color if depth_channel else -1
+        ctx.depth_slot = 12 + n_color if (depth_channel and nxq == 0) else -1
+        ctx.nd = (nxq, bool(depth_channel), features is not None)
         ctx.has_rest, ctx.has_aux = colors_rest is not None, sh_aux is not None
         ctx.means2d_ref = weakref.ref(means2d)
         ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps,
                               colors_rest if colors_rest is not None else colors,
-                              sh_aux if sh_aux is not None else comps, grec, alpha, last_ids, median_ids, render)
+                              sh_aux if sh_aux is not None else comps, grec, alpha, last_ids, median_ids, render,
+                              features if features is not None else comps)
         ctx.mark_non_differentiable(radii, depths, comps, grec, last_ids, median_ids)
         ctx.set_materialize_grads(False)
         return render, alpha, exp_depth, med_depth, normal, means2d, radii, depths, comps, grec, last_ids, median_ids
@@ -949,7 +960,10 @@ class _RasterFused(torch.autograd.Function):
     def backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, v_means2d_in, *_unused):
         lib = _lib.load()
         (means, quats, scales, opacities, colors, viewmats, Ks, radii, comps, colors_rest, sh_aux, grec, alpha, last_ids,
-         median_ids, render) = ctx.saved_tensors
+         median_ids, render, features) = ctx.saved_tensors
+        nxq, nd_depth, has_feat = ctx.nd
+        if not has_feat:
+            features = None
         if not ctx.has_rest:
             colors_rest = None
         if not ctx.has_aux:
@@ -976,6 +990,17 @@ class _RasterFused(torch.autograd.Function):
             flags |= 2
         v_colors = _grad_out(colors, cvb)
         v_colors_rest = _grad_out(colors_rest, cvb) if colors_rest is not None else None
+        v_features = _grad_out(features, cvb) if features is not None else None
+        v_featx = None
+        if nxq > 0:
+            v_featx = bins.pop("v_featx_zero", None)                 # cleared by the forward's colour stage
+            if v_featx is not None:
+                flags |= 4
+            else:
+                v_featx = cvb.take(rows * 4 * nxq, torch.float32).view(rows, 4 * nxq)
+            if v_means2d_in is not None:
+                raise _lib.MisplatError("a gradient reached meta['means2d'] from outside the rasterizer in a call with more than four "
+                                        "colour channels: that combination goes stage by stage only (MISPLAT_FUSED_NODE=0)")
         v_means_dir = cvb.take(means.numel(), torch.float32).view(means.shape) if deg >= 0 else None
         v_means, v_quats = _grad_out(means, cvb), _grad_out(quats, cvb)
         v_scales, v_opac = _grad_out(scales, cvb), _grad_out(opacities, cvb)
@@ -1003,6 +1028,10 @@ class _RasterFused(torch.autograd.Function):
             b.compensations, b.sh_aux, b.v_means2d = _dp(comps), _dp(sh_aux), None
             b.v_colors, b.v_colors_rest, b.v_means_dir = _dp(v_colors), _dp(v_colors_rest), _dp(v_means_dir)
             b.v_means, b.v_quats, b.v_scales, b.v_opacities = _dp(v_means), _dp(v_quats), _dp(v_scales), _dp(v_opac)
+            if nxq > 0:
+                b.nxq, b.featx, b.v_featx, b.depth_channel = nxq, _dp(bins["featx"]), _dp(v_featx), int(nd_depth)
+                b.features, b.v_features, b.n_feat = _dp(features), _dp(v_features), (features.shape[-1] if features is not None else 0)
+                b.zero_flags = flags
             if KERNEL_EVENTS is not None:                             # a measurement pass: events around the compositing backward
                 ev = _kernel_event_pair()
                 b.ev_blend_begin, b.ev_blend_end = ev[0].cuda_event, ev[1].cuda_event
@@ -1068,12 +1097,15 @@ class _RasterFused(torch.autograd.Function):
             m2d.grad = g2d if v_means2d_in is None else g2d + v_means2d_in
             if ctx.absgrad:
                 m2d.absgrad = v_abs.view(P.n_cams, P.n_gauss, 2)
-        return (v_means, v_quats, v_scales, v_opac, v_colors, v_colors_rest, None, None, None, None, None, None, None, None)
+        return (v_means, v_quats, v_scales, v_opac, v_colors, v_colors_rest, v_features, None, None, None, None, None, None, None,
+                None)
 
 
 def raster_fused(means, quats, scales, opacities, colors, viewmats, Ks, P: Params, sh_degree, depth_channel: bool,
-                 cd: int, absgrad: bool):
-    """(render, alpha, exp_depth, med_depth, normal, means2d, radii, depths, comps, grec, last_ids, median_ids), bins."""
+                 cd: int, absgrad: bool, features: Optional[Tensor] = None):
+    """(render, alpha, exp_depth, med_depth, normal, means2d, radii, depths, comps, grec, last_ids, median_ids), bins.
+    ``features`` [N,F] (with SH ``colors``): the features model's call as one entry -- channels 0..2 = max(SH + 0.5, 0),
+    channels 3.. = the features (rade_features_model.py:427-441), ``cd`` = 3 + F (+ 1 with a depth channel)."""
     rest = None
     if isinstance(colors, (tuple, list)):
         colors, rest = colors
@@ -1081,7 +1113,8 @@ def raster_fused(means, quats, scales, opacities, colors, viewmats, Ks, P: Param
     args = [_f32(t, n) for t, n in ((means, "means"), (quats, "quats"), (scales, "scales"),
                                     (opacities, "opacities"), (colors, "colors"))]
     extra: dict = {}
-    out = _RasterFused.apply(*args, rest, _f32(viewmats, "viewmats"), _f32(Ks, "Ks"), P, sh_degree, bool(depth_channel),
+    feat = None if features is None else _f32(features, "features")
+    out = _RasterFused.apply(*args, rest, feat, _f32(viewmats, "viewmats"), _f32(Ks, "Ks"), P, sh_degree, bool(depth_channel),
                              int(cd), bool(absgrad), extra)
     return out, extra["bins"]
 

@@ -298,13 +298,19 @@ class RadegsModel(nn.Module):
                                        sparse_grad=False, calc_compensations=False)[0]
         return torch.sum(radii, dim=-1).squeeze() > 0
 
+    def _features_for_render(self, pick):
+        """[N,F] feature channels composited behind the colours, or None (the features model overrides this)."""
+        return None
+
     def _render(self, means, quats, scales, opacities, colors, render_mode, sh_degree_to_use,
-                camera_params, visible_mask=None):
-        """rade_gs_model.py:401-467."""
+                camera_params, visible_mask=None, features=None):
+        """rade_gs_model.py:401-467 (``features``: rade_features_model.py:390-478 -- SH colours and feature channels go to the
+        rasterizer side by side, ``rasterization(..., features=...)``, instead of through spherical_harmonics / clamp / cat)."""
         if visible_mask is not None:
             means, quats, scales = means[visible_mask], quats[visible_mask], scales[visible_mask]
             opacities = opacities[visible_mask]
             colors = tuple(c[visible_mask] for c in colors) if isinstance(colors, tuple) else colors[visible_mask]
+            features = features[visible_mask] if features is not None else None
         # (the activations of rade_gs_model.py:443-444 run inside the projection kernels: see rendering.rasterization)
         return rasterization(
             means=means, quats=quats, scales=scales, scales_are_log=True,
@@ -314,7 +320,8 @@ class RadegsModel(nn.Module):
             packed=False, near_plane=0.01, far_plane=1e10, render_mode=render_mode,
             sh_degree=sh_degree_to_use, sparse_grad=False,
             absgrad=self.strategy.absgrad if isinstance(self.strategy, DefaultStrategy) else False,
-            rasterize_mode=self.config.rasterize_mode, return_depth_normal=True)
+            rasterize_mode=self.config.rasterize_mode, return_depth_normal=True,
+            **({"features": features} if features is not None and sh_degree_to_use is not None else {}))
 
     def get_outputs(self, camera) -> Dict[str, Union[Tensor, List, None]]:
         """rade_gs_model.py:80-272."""
@@ -361,10 +368,22 @@ class RadegsModel(nn.Module):
             colors_crop = torch.sigmoid(pick(self.features_dc))         # [N, 1, 3] -> [N, 3]  (:163)
             sh_degree_to_use = None
 
+        feats = self._features_for_render(pick)
+        if feats is not None and sh_degree_to_use is None:
+            colors_crop, feats = torch.cat((colors_crop, feats), dim=-1), None      # (degree-0 model: sigmoid colours, pass-through)
         render, alpha, expected_depths, median_depths, expected_normals, self.info = self._render(
             means=pick(self.means), quats=pick(self.quats), scales=pick(self.scales), opacities=pick(self.opacities),
             colors=colors_crop, render_mode=render_mode, sh_degree_to_use=sh_degree_to_use,
-            visible_mask=voxel_visible_mask, camera_params=camera_params)
+            visible_mask=voxel_visible_mask, camera_params=camera_params, features=feats)
+        feature_image = None
+        n_feat = int(getattr(self.config, "features_latent_dim", 0))
+        if n_feat > 0 and render.shape[-1] >= 3 + n_feat:
+            # rade_features_model.py:360: features = render[..., 3 : 3 + latent_dim]; the colour (+ ED) channels go on to the
+            # post-processing below.  (The reference takes depth_im from render[..., 3:4] there (:347) -- a feature channel; the
+            # ED channel is the LAST one, which is what this mirror hands on.)
+            feature_image = render[..., 3:3 + n_feat]
+            render = (torch.cat((render[..., :3], render[..., 3 + n_feat:]), dim=-1) if render.shape[-1] > 3 + n_feat
+                      else render[..., :3].contiguous())
 
         if self.training:
             self.strategy.step_pre_backward(self.gauss_params, self.optimizers, self.strategy_state,
@@ -390,13 +409,16 @@ class RadegsModel(nn.Module):
             depth_im = ep[4].squeeze(0) if want_depth_im else None
         if background.shape[0] == 3 and not self.training:
             background = background.expand(H, W, 3)
-        return {
+        out = {
             "rgb": rgb.squeeze(0), "depth": expected_depths.squeeze(0), "median_depth": median_depths.squeeze(0),
             "depth_im": depth_im, "accumulation": alpha.squeeze(0), "normals": normals.squeeze(0),
             "depth_normal_error_map": normal_error_map[0, ...].unsqueeze(-1),
             "middepth_normal_error_map": normal_error_map[1, ...].unsqueeze(-1),
             "background": background,
         }
+        if feature_image is not None:
+            out["features"] = feature_image.squeeze(0)                   # rade_features_model.py:387
+        return out
 
     @staticmethod
     def get_empty_outputs(width: int, height: int, background: Tensor) -> Dict[str, Union[Tensor, List]]:
@@ -519,3 +541,29 @@ class RadegsModel(nn.Module):
             depth_normal_loss = ((1 - self.config.depth_ratio) * e1.mean() + self.config.depth_ratio * e2.mean())
             loss_dict["depth_normal_loss"] = self.config.depth_normal_lambda * depth_normal_loss
         return loss_dict
+
+
+@dataclass
+class RadegsFeaturesModelConfig(RadegsModelConfig):
+    """rade_features_model.py: the hot-path field of its config -- the width of the distilled feature vector a Gaussian
+    carries (13 in the reference: 3 + 13 = 16 fused channels)."""
+    features_latent_dim: int = 13
+
+
+class RadegsFeaturesModel(RadegsModel):
+    """The rasterizer side of ``RadegsFeaturesModel`` (rade_features_model.py:195-478): every Gaussian carries
+    ``distill_features`` [N, latent_dim] that are composited behind its SH colour; ``get_outputs`` returns them as
+    ``outputs["features"]`` [H, W, latent_dim].  The decoder MLP, the text queries and the feature loss (:545-584) are
+    foundation-model code outside the path."""
+
+    def __init__(self, config: RadegsFeaturesModelConfig, means, scales, quats, opacities, features_dc, features_rest,
+                 distill_features: Tensor):
+        super().__init__(config, means, scales, quats, opacities, features_dc, features_rest)
+        if distill_features.shape != (means.shape[0], config.features_latent_dim):
+            raise ValueError(f"distill_features must be [N, {config.features_latent_dim}], got {tuple(distill_features.shape)}")
+        self.gauss_params["distill_features"] = nn.Parameter(distill_features)
+
+    distill_features = property(lambda self: self.gauss_params["distill_features"])
+
+    def _features_for_render(self, pick):
+        return pick(self.distill_features)

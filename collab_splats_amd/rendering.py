@@ -72,6 +72,12 @@ def rasterization(
     # rade_gs_model.py:443-444 and their backward: four launches per step less).  Same results up to rounding.
     scales_are_log: bool = False,
     opacities_are_logit: bool = False,
+    # extension: the features model's call as ONE entry (rade_features_model.py:427-476).  ``features`` [N,F] with SH
+    # ``colors`` and ``sh_degree``: the render has 3 + F (+ 1) channels -- channels 0..2 = max(SH(colors) + 0.5, 0), channels
+    # 3.. = the features -- exactly what the reference gets from spherical_harmonics -> clamp_min(c + 0.5, 0) -> cat((colors,
+    # features)) -> rasterization(sh_degree=None), without the [N,16] concatenation and with gradients to the coefficients
+    # AND the features.
+    features: Optional[Tensor] = None,
 ):
     if render_mode not in _RENDER_MODES:
         raise ValueError(f"Unknown render_mode: {render_mode}")
@@ -110,35 +116,59 @@ def rasterization(
     viewmats = viewmats.contiguous().float()
     Ks = Ks.contiguous().float()
 
+    if features is not None:
+        if sh_degree is None or render_mode in ("D", "ED"):
+            raise ValueError("features=... rides behind SH colours: it needs sh_degree and an RGB render mode")
+        assert features.shape[0] == N and features.dim() == 2 and features.shape[1] >= 1, features.shape
     depth_channel = render_mode in ("RGB+D", "RGB+ED", "D", "ED")
     n_user = 0 if render_mode in ("D", "ED") else (3 if sh_degree is not None else colors.shape[-1])
+    if features is not None:
+        n_user += features.shape[1]
     n_sh = (1 + colors[1].shape[1]) if split_sh else (colors.shape[1] if sh_degree is not None else 0)
     fused = n_user + int(depth_channel) <= 4 and n_sh <= 16
-    if split_sh and not fused:
-        colors = torch.cat((colors[0][:, None, :], colors[1]), dim=1)
     # N-D colours in one pass (a8): 5..20 channels, pass-through colours, atomic gradient mode
     n_total = n_user + int(depth_channel)
     fused_x = (ENABLE_ND_ONE_PASS and (not fused) and sh_degree is None and 5 <= n_total <= 20
                and not ops.DETERMINISTIC_BACKWARD)
+    fused_feat = features is not None and ENABLE_ND_ONE_PASS and 5 <= n_total <= 20 and n_sh <= 16 and Cn == 1
+    if features is not None and not (fused_feat and ops.fused_node_ok() and N > 0):
+        # outside the one-entry path (deterministic mode, > 20 channels, several cameras): as the reference composes it
+        from .wrapper import spherical_harmonics
+        coeffs = torch.cat((colors[0][:, None, :], colors[1]), dim=1) if split_sh else colors
+        cam_centers = -torch.einsum("cji,cj->ci", viewmats[:, :3, :3], viewmats[:, :3, 3])
+        rgb = torch.clamp_min(spherical_harmonics(sh_degree, means[None] - cam_centers[:, None, :], coeffs) + 0.5, 0.0)
+        fused_cols = torch.cat((rgb, features[None].expand(Cn, N, features.shape[1])), dim=-1)
+        return rasterization(means, quats, scales, opacities, fused_cols if Cn > 1 else fused_cols[0], viewmats, Ks, width, height,
+                             near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip, eps2d=eps2d, sh_degree=None,
+                             tile_size=tile_size, backgrounds=backgrounds, render_mode=render_mode, absgrad=absgrad,
+                             rasterize_mode=rasterize_mode, return_depth_normal=return_depth_normal, radius_sigma=radius_sigma,
+                             opacity_aware_radius=opacity_aware_radius, alpha_max=alpha_max,
+                             normalise_expected_depth=normalise_expected_depth, scales_are_log=scales_are_log,
+                             opacities_are_logit=opacities_are_logit)
     # fused paths: the kernels divide the depth channel by max(alpha, 1e-10) themselves ("ED")
-    ed_fused = (fused or fused_x) and render_mode in ("ED", "RGB+ED")
+    if split_sh and not fused and not fused_feat:
+        colors = torch.cat((colors[0][:, None, :], colors[1]), dim=1)
+    ed_fused = (fused or fused_x or fused_feat) and render_mode in ("ED", "RGB+ED")
     P = make_params(N, Cn, width, height, tile_size=tile_size, antialiased=aa,
                     opacity_aware_radius=opacity_aware_radius, eps2d=eps2d, near_plane=near_plane,
                     far_plane=far_plane, radius_clip=radius_clip, radius_sigma=radius_sigma,
                     alpha_max=alpha_max, ed_slot=n_user if ed_fused else -1)
     act = (1 if scales_are_log else 0) | (2 if opacities_are_logit else 0)
-    if act and not (fused and ops.fused_node_ok() and N > 0 and Cn == 1):
+    nd_one_node = (fused_x or fused_feat) and ops.fused_node_ok() and N > 0
+    if act and not ((fused or nd_one_node) and ops.fused_node_ok() and N > 0 and Cn == 1):
         # only the single-node path of one camera carries the activations inside its kernels: elsewhere, as the caller would
         scales = torch.exp(scales) if scales_are_log else scales
         opacities = torch.sigmoid(opacities) if opacities_are_logit else opacities
         act = 0
     P.activations = act
-    if fused and ops.fused_node_ok() and N > 0:
-        # ---- the reference's path as ONE autograd node (ops._RasterFused): two C calls forward, one backward
+    if (fused and ops.fused_node_ok() and N > 0) or nd_one_node:
+        # ---- the reference's path as ONE autograd node (ops._RasterFused): two C calls forward, one backward -- RGB(+ED),
+        # and the features model's 16 / 17 channels (pass-through colours [N,D], or SH coefficients + features side by side)
         cin = colors if n_user > 0 else means.new_zeros(N, 1)[:, :0].contiguous()
         D = n_user + int(depth_channel)
         out12, bins = ops.raster_fused(means, quats, scales, opacities, cin, viewmats, Ks, P,
-                                       sh_degree if n_user > 0 else None, depth_channel, D, absgrad)
+                                       sh_degree if n_user > 0 else None, depth_channel, D, absgrad,
+                                       features=features if fused_feat else None)
         render, alpha_, ed_, md_, nrm_, means2d, radii, depths, comps, grec, last_ids_, median_ids_ = out12
         first = (render, alpha_, ed_, md_, nrm_, last_ids_, median_ids_)
         gv = grec.view(Cn, N, 16)

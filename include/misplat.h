@@ -493,6 +493,15 @@ typedef struct misplat_raster_args {
      * flatten_ids holds rows either way.  Sorting such a payload by hand: misplat_tile_sort(flags | 4, depths = depth_sorted,
      * isect_gid = order).  Required by front_n. */
     float* depth_sorted;
+    /* N-D colours in the one-entry path (a8: rade_features_model.py:427-476), nxq > 0: D' = color_dim composited channels
+     * in 5..20, channels 0..3 in the record's colour slots, channels 4.. in featx[C*N, 4*nxq] (nxq = ceil((D' - 4) / 4)).
+     *   sh_degree < 0:  colors [(C,)N,D] (D = K_or_D) are the channels (+ depth behind them if depth_channel);
+     *   sh_degree >= 0: the model's call as ONE entry -- channels 0..2 = max(SH(colors | colors, colors_rest) + 0.5, 0),
+     *                   channels 3.. = features[N, n_feat] (+ depth): no [N,16] concatenation exists anywhere.
+     * v_featx_zero (or NULL): gradient rows [C*N, 4*nxq] cleared by the forward, like v_grec_zero.  lazy_colour must be 0. */
+    const float* features;
+    float *featx, *v_featx_zero;
+    int32_t n_feat, nxq;
 } misplat_raster_args;
 /* Graph cache (optional, caller-owned, thread-safe; the library itself keeps no state): with a cache, the launch
  * sequence of a call is captured into a hipGraph the first time a given (params, args, phases, stream) block is seen
@@ -540,6 +549,14 @@ typedef struct misplat_raster_bwd_args {
     /* view-keyed launch order: unit_perm is the table base, see misplat_params.unit_sel (or NULL / 0) */
     const int32_t* unit_sel;
     int32_t unit_stride, unit_slots;
+    /* N-D colours (nxq > 0; see misplat_raster_args.featx): featx as the forward wrote it, v_featx [C*N, 4*nxq] (zero_flags
+     * bit 2: cleared by the forward), depth_channel != 0 if a depth channel rides behind the user channels (its gradient is
+     * read from where it sits: record slot or featx); sh_degree >= 0: features [N,n_feat] were the channels 3.. and
+     * v_features [N,n_feat] receives their gradient, v_colors (/ v_colors_rest) the SH coefficients'; sh_degree < 0:
+     * v_colors [(C,)N,D] receives all of them.  depth_slot is ignored. */
+    const float *featx, *features;
+    float *v_featx, *v_features;
+    int32_t n_feat, nxq, depth_channel, reserved_x;
 } misplat_raster_bwd_args;
 int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
                        misplat_graph_cache* cache /* or NULL */);

@@ -289,6 +289,93 @@ def _feature_case(dev, craster, D, rm):
     assert len(r3) == 3 and r3[0].shape == (1, H, W, 3)
 
 
+@pytest.mark.parametrize("rm,split", [("RGB+ED", False), ("RGB", True)])
+def test_features_model_call_as_one_entry_steady_state_vs_c_port(dev, craster, rm, split):
+    """rade_features_model.py:427-476 as ONE product entry: ``rasterization(colors=SH coefficients, features=[N,13], sh_degree=3)``
+    renders 16 (RGB) / 17 (RGB+ED) channels -- channels 0..2 = max(SH + 0.5, 0), channels 3..15 the features, no [N,16]
+    concatenation, one autograd node, the one-entry forward / backward with graph replay and the view's launch order.  Steady
+    state (the EIGHTH call on one set of leaves) against the C port fed what the reference would feed gsplat --
+    ``cat(clamp_min(SH(dirs) + 0.5, 0), features)`` with ``sh_degree=None`` --, gradients chained back to the coefficients,
+    the features and (through the view direction) the means with the fp64 torch oracle's SH."""
+    from collab_splats_amd import ops, rasterization
+    from collab_splats_amd.synthetic import random_scene
+    from oracle.torch_oracle import eval_sh
+    W, H, N, F = 320, 192, 30_000, 13
+    sc = random_scene(N, W, H, seed=17)
+    g = torch.Generator().manual_seed(5)
+    feats = torch.rand(N, F, generator=g)
+    scales, op = torch.exp(sc["log_scales"]), torch.sigmoid(sc["opacity_logits"])
+    sh = sc["sh"].clone()
+    sh[:, 0] *= 0.4                                              # (colours around the clamp at 0: both sides of it occur)
+    leaves = [t.to(dev).requires_grad_(True) for t in (sc["means"], sc["quats"], scales, op)]
+    if split:
+        col_leaves = [sh[:, 0].contiguous().to(dev).requires_grad_(True), sh[:, 1:].contiguous().to(dev).requires_grad_(True)]
+        colors = tuple(col_leaves)
+    else:
+        col_leaves = [sh.to(dev).requires_grad_(True)]
+        colors = col_leaves[0]
+    f_leaf = feats.to(dev).requires_grad_(True)
+    V, K = sc["viewmats"].to(dev), sc["Ks"].to(dev)
+    Dp = 3 + F + (1 if rm == "RGB+ED" else 0)
+    ups = upstream([(1, H, W, Dp), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3)], dtype=torch.float32)
+    ups_dev = [u.to(dev) for u in ups]
+    ops.reset_graph_cache(dev)
+    ops._CAP_HINT.pop(ops._cap_key(ops._lib.make_params(N, 1, W, H), dev), None)
+    before = dict(ops.PATH_STATS)
+    out = None
+    for call in range(8):
+        for l in leaves + col_leaves + [f_leaf]:
+            l.grad = None
+        del out
+        out = rasterization(*leaves, colors, V, K, W, H, sh_degree=3, render_mode=rm, rasterize_mode="antialiased",
+                            features=f_leaf, return_depth_normal=True)
+        torch.autograd.backward(list(out[:5]), ups_dev)
+    torch.cuda.synchronize()
+    took = {k: ops.PATH_STATS[k] - before.get(k, 0) for k in ops.PATH_STATS}
+    assert took.get("forward_nd") == 8 and took.get("backward_one_call") == 8 and took.get("forward_merged_phases") == 7, took
+    assert took.get("forward_view_order") == 8 and ops.graph_cache_stats(dev)["hits"] >= 2
+    assert out[0].shape == (1, H, W, Dp)
+    # ---- what the reference feeds gsplat: colours evaluated on the host in fp32 exactly as the kernels do is not available
+    # to the checker, so the C port gets the DEVICE's own fused colours (record slots + featx are not exposed either): it
+    # is given cat(clamp(SH) from the fp64 oracle, features) and the images are compared at 1e-4 like everywhere else
+    cam_c = -(sc["viewmats"][0, :3, :3].T @ sc["viewmats"][0, :3, 3])
+    means64 = sc["means"].double().requires_grad_(True)
+    sh64 = sh.double().requires_grad_(True)
+    feats64 = feats.double().requires_grad_(True)
+    rgb64 = torch.clamp_min(eval_sh(3, means64 - cam_c.double(), sh64) + 0.5, 0.0)
+    fused64 = torch.cat((rgb64, feats64), dim=-1)
+    cr = craster.CRaster(np.float32)
+    st = cr.forward(sc["means"].numpy(), sc["quats"].numpy(), scales.numpy(), op.numpy(), fused64.detach().float().numpy(),
+                    sc["viewmats"][0].numpy(), sc["Ks"][0].numpy(), W, H, sh_degree=None, render_mode=rm,
+                    rasterize_mode="antialiased")
+    meta = out[5]
+    assert np.array_equal(st["bins"]["flatten_ids"], meta["flatten_ids"].cpu().numpy())
+    fw = st["fwd"]
+    proof = FlipProof(cr.blend_margin(st), st["proj"]["means2d"], st["proj"]["radii"])
+    for name, got, ref in (("render", out[0], st["render"]), ("alpha", out[1], fw["alpha"]), ("exp_depth", out[2], fw["exp_depth"]),
+                           ("med_depth", out[3], fw["med_depth"]), ("normal", out[4], fw["normal"])):
+        assert_close_flips(got[0], ref, name, proof=proof)
+    gr = cr.backward(st, *[u[0].numpy() for u in ups])
+    fused64.backward(torch.from_numpy(gr["v_colors"]).double())
+    want_means = gr["v_means"] + means64.grad.float().numpy()          # geometry + the SH view-direction term
+    for name, leaf, ref in (("v_means", leaves[0], want_means), ("v_quats", leaves[1], gr["v_quats"]),
+                            ("v_scales", leaves[2], gr["v_scales"]), ("v_opacities", leaves[3], gr["v_opacities"]),
+                            ("v_features", f_leaf, feats64.grad.float().numpy())):
+        assert_close_flips(leaf.grad, ref, name, proof=proof)
+    got_sh = torch.cat((col_leaves[0].grad[:, None, :], col_leaves[1].grad), dim=1) if split else col_leaves[0].grad
+    assert_close_flips(got_sh, sh64.grad.float().numpy(), "v_sh", proof=proof)
+    # the reference's own composition (spherical_harmonics -> clamp -> cat -> rasterization(sh_degree=None)) through the same
+    # library gives the same images (alpha / depths / normals bit for bit): the one-entry form is a fusion, not another algorithm
+    from collab_splats_amd import spherical_harmonics
+    with torch.no_grad():
+        coeffs = torch.cat((col_leaves[0][:, None, :], col_leaves[1]), dim=1) if split else col_leaves[0]
+        rgb = torch.clamp_min(spherical_harmonics(3, leaves[0] - cam_c.to(dev), coeffs) + 0.5, 0.0)
+        ref_out = rasterization(*leaves, torch.cat((rgb, f_leaf), dim=-1), V, K, W, H, sh_degree=None, render_mode=rm,
+                                rasterize_mode="antialiased", return_depth_normal=True)
+    for k, (a, b) in enumerate(zip(out[:5], ref_out[:5])):              # (geometry identical; the two SH kernels may round differently)
+        assert torch.equal(a.detach(), b) if k > 0 else rel_err(a, b) < 1e-5, ("fused entry differs from the composed call", k)
+
+
 def _compare_with_c_port(dev, craster, means, quats, scales, opac, cols, V, K, W, H, sh_degree=None, rm="RGB+ED",
                          mode="antialiased", tol=TOL):
     from collab_splats_amd import rasterization
@@ -645,6 +732,36 @@ def test_resolution_schedule_renders_the_downscaled_camera(dev):
     assert (int(full.width.item()), int(full.height.item()), full.fx, full.cx) == (W, H, 0.9 * W, W / 2.0)
     sum(m1.get_loss_dict(a, {"image": torch.rand(H // 2, W // 2, 3)}).values()).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m1.gauss_params.values())
+
+
+def test_features_model_mirror_outputs(dev):
+    """``RadegsFeaturesModel`` (rade_features_model.py:195-478, rasterizer side): the distilled features are composited
+    behind the SH colours in the same call -- ``outputs["features"]`` [H, W, 13] --, the colour / depth / normal outputs
+    are those of the base model on the same Gaussians, and the backward reaches the feature parameters too."""
+    from collab_splats_amd import radegs
+    from collab_splats_amd.synthetic import random_scene
+    W, H, N = 208, 128, 5000
+    sc = random_scene(N, W, H, seed=8)
+    feats = torch.rand(N, 13, generator=torch.Generator().manual_seed(2))
+    c2w = torch.tensor([[1.0, 0, 0, 0], [0, -1.0, 0, 0], [0, 0, -1.0, 0]])
+    cam = radegs.PinholeCamera.make(c2w, 0.9 * W, 0.9 * W, W, H)
+    args = (sc["means"], sc["log_scales"], sc["quats"], sc["opacity_logits"], sc["sh"][:, 0], sc["sh"][:, 1:])
+    kw = dict(rasterize_mode="antialiased", regularization_from_iter=0, output_depth_during_training=True)
+    fm = radegs.RadegsFeaturesModel(radegs.RadegsFeaturesModelConfig(**kw), *args, feats).to(dev)
+    bm = radegs.RadegsModel(radegs.RadegsModelConfig(**kw), *args).to(dev)
+    fm.train(); bm.train()
+    fm.step = bm.step = 5000
+    fo, bo = fm.get_outputs(cam), bm.get_outputs(cam)
+    assert fo["features"].shape == (H, W, 13) and "features" not in bo
+    for k in ("rgb", "depth", "median_depth", "accumulation", "normals", "depth_im", "depth_normal_error_map"):
+        assert rel_err(fo[k], bo[k]) < 1e-6, k
+    acc = fo["accumulation"]
+    hit = acc[..., 0] > 0.99
+    assert hit.any() and float(fo["features"][hit].min()) >= 0.0 and float(fo["features"][hit].max()) <= 1.0 + 1e-5
+    loss = fm.get_loss_dict(fo, {"image": torch.rand(H, W, 3)})
+    (sum(loss.values()) + fo["features"].square().mean()).backward()
+    for k, p in fm.gauss_params.items():
+        assert p.grad is not None and torch.isfinite(p.grad).all() and (k != "distill_features" or p.grad.abs().sum() > 0), k
 
 
 def test_crop_box_renders_exactly_the_cropped_subset(dev):
