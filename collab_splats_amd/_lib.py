@@ -58,7 +58,8 @@ class RasterArgs(C.Structure):
                 + [("order_slots", C.c_int32), ("order_stride", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("unit_reach", "front_n", "tile_flag")]
                 + [("front_margin", C.c_float), ("front_min_bucket", C.c_int32), ("depth_sorted", C.c_void_p)]
-                + [(n, C.c_void_p) for n in ("features", "featx", "v_featx_zero")] + [("n_feat", C.c_int32), ("nxq", C.c_int32)])
+                + [(n, C.c_void_p) for n in ("features", "featx", "v_featx_zero")] + [("n_feat", C.c_int32), ("nxq", C.c_int32)]
+                + [("est_isects", C.c_int64)])
 
 
 class RasterBwdArgs(C.Structure):
@@ -114,6 +115,7 @@ SYMBOLS = {
     "misplat_graph_cache_destroy": (None, 1), "misplat_graph_cache_stats": (C.c_int, 3), "misplat_wait_count": (C.c_int64, 2), "misplat_zero_bytes": (C.c_int, 3), "misplat_stream_copy": (C.c_int, 5),
     "misplat_touched_bits": (C.c_int, 4), "misplat_union_count": (C.c_int, 5), "misplat_union_ids": (C.c_int, 6),
     "misplat_rows_pack": (C.c_int, 7), "misplat_rows_unpack": (C.c_int, 7),
+    "misplat_debug_memset_replay": (C.c_int, 5),
     "misplat_version": (C.c_char_p, 0),
 }
 

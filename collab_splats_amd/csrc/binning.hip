@@ -813,13 +813,15 @@ __global__ __launch_bounds__(64 * kFrontWaves) void tile_sort_front_kernel(
 template <int MAP, bool UNORDERED>
 static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
                             const int32_t* isect_gid, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,
-                            int has_longest, hipStream_t s, TileSel sel = TileSel{nullptr, 0}, bool rest_only = false) {
+                            int has_longest, hipStream_t s, TileSel sel = TileSel{nullptr, 0}, bool rest_only = false,
+                            int64_t est_isects = -1) {
     // size classes (entries per bucket): <=1024 | <=4096 | <=8192 | longer (global scratch).  Every class walks
     // all tiles and skips buckets of the other classes.  A class that the typical bucket (n_isects / n_tiles)
     // can reach gets one workgroup per tile; the others get a small grid whose workgroups test their chunk of
     // tiles in parallel first (tile_range), so an unused class costs a few microseconds.
     // (n_isects may be the CAPACITY of a speculative launch, about 1.25 x the real count: 4 / 5 of it is the estimate)
-    const int64_t avg = n_isects / n_tiles * 4 / 5;
+    // est_isects >= 0: the caller's own estimate of the count (a capacity may be far above it: ops.py keeps capacities put)
+    const int64_t avg = est_isects >= 0 ? est_isects / n_tiles : n_isects / n_tiles * 4 / 5;
     // (behind the front kernel most tiles are done: a workgroup per tile would be ~8 000 workgroups of up to 1 024 threads
     // and 64 KB of LDS that start, read two words and leave -- 16 dispatch rounds, 31 us at 5 M Gaussians; 1 024 workgroups
     // test their 8 tiles in parallel and leave at once, or sort the few that are left; a view's first visit, when ALL are left, runs ~1.5 x slower here)
@@ -858,7 +860,7 @@ static int launch_tile_sort(const int32_t* offsets, int32_t n_tiles, int64_t n_i
 // Front-only ordering, first part: the front kernel, then the regular size classes for the tiles it left undone.
 int misplat_internal::tile_sort_front(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths,
                                       const int32_t* row_map, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch,
-                                      const FrontSort& F, hipStream_t s) {
+                                      const FrontSort& F, int64_t est_isects, hipStream_t s) {
     if (n_isects < 0 || n_tiles < 1 || n_isects > 0x7fffffffLL || !scratch || !row_map || !F.order_table || !F.order_sel || !F.front_n ||
         !F.tile_flag || F.order_slots < 1 || F.pivot_off < MISPLAT_ORDER_HEADER || F.order_stride < F.pivot_off + n_tiles)
         return MISPLAT_EINVAL;
@@ -867,7 +869,7 @@ int misplat_internal::tile_sort_front(const int32_t* offsets, int32_t n_tiles, i
                        row_map, (const int32_t*)payload, flatten_ids, F);
     if (n_isects == 0) return check_launch();
     return launch_tile_sort<2, true>(offsets, n_tiles, n_isects, depths, row_map, payload, flatten_ids, scratch, 1, s,
-                                     TileSel{F.front_n, 1});
+                                     TileSel{F.front_n, 1}, false, est_isects);
 }
 
 // Second part: the tiles whose flag the compositing forward set, in full (one launch; few tiles are expected).
@@ -884,17 +886,25 @@ extern "C" int misplat_tile_sort(const int32_t* offsets, int32_t n_tiles_total, 
                                  const float* depths, const int32_t* isect_gid, int32_t* payload,
                                  int32_t* flatten_ids, uint32_t* scratch, int32_t flags,
                                  misplat_stream_t stream) {
+    return misplat_internal::tile_sort(offsets, n_tiles_total, n_isects, -1, depths, isect_gid, payload, flatten_ids, scratch, flags,
+                                       (hipStream_t)stream);
+}
+
+int misplat_internal::tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects, int64_t est_isects,
+                                const float* depths, const int32_t* isect_gid, int32_t* payload, int32_t* flatten_ids,
+                                uint32_t* scratch, int32_t flags, hipStream_t stream) {
     if (n_isects < 0 || n_tiles_total < 1 || n_isects > 0x7fffffffLL || !scratch || (flags & ~7) || ((flags & 4) && !isect_gid))
         return MISPLAT_EINVAL;
     if (n_isects == 0) return MISPLAT_OK;
     hipStream_t s = (hipStream_t)stream;
     const int has_longest = (flags >> 1) & 1;      // (bit 0, "unordered", is what every bucket is now: accepted, ignored)
+    const TileSel all{nullptr, 0};
     if (flags & 4)                                 // entries are positions in the cell-ordered row list (see MAP)
         return launch_tile_sort<2, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
-                                         has_longest, s);
+                                         has_longest, s, all, false, est_isects);
     if (isect_gid)
         return launch_tile_sort<1, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
-                                            has_longest, s);
+                                         has_longest, s, all, false, est_isects);
     return launch_tile_sort<0, true>(offsets, n_tiles_total, n_isects, depths, isect_gid, payload, flatten_ids, scratch,
-                                     has_longest, s);
+                                     has_longest, s, all, false, est_isects);
 }

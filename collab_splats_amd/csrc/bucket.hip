@@ -281,9 +281,8 @@ __global__ void bucket_rows_empty_kernel(int n_cells, uint32_t* __restrict__ cel
 // touch global memory tile by tile.
 struct TileWg {
     uint4 info[kRowsPerWg];         // (fill pass) per row: exclusive scan of the tile counts | x0 | y0 << 16 |
-                                    //   rectangle width | in_window << 31 | bits of 1 / width
+                                    //   rectangle width | depth code << 16 (index mode) | in_window << 31 | bits of 1 / width
     int32_t row[kRowsPerWg];
-    uint16_t dcode[kRowsPerWg];     // (fill pass, index mode) 9-bit depth code of the row (misplat_internal::depth_code9)
     int32_t tab[kWinMax];           // difference array -> counts (stride ww + 1) -> (fill pass) cursors
     uint32_t wsum[kRowsPerWg / 64];
     int bb[4];                      // min x, min y, max x, max y of the small rectangles
@@ -487,7 +486,10 @@ __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_fill_kernel(
     const int64_t first_pos = (int64_t)blockIdx.x * rows_per_wg(n_vis);
     // (index mode: the row's depth code rides in the entry's top bits -- the front kernel of the per-tile sort drops the
     // entries behind its pivot by the code alone; depth_sorted[position] is a coalesced read here)
-    if (IDX) L.dcode[threadIdx.x] = r_ >= 0 ? (uint16_t)misplat_internal::depth_code9(depth_sorted[first_pos + threadIdx.x]) : 0;
+    // The code travels in spare bits of the row's info word: the expansion below is a chain of LDS round trips per output, and
+    // a second array (one more dependent ds_read per output, the row read no longer overlapped) cost the kernel 50 % --
+    // 117 -> 180 us at 5 M Gaussians with the same memory traffic (FETCH / WRITE counters equal in both modes).
+    if (IDX && r_ >= 0) L.info[threadIdx.x].z |= misplat_internal::depth_code9(depth_sorted[first_pos + threadIdx.x]) << 16;
     const uint32_t total = L.total;
     const int stride = ww + 1;
     // one returning atomic per (workgroup, tile): a contiguous range of the tile's bucket; tab becomes the cursors
@@ -541,22 +543,24 @@ __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_fill_kernel(
             const uint32_t ry = (uint32_t)(((float)q + 0.5f) * __uint_as_float(inf.w));
             const uint32_t rx = q - ry * w;
             const int tx = (int)((inf.y & 0xffffu) + rx), ty = (int)((inf.y >> 16) + ry);
-            const int32_t r = L.row[e];
             int64_t slot;
             if (inf.z >> 31) {
                 const int i = (ty - wy0) * stride + (tx - wx0);
                 slot = (int64_t)tbase[i] + (int64_t)atomicAdd(&L.tab[i], 1);
             } else {
-                const int gt = (r / n_gauss) * tiles_per_cam + ty * tw + tx;
+                const int gt = (L.row[e] / n_gauss) * tiles_per_cam + ty * tw + tx;
                 slot = (int64_t)offsets[gt] + (int64_t)atomicAdd(&cursors[gt], 1);
             }
             if (slot < cap) {
                 if (DET) {
+                    const int32_t r = L.row[e];
                     const int64_t es = cum[r] + (int64_t)q;         // emission slot: the rows of the gradient slab
                     payload[slot] = (int32_t)es;
                     if (es < cap) isect_gid[es] = r;
+                } else if (IDX) {                                    // position in order[] | depth code (no row needed)
+                    payload[slot] = (int32_t)((uint32_t)(first_pos + e) | (((inf.z >> 16) & 0x1ffu) << misplat_internal::kIdxBits));
                 } else {
-                    payload[slot] = IDX ? (int32_t)((uint32_t)(first_pos + e) | ((uint32_t)L.dcode[e] << misplat_internal::kIdxBits)) : r;
+                    payload[slot] = L.row[e];
                 }
             }
         }

@@ -95,7 +95,12 @@ struct FrontSort {
 };
 // (bucket entries are positions in the cell-ordered row list: depths = depth_sorted, row_map = order -- bucket_tiles below)
 int tile_sort_front(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths, const int32_t* row_map,
-                    int32_t* payload, int32_t* flatten_ids, uint32_t* scratch, const FrontSort& F, hipStream_t s);
+                    int32_t* payload, int32_t* flatten_ids, uint32_t* scratch, const FrontSort& F, int64_t est_isects,
+                    hipStream_t s);
+// misplat_tile_sort with the caller's estimate of the intersection count (or -1): it picks the size classes that get a
+// grid of their own; n_isects itself may be a capacity far above the count.
+int tile_sort(const int32_t* offsets, int32_t n_tiles_total, int64_t n_isects, int64_t est_isects, const float* depths,
+              const int32_t* isect_gid, int32_t* payload, int32_t* flatten_ids, uint32_t* scratch, int32_t flags, hipStream_t s);
 int tile_sort_flagged(const int32_t* offsets, int32_t n_tiles, int64_t n_isects, const float* depths, const int32_t* row_map,
                       int32_t* payload, int32_t* flatten_ids, uint32_t* scratch, const int32_t* tile_flag, hipStream_t s);
 

@@ -110,11 +110,11 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
             F.min_bucket = a->front_min_bucket > 0 ? a->front_min_bucket : 1;
             F.front_n = a->front_n; F.tile_flag = a->tile_flag;
             rc = misplat_internal::tile_sort_front(a->offsets, n_tiles, a->cap_isects, sort_depths, sort_map, a->payload,
-                                                   a->flatten_ids, a->scratch, F, s);
+                                                   a->flatten_ids, a->scratch, F, a->est_isects > 0 ? a->est_isects : -1, s);
             if (rc != MISPLAT_OK) return rc;
         } else if (a->cap_isects > 0) {
-            rc = misplat_tile_sort(a->offsets, n_tiles, a->cap_isects, sort_depths, sort_map, a->payload, a->flatten_ids,
-                                   a->scratch, sort_flags, stream);
+            rc = misplat_internal::tile_sort(a->offsets, n_tiles, a->cap_isects, a->est_isects > 0 ? a->est_isects : -1, sort_depths,
+                                             sort_map, a->payload, a->flatten_ids, a->scratch, sort_flags, s);
             if (rc != MISPLAT_OK) return rc;
         }
         misplat_params q = *p;
@@ -521,6 +521,47 @@ int misplat_internal::fill_bytes(void* dst, size_t bytes, uint32_t word, hipStre
 // slices of one allocation, so a framework-level in-place clear would invalidate tensors saved for the backward).
 extern "C" int misplat_zero_bytes(void* dst, size_t bytes, misplat_stream_t stream) {
     return misplat_internal::fill_bytes(dst, bytes, 0u, (hipStream_t)stream);
+}
+
+// ---- diagnosis (tests only): does a MEMSET NODE inside a sequence captured the way run_cached captures (private
+// non-blocking stream, thread-local mode) take effect on every replay?  Round 2 saw the bucketing counters come back as
+// "garbage + n" from a replayed forward whose sequence began with hipMemsetAsync(counters, 0, 16) and designed every memset
+// out without establishing the cause.  The sequence here is that one in miniature: memset 16 bytes ->
+// a kernel adds `add[k]` into the two 64-bit counters; between replays a plain kernel overwrites the counters with garbage
+// (what recycled allocator memory holds).  out[k] (k < n_replays) = counters[0] after replay k: equal to add[k] iff the
+// memset node ran.  Returns MISPLAT_OK, or MISPLAT_ELAUNCH when the runtime refuses any step.
+__global__ void debug_add_kernel(unsigned long long* c, const unsigned long long* add) { c[0] += add[0]; c[1] += add[0]; }
+__global__ void debug_garbage_kernel(unsigned long long* c) { c[0] = 0xdeadbeefcafeull; c[1] = 0x123456789abcull; }
+extern "C" int misplat_debug_memset_replay(void* counters16, void* add8, int32_t n_replays, int64_t* out_host, misplat_stream_t stream) {
+    if (!counters16 || !add8 || !out_host || n_replays < 1 || n_replays > 64) return MISPLAT_EINVAL;
+    hipStream_t s = (hipStream_t)stream, cs = nullptr;
+    if (hipStreamCreateWithFlags(&cs, hipStreamNonBlocking) != hipSuccess) return MISPLAT_ELAUNCH;
+    int rc = MISPLAT_ELAUNCH;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    do {
+        if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) break;
+        const hipError_t em = hipMemsetAsync(counters16, 0, 16, cs);
+        hipLaunchKernelGGL(debug_add_kernel, dim3(1), dim3(1), 0, cs, (unsigned long long*)counters16, (const unsigned long long*)add8);
+        const hipError_t ek = hipGetLastError();
+        if (hipStreamEndCapture(cs, &graph) != hipSuccess || em != hipSuccess || ek != hipSuccess || !graph) break;
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) break;
+        rc = MISPLAT_OK;
+        for (int k = 0; k < n_replays && rc == MISPLAT_OK; k++) {
+            const unsigned long long addv = 1000ull + (unsigned long long)k;
+            hipLaunchKernelGGL(debug_garbage_kernel, dim3(1), dim3(1), 0, s, (unsigned long long*)counters16);
+            if (hipMemcpyAsync(add8, &addv, 8, hipMemcpyHostToDevice, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+                hipGraphLaunch(exec, s) != hipSuccess ||
+                hipMemcpyAsync(&out_host[k], counters16, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                rc = MISPLAT_ELAUNCH;
+        }
+    } while (0);
+    (void)hipGetLastError();
+    if (exec) (void)hipGraphExecDestroy(exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipStreamDestroy(cs);
+    return rc;
 }
 
 // Host-side wait for the intersection count of phase A: *slot was set to -1 by the caller before the launch and is

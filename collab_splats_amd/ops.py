@@ -540,6 +540,11 @@ def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Par
 FUSED_ENTRY = os.environ.get("MISPLAT_FUSED", "1") == "1"
 SPECULATE = os.environ.get("MISPLAT_SPECULATE", "1") == "1"
 CAP_MARGIN = float(os.environ.get("MISPLAT_CAP_MARGIN", "1.25"))
+# A capacity, once chosen, STAYS: it is part of every phase-B argument block (a change re-captures every graph of the shape)
+# and it sizes the per-tile lists inside the arena slot.  The first choice (and every later increase) is generous -- the views
+# of one scene differ by tens of percent in their counts (the bench's eight: 3.8 - 6.4 M) --, address space is what it costs.
+CAP_FIRST_MARGIN = float(os.environ.get("MISPLAT_CAP_FIRST_MARGIN", "1.75"))
+_CAP_CHOSEN: Dict[tuple, int] = {}
 _CAP_HINT: Dict[tuple, int] = {}
 _READBACK: Dict[tuple, Tensor] = {}
 
@@ -804,7 +809,10 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         n_known = _wait_count(state["host"])
         cap = max(n_known, 1)
     else:
-        cap = _quantise_cap(int(hint * CAP_MARGIN))
+        cap = _CAP_CHOSEN.get(key)
+        if cap is None or _quantise_cap(int(hint * CAP_MARGIN)) > cap or 4 * _quantise_cap(int(hint * CAP_FIRST_MARGIN)) < cap:
+            cap = _CAP_CHOSEN[key] = _quantise_cap(int(hint * CAP_FIRST_MARGIN))
+        a.est_isects = int(hint)
     if cap >= 2 ** 31:
         raise _lib.MisplatError(f"{cap} tile intersections exceed int32 indexing")
     cv = state.get("carver")

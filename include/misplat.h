@@ -502,6 +502,8 @@ typedef struct misplat_raster_args {
     const float* features;
     float *featx, *v_featx_zero;
     int32_t n_feat, nxq;
+    int64_t est_isects; /* > 0: the caller's estimate of the intersection count (cap_isects may be a generous, long-lived
+                           capacity): picks the per-tile sort's size classes; 0: 4/5 of cap_isects */
 } misplat_raster_args;
 /* Graph cache (optional, caller-owned, thread-safe; the library itself keeps no state): with a cache, the launch
  * sequence of a call is captured into a hipGraph the first time a given (params, args, phases, stream) block is seen
@@ -603,6 +605,11 @@ int misplat_rows_pack(int32_t n_tensors, const float* const* srcs, const int32_t
                       float* packed, misplat_stream_t stream);
 int misplat_rows_unpack(int32_t n_tensors, float* const* dsts, const int32_t* widths, const int32_t* ids, int64_t n_ids,
                         const float* packed, misplat_stream_t stream);
+
+/* Diagnosis (tests only; csrc/raster.hip): a 16-byte memset node + a kernel captured the way the graph cache captures, replayed
+ * n_replays (<= 64) times with the 16 bytes overwritten with garbage in between; out_host[k] = the first counter after replay k
+ * (= 1000 + k iff the memset node was applied).  counters16 / add8: device memory (16 / 8 bytes), out_host: host memory. */
+int misplat_debug_memset_replay(void* counters16, void* add8, int32_t n_replays, int64_t* out_host, misplat_stream_t stream);
 
 /* Measurement helper: dst[i] = src[i] over n_float4 16-byte elements (a plain streaming copy; bench.py times it to
  * report the HBM roof of the box it runs on).  variant: 0 plain, 1 non-temporal loads / stores, 2 four loads in flight

@@ -755,9 +755,9 @@ def test_features_model_mirror_outputs(dev):
     assert fo["features"].shape == (H, W, 13) and "features" not in bo
     for k in ("rgb", "depth", "median_depth", "accumulation", "normals", "depth_im", "depth_normal_error_map"):
         assert rel_err(fo[k], bo[k]) < 1e-6, k
-    acc = fo["accumulation"]
-    hit = acc[..., 0] > 0.99
-    assert hit.any() and float(fo["features"][hit].min()) >= 0.0 and float(fo["features"][hit].max()) <= 1.0 + 1e-5
+    acc = fo["accumulation"]                                         # features in [0, 1]: sum w f <= sum w = alpha, pixel by pixel
+    assert float(fo["features"].min()) >= 0.0 and bool((fo["features"].amax(-1, keepdim=True) <= acc + 1e-5).all())
+    assert float(fo["features"].max()) > 0.1
     loss = fm.get_loss_dict(fo, {"image": torch.rand(H, W, 3)})
     (sum(loss.values()) + fo["features"].square().mean()).backward()
     for k, p in fm.gauss_params.items():
@@ -1391,8 +1391,9 @@ def test_speculative_capacity_overflow_is_detected_and_redone_exactly(dev):
     big = _bench_like_scene(dev, 20_000, 480, 270, seed=8, scale_mul=5.0)
     ref_img, ref_grad, ref_meta = _fwd_bwd(big, FUSED_ENTRY=False)
     ops._CAP_HINT.clear()
+    ops._CAP_CHOSEN.clear()
     _, _, m_small = _fwd_bwd(small, FUSED_ENTRY=True, SPECULATE=True)
-    assert ref_meta["n_isects"] > 1.5 * ops._quantise_cap(int(m_small["n_isects"] * ops.CAP_MARGIN))     # it WILL overflow
+    assert ref_meta["n_isects"] > 1.5 * ops._quantise_cap(int(m_small["n_isects"] * ops.CAP_FIRST_MARGIN))   # it WILL overflow
     img, grad, meta = _fwd_bwd(big, FUSED_ENTRY=True, SPECULATE=True)
     assert meta["n_isects"] == ref_meta["n_isects"] == int(meta["tiles_per_gauss"].sum())
     assert torch.equal(meta["flatten_ids"], ref_meta["flatten_ids"])
@@ -2139,6 +2140,25 @@ def test_sparse_reduce_kernels_bitmaps_union_pack_unpack(dev):
         keep[rows] = False
         for o, t in zip(outs, tens):
             assert torch.equal(o[idt.long()], 2 * t[idt.long()]) and bool((o[torch.from_numpy(keep).to(dev)] == 7.0).all())
+
+
+def test_memset_node_in_a_captured_sequence_is_applied_on_every_replay(dev):
+    """Round 2 saw a replayed forward return "garbage + n" intersections when its captured sequence began with a 16-byte
+    hipMemsetAsync of the counters, and removed every memset from the library without finding out why.  The same construct in
+    miniature (memset 16 B + a kernel that adds into the counters, captured on a private non-blocking stream in thread-local
+    mode, the counters overwritten with garbage between replays): on this ROCm the memset node IS applied on every replay --
+    so the node itself was not what failed (DESIGN.md section 8 has the reading of the round-2 evidence).  Kept as a canary:
+    if a ROCm update breaks memset nodes, a caller's whole-step capture that contains torch memsets would be affected."""
+    from collab_splats_amd import _lib
+    lib = _lib.load()
+    counters = torch.zeros(2, dtype=torch.int64, device=dev)
+    add = torch.zeros(1, dtype=torch.int64, device=dev)
+    n = 12
+    out = (C.c_int64 * n)()
+    torch.cuda.synchronize()
+    rc = lib.misplat_debug_memset_replay(_lib.ptr(counters), _lib.ptr(add), C.c_int32(n), out, _lib.stream_ptr())
+    assert rc == 0
+    assert list(out) == [1000 + k for k in range(n)], list(out)
 
 
 def test_view_keyed_orders_survive_eviction_and_collisions(dev, monkeypatch):
