@@ -130,23 +130,18 @@ struct LazyColour {
 // speed decision the results must not show).  The coefficients are read straight from global memory as the walk
 // reaches them; its scheduling barriers keep the compiler from hoisting all 48 loads to the top: the evaluation sits
 // inside the compositing kernel and must not cost it its occupancy (80 VGPRs without it, 111 with).
-// Round 4: the evaluation reads a row the WAVE staged in LDS -- `cf` = the record's 48 coefficients (row-major [16,3], dc
-// first) followed by its mean (3 floats).  Straight from global memory it was 51 dependent-ish loads issued by the one or
-// two lanes of a batch that meet an unset colour, a latency chain per evaluation at 1.2 evaluations per 64-entry batch;
-// now the wave fetches the rows of all of a batch's unset records together, 64 elements per instruction
-// (stage_records), and the same term walk -- the same bits -- runs out of LDS.
-constexpr int kLazyRows = 8;                       // unset records staged per round
-constexpr int kLazyStride = 52;                    // 48 coefficients + mean (3) + pad
-__device__ __forceinline__ float4 lazy_colour(const LazyColour& lz, int g, const float* cf) {
+__device__ __forceinline__ float4 lazy_colour(const LazyColour& lz, int g) {
 #pragma clang fp contract(off)
     using namespace misplat_sh;
-    const float dx = cf[48] - lz.ccx, dy = cf[49] - lz.ccy, dz = cf[50] - lz.ccz;
+    const int gg = g % lz.n_gauss;
+    const float dx = lz.means[3 * gg] - lz.ccx, dy = lz.means[3 * gg + 1] - lz.ccy, dz = lz.means[3 * gg + 2] - lz.ccz;
     const float nn = sqrtf(dx * dx + dy * dy + dz * dz);
     const float inv = nn > 0.f ? 1.0f / nn : 0.f;
     const float x = dx * inv, y = dy * inv, z = dz * inv;
-    // coefficient (k, ch): float 3 k + ch of the staged row
-    const float* row = cf;
-    const float* dc = cf;
+    const bool split = lz.coeffs_rest != nullptr;
+    // coefficient (k, ch): float 3 k + ch of the row ([N,16,3]), or dc[ch] for k = 0 and rest[3 (k - 1) + ch] (split)
+    const float* row = split ? lz.coeffs_rest + (size_t)gg * 45 - 3 : lz.coeffs + (size_t)gg * 48;
+    const float* dc = split ? lz.coeffs + (size_t)gg * 3 : row;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #define LZ_TERM(k, B, BX, BY, BZ)                                                       \
     {                                                                                   \
@@ -177,7 +172,7 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
                                              const int32_t* __restrict__ slots, float xlo, float xhi,
                                              float ylo, float yhi, float alpha_min,
                                              float4* smx = nullptr, const float4* __restrict__ featx = nullptr,
-                                             const LazyColour* lz = nullptr, float* lz_stage = nullptr, int* lz_rows = nullptr) {
+                                             const LazyColour* lz = nullptr) {
     float4 q0, q1, q2, q3;
     bool keep = false;
     int slot = 0;
@@ -191,34 +186,12 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
         keep = q1.y * __builtin_amdgcn_exp2f(-smin * kLog2e) * 1.002f >= alpha_min;
     }
     if (LAZY) {
+        // (a real call, not inlined: the evaluation needs ~100 registers that the compositing loop must not pay for)
         // (all four slots start unset and any unset slot means "not there yet": correct whatever the granularity at which a
         // concurrent 16-byte store of another wave becomes visible)
-        bool need = keep && (__float_as_uint(q3.x) == kColourUnset || __float_as_uint(q3.y) == kColourUnset ||
-                             __float_as_uint(q3.z) == kColourUnset || __float_as_uint(q3.w) == kColourUnset);
-        unsigned long long nm = __ballot(need);
-        const bool split = lz->coeffs_rest != nullptr;
-        while (nm != 0ull) {                     // (wave-uniform) rounds of up to kLazyRows unset records of this batch
-            const int rank = __popcll(nm & ((1ull << lane) - 1ull));
-            const bool mine = need && rank < kLazyRows;
-            const int m = min(__popcll(nm), kLazyRows);
-            if (mine) lz_rows[rank] = g % lz->n_gauss;
-            __syncthreads();                     // (a block is one wave: this is a wait for the LDS stores)
-            // the wave fetches the m rows together: 48 coefficients + the mean of each, 64 elements per instruction
-            for (int e = lane; e < 51 * m; e += 64) {
-                const int r = e / 51, k = e - 51 * r;
-                const size_t gg = (size_t)lz_rows[r];
-                float v;
-                if (k >= 48) v = lz->means[3 * gg + (k - 48)];
-                else if (!split) v = lz->coeffs[gg * 48 + k];
-                else v = k < 3 ? lz->coeffs[gg * 3 + k] : lz->coeffs_rest[gg * 45 + (k - 3)];
-                lz_stage[r * kLazyStride + k] = v;
-            }
-            __syncthreads();
-            if (mine) q3 = lazy_colour(*lz, g, lz_stage + rank * kLazyStride);
-            need = need && !mine;
-            nm = __ballot(need);
-            __syncthreads();                     // (the next round overwrites the stage)
-        }
+        if (keep && (__float_as_uint(q3.x) == kColourUnset || __float_as_uint(q3.y) == kColourUnset ||
+                     __float_as_uint(q3.z) == kColourUnset || __float_as_uint(q3.w) == kColourUnset))
+            q3 = lazy_colour(*lz, g);
     }
     const unsigned long long mask = __ballot(keep);
     if (keep) {
@@ -282,8 +255,6 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
     __shared__ float4 sm[4 * 64 + 4];
     __shared__ int sm_idx[64 + 4];
     __shared__ float4 smx[NXQ > 0 ? NXQ * 64 + 4 : 1];
-    __shared__ float lz_stage[LAZY ? kLazyRows * kLazyStride : 1];      // coefficient rows of a batch's unset records
-    __shared__ int lz_rows[LAZY ? kLazyRows : 1];
     float colx[PPL][NXQ > 0 ? 4 * NXQ : 1];
 #pragma unroll
     for (int k = 0; k < PPL; k++)
@@ -371,7 +342,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
         }
         __syncthreads();
         const int n = stage_records<NXQ, LAZY>(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
-                                               nullptr, xlo, xhi, ylo, yhi, amin, smx, featx, &lz, lz_stage, lz_rows);
+                                               nullptr, xlo, xhi, ylo, yhi, amin, smx, featx, &lz);
         __syncthreads();
         reach_end = min(bs + 64, c.end);
         if (n == 0) continue;

@@ -482,14 +482,19 @@ __global__ __launch_bounds__(kRowsPerWg) void bucket_tile_fill_kernel(
     int32_t r_;
     uint2 r2_;
     bool in_;
-    tile_wg_prologue<true>(L, n_vis, n_gauss, order, rect2, cam0, wx0, wy0, ww, wh, r_, r2_, in_);
     const int64_t first_pos = (int64_t)blockIdx.x * rows_per_wg(n_vis);
+    // (issued BEFORE the prologue's own loads: behind them it was one more exposed memory round trip per workgroup -- a
+    // workgroup lives for some 12 us, a handful of dependent round trips under 18 M scattered stores -- and cost the kernel 60 us)
+    // (unconditional, from a clamped position: behind a branch the compiler waits for the load where the branch ends)
+    float dz_ = 0.f;
+    if (IDX) { const int64_t pz = first_pos + threadIdx.x; dz_ = depth_sorted[pz < n_vis ? pz : n_vis - 1]; }
+    tile_wg_prologue<true>(L, n_vis, n_gauss, order, rect2, cam0, wx0, wy0, ww, wh, r_, r2_, in_);
     // (index mode: the row's depth code rides in the entry's top bits -- the front kernel of the per-tile sort drops the
     // entries behind its pivot by the code alone; depth_sorted[position] is a coalesced read here)
     // The code travels in spare bits of the row's info word: the expansion below is a chain of LDS round trips per output, and
     // a second array (one more dependent ds_read per output, the row read no longer overlapped) cost the kernel 50 % --
     // 117 -> 180 us at 5 M Gaussians with the same memory traffic (FETCH / WRITE counters equal in both modes).
-    if (IDX && r_ >= 0) L.info[threadIdx.x].z |= misplat_internal::depth_code9(depth_sorted[first_pos + threadIdx.x]) << 16;
+    if (IDX && r_ >= 0) L.info[threadIdx.x].z |= misplat_internal::depth_code9(dz_) << 16;
     const uint32_t total = L.total;
     const int stride = ww + 1;
     // one returning atomic per (workgroup, tile): a contiguous range of the tile's bucket; tab becomes the cursors

@@ -686,7 +686,8 @@ LAZY_SH_MIN_BUCKET = int(os.environ.get("MISPLAT_LAZY_SH_MIN_BUCKET", "450"))   
 # pivots live in the view-keyed launch-order records) is sorted; a tile whose pixels outlive its sorted part is sorted in
 # full and composited again (exact images either way), and meta["flatten_ids"] / ["isect_ids"] are completed on access.
 # "auto": from a typical bucket of FRONT_MIN_AVG entries (the hint of the previous call of the shape); "1": always; "0": off.
-INDEXED_BUCKETS = os.environ.get("MISPLAT_INDEXED_BUCKETS", "1") == "1"   # (one-entry path: see misplat_raster_args.depth_sorted)
+INDEXED_BUCKETS = os.environ.get("MISPLAT_INDEXED_BUCKETS", "1")          # "force": also without front-only ordering (measurements)
+INDEXED_BUCKETS = INDEXED_BUCKETS if INDEXED_BUCKETS == "force" else INDEXED_BUCKETS == "1"   # (one-entry path: see misplat_raster_args.depth_sorted)
 FRONT_ONLY = os.environ.get("MISPLAT_FRONT_ONLY", "auto")
 FRONT_MIN_AVG = int(os.environ.get("MISPLAT_FRONT_MIN_AVG", "1024"))
 FRONT_MIN_BUCKET = int(os.environ.get("MISPLAT_FRONT_MIN_BUCKET", "256"))
@@ -727,7 +728,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     # (records, lists) start on 2 MiB boundaries.  A slot is handed out again only when nothing refers to its storage.
     # (bucket entries as positions in the cell-ordered row list: pays where the per-tile sort's depth gather misses the L2 --
     # dense scenes, i.e. together with front-only ordering; at 1 M Gaussians it costs the sort a second gather: 55 -> 86 us)
-    indexed = INDEXED_BUCKETS and _front_only_wanted(P, dev) and rows < (1 << 23)     # (23 index bits + 9 bits of depth code)
+    indexed = INDEXED_BUCKETS and (INDEXED_BUCKETS == "force" or _front_only_wanted(P, dev)) and rows < (1 << 23)     # (23 index bits + 9 bits of depth code)
     cv = arena.Carver(("fwd", dev.index, _stream_id(), N, Cn, P.width, P.height, kd, int(want_grad), int(want_aux), int(absgrad),
                        int(depth_channel), int(indexed), int(nxq)), dev)
     means2d, depths, comps, sh_aux = _carve_f(dev, (2 * rows, rows, rows, 12 * rows if want_aux else 0), cv)

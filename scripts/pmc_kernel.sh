@@ -10,6 +10,9 @@ cd /tmp && export TMPDIR=/tmp
 ARGS="$GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 4 --no-cpu-baseline --no-variants $*"
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/fetch -- python3 $ARGS > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $ARGS > $OUT/write.log 2>&1
+n=0; for grp in ${PMCK_EXTRA:-}; do n=$((n+1))       # PMCK_EXTRA="A,B C,D": one more counters-only pass per group
+  rocprofv3 --pmc ${grp//,/ } --output-format csv -d $OUT/extra$n -- python3 $ARGS > $OUT/extra$n.log 2>&1 || tail -3 $OUT/extra$n.log
+done
 cd $GRAFT_REPO_ROOT
 python3 - "$OUT" "$KER" > gpurun_out/pmck_$TAG.txt <<'PY'
 import csv, glob, sys, collections
