@@ -136,7 +136,7 @@ class Carver:
 
     def __init__(self, key: tuple, dev: torch.device):
         self.dev = dev
-        self.ring = ring(key, dev)
+        self.ring = ring(key, dev) if key is not None else None    # (key None: a throw-away call -- plain allocator memory)
         self.slot = self.ring.acquire() if self.ring is not None else None
         self.shadow = 0                                           # demand counted when there is no slot
 

@@ -539,12 +539,39 @@ def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Par
 # count is checked afterwards (exact results always: an overflow re-runs phase B with the exact size).
 FUSED_ENTRY = os.environ.get("MISPLAT_FUSED", "1") == "1"
 SPECULATE = os.environ.get("MISPLAT_SPECULATE", "1") == "1"
-CAP_MARGIN = float(os.environ.get("MISPLAT_CAP_MARGIN", "1.25"))
+CAP_MARGIN = float(os.environ.get("MISPLAT_CAP_MARGIN", "1.1"))        # re-chosen when the count comes within this of it
 # A capacity, once chosen, STAYS: it is part of every phase-B argument block (a change re-captures every graph of the shape)
 # and it sizes the per-tile lists inside the arena slot.  The first choice (and every later increase) is generous -- the views
 # of one scene differ by tens of percent in their counts (the bench's eight: 3.8 - 6.4 M) --, address space is what it costs.
-CAP_FIRST_MARGIN = float(os.environ.get("MISPLAT_CAP_FIRST_MARGIN", "1.75"))
+CAP_FIRST_MARGIN = float(os.environ.get("MISPLAT_CAP_FIRST_MARGIN", "2.0"))
 _CAP_CHOSEN: Dict[tuple, int] = {}
+# (measurement aid: a list here collects (entry, byte image of the argument blocks) per call -- the graph cache's keys;
+# key_trace_report() names the fields that differ between a call and the one `period` calls earlier)
+KEY_TRACE: Optional[list] = [] if os.environ.get("MISPLAT_KEY_TRACE") else None
+# (the first call of a shape learns its intersection count from a counting pass and then runs in the steady form)
+PROBE_FIRST = os.environ.get("MISPLAT_PROBE_FIRST", "1") == "1"
+
+
+def key_trace_report(period: int, start: int = 0) -> list:
+    out = []
+    tr = KEY_TRACE or []
+    for i in range(max(start, period), len(tr)):
+        (na, a), (nb, b) = tr[i - period], tr[i]
+        if na != nb or len(a) != len(b):
+            out.append((i, "entry", na, nb))
+            continue
+        if a == b:
+            continue
+        np_ = C.sizeof(Params)
+        T = _lib.RasterArgs if nb.startswith("fwd") else _lib.RasterBwdArgs
+        names = []
+        for blk, cls, off in ((b[:np_], Params, 0), (b[np_:], T, np_)):
+            for f in cls._fields_:
+                d = getattr(cls, f[0])
+                if a[off + d.offset: off + d.offset + d.size] != b[off + d.offset: off + d.offset + d.size]:
+                    names.append(f[0])
+        out.append((i, nb, names))
+    return out
 _CAP_HINT: Dict[tuple, int] = {}
 _READBACK: Dict[tuple, Tensor] = {}
 
@@ -714,7 +741,8 @@ def _front_only_wanted(P: Params, dev) -> bool:
 
 def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg: int, kd: int,
                     n_color: int, per_cam: int, depth_channel: bool, want_aux: bool, want_grad: bool, defer: bool = False,
-                    lazy: bool = False, flags: bool = False, absgrad: bool = False, nxq: int = 0, features=None):
+                    lazy: bool = False, flags: bool = False, absgrad: bool = False, nxq: int = 0, features=None,
+                    probe: bool = False):
     """Allocations + phase A of misplat_raster_fwd (``defer``: phase A is launched together with B, by _raster_phase_b).
     Returns (radii, means2d, depths, comps, grec, sh_aux, state)."""
     lib = _lib.load()
@@ -729,8 +757,8 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     # (bucket entries as positions in the cell-ordered row list: pays where the per-tile sort's depth gather misses the L2 --
     # dense scenes, i.e. together with front-only ordering; at 1 M Gaussians it costs the sort a second gather: 55 -> 86 us)
     indexed = INDEXED_BUCKETS and (INDEXED_BUCKETS == "force" or _front_only_wanted(P, dev)) and rows < (1 << 23)     # (23 index bits + 9 bits of depth code)
-    cv = arena.Carver(("fwd", dev.index, _stream_id(), N, Cn, P.width, P.height, kd, int(want_grad), int(want_aux), int(absgrad),
-                       int(depth_channel), int(indexed), int(nxq)), dev)
+    cv = arena.Carver(None if probe else ("fwd", dev.index, _stream_id(), N, Cn, P.width, P.height, kd, int(want_grad), int(want_aux),
+                                          int(absgrad), int(depth_channel), int(indexed), int(nxq)), dev)
     means2d, depths, comps, sh_aux = _carve_f(dev, (2 * rows, rows, rows, 12 * rows if want_aux else 0), cv)
     grec = cv.take(MISPLAT_REC * rows, torch.float32)
     v_grec_zero = cv.take(MISPLAT_REC * rows, torch.float32).view(rows, MISPLAT_REC) if want_grad else None
@@ -811,9 +839,11 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         cap = max(n_known, 1)
     else:
         cap = _CAP_CHOSEN.get(key)
-        if cap is None or _quantise_cap(int(hint * CAP_MARGIN)) > cap or 4 * _quantise_cap(int(hint * CAP_FIRST_MARGIN)) < cap:
-            cap = _CAP_CHOSEN[key] = _quantise_cap(int(hint * CAP_FIRST_MARGIN))
-        a.est_isects = int(hint)
+        if cap is None or int(hint * CAP_MARGIN) > cap or 4 * _quantise_cap(int(hint * CAP_FIRST_MARGIN)) < cap:
+            cap = _CAP_CHOSEN[key] = min(_quantise_cap(int(hint * CAP_FIRST_MARGIN)), 2 ** 31 - 1)
+        # (the estimate that picks the sort's size classes is tied to the capacity, not to the running count: the count moves
+        # every step, and the argument block is the graph key)
+        a.est_isects = int(cap / CAP_FIRST_MARGIN)
     if cap >= 2 ** 31:
         raise _lib.MisplatError(f"{cap} tile intersections exceed int32 indexing")
     cv = state.get("carver")
@@ -859,6 +889,8 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
             a.ev_blend_begin, a.ev_blend_end = ev[0].cuda_event, ev[1].cuda_event
             KERNEL_EVENTS.setdefault("blend_fwd", []).append(ev)
         with _timed("raster_fwd_B"):
+            if KEY_TRACE is not None:
+                KEY_TRACE.append(("fwd%d" % phases, bytes(P) + bytes(a)))
             check(lib.misplat_raster_fwd(C.byref(P), C.byref(a), C.c_int32(phases), stream_ptr(), _graph_cache(dev)),
                   "misplat_raster_fwd(B)")
         a.ev_blend_begin, a.ev_blend_end = None, None
@@ -940,6 +972,19 @@ class _RasterFused(torch.autograd.Function):
         nxq = (cd - 4 + 3) // 4 if cd > 4 else 0
         lazy = nxq == 0 and _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd)
         want_aux = SH_AUX and deg >= 0 and want_grad and not lazy
+        if (PROBE_FIRST and MERGE_PHASES and SPECULATE and _STATIC_CAP is None and _cap_key(P, means.device) not in _CAP_HINT
+                and not torch.cuda.is_current_stream_capturing()):
+            # First call of a shape: a counting pass (projection + bucketing, results dropped) learns the intersection count,
+            # so that THIS call already runs in the steady form -- one merged entry with a speculative capacity, the argument
+            # block the later visits of the view will present (graph key), the arena demand of the steady call.
+            Pp = Params.from_buffer_copy(bytes(P))
+            st = _raster_phase_a(Pp, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam,
+                                 depth_channel, False, False, nxq=nxq, features=features, probe=True)[-1]
+            _CAP_HINT[_cap_key(P, means.device)] = max(_wait_count(st["host"]), 1)
+            del st
+            PATH_STATS["forward_probe"] += 1
+            lazy = nxq == 0 and _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd)
+            want_aux = SH_AUX and deg >= 0 and want_grad and not lazy
         defer = _STATIC_CAP is not None or (MERGE_PHASES and SPECULATE and _cap_key(P, means.device) in _CAP_HINT)
         PATH_STATS["forward"] += 1
         PATH_STATS["forward_lazy_colour"] += int(lazy)
@@ -1057,6 +1102,8 @@ class _RasterFused(torch.autograd.Function):
                 b.zero_flags = flags & ~1
                 PATH_STATS["backward_rows_refilled"] += 1
             with _timed("raster_bwd"):
+                if KEY_TRACE is not None:
+                    KEY_TRACE.append(("bwd", bytes(P) + bytes(b)))
                 check(lib.misplat_raster_bwd(C.byref(P), C.byref(b), stream_ptr(), _graph_cache(dev)), "misplat_raster_bwd")
             PATH_STATS["backward_one_call"] += 1
             PATH_STATS["backward_background_fill"] += sparse

@@ -332,7 +332,7 @@ def test_features_model_call_as_one_entry_steady_state_vs_c_port(dev, craster, r
         torch.autograd.backward(list(out[:5]), ups_dev)
     torch.cuda.synchronize()
     took = {k: ops.PATH_STATS[k] - before.get(k, 0) for k in ops.PATH_STATS}
-    assert took.get("forward_nd") == 8 and took.get("backward_one_call") == 8 and took.get("forward_merged_phases") == 7, took
+    assert took.get("forward_nd") == 8 and took.get("backward_one_call") == 8 and took.get("forward_merged_phases") == 8 and took.get("forward_probe") == 1, took
     assert took.get("forward_view_order") == 8 and ops.graph_cache_stats(dev)["hits"] >= 2
     assert out[0].shape == (1, H, W, Dp)
     # ---- what the reference feeds gsplat: colours evaluated on the host in fp32 exactly as the kernels do is not available
@@ -1862,21 +1862,21 @@ def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H
     took = {k: ops.PATH_STATS[k] - before.get(k, 0) for k in ops.PATH_STATS}
     # ---- the machinery was ON for the call that is compared
     assert took.get("forward") == n_calls and took.get("backward_one_call") == n_calls and took.get("backward_staged", 0) == 0
-    assert took.get("forward_merged_phases", 0) == n_calls - 1      # from the second call on
+    assert took.get("forward_merged_phases", 0) == n_calls and took.get("forward_probe", 0) == 1   # (a counting pass first)
     assert took.get("forward_view_order", 0) == n_calls             # the launch order comes from the record of this view
     assert took.get("capacity_redo", 0) == 0
     gs = ops.graph_cache_stats(dev)
     assert gs["hits"] >= 1 and gs["captures"] >= 1, gs
     dense = N >= 262_144
     n_lazy = took.get("forward_lazy_colour", 0)
-    assert n_lazy == (n_calls if lazy == "1" else (n_calls - 1 if dense else 0)), took   # "auto": from the second call of a dense scene
+    assert n_lazy == (n_calls if (lazy == "1" or dense) else 0), took   # "auto": a dense scene (known from the counting pass on)
     if dense:                                                   # background fill + one-launch per-Gaussian backward
         assert took.get("backward_background_fill", 0) == n_lazy, took
     r, a, ed, md, n, meta = out
     if dense:
-        # front-only ordering (forced on above): from the second call (the first one has no capacity hint), with the view's
-        # own pivots from the third; meta["flatten_ids"] below is completed on access
-        assert took.get("forward_front_only", 0) == n_calls - 1, took
+        # front-only ordering (forced on above): from the first call (the counting pass has left the capacity hint), with the
+        # view's own pivots from the second; meta["flatten_ids"] below is completed on access
+        assert took.get("forward_front_only", 0) == n_calls, took
         assert meta["_bins"]["partial"] is not None and "flatten_ids" not in dict.keys(meta)
         fn = meta["_bins"]["partial"]["front_n"].cpu().numpy()
         cnt = np.diff(np.concatenate([meta["isect_offsets"].reshape(-1).cpu().numpy(), [meta["n_isects"]]]))
