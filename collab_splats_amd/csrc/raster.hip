@@ -270,11 +270,16 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
         return enqueue(s);
     }
     cache->window_captures++;
+    // This call's work goes out plainly FIRST: the GPU runs it while the host records and instantiates the graph for the
+    // next visit (capturing executes nothing).  Captured-then-launched, the capturing round of the bench's eight views ran
+    // 0.06 ms per step behind the replaying rounds (1.338 vs 1.277 ms: the device waited for the host).
+    const int rc_plain = enqueue(s);
+    if (rc_plain != MISPLAT_OK) return rc_plain;
     // capture on the private stream (thread-local mode: other host threads keep using the runtime normally)
     hipStream_t cs = cache->capture_stream;
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
-        return enqueue(s);
+        return MISPLAT_OK;
     }
     const int rc = enqueue(cs);
     hipGraph_t graph = nullptr;
@@ -282,14 +287,14 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
     if (rc != MISPLAT_OK || ec != hipSuccess || !graph) {
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        return rc != MISPLAT_OK ? rc : enqueue(s);
+        return MISPLAT_OK;                                          // (the work itself is already out)
     }
     hipGraphExec_t exec = nullptr;
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     if (ei != hipSuccess || !exec) {
         (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
-        return enqueue(s);
+        return MISPLAT_OK;
     }
     if ((int)cache->entries.size() >= cache->max_entries) {       // evict the least recently used graph
         size_t victim = 0;
@@ -311,7 +316,7 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
     }
     cache->entries.push_back(GraphEntry{std::move(key), exec, graph, cache->clock, s});
     cache->captures++;
-    return hipGraphLaunch(exec, s) == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
+    return MISPLAT_OK;
 }
 
 template <class A>
