@@ -570,6 +570,14 @@ def main():
             except Exception:
                 pmc = {}
         vif = pmc.get("valu_issue_frac")
+        # class-weighted issue budget of the dominant kernel (scripts/valu_budget.py on the same PMC file: plain 2.5 cycles,
+        # DPP 4.5, packed 4.9, transcendental 8.5 ... per wave instruction, and the measured busy share of the vector ALU)
+        valu_budget = None
+        try:
+            vb = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_budget.json")))["kernels"]
+            valu_budget = (vb.get(dom) or {}).get("issue_frac") if pmc else None
+        except Exception:
+            valu_budget = None
         view_txt = ("one fixed view" if headline_mode["fixed"] else "8 cycling views (configs[3]'s cameras, one per step)")
         if args.dn_loss:
             img_loss = "L1 (no SSIM: --no-ssim)" if args.no_ssim else "main_loss = 0.8 L1 + 0.2 (1 - SSIM) (Splatfacto's, restated)"
@@ -620,6 +628,7 @@ def main():
                          "frac_of_guide_copy_6290": round(achieved / GUIDE_COPY_GBS, 5),
                          "traffic": pmc.get(dom), "traffic_git_rev": pmc.get("git_rev"),
                          "valu_issue_frac": vif.get(dom) if isinstance(vif, dict) else None,
+                         "valu_issue_budget": valu_budget,
                          "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
                          "kernel_ms_note": "mean per launch: HIP events recorded by the C entries directly around the compositing "
                                            "kernels of the headline path, in a separate pass of plain launches after the timed region",
@@ -637,7 +646,8 @@ def main():
                          "step_frac_of_guide_copy_6290": round(step_gbs / GUIDE_COPY_GBS, 5),
                          "step_frac_of_copy_roof": round(step_gbs / max(roof, 1e-9), 5),
                          "note": "the compositing kernels are VALU (v_exp/FMA) issue bound, not HBM bound: "
-                                 "valu_issue_frac is the share of SIMD issue cycles (PMC, profiles/), see DESIGN.md"},
+                                 "valu_issue_frac = instructions x 4 cycles / SIMD cycles (PMC, profiles/); valu_issue_budget: the same count priced "
+                                 "per instruction class, and the measured busy share of the vector ALU (DESIGN.md section 6)"},
         }
         if allreduce_ms:
             line["allreduce_ms"] = round(allreduce_ms[len(allreduce_ms) // 2], 4)
