@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256) void union_count_kernel(const uint8_t* __restr
 }
 
 __global__ __launch_bounds__(256) void union_ids_kernel(const uint8_t* __restrict__ gathered, int world, int64_t nbytes,
-                                                        const int64_t* __restrict__ block_offsets, int32_t* __restrict__ ids) {
+                                                        const int64_t* __restrict__ block_offsets, int32_t* __restrict__ ids,
+                                                        int64_t ids_cap) {
     __shared__ uint32_t wsum[4];
     const int64_t b = (int64_t)blockIdx.x * kBitsBlock + threadIdx.x;
     uint32_t v = union_byte(gathered, world, nbytes, b);
@@ -187,7 +188,8 @@ __global__ __launch_bounds__(256) void union_ids_kernel(const uint8_t* __restric
     int64_t pos = block_offsets[blockIdx.x] + (int64_t)block_scan_excl((uint32_t)__popc(v), wsum, total);
     while (v) {
         const int k = __ffs((int)v) - 1;
-        ids[pos++] = (int32_t)(b * 8 + k);
+        if (pos < ids_cap) ids[pos] = (int32_t)(b * 8 + k);     // (a speculative capacity may be short: the caller checks the count)
+        pos++;
         v &= v - 1u;
     }
 }
@@ -201,10 +203,20 @@ struct RowTable {
 
 template <bool PACK>
 __global__ __launch_bounds__(256) void rows_move_kernel(RowTable T, const int32_t* __restrict__ ids, int64_t n_ids,
-                                                        float* __restrict__ packed) {
+                                                        const int64_t* __restrict__ count_dev, float* __restrict__ packed) {
+    // count_dev (or NULL = n_ids): how many of the n_ids slots hold a row -- known on the device only (the union's size; the
+    // host sized the buffers from the previous step's).  PACK: the slots behind it are zeros (they are reduced with the
+    // rest).  UNPACK: nothing at all when the count exceeds n_ids (the caller then reduces the dense buffer, which must be
+    // as the backward left it).
+    const int64_t have = count_dev ? *count_dev : n_ids;
+    if (!PACK && have > n_ids) return;
     const int64_t total = n_ids * T.W;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t u = i / T.W;
+        if (u >= have) {
+            if (PACK) packed[i] = 0.f;
+            continue;
+        }
         const int c = (int)(i - u * T.W);
         int t = 0;
 #pragma unroll
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(256) void rows_move_kernel(RowTable T, const int32_
 }
 
 int rows_move(bool pack, int32_t n_tensors, float* const* tensors, const int32_t* widths, const int32_t* ids, int64_t n_ids,
-              float* packed, hipStream_t s) {
+              const int64_t* count_dev, float* packed, hipStream_t s) {
     if (n_tensors < 1 || n_tensors > MISPLAT_ROWS_MAX_TENSORS || !tensors || !widths || n_ids < 0) return MISPLAT_EINVAL;
     if (n_ids == 0) return MISPLAT_OK;
     if (!ids || !packed) return MISPLAT_EINVAL;
@@ -233,8 +245,8 @@ int rows_move(bool pack, int32_t n_tensors, float* const* tensors, const int32_t
     T.count = n_tensors; T.W = W;
     int64_t blocks = (n_ids * W + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    if (pack) hipLaunchKernelGGL(rows_move_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, T, ids, n_ids, packed);
-    else hipLaunchKernelGGL(rows_move_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, T, ids, n_ids, packed);
+    if (pack) hipLaunchKernelGGL(rows_move_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, T, ids, n_ids, count_dev, packed);
+    else hipLaunchKernelGGL(rows_move_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, T, ids, n_ids, count_dev, packed);
     return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
 }
 
@@ -259,20 +271,20 @@ extern "C" int misplat_union_count(const uint8_t* gathered, int32_t world, int64
 }
 
 extern "C" int misplat_union_ids(const uint8_t* gathered, int32_t world, int64_t nbytes, const int64_t* block_offsets,
-                                 int32_t* ids, misplat_stream_t stream) {
-    if (world < 1 || nbytes < 0 || (nbytes > 0 && (!gathered || !block_offsets || !ids))) return MISPLAT_EINVAL;
+                                 int32_t* ids, int64_t ids_cap, misplat_stream_t stream) {
+    if (world < 1 || nbytes < 0 || ids_cap < 0 || (nbytes > 0 && (!gathered || !block_offsets || !ids))) return MISPLAT_EINVAL;
     if (nbytes == 0) return MISPLAT_OK;
     hipLaunchKernelGGL(union_ids_kernel, dim3((unsigned)((nbytes + kBitsBlock - 1) / kBitsBlock)), dim3(256), 0,
-                       (hipStream_t)stream, gathered, (int)world, nbytes, block_offsets, ids);
+                       (hipStream_t)stream, gathered, (int)world, nbytes, block_offsets, ids, ids_cap);
     return hipGetLastError() == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
 }
 
 extern "C" int misplat_rows_pack(int32_t n_tensors, const float* const* srcs, const int32_t* widths, const int32_t* ids,
-                                 int64_t n_ids, float* packed, misplat_stream_t stream) {
-    return rows_move(true, n_tensors, (float* const*)srcs, widths, ids, n_ids, packed, (hipStream_t)stream);
+                                 int64_t n_ids, const int64_t* count_dev, float* packed, misplat_stream_t stream) {
+    return rows_move(true, n_tensors, (float* const*)srcs, widths, ids, n_ids, count_dev, packed, (hipStream_t)stream);
 }
 
 extern "C" int misplat_rows_unpack(int32_t n_tensors, float* const* dsts, const int32_t* widths, const int32_t* ids,
-                                   int64_t n_ids, const float* packed, misplat_stream_t stream) {
-    return rows_move(false, n_tensors, dsts, widths, ids, n_ids, (float*)packed, (hipStream_t)stream);
+                                   int64_t n_ids, const int64_t* count_dev, const float* packed, misplat_stream_t stream) {
+    return rows_move(false, n_tensors, dsts, widths, ids, n_ids, count_dev, (float*)packed, (hipStream_t)stream);
 }

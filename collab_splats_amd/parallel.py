@@ -55,7 +55,7 @@ ALLREDUCE = os.environ.get("MISPLAT_ALLREDUCE", "auto")
 # One-GPU rehearsal (bench.py --buckets): run the flags -> bitmap -> union -> pack -> [no collective] -> unpack path with a
 # world of one, to measure what the sparse reduce costs on the device besides the bytes it saves on the links.
 REHEARSE = os.environ.get("MISPLAT_SPARSE_REHEARSE", "0") == "1"
-STATS: dict = {"dense": 0, "sparse": 0, "rows_reduced": 0, "rows_total": 0}
+STATS: dict = {"dense": 0, "sparse": 0, "rows_reduced": 0, "rows_total": 0, "union_overflow": 0, "host_reads_in_step": 0}
 
 
 class _Done:
@@ -169,6 +169,14 @@ class GradientBuckets:
         self._touched = None
         self._union = None
         self._colour_version = None
+        # Row capacity of the packed buffers, from the unions of earlier steps (None: unknown -- the first sparse step reads the
+        # union's size on the host once).  With it a step enqueues bitmap -> gather -> OR -> ids -> pack -> reduce -> unpack
+        # without waiting for anything: the size stays on the device (misplat_rows_pack's count_dev) and is read back after
+        # the collectives have been waited for -- a union that outgrew the capacity leaves the dense buffer untouched and is
+        # reduced densely then.  (The host read in the middle of the backward cost the 5 M step 0.6 ms on one GPU.)
+        self._row_cap = None
+        self._pin = None
+        self._pending = None                             # (event, the capacity the step ran with) of the count copy in flight
 
     # -- the step
     def attach(self, views_per_backward: int = 1, early_colour: bool = True) -> None:
@@ -182,6 +190,7 @@ class GradientBuckets:
         self._work, self._reduced, self._nodes_done = [], 0, 0
         self._handed = set()
         self._touched, self._union, self._colour_version = None, None, None
+        self._union_counted, self._pending = False, None
         self.views_per_backward = max(1, int(views_per_backward))
         self.early_colour = bool(early_colour)
         ops.GRAD_SINK = self
@@ -260,6 +269,9 @@ class GradientBuckets:
         for w in self._work:
             self._finish(w)
         self._work = []
+        if self._pending is not None:                    # (also when this step went dense: the union may have shrunk)
+            self._settle_count()
+            self._pending = None
         if average and _world() > 1:
             self.flat /= _world()
         for i, p in enumerate(self.params):
@@ -271,11 +283,13 @@ class GradientBuckets:
     # -- collectives
     def _union_rows(self):
         """Row ids of the union of the ranks' touched rows (ascending int32, the same on every rank), or None when the
-        flags are missing or the union is too large a part of the scene for packing to pay.  One small collective and one
-        host read (the union's size) per step."""
+        flags are missing or the union is too large a part of the scene for packing to pay.  One small collective per step;
+        on the device the list is a CAPACITY of rows sized from earlier steps (``_union_counted``) and nothing is read back
+        before ``allreduce()`` has waited for its collectives -- only a sink's first sparse step reads the size at once."""
         if self._union is not None:
             return self._union if self._union is not False else None
         self._union = False
+        self._union_counted = False
         if SPARSE == "0" or self._touched is None or not self.row_params:
             return None
         n, world, t = self.n_rows, _world(), self._touched
@@ -293,14 +307,35 @@ class GradientBuckets:
             _lib.check(lib.misplat_union_count(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr(counts),
                                                _lib.stream_ptr()), "misplat_union_count")
             incl = torch.cumsum(counts, dim=0, dtype=torch.int64)
-            total = int(incl[-1].item())                                   # the step's one host read
-            if SPARSE != "1" and total > SPARSE_MAX_FRACTION * n:
-                return None
             offs = (incl - counts).contiguous()
-            ids = torch.empty(max(total, 1), device=t.device, dtype=torch.int32)
-            _lib.check(lib.misplat_union_ids(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr(offs), _lib.ptr(ids),
-                                             _lib.stream_ptr()), "misplat_union_ids")
-            ids = ids[:total]
+            cap = self._row_cap
+            if cap is None:                                                # first sparse step of this sink: one host read
+                total = int(incl[-1].item())
+                STATS["host_reads_in_step"] += 1
+                self._row_cap = _row_capacity(total)
+                if SPARSE != "1" and total > SPARSE_MAX_FRACTION * n:
+                    return None
+                ids = torch.empty(max(total, 1), device=t.device, dtype=torch.int32)
+                _lib.check(lib.misplat_union_ids(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr(offs), _lib.ptr(ids),
+                                                 C.c_int64(ids.numel()), _lib.stream_ptr()), "misplat_union_ids")
+                ids = ids[:total]
+            else:
+                # the size goes to a pinned slot behind everything else of the step; allreduce() reads it at the end
+                if self._pin is None:
+                    self._pin = torch.empty(1, dtype=torch.int64).pin_memory()
+                self._count_dev = incl[-1:]
+                self._pin.copy_(self._count_dev, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._pending = (ev, cap)
+                if SPARSE != "1" and cap > SPARSE_MAX_FRACTION * n:
+                    return None                                            # (dense; the count is still tracked: the union may shrink)
+                ids = torch.empty(cap, device=t.device, dtype=torch.int32)
+                _lib.check(lib.misplat_union_ids(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr(offs), _lib.ptr(ids),
+                                                 C.c_int64(cap), _lib.stream_ptr()), "misplat_union_ids")
+                self._union = ids
+                self._union_counted = True
+                return ids
         else:                                             # CPU rehearsal (gloo): the same steps with numpy / torch
             import numpy as np
             host = (t.detach().cpu().numpy() != 0)
@@ -342,15 +377,17 @@ class GradientBuckets:
         n_pad = (n_pack + world - 1) // world * world                      # (rs_ag wants a multiple of the world size)
         dev = self.flat.device
         packed = torch.zeros(n_pad, device=dev, dtype=torch.float32) if n_pad != n_pack else torch.empty(n_pad, device=dev, dtype=torch.float32)
-        self._rows_move(True, members, widths, ids, packed)
+        counted = bool(getattr(self, "_union_counted", False))
+        self._rows_move(True, members, widths, ids, packed, counted)
         if _backend() == "gloo" and packed.is_cuda:
             host = packed.cpu()
-            self._work.append(dict(work=_reduce(host, True), host=host, dst=packed, unpack=(members, widths, ids)))
+            self._work.append(dict(work=_reduce(host, True), host=host, dst=packed, unpack=(members, widths, ids), span=(a, b), counted=counted))
         else:
-            self._work.append(dict(work=_reduce(packed, True), host=None, dst=packed, unpack=(members, widths, ids)))
+            self._work.append(dict(work=_reduce(packed, True), host=None, dst=packed, unpack=(members, widths, ids), span=(a, b), counted=counted))
 
-    def _rows_move(self, pack: bool, members, widths, ids, packed) -> None:
-        """packed[u, :] <-> the rows ids[u] of the member slices, side by side."""
+    def _rows_move(self, pack: bool, members, widths, ids, packed, counted: bool = False) -> None:
+        """packed[u, :] <-> the rows ids[u] of the member slices, side by side (``counted``: ids is a capacity, the number of
+        rows it holds is on the device)."""
         if ids.numel() == 0:
             return
         tensors = [self.views[i].reshape(self.n_rows, w) for i, w in zip(members, widths)]
@@ -361,7 +398,8 @@ class GradientBuckets:
             ptrs = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
             wid = (C.c_int32 * len(widths))(*widths)
             fn = lib.misplat_rows_pack if pack else lib.misplat_rows_unpack
-            _lib.check(fn(C.c_int32(len(tensors)), ptrs, wid, _lib.ptr(ids), C.c_int64(ids.numel()), _lib.ptr(packed),
+            _lib.check(fn(C.c_int32(len(tensors)), ptrs, wid, _lib.ptr(ids), C.c_int64(ids.numel()),
+                          _lib.ptr(self._count_dev) if counted else None, _lib.ptr(packed),
                           _lib.stream_ptr()), "misplat_rows_pack" if pack else "misplat_rows_unpack")
             return
         rows = ids.long()
@@ -380,7 +418,39 @@ class GradientBuckets:
             w["dst"].copy_(w["host"])
         if "unpack" in w:
             members, widths, ids = w["unpack"]
-            self._rows_move(False, members, widths, ids, w["dst"])
+            if w.get("counted") and self._settle_count() > ids.numel():
+                # the union outgrew the capacity: the scatter kernel would have done nothing, the dense slice is as the backward
+                # left it -- reduce that (every rank sees the same count, so every rank takes this branch)
+                STATS["union_overflow"] += 1
+                a, b = w["span"]
+                t = self.flat[a:b]
+                if _backend() == "gloo" and t.is_cuda:
+                    host = t.cpu()
+                    _reduce(host, False)
+                    t.copy_(host)
+                else:
+                    _reduce(t, False)
+                return
+            self._rows_move(False, members, widths, ids, w["dst"], bool(w.get("counted")))
+
+    def _settle_count(self) -> int:
+        """This step's union size (waits for the copy that was enqueued behind the union kernels; by the time the collectives
+        have been waited for it has long landed) and the capacity of the next step."""
+        if self._pending is None:
+            return -1
+        ev, _cap = self._pending
+        ev.synchronize()
+        total = int(self._pin[0])
+        cap = self._row_cap
+        if cap is None or int(total * 1.1) > cap or 4 * _row_capacity(total) < cap:
+            self._row_cap = _row_capacity(total)
+        return total
+
+
+def _row_capacity(total: int) -> int:
+    """Row capacity for a union of ``total`` rows: half as much again (the unions of consecutive steps of a training run differ by
+    the views' own variation), at least 1 024."""
+    return max(1024, int(total * 1.5))
 
 
 def _world() -> int:

@@ -600,11 +600,14 @@ int misplat_touched_bits(const uint8_t* flags, int64_t n_rows, uint8_t* bits, mi
 int misplat_union_count(const uint8_t* gathered, int32_t world, int64_t nbytes, int32_t* block_counts,
                         misplat_stream_t stream);
 int misplat_union_ids(const uint8_t* gathered, int32_t world, int64_t nbytes, const int64_t* block_offsets, int32_t* ids,
-                      misplat_stream_t stream);
+                      int64_t ids_cap, misplat_stream_t stream);
+/* count_dev (device, or NULL = n_ids): how many of the n_ids slots hold a row, for a caller that sized ids / packed from the
+ * previous step's union and reads this step's size only after everything is enqueued: pack writes zeros into the slots behind
+ * the count; unpack does NOTHING when the count exceeds n_ids (the caller then reduces the dense buffer instead). */
 int misplat_rows_pack(int32_t n_tensors, const float* const* srcs, const int32_t* widths, const int32_t* ids, int64_t n_ids,
-                      float* packed, misplat_stream_t stream);
+                      const int64_t* count_dev, float* packed, misplat_stream_t stream);
 int misplat_rows_unpack(int32_t n_tensors, float* const* dsts, const int32_t* widths, const int32_t* ids, int64_t n_ids,
-                        const float* packed, misplat_stream_t stream);
+                        const int64_t* count_dev, const float* packed, misplat_stream_t stream);
 
 /* Diagnosis (tests only; csrc/raster.hip): a 16-byte memset node + a kernel captured the way the graph cache captures, replayed
  * n_replays (<= 64) times with the 16 bytes overwritten with garbage in between; out_host[k] = the first counter after replay k

@@ -1651,6 +1651,63 @@ def test_gradient_sink_with_activations_inside_the_kernels(dev, N):
             assert rel_err(a, b) < 2e-5, (name, rel_err(a, b))
 
 
+def test_sparse_reduce_without_a_host_read_and_its_overflow_fallback(dev, monkeypatch):
+    """The sparse shared-Gaussian reduce on the device (one GPU, rehearsal mode: every step of the multi-rank path except the
+    collective itself): from a sink's second step on, bitmap -> union -> pack -> unpack run with a row CAPACITY from the earlier
+    steps and the union's size is read only after everything has been waited for (no host read inside the step); a union
+    that outgrows the capacity leaves the dense buffer untouched and is reduced densely.  In every case the gradients are
+    those of a step without a sink (atomic backward: to the order of its sums)."""
+    from collab_splats_amd import ops, parallel, rasterization
+    monkeypatch.setattr(parallel, "REHEARSE", True)
+    monkeypatch.setattr(parallel, "SPARSE", "1")
+    N, W, H = 300_000, 640, 360
+    args = _bench_like_scene(dev, N, W, H, seed=17, scale_mul=1.5)
+    raw = [args[0], args[1], torch.log(args[2]), torch.logit(args[3].clamp(1e-4, 1 - 1e-4)), args[4]]
+    kw = dict(sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True,
+              scales_are_log=True, opacities_are_logit=True)
+    leaves = [t.clone().requires_grad_(True) for t in raw]
+    ups = None
+
+    def step(bucket):
+        nonlocal ups
+        for l in leaves:
+            l.grad = None
+        if bucket is not None:
+            bucket.attach()
+        try:
+            out = rasterization(*leaves, args[5], args[6], W, H, **kw)
+            if ups is None:
+                ups = [u.to(dev) for u in upstream([t.shape for t in out[:5]], dtype=torch.float32)]
+            torch.autograd.backward(list(out[:5]), ups)
+        finally:
+            if bucket is not None:
+                bucket.allreduce(average=False)
+        return [l.grad.clone() for l in leaves]
+
+    def same(g, ref):
+        for name, a, b in zip(("v_means", "v_quats", "v_log_scales", "v_opacity_logits", "v_sh"), g, ref):
+            assert torch.isfinite(a).all() and rel_err(a, b) < 2e-5, (name, rel_err(a, b))
+
+    try:
+        ref = step(None)
+        bucket = parallel.GradientBuckets(leaves, geometry=[0, 1, 2, 3], colour=[4])
+        stats0 = dict(parallel.STATS)
+        got = [step(bucket) for _ in range(3)]
+        took = {k: parallel.STATS[k] - stats0.get(k, 0) for k in parallel.STATS}
+        # step 1 reads the union's size once; steps 2 and 3 run on the capacity it left
+        assert took["host_reads_in_step"] == 1 and took["union_overflow"] == 0 and took["sparse"] >= 3, took
+        assert bucket._row_cap is not None and bucket._row_cap < N
+        for g in got:
+            same(g, ref)
+        bucket._row_cap = 1024                                    # far too small: the scatter must do nothing, dense fallback
+        g = step(bucket)
+        assert parallel.STATS["union_overflow"] - stats0.get("union_overflow", 0) >= 1 and bucket._row_cap > 1024
+        same(g, ref)
+        same(step(bucket), ref)                                   # and sparse again on the corrected capacity
+    finally:
+        assert ops.GRAD_SINK is None
+
+
 def test_large_scene_entirely_out_of_view_gives_zero_gradients(dev):
     """No intersection at all in a scene large enough for the background-fill path (>= 262 144 Gaussians): the compositing
     backward has no grid to carry the fill, the zeros are then written by plain fill launches -- every gradient is
@@ -2120,7 +2177,7 @@ def test_sparse_reduce_kernels_bitmaps_union_pack_unpack(dev):
         assert int(incl[-1]) == rows.size
         ids = torch.empty(max(rows.size, 1), dtype=torch.int32, device=dev)
         _lib.check(lib.misplat_union_ids(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr((incl - counts).contiguous()),
-                                         _lib.ptr(ids), _lib.stream_ptr()), "ids")
+                                         _lib.ptr(ids), C.c_int64(ids.numel()), _lib.stream_ptr()), "ids")
         assert np.array_equal(ids[:rows.size].cpu().numpy(), rows.astype(np.int32))
         widths = [3, 45, 3, 3, 4, 1]
         tens = [torch.randn(n, w, device=dev) for w in widths]
@@ -2129,12 +2186,36 @@ def test_sparse_reduce_kernels_bitmaps_union_pack_unpack(dev):
         ptrs = (C.c_void_p * 6)(*[t.data_ptr() for t in tens])
         wid = (C.c_int32 * 6)(*widths)
         idt = ids[:rows.size].contiguous()
-        _lib.check(lib.misplat_rows_pack(C.c_int32(6), ptrs, wid, _lib.ptr(idt), C.c_int64(rows.size), _lib.ptr(packed), _lib.stream_ptr()), "pack")
+        _lib.check(lib.misplat_rows_pack(C.c_int32(6), ptrs, wid, _lib.ptr(idt), C.c_int64(rows.size), None, _lib.ptr(packed), _lib.stream_ptr()), "pack")
         want = torch.cat([t[idt.long()] for t in tens], dim=1)
         assert torch.equal(packed.view(rows.size, W), want)
+        # the sync-free form: buffers sized from an earlier step (larger or smaller than this union), the count on the device
+        count_dev = incl[-1:].contiguous()
+        for cap in (rows.size + 37, max(rows.size - 3, 0)):
+            ids_c = torch.full((max(cap, 1),), -1, dtype=torch.int32, device=dev)
+            _lib.check(lib.misplat_union_ids(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr((incl - counts).contiguous()),
+                                             _lib.ptr(ids_c), C.c_int64(cap), _lib.stream_ptr()), "ids capped")
+            m = min(cap, rows.size)
+            assert np.array_equal(ids_c[:m].cpu().numpy(), rows[:m].astype(np.int32)) and bool((ids_c[m:cap] == -1).all())
+            packed_c = torch.full((max(cap, 1) * W,), 5.0, device=dev)
+            outs_c = [torch.full_like(t, 7.0) for t in tens]
+            optrs_c = (C.c_void_p * 6)(*[t.data_ptr() for t in outs_c])
+            if cap > 0:
+                _lib.check(lib.misplat_rows_pack(C.c_int32(6), ptrs, wid, _lib.ptr(ids_c), C.c_int64(cap), _lib.ptr(count_dev), _lib.ptr(packed_c),
+                                                 _lib.stream_ptr()), "pack counted")
+                _lib.check(lib.misplat_rows_unpack(C.c_int32(6), optrs_c, wid, _lib.ptr(ids_c), C.c_int64(cap), _lib.ptr(count_dev),
+                                                   _lib.ptr(packed_c), _lib.stream_ptr()), "unpack counted")
+            if cap >= rows.size:                                   # fits: rows behind the count are zeros, the scatter is exact
+                pc = packed_c[:cap * W].view(cap, W)
+                assert torch.equal(pc[:rows.size], want) and bool((pc[rows.size:] == 0).all())
+                for o, t in zip(outs_c, tens):
+                    assert torch.equal(o[idt.long()], t[idt.long()])
+            else:                                                  # too small: the scatter must not have touched anything
+                for o in outs_c:
+                    assert bool((o == 7.0).all())
         outs = [torch.full_like(t, 7.0) for t in tens]
         optrs = (C.c_void_p * 6)(*[t.data_ptr() for t in outs])
-        _lib.check(lib.misplat_rows_unpack(C.c_int32(6), optrs, wid, _lib.ptr(idt), C.c_int64(rows.size), _lib.ptr(packed * 2), _lib.stream_ptr()), "unpack")
+        _lib.check(lib.misplat_rows_unpack(C.c_int32(6), optrs, wid, _lib.ptr(idt), C.c_int64(rows.size), None, _lib.ptr(packed * 2), _lib.stream_ptr()), "unpack")
         torch.cuda.synchronize()
         keep = np.ones(n, bool)
         keep[rows] = False
