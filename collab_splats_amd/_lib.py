@@ -75,7 +75,7 @@ class RasterBwdArgs(C.Structure):
                                              "v_means2d_out", "unit_sel")]
                 + [("unit_stride", C.c_int32), ("unit_slots", C.c_int32)]
                 + [(n, C.c_void_p) for n in ("featx", "features", "v_featx", "v_features")]
-                + [(n, C.c_int32) for n in ("n_feat", "nxq", "depth_channel", "reserved_x")])
+                + [(n, C.c_int32) for n in ("n_feat", "nxq", "depth_channel", "reserved_x")] + [("depths", C.c_void_p)])
 
 
 def make_params(n_gauss: int, n_cams: int, width: int, height: int, tile_size: int = 16,

@@ -123,6 +123,17 @@ struct LazyColour {
     float4* v_rows;                                  // or NULL: gradient rows [C*N,16], a row is cleared when its colour is set
     float ccx, ccy, ccz;                             // camera centre of the workgroup's tile (set in the kernel)
     int deg, depth_channel, n_gauss;
+    // N-D records (the features model, nxq > 0): channel 3 = features[g][0]; channels 4.. are read from the feature rows
+    // themselves by whoever stages the record (FeatSrc: no featx array is written -- what one wave lays out during a launch
+    // another wave, on another XCD's L2, could not rely on); v_rows_x (or NULL): the featx gradient rows, cleared with v_rows
+    const float* features; float4* v_rows_x;
+    int n_feat, nxq;
+};
+// Channels 4.. of an N-D record straight from the caller's tensors (color_copy_x_kernel's layout without the copy: fused
+// channel 3 + j = features[g][j], the depth behind the last feature, zero padded); features == NULL: read featx rows.
+struct FeatSrc {
+    const float* features; const float* depths;
+    int n_feat, depth_channel, n_gauss;
 };
 
 // Colour of row g from its 16 x 3 coefficients, term by term (MISPLAT_SH_WALK: the same expressions in the same order as
@@ -130,6 +141,7 @@ struct LazyColour {
 // speed decision the results must not show).  The coefficients are read straight from global memory as the walk
 // reaches them; its scheduling barriers keep the compiler from hoisting all 48 loads to the top: the evaluation sits
 // inside the compositing kernel and must not cost it its occupancy (80 VGPRs without it, 111 with).
+template <int NXQ>
 __device__ __forceinline__ float4 lazy_colour(const LazyColour& lz, int g) {
 #pragma clang fp contract(off)
     using namespace misplat_sh;
@@ -151,8 +163,17 @@ __device__ __forceinline__ float4 lazy_colour(const LazyColour& lz, int g) {
     }
     MISPLAT_SH_WALK(lz.deg, x, y, z, LZ_TERM)
 #undef LZ_TERM
-    const float4 q3 = make_float4(fmaxf(c0 + 0.5f, 0.f), fmaxf(c1 + 0.5f, 0.f), fmaxf(c2 + 0.5f, 0.f),
-                                  lz.depth_channel ? lz.depths[g] : 0.f);
+    float w3 = 0.f;
+    if (NXQ > 0) {                                             // (compile time: the 4-channel kernel must not pay for it)
+        w3 = lz.features[(size_t)gg * lz.n_feat];              // channel 3 = feature 0 (the other channels: FeatSrc)
+        if (lz.v_rows_x) {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < NXQ; q++) lz.v_rows_x[(size_t)g * NXQ + q] = z;
+        }
+    } else if (lz.depth_channel)
+        w3 = lz.depths[g];
+    const float4 q3 = make_float4(fmaxf(c0 + 0.5f, 0.f), fmaxf(c1 + 0.5f, 0.f), fmaxf(c2 + 0.5f, 0.f), w3);
     lz.grec_rw[4 * (size_t)g + 3] = q3;
     if (lz.v_rows) {
         // The backward adds into the gradient row of a record only where a pixel of the band takes it, and such a band
@@ -172,7 +193,7 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
                                              const int32_t* __restrict__ slots, float xlo, float xhi,
                                              float ylo, float yhi, float alpha_min,
                                              float4* smx = nullptr, const float4* __restrict__ featx = nullptr,
-                                             const LazyColour* lz = nullptr) {
+                                             const LazyColour* lz = nullptr, const FeatSrc* fs = nullptr) {
     float4 q0, q1, q2, q3;
     bool keep = false;
     int slot = 0;
@@ -191,7 +212,7 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
         // concurrent 16-byte store of another wave becomes visible)
         if (keep && (__float_as_uint(q3.x) == kColourUnset || __float_as_uint(q3.y) == kColourUnset ||
                      __float_as_uint(q3.z) == kColourUnset || __float_as_uint(q3.w) == kColourUnset))
-            q3 = lazy_colour(*lz, g);
+            q3 = lazy_colour<NXQ>(*lz, g);
     }
     const unsigned long long mask = __ballot(keep);
     if (keep) {
@@ -200,8 +221,23 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
         sm[pos] = q0; sm[64 + pos] = q1; sm[128 + pos] = q2; sm[192 + pos] = q3;
         sm_idx[pos] = i;
         if (sm_slot) sm_slot[pos] = slot;      // emission slot (slab mode) or Gaussian row (atomic mode)
+        if (NXQ > 0 && fs && fs->features) {
+            const float* fr = fs->features + (size_t)g * fs->n_feat;       // (one camera: row = Gaussian; the launchers check)
+            const float dz = fs->depth_channel ? fs->depths[g] : 0.f;
 #pragma unroll
-        for (int q = 0; q < NXQ; q++) smx[q * 64 + pos] = featx[(size_t)g * NXQ + q];   // channels 4 .. 4+4*NXQ
+            for (int q = 0; q < NXQ; q++) {
+                float e[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = 4 * q + k + 1;
+                    e[k] = j < fs->n_feat ? fr[j] : (j == fs->n_feat ? dz : 0.f);
+                }
+                smx[q * 64 + pos] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NXQ; q++) smx[q * 64 + pos] = featx[(size_t)g * NXQ + q];   // channels 4 .. 4+4*NXQ
+        }
     }
     return __popcll(mask);
 }
@@ -245,7 +281,8 @@ template <int CD, int PPL, int NXQ = 0, bool LAZY = false>
                                           end of round 3 (view-keyed orders on): five waves, no spill, 0.339 -> 0.323 ms on the
                                           cycling views, 0.217 -> 0.213 fixed, 5 M and 100 k unchanged; four waves 0.344 */
 #endif
-__global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0) ? MISPLAT_FWD_WAVES : 1) void blend_fwd_kernel(
+// (N-D records on demand: 129 VGPRs unbounded at NXQ = 4 -- one over the four-wave limit)
+__global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0) ? MISPLAT_FWD_WAVES : ((NXQ > 0 && LAZY) ? 4 : 1)) void blend_fwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* grec,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ offsets, int64_t n_isects,
     float* __restrict__ render, float* __restrict__ alpha, float* __restrict__ exp_depth,
@@ -269,6 +306,9 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
         lz.ccy = -(V[1] * V[3] + V[5] * V[7] + V[9] * V[11]);
         lz.ccz = -(V[2] * V[3] + V[6] * V[7] + V[10] * V[11]);
     }
+    FeatSrc fsrc;
+    fsrc.features = lz.features; fsrc.depths = lz.depths; fsrc.n_feat = lz.n_feat; fsrc.depth_channel = lz.depth_channel;
+    fsrc.n_gauss = lz.n_gauss;
     const int lane = threadIdx.x;
     const int x = c.tx * MISPLAT_TILE + (lane & 15);
     const int ybase = c.y0 + (lane >> 4);
@@ -342,7 +382,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
         }
         __syncthreads();
         const int n = stage_records<NXQ, LAZY>(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
-                                               nullptr, xlo, xhi, ylo, yhi, amin, smx, featx, &lz);
+                                               nullptr, xlo, xhi, ylo, yhi, amin, smx, featx, &lz, (LAZY && NXQ > 0) ? &fsrc : nullptr);
         __syncthreads();
         reach_end = min(bs + 64, c.end);
         if (n == 0) continue;
@@ -589,7 +629,7 @@ template <int CD, int PPL, bool ABS, bool ATOMIC, int NXQ = 0>
 #ifndef MISPLAT_BWD_WAVES
 #define MISPLAT_BWD_WAVES 5
 #endif
-__global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (PPL == 4 ? 3 : 1)) void blend_bwd_kernel(
+__global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (PPL == 4 ? 3 : (NXQ > 0 ? 4 : 1))) void blend_bwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ slots,
     const int32_t* __restrict__ offsets, int64_t n_isects, const float* __restrict__ alpha,
@@ -598,7 +638,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
     const float* __restrict__ v_exp_depth, const float* __restrict__ v_med_depth,
     const float* __restrict__ v_normal, float* __restrict__ slab, float* __restrict__ slab_abs,
     uint8_t* __restrict__ valid, const float4* __restrict__ featx = nullptr, float* __restrict__ v_featx = nullptr,
-    int n_channels = CD, misplat_internal::FillList F = {}) {
+    int n_channels = CD, misplat_internal::FillList F = {}, FeatSrc fsrc = FeatSrc()) {
     static_assert(NXQ == 0 || ATOMIC, "N-D colours: atomic gradient mode only");
     // Background role (F.blocks > 0): the last workgroups of the grid -- dispatched when the machine starts to drain --
     // or (at_head: fills too large for the tail) the first ones clear the tensors the per-Gaussian backward kernels write
@@ -712,7 +752,8 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
         const int bs = c.beg + (b << 6);
         __syncthreads();
         const int n = stage_records<NXQ>(sm, sm_idx, sm_slot, lane, bs + lane, bs + lane <= maxlast, grec, flatten_ids,
-                                         ATOMIC ? nullptr : slots, xlo, xhi, ylo, yhi, amin, smx, featx);
+                                         ATOMIC ? nullptr : slots, xlo, xhi, ylo, yhi, amin, smx, featx, nullptr,
+                                         NXQ > 0 ? &fsrc : nullptr);
         __syncthreads();
         if (n == 0) continue;
         // does any pixel of the band take its median depth from a Gaussian of this batch?
@@ -1259,6 +1300,7 @@ int misplat_internal::blend_fwd_lazy(const misplat_params* p, int32_t color_dim,
     lz.means = means; lz.coeffs = coeffs; lz.coeffs_rest = coeffs_rest; lz.depths = depths; lz.viewmats = viewmats;
     lz.grec_rw = (float4*)grec; lz.sh_aux = sh_aux; lz.v_rows = (float4*)rows_on_touch; lz.ccx = lz.ccy = lz.ccz = 0.f;
     lz.deg = sh_degree; lz.depth_channel = depth_channel; lz.n_gauss = p->n_gauss;
+    lz.features = nullptr; lz.v_rows_x = nullptr; lz.n_feat = 0; lz.nxq = 0;
     if (color_dim == 3)
         hipLaunchKernelGGL((blend_fwd_kernel<3, 2, 0, true>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec, flatten_ids,
                            offsets, n_isects, render, alpha, exp_depth, med_depth, normal, last_ids, median_ids,
@@ -1395,6 +1437,39 @@ extern "C" int misplat_blend_fwd_x(const misplat_params* p, int32_t n_channels, 
     return check_launch();
 }
 
+// misplat_blend_fwd_x with on-demand records (the features model's call in training): the colour slots of grec start UNSET,
+// the first wave that stages a record past its cull evaluates SH -> max(. + 0.5, 0), takes channel 3 from features[g][0] and
+// clears the record's gradient rows (rows_on_touch / rows_on_touch_x or NULL); channels 4.. are read from features[g][1..]
+// (+ depths[g]) by every wave that stages the record -- there is no featx array in this mode.
+int misplat_internal::blend_fwd_x_lazy(const misplat_params* p, int32_t n_channels, int32_t nxq, const float* Ks, float* grec,
+                                       const int32_t* flatten_ids, const int32_t* offsets, int64_t n_isects,
+                                       float* render, float* alpha, float* exp_depth, float* med_depth, float* normal,
+                                       int32_t* last_ids, int32_t* median_ids, const float* means, const float* viewmats,
+                                       const float* coeffs, const float* coeffs_rest, int32_t sh_degree, int32_t depth_channel,
+                                       const float* depths, const float* features, int32_t n_feat, float* rows_on_touch,
+                                       float* rows_on_touch_x, hipStream_t s) {
+    if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || nxq < 3 || nxq > 4 || n_channels < 5 ||
+        n_channels > 4 + 4 * nxq || !means || !viewmats || !coeffs || sh_degree < 0 || sh_degree > 3 || !features ||
+        n_feat < 1 || 3 + n_feat + (depth_channel ? 1 : 0) != n_channels || (depth_channel && !depths) || p->n_cams != 1 ||
+        ((((uintptr_t)rows_on_touch) | ((uintptr_t)rows_on_touch_x)) & 15))
+        return MISPLAT_EINVAL;
+    const int total = p->tile_w * p->tile_h * p->n_cams * kBands;
+    const int grid = ((total + 7) / 8) * 8;
+    LazyColour lz;
+    lz.means = means; lz.coeffs = coeffs; lz.coeffs_rest = coeffs_rest; lz.depths = depths; lz.viewmats = viewmats;
+    lz.grec_rw = (float4*)grec; lz.sh_aux = nullptr; lz.v_rows = (float4*)rows_on_touch; lz.ccx = lz.ccy = lz.ccz = 0.f;
+    lz.deg = sh_degree; lz.depth_channel = depth_channel; lz.n_gauss = p->n_gauss;
+    lz.features = features; lz.v_rows_x = (float4*)rows_on_touch_x; lz.n_feat = n_feat; lz.nxq = nxq;
+#define LAUNCH_FWDXL(NXQ_)                                                                                            \
+    hipLaunchKernelGGL((blend_fwd_kernel<4, 2, NXQ_, true>), dim3(grid), dim3(64), 0, s, *p, Ks, (const float4*)grec,  \
+                       flatten_ids, offsets, n_isects, render, alpha, exp_depth, med_depth, normal, last_ids,          \
+                       median_ids, (const float4*)nullptr, n_channels, lz)
+    if (nxq == 3) LAUNCH_FWDXL(3);                 // (D' = 16 and 17: the features model without / with the depth channel)
+    else LAUNCH_FWDXL(4);
+#undef LAUNCH_FWDXL
+    return check_launch();
+}
+
 extern "C" int misplat_blend_bwd_x_atomic(const misplat_params* p, int32_t n_channels, int32_t nxq, const float* Ks,
                                           const float* grec, const float* featx, const int32_t* flatten_ids,
                                           const int32_t* offsets, int64_t n_isects, const float* alpha,
@@ -1404,7 +1479,7 @@ extern "C" int misplat_blend_bwd_x_atomic(const misplat_params* p, int32_t n_cha
                                           float* v_featx, float* v_abs, misplat_stream_t stream) {
     return misplat_internal::blend_bwd_x_atomic(p, n_channels, nxq, Ks, grec, featx, flatten_ids, offsets, n_isects, alpha, last_ids,
                                                 median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, v_grec,
-                                                v_featx, v_abs, 0, (hipStream_t)stream);
+                                                v_featx, v_abs, 0, nullptr, (hipStream_t)stream, nullptr, 0, 0, nullptr);
 }
 
 int misplat_internal::blend_bwd_x_atomic(const misplat_params* p, int32_t n_channels, int32_t nxq, const float* Ks,
@@ -1413,10 +1488,19 @@ int misplat_internal::blend_bwd_x_atomic(const misplat_params* p, int32_t n_chan
                                          const int32_t* last_ids, const int32_t* median_ids, const float* render,
                                          const float* v_render, const float* v_alpha, const float* v_exp_depth,
                                          const float* v_med_depth, const float* v_normal, float* v_grec,
-                                         float* v_featx, float* v_abs, int32_t zero_flags, hipStream_t stream) {
+                                         float* v_featx, float* v_abs, int32_t zero_flags, const FillList* fills,
+                                         hipStream_t stream, const float* features, int32_t n_feat, int32_t depth_channel,
+                                         const float* depths) {
+    // featx == NULL: channels 4.. straight from features [N, n_feat] (+ depths): the forward ran with on-demand records
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || nxq < 1 || nxq > 4 || n_channels < 5 ||
-        n_channels > 4 + 4 * nxq || !featx || !v_grec || !v_featx)
+        n_channels > 4 + 4 * nxq || !v_grec || !v_featx)
         return MISPLAT_EINVAL;
+    if (!featx && (!features || n_feat < 1 || 3 + n_feat + (depth_channel ? 1 : 0) != n_channels || (depth_channel && !depths) ||
+                   p->n_cams != 1))
+        return MISPLAT_EINVAL;
+    FeatSrc fsrc;
+    fsrc.features = featx ? nullptr : features; fsrc.depths = depths; fsrc.n_feat = n_feat; fsrc.depth_channel = depth_channel;
+    fsrc.n_gauss = p->n_gauss;
     hipStream_t s = (hipStream_t)stream;
     const size_t rows = (size_t)p->n_gauss * p->n_cams;
     if (rows == 0) return MISPLAT_OK;
@@ -1424,14 +1508,30 @@ int misplat_internal::blend_bwd_x_atomic(const misplat_params* p, int32_t n_chan
     if (!(zero_flags & 1) && misplat_internal::fill_bytes(v_grec, rows * MISPLAT_REC * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     if (!(zero_flags & 4) && misplat_internal::fill_bytes(v_featx, rows * 4 * nxq * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
     if (v_abs && !(zero_flags & 2) && misplat_internal::fill_bytes(v_abs, rows * 2 * sizeof(float), 0u, s) != MISPLAT_OK) return MISPLAT_ELAUNCH;
+    FillList F = {};
+    if (fills) {                                    // (as blend_bwd_atomic: zeros for the next kernel, written by extra workgroups)
+        if (fills->count < 0 || fills->count > 8) return MISPLAT_EINVAL;
+        for (int k = 0; k < fills->count; k++)
+            if (!fills->p[k] || (((uintptr_t)fills->p[k]) & 15) || fills->n[k] < 0) return MISPLAT_EINVAL;
+        if (n_isects > 0) {
+            F = *fills;
+            F.blocks = kFillBlocks;
+            F.at_head = (int64_t)rows >= kFillHeadRows;
+        } else {
+            for (int k = 0; k < fills->count; k++) {
+                const int rf = zero_fill(fills->p[k], fills->n[k], 0, s);
+                if (rf != MISPLAT_OK) return rf;
+            }
+        }
+    }
     if (n_isects == 0) return MISPLAT_OK;
     const int total = p->tile_w * p->tile_h * p->n_cams * kBands;
-    const int grid = ((total + 7) / 8) * 8;
+    const int grid = ((total + 7) / 8) * 8 + F.blocks;
 #define LAUNCH_BWDX(NXQ_, ABS_)                                                                              \
     hipLaunchKernelGGL((blend_bwd_kernel<4, 2, ABS_, true, NXQ_>), dim3(grid), dim3(64), 0, s, *p, Ks,          \
                        (const float4*)grec, flatten_ids, (const int32_t*)nullptr, offsets, n_isects, alpha,    \
                        last_ids, median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal,    \
-                       v_grec, v_abs, (uint8_t*)nullptr, (const float4*)featx, v_featx, n_channels)
+                       v_grec, v_abs, (uint8_t*)nullptr, (const float4*)featx, v_featx, n_channels, F, fsrc)
 #define DISPATCH_BWDX(NXQ_)                     \
     do {                                        \
         if (v_abs) LAUNCH_BWDX(NXQ_, true);     \

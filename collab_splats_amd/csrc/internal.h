@@ -51,6 +51,13 @@ int unit_order_table(const misplat_params* p, const int32_t* unit_work, int32_t*
                      int32_t stride, int32_t slots, const float* unit_reach, hipStream_t s);
 
 // misplat_blend_fwd_lazy that also clears row g of rows_on_touch[C*N,16] (or NULL) when it sets the colour of record g.
+// N-D records on demand (blend.hip): see the definition.
+int blend_fwd_x_lazy(const misplat_params* p, int32_t n_channels, int32_t nxq, const float* Ks, float* grec,
+                     const int32_t* flatten_ids, const int32_t* offsets, int64_t n_isects, float* render, float* alpha,
+                     float* exp_depth, float* med_depth, float* normal, int32_t* last_ids, int32_t* median_ids, const float* means,
+                     const float* viewmats, const float* coeffs, const float* coeffs_rest, int32_t sh_degree, int32_t depth_channel,
+                     const float* depths, const float* features, int32_t n_feat, float* rows_on_touch, float* rows_on_touch_x,
+                     hipStream_t s);
 int blend_fwd_lazy(const misplat_params* p, int32_t color_dim, const float* Ks, float* grec, const int32_t* flatten_ids,
                    const int32_t* offsets, int64_t n_isects, float* render, float* alpha, float* exp_depth, float* med_depth,
                    float* normal, int32_t* last_ids, int32_t* median_ids, const float* means, const float* viewmats,
@@ -65,7 +72,9 @@ int gauss_bwd_sparse(const misplat_params* p, int32_t sh_degree, int32_t depth_s
                      const float* coeffs_rest, const float* compensations, const float* v_grec, float* v_coeffs,
                      float* v_coeffs_rest, float* v_means, float* v_quats, float* v_scales, float* v_opacities,
                      float* v_means2d_out /* or NULL: [N,2] (cleared like the others), columns 0:2 of the flagged rows */,
-                     hipStream_t s);
+                     hipStream_t s, const float* v_featx = nullptr, int32_t nxq = 0,
+                     float* v_features = nullptr /* N-D records: [N, n_feat] (cleared like the others), the flagged rows */,
+                     int32_t n_feat = 0, int32_t depth_in_featx = 0);
 
 // Bucket entries in index mode (bucket_tiles(indexed)): position in the cell-ordered row list in the low 23 bits, a 9-bit
 // MONOTONE code of the row's depth above them (6 bits of the float's exponent from 2^-7 up, 3 bits of mantissa: buckets 9 %
@@ -135,6 +144,9 @@ int blend_bwd_x_atomic(const misplat_params* p, int32_t n_channels, int32_t nxq,
                        const float* featx, const int32_t* flatten_ids, const int32_t* offsets, int64_t n_isects,
                        const float* alpha, const int32_t* last_ids, const int32_t* median_ids, const float* render,
                        const float* v_render, const float* v_alpha, const float* v_exp_depth, const float* v_med_depth,
-                       const float* v_normal, float* v_grec, float* v_featx, float* v_abs, int32_t zero_flags, hipStream_t s);
+                       const float* v_normal, float* v_grec, float* v_featx, float* v_abs, int32_t zero_flags,
+                       const FillList* fills /* or NULL: as blend_bwd_atomic */, hipStream_t s,
+                       const float* features = nullptr /* featx == NULL: channels 4.. from features [N, n_feat] (+ depths) */,
+                       int32_t n_feat = 0, int32_t depth_channel = 0, const float* depths = nullptr);
 
 }  // namespace misplat_internal

@@ -1549,7 +1549,10 @@ __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
     const float* __restrict__ Ks, const float* __restrict__ coeffs, const float* __restrict__ coeffs_rest,
     const float* __restrict__ comps, const float* __restrict__ v_grec, float* __restrict__ v_coeffs,
     float* __restrict__ v_coeffs_rest, float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
-    float* __restrict__ v_opacities, float2* __restrict__ v_m2d) {
+    float* __restrict__ v_opacities, float2* __restrict__ v_m2d, const float* __restrict__ v_featx, int nx,
+    float* __restrict__ v_features, int n_feat, int depth_in_featx) {
+    // (N-D records, v_features != NULL: the flagged rows' feature gradients are picked from the record row's slot 15 and the
+    // featx row -- color_copy_x_bwd's job for these rows --, the depth gradient rides behind the last feature in featx)
     __shared__ int queue[128];
     __shared__ int rows[64];
     __shared__ float stage[64 * kShStageStride];
@@ -1567,8 +1570,14 @@ __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
                            stage, rows, dir);
         if (active) {
             pp_bwd_row(P, cam, depth_slot, g, means, quats, scales, opacities, comps, nullptr, v_grec, dir, v_means, v_quats,
-                       v_scales, v_opacities);
+                       v_scales, v_opacities, depth_in_featx ? v_featx + (n_feat - 1) : nullptr, depth_in_featx ? nx : 0);
             if (v_m2d) v_m2d[g] = *reinterpret_cast<const float2*>(v_grec + (size_t)g * MISPLAT_REC);
+            if (v_features) {
+                const float* gx = v_featx + (size_t)g * nx;
+                float* o = v_features + (size_t)g * n_feat;
+                o[0] = v_grec[(size_t)g * MISPLAT_REC + 15];
+                for (int j = 1; j < n_feat; j++) o[j] = gx[j - 1];
+            }
         }
     };
     int qn = 0;
@@ -1822,8 +1831,14 @@ int misplat_internal::gauss_bwd_sparse(const misplat_params* p, int32_t sh_degre
                                        const float* quats, const float* scales, const float* opacities, const float* viewmats,
                                        const float* Ks, const float* coeffs, const float* coeffs_rest, const float* compensations,
                                        const float* v_grec, float* v_coeffs, float* v_coeffs_rest, float* v_means, float* v_quats,
-                                       float* v_scales, float* v_opacities, float* v_means2d_out, hipStream_t s) {
+                                       float* v_scales, float* v_opacities, float* v_means2d_out, hipStream_t s,
+                                       const float* v_featx, int32_t nxq, float* v_features, int32_t n_feat,
+                                       int32_t depth_in_featx) {
     if (!p || p->n_gauss < 1 || p->n_cams != 1 || !p->touched || sh_degree < 0 || sh_degree > 3) return MISPLAT_EINVAL;
+    if (v_features && (!v_featx || nxq < 1 || nxq > 4 || n_feat < 1 || n_feat - 1 + (depth_in_featx ? 1 : 0) > 4 * nxq ||
+                       (depth_in_featx && depth_slot != -1)))
+        return MISPLAT_EINVAL;
+    if (!v_features && depth_in_featx) return MISPLAT_EINVAL;
     if (((uintptr_t)v_means2d_out) & 7) return MISPLAT_EINVAL;
     if (depth_slot != -1 && (depth_slot < 12 || depth_slot > 15)) return MISPLAT_EINVAL;
     if ((coeffs_rest != nullptr) != (v_coeffs_rest != nullptr)) return MISPLAT_EINVAL;
@@ -1840,7 +1855,8 @@ int misplat_internal::gauss_bwd_sparse(const misplat_params* p, int32_t sh_degre
 #define LAUNCH_SPARSE(SPLIT_, FPL_)                                                                                          \
     hipLaunchKernelGGL((gauss_bwd_sparse_kernel<SPLIT_, FPL_>), dim3((unsigned)waves), dim3(64), 0, s, *p, sh_degree, depth_slot, \
                        means, quats, scales, opacities, viewmats, Ks, coeffs, coeffs_rest, compensations, v_grec, v_coeffs,  \
-                       v_coeffs_rest, v_means, v_quats, v_scales, v_opacities, (float2*)v_means2d_out)
+                       v_coeffs_rest, v_means, v_quats, v_scales, v_opacities, (float2*)v_means2d_out, v_featx, 4 * (int)nxq, \
+                       v_features, (int)n_feat, (int)depth_in_featx)
     if (coeffs_rest) { if (fine) LAUNCH_SPARSE(true, 4); else LAUNCH_SPARSE(true, 8); }
     else { if (fine) LAUNCH_SPARSE(false, 4); else LAUNCH_SPARSE(false, 8); }
 #undef LAUNCH_SPARSE

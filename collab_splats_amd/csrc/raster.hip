@@ -65,8 +65,12 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         if (rc != MISPLAT_OK) return rc;
         if (a->nxq > 0) {
             // N-D channels (the features model): SH colours + feature channels written side by side, or pass-through
-            if (a->lazy_colour || !a->featx || a->nxq > 4) return MISPLAT_EINVAL;
-            if (a->sh_degree >= 0) {
+            if ((!a->featx && !a->lazy_colour) || a->nxq > 4) return MISPLAT_EINVAL;
+            if (a->lazy_colour) {
+                // on-demand N-D records: nothing to launch here -- the compositing forward evaluates SH, picks the features and
+                // lays out featx for the records it stages (blend_fwd_x_lazy); SH colours + a feature tensor only
+                if (a->sh_degree < 0 || !a->features || a->n_feat < 1 || a->nxq < 3 || p->n_cams != 1) return MISPLAT_EINVAL;
+            } else if (a->sh_degree >= 0) {
                 if (!a->features || a->n_feat < 1) return MISPLAT_EINVAL;
                 rc = misplat_internal::color_fwd(p, a->sh_degree, a->K_or_D, 3, 0, 0, a->means, a->viewmats, a->colors,
                                                  a->colors_rest, a->radii, a->depths, a->grec, a->sh_aux, a->v_grec_zero,
@@ -129,8 +133,15 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
         q.tile_flag = front ? a->tile_flag : nullptr;
         q.front_pass = 0;
         if (a->ev_blend_begin && hipEventRecord((hipEvent_t)a->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
-        if (a->lazy_colour == 2 && !a->v_grec_zero) return MISPLAT_EINVAL;
+        if (a->lazy_colour == 2 && (!a->v_grec_zero || (a->nxq > 0 && !a->v_featx_zero))) return MISPLAT_EINVAL;
         auto composite = [&]() -> int {
+        if (a->nxq > 0 && a->lazy_colour)
+            return misplat_internal::blend_fwd_x_lazy(&q, a->color_dim, a->nxq, a->Ks, a->grec, a->flatten_ids, a->offsets,
+                                                      a->cap_isects, a->render, a->alpha, a->exp_depth, a->med_depth, a->normal,
+                                                      a->last_ids, a->median_ids, a->means, a->viewmats, a->colors, a->colors_rest,
+                                                      a->sh_degree, a->depth_channel, a->depths, a->features, a->n_feat,
+                                                      a->lazy_colour == 2 ? a->v_grec_zero : nullptr,
+                                                      a->lazy_colour == 2 ? a->v_featx_zero : nullptr, s);
         if (a->nxq > 0)
             return misplat_blend_fwd_x(&q, a->color_dim, a->nxq, a->Ks, a->grec, a->featx, a->flatten_ids, a->offsets,
                                        a->cap_isects, a->render, a->alpha, a->exp_depth, a->med_depth, a->normal, a->last_ids,
@@ -352,8 +363,12 @@ extern "C" int misplat_raster_fwd(const misplat_params* p, const misplat_raster_
 // launcher puts them in front from 2.5 M rows.  Needs the row flags (misplat_params.touched), one camera, 16 SH
 // coefficients without Jacobian cache.
 static bool background_fill_ok(const misplat_params* p, const misplat_raster_bwd_args* b) {
-    if (!(p->touched && p->n_cams == 1 && p->n_gauss >= 262144 && b->sh_degree >= 0 && !b->sh_aux && b->K_or_D == 16 && b->nxq == 0 &&
+    if (!(p->touched && p->n_cams == 1 && p->n_gauss >= 262144 && b->sh_degree >= 0 && !b->sh_aux && b->K_or_D == 16 &&
           !b->v_means2d && (b->colors_rest != nullptr) == (b->v_colors_rest != nullptr)))
+        return false;
+    // N-D records: SH colours + a feature tensor (the features model's call), whose gradient is one more tensor to clear
+    if (b->nxq > 0 && !(b->features && b->v_features && b->v_featx && b->n_feat >= 1 &&
+                        (((uintptr_t)b->v_features | (uintptr_t)b->v_featx) & 15) == 0))
         return false;
     const uintptr_t a16 = (uintptr_t)b->colors | (uintptr_t)b->v_colors | (uintptr_t)b->v_colors_rest | (uintptr_t)b->v_grec |
                           (uintptr_t)b->v_means | (uintptr_t)b->v_quats | (uintptr_t)b->v_scales | (uintptr_t)b->v_opacities |
@@ -382,17 +397,25 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
         add(b->v_scales, n * 3);
         add(b->v_opacities, n);
         if (b->v_means2d_out) add(b->v_means2d_out, n * 2);
+        if (b->nxq > 0) add(b->v_features, n * b->n_feat);
     }
     if (b->nxq > 0) {
         // N-D channels: compositing backward over record + featx rows, then the colour stage's backward, then the projection's
-        if (!b->featx || !b->v_featx || b->nxq > 4) return MISPLAT_EINVAL;
+        if (!b->v_featx || b->nxq > 4 || (!b->featx && !(b->features && b->sh_degree >= 0))) return MISPLAT_EINVAL;
         if (b->ev_blend_begin && hipEventRecord((hipEvent_t)b->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
         int rx = misplat_internal::blend_bwd_x_atomic(&q, b->color_dim, b->nxq, b->Ks, b->grec, b->featx, b->flatten_ids, b->offsets,
                                                       b->n_isects, b->alpha, b->last_ids, b->median_ids, b->render, b->v_render,
                                                       b->v_alpha, b->v_exp_depth, b->v_med_depth, b->v_normal, b->v_grec,
-                                                      b->v_featx, b->v_abs, b->zero_flags, s);
+                                                      b->v_featx, b->v_abs, b->zero_flags, background ? &F : nullptr, s,
+                                                      b->features, b->n_feat, b->depth_channel, b->depths);
         if (rx != MISPLAT_OK) return rx;
         if (b->ev_blend_end && hipEventRecord((hipEvent_t)b->ev_blend_end, s) != hipSuccess) return MISPLAT_ELAUNCH;
+        if (background)    // flagged rows only: SH backward, feature gradients and the projection backward in one launch
+            return misplat_internal::gauss_bwd_sparse(p, b->sh_degree, -1, b->means, b->quats, b->scales, b->opacities, b->viewmats,
+                                                      b->Ks, b->colors, b->colors_rest, b->compensations, b->v_grec, b->v_colors,
+                                                      b->v_colors_rest, b->v_means, b->v_quats, b->v_scales, b->v_opacities,
+                                                      b->v_means2d_out, s, b->v_featx, b->nxq, b->v_features, b->n_feat,
+                                                      b->depth_channel ? 1 : 0);
         const int n_pre = b->sh_degree >= 0 ? 3 : 0, d_src = b->sh_degree >= 0 ? b->n_feat : b->K_or_D;
         if (b->sh_degree >= 0) {
             if (!b->v_features || !b->v_means_dir) return MISPLAT_EINVAL;

@@ -707,6 +707,7 @@ def _cap_key(P: Params, dev: torch.device):
 SPARSE_BWD_MIN_ROWS = 262144        # raster.hip: background_fill_ok
 ROWS_ON_TOUCH = os.environ.get("MISPLAT_ROWS_ON_TOUCH", "1") != "0"
 LAZY_SH = os.environ.get("MISPLAT_LAZY_SH", "auto")
+LAZY_ND = os.environ.get("MISPLAT_LAZY_ND", "1")                       # on-demand N-D records (features model) where LAZY_SH allows
 LAZY_SH_MIN_BUCKET = int(os.environ.get("MISPLAT_LAZY_SH_MIN_BUCKET", "450"))   # measured crossover at 1080p: 391 even, 549 ahead
 # Front-only ordering (csrc/binning.hip, tile_sort_front_kernel): in a dense scene the compositing stops long before the end of
 # a tile's list, so only the part of every bucket in front of the depth the view's LAST visit reached (x a margin; the
@@ -721,8 +722,14 @@ FRONT_MIN_BUCKET = int(os.environ.get("MISPLAT_FRONT_MIN_BUCKET", "256"))
 FRONT_MARGIN = float(os.environ.get("MISPLAT_FRONT_MARGIN", "1.05"))
 
 
-def _lazy_colour_ok(P: Params, dev, deg: int, kd: int, n_color: int, want_grad: bool, cd: int) -> bool:
-    if LAZY_SH == "0" or deg < 0 or kd != 16 or n_color != 3 or not want_grad or cd not in (3, 4):
+def _lazy_colour_ok(P: Params, dev, deg: int, kd: int, n_color: int, want_grad: bool, cd: int, nxq: int = 0,
+                    features=None) -> bool:
+    if LAZY_SH == "0" or deg < 0 or kd != 16 or n_color != 3 or not want_grad:
+        return False
+    if nxq == 0 and cd not in (3, 4):
+        return False
+    # N-D records on demand (the features model's call: SH colours + a feature tensor, D' = 16 / 17, one camera)
+    if nxq > 0 and (LAZY_ND == "0" or features is None or nxq not in (3, 4) or P.n_cams != 1):
         return False
     if LAZY_SH == "1":
         return True
@@ -764,7 +771,8 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     v_grec_zero = cv.take(MISPLAT_REC * rows, torch.float32).view(rows, MISPLAT_REC) if want_grad else None
     v_abs_zero = cv.take(2 * rows, torch.float32).view(rows, 2) if (want_grad and absgrad) else None
     # N-D colours (the features model, nxq > 0): channels 4.. of every row, and their gradient rows
-    featx = cv.take(4 * nxq * rows, torch.float32).view(rows, 4 * nxq) if nxq > 0 else None
+    # (on-demand N-D records: no featx -- the compositing kernels read the feature rows themselves)
+    featx = cv.take(4 * nxq * rows, torch.float32).view(rows, 4 * nxq) if (nxq > 0 and not lazy) else None
     v_featx_zero = cv.take(4 * nxq * rows, torch.float32).view(rows, 4 * nxq) if (nxq > 0 and want_grad) else None
     # (cell_count, cell_cursor, counters, tile_count back to back: the projection kernel clears that contiguous range -- no
     # memset, no clearing launch)
@@ -923,7 +931,9 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         PATH_STATS["forward_arena_slot"] += int(cv.slot is not None)
     bins = dict(tiles_per_gauss=state["tiles_per_gauss"], n_isects=cap if static else n_known, depths=state["depths"],
                 tile_ids=None, v_grec_zero=state.get("v_grec_zero"), v_abs_zero=state.get("v_abs_zero"),
-                featx=state.get("featx"), v_featx_zero=state.get("v_featx_zero"),
+                featx=state.get("featx"),
+                # (on-demand N-D records without rows-on-touch: nobody has cleared the featx gradient rows -- the backward does)
+                v_featx_zero=(state.get("v_featx_zero") if (a.lazy_colour != 1 or a.nxq == 0) else None),
                 rows_on_touch=bool(state.get("rows_on_touch")), n_isects_dev=state["counters"].view(torch.int64)[0] if static else None,
                 n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:cap if static else n_known],
                 isect_offsets=offsets[:n_tiles + 1], _keep=(scratch, payload, reach),
@@ -970,7 +980,7 @@ class _RasterFused(torch.autograd.Function):
         want_grad = any(ctx.needs_input_grad[:7])
         # N-D colours in one pass (a8, rade_features_model.py:427-476): cd = D' composited channels, 4 in the record + 4 nxq
         nxq = (cd - 4 + 3) // 4 if cd > 4 else 0
-        lazy = nxq == 0 and _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd)
+        lazy = _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd, nxq, features)
         want_aux = SH_AUX and deg >= 0 and want_grad and not lazy
         if (PROBE_FIRST and MERGE_PHASES and SPECULATE and _STATIC_CAP is None and _cap_key(P, means.device) not in _CAP_HINT
                 and not torch.cuda.is_current_stream_capturing()):
@@ -983,7 +993,7 @@ class _RasterFused(torch.autograd.Function):
             _CAP_HINT[_cap_key(P, means.device)] = max(_wait_count(st["host"]), 1)
             del st
             PATH_STATS["forward_probe"] += 1
-            lazy = nxq == 0 and _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd)
+            lazy = _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd, nxq, features)
             want_aux = SH_AUX and deg >= 0 and want_grad and not lazy
         defer = _STATIC_CAP is not None or (MERGE_PHASES and SPECULATE and _cap_key(P, means.device) in _CAP_HINT)
         PATH_STATS["forward"] += 1
@@ -1084,6 +1094,7 @@ class _RasterFused(torch.autograd.Function):
             b.v_means, b.v_quats, b.v_scales, b.v_opacities = _dp(v_means), _dp(v_quats), _dp(v_scales), _dp(v_opac)
             if nxq > 0:
                 b.nxq, b.featx, b.v_featx, b.depth_channel = nxq, _dp(bins["featx"]), _dp(v_featx), int(nd_depth)
+                b.depths = _dp(bins["depths"]) if bins["featx"] is None else None
                 b.features, b.v_features, b.n_feat = _dp(features), _dp(v_features), (features.shape[-1] if features is not None else 0)
                 b.zero_flags = flags
             if KERNEL_EVENTS is not None:                             # a measurement pass: events around the compositing backward
@@ -1099,7 +1110,7 @@ class _RasterFused(torch.autograd.Function):
             if not sparse:
                 v_m2d, b.v_means2d_out = None, None
             if on_touch and not sparse:                               # every row is going to be read: clear them all first
-                b.zero_flags = flags & ~1
+                b.zero_flags = flags & ~1 & (~4 if nxq > 0 else ~0)
                 PATH_STATS["backward_rows_refilled"] += 1
             with _timed("raster_bwd"):
                 if KEY_TRACE is not None:

@@ -559,6 +559,9 @@ typedef struct misplat_raster_bwd_args {
     const float *featx, *features;
     float *v_featx, *v_features;
     int32_t n_feat, nxq, depth_channel, reserved_x;
+    /* featx == NULL (the forward ran with on-demand N-D records, misplat_raster_args.lazy_colour with nxq > 0: it wrote no
+     * featx): channels 4.. are read from features [N,n_feat] and the depth channel from depths [C*N] */
+    const float* depths;
 } misplat_raster_bwd_args;
 int misplat_raster_bwd(const misplat_params* p, const misplat_raster_bwd_args* b, misplat_stream_t stream,
                        misplat_graph_cache* cache /* or NULL */);

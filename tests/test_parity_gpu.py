@@ -289,18 +289,25 @@ def _feature_case(dev, craster, D, rm):
     assert len(r3) == 3 and r3[0].shape == (1, H, W, 3)
 
 
-@pytest.mark.parametrize("rm,split", [("RGB+ED", False), ("RGB", True)])
-def test_features_model_call_as_one_entry_steady_state_vs_c_port(dev, craster, rm, split):
+@pytest.mark.parametrize("rm,split,N,W,H,lazy", [("RGB+ED", False, 30_000, 320, 192, "auto"), ("RGB", True, 30_000, 320, 192, "auto"),
+                                                 ("RGB+ED", True, 30_000, 320, 192, "1"), ("RGB+ED", False, 300_000, 640, 360, "1"),
+                                                 ("RGB", True, 300_000, 640, 360, "1")])
+def test_features_model_call_as_one_entry_steady_state_vs_c_port(dev, craster, monkeypatch, rm, split, N, W, H, lazy):
     """rade_features_model.py:427-476 as ONE product entry: ``rasterization(colors=SH coefficients, features=[N,13], sh_degree=3)``
     renders 16 (RGB) / 17 (RGB+ED) channels -- channels 0..2 = max(SH + 0.5, 0), channels 3..15 the features, no [N,16]
     concatenation, one autograd node, the one-entry forward / backward with graph replay and the view's launch order.  Steady
     state (the EIGHTH call on one set of leaves) against the C port fed what the reference would feed gsplat --
     ``cat(clamp_min(SH(dirs) + 0.5, 0), features)`` with ``sh_degree=None`` --, gradients chained back to the coefficients,
-    the features and (through the view direction) the means with the fp64 torch oracle's SH."""
+    the features and (through the view direction) the means with the fp64 torch oracle's SH.
+    ``lazy`` = "1": the records ON DEMAND -- no colour kernel and no feature copy; the compositing forward evaluates SH, picks
+    feature 0 and lays features 1.. (+ depth) into the featx row of the records it stages; from 262 144 Gaussians on also the
+    gradient rows cleared on touch, the zeros of the untouched rows written in the background of the compositing backward and
+    ONE kernel for the SH / feature / projection backward of the flagged rows."""
     from collab_splats_amd import ops, rasterization
     from collab_splats_amd.synthetic import random_scene
     from oracle.torch_oracle import eval_sh
-    W, H, N, F = 320, 192, 30_000, 13
+    monkeypatch.setattr(ops, "LAZY_SH", lazy)
+    F = 13
     sc = random_scene(N, W, H, seed=17)
     g = torch.Generator().manual_seed(5)
     feats = torch.rand(N, F, generator=g)
@@ -333,6 +340,9 @@ def test_features_model_call_as_one_entry_steady_state_vs_c_port(dev, craster, r
     torch.cuda.synchronize()
     took = {k: ops.PATH_STATS[k] - before.get(k, 0) for k in ops.PATH_STATS}
     assert took.get("forward_nd") == 8 and took.get("backward_one_call") == 8 and took.get("forward_merged_phases") == 8 and took.get("forward_probe") == 1, took
+    assert took.get("forward_lazy_colour", 0) == (8 if lazy == "1" else 0), took
+    dense = lazy == "1" and N >= 262_144
+    assert took.get("forward_rows_on_touch", 0) == (8 if dense else 0) and took.get("backward_background_fill", 0) == (8 if dense else 0), took
     assert took.get("forward_view_order") == 8 and ops.graph_cache_stats(dev)["hits"] >= 2
     assert out[0].shape == (1, H, W, Dp)
     # ---- what the reference feeds gsplat: colours evaluated on the host in fp32 exactly as the kernels do is not available
