@@ -49,8 +49,12 @@ class Slot:
         self.raw = torch.empty(self.size + ALIGN_SLOT, device=dev, dtype=torch.uint8)
         shift = (-self.raw.data_ptr()) % ALIGN_SLOT
         self.base = self.raw[shift:shift + self.size]
+        # one typed view of the whole slot per element size: an array is then ONE slice (host time: ~60 arrays per step)
+        self.typed = {torch.uint8: self.base, torch.float32: self.base.view(torch.float32), torch.int32: self.base.view(torch.int32),
+                      torch.int64: self.base.view(torch.int64), torch.float64: self.base.view(torch.float64),
+                      torch.int16: self.base.view(torch.int16)}
         self.storage = self.raw.untyped_storage()                 # (kept: the use count below then has a fixed floor)
-        self.floor = self._count()                                # raw + base + the storage wrapper
+        self.floor = self._count()                                # raw + base + the typed views + the storage wrapper
         self.off = 0
         self.demand = 0
 
@@ -66,7 +70,8 @@ class Slot:
 
     def take(self, count: int, dtype: torch.dtype) -> Optional[Tensor]:
         """``count`` elements of ``dtype`` from the slot, or None when it is full (the caller then asks the allocator)."""
-        nbytes = int(count) * _ESIZE[dtype]
+        esize = _ESIZE[dtype]
+        nbytes = int(count) * esize
         align = ALIGN_BIG if nbytes >= BIG else ALIGN_SMALL
         start = (self.off + align - 1) // align * align
         self.demand = start + nbytes                                        # (what a slot must hold to serve this call)
@@ -74,7 +79,8 @@ class Slot:
             self.off = start + nbytes                                       # keep counting: the demand of the whole call
             return None
         self.off = start + nbytes
-        return self.base[start:start + nbytes].view(dtype)
+        first = start // esize                                              # (align is a multiple of every element size)
+        return self.typed[dtype][first:first + int(count)]
 
 
 class Ring:

@@ -73,6 +73,8 @@ small)
 features)
   python3 bench.py --features 13 --fixed-view --no-cpu-baseline > $OUT/bench_features.json 2> $OUT/bench_features.err
   timeline 1M_features_fixed --features 13 --fixed-view
+  MISPLAT_LAZY_ND=0 python3 bench.py --features 13 --fixed-view --no-cpu-baseline --no-variants > $OUT/bench_features_dense.json 2> /dev/null
+  MISPLAT_LAZY_ND=0 timeline 1M_features_fixed_dense --features 13 --fixed-view
   say "features: $(python3 -c "import json; d=json.load(open('$OUT/bench_features.json')); print(d['ms_per_step'], {k: v['ms_per_step'] for k, v in d['variants'].items()})" 2>&1)";;
 esac; done
 cat $OUT/progress.txt

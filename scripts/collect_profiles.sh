@@ -16,6 +16,8 @@ for t in 1M_fixed_ext 1M_cycling_torch 5M_dnloss_fixed 5M_dnloss_cycling 5M_dnlo
 for b in bench_1M_dnloss bench_1M_dnloss_fixed bench_5M_dnloss bench_5M_dnloss_fixed bench_5M_dnloss_fixed_full_sort bench_5M_dnloss_fixed_buckets \
          bench_5M_dnloss_fixed_buckets_sparse_rehearsal bench_100k bench_10k bench_10k_graphed bench_features; do [ -s $B/$b.json ] && cp $B/$b.json $P/${R}_$b.json; done
 cp $B/timeline_1M_features_fixed.txt $P/${R}_timeline_1M_features_fixed.txt
+cp $B/timeline_1M_features_fixed_dense.txt $P/${R}_timeline_1M_features_fixed_dense.txt
+cp $B/bench_features_dense.json $P/${R}_bench_features_dense.json
 # instruction-class tables of the compositing kernels' trip loops and the class-weighted issue budget (hipcc -S of the current source)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -fno-fast-math -S --cuda-device-only -o /tmp/blend_isa.s collab_splats_amd/csrc/blend.hip 2>/dev/null
 python scripts/isa_table.py /tmp/blend_isa.s 'blend_bwd_kernelILi4ELi2ELb0ELb1ELi0E' --dump > $P/${R}_isa_blend_bwd.txt
