@@ -1467,6 +1467,18 @@ def test_whole_step_graph_replays_equal_eager_steps(dev, monkeypatch, lazy):
             assert torch.equal(a, b), rep
         for a, k in zip(static_grads, names):
             assert rel_err(a, ref[k].grad) < 1e-5, (rep, k)
+    # The launch-order feedback survives the capture: the captured step uses the warm-up stream's table (no zero-fill node
+    # inside the graph that would wipe it on every replay), the projection kernel FOUND the record of this camera in the last
+    # replay (selector word 1) and the record carries the camera's tag and a valid permutation.
+    assert ops.PATH_STATS["capture_reused_order_table"] >= 1
+    found = False
+    for key, (table, sel, stride) in ops._ORDER_TABLES.items():
+        if key[2:5] != (1, (W + 15) // 16, (H + 15) // 16):
+            continue
+        sel_h, head = sel.cpu(), table.view(-1, stride)[:, :3].cpu()
+        hit = (head[:, 2] != 0) & ((head[:, 0] != 0) | (head[:, 1] != 0))
+        found |= bool(sel_h[1] == 1) and bool(hit[int(sel_h[0])]) and (int(head[int(sel_h[0]), 0]), int(head[int(sel_h[0]), 1])) == (int(sel_h[2]), int(sel_h[3]))
+    assert found
 
 
 @pytest.mark.parametrize("N,W,H,scale_mul", [(30_000, 640, 360, 1.0), (5_000, 333, 197, 1.0), (60_000, 320, 200, 2.0)])
