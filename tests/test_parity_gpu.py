@@ -774,6 +774,46 @@ def test_features_model_mirror_outputs(dev):
         assert p.grad is not None and torch.isfinite(p.grad).all() and (k != "distill_features" or p.grad.abs().sum() > 0), k
 
 
+def test_features_model_mirror_dense_scene_records_on_demand_equal_the_dense_stages(dev, monkeypatch):
+    """``RadegsFeaturesModel`` on a dense scene (300 k Gaussians: the training path takes the N-D records ON DEMAND -- no colour
+    kernel, no feature copy, rows cleared on touch, flagged-row backward; activations inside the kernels): the outputs are
+    bit for bit those of the dense colour stages (``MISPLAT_LAZY_ND=0``) and the gradients of all seven parameter groups agree to
+    the order of the atomic sums, steady state (third step of each)."""
+    from collab_splats_amd import ops, radegs
+    from collab_splats_amd.synthetic import random_scene
+    W, H, N = 640, 360, 300_000
+    sc = random_scene(N, W, H, seed=12)
+    feats = torch.rand(N, 13, generator=torch.Generator().manual_seed(4))
+    c2w = torch.tensor([[1.0, 0, 0, 0], [0, -1.0, 0, 0], [0, 0, -1.0, 0]])
+    cam = radegs.PinholeCamera.make(c2w, 0.9 * W, 0.9 * W, W, H)
+    args = (sc["means"], sc["log_scales"], sc["quats"], sc["opacity_logits"], sc["sh"][:, 0], sc["sh"][:, 1:])
+    kw = dict(rasterize_mode="antialiased", regularization_from_iter=0, output_depth_during_training=True)
+    gt = {"image": torch.rand(H, W, 3, generator=torch.Generator().manual_seed(6))}
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setattr(ops, "LAZY_ND", mode)
+        monkeypatch.setattr(ops, "LAZY_SH", "1")
+        m = radegs.RadegsFeaturesModel(radegs.RadegsFeaturesModelConfig(**kw), *args, feats).to(dev)
+        m.train()
+        m.step = 5000
+        before = dict(ops.PATH_STATS)
+        for it in range(3):
+            for p in m.gauss_params.values():
+                p.grad = None
+            out = m.get_outputs(cam)
+            loss = m.get_loss_dict(out, gt)
+            (sum(loss.values()) + out["features"].square().mean()).backward()
+        took = {k: ops.PATH_STATS[k] - before.get(k, 0) for k in ops.PATH_STATS}
+        assert took.get("forward_nd") == 3 and took.get("forward_lazy_colour", 0) == (3 if mode == "1" else 0), took
+        assert took.get("backward_background_fill", 0) == (3 if mode == "1" else 0), took
+        res[mode] = ({k: out[k].detach().clone() for k in ("rgb", "features", "depth", "accumulation", "normals")},
+                     {k: p.grad.clone() for k, p in m.gauss_params.items()})
+    for k, v in res["1"][0].items():
+        assert torch.equal(v, res["0"][0][k]), k
+    for k, g in res["1"][1].items():
+        assert torch.isfinite(g).all() and rel_err(g, res["0"][1][k]) < 2e-5, (k, rel_err(g, res["0"][1][k]))
+
+
 def test_crop_box_renders_exactly_the_cropped_subset(dev):
     """rade_gs_model.py:96-119 (evaluation only): a crop box selects Gaussians by ``within(means)``; the outputs are those
     of a model that holds only the selected ones, and an empty crop returns ``get_empty_outputs``."""
