@@ -638,6 +638,16 @@ def _wait_count(host: Tensor) -> int:
     return n
 
 
+def _choose_cap(key: tuple, hint: int) -> int:
+    """The intersection capacity of a speculative forward of this shape: CAP_FIRST_MARGIN x the running count when it is
+    chosen, then KEPT -- until the count comes within CAP_MARGIN of it (chosen again, as generously) or has fallen to an
+    eighth of it (given back)."""
+    cap = _CAP_CHOSEN.get(key)
+    if cap is None or int(hint * CAP_MARGIN) > cap or 4 * _quantise_cap(int(hint * CAP_FIRST_MARGIN)) < cap:
+        cap = _CAP_CHOSEN[key] = min(_quantise_cap(int(hint * CAP_FIRST_MARGIN)), 2 ** 31 - 1)
+    return cap
+
+
 def _quantise_cap(x: int) -> int:
     """Round a capacity up to 8 steps per octave: the speculative buffers (and with them the pointers the allocator
     hands out and the graph-cache key) then stay the same while the count moves by a few percent from step to step."""
@@ -846,9 +856,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         n_known = _wait_count(state["host"])
         cap = max(n_known, 1)
     else:
-        cap = _CAP_CHOSEN.get(key)
-        if cap is None or int(hint * CAP_MARGIN) > cap or 4 * _quantise_cap(int(hint * CAP_FIRST_MARGIN)) < cap:
-            cap = _CAP_CHOSEN[key] = min(_quantise_cap(int(hint * CAP_FIRST_MARGIN)), 2 ** 31 - 1)
+        cap = _choose_cap(key, hint)
         # (the estimate that picks the sort's size classes is tied to the capacity, not to the running count: the count moves
         # every step, and the argument block is the graph key)
         a.est_isects = int(cap / CAP_FIRST_MARGIN)

@@ -460,3 +460,47 @@ def test_resolution_schedule_rescales_the_camera_and_restores_it_even_on_error(m
         m.get_outputs(cam)
     assert seen == dict(W=160, H=90, fx=125.0, cx=80.0)                   # the call saw the camera at 1/4 resolution
     assert (int(cam.width.item()), int(cam.height.item()), cam.fx, cam.fy, cam.cx, cam.cy) == (640, 360, 500.0, 480.0, 320.0, 180.0)
+
+
+def test_capacity_of_the_speculative_forward_stays_put(monkeypatch):
+    """ops._choose_cap: a capacity is part of every phase-B argument block (the graph key) and places the per-tile lists inside
+    the arena slot, so it is chosen generously once and kept while the count of the views moves by tens of percent; it is chosen
+    again when the count comes within 10 % of it, and given back when the scene has shrunk to an eighth."""
+    from collab_splats_amd import ops
+    monkeypatch.setattr(ops, "_CAP_CHOSEN", {})
+    key = ("cap-test",)
+    first = ops._choose_cap(key, 4_000_000)
+    assert first >= 8_000_000 and first == ops._quantise_cap(8_000_000)
+    for hint in (3_800_000, 5_400_000, 6_404_069, 7_000_000):            # the bench's eight views: 3.8 - 6.4 M
+        assert ops._choose_cap(key, hint) == first
+    grown = ops._choose_cap(key, 7_700_000)                                # within 10 %: chosen again, twice the count
+    assert grown > first and grown >= 15_000_000
+    assert ops._choose_cap(key, 7_800_000) == grown
+    assert ops._choose_cap(key, 2_000_000) == grown                        # a quarter of it: kept
+    small = ops._choose_cap(key, 900_000)                                  # an eighth: given back
+    assert small < grown and small >= 1_800_000
+    assert ops._choose_cap(("other",), 2 ** 31) == 2 ** 31 - 1             # (int32 indexing: the check of the count itself is elsewhere)
+
+
+def test_key_trace_report_names_the_fields_that_moved(monkeypatch):
+    """ops.key_trace_report (MISPLAT_KEY_TRACE): which fields of the argument blocks -- the graph cache's keys -- differ between
+    a call and the one ``period`` calls earlier."""
+    import ctypes as C
+    from collab_splats_amd import _lib, ops
+    P = _lib.make_params(1000, 1, 64, 48)
+    a0, a1 = _lib.RasterArgs(), _lib.RasterArgs()
+    a0.means, a1.means = 0x1000, 0x1000
+    a0.opacities, a1.opacities = 0x2000, 0x2400
+    a0.cap_isects, a1.cap_isects = 4096, 8192
+    b0 = _lib.RasterBwdArgs()
+    monkeypatch.setattr(ops, "KEY_TRACE", [("fwd3", bytes(P) + bytes(a0)), ("bwd", bytes(P) + bytes(b0)),
+                                           ("fwd3", bytes(P) + bytes(a1)), ("bwd", bytes(P) + bytes(b0)),
+                                           ("fwd2", bytes(P) + bytes(a1))])
+    rep = ops.key_trace_report(2)
+    assert rep[0][0] == 2 and rep[0][1] == "fwd3" and set(rep[0][2]) == {"opacities", "cap_isects"}
+    assert rep[1] == (4, "entry", "fwd3", "fwd2") and len(rep) == 2          # (call 3 equals call 1: not reported)
+
+
+def test_row_capacity_of_the_sparse_reduce():
+    from collab_splats_amd import parallel
+    assert parallel._row_capacity(0) == 1024 and parallel._row_capacity(100_000) == 150_000
