@@ -290,7 +290,7 @@ def parity(args, params, viewmats, Ks, W, H, ext, ups_dev, st, gr, act, what: st
 
 def copy_roof(dev):
     """GB/s of a float4 streaming copy (read + write bytes) on this box, 512 MiB buffers: best of 5 for each kernel variant
-    (plain / non-temporal / four loads in flight); returns (best, per-variant list)."""
+    (plain / non-temporal / four loads in flight / the same with one contiguous piece per workgroup); returns (best, per-variant list)."""
     import ctypes as C
     from collab_splats_amd import _lib
     lib = _lib.load()
@@ -298,7 +298,7 @@ def copy_roof(dev):
     src = torch.empty(n4 * 4, device=dev, dtype=torch.float32).normal_()
     dst = torch.empty_like(src)
     per = []
-    for variant in range(3):
+    for variant in range(4):
         best = 0.0
         for i in range(7):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -619,7 +619,7 @@ int misplat_debug_memset_replay(void* counters16, void* add8, int32_t n_replays,
 
 /* Measurement helper: dst[i] = src[i] over n_float4 16-byte elements (a plain streaming copy; bench.py times it to
  * report the HBM roof of the box it runs on).  variant: 0 plain, 1 non-temporal loads / stores, 2 four loads in flight
- * per lane + non-temporal stores. */
+ * per lane + non-temporal stores, 3 the same with one contiguous piece per workgroup. */
 int misplat_stream_copy(const void* src, void* dst, int64_t n_float4, int32_t variant, misplat_stream_t stream);
 
 /* Library identification ("misplat <version> gfx950"). */
