@@ -1793,6 +1793,57 @@ def test_large_scene_entirely_out_of_view_gives_zero_gradients(dev):
         assert float(out[5]["means2d"].absgrad.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("F,rm", [(12, "RGB+ED"), (13, "RGB+ED"), (9, "RGB")])
+def test_feature_records_on_demand_other_widths_and_an_empty_view(dev, monkeypatch, F, rm):
+    """N-D records on demand beside the features model's own 13 channels: F = 12 with a depth channel (D' = 16, three quads,
+    none of them padded), F = 9 (D' = 12: two quads -- not an on-demand width, the dense stages must serve it), and a scene
+    that is entirely out of view (no intersection: the zeros of every gradient, v_features included, come from plain fills)."""
+    from collab_splats_amd import ops, rasterization
+    from collab_splats_amd.synthetic import random_scene
+    N, W, H = 300_000, 480, 270
+    sc = random_scene(N, W, H, seed=23)
+    feats = torch.rand(N, F, generator=torch.Generator().manual_seed(9))
+    V, K = sc["viewmats"].to(dev), sc["Ks"].to(dev)
+    Dp = 3 + F + (1 if rm == "RGB+ED" else 0)
+    ups = [u.to(dev) for u in upstream([(1, H, W, Dp), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3)], dtype=torch.float32)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setattr(ops, "LAZY_ND", mode)
+        monkeypatch.setattr(ops, "LAZY_SH", "1")
+        leaves = [sc[k].to(dev).requires_grad_(True) for k in ("means", "quats", "log_scales", "opacity_logits", "sh")]
+        f_leaf = feats.to(dev).requires_grad_(True)
+        before = dict(ops.PATH_STATS)
+        for it in range(3):
+            for l in leaves + [f_leaf]:
+                l.grad = None
+            out = rasterization(*leaves, V, K, W, H, sh_degree=3, render_mode=rm, rasterize_mode="antialiased", features=f_leaf,
+                                return_depth_normal=True, scales_are_log=True, opacities_are_logit=True)
+            torch.autograd.backward(list(out[:5]), ups)
+        took = {k: ops.PATH_STATS[k] - before.get(k, 0) for k in ops.PATH_STATS}
+        on_demand = mode == "1" and (Dp - 4 + 3) // 4 in (3, 4)
+        assert took.get("forward_nd") == 3 and took.get("forward_lazy_colour", 0) == (3 if on_demand else 0), took
+        res[mode] = ([t.detach().clone() for t in out[:5]], [l.grad.clone() for l in leaves + [f_leaf]])
+    for a, b in zip(res["1"][0], res["0"][0]):
+        assert torch.equal(a, b)
+    for a, b in zip(res["1"][1], res["0"][1]):
+        assert torch.isfinite(a).all() and rel_err(a, b) < 2e-5
+    # nothing in view: every gradient exactly zero (the allocator is seeded with NaNs first)
+    monkeypatch.setattr(ops, "LAZY_ND", "1")
+    Vb = V.clone()
+    Vb[:, 2, 3] -= 1.0e4
+    for rep in range(2):
+        poison = [torch.full((N * 48 + 64 * k,), float("nan"), device=dev) for k in range(4)]
+        del poison
+        leaves = [sc[k].to(dev).requires_grad_(True) for k in ("means", "quats", "log_scales", "opacity_logits", "sh")]
+        f_leaf = feats.to(dev).requires_grad_(True)
+        out = rasterization(*leaves, Vb, K, W, H, sh_degree=3, render_mode=rm, rasterize_mode="antialiased", features=f_leaf,
+                            return_depth_normal=True, scales_are_log=True, opacities_are_logit=True)
+        assert int(out[5]["n_isects"]) == 0 and float(out[0].detach().abs().sum()) == 0.0
+        torch.autograd.backward(list(out[:5]), ups)
+        for l in leaves + [f_leaf]:
+            assert l.grad is not None and float(l.grad.abs().sum()) == 0.0
+
+
 def test_two_node_form_backpropagates_a_loss_on_projection_outputs(dev, monkeypatch):
     """MISPLAT_FUSED_NODE=0: the projection's own outputs in ``meta`` are differentiable, and a loss on them reaches the
     projection backward WITHOUT passing the compositing kernels -- the `touched` row flags (set by the compositing
