@@ -25,6 +25,9 @@ from torch import Tensor
 ENABLED = os.environ.get("MISPLAT_ARENA", "1") == "1"
 MAX_SLOTS = int(os.environ.get("MISPLAT_ARENA_SLOTS", "4"))
 MAX_RINGS = int(os.environ.get("MISPLAT_ARENA_RINGS", "12"))      # distinct (stream, shape, role) keys kept; LRU beyond
+# A ring nobody has asked for in this many lookups is dropped: densification changes the number of Gaussians every few hundred
+# steps and never comes back to the old one (scripts/soak.py: +0.7 GB of reserved memory per change at 1 M without this).
+IDLE_LOOKUPS = int(os.environ.get("MISPLAT_ARENA_IDLE", "64"))
 # Placement inside a slot.  Measured (5 M Gaussians / 1080p, one box): with every array of >= 1 MiB on a 2 MiB boundary
 # the kernels that write several arrays at the same element offset (bucket_rows: order / rect_sorted / depth_sorted at
 # [pos]) ran 2 x slower (74 -> 182 us; their streams then map to the same memory channels) and the step lost 0.1 ms; the
@@ -88,6 +91,7 @@ class Ring:
         self.dev = dev
         self.slots: List[Slot] = []
         self.want = 0                                             # bytes the largest call so far asked for
+        self.last_lookup = 0
 
     def acquire(self) -> Optional[Slot]:
         """A slot nothing refers to (regrown first if the last call did not fit), a new one, or None."""
@@ -119,6 +123,7 @@ class Ring:
 
 
 _RINGS: "collections.OrderedDict[tuple, Ring]" = collections.OrderedDict()
+_LOOKUPS = 0
 
 
 def ring(key: tuple, dev: torch.device) -> Optional[Ring]:
@@ -126,6 +131,8 @@ def ring(key: tuple, dev: torch.device) -> Optional[Ring]:
     allocated during a capture belongs to that graph's private pool and must not outlive it in a ring)."""
     if not ENABLED or _use_count is None or torch.cuda.is_current_stream_capturing():
         return None
+    global _LOOKUPS
+    _LOOKUPS += 1
     r = _RINGS.get(key)
     if r is None:
         r = _RINGS[key] = Ring(dev)
@@ -133,6 +140,14 @@ def ring(key: tuple, dev: torch.device) -> Optional[Ring]:
             _RINGS.popitem(last=False)                            # (its slots live on while views of them do)
     else:
         _RINGS.move_to_end(key)
+    r.last_lookup = _LOOKUPS
+    if IDLE_LOOKUPS > 0:                                          # (oldest first: the dict is in LRU order)
+        while len(_RINGS) > 1:
+            k0 = next(iter(_RINGS))
+            if _LOOKUPS - _RINGS[k0].last_lookup <= IDLE_LOOKUPS:
+                break
+            del _RINGS[k0]
+            STATS["rings_dropped_idle"] += 1
     return r
 
 

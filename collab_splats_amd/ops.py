@@ -943,7 +943,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
                 # (on-demand N-D records without rows-on-touch: nobody has cleared the featx gradient rows -- the backward does)
                 v_featx_zero=(state.get("v_featx_zero") if (a.lazy_colour != 1 or a.nxq == 0) else None),
                 rows_on_touch=bool(state.get("rows_on_touch")), n_isects_dev=state["counters"].view(torch.int64)[0] if static else None,
-                n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:cap if static else n_known],
+                n_tiles=n_tiles, slots=None, flatten_ids=flatten_ids[:cap if static else n_known], cap_isects=int(cap),
                 isect_offsets=offsets[:n_tiles + 1], _keep=(scratch, payload, reach),
                 # one byte per row, set by the atomic compositing backward for the rows it adds a gradient to
                 touched=(state["touched"].view(torch.uint8)[:P.n_gauss * Cn] if P.touched else None),
@@ -1086,7 +1086,9 @@ class _RasterFused(torch.autograd.Function):
         if simple:
             b = RasterBwdArgs()
             b.Ks, b.grec, b.flatten_ids, b.offsets = _dp(Ks), _dp(grec), _dp(bins["flatten_ids"]), _dp(bins["isect_offsets"])
-            b.n_isects = bins["n_isects"]
+            # (the CAPACITY of the lists, not this call's count: the kernels take every range from `offsets`, and the count of
+            # a scene that is being trained changes with every step -- it must not be part of the graph key)
+            b.n_isects = bins.get("cap_isects") or bins["n_isects"]
             b.alpha, b.last_ids, b.median_ids, b.render = _dp(alpha), _dp(last_ids), _dp(median_ids), _dp(render)
             b.v_render, b.v_alpha, b.v_exp_depth, b.v_med_depth, b.v_normal = [_dp(t) for t in ups]
             b.v_grec, b.v_abs, b.unit_perm = _dp(v_grec), _dp(v_abs), _dp(perm)

@@ -525,7 +525,9 @@ typedef struct misplat_raster_bwd_args {
     /* compositing backward: saved by the forward */
     const float *Ks, *grec;
     const int32_t *flatten_ids, *offsets;
-    int64_t n_isects;
+    int64_t n_isects;   /* the number of list entries, or any upper bound inside flatten_ids' buffer (the forward's capacity):
+                           every range comes from `offsets`, this only clamps them -- a caller that replays graphs passes the
+                           capacity, because the exact count of a scene in training changes with every step */
     const float* alpha;
     const int32_t *last_ids, *median_ids;
     const float* render;

@@ -2151,6 +2151,61 @@ def test_front_only_ordering_is_exact_and_flags_the_tiles_it_cut_too_short(dev, 
         assert_close_flips(leaf.grad, gr[name], name, proof=proof)
 
 
+def test_graphs_replay_while_the_scene_is_being_trained(dev):
+    """What a graph key may depend on: a training loop updates its parameters IN PLACE every step, so the intersection count of
+    a view changes from visit to visit -- and so did, until round 4, the backward's argument block (it carried this call's
+    exact count), which therefore never replayed outside a benchmark with frozen parameters.  The backward is keyed on the
+    forward's CAPACITY now (every list range comes from ``offsets``).  Eight cycling views, parameters moved a little after
+    every step: from the fourth round on every forward and every backward is a replay, nothing is captured any more, and the
+    gradients are those of a cold call on the same values."""
+    from collab_splats_amd import ops, rasterization
+    from collab_splats_amd.synthetic import random_scene, view_matrix
+    N, W, H = 60_000, 640, 360
+    sc = random_scene(N, W, H, seed=13)
+    leaves = [sc[k].to(dev).requires_grad_(True) for k in ("means", "quats", "log_scales", "opacity_logits", "sh")]
+    views = [view_matrix(v).to(dev) for v in range(8)]
+    K = sc["Ks"].to(dev)
+    ups = [u.to(dev) for u in upstream([(1, H, W, 4), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3)], dtype=torch.float32)]
+    kw = dict(sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True,
+              scales_are_log=True, opacities_are_logit=True)
+
+    def step(v, ls):
+        for l in ls:
+            l.grad = None
+        out = rasterization(*ls, views[v], K, W, H, **kw)
+        torch.autograd.backward(list(out[:5]), ups)
+        return int(out[5]["n_isects"])
+
+    ops.reset_graph_cache(dev)
+    ops._CAP_HINT.pop(ops._cap_key(ops._lib.make_params(N, 1, W, H), dev), None)
+    counts = set()
+    for rnd in range(5):
+        if rnd == 3:
+            g0 = ops.graph_cache_stats(dev)
+        for v in range(8):
+            n = step(v, leaves)
+            if v == 0:
+                counts.add(n)
+            with torch.no_grad():                                     # the optimiser: a bounded in-place step
+                for l in leaves:
+                    l.add_(torch.sign(l.grad), alpha=-2e-3)
+    g1 = ops.graph_cache_stats(dev)
+    assert len(counts) >= 4, counts                                   # the count of view 0 really moved from visit to visit
+    assert g1["captures"] == g0["captures"] and g1["hits"] - g0["hits"] == 32, (g0, g1)
+    # and the replayed step computes what a cold call computes on the same values
+    n = step(3, leaves)
+    got = [l.grad.clone() for l in leaves]
+    cold = [l.detach().clone().requires_grad_(True) for l in leaves]
+    old = (ops.GRAPHS, ops.SPECULATE)
+    try:
+        ops.GRAPHS, ops.SPECULATE = False, False
+        assert step(3, cold) == n
+    finally:
+        ops.GRAPHS, ops.SPECULATE = old
+    for a, b in zip(got, cold):
+        assert rel_err(a, b.grad) < 2e-5
+
+
 def test_cycling_views_reuse_graphs_without_capacity_redo(dev):
     """A training loop renders a different camera every step (rade_gs_model.py:94-95).  Eight resident view matrices
     cycled over one set of leaves with graphs, merged phases and the speculative capacity on: the decaying-maximum
