@@ -21,6 +21,8 @@ K = sc["Ks"].to(dev)
 g = torch.Generator().manual_seed(7)
 ups = [torch.rand(s, generator=g).to(dev) for s in ((1, H, W, 4), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3))]
 marks = {}
+front = []                                                           # (tiles sorted in front only, tiles flagged, tiles) of sampled steps
+STEP = float(os.environ.get("SOAK_STEP", "1e-4"))
 t_mark = time.perf_counter()
 for it in range(STEPS):
     if it and it % 100 == 0:                                         # "densification": the shapes change
@@ -35,11 +37,14 @@ for it in range(STEPS):
                         params["sh"], views[it % 8], K, W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased",
                         return_depth_normal=True)
     torch.autograd.backward(list(out[:5]), ups)
+    part = out[5]["_bins"]["partial"] if it % 8 == 3 else None       # front-only ordering (dense scenes): how stale were the pivots?
+    if part is not None:
+        front.append((int((part["front_n"] >= 0).sum()), int((part["tile_flag"] != 0).sum()), int(part["front_n"].numel())))
     with torch.no_grad():                                            # the optimiser's in-place update
         for k, p in params.items():
             if it % 25 == 0:
                 assert torch.isfinite(p.grad).all(), (it, k)
-            p.add_(torch.sign(p.grad), alpha=-1e-4)                  # (a bounded step: 400 of them move a value by 0.04 at most)
+            p.add_(torch.sign(p.grad), alpha=-STEP)                  # (a bounded step: 400 of them move a value by 0.04 at most)
     del out
     if it in (49, 99, 199, 299, STEPS - 1):
         torch.cuda.synchronize()
@@ -51,7 +56,8 @@ for it in range(STEPS):
                          "wall_s": round(now - t_mark, 3)}
 for p in params.values():
     assert torch.isfinite(p).all()
-print(json.dumps({"steps": STEPS, "marks": marks}))
+print(json.dumps({"steps": STEPS, "step_size": STEP, "marks": marks, "front_only_samples": front[-12:],
+                  "front_only_flagged_mean": (sum(f[1] for f in front[4:]) / max(len(front[4:]), 1)) if front else None}))
 if ops.KEY_TRACE:                                                    # MISPLAT_KEY_TRACE=1: what moved between two visits of a view
     for line in ops.key_trace_report(16, start=64)[:12]:
         print("key-trace", line, file=sys.stderr)
