@@ -182,6 +182,7 @@ int enqueue_forward(const misplat_params* p, const misplat_raster_args* a, int32
 
 struct GraphEntry {
     std::vector<uint8_t> key;
+    uint64_t hash;                  // of key: the lookup compares 8 bytes per entry, the ~1 KB key only on a match
     hipGraphExec_t exec;
     hipGraph_t graph;               // the captured template stays alive as long as its executable does
     uint64_t stamp;
@@ -200,7 +201,7 @@ struct misplat_graph_cache {
     std::vector<GraphEntry> entries;
     std::vector<Retired> retired;
     uint64_t clock = 0, hits = 0, captures = 0;
-    std::vector<uint64_t> seen;                 // hashes of the last 256 argument blocks that missed (capture on second sighting)
+    std::vector<uint64_t> seen;                 // hashes of the last 1 024 argument blocks that missed (capture on second sighting)
     uint64_t seen_next = 0, window_start = 0, window_captures = 0;
     int max_entries = 16;
     // Sequences are captured on this private stream (the caller's may be the legacy default stream, which cannot be
@@ -254,8 +255,10 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
             i++;
         }
     }
+    uint64_t h = 1469598103934665603ull;
+    for (uint8_t bt : key) { h ^= bt; h *= 1099511628211ull; }
     for (auto& e : cache->entries)
-        if (e.key == key) {
+        if (e.hash == h && e.key == key) {
             e.stamp = cache->clock;
             e.last_stream = s;
             cache->hits++;
@@ -264,19 +267,17 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
     // A capture + instantiation costs host time (of the order of a millisecond), a replay saves some tens of
     // microseconds: a caller whose argument blocks do not repeat (fresh camera tensors at addresses that never come back,
     // intersection capacities that drift) must not capture at all.  So a block is captured when it is seen for the
-    // SECOND time: its first sighting only leaves a 64-bit hash in a ring of the last 256 misses and launches plainly.
+    // SECOND time: its first sighting only leaves a 64-bit hash in a ring of the last 1 024 misses and launches plainly.
     // A trainer that cycles through a few resident camera tensors pays one plain round, one capturing round and
     // replays from then on; a caller whose blocks never recur pays nothing.  Safety net for blocks that recur exactly
     // once (period-2 address patterns that then move on): at most max_entries captures per 256 calls.
-    uint64_t h = 1469598103934665603ull;
-    for (uint8_t bt : key) { h ^= bt; h *= 1099511628211ull; }
     bool seen = false;
     for (uint64_t v : cache->seen) seen |= (v == h);
     if (cache->clock - cache->window_start >= 256) { cache->window_start = cache->clock; cache->window_captures = 0; }
     if (!seen || cache->window_captures >= (uint64_t)cache->max_entries) {
         if (!seen) {
-            if (cache->seen.size() < 256) cache->seen.push_back(h);
-            else cache->seen[cache->seen_next++ & 255] = h;
+            if (cache->seen.size() < 1024) cache->seen.push_back(h);
+            else cache->seen[cache->seen_next++ & 1023] = h;
         }
         return enqueue(s);
     }
@@ -325,7 +326,7 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
         }
         cache->entries.erase(cache->entries.begin() + victim);
     }
-    cache->entries.push_back(GraphEntry{std::move(key), exec, graph, cache->clock, s});
+    cache->entries.push_back(GraphEntry{std::move(key), h, exec, graph, cache->clock, s});
     cache->captures++;
     return MISPLAT_OK;
 }

@@ -584,7 +584,7 @@ def _carve_f(dev: torch.device, sizes, cv: "Optional[arena.Carver]" = None) -> l
 GRAPHS = os.environ.get("MISPLAT_GRAPH", "1") == "1"
 # one graph per distinct argument block: a trainer that cycles through a few resident camera tensors needs forward +
 # backward graphs for each of them (8 views -> 16 graphs and the first-call variants)
-GRAPH_CACHE_ENTRIES = int(os.environ.get("MISPLAT_GRAPH_ENTRIES", "64"))
+GRAPH_CACHE_ENTRIES = int(os.environ.get("MISPLAT_GRAPH_ENTRIES", "256"))   # (2 per resident camera tensor: forward + backward)
 _GRAPH_CACHE: Dict[int, int] = {}
 
 
