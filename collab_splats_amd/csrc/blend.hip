@@ -1037,15 +1037,17 @@ __global__ __launch_bounds__(kDnTX * kDnTY) void depth_normal_bwd_tiled_kernel(
         dep[k][ly][lx] = z;
     }
     __syncthreads();
-    for (int e = tid; e < RH * RW; e += kDnTX * kDnTY) {
+    // (one adjoint evaluation per (map, pixel) item: 2 x 340 items on 256 threads are 2.7 rounds of one evaluation; both maps
+    // of a pixel in one thread were 2 rounds of two, the second round a third full)
+    for (int e2 = tid; e2 < 2 * RH * RW; e2 += kDnTX * kDnTY) {
+        const int k = e2 / (RH * RW), e = e2 - k * (RH * RW);
         const int ly = e / RW, lx = e - ly * RW;
         const int yn = y0 + ly - 1, xn = x0 + lx - 1;
         const bool interior = xn >= 1 && yn >= 1 && xn < d.W - 1 && yn < d.H - 1;
         const size_t pid = interior ? (size_t)yn * d.W + xn : 0;
         float r0 = 0.f, r1 = 0.f, r2 = 0.f;
         if (interior && v_err) { r0 = nr[pid * 3]; r1 = nr[pid * 3 + 1]; r2 = nr[pid * 3 + 2]; }
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
+        {
             float va[3] = {0.f, 0.f, 0.f}, vb[3] = {0.f, 0.f, 0.f}, ven[3] = {0.f, 0.f, 0.f};
             if (interior) {
                 // points of the four neighbours (dn_point), from the staged tile: (ly, lx) of the adjoint tile is
