@@ -596,7 +596,9 @@ def main():
         elif world == 1:
             par = "one GPU, no collective" + ("; gradients written into a GradientBuckets flat buffer (--buckets)" if bucket is not None else "")
         else:
-            par = "shared Gaussians, RCCL all-reduce of 236 B/Gaussian grads (colour + geometry bucket, zero-copy flat buffer)"
+            be = dist.get_backend() if dist.is_initialized() else "none"
+            par = (f"shared Gaussians, {'RCCL' if be == 'nccl' else be + ' (a rehearsal: not RCCL)'} reduce of 236 B/Gaussian grads (colour + geometry "
+                   f"bucket, zero-copy flat buffer; sparse rows where the flags allow: {dict(parallel.STATS)})")
         line = {
             "metric": "Msplats/s fwd+bwd @1080p (1M Gaussians); grad max-rel-err vs reference",
             "value": round(world * N / (dt / args.steps) / 1e6, 3), "unit": "Msplats/s",
