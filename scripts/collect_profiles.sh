@@ -21,6 +21,6 @@ cp $B/bench_features_dense.json $P/${R}_bench_features_dense.json
 # instruction-class tables of the compositing kernels' trip loops and the class-weighted issue budget (hipcc -S of the current source)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -fno-fast-math -S --cuda-device-only -o /tmp/blend_isa.s collab_splats_amd/csrc/blend.hip 2>/dev/null
 python scripts/isa_table.py /tmp/blend_isa.s 'blend_bwd_kernelILi4ELi2ELb0ELb1ELi0E' --dump > $P/${R}_isa_blend_bwd.txt
-python scripts/isa_table.py /tmp/blend_isa.s 'blend_fwd_kernelILi4ELi2ELi0ELb1E' --dump > $P/${R}_isa_blend_fwd.txt
+python scripts/isa_table.py /tmp/blend_isa.s 'blend_fwd_kernelILi4ELi2ELi0ELb0E' --dump > $P/${R}_isa_blend_fwd.txt
 python scripts/valu_budget.py /tmp/blend_isa.s $P/pmc_traffic.json > $P/${R}_valu_budget.json
 ls $P | grep ${R} | wc -l

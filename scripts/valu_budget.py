@@ -35,7 +35,9 @@ COST = {                                                          # cycles per w
     "v_mov / lane reads": 2.5,
     "other VALU": 2.5,
 }
-KERNELS = {"blend_fwd": "blend_fwd_kernelILi4ELi2ELi0ELb1E", "blend_bwd": "blend_bwd_kernelILi4ELi2ELb0ELb1ELi0E"}
+# (forward: the trip loop is taken from the plain-record instantiation -- the on-demand-colour one has the same trip loop, but
+# its innermost loop with the most vector instructions is the SH evaluation walk, which the "hottest loop" rule would pick)
+KERNELS = {"blend_fwd": "blend_fwd_kernelILi4ELi2ELi0ELb0E", "blend_bwd": "blend_bwd_kernelILi4ELi2ELb0ELb1ELi0E"}
 CONTRIB = 8.0 / 9.0                                               # staged entries some pixel takes
 N_SIMD = 1024
 
