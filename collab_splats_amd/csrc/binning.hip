@@ -15,19 +15,6 @@
 
 namespace {
 
-__device__ __forceinline__ void tile_rect(float mx, float my, int rxi, int ryi, int tw, int th,
-                                          int& x0, int& x1, int& y0, int& y1) {
-    const float ts = (float)MISPLAT_TILE;
-    float rx = (float)rxi, ry = (float)ryi;
-    float fx0 = floorf((mx - rx) / ts), fx1 = ceilf((mx + rx) / ts);
-    float fy0 = floorf((my - ry) / ts), fy1 = ceilf((my + ry) / ts);
-    float ftw = (float)tw, fth = (float)th;
-    fx0 = fx0 > 0.f ? fx0 : 0.f; fx1 = fx1 > 0.f ? fx1 : 0.f;
-    fy0 = fy0 > 0.f ? fy0 : 0.f; fy1 = fy1 > 0.f ? fy1 : 0.f;
-    x0 = (int)(fx0 < ftw ? fx0 : ftw); x1 = (int)(fx1 < ftw ? fx1 : ftw);
-    y0 = (int)(fy0 < fth ? fy0 : fth); y1 = (int)(fy1 < fth ? fy1 : fth);
-}
-
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ uint32_t dpp_take(uint32_t ident, uint32_t x) {
     return (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)x, CTRL, ROW_MASK, 0xF, false);

@@ -1182,14 +1182,14 @@ __global__ __launch_bounds__(1024) void unit_order_kernel(int units, int per, co
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off);
-            if ((threadIdx.x & 63) >= off) incl += o;
+            if ((int)(threadIdx.x & 63) >= off) incl += o;
         }
         if ((threadIdx.x & 63) == 63) wmax[threadIdx.x >> 6] = incl;
     }
     __syncthreads();
     if (threadIdx.x < 256) {
         uint32_t carry = 0u;
-        for (int w = 0; w < (threadIdx.x >> 6); w++) carry += wmax[w];
+        for (int w = 0; w < (int)(threadIdx.x >> 6); w++) carry += wmax[w];
         hist[threadIdx.x] = carry + incl - v;
     }
     __syncthreads();
