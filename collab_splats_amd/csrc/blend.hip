@@ -1037,6 +1037,11 @@ __global__ __launch_bounds__(kDnTX * kDnTY) void depth_normal_bwd_tiled_kernel(
         dep[k][ly][lx] = z;
     }
     __syncthreads();
+    // The backward multiplies by reciprocals where the forward divides (IEEE divisions are ~10 instructions each and an
+    // adjoint evaluation had a dozen of them: the kernel was 77 % vector-ALU busy at 3.5 x its memory time; gradients are
+    // compared at 1e-4, the forward's normals stay bit for bit what dn_normal computes).
+    const float ifx = 1.0f / d.fx, ify = 1.0f / d.fy;
+    const float cxr = (float)d.W * 0.5f * ifx, cyr = (float)d.H * 0.5f * ify;
     // (one adjoint evaluation per (map, pixel) item: 2 x 340 items on 256 threads are 2.7 rounds of one evaluation; both maps
     // of a pixel in one thread were 2 rounds of two, the second round a third full)
     for (int e2 = tid; e2 < 2 * RH * RW; e2 += kDnTX * kDnTY) {
@@ -1058,8 +1063,8 @@ __global__ __launch_bounds__(kDnTX * kDnTY) void depth_normal_bwd_tiled_kernel(
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const float z = dep[k][dy[q]][dx[q]];
-                    pt[q][0] = z * (((float)nx[q] + 0.5f) / d.fx - (float)d.W / (2.0f * d.fx));
-                    pt[q][1] = z * (((float)ny[q] + 0.5f) / d.fy - (float)d.H / (2.0f * d.fy));
+                    pt[q][0] = z * (((float)nx[q] + 0.5f) * ifx - cxr);
+                    pt[q][1] = z * (((float)ny[q] + 0.5f) * ify - cyr);
                     pt[q][2] = z;
                 }
                 float a[3], b[3], cr[3], n[3];
@@ -1082,10 +1087,10 @@ __global__ __launch_bounds__(kDnTX * kDnTY) void depth_normal_bwd_tiled_kernel(
                 if (len > 1e-12f) {
                     const float dot = n[0] * vn[0] + n[1] * vn[1] + n[2] * vn[2];
 #pragma unroll
-                    for (int q = 0; q < 3; q++) vc[q] = (vn[q] - n[q] * dot) / len;
+                    for (int q = 0; q < 3; q++) vc[q] = (vn[q] - n[q] * dot) * inv;          // (inv = 1 / len here)
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 3; q++) vc[q] = vn[q] / 1e-12f;
+                    for (int q = 0; q < 3; q++) vc[q] = vn[q] * 1e12f;
                 }
                 va[0] = b[1] * vc[2] - b[2] * vc[1]; va[1] = b[2] * vc[0] - b[0] * vc[2]; va[2] = b[0] * vc[1] - b[1] * vc[0];
                 vb[0] = vc[1] * a[2] - vc[2] * a[1]; vb[1] = vc[2] * a[0] - vc[0] * a[2]; vb[2] = vc[0] * a[1] - vc[1] * a[0];
@@ -1099,8 +1104,8 @@ __global__ __launch_bounds__(kDnTX * kDnTY) void depth_normal_bwd_tiled_kernel(
     const int x = x0 + lx, y = y0 + ly;
     if (x >= d.W || y >= d.H) return;
     const size_t pid = (size_t)y * d.W + x;
-    const float rx = ((float)x + 0.5f) / d.fx - (float)d.W / (2.0f * d.fx);
-    const float ry = ((float)y + 0.5f) / d.fy - (float)d.H / (2.0f * d.fy);
+    const float rx = ((float)x + 0.5f) * ifx - cxr;
+    const float ry = ((float)y + 0.5f) * ify - cyr;
     float vnr[3] = {0.f, 0.f, 0.f};
     const int cy = ly + 1, cx = lx + 1;                      // own position in the adjoint tile
 #pragma unroll
