@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--fixed-view", action="store_true",
                     help="headline = the same camera every step; default: the eight views of configs[3] cycled, one per step")
     ap.add_argument("--no-variants", action="store_true", help="skip the other three corners of the 2 x 2 (`variants`)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two counters-only rocprofv3 passes over a short child run, "
+                         "after the timed region; part of the default line like cpu_baseline): quote profiles/pmc_traffic.json")
     ap.add_argument("--buckets", action="store_true",
                     help="attach a parallel.GradientBuckets sink even on one GPU (no collective): measures what the "
                          "data-parallel backward costs on top of the plain one")
@@ -286,6 +289,57 @@ def parity(args, params, viewmats, Ks, W, H, ext, ups_dev, st, gr, act, what: st
             "gradient_mode": "deterministic (slab + fixed-order reduce)" if deterministic else "atomic (the timed mode)",
             "on": what, "call": "the timed step's own call (" + ("extension" if ext else "torch") + " activations), raw-parameter gradients",
             "against": "oracle/craster.c (fp32 C port; upstream gsplat-rade absent: parity unpinned)", "target": 1e-4}
+
+
+def live_pmc(args):
+    """HBM bytes per launch of the two compositing kernels and their vector-ALU share, measured in THIS run: counters-only
+    rocprofv3 passes (FETCH_SIZE + GRBM_GUI_ACTIVE | WRITE_SIZE | SQ_INSTS_VALU + SQ_ACTIVE_INST_VALU, separate passes, no trace
+    domain, the program directly behind `--`) over a short child run of this file with the same workload flags, after the timed
+    region.  traffic = (2 * FETCH_SIZE + WRITE_SIZE) KiB * 1024 (FETCH_SIZE doubled for gfx950 as MI355X_MICROARCH.md's HBM section
+    prescribes).  None when rocprofv3 is not there, when this process is itself being profiled, or when a pass fails."""
+    import collections, csv, glob, shutil, signal, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ):
+        return None
+    root = tempfile.mkdtemp(prefix="misplat_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "4", "--warmup", "4", "--no-cpu-baseline", "--no-variants",
+             "--no-live-pmc", "--gaussians", str(args.gaussians), "--width", str(args.width), "--height", str(args.height),
+             "--render-mode", args.render_mode, "--rasterize-mode", args.rasterize_mode]
+    child += ["--fixed-view"] if args.fixed_view else []
+    child += ["--ext-activations"] if args.ext_activations else []
+    env = dict(os.environ, TMPDIR="/tmp")
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    try:
+        for i, counters in enumerate((["FETCH_SIZE", "GRBM_GUI_ACTIVE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"])):
+            out = os.path.join(root, f"p{i}")
+            proc = subprocess.Popen([exe, "--pmc", *counters, "--output-format", "csv", "-d", out, "--", *child], cwd="/tmp", env=env,
+                                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=240)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)                  # (the group this call started, nothing else)
+                proc.wait()
+                return None
+            if rc != 0:
+                return None
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    for key in ("blend_fwd", "blend_bwd"):
+                        if key + "_kernel" in r["Kernel_Name"]:
+                            agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    res = {}
+    for k, d in agg.items():
+        m = {c: sum(v[len(v) // 2:]) / max(len(v[len(v) // 2:]), 1) for c, v in d.items()}     # (the steady half of the launches)
+        if not {"FETCH_SIZE", "WRITE_SIZE", "GRBM_GUI_ACTIVE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU"} <= set(m):
+            return None
+        simd_cycles = 1024 * m["GRBM_GUI_ACTIVE"] / 8.0
+        res[k] = {"traffic": int((2 * m["FETCH_SIZE"] + m["WRITE_SIZE"]) * 1024),
+                  "valu_issue_frac": round(m["SQ_INSTS_VALU"] * 4.0 / simd_cycles, 4),
+                  "valu_busy": round(m["SQ_ACTIVE_INST_VALU"] * 4.0 / simd_cycles, 4),
+                  "counters": {c: float(f"{v:.6g}") for c, v in sorted(m.items())}}
+    return res or None
 
 
 def copy_roof(dev):
@@ -664,6 +718,18 @@ def main():
             line["roofline"]["algorithmic_bytes_note"] = ("SURVEY 8(d) with 4 D' substituted in the colour terms (D' = "
                                                           f"{cd}): see bench.algorithmic_bytes")
             line["cpu_baseline_note"] = "not timed for this leg (the default run carries cpu_baseline and the gradient check)"
+        if world == 1 and not args.no_cpu_baseline and not args.no_live_pmc and not args.dn_loss and args.features == 0 and graphed is None:
+            live = live_pmc(args)
+            if live and dom in live:
+                rf = line["roofline"]
+                rf["traffic"], rf["valu_issue_frac"] = live[dom]["traffic"], live[dom]["valu_issue_frac"]
+                rf["traffic_source"] = ("measured in this run: counters-only rocprofv3 passes (FETCH_SIZE, WRITE_SIZE, SQ) over a "
+                                        "short child run of the same workload, after the timed region")
+                rf["traffic_git_rev"] = git_rev()
+                rf["valu_busy_measured"] = live[dom]["valu_busy"]
+                rf["pmc_live"] = live
+            else:
+                line["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (no live measurement: rocprofv3 missing, nested, or failed)"
         if world == 1 and not args.no_cpu_baseline and not args.dn_loss and args.features == 0:
             import numpy as np
             from oracle.craster import CRaster
