@@ -187,6 +187,7 @@ struct GraphEntry {
     hipGraph_t graph;               // the captured template stays alive as long as its executable does
     uint64_t stamp;
     hipStream_t last_stream;        // where it was launched last
+    uint32_t hits = 0;              // replays of this graph
 };
 struct Retired {                    // an evicted graph may still be executing: destroyed once `done` has fired
     hipGraphExec_t exec;
@@ -203,6 +204,10 @@ struct misplat_graph_cache {
     uint64_t clock = 0, hits = 0, captures = 0;
     std::vector<uint64_t> seen;                 // hashes of the last 1 024 argument blocks that missed (capture on second sighting)
     uint64_t seen_next = 0, window_start = 0, window_captures = 0;
+    // A working set larger than the cache (more resident camera tensors than max_entries / 2) evicts every graph before its
+    // block comes round again: each capture is then wasted.  Graphs evicted without a single replay are counted; 32 of them
+    // and the cache stops capturing for the next 4 096 lookups (plain launches, which is what such a caller gets anyway).
+    uint64_t wasted = 0, quiet_until = 0;
     int max_entries = 16;
     // Sequences are captured on this private stream (the caller's may be the legacy default stream, which cannot be
     // captured) and the resulting graph is launched on the caller's stream.
@@ -261,6 +266,7 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
         if (e.hash == h && e.key == key) {
             e.stamp = cache->clock;
             e.last_stream = s;
+            e.hits++;
             cache->hits++;
             return hipGraphLaunch(e.exec, s) == hipSuccess ? MISPLAT_OK : MISPLAT_ELAUNCH;
         }
@@ -274,7 +280,7 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
     bool seen = false;
     for (uint64_t v : cache->seen) seen |= (v == h);
     if (cache->clock - cache->window_start >= 256) { cache->window_start = cache->clock; cache->window_captures = 0; }
-    if (!seen || cache->window_captures >= (uint64_t)cache->max_entries) {
+    if (!seen || cache->window_captures >= (uint64_t)cache->max_entries || cache->clock < cache->quiet_until) {
         if (!seen) {
             if (cache->seen.size() < 1024) cache->seen.push_back(h);
             else cache->seen[cache->seen_next++ & 1023] = h;
@@ -312,6 +318,10 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
         size_t victim = 0;
         for (size_t i = 1; i < cache->entries.size(); i++)
             if (cache->entries[i].stamp < cache->entries[victim].stamp) victim = i;
+        if (cache->entries[victim].hits == 0 && ++cache->wasted >= 32) {
+            cache->wasted = 0;
+            cache->quiet_until = cache->clock + 4096;
+        }
         Retired r{cache->entries[victim].exec, cache->entries[victim].graph, nullptr};
         // it may still be running: keep it until an event recorded behind its last launch has fired
         if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) == hipSuccess &&
@@ -326,7 +336,7 @@ static int run_cached(misplat_graph_cache* cache, std::vector<uint8_t>&& key, hi
         }
         cache->entries.erase(cache->entries.begin() + victim);
     }
-    cache->entries.push_back(GraphEntry{std::move(key), h, exec, graph, cache->clock, s});
+    cache->entries.push_back(GraphEntry{std::move(key), h, exec, graph, cache->clock, s, 0u});
     cache->captures++;
     return MISPLAT_OK;
 }

@@ -2206,6 +2206,50 @@ def test_graphs_replay_while_the_scene_is_being_trained(dev):
         assert rel_err(a, b.grad) < 2e-5
 
 
+def test_graph_cache_smaller_than_the_working_set_stops_capturing(dev, monkeypatch):
+    """More resident camera tensors than the cache holds graphs for (here: 4 entries, 8 views x 2 calls): every graph is evicted
+    before its block comes round again, so every capture would be wasted.  The cache counts graphs evicted without a replay and
+    goes quiet (plain launches) after 32 of them; the images stay those of a cold call throughout."""
+    from collab_splats_amd import ops, rasterization
+    from collab_splats_amd.synthetic import random_scene, view_matrix
+    N, W, H = 20_000, 320, 192
+    sc = random_scene(N, W, H, seed=19)
+    leaves = [sc[k].to(dev).requires_grad_(True) for k in ("means", "quats", "log_scales", "opacity_logits", "sh")]
+    views = [view_matrix(v).to(dev) for v in range(8)]
+    K = sc["Ks"].to(dev)
+    ups = [u.to(dev) for u in upstream([(1, H, W, 4), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3)], dtype=torch.float32)]
+    kw = dict(sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True,
+              scales_are_log=True, opacities_are_logit=True)
+
+    def call(v):
+        for l in leaves:
+            l.grad = None
+        out = rasterization(*leaves, views[v], K, W, H, **kw)
+        torch.autograd.backward(list(out[:5]), ups)
+        return [t.detach().clone() for t in out[:5]]
+
+    old = (ops.GRAPHS, ops.SPECULATE)
+    try:
+        ops.GRAPHS, ops.SPECULATE = False, False
+        cold = [call(v) for v in range(8)]
+    finally:
+        ops.GRAPHS, ops.SPECULATE = old
+    monkeypatch.setattr(ops, "GRAPH_CACHE_ENTRIES", 4)
+    ops.reset_graph_cache(dev)
+    try:
+        marks = []
+        for rnd in range(14):
+            for v in range(8):
+                img = call(v)
+                for x, y in zip(img, cold[v]):
+                    assert torch.equal(x, y), (rnd, v)
+            marks.append(ops.graph_cache_stats(dev)["captures"])
+        # captures stop: 32 wasted graphs after the first 4 fill the cache, then silence for 4 096 lookups
+        assert marks[-1] == marks[-4] and marks[-1] <= 4 + 32 + 4, marks
+    finally:
+        ops.reset_graph_cache(dev)                                # (the next test gets a cache of the default size)
+
+
 def test_cycling_views_reuse_graphs_without_capacity_redo(dev):
     """A training loop renders a different camera every step (rade_gs_model.py:94-95).  Eight resident view matrices
     cycled over one set of leaves with graphs, merged phases and the speculative capacity on: the decaying-maximum
