@@ -523,13 +523,39 @@ def main():
     if args.graphed:
         if args.dn_loss or shared or args.buckets:
             raise SystemExit("bench.py: --graphed covers the plain rasterization step only")
-        mode["fixed"] = True                       # (a captured graph replays ONE argument block: one camera)
         from collab_splats_amd import graphs
-        step()                                     # one eager step: learn the intersection count
-        torch.cuda.synchronize()
-        capacity = int(int(info["n_isects"]) * 1.5) + 4096
-        graphed = graphs.GraphedStep(step, capacity=capacity)
-        step = graphed.replay
+        if mode["fixed"]:                          # a captured graph replays ONE argument block: one camera
+            step()                                 # one eager step: learn the intersection count
+            torch.cuda.synchronize()
+            capacity = int(int(info["n_isects"]) * 1.5) + 4096
+            graphed = graphs.GraphedStep(step, capacity=capacity)
+            graphed_all = [graphed]
+            step = graphed.replay
+        else:
+            # the headline's eight cycling views: ONE whole-step graph per resident camera, replayed in turn
+            counts = []
+            for v in range(8):
+                info["it"] = v
+                step()
+                torch.cuda.synchronize()
+                counts.append(int(info["n_isects"]))
+            capacity = int(max(counts) * 1.5) + 4096
+            one_step = step
+
+            def make(v):
+                def step_v():
+                    info["it"] = v                 # (view_index() = this view, at capture time -- replays do not run Python)
+                    one_step()
+                return graphs.GraphedStep(step_v, capacity=capacity)
+
+            graphed_all = [make(v) for v in range(8)]
+            graphed = graphed_all[0]
+            turn = {"i": 0}
+
+            def step():
+                gph = graphed_all[turn["i"] % 8]
+                turn["i"] += 1
+                return gph.replay()
     stats0 = dict(ops.PATH_STATS)
     g_start = ops.graph_cache_stats()
     dt, dev_med = timed(step, args.steps, args.warmup)
@@ -555,7 +581,8 @@ def main():
     graph_all["hit_rate_of_replayable"] = round(graph_all["hits"] / replayable, 4) if replayable else None
     headline_mode = dict(mode)
     if graphed is not None:
-        graphed.check()                            # the fixed capacity held for every replay
+        for gph in graphed_all:
+            gph.check()                            # the fixed capacity held for every replay
         step = eager_step
         step()                                     # (eager again: info[...] must not point into the graph's pool)
     allreduce_ms = sorted(ev[0].elapsed_time(ev[1]) for ev in info["allreduce_ms"] if ev is not None)
@@ -679,7 +706,8 @@ def main():
                                                            "forward_arena_slot", "forward_probe")},
                        "path_note": f"counts over the {args.steps + args.warmup} headline steps: on-demand colours, merged "
                                     "phases, view-keyed launch order, capacity misses, one-call backward, background fill, gradient rows cleared on touch",
-                       "host": (f"whole step replayed as one hipGraph (graphs.GraphedStep, fixed capacity "
+                       "host": ((f"whole step replayed as one hipGraph ({len(graphed_all)} graph(s): one per resident camera, replayed in "
+                                 f"turn; graphs.GraphedStep, fixed capacity ") +
                                 f"{graphed.capacity} intersections, no host synchronisation)" if graphed is not None
                                 else "eager PyTorch step (the reference's training loop is eager)")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,

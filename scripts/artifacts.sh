@@ -68,7 +68,9 @@ models)
 small)
   python3 bench.py --no-cpu-baseline --gaussians 10000 --width 256 --height 256 > $OUT/bench_10k.json 2> /dev/null
   python3 bench.py --no-cpu-baseline --gaussians 100000 > $OUT/bench_100k.json 2> /dev/null
-  python3 bench.py --no-cpu-baseline --gaussians 10000 --width 256 --height 256 --graphed > $OUT/bench_10k_graphed.json 2> /dev/null
+  python3 bench.py --no-cpu-baseline --gaussians 10000 --width 256 --height 256 --graphed --fixed-view > $OUT/bench_10k_graphed.json 2> /dev/null
+  python3 bench.py --no-cpu-baseline --gaussians 10000 --width 256 --height 256 --graphed > $OUT/bench_10k_graphed_cycling.json 2> /dev/null
+  python3 bench.py --no-cpu-baseline --gaussians 100000 --graphed > $OUT/bench_100k_graphed_cycling.json 2> /dev/null
   say "10k / 100k / 10k graphed: $(for f in 10k 100k 10k_graphed; do python3 -c "import json; d=json.load(open('$OUT/bench_$f.json')); print(d['ms_per_step'], {k: v['ms_per_step'] for k, v in d['variants'].items()}, d['config'].get('graph_hit_rate'), end=' | ')"; done 2>&1)";;
 features)
   python3 bench.py --features 13 --fixed-view --no-cpu-baseline > $OUT/bench_features.json 2> $OUT/bench_features.err
