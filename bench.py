@@ -542,20 +542,18 @@ def main():
             capacity = int(max(counts) * 1.5) + 4096
             one_step = step
 
-            def make(v):
-                def step_v():
-                    info["it"] = v                 # (view_index() = this view, at capture time -- replays do not run Python)
-                    one_step()
-                return graphs.GraphedStep(step_v, capacity=capacity)
+            def step_of(v):
+                info["it"] = v                     # (view_index() = this view, at capture time -- replays do not run Python)
+                one_step()
 
-            graphed_all = [make(v) for v in range(8)]
+            graphed_views = graphs.GraphedViews(step_of, 8, capacity)
+            graphed_all = graphed_views.steps
             graphed = graphed_all[0]
             turn = {"i": 0}
 
             def step():
-                gph = graphed_all[turn["i"] % 8]
                 turn["i"] += 1
-                return gph.replay()
+                return graphed_views.replay((turn["i"] - 1) % 8)
     stats0 = dict(ops.PATH_STATS)
     g_start = ops.graph_cache_stats()
     dt, dev_med = timed(step, args.steps, args.warmup)

@@ -119,3 +119,29 @@ class GraphedStep:
         """Synchronise and return the intersection count of the last replay; raises if it exceeded the capacity."""
         torch.cuda.synchronize(self.device)
         return ops.check_static_capacity(self.device)
+
+
+class GraphedViews:
+    """One whole-step graph per RESIDENT camera: a trainer that keeps its views on the device replays ``fn(v)`` -- activations,
+    rasterization of view ``v``, loss, backward -- as one hipGraph per view, in whatever order it visits them.  ``fn(v)`` obeys
+    GraphedStep's rules (no tensor with autograd history may outlive the call; parameters are updated in place) and one more:
+    gradients must live in STATIC tensors that every graph accumulates into -- clear them with ``p.grad.zero_()`` inside
+    ``fn``, not with ``p.grad = None`` (a replay does not run Python: a ``.grad`` attribute assigned while one view's graph was
+    captured does not follow the replays of another's), or put the optimiser step inside ``fn``.  ``capacity`` covers the
+    largest view.  ``bench.py --graphed`` on the cycling views: 0.14 ms per step at 10 k / 256^2, 0.38 ms at
+    100 k / 1080p, where the eager loop is host-bound at 0.5 ms."""
+
+    def __init__(self, fn: Callable[[int], object], n_views: int, capacity: int, warmup: int = 3,
+                 device: Optional[torch.device] = None):
+        self.capacity = int(capacity)
+        self.steps = [GraphedStep((lambda v=v: fn(v)), capacity, warmup=warmup, device=device) for v in range(int(n_views))]
+
+    def __len__(self) -> int:
+        return len(self.steps)
+
+    def replay(self, v: int):
+        return self.steps[v].replay()
+
+    def check(self) -> int:
+        """Synchronise; the intersection count of the LAST replay (raises if it exceeded the capacity)."""
+        return self.steps[0].check()

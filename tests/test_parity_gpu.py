@@ -1521,6 +1521,58 @@ def test_whole_step_graph_replays_equal_eager_steps(dev, monkeypatch, lazy):
     assert found
 
 
+def test_one_whole_step_graph_per_resident_camera(dev):
+    """graphs.GraphedViews: a trainer with its views resident on the device replays activations + forward + backward of view v
+    as one hipGraph per view, in any order, while the parameters move in place.  The gradients live in STATIC tensors that every
+    graph accumulates into (``p.grad.zero_()`` inside the step, not ``p.grad = None``: a replay does not run Python, so a
+    ``.grad`` attribute assigned during one graph's capture would not follow the replays of another): every replay gives bitwise
+    the images and (to 1e-5) the gradients of an eager step of that view on the same values."""
+    from collab_splats_amd import graphs, ops, rasterization
+    from collab_splats_amd.synthetic import random_scene, view_matrix
+    N, W, H = 10_000, 256, 256
+    sc = random_scene(N, W, H, seed=5)
+    names = ("means", "log_scales", "quats", "opacity_logits", "sh")
+    params = {k: sc[k].to(dev).requires_grad_(True) for k in names}
+    views = [view_matrix(v).to(dev) for v in range(3)]
+    K = sc["Ks"].to(dev)
+    ups = [u.to(dev) for u in upstream([(1, H, W, 4), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3)], dtype=torch.float32)]
+
+    def run(p, v):
+        for t in p.values():
+            if t.grad is None:
+                t.grad = None
+            else:
+                t.grad.zero_()
+        out = rasterization(p["means"], p["quats"], torch.exp(p["log_scales"]), torch.sigmoid(p["opacity_logits"]), p["sh"],
+                            views[v], K, W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased",
+                            return_depth_normal=True)
+        torch.autograd.backward(list(out[:5]), ups)
+        return [t.detach() for t in out[:5]], out[5]["n_isects"]
+
+    n_max = 0
+    for v in range(3):
+        _, n = run(params, v)                                     # (leaves .grad tensors behind: the static ones from here on)
+        torch.cuda.synchronize()
+        n_max = max(n_max, int(n))
+    static = {k: params[k].grad for k in names}
+    gv = graphs.GraphedViews(lambda v: run(params, v), 3, capacity=2 * n_max)
+    assert len(gv) == 3 and all(params[k].grad is static[k] for k in names)
+    for rep, v in enumerate((2, 0, 1, 1, 2, 0)):
+        with torch.no_grad():
+            params["means"].add_(0.004)
+            params["log_scales"].add_(0.01)
+        imgs, n_dev = gv.replay(v)
+        n_graph = gv.check()
+        ref = {k: params[k].detach().clone().requires_grad_(True) for k in names}
+        ref_imgs, ref_n = run(ref, v)
+        torch.cuda.synchronize()
+        assert n_graph == int(n_dev) == int(ref_n), (rep, v)
+        for a, b in zip(imgs, ref_imgs):
+            assert torch.equal(a, b), (rep, v)
+        for k in names:
+            assert rel_err(static[k], ref[k].grad) < 1e-5, (rep, v, k)
+
+
 @pytest.mark.parametrize("N,W,H,scale_mul", [(30_000, 640, 360, 1.0), (5_000, 333, 197, 1.0), (60_000, 320, 200, 2.0)])
 def test_on_demand_colours_equal_the_colour_kernel(dev, N, W, H, scale_mul):
     """MISPLAT_LAZY_SH: the compositing forward evaluates a record's SH colour when it first stages it (and the backward
