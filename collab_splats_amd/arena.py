@@ -39,6 +39,26 @@ ALIGN_SLOT = 2 << 20              # the slot itself starts on a 2 MiB boundary
 ALIGN_BIG = int(float(os.environ.get("MISPLAT_ARENA_ALIGN_MB", "0")) * (1 << 20)) or 256
 ALIGN_SMALL = 256
 STATS: "collections.Counter" = collections.Counter()             # slots_created / slot_hits / fallbacks / regrown
+# The slots (and the allocator memory a ring's FIRST call runs from) come from a memory pool of their own
+# (torch.cuda.MemPool): creating a 200 MB slot, or freeing the first call's arrays, then does not reshuffle the free blocks the
+# CALLER's tensors come from -- the torch.exp / torch.sigmoid outputs of the reference's call kept moving for two steps after
+# our slots appeared, and every address that moves is a graph key that does not recur.
+USE_POOL = os.environ.get("MISPLAT_ARENA_POOL", "1") == "1"
+_POOLS: Dict[int, object] = {}
+
+
+def pool_ctx(dev: torch.device):
+    """Context in which allocations of this thread on ``dev`` come from the arena's private pool (a no-op context when the
+    pool is off, unavailable, or a graph is being captured: a capture has a pool of its own)."""
+    import contextlib
+    if not USE_POOL or not hasattr(torch.cuda, "MemPool") or torch.cuda.is_current_stream_capturing():
+        return contextlib.nullcontext()
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    pool = _POOLS.get(idx)
+    if pool is None:
+        with torch.cuda.device(idx):
+            pool = _POOLS[idx] = torch.cuda.MemPool()
+    return torch.cuda.use_mem_pool(pool, device=idx)
 
 _use_count = getattr(torch._C, "_storage_Use_Count", None)
 _ESIZE = {torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8, torch.int16: 2, torch.float64: 8}
@@ -49,7 +69,8 @@ class Slot:
 
     def __init__(self, dev: torch.device, nbytes: int):
         self.size = int(nbytes)
-        self.raw = torch.empty(self.size + ALIGN_SLOT, device=dev, dtype=torch.uint8)
+        with pool_ctx(dev):
+            self.raw = torch.empty(self.size + ALIGN_SLOT, device=dev, dtype=torch.uint8)
         shift = (-self.raw.data_ptr()) % ALIGN_SLOT
         self.base = self.raw[shift:shift + self.size]
         # one typed view of the whole slot per element size: an array is then ONE slice (host time: ~60 arrays per step)
@@ -161,6 +182,15 @@ class Carver:
         self.slot = self.ring.acquire() if self.ring is not None else None
         self.shadow = 0                                           # demand counted when there is no slot
 
+    def reserve(self, nbytes: int) -> None:
+        """Before the first ``take`` of a ring's FIRST call: the caller's own estimate of the call's demand (an upper bound
+        is fine; an estimate that falls short only means allocator memory for what does not fit, as without it).  The ring
+        then owns a slot from call one -- the addresses, and with them the graph keys, of the first call are those of
+        every later one."""
+        if self.ring is not None and self.slot is None and self.ring.want == 0 and not self.ring.slots and nbytes > 0:
+            self.ring.want = int(nbytes)
+            self.slot = self.ring.acquire()
+
     def take(self, count: int, dtype: torch.dtype) -> Tensor:
         count = int(count)
         if self.slot is not None:
@@ -172,6 +202,8 @@ class Carver:
             nbytes = count * _ESIZE[dtype]
             align = ALIGN_BIG if nbytes >= BIG else ALIGN_SMALL
             self.shadow = (self.shadow + align - 1) // align * align + nbytes
+            with pool_ctx(self.dev):                              # (a ring's first call: see USE_POOL)
+                return torch.empty(max(count, 0), device=self.dev, dtype=dtype)
         return torch.empty(max(count, 0), device=self.dev, dtype=dtype)
 
     def carve(self, sizes: Sequence[int], dtype: torch.dtype) -> list:

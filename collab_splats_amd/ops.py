@@ -759,7 +759,7 @@ def _front_only_wanted(P: Params, dev) -> bool:
 def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg: int, kd: int,
                     n_color: int, per_cam: int, depth_channel: bool, want_aux: bool, want_grad: bool, defer: bool = False,
                     lazy: bool = False, flags: bool = False, absgrad: bool = False, nxq: int = 0, features=None,
-                    probe: bool = False):
+                    probe: bool = False, cd_hint: int = 20):
     """Allocations + phase A of misplat_raster_fwd (``defer``: phase A is launched together with B, by _raster_phase_b).
     Returns (radii, means2d, depths, comps, grec, sh_aux, state)."""
     lib = _lib.load()
@@ -776,6 +776,19 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     indexed = INDEXED_BUCKETS and (INDEXED_BUCKETS == "force" or _front_only_wanted(P, dev)) and rows < (1 << 23)     # (23 index bits + 9 bits of depth code)
     cv = arena.Carver(None if probe else ("fwd", dev.index, _stream_id(), N, Cn, P.width, P.height, kd, int(want_grad), int(want_aux),
                                           int(absgrad), int(depth_channel), int(indexed), int(nxq)), dev)
+    if defer and not probe and _STATIC_CAP is None and _CAP_HINT.get(_cap_key(P, dev)) is not None:
+        # a ring's first call: its demand, summed the way the takes below (and phase B's) go -- 64-element rounding inside a
+        # carve, 256 bytes between takes --, so that the slot exists from call one (arena.Carver.reserve)
+        g_, nd_ = int(bool(want_grad)), int(nxq > 0)
+        n_pix_, units_ = Cn * P.height * P.width, n_tiles * BANDS
+        cap_ = _choose_cap(_cap_key(P, dev), _CAP_HINT[_cap_key(P, dev)])
+        carves = ((2 * rows, rows, rows, 12 * rows * int(bool(want_aux))), (MISPLAT_REC * rows,), (MISPLAT_REC * rows * g_,),
+                  (2 * rows * g_ * int(bool(absgrad)),), (4 * nxq * rows * nd_ * int(not lazy),), (4 * nxq * rows * nd_ * g_,),
+                  (2 * rows, rows, 2 * rows, n_blocks * n_cells, n_cells, n_cells, 4, n_tiles + 1, n_cells + 1, rows, 2 * rows,
+                   (rows + 3) // 4 * g_, rows * int(bool(indexed))),
+                  (cd_hint * n_pix_, n_pix_, n_pix_, n_pix_, 3 * n_pix_), (units_, 8 * ((units_ + 7) // 8)),
+                  (n_pix_, n_pix_, n_tiles + 2, units_, n_tiles, n_tiles), (cap_,), (cap_,), (2 * cap_,))
+        cv.reserve(sum(4 * sum((int(n) + 63) // 64 * 64 for n in c) + 512 for c in carves))
     means2d, depths, comps, sh_aux = _carve_f(dev, (2 * rows, rows, rows, 12 * rows if want_aux else 0), cv)
     grec = cv.take(MISPLAT_REC * rows, torch.float32)
     v_grec_zero = cv.take(MISPLAT_REC * rows, torch.float32).view(rows, MISPLAT_REC) if want_grad else None
@@ -1009,7 +1022,7 @@ class _RasterFused(torch.autograd.Function):
         PATH_STATS["forward_merged_phases"] += int(bool(defer))
         radii, means2d, depths, comps, grec, sh_aux, state = _raster_phase_a(
             P, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam, depth_channel,
-            want_aux, want_grad, defer=defer, lazy=lazy, flags=True, absgrad=bool(absgrad), nxq=nxq, features=features)
+            want_aux, want_grad, defer=defer, lazy=lazy, flags=True, absgrad=bool(absgrad), nxq=nxq, features=features, cd_hint=cd)
         PATH_STATS["forward_nd"] += int(nxq > 0)
         imgs, bins, sched = _raster_phase_b(P, state, cd)
         render, alpha, exp_depth, med_depth, normal, last_ids, median_ids = imgs
@@ -1048,6 +1061,12 @@ class _RasterFused(torch.autograd.Function):
         # the gradients this call hands to autograd, from the backward's own arena ring (they may live on as `.grad` of the
         # caller's parameters: the slot is reused when nothing refers to it any more -- arena.py)
         cvb = arena.Carver(("bwd", dev.index, _stream_id(), P.n_gauss, P.n_cams, kd, int(colors_rest is not None), deg), dev)
+        # (the ring's first call: an upper bound of what the takes below ask for -- every gradient tensor, the packed rows, the
+        # direction gradient, means2d's own tensor)
+        cvb.reserve(sum(4 * ((int(n) + 63) // 64 * 64) + 512 for n in (
+            rows * MISPLAT_REC, colors.numel(), colors_rest.numel() if colors_rest is not None else 0,
+            features.numel() if features is not None else 0, rows * 4 * nxq, means.numel(), means.numel(), quats.numel(),
+            scales.numel(), opacities.numel(), rows * 2)))
         v_grec = bins.pop("v_grec_zero", None)
         flags = 1 if v_grec is not None else 0
         # (rows cleared on first touch by the forward: as good as cleared for a backward that reads flagged rows only)

@@ -2414,7 +2414,8 @@ def test_arena_slots_are_not_recycled_under_tensors_that_are_still_held(dev):
         l.grad = None
     again = call()
     assert again[0].data_ptr() in (ptr0, others[0])
-    assert arena.STATS["slots_created"] - before.get("slots_created", 0) <= 2
+    # (one more forward slot while the first is held, and the backward ring's first slot -- it owns one from its first call)
+    assert arena.STATS["slots_created"] - before.get("slots_created", 0) <= 3
 
 
 def test_sparse_reduce_kernels_bitmaps_union_pack_unpack(dev):
