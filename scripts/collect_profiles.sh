@@ -13,7 +13,7 @@ cp $A/pmc_summary.txt $P/${R}_pmc_summary.txt
 cp $A/pmc_traffic_fixed_ext.json $P/${R}_pmc_traffic_fixed_ext.json
 cp $A/pmc_traffic_cycling.json $P/pmc_traffic.json
 for t in 1M_fixed_ext 1M_cycling_torch 5M_dnloss_fixed 5M_dnloss_cycling 5M_dnloss_fixed_full_sort 1M_dnloss_cycling; do cp $A/timeline_$t.txt $P/${R}_timeline_$t.txt; done
-for b in bench_1M_dnloss bench_1M_dnloss_fixed bench_5M_dnloss bench_5M_dnloss_fixed bench_5M_dnloss_fixed_full_sort bench_5M_dnloss_fixed_buckets \
+for b in bench_10k_graphed_cycling bench_100k_graphed_cycling bench_1M_dnloss bench_1M_dnloss_fixed bench_5M_dnloss bench_5M_dnloss_fixed bench_5M_dnloss_fixed_full_sort bench_5M_dnloss_fixed_buckets \
          bench_5M_dnloss_fixed_buckets_sparse_rehearsal bench_100k bench_10k bench_10k_graphed bench_features; do [ -s $B/$b.json ] && cp $B/$b.json $P/${R}_$b.json; done
 cp $B/timeline_1M_features_fixed.txt $P/${R}_timeline_1M_features_fixed.txt
 cp $B/timeline_1M_features_fixed_dense.txt $P/${R}_timeline_1M_features_fixed_dense.txt
