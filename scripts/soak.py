@@ -12,14 +12,17 @@ from collab_splats_amd.synthetic import random_scene, view_matrix     # (the ben
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 400
 W, H = 1920, 1080
+FEATS = int(os.environ.get("SOAK_FEATURES", "0"))                   # > 0: the features model's call (SH + F feature channels)
 dev = torch.device("cuda:0")
 sc = random_scene(N, W, H, seed=42)
 names = ("means", "quats", "log_scales", "opacity_logits", "sh")
 params = {k: sc[k].to(dev).requires_grad_(True) for k in names}
+if FEATS:
+    params["features"] = torch.rand(N, FEATS, generator=torch.Generator().manual_seed(3)).to(dev).requires_grad_(True)
 views = [view_matrix(v).to(dev) for v in range(8)]
 K = sc["Ks"].to(dev)
 g = torch.Generator().manual_seed(7)
-ups = [torch.rand(s, generator=g).to(dev) for s in ((1, H, W, 4), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3))]
+ups = [torch.rand(s, generator=g).to(dev) for s in ((1, H, W, 4 + FEATS), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3))]
 marks = {}
 front = []                                                           # (tiles sorted in front only, tiles flagged, tiles) of sampled steps
 STEP = float(os.environ.get("SOAK_STEP", "1e-4"))
@@ -35,7 +38,7 @@ for it in range(STEPS):
         p.grad = None
     out = rasterization(params["means"], params["quats"], torch.exp(params["log_scales"]), torch.sigmoid(params["opacity_logits"]),
                         params["sh"], views[it % 8], K, W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased",
-                        return_depth_normal=True)
+                        return_depth_normal=True, **({"features": params["features"]} if FEATS else {}))
     torch.autograd.backward(list(out[:5]), ups)
     part = out[5]["_bins"]["partial"] if it % 8 == 3 else None       # front-only ordering (dense scenes): how stale were the pivots?
     if part is not None:
