@@ -495,7 +495,7 @@ def main():
             info["it"] += 1
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():                  # (world > 1, or a group of one under MISPLAT_FORCE_COLLECTIVES)
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -802,7 +802,7 @@ def main():
                         "the target is counted in rows_over and must be covered by such a pixel (rows_flip) -- "
                         "rows_over_unexplained must be 0")
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -879,7 +879,16 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                 const float r = wave_reduce16(acc, lane);
                 if (ATOMIC) {
                     // one 64-byte contiguous no-return fp32 atomic per (band, Gaussian): 32-bit byte offset from a uniform base
+#if defined(MISPLAT_DIAG_NO_ROW_ATOMICS)
+                    // diagnostic build only (scripts/build_variant.sh): the reduced row is kept alive but leaves the wave nowhere --
+                    // what the kernel costs without its memory-side atomics (verdict round 4, item 7)
+                    asm volatile("" ::"v"(r * out_scale), "v"(slot_off + comp_off));
+#elif defined(MISPLAT_DIAG_ROW_STORES)
+                    // diagnostic build only: plain (racing, wrong) stores instead of atomics -- the same lines dirtied, no read-modify-write
+                    if (writer) *reinterpret_cast<float*>(reinterpret_cast<char*>(slab_b) + (slot_off + comp_off)) = r * out_scale;
+#else
                     if (writer) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(slab_b) + (slot_off + comp_off)), r * out_scale);
+#endif
                     touched_j |= 1ull << j;        // (flagged once per batch, below)
                     if (NXQ > 0) {
                         const float rx = wave_reduce16(accx, lane);

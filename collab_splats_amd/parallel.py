@@ -21,7 +21,7 @@ def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or FORCE_COLLECTIVES) and not dist.is_initialized():    # (FORCE_COLLECTIVES: a group of one that still issues its collectives)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -55,7 +55,13 @@ ALLREDUCE = os.environ.get("MISPLAT_ALLREDUCE", "auto")
 # One-GPU rehearsal (bench.py --buckets): run the flags -> bitmap -> union -> pack -> [no collective] -> unpack path with a
 # world of one, to measure what the sparse reduce costs on the device besides the bytes it saves on the links.
 REHEARSE = os.environ.get("MISPLAT_SPARSE_REHEARSE", "0") == "1"
-STATS: dict = {"dense": 0, "sparse": 0, "rows_reduced": 0, "rows_total": 0, "union_overflow": 0, "host_reads_in_step": 0}
+# A process group of ONE rank normally short-cuts every collective (there is nothing to sum).  With this switch the calls are
+# issued all the same -- uint8 all_gather_into_tensor, the packed all_reduce, reduce_scatter_tensor + all_gather_into_tensor,
+# the dense all_reduce, the early colour launch -- so that one GPU can put the whole sequence through RCCL (dtype, size,
+# stream and ordering errors show up there, not on the first 8-GPU run): tests/test_parity_gpu.py::test_rccl_world_of_one_*.
+FORCE_COLLECTIVES = os.environ.get("MISPLAT_FORCE_COLLECTIVES", "0") == "1"
+STATS: dict = {"dense": 0, "sparse": 0, "rows_reduced": 0, "rows_total": 0, "union_overflow": 0, "host_reads_in_step": 0,
+               "collectives": 0, "geometry_touched_late": 0}
 
 
 class _Done:
@@ -63,8 +69,13 @@ class _Done:
         return True
 
 
+def _collective() -> bool:
+    """True when collectives are to be issued: more than one rank, or a group of one with FORCE_COLLECTIVES."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE_COLLECTIVES)
+
+
 def _gather_bits(gathered: torch.Tensor, bits: torch.Tensor) -> None:
-    if _world() > 1:
+    if _collective():
         dist.all_gather_into_tensor(gathered, bits)
     else:
         gathered.copy_(bits)
@@ -76,8 +87,9 @@ def _backend() -> str:
 
 def _reduce(t: torch.Tensor, async_op: bool):
     """Sum ``t`` (flat fp32, a multiple of the world size long in rs_ag mode) over the ranks, in place."""
-    if _world() <= 1:
+    if not _collective():
         return _Done()
+    STATS["collectives"] += 1
     if ALLREDUCE == "rs_ag" and t.numel() % _world() == 0 and t.numel() > 0:
         chunk = t.numel() // _world()
         mine = torch.empty(chunk, device=t.device, dtype=t.dtype)
@@ -152,9 +164,14 @@ class GradientBuckets:
         # The colour prefix as a tensor of its OWN over the same memory (not a view of ``flat``): its version counter then
         # counts what autograd does to the colour slices alone -- the guard of the early launch.
         self._colour_alias = torch.empty(0, device=dev, dtype=torch.float32).set_(self.flat.untyped_storage(), 0, (self.n_colour,))
+        # ... and the same for the rest of the buffer: autograd accumulating IN PLACE into a geometry slice that the
+        # rasterizer's gradient had become (a regulariser node behind the rasterizer's) shows in THIS counter and nowhere else
+        # (the kernels and the collectives go through raw pointers / through ``flat``).
+        self._geom_alias = torch.empty(0, device=dev, dtype=torch.float32).set_(self.flat.untyped_storage(), 0, (total,))
+        self._geom_version = None
         for i in order:
             n = self.params[i].numel()
-            base = self._colour_alias if i in self.colour else self.flat
+            base = self._colour_alias if i in self.colour else self._geom_alias
             self.views[i] = base[starts[i]:starts[i] + n].view_as(self.params[i])
         self._starts = starts
         self.n_rows = int(self.params[0].shape[0])
@@ -189,7 +206,7 @@ class GradientBuckets:
         self._by_ptr = {p.data_ptr(): i for i, p in enumerate(self.params)}
         self._work, self._reduced, self._nodes_done = [], 0, 0
         self._handed = set()
-        self._touched, self._union, self._colour_version = None, None, None
+        self._touched, self._union, self._colour_version, self._geom_version = None, None, None, None
         self._union_counted, self._pending = False, None
         self.views_per_backward = max(1, int(views_per_backward))
         self.early_colour = bool(early_colour)
@@ -217,7 +234,9 @@ class GradientBuckets:
         the rows that received a gradient in this backward (``misplat_params.touched``)."""
         self._nodes_done += 1
         self._touched = touched if (self._nodes_done == 1 and touched is not None and touched.numel() == self.n_rows) else None
-        if self.views_per_backward != 1 or self._reduced or (_world() <= 1 and not REHEARSE) or not self.early_colour:
+        if self._nodes_done == 1:
+            self._geom_version = self._geom_alias._version
+        if self.views_per_backward != 1 or self._reduced or not (_collective() or REHEARSE) or not self.early_colour:
             return
         if self.colour and all(i in self._handed for i in self.colour):
             self._colour_version = self._colour_alias._version
@@ -225,7 +244,7 @@ class GradientBuckets:
 
     def colour_ready(self) -> None:
         """Two-node / stage-by-stage form: called right after the colour backward kernel has been enqueued."""
-        if self.views_per_backward == 1 and not self._reduced and self.colour and _world() > 1 and self.early_colour \
+        if self.views_per_backward == 1 and not self._reduced and self.colour and _collective() and self.early_colour \
                 and all(i in self._handed for i in self.colour):
             self._colour_version = self._colour_alias._version
             self._launch(self.n_colour)
@@ -264,7 +283,14 @@ class GradientBuckets:
             elif g.data_ptr() != self.views[i].data_ptr():
                 self.views[i].copy_(g)                   # produced by autograd outside the rasterizer (activations)
                 in_place = False
-        if (_world() > 1 or REHEARSE) and self._reduced < self.flat.numel():
+        if in_place and self._geom_version is not None and self._geom_alias._version != self._geom_version:
+            # A slice the rasterizer wrote in place became p.grad, and something later in the same backward was ADDED to it in
+            # place (a scale / opacity regulariser whose node ran after the rasterizer's): rows outside the rasterizer's flags
+            # then carry a gradient too, and the sparse row reduce would leave them unreduced.  The geometry slices have a
+            # version counter of their own for exactly this (advisor, round 4): such a step goes dense.
+            in_place = False
+            STATS["geometry_touched_late"] += 1
+        if (_collective() or REHEARSE) and self._reduced < self.flat.numel():
             self._launch(self.flat.numel(), sparse=(in_place if sparse is None else bool(sparse)))
         for w in self._work:
             self._finish(w)

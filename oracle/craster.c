@@ -809,6 +809,195 @@ void cr_quad_stats(const real* means2d, const real* conics, const real* opac,
     }
 }
 
+/* Design tooling: how many contributing (band, Gaussian) trips of the 16 x 8 band backward reach only ONE 16 x 4 half of
+ * the band (rows 0..3 = the lanes' first pixel, rows 4..7 = their second).  A band's traversal runs from its largest
+ * last_id down to the tile's first entry; an entry is STAGED when the exact minimum of sigma over the band's box of pixel
+ * centres allows alpha >= alpha_min (the kernels' cull, with their 1.002 slack).
+ * out: [0] staged trips, [1] trips in which some pixel contributes, [2] of those, trips whose contributing pixels all lie in
+ * one half, [3] of [1], trips for which a staging-time test (the same box test on each half AND i <= the half's largest
+ * last_id: both wave-uniform) proves that only one half can contribute, [4] contributing pixel pairs, [5] the same
+ * staging-time test over ALL staged trips (the forward's view: no last_id yet -- box test only). */
+static real cr_sigma_min_box(real a, real b, real c, real dxl, real dxh, real dyl, real dyh) {
+    real dxc = RMIN(RMAX(R(0), dxl), dxh), dyc = RMIN(RMAX(R(0), dyl), dyh);
+    real dys = RMIN(RMAX(-b * dxc / c, dyl), dyh);
+    real dxs = RMIN(RMAX(-b * dyc / a, dxl), dxh);
+    real s1 = R(0.5) * (a * dxc * dxc + c * dys * dys) + b * dxc * dys;
+    real s2 = R(0.5) * (a * dxs * dxs + c * dyc * dyc) + b * dxs * dyc;
+    return RMIN(s1, s2);
+}
+void cr_half_stats(const real* means2d, const real* conics, const real* opac,
+                   const int32_t* flatten_ids, const int32_t* offsets, int64_t I,
+                   const cr_params* P, const int32_t* last_ids, int64_t* out) {
+    int ts = P->tile_size;
+    int tw = (P->width + ts - 1) / ts, tht = (P->height + ts - 1) / ts;
+    int nt = tw * tht;
+    for (int k = 0; k < 6; k++) out[k] = 0;
+#pragma omp parallel
+    {
+        int64_t loc[6] = {0, 0, 0, 0, 0, 0};
+#pragma omp for schedule(dynamic, 1)
+        for (int t = 0; t < nt; t++) {
+            int ty = t / tw, tx = t % tw;
+            int64_t beg = offsets[t];
+            (void)I;
+            for (int band = 0; band < 2; band++) {
+                int y0 = ty * ts + band * 8;
+                if (y0 >= P->height) continue;
+                int32_t maxlast = -1, hl[2] = {-1, -1};
+                for (int ly = 0; ly < 8; ly++)
+                    for (int lx = 0; lx < 16; lx++) {
+                        int x = tx * ts + lx, y = y0 + ly;
+                        if (x >= P->width || y >= P->height) continue;
+                        int32_t l = last_ids[(size_t)y * P->width + x];
+                        if (l > maxlast) maxlast = l;
+                        if (l > hl[ly >> 2]) hl[ly >> 2] = l;
+                    }
+                if (maxlast < beg) continue;
+                real xlo = (real)(tx * ts) + R(0.5), xhi = xlo + R(15);
+                for (int64_t i = maxlast; i >= beg; i--) {
+                    int g = flatten_ids[i];
+                    real mx = means2d[2 * g], my = means2d[2 * g + 1];
+                    real cA = conics[3 * g], cB = conics[3 * g + 1], cC = conics[3 * g + 2];
+                    real ylo = (real)y0 + R(0.5);
+                    real smin = cr_sigma_min_box(cA, cB, cC, mx - xhi, mx - xlo, my - (ylo + R(7)), my - ylo);
+                    if (!(opac[g] * EXP(-smin) * R(1.002) >= P->alpha_min)) continue;
+                    loc[0]++;
+                    int con[2] = {0, 0}, box[2];
+                    for (int h = 0; h < 2; h++) {
+                        real yl = ylo + (real)(4 * h);
+                        real sm = cr_sigma_min_box(cA, cB, cC, mx - xhi, mx - xlo, my - (yl + R(3)), my - yl);
+                        box[h] = opac[g] * EXP(-sm) * R(1.002) >= P->alpha_min;
+                    }
+                    for (int ly = 0; ly < 8; ly++)
+                        for (int lx = 0; lx < 16; lx++) {
+                            int x = tx * ts + lx, y = y0 + ly;
+                            if (x >= P->width || y >= P->height) continue;
+                            if ((int32_t)i > last_ids[(size_t)y * P->width + x]) continue;
+                            real px = (real)x + R(0.5), py = (real)y + R(0.5);
+                            real dx = mx - px, dy = my - py;
+                            real sigma = R(0.5) * (cA * dx * dx + cC * dy * dy) + cB * dx * dy;
+                            if (sigma < R(0)) continue;
+                            real a = RMIN(P->alpha_max, opac[g] * EXP(-sigma));
+                            if (a < P->alpha_min) continue;
+                            con[ly >> 2] = 1; loc[4]++;
+                        }
+                    if (box[0] + box[1] == 1) loc[5]++;
+                    if (con[0] | con[1]) {
+                        loc[1]++;
+                        if (con[0] + con[1] == 1) loc[2]++;
+                        int r0 = box[0] && (int32_t)i <= hl[0], r1 = box[1] && (int32_t)i <= hl[1];
+                        if (r0 + r1 == 1) loc[3]++;
+                    }
+                }
+            }
+        }
+#pragma omp critical
+        for (int k = 0; k < 6; k++) out[k] += loc[k];
+    }
+}
+
+/* Design tooling: sub-block reach of the compositing backward for three decompositions of a tile, each counted with the
+ * staging-time, wave-uniform test (box test of the sub-block AND i <= the sub-block's largest last_id) and exactly:
+ *   shape 0: 16x8 band, halves = rows 0..3 / 4..7       shape 1: 16x8 band, halves = columns 0..7 / 8..15
+ *   shape 2: 16x16 tile, quarters = 8x8 quadrants       shape 3: 16x16 tile, quarters = 16x4 row groups
+ * out[shape*8 + k]: k=0 contributing units (band or tile, Gaussian), k=1 sum over them of the sub-blocks that PROVABLY may
+ * contribute, k=2 the same exactly (sub-blocks that do contribute), k=3 staged units (passed the unit-level box test). */
+void cr_subblock_stats(const real* means2d, const real* conics, const real* opac,
+                       const int32_t* flatten_ids, const int32_t* offsets, int64_t I,
+                       const cr_params* P, const int32_t* last_ids, int64_t* out) {
+    int ts = P->tile_size;
+    int tw = (P->width + ts - 1) / ts, tht = (P->height + ts - 1) / ts;
+    int nt = tw * tht;
+    (void)I;
+    for (int k = 0; k < 32; k++) out[k] = 0;
+    /* per shape: unit height, number of units per tile, sub-block (w, h), sub-blocks per unit */
+    static const int UH[4] = {8, 8, 16, 16}, SW[4] = {16, 8, 8, 16}, SH[4] = {4, 8, 8, 4}, NS[4] = {2, 2, 4, 4};
+#pragma omp parallel
+    {
+        int64_t loc[32];
+        for (int k = 0; k < 32; k++) loc[k] = 0;
+#pragma omp for schedule(dynamic, 1)
+        for (int t = 0; t < nt; t++) {
+            int ty = t / tw, tx = t % tw;
+            int64_t beg = offsets[t];
+            int32_t tilemax = -1;
+            for (int ly = 0; ly < 16; ly++)
+                for (int lx = 0; lx < 16; lx++) {
+                    int x = tx * ts + lx, y = ty * ts + ly;
+                    if (x >= P->width || y >= P->height) continue;
+                    int32_t l = last_ids[(size_t)y * P->width + x];
+                    if (l > tilemax) tilemax = l;
+                }
+            if (tilemax < beg) continue;
+            for (int64_t i = tilemax; i >= beg; i--) {
+                int g = flatten_ids[i];
+                real mx = means2d[2 * g], my = means2d[2 * g + 1];
+                real cA = conics[3 * g], cB = conics[3 * g + 1], cC = conics[3 * g + 2];
+                unsigned char con[256];
+                int anyc = 0;
+                for (int ly = 0; ly < 16; ly++)
+                    for (int lx = 0; lx < 16; lx++) {
+                        int x = tx * ts + lx, y = ty * ts + ly;
+                        con[ly * 16 + lx] = 0;
+                        if (x >= P->width || y >= P->height) continue;
+                        if ((int32_t)i > last_ids[(size_t)y * P->width + x]) continue;
+                        real dx = mx - ((real)x + R(0.5)), dy = my - ((real)y + R(0.5));
+                        real sigma = R(0.5) * (cA * dx * dx + cC * dy * dy) + cB * dx * dy;
+                        if (sigma < R(0)) continue;
+                        real a = RMIN(P->alpha_max, opac[g] * EXP(-sigma));
+                        if (a < P->alpha_min) continue;
+                        con[ly * 16 + lx] = 1; anyc = 1;
+                    }
+                (void)anyc;
+                for (int s = 0; s < 4; s++) {
+                    for (int uy = 0; uy < 16; uy += UH[s]) {
+                        int y0 = ty * ts + uy;
+                        if (y0 >= P->height) continue;
+                        real xlo = (real)(tx * ts) + R(0.5), ylo = (real)y0 + R(0.5);
+                        real smin = cr_sigma_min_box(cA, cB, cC, mx - (xlo + R(15)), mx - xlo, my - (ylo + (real)(UH[s] - 1)), my - ylo);
+                        /* unit-level maxlast */
+                        int32_t umax = -1;
+                        for (int ly = uy; ly < uy + UH[s]; ly++)
+                            for (int lx = 0; lx < 16; lx++) {
+                                int x = tx * ts + lx, y = ty * ts + ly;
+                                if (x >= P->width || y >= P->height) continue;
+                                int32_t l = last_ids[(size_t)y * P->width + x];
+                                if (l > umax) umax = l;
+                            }
+                        if ((int32_t)i > umax) continue;
+                        if (!(opac[g] * EXP(-smin) * R(1.002) >= P->alpha_min)) continue;
+                        loc[s * 8 + 3]++;
+                        int uc = 0, prov = 0, exact = 0;
+                        int nsx = 16 / SW[s];
+                        for (int b = 0; b < NS[s]; b++) {
+                            int bx = (b % nsx) * SW[s], by = uy + (b / nsx) * SH[s];
+                            int32_t bmax = -1;
+                            int c = 0;
+                            for (int ly = by; ly < by + SH[s]; ly++)
+                                for (int lx = bx; lx < bx + SW[s]; lx++) {
+                                    int x = tx * ts + lx, y = ty * ts + ly;
+                                    if (x >= P->width || y >= P->height) continue;
+                                    int32_t l = last_ids[(size_t)y * P->width + x];
+                                    if (l > bmax) bmax = l;
+                                    c |= con[ly * 16 + lx];
+                                }
+                            real bxlo = (real)(tx * ts + bx) + R(0.5), bylo = (real)(ty * ts + by) + R(0.5);
+                            real sm = cr_sigma_min_box(cA, cB, cC, mx - (bxlo + (real)(SW[s] - 1)), mx - bxlo,
+                                                       my - (bylo + (real)(SH[s] - 1)), my - bylo);
+                            int box = opac[g] * EXP(-sm) * R(1.002) >= P->alpha_min;
+                            if (box && (int32_t)i <= bmax) prov++;
+                            exact += c; uc |= c;
+                        }
+                        if (uc) { loc[s * 8 + 0]++; loc[s * 8 + 1] += prov; loc[s * 8 + 2] += exact; }
+                    }
+                }
+            }
+        }
+#pragma omp critical
+        for (int k = 0; k < 32; k++) out[k] += loc[k];
+    }
+}
+
 /* ------------------------------------------------------------------ blend backward
  * Gradients are reduced per (tile, Gaussian) first and then added per Gaussian, the shape of
  * the HIP design.  v_* per-Gaussian outputs must be zeroed by the caller. */

@@ -187,6 +187,31 @@ class CRaster:
         return dict(band_units=int(out[0]), sub_units=int(out[1]), trips_every_batch=int(out[2]),
                     trips=int(out[3]), rounds=int(out[4]), batches=int(out[5]))
 
+    def half_stats(self, st) -> Dict:
+        """Share of the 16x8 band backward's contributing trips that reach one 16x4 half only (design tooling; cr_half_stats)."""
+        P, pr, bs = st["P"], st["proj"], st["bins"]
+        ins = [self._a(x) for x in (pr["means2d"], pr["conics"], st["opac"])]
+        fl, of = self._a(bs["flatten_ids"], np.int32), self._a(bs["isect_offsets"], np.int32).reshape(-1)
+        li = self._a(st["fwd"]["last_ids"], np.int32)
+        out = np.zeros(6, np.int64)
+        self.lib.cr_half_stats(*[self._p(a) for a in ins], self._p(fl), self._p(of), C.c_int64(fl.shape[0]),
+                               C.byref(P), self._p(li), self._p(out))
+        return dict(staged=int(out[0]), contributing=int(out[1]), one_half_exact=int(out[2]), one_half_provable=int(out[3]),
+                    pairs=int(out[4]), one_half_box_all_staged=int(out[5]))
+
+    def subblock_stats(self, st) -> Dict:
+        """Sub-block reach of the backward under four decompositions of a tile (design tooling; cr_subblock_stats)."""
+        P, pr, bs = st["P"], st["proj"], st["bins"]
+        ins = [self._a(x) for x in (pr["means2d"], pr["conics"], st["opac"])]
+        fl, of = self._a(bs["flatten_ids"], np.int32), self._a(bs["isect_offsets"], np.int32).reshape(-1)
+        li = self._a(st["fwd"]["last_ids"], np.int32)
+        out = np.zeros(32, np.int64)
+        self.lib.cr_subblock_stats(*[self._p(a) for a in ins], self._p(fl), self._p(of), C.c_int64(fl.shape[0]),
+                                   C.byref(P), self._p(li), self._p(out))
+        names = ("band16x8_rows", "band16x8_cols", "tile_quadrants8x8", "tile_rows16x4")
+        return {n: dict(units=int(out[8 * k]), sub_provable=int(out[8 * k + 1]), sub_exact=int(out[8 * k + 2]),
+                        staged=int(out[8 * k + 3])) for k, n in enumerate(names)}
+
     def blend_bwd(self, P, means2d, conics, opac, colors, ray_ts, ray_planes, normals, flatten_ids,
                   offsets, fwd, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
         N, D = means2d.shape[0], colors.shape[1]

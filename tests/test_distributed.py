@@ -250,6 +250,7 @@ def test_colour_gradient_added_after_the_early_launch_is_refused(monkeypatch):
     the way to run such a step."""
     from collab_splats_amd._lib import MisplatError
     monkeypatch.setattr(parallel, "_world", lambda: 2)                    # (no process group: _launch is stubbed below)
+    monkeypatch.setattr(parallel, "_collective", lambda: True)
     params = [torch.zeros(6, 3, requires_grad=True), torch.zeros(6, 15, 3, requires_grad=True)]
     launched = []
     for early_colour in (True, False):
@@ -269,3 +270,62 @@ def test_colour_gradient_added_after_the_early_launch_is_refused(monkeypatch):
         else:
             bk.allreduce()
             assert torch.equal(params[1].grad, torch.full((6, 15, 3), 3.0))
+
+
+def _regulariser_worker(rank, world, port, n, q):
+    """a regulariser node that runs AFTER the rasterizer's in one backward().  The rasterizer's gradient has become
+    ``p.grad`` (its slice of the buffer, written in place, touched rows only); the regulariser's gradient -- every row, and
+    different on every rank -- is then accumulated IN PLACE at the same address.  The geometry bucket must notice (its slices
+    have a version counter of their own) and travel densely: the sparse row reduce would leave the rows outside the flags
+    as each rank has them, and the replicas would diverge."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    parallel.init_distributed(backend="gloo")
+    parallel.SPARSE = "auto"
+    for k in parallel.STATS:
+        parallel.STATS[k] = 0
+    rows = torch.arange(n)[rank::world][: n // 8]
+    touched = torch.zeros(n, dtype=torch.uint8)
+    touched[rows] = 1
+    params = [torch.zeros(s, requires_grad=True) for s in _shapes(n).values()]
+    bk = parallel.GradientBuckets(params)
+    bk.attach()
+    for i, p in enumerate(params):
+        out = bk.sink(p)
+        out.zero_()
+        out[rows] = _view_grad(100 * rank + i, p.shape)[rows]
+        p.grad = out
+    bk.rasterizer_done(touched)
+    reg = _view_grad(900 + rank, params[1].shape)                     # scale regulariser: all rows, rank-dependent
+    params[1].grad += reg                                             # (what AccumulateGrad does with a stolen gradient)
+    bk.allreduce()
+    expect = torch.zeros(params[1].shape)
+    for r in range(world):
+        rr = torch.arange(n)[r::world][: n // 8]
+        expect[rr] += _view_grad(100 * r + 1, params[1].shape)[rr]
+        expect += _view_grad(900 + r, params[1].shape)
+    digest = torch.cat([p.grad.reshape(-1) for p in params])
+    gathered = [torch.zeros_like(digest) for _ in range(world)]
+    dist.all_gather(gathered, digest)
+    q.put((rank, bool(torch.allclose(params[1].grad, expect, atol=1e-5)), all(torch.equal(gathered[0], t) for t in gathered),
+           dict(parallel.STATS)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_regulariser_behind_the_rasterizer_sends_the_geometry_bucket_densely_gloo_ws2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_regulariser_worker, args=(r, 2, port, 1003, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    for rank, right, same, st in res:
+        assert right, f"rank {rank}: the regulariser's rows were not reduced"
+        assert same, "replicas diverged"
+        assert st["geometry_touched_late"] == 1 and st["sparse"] == 1 and st["dense"] == 1, st   # colour sparse, geometry dense

@@ -1822,6 +1822,39 @@ def test_sparse_reduce_without_a_host_read_and_its_overflow_fallback(dev, monkey
         assert ops.GRAD_SINK is None
 
 
+@pytest.mark.timeout(900)
+def test_rccl_world_of_one_runs_every_collective_of_the_gradient_buckets(dev):
+    """BASELINE configs[4] / SURVEY.md section 8(e): the device branch of ``parallel.GradientBuckets`` through RCCL.  One GPU
+    cannot measure scaling, but it can put every collective the N > 1 path issues through the ``nccl`` backend: a process
+    group of ONE rank with ``parallel.FORCE_COLLECTIVES`` (tests/rccl_world1.py, a child process: the group is initialised
+    before anything else touches the card; the child is started, not exec'd) -- uint8 bitmap all-gather, packed sparse
+    all-reduce (host-sized first step, capacity-sized later steps, overflow fallback), rs_ag's reduce-scatter + all-gather,
+    the dense all-reduce, the early colour launch from inside backward(), a late regulariser gradient on the geometry slices
+    (advisor, round 4: such a step must go dense).  Sum over one rank = identity: results equal what was written, bit for
+    bit, and the rasterizer's own no-collective gradients to the order of its atomic sums."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_world1.py")
+    r = subprocess.run([sys.executable, child, str(port)], env=env, capture_output=True, text=True, timeout=800)
+    tail = (r.stdout[-3000:] + "\n---- stderr ----\n" + r.stderr[-3000:])
+    assert r.returncode == 0, tail
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RCCL_WORLD1 ")]
+    assert lines, tail
+    res = json.loads(lines[-1][len("RCCL_WORLD1 "):])
+    assert res["ok"] and res["backend"] == "nccl"
+    assert res["rasterizer_max_rel_err_vs_no_sink"] < 2e-5
+    assert all(c["stats"]["collectives"] > 0 for c in res["cases"].values())
+
+
 def test_large_scene_entirely_out_of_view_gives_zero_gradients(dev):
     """No intersection at all in a scene large enough for the background-fill path (>= 262 144 Gaussians): the compositing
     backward has no grid to carry the fill, the zeros are then written by plain fill launches -- every gradient is
