@@ -28,7 +28,10 @@ SOURCES = {
     "binning.hip": [],
     "bucket.hip": [],
     "raster.hip": [],
-    "blend.hip": [],
+    # blend.hip: the compositing loops are written for the issue slots they cost -- packed (v_pk_*) where two pixels run, plain
+    # where one does; the SLP vectoriser re-packs the one-pixel bodies across unrelated values (103 packed + 83 moves in the
+    # backward's trip loop, 154 registers; without it 37 + 17 and 115)
+    "blend.hip": ["-fno-slp-vectorize"],
     "epilogue.hip": [],
     "ssim.hip": [],
     "optim.hip": [],

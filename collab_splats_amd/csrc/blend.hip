@@ -99,10 +99,13 @@ __device__ __forceinline__ bool band_ctx(const misplat_params& P, const float* _
 // Exact minimum of sigma(d) = 0.5 (a dx^2 + c dy^2) + b dx dy over the box d in [dxl,dxh] x [dyl,dyh]
 // (d = mean2d - pixel centre): 0 if the mean is inside, else the minimum lies on one of the two box
 // faces nearest to the mean (convexity).
-__device__ __forceinline__ float sigma_min_box(float a, float b, float c, float dxl, float dxh, float dyl, float dyh) {
+// nb_c = -b / c, nb_a = -b / a: the slopes of the two lines of stationary points (hardware reciprocals will do: the slopes
+// only place the candidate points, and the minimum is second-order flat around them; the test has 0.2 % of slack).
+__device__ __forceinline__ float sigma_min_box(float a, float b, float c, float nb_c, float nb_a, float dxl, float dxh, float dyl,
+                                               float dyh) {
     const float dxc = fminf(fmaxf(0.f, dxl), dxh), dyc = fminf(fmaxf(0.f, dyl), dyh);
-    const float dys = fminf(fmaxf(-b * dxc / c, dyl), dyh);
-    const float dxs = fminf(fmaxf(-b * dyc / a, dxl), dxh);
+    const float dys = fminf(fmaxf(nb_c * dxc, dyl), dyh);
+    const float dxs = fminf(fmaxf(nb_a * dyc, dxl), dxh);
     const float s1 = 0.5f * (a * dxc * dxc + c * dys * dys) + b * dxc * dys;
     const float s2 = 0.5f * (a * dxs * dxs + c * dyc * dyc) + b * dxs * dyc;
     return fminf(s1, s2);
@@ -186,25 +189,46 @@ __device__ __forceinline__ float4 lazy_colour(const LazyColour& lz, int g) {
     return q3;
 }
 
-template <int NXQ = 0, bool LAZY = false>
-__device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_slot, int lane, int i, bool valid,
+// Sub-blocks (round 5).  The band's 16 x 8 pixels are two 8 x 8 HALVES (columns 0..7 | 8..15 of the tile): lane l owns
+// pixel (l & 7, l >> 3) of each half.  Every staged record carries a 2-bit mask of the halves whose pixel box it can reach with
+// alpha >= alpha_min (the same exact-minimum test, per half): the staged Gaussian is wave-uniform in the trip loops, so "run the
+// body of half h" is a real scalar branch, and a half that the Gaussian cannot reach -- or whose pixels have all terminated
+// (forward) / all ended in front of this entry (backward) -- costs nothing.  Measured on the headline's eight views with the C
+// port (scripts/half_band_stats.py, cr_subblock_stats): 34 - 47 % of the contributing (band, Gaussian) trips need ONE half;
+// halves of 16 x 4 (the lane's two pixels four rows apart, the layout of rounds 1 - 4): 20 - 30 %.  The union of the two
+// boxes of pixel centres has a gap of one pixel pitch that the band box covered: the cull got tighter, not looser.
+template <int NXQ = 0, bool LAZY = false, bool HALVES = false>
+__device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_slot, int* sm_sub, int lane, int i, bool valid,
                                              const float4* grec,
                                              const int32_t* __restrict__ flatten_ids,
                                              const int32_t* __restrict__ slots, float xlo, float xhi,
                                              float ylo, float yhi, float alpha_min,
                                              float4* smx = nullptr, const float4* __restrict__ featx = nullptr,
-                                             const LazyColour* lz = nullptr, const FeatSrc* fs = nullptr) {
+                                             const LazyColour* lz = nullptr, const FeatSrc* fs = nullptr, int* n_both = nullptr) {
     float4 q0, q1, q2, q3;
     bool keep = false;
     int slot = 0;
     int g = 0;
+    int sub = 0;
     if (valid) {
         g = flatten_ids[i];
         q0 = grec[4 * (size_t)g + 0]; q1 = grec[4 * (size_t)g + 1];
         q2 = grec[4 * (size_t)g + 2]; q3 = grec[4 * (size_t)g + 3];
         if (slots) slot = slots[i]; else slot = g;
-        const float smin = sigma_min_box(q0.z, q0.w, q1.x, q0.x - xhi, q0.x - xlo, q0.y - yhi, q0.y - ylo);
-        keep = q1.y * __builtin_amdgcn_exp2f(-smin * kLog2e) * 1.002f >= alpha_min;
+        if (HALVES) {
+            const float xmid = xlo + 7.0f;                     // (xhi = xlo + 15: left half [xlo, xlo+7], right half [xlo+8, xhi])
+            const float nb_c = -q0.w * __builtin_amdgcn_rcpf(q1.x), nb_a = -q0.w * __builtin_amdgcn_rcpf(q0.z);
+            const float s0 = sigma_min_box(q0.z, q0.w, q1.x, nb_c, nb_a, q0.x - xmid, q0.x - xlo, q0.y - yhi, q0.y - ylo);
+            const float s1 = sigma_min_box(q0.z, q0.w, q1.x, nb_c, nb_a, q0.x - xhi, q0.x - (xmid + 1.0f), q0.y - yhi, q0.y - ylo);
+            const float bound = q1.y * 1.002f;
+            sub = (bound * __builtin_amdgcn_exp2f(-s0 * kLog2e) >= alpha_min ? 1 : 0) |
+                  (bound * __builtin_amdgcn_exp2f(-s1 * kLog2e) >= alpha_min ? 2 : 0);
+            keep = sub != 0;
+        } else {
+            const float smin = sigma_min_box(q0.z, q0.w, q1.x, -q0.w * __builtin_amdgcn_rcpf(q1.x), -q0.w * __builtin_amdgcn_rcpf(q0.z),
+                                             q0.x - xhi, q0.x - xlo, q0.y - yhi, q0.y - ylo);
+            keep = q1.y * __builtin_amdgcn_exp2f(-smin * kLog2e) * 1.002f >= alpha_min;
+        }
     }
     if (LAZY) {
         // (a real call, not inlined: the evaluation needs ~100 registers that the compositing loop must not pay for)
@@ -215,11 +239,13 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
             q3 = lazy_colour<NXQ>(*lz, g);
     }
     const unsigned long long mask = __ballot(keep);
+    if (HALVES && n_both) *n_both = __popcll(__ballot(sub == 3));
     if (keep) {
         const int pos = __popcll(mask & ((1ull << lane) - 1ull));
         q0.z *= -0.5f * kLog2e; q0.w *= -kLog2e; q1.x *= -0.5f * kLog2e;
         sm[pos] = q0; sm[64 + pos] = q1; sm[128 + pos] = q2; sm[192 + pos] = q3;
         sm_idx[pos] = i;
+        if (HALVES && sm_sub) sm_sub[pos] = sub;
         if (sm_slot) sm_slot[pos] = slot;      // emission slot (slab mode) or Gaussian row (atomic mode)
         if (NXQ > 0 && fs && fs->features) {
             const float* fr = fs->features + (size_t)g * fs->n_feat;       // (one camera: row = Gaussian; the launchers check)
@@ -242,8 +268,21 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
     return __popcll(mask);
 }
 
+// The exponent of a pair, e = -sigma log2(e) = A' dx^2 + B' dx dy + C' dy^2 with the staged (pre-multiplied) conic, from the
+// half-independent terms of the trip (bdy = B' dy, ecc = C' dy^2): written with explicit fused operations so that the forward
+// and the backward -- which must take the same side of every threshold for the same pair -- evaluate the same bits.
+__device__ __forceinline__ float pair_exponent(float a_, float dx, float bdy, float ecc) {
+    return __builtin_fmaf(__builtin_fmaf(a_, dx, bdy), dx, ecc);
+}
+template <int K> struct KC { static constexpr int value = K; };
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f fma2(float a, v2f b, v2f c) { return __builtin_elementwise_fma(mk2(a, a), b, c); }
+__device__ __forceinline__ v2f fma2(float a, v2f b, float c) { return __builtin_elementwise_fma(mk2(a, a), b, mk2(c, c)); }
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, float c) { return __builtin_elementwise_fma(a, b, mk2(c, c)); }
+__device__ __forceinline__ v2f fma2(v2f a, float b, v2f c) { return __builtin_elementwise_fma(a, mk2(b, b), c); }
+__device__ __forceinline__ float dot2(v2f a, v2f b) { return __builtin_fmaf(a.y, b.y, a.x * b.x); }
 
 // Forward.  The per-pixel loop is branch-free: a pixel that has terminated carries T = 0 (its
 // transmittance at termination is parked in Tfin), so every later weight w = a*T vanishes by itself;
@@ -310,19 +349,24 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
     fsrc.features = lz.features; fsrc.depths = lz.depths; fsrc.n_feat = lz.n_feat; fsrc.depth_channel = lz.depth_channel;
     fsrc.n_gauss = lz.n_gauss;
     const int lane = threadIdx.x;
-    const int x = c.tx * MISPLAT_TILE + (lane & 15);
-    const int ybase = c.y0 + (lane >> 4);
-    const float px = (float)x + 0.5f;
-    const float rxn = (px - c.cx) / c.fx;
-    float py[PPL], inv_ell[PPL], T[PPL], Tfin[PPL], dep[PPL], med[PPL], col[PPL][CD], nrm[PPL][3];
-    int last[PPL], medi[PPL];
+    // lane -> pixel (lane & 7, lane >> 3) of each 8 x 8 half of the band: pixel k of the lane sits at column 8 k + (lane & 7).
+    // The halves are what the BACKWARD's trips skip (see stage_records); here every trip runs the lane's two pixels in packed
+    // instructions -- a forward that branches on the halves was built and measured (round 5): its accumulators are pixel
+    // pairs either way, the three-way control flow costs the compiler ~20 register copies per trip, 0.33 -> 0.40 ms.
+    // Both kernels evaluate a pair's exponent with the same fused operations (pair_exponent / its packed form), so that a
+    // pair is on the same side of every threshold in the forward and in the backward.
+    const int y = c.y0 + (lane >> 3);
+    const float py = (float)y + 0.5f;
+    const float ryn = (py - c.cy) / c.fy;
+    float px[PPL], inv_ell[PPL], T[PPL], Tfin[PPL], dep[PPL], med[PPL], col[PPL][CD], nrm[PPL][3];
+    int xk[PPL], last[PPL], medi[PPL];
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
-        const int y = ybase + 4 * k;
-        py[k] = (float)y + 0.5f;
-        const float ryn = (py[k] - c.cy) / c.fy;
+        xk[k] = c.tx * MISPLAT_TILE + 8 * k + (lane & 7);
+        px[k] = (float)xk[k] + 0.5f;
+        const float rxn = (px[k] - c.cx) / c.fx;
         inv_ell[k] = 1.0f / sqrtf(rxn * rxn + ryn * ryn + 1.0f);
-        const bool inside = x < P.width && y < P.height;
+        const bool inside = xk[k] < P.width && y < P.height;
         T[k] = inside ? 1.0f : 0.0f;           // T == 0  <=>  pixel finished
         Tfin[k] = 1.0f; dep[k] = 0.f; med[k] = 0.f; last[k] = -1; medi[k] = -1;
 #pragma unroll
@@ -338,12 +382,12 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
     static_assert(PPL % 2 == 0, "the compositing loops work on pixel pairs");
     constexpr int NP = PPL / 2;
     constexpr int NXF = NXQ > 0 ? 4 * NXQ : 1;
-    v2f py2[NP], il2[NP], T2[NP], dep2[NP], med2[NP], col2[NP][CD], nrm2[NP][3], colx2[NP][NXF];
+    v2f px2[NP], il2[NP], T2[NP], dep2[NP], med2[NP], col2[NP][CD], nrm2[NP][3], colx2[NP][NXF];
     {
 #pragma unroll
         for (int kp = 0; kp < NP; kp++) {
             const int k0 = 2 * kp, k1 = 2 * kp + 1;
-            py2[kp] = mk2(py[k0], py[k1]); il2[kp] = mk2(inv_ell[k0], inv_ell[k1]);
+            px2[kp] = mk2(px[k0], px[k1]); il2[kp] = mk2(inv_ell[k0], inv_ell[k1]);
             T2[kp] = mk2(T[k0], T[k1]);
             dep2[kp] = mk2(0.f, 0.f); med2[kp] = mk2(0.f, 0.f);
 #pragma unroll
@@ -381,12 +425,13 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
             if (any == 0ull) break;
         }
         __syncthreads();
-        const int n = stage_records<NXQ, LAZY>(sm, sm_idx, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
-                                               nullptr, xlo, xhi, ylo, yhi, amin, smx, featx, &lz, (LAZY && NXQ > 0) ? &fsrc : nullptr);
+        int n_both = 0;
+        const int n = stage_records<NXQ, LAZY, true>(sm, sm_idx, nullptr, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
+                                                     nullptr, xlo, xhi, ylo, yhi, amin, smx, featx, &lz, (LAZY && NXQ > 0) ? &fsrc : nullptr, &n_both);
         __syncthreads();
         reach_end = min(bs + 64, c.end);
         if (n == 0) continue;
-        work += n;
+        work += 2 * n + n_both;           // (what the backward will pay for these entries: 3 per two-half trip, 2 per one-half trip)
         // LDS latency is hidden without a second register set: the half of the record consumed late (q2, q3 =
         // ray plane / normal / colour, and the index) is read at the top of its own iteration, the half consumed
         // early (q0, q1 = mean, conic, opacity) is read for the NEXT Gaussian as soon as this one's alpha is known.
@@ -400,17 +445,16 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
 #pragma unroll
             for (int q = 0; q < NXQ; q++) xq[q] = smx[q * 64 + j];
             __builtin_amdgcn_sched_barrier(0);
-            const float dx = q0.x - px;
-            const float ea = q0.z * dx * dx, eb = q0.w * dx;
-            const float tpx = q1.z - q1.w * dx;
+            const float dy = q0.y - py;
+            const float ecc = (q1.x * dy) * dy, bdy = q0.w * dy;
             {
                 // two pixels of the lane per packed instruction (see blend_bwd_kernel)
-                v2f dy_[NP], a_[NP];
+                v2f dx_[NP], a_[NP];
                 lmask ok_[PPL];
 #pragma unroll
                 for (int kp = 0; kp < NP; kp++) {
-                    const v2f dy = q0.y - py2[kp];
-                    const v2f e = ea + (q1.x * dy + eb) * dy;
+                    const v2f dx = q0.x - px2[kp];
+                    const v2f e = fma2(fma2(q0.z, dx, bdy), dx, ecc);
                     v2f vis;
                     vis.x = __builtin_amdgcn_exp2f(e.x); vis.y = __builtin_amdgcn_exp2f(e.y);
                     const v2f ov = q1.y * vis;
@@ -424,15 +468,16 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
                     const lmask ok1 = alive[2 * kp + 1] & __ballot(e.y <= 0.f) & __ballot(am1 >= amin);
                     v2f a;
                     a.x = MISPLAT_LANE(ok0) ? am0 : 0.f; a.y = MISPLAT_LANE(ok1) ? am1 : 0.f;
-                    dy_[kp] = dy; a_[kp] = a; ok_[2 * kp] = ok0; ok_[2 * kp + 1] = ok1;
+                    dx_[kp] = dx; a_[kp] = a; ok_[2 * kp] = ok0; ok_[2 * kp + 1] = ok1;
                 }
+                const float q1z = q1.z, q1w = q1.w;
                 q0 = sm[j + 1]; q1 = sm[64 + j + 1];                   // next Gaussian (array padded)
                 __builtin_amdgcn_sched_barrier(0);
                 lmask any_alive = 0ull;
 #pragma unroll
                 for (int kp = 0; kp < NP; kp++) {
                     const int k0 = 2 * kp, k1 = 2 * kp + 1;
-                    const v2f dy = dy_[kp], a = a_[kp];
+                    const v2f dx = dx_[kp], a = a_[kp];
                     const v2f Tk = T2[kp];
                     v2f w = a * Tk;                                      // (a = 0 for a finished pixel: its T stays as it is)
                     const v2f Tn = Tk - w;
@@ -442,7 +487,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
                     w.x = MISPLAT_LANE(stop0) ? 0.f : w.x; w.y = MISPLAT_LANE(stop1) ? 0.f : w.y;
                     alive[k0] &= ~stop0; alive[k1] &= ~stop1;
                     any_alive |= alive[k0] | alive[k1];
-                    const v2f zp = (tpx - q2.x * dy) * il2[kp];
+                    const v2f zp = ((q1z - q2.x * dy) - q1w * dx) * il2[kp];     // (q2 is consumed late: its LDS read hides behind alpha)
                     col2[kp][0] += w * q3.x;
                     if (CD > 1) col2[kp][CD > 1 ? 1 : 0] += w * q3.y;
                     if (CD > 2) col2[kp][CD > 2 ? 2 : 0] += w * q3.z;
@@ -510,9 +555,8 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
     }
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
-        const int y = ybase + 4 * k;
-        if (x < P.width && y < P.height) {
-            const size_t pid = ((size_t)c.cam * P.height + y) * P.width + x;
+        if (xk[k] < P.width && y < P.height) {
+            const size_t pid = ((size_t)c.cam * P.height + y) * P.width + xk[k];
             const float al = 1.0f - (T[k] > 0.f ? T[k] : Tfin[k]);
             const float inv_al = 1.0f / fmaxf(al, 1e-10f);
             if (NXQ == 0) {
@@ -629,7 +673,7 @@ template <int CD, int PPL, bool ABS, bool ATOMIC, int NXQ = 0>
 #ifndef MISPLAT_BWD_WAVES
 #define MISPLAT_BWD_WAVES 5
 #endif
-__global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (PPL == 4 ? 3 : (NXQ > 0 ? 4 : 1))) void blend_bwd_kernel(
+__global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (NXQ > 0 ? 4 : 1)) void blend_bwd_kernel(
     misplat_params P, const float* __restrict__ Ks, const float4* __restrict__ grec,
     const int32_t* __restrict__ flatten_ids, const int32_t* __restrict__ slots,
     const int32_t* __restrict__ offsets, int64_t n_isects, const float* __restrict__ alpha,
@@ -640,6 +684,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
     uint8_t* __restrict__ valid, const float4* __restrict__ featx = nullptr, float* __restrict__ v_featx = nullptr,
     int n_channels = CD, misplat_internal::FillList F = {}, FeatSrc fsrc = FeatSrc()) {
     static_assert(NXQ == 0 || ATOMIC, "N-D colours: atomic gradient mode only");
+    static_assert(PPL == 2, "a band is two 8 x 8 halves, one pixel of each per lane");
     // Background role (F.blocks > 0): the last workgroups of the grid -- dispatched when the machine starts to drain --
     // or (at_head: fills too large for the tail) the first ones clear the tensors the per-Gaussian backward kernels write
     // sparsely afterwards: memory-bound waves beside this kernel's issue-bound ones, no launch, no graph branch.
@@ -647,42 +692,41 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
     __shared__ float4 sm[4 * 64 + 4];
     __shared__ int sm_idx[64 + 4];
     __shared__ int sm_slot[64 + 4];
+    __shared__ int sm_sub[64 + 4];
     __shared__ float4 smx[NXQ > 0 ? NXQ * 64 + 4 : 1];
     constexpr int NX = NXQ > 0 ? 4 * NXQ : 1;
-    float vcolx[PPL][NX];
-#pragma unroll
-    for (int k = 0; k < PPL; k++)
-#pragma unroll
-        for (int ch = 0; ch < NX; ch++) vcolx[k][ch] = 0.f;
     const size_t rstride = NXQ > 0 ? (size_t)n_channels : (size_t)CD;
     BandCtx c;
     if (!band_ctx<PPL>(P, Ks, offsets, n_isects, c, F.at_head ? F.blocks : 0)) return;
     if (c.end <= c.beg) return;
     const int lane = threadIdx.x;
-    const int x = c.tx * MISPLAT_TILE + (lane & 15);
-    const int ybase = c.y0 + (lane >> 4);
-    const float px = (float)x + 0.5f;
-    const float rxn = (px - c.cx) / c.fx;
-    float py[PPL], inv_ell[PPL], T[PPL], tfva[PPL], B[PPL], vcol[PPL][CD], vn[PPL][3], vd[PPL], vm[PPL];
-    int last[PPL], medi[PPL];
-    int mymax = -1;
+    // lane -> pixel (lane & 7, lane >> 3) of each 8 x 8 half (see stage_records); the lane's two pixels as 2-vectors, a trip
+    // that reaches both halves in packed instructions, a trip that reaches one on component k (see blend_fwd_kernel)
+    const int y = c.y0 + (lane >> 3);
+    const float py = (float)y + 0.5f;
+    const float ryn = (py - c.cy) / c.fy;
+    v2f px2, il2, T2, D2, vd2, vm2, vcol2[CD], vn2[3], vcolx2[NX];   // D2 = T_final v_alpha - (what the pixels behind have composited) . v
+    int last[PPL], medi[PPL], sublast[PPL];
+#pragma unroll
+    for (int ch = 0; ch < CD; ch++) vcol2[ch] = mk2(0.f, 0.f);
+#pragma unroll
+    for (int ch = 0; ch < NX; ch++) vcolx2[ch] = mk2(0.f, 0.f);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) vn2[ch] = mk2(0.f, 0.f);
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
-        const int y = ybase + 4 * k;
-        py[k] = (float)y + 0.5f;
-        const float ryn = (py[k] - c.cy) / c.fy;
-        inv_ell[k] = 1.0f / sqrtf(rxn * rxn + ryn * ryn + 1.0f);
-        last[k] = -1; medi[k] = -1; T[k] = 1.f; tfva[k] = 0.f; B[k] = 0.f; vd[k] = 0.f; vm[k] = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < CD; ch++) vcol[k][ch] = 0.f;
-        vn[k][0] = vn[k][1] = vn[k][2] = 0.f;
+        const int x = c.tx * MISPLAT_TILE + 8 * k + (lane & 7);
+        px2[k] = (float)x + 0.5f;
+        const float rxn = (px2[k] - c.cx) / c.fx;
+        il2[k] = 1.0f / sqrtf(rxn * rxn + ryn * ryn + 1.0f);
+        last[k] = -1; medi[k] = -1; T2[k] = 1.f; D2[k] = 0.f; vd2[k] = 0.f; vm2[k] = 0.f;
         if (x < P.width && y < P.height) {
             const size_t pid = ((size_t)c.cam * P.height + y) * P.width + x;
             last[k] = last_ids[pid];
             medi[k] = median_ids[pid];
             const float al = alpha[pid];
             const float Tf = 1.0f - al;
-            T[k] = Tf;
+            T2[k] = Tf;
             float va = v_alpha[pid];
 #pragma unroll
             for (int ch = 0; ch < CD; ch++) {
@@ -692,7 +736,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                     g *= inv_al;
                     if (al > 1e-10f) va -= g * render[pid * rstride + ch];
                 }
-                vcol[k][ch] = g;
+                vcol2[ch][k] = g;
             }
 #pragma unroll
             for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) {
@@ -703,37 +747,19 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                         g *= inv_al;
                         if (al > 1e-10f) va -= g * render[pid * rstride + CD + ch];
                     }
-                    vcolx[k][ch] = g;
+                    vcolx2[ch][k] = g;
                 }
             }
-            tfva[k] = Tf * va;
-            vn[k][0] = v_normal[pid * 3]; vn[k][1] = v_normal[pid * 3 + 1]; vn[k][2] = v_normal[pid * 3 + 2];
-            vd[k] = v_exp_depth[pid];
-            vm[k] = v_med_depth[pid];
+            D2[k] = Tf * va;
+            vn2[0][k] = v_normal[pid * 3]; vn2[1][k] = v_normal[pid * 3 + 1]; vn2[2][k] = v_normal[pid * 3 + 2];
+            vd2[k] = v_exp_depth[pid];
+            vm2[k] = v_med_depth[pid];
         }
-        mymax = max(mymax, last[k]);
+        // (wave-uniform, and in a SCALAR register: the deepest entry any pixel of half k composited)
+        sublast[k] = __builtin_amdgcn_readfirstlane(wave_max(last[k]));
     }
-    const int maxlast = wave_max(mymax);
+    const int maxlast = max(sublast[0], sublast[1]);
     if (maxlast < c.beg) return;
-    // pixel pairs (k = 2 kp, 2 kp + 1) as 2-vectors for the packed-math loop (even PPL)
-    static_assert(PPL % 2 == 0, "the compositing loops work on pixel pairs");
-    constexpr int NP = PPL / 2;
-    v2f py2[NP], il2[NP], T2[NP], B2[NP], tf2[NP], vd2[NP], vm2[NP], vcol2[NP][CD], vn2[NP][3], vcolx2[NP][NX];
-    {
-#pragma unroll
-        for (int kp = 0; kp < NP; kp++) {
-            const int k0 = 2 * kp, k1 = 2 * kp + 1;
-            py2[kp] = mk2(py[k0], py[k1]); il2[kp] = mk2(inv_ell[k0], inv_ell[k1]);
-            T2[kp] = mk2(T[k0], T[k1]); B2[kp] = mk2(B[k0], B[k1]); tf2[kp] = mk2(tfva[k0], tfva[k1]);
-            vd2[kp] = mk2(vd[k0], vd[k1]); vm2[kp] = mk2(vm[k0], vm[k1]);
-#pragma unroll
-            for (int ch = 0; ch < CD; ch++) vcol2[kp][ch] = mk2(vcol[k0][ch], vcol[k1][ch]);
-#pragma unroll
-            for (int ch = 0; ch < 3; ch++) vn2[kp][ch] = mk2(vn[k0][ch], vn[k1][ch]);
-#pragma unroll
-            for (int ch = 0; ch < NX; ch++) vcolx2[kp][ch] = mk2(vcolx[k0][ch], vcolx[k1][ch]);
-        }
-    }
     const int comp = butterfly_comp(lane);
     const bool writer = (lane & 3) == 0;          // one lane per quad holds (and writes) component `comp`
     // per-lane scale undoing the conic pre-multiplication (component = record layout index)
@@ -747,124 +773,168 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
     float* slab_b = ATOMIC ? slab : slab + (size_t)c.band * (size_t)n_isects * MISPLAT_REC;
     float* abs_b = ABS ? (ATOMIC ? slab_abs : slab_abs + (size_t)c.band * (size_t)n_isects * 2) : nullptr;
     uint8_t* valid_b = ATOMIC ? nullptr : valid + (size_t)c.band * (size_t)n_isects;
+    typedef unsigned long long lmask;
 
     for (int b = (maxlast - c.beg) >> 6; b >= 0; b--) {
         const int bs = c.beg + (b << 6);
         __syncthreads();
-        const int n = stage_records<NXQ>(sm, sm_idx, sm_slot, lane, bs + lane, bs + lane <= maxlast, grec, flatten_ids,
+        const int n = stage_records<NXQ, false, true>(sm, sm_idx, sm_slot, sm_sub, lane, bs + lane, bs + lane <= maxlast, grec, flatten_ids,
                                          ATOMIC ? nullptr : slots, xlo, xhi, ylo, yhi, amin, smx, featx, nullptr,
                                          NXQ > 0 ? &fsrc : nullptr);
         __syncthreads();
         if (n == 0) continue;
         // does any pixel of the band take its median depth from a Gaussian of this batch?
-        bool mine_med = false;
-#pragma unroll
-        for (int k = 0; k < PPL; k++) mine_med |= (unsigned)(medi[k] - bs) < 64u;
-        const bool batch_has_median = __ballot(mine_med) != 0ull;
+        const bool batch_has_median = __ballot(((unsigned)(medi[0] - bs) < 64u) | ((unsigned)(medi[1] - bs) < 64u)) != 0ull;
         // The record of the next Gaussian is fetched from LDS into the SAME registers right after the last
         // use of the current one (before the butterfly, which hides the latency): no second register set
         // and no copies.
         float4 q0 = sm[n - 1], q1 = sm[64 + n - 1], q2 = sm[128 + n - 1], q3 = sm[192 + n - 1];
-        int i = sm_idx[n - 1], islot = sm_slot[n - 1];
+        int iv = sm_idx[n - 1], islot = sm_slot[n - 1], subv = sm_sub[n - 1];
         unsigned long long touched_j = 0ull;       // staged entries of this batch that received a gradient row
         for (int j = n - 1; j >= 0; j--) {
-            float4 xq[NXQ > 0 ? NXQ : 1];
-#pragma unroll
-            for (int q = 0; q < NXQ; q++) xq[q] = smx[q * 64 + j];
-            const float dx = q0.x - px;
-            const float ea = q0.z * dx * dx, eb = q0.w * dx;
-            const float tpx = q1.z - q1.w * dx;
+            // The halves this trip has to run: those the staged box test admits AND whose pixels reach this deep
+            // (i <= the half's deepest last_id) -- all wave-uniform, so a real scalar branch per half.
+            const int i = __builtin_amdgcn_readfirstlane(iv);
+            const int sub = __builtin_amdgcn_readfirstlane(subv) & ((i <= sublast[0] ? 1 : 0) | (i <= sublast[1] ? 2 : 0));
             float acc[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[r] = 0.f;
             float accx[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) accx[r] = 0.f;
             float ab0 = 0.f, ab1 = 0.f;
-            unsigned long long any_ok = 0ull;      // lanes with a contributing pixel
-            {
-                // Two pixels of the lane at a time in 2-vectors (v_pk_{fma,mul,add}_f32) for the per-pixel chain.
-                // The per-pixel decisions are lane masks in scalar registers (one ballot per vector compare, combined
-                // with scalar ANDs, turned back into select conditions with inverse_ballot): see blend_fwd_kernel.
-                const float dxx = dx * dx, ndx = -dx;
-                const float c1x = 2.0f * q0.z * dx, c1y = q0.w * dx;
+            lmask any_ok = 0ull;                   // lanes with a contributing pixel
+            if (sub != 0) {
+                float4 xq[NXQ > 0 ? NXQ : 1];
 #pragma unroll
-                for (int kp = 0; kp < PPL / 2; kp++) {
-                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
-                    const v2f dy = q0.y - py2[kp];
-                    const v2f e = ea + (q1.x * dy + eb) * dy;
+                for (int q = 0; q < NXQ; q++) xq[q] = smx[q * 64 + j];
+                // terms that do not depend on the half (the lane's two pixels share their row)
+                const float dy = q0.y - py;
+                const float bdy = q0.w * dy, ecc = (q1.x * dy) * dy;
+                const float tpy = q1.z - q2.x * dy;
+                if (sub == 3) {
+                    // ---- both halves: the lane's two pixels in packed instructions (v_pk_{fma,mul,add}_f32); the per-pixel
+                    // decisions are lane masks in scalar registers (one ballot per vector compare, combined with scalar ANDs,
+                    // turned back into select conditions with inverse_ballot): see blend_fwd_kernel
+                    const float dyy = dy * dy, ndy = -dy;
+                    const float c1y = 2.0f * q1.x * dy;
+                    const v2f dx = q0.x - px2;
+                    const v2f e = fma2(fma2(q0.z, dx, bdy), dx, ecc);
                     v2f vis;
                     vis.x = __builtin_amdgcn_exp2f(e.x); vis.y = __builtin_amdgcn_exp2f(e.y);
                     const v2f ov = q1.y * vis;
                     // min(alpha_max, o vis) as an unsigned minimum of the bit patterns (non-negative floats; a NaN fails e <= 0)
                     const float am0 = __uint_as_float(min(amax_bits, __float_as_uint(ov.x)));
                     const float am1 = __uint_as_float(min(amax_bits, __float_as_uint(ov.y)));
-                    const unsigned long long okm0 = __ballot(i <= last[k0]) & __ballot(e.x <= 0.f) & __ballot(am0 >= amin);
-                    const unsigned long long okm1 = __ballot(i <= last[k1]) & __ballot(e.y <= 0.f) & __ballot(am1 >= amin);
-                    any_ok |= okm0 | okm1;
+                    const lmask okm0 = __ballot(i <= last[0]) & __ballot(e.x <= 0.f) & __ballot(am0 >= amin);
+                    const lmask okm1 = __ballot(i <= last[1]) & __ballot(e.y <= 0.f) & __ballot(am1 >= amin);
+                    any_ok = okm0 | okm1;
                     const bool ok0 = __builtin_amdgcn_inverse_ballot_w64(okm0), ok1 = __builtin_amdgcn_inverse_ballot_w64(okm1);
                     v2f a;
                     a.x = ok0 ? am0 : 0.f; a.y = ok1 ? am1 : 0.f;
                     const v2f om = 1.0f - a;
                     v2f ra;
                     ra.x = __builtin_amdgcn_rcpf(om.x); ra.y = __builtin_amdgcn_rcpf(om.y);
-                    T2[kp] *= ra;
-                    const v2f Tk = T2[kp];
+                    T2 *= ra;
+                    const v2f Tk = T2;
                     const v2f w = a * Tk;
-                    const v2f zp = (tpx - q2.x * dy) * il2[kp];
-                    v2f dot = q3.x * vcol2[kp][0];
-                    if (CD > 1) dot += q3.y * vcol2[kp][CD > 1 ? 1 : 0];
-                    if (CD > 2) dot += q3.z * vcol2[kp][CD > 2 ? 2 : 0];
-                    if (CD > 3) dot += q3.w * vcol2[kp][CD > 3 ? 3 : 0];
+                    const v2f zp = (tpy - q1.w * dx) * il2;
+                    v2f dot = q3.x * vcol2[0];
+                    if (CD > 1) dot += q3.y * vcol2[CD > 1 ? 1 : 0];
+                    if (CD > 2) dot += q3.z * vcol2[CD > 2 ? 2 : 0];
+                    if (CD > 3) dot += q3.w * vcol2[CD > 3 ? 3 : 0];
 #pragma unroll
                     for (int q = 0; q < NXQ; q++)
-                        dot += xq[q].x * vcolx2[kp][4 * q] + xq[q].y * vcolx2[kp][4 * q + 1] +
-                               xq[q].z * vcolx2[kp][4 * q + 2] + xq[q].w * vcolx2[kp][4 * q + 3];
-                    dot += q2.y * vn2[kp][0] + q2.z * vn2[kp][1] + q2.w * vn2[kp][2] + zp * vd2[kp];
-                    const v2f v_a = (tf2[kp] - B2[kp]) * ra + Tk * dot;     // (only used through vam below: masked there)
-                    B2[kp] += w * dot;
-                    v2f vz = w * vd2[kp];
+                        dot += xq[q].x * vcolx2[4 * q] + xq[q].y * vcolx2[4 * q + 1] + xq[q].z * vcolx2[4 * q + 2] + xq[q].w * vcolx2[4 * q + 3];
+                    dot += q2.y * vn2[0] + q2.z * vn2[1] + q2.w * vn2[2] + zp * vd2;
+                    const v2f v_a = D2 * ra + Tk * dot;                   // (only used through vam below: masked there)
+                    D2 -= w * dot;
+                    v2f vz = w * vd2;
                     if (batch_has_median) {          // wave-uniform: most batches hold no pixel's median Gaussian
                         asm volatile("; median gradient" ::);               // (a real branch, not a speculated select)
                         v2f vmed;
-                        vmed.x = (ok0 && i == medi[k0]) ? vm2[kp].x : 0.f; vmed.y = (ok1 && i == medi[k1]) ? vm2[kp].y : 0.f;
+                        vmed.x = (ok0 && i == medi[0]) ? vm2.x : 0.f; vmed.y = (ok1 && i == medi[1]) ? vm2.y : 0.f;
                         vz += vmed;
                     }
-                    const v2f vzl = vz * il2[kp];
+                    const v2f vzl = vz * il2;
                     // d alpha / d (o vis) is 1 below the clamp, 0 at it; and nothing flows through a pixel that skipped
                     const bool un0 = __builtin_amdgcn_inverse_ballot_w64(okm0 & __ballot(ov.x <= amax));
                     const bool un1 = __builtin_amdgcn_inverse_ballot_w64(okm1 & __ballot(ov.y <= amax));
                     v2f vam;
                     vam.x = un0 ? v_a.x : 0.f; vam.y = un1 ? v_a.y : 0.f;
                     const v2f v_e = (kLn2 * ov) * vam;
-                    const v2f dyve = dy * v_e;
-                    const v2f vmx = (c1x + q0.w * dy) * v_e - vzl * q1.w;
-                    const v2f vmy = (2.0f * q1.x * dy + c1y) * v_e - vzl * q2.x;
-                    // first pair: plain products, later pairs (PPL 4): fused accumulate
-                    // Per-Gaussian sums over the lane's pixels.  A packed multiply costs two plain issue slots on gfx950
-                    // (scripts/ubench/valu_rates.hip), so forming 16 packed products and then adding their halves
-                    // (16 v_pk_mul + 16 v_add = 48 slots) loses against scalar mul + fma on the halves (<= 2 per
-                    // component); sums that share a factor are factored (dxx * (v_e.x + v_e.y), ...): 28 slots.
-#define MISPLAT_DOT2(dst, A, B) do { if (kp == 0) dst = fmaf((A).y, (B).y, (A).x * (B).x);                       \
-                                     else dst = fmaf((A).y, (B).y, fmaf((A).x, (B).x, dst)); } while (0)
-#define MISPLAT_ADD1(dst, val) do { if (kp == 0) dst = (val); else dst += (val); } while (0)
-                    const float s_ve = v_e.x + v_e.y, s_dyve = dyve.x + dyve.y, s_vzl = vzl.x + vzl.y;
-                    MISPLAT_ADD1(acc[0], vmx.x + vmx.y); MISPLAT_ADD1(acc[1], vmy.x + vmy.y);
-                    MISPLAT_ADD1(acc[2], dxx * s_ve); MISPLAT_ADD1(acc[3], dx * s_dyve); MISPLAT_DOT2(acc[4], dy, dyve);
-                    MISPLAT_DOT2(acc[5], vis, vam);
-                    MISPLAT_ADD1(acc[6], s_vzl); MISPLAT_ADD1(acc[7], ndx * s_vzl);
-                    { const v2f nvzl = -vzl; MISPLAT_DOT2(acc[8], nvzl, dy); }
-                    MISPLAT_DOT2(acc[9], w, vn2[kp][0]); MISPLAT_DOT2(acc[10], w, vn2[kp][1]);
-                    MISPLAT_DOT2(acc[11], w, vn2[kp][2]);
-                    MISPLAT_DOT2(acc[12], w, vcol2[kp][0]);
-                    if (CD > 1) MISPLAT_DOT2(acc[13], w, vcol2[kp][CD > 1 ? 1 : 0]);
-                    if (CD > 2) MISPLAT_DOT2(acc[14], w, vcol2[kp][CD > 2 ? 2 : 0]);
-                    if (CD > 3) MISPLAT_DOT2(acc[15], w, vcol2[kp][CD > 3 ? 3 : 0]);
+                    const v2f dxve = dx * v_e;
+                    const v2f vmx = (2.0f * q0.z * dx + bdy) * v_e - vzl * q1.w;
+                    const v2f vmy = (c1y + q0.w * dx) * v_e - vzl * q2.x;
+                    // Per-Gaussian sums over the lane's two pixels.  A packed multiply costs two plain issue slots on gfx950
+                    // (scripts/ubench/valu_rates.hip), so forming 16 packed products and then adding their halves (48 slots)
+                    // loses against scalar mul + fma on the halves (<= 2 per component) with shared factors pulled out: 28.
+                    const float s_ve = v_e.x + v_e.y, s_dxve = dxve.x + dxve.y, s_vzl = vzl.x + vzl.y;
+                    acc[0] = vmx.x + vmx.y; acc[1] = vmy.x + vmy.y;
+                    acc[2] = dot2(dx, dxve); acc[3] = dy * s_dxve; acc[4] = dyy * s_ve;
+                    acc[5] = dot2(vis, vam);
+                    acc[6] = s_vzl; acc[7] = dot2(-vzl, dx); acc[8] = ndy * s_vzl;
+                    acc[9] = dot2(w, vn2[0]); acc[10] = dot2(w, vn2[1]); acc[11] = dot2(w, vn2[2]);
+                    acc[12] = dot2(w, vcol2[0]);
+                    acc[13] = CD > 1 ? dot2(w, vcol2[CD > 1 ? 1 : 0]) : 0.f;
+                    acc[14] = CD > 2 ? dot2(w, vcol2[CD > 2 ? 2 : 0]) : 0.f;
+                    acc[15] = CD > 3 ? dot2(w, vcol2[CD > 3 ? 3 : 0]) : 0.f;
 #pragma unroll
-                    for (int ch = 0; ch < (NXQ > 0 ? NX : 0); ch++) MISPLAT_DOT2(accx[ch], w, vcolx2[kp][ch]);
-#undef MISPLAT_DOT2
-#undef MISPLAT_ADD1
-                    if (ABS) { ab0 += fabsf(vmx.x) + fabsf(vmx.y); ab1 += fabsf(vmy.x) + fabsf(vmy.y); }
+                    for (int ch = 0; ch < 16; ch++) accx[ch] = (NXQ > 0 && ch < NX) ? dot2(w, vcolx2[ch < NX ? ch : 0]) : 0.f;
+                    if (ABS) { ab0 = fabsf(vmx.x) + fabsf(vmx.y); ab1 = fabsf(vmy.x) + fabsf(vmy.y); }
+                } else {
+                    // ---- one half: the same operations on component k alone
+                    auto half = [&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        const float dx = q0.x - px2[k];
+                        const float e = pair_exponent(q0.z, dx, bdy, ecc);
+                        const float vis = __builtin_amdgcn_exp2f(e);
+                        const float ov = q1.y * vis;
+                        const float am = __uint_as_float(min(amax_bits, __float_as_uint(ov)));
+                        const lmask okm = __ballot(i <= last[k]) & __ballot(e <= 0.f) & __ballot(am >= amin);
+                        any_ok = okm;
+                        const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
+                        const float a = ok ? am : 0.f;
+                        const float ra = __builtin_amdgcn_rcpf(1.0f - a);
+                        // (the two state vectors are updated with PACKED operations here too, the other half's component by a
+                        // neutral operand: a write to one component of a register pair on one path and to the pair on another
+                        // makes the compiler copy the whole state around the loop)
+                        T2 *= k == 0 ? mk2(ra, 1.0f) : mk2(1.0f, ra);
+                        const float Tk = T2[k];
+                        const float w = a * Tk;
+                        const float zp = (tpy - q1.w * dx) * il2[k];
+                        float dot = q3.x * vcol2[0][k];
+                        if (CD > 1) dot += q3.y * vcol2[CD > 1 ? 1 : 0][k];
+                        if (CD > 2) dot += q3.z * vcol2[CD > 2 ? 2 : 0][k];
+                        if (CD > 3) dot += q3.w * vcol2[CD > 3 ? 3 : 0][k];
+#pragma unroll
+                        for (int q = 0; q < NXQ; q++)
+                            dot += xq[q].x * vcolx2[4 * q][k] + xq[q].y * vcolx2[4 * q + 1][k] + xq[q].z * vcolx2[4 * q + 2][k] +
+                                   xq[q].w * vcolx2[4 * q + 3][k];
+                        dot += q2.y * vn2[0][k] + q2.z * vn2[1][k] + q2.w * vn2[2][k] + zp * vd2[k];
+                        const float v_a = D2[k] * ra + Tk * dot;
+                        D2 -= (k == 0 ? mk2(w, 0.f) : mk2(0.f, w)) * dot;
+                        float vz = w * vd2[k];
+                        if (batch_has_median) {
+                            asm volatile("; median gradient" ::);
+                            vz += (ok && i == medi[k]) ? vm2[k] : 0.f;
+                        }
+                        const float vzl = vz * il2[k];
+                        const bool un = __builtin_amdgcn_inverse_ballot_w64(okm & __ballot(ov <= amax));
+                        const float vam = un ? v_a : 0.f;
+                        const float v_e = (kLn2 * ov) * vam;
+                        const float dxve = dx * v_e;
+                        acc[0] = (2.0f * q0.z * dx + bdy) * v_e - vzl * q1.w;
+                        acc[1] = (2.0f * q1.x * dy + q0.w * dx) * v_e - vzl * q2.x;
+                        acc[2] = dx * dxve; acc[3] = dy * dxve; acc[4] = (dy * dy) * v_e;
+                        acc[5] = vis * vam;
+                        acc[6] = vzl; acc[7] = -vzl * dx; acc[8] = -dy * vzl;
+                        acc[9] = w * vn2[0][k]; acc[10] = w * vn2[1][k]; acc[11] = w * vn2[2][k];
+                        acc[12] = w * vcol2[0][k];
+                        acc[13] = CD > 1 ? w * vcol2[CD > 1 ? 1 : 0][k] : 0.f;
+                        acc[14] = CD > 2 ? w * vcol2[CD > 2 ? 2 : 0][k] : 0.f;
+                        acc[15] = CD > 3 ? w * vcol2[CD > 3 ? 3 : 0][k] : 0.f;
+#pragma unroll
+                        for (int ch = 0; ch < 16; ch++) accx[ch] = (NXQ > 0 && ch < NX) ? w * vcolx2[ch < NX ? ch : 0][k] : 0.f;
+                        if (ABS) { ab0 = fabsf(acc[0]); ab1 = fabsf(acc[1]); }
+                    };
+                    if (sub == 1) half(KC<0>()); else half(KC<1>());
                 }
             }
             const size_t slot = (size_t)islot;
@@ -872,10 +942,9 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
             {
                 const int jn = j > 0 ? j - 1 : 0;
                 q0 = sm[jn]; q1 = sm[64 + jn]; q2 = sm[128 + jn]; q3 = sm[192 + jn];
-                i = sm_idx[jn]; islot = sm_slot[jn];
+                iv = sm_idx[jn]; islot = sm_slot[jn]; subv = sm_sub[jn];
             }
-            const bool contributes = any_ok != 0ull;
-            if (contributes) {
+            if (any_ok != 0ull) {                  // (implies sub != 0: acc is set)
                 const float r = wave_reduce16(acc, lane);
                 if (ATOMIC) {
                     // one 64-byte contiguous no-return fp32 atomic per (band, Gaussian): 32-bit byte offset from a uniform base
@@ -883,9 +952,6 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (P
                     // diagnostic build only (scripts/build_variant.sh): the reduced row is kept alive but leaves the wave nowhere --
                     // what the kernel costs without its memory-side atomics (verdict round 4, item 7)
                     asm volatile("" ::"v"(r * out_scale), "v"(slot_off + comp_off));
-#elif defined(MISPLAT_DIAG_ROW_STORES)
-                    // diagnostic build only: plain (racing, wrong) stores instead of atomics -- the same lines dirtied, no read-modify-write
-                    if (writer) *reinterpret_cast<float*>(reinterpret_cast<char*>(slab_b) + (slot_off + comp_off)) = r * out_scale;
 #else
                     if (writer) atomicAdd(reinterpret_cast<float*>(reinterpret_cast<char*>(slab_b) + (slot_off + comp_off)), r * out_scale);
 #endif

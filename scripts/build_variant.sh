@@ -10,9 +10,12 @@ python -m collab_splats_amd.build > /dev/null
 mkdir -p collab_splats_amd/_exp
 EXTRA=""
 [ "$SRC" = "project.hip" ] && EXTRA="-ffp-contract=off"
+[ "$SRC" = "blend.hip" ] && [ -z "$MISPLAT_VARIANT_SRC" ] && EXTRA="-fno-slp-vectorize"
+# MISPLAT_VARIANT_SRC: compile THIS file in place of csrc/$SRC (an older revision, `git show REV:path > file`)
+SRCPATH=${MISPLAT_VARIANT_SRC:-collab_splats_amd/csrc/$SRC}
 O=collab_splats_amd/_exp/${TAG}_${SRC%.hip}.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I include -Wall -Wno-unused-function -fno-fast-math $EXTRA "$@" \
-    -c collab_splats_amd/csrc/$SRC -o $O
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I include -I collab_splats_amd/csrc -Wall -Wno-unused-function -fno-fast-math $EXTRA "$@" \
+    -c $SRCPATH -o $O
 OBJS=""
 for f in collab_splats_amd/_obj/*.o; do
     [ "$(basename $f)" = "${SRC%.hip}.o" ] && OBJS="$OBJS $O" || OBJS="$OBJS $f"
