@@ -2070,9 +2070,18 @@ def test_fused_get_outputs_node_matches_separate_nodes(dev):
 
 
 # ---------------------------------------------------------------- the TIMED path itself against the oracle
+_FULL_SIZE = pytest.mark.skipif((os.cpu_count() or 1) < 32, reason="the C port at full size needs the GPU box's host cores")
+
+
 @pytest.mark.parametrize("lazy", ["1", "auto"])
-@pytest.mark.parametrize("N,W,H,view,scale_mul", [(100_000, 1920, 1080, None, 1.0), (100_000, 1920, 1080, 5, 1.0),
-                                                  (300_000, 640, 360, None, 1.5)])
+@pytest.mark.parametrize("N,W,H,view,scale_mul", [
+    (100_000, 1920, 1080, None, 1.0), (100_000, 1920, 1080, 5, 1.0), (300_000, 640, 360, None, 1.5),
+    # BASELINE configs[2] / [3] at full size: the headline workload on its heaviest rotated view, every gradient (round 4 had
+    # this comparison in bench.py's post-timing leg only)
+    pytest.param(1_000_000, 1920, 1080, 3, 1.0, marks=_FULL_SIZE),
+    # BASELINE configs[4] at full size (minus the collective): 5 M Gaussians, where front-only ordering, the 8 192-entry sort
+    # class, indexed buckets and head-of-grid fills are the DEFAULT path (nothing forced here)
+    pytest.param(5_000_000, 1920, 1080, None, 1.0, marks=_FULL_SIZE)])
 def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H, view, scale_mul, lazy):
     """What ``bench.py --ext-activations`` and the model mirror run from their second step on -- ONE set of raw leaves
     (log-scales, logits) reused call after call with ``scales_are_log`` / ``opacities_are_logit``, both phases in one
@@ -2087,9 +2096,13 @@ def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H
     import math
     from collab_splats_amd import ops, rasterization
     from collab_splats_amd.synthetic import random_scene, view_matrix
+    full_size = N >= 1_000_000
+    if full_size and lazy != "auto":
+        pytest.skip("full size: the default switches only")
     monkeypatch.setattr(ops, "LAZY_SH", lazy)
-    if N >= 262_144:
+    if 262_144 <= N < 1_000_000:
         monkeypatch.setattr(ops, "FRONT_ONLY", "1")             # ("auto" takes it from a typical bucket of 1 024 entries: 5 M Gaussians)
+    assert ops.FRONT_ONLY == ("1" if 262_144 <= N < 1_000_000 else "auto")
     assert ops.GRAPHS and ops.MERGE_PHASES and ops.SPECULATE and ops.UNIT_ORDER and ops.FUSED_NODE
     assert not ops.DETERMINISTIC_BACKWARD
     sc = random_scene(N, W, H, seed=42)
@@ -2128,9 +2141,12 @@ def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H
     if dense:                                                   # background fill + one-launch per-Gaussian backward
         assert took.get("backward_background_fill", 0) == n_lazy, took
     r, a, ed, md, n, meta = out
-    if dense:
-        # front-only ordering (forced on above): from the first call (the counting pass has left the capacity hint), with the
-        # view's own pivots from the second; meta["flatten_ids"] below is completed on access
+    if N == 1_000_000:
+        assert took.get("forward_front_only", 0) == 0, took     # (typical bucket ~800 entries: below the 1 024 of "auto")
+    elif dense:
+        # front-only ordering (forced on above for the small dense scene, the default at 5 M): from the first call (the
+        # counting pass has left the capacity hint), with the view's own pivots from the second; meta["flatten_ids"] below is
+        # completed on access
         assert took.get("forward_front_only", 0) == n_calls, took
         assert meta["_bins"]["partial"] is not None and "flatten_ids" not in dict.keys(meta)
         fn = meta["_bins"]["partial"]["front_n"].cpu().numpy()
