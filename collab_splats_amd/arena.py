@@ -43,22 +43,43 @@ STATS: "collections.Counter" = collections.Counter()             # slots_created
 # (torch.cuda.MemPool): creating a 200 MB slot, or freeing the first call's arrays, then does not reshuffle the free blocks the
 # CALLER's tensors come from -- the torch.exp / torch.sigmoid outputs of the reference's call kept moving for two steps after
 # our slots appeared, and every address that moves is a graph key that does not recur.
+# ONE POOL PER RING (round 5; round 4 had one per device).  A private pool never gives a freed block back to the device while the
+# pool object lives, and densification makes every ring obsolete sooner or later (N only grows): with one pool per device every
+# slot ever created stayed reserved (advisor, round 4: 4.25 GB reserved against 0.79 GB allocated after two growths at 400 k).
+# A ring's pool dies with the ring; the allocator may then hand its blocks to anyone on an out-of-memory retry, and ``trim()``
+# -- called from ``ring()`` when the next NEW shape arrives with a dropped ring on record -- returns them to the device
+# (torch.cuda.empty_cache(): a synchronisation, paid once per refinement step of a densifying run, at the moment every
+# address changes anyway; at most two generations of rings are held).
 USE_POOL = os.environ.get("MISPLAT_ARENA_POOL", "1") == "1"
-_POOLS: Dict[int, object] = {}
+_TRIM_PENDING = False
 
 
-def pool_ctx(dev: torch.device):
-    """Context in which allocations of this thread on ``dev`` come from the arena's private pool (a no-op context when the
-    pool is off, unavailable, or a graph is being captured: a capture has a pool of its own)."""
+def _new_pool(dev: torch.device):
+    if not USE_POOL or not hasattr(torch.cuda, "MemPool"):
+        return None
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(idx):
+        return torch.cuda.MemPool()
+
+
+def pool_ctx(dev: torch.device, pool=None):
+    """Context in which allocations of this thread on ``dev`` come from ``pool`` (a ring's private pool; a no-op context when
+    there is none or a graph is being captured: a capture has a pool of its own)."""
     import contextlib
-    if not USE_POOL or not hasattr(torch.cuda, "MemPool") or torch.cuda.is_current_stream_capturing():
+    if pool is None or torch.cuda.is_current_stream_capturing():
         return contextlib.nullcontext()
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    pool = _POOLS.get(idx)
-    if pool is None:
-        with torch.cuda.device(idx):
-            pool = _POOLS[idx] = torch.cuda.MemPool()
     return torch.cuda.use_mem_pool(pool, device=idx)
+
+
+def trim() -> None:
+    """Give the memory of dropped rings back to the device (their pools are gone: their cached blocks are free to go)."""
+    global _TRIM_PENDING
+    if _TRIM_PENDING and not torch.cuda.is_current_stream_capturing():
+        _TRIM_PENDING = False
+        torch.cuda.empty_cache()
+        STATS["trims"] += 1
+
 
 _use_count = getattr(torch._C, "_storage_Use_Count", None)
 _ESIZE = {torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8, torch.int16: 2, torch.float64: 8}
@@ -67,9 +88,9 @@ _ESIZE = {torch.float32: 4, torch.int32: 4, torch.uint8: 1, torch.int64: 8, torc
 class Slot:
     """One arena: a 2 MiB-aligned byte range carved front to back by ``take``; ``demand`` records what a call wanted."""
 
-    def __init__(self, dev: torch.device, nbytes: int):
+    def __init__(self, dev: torch.device, nbytes: int, pool=None):
         self.size = int(nbytes)
-        with pool_ctx(dev):
+        with pool_ctx(dev, pool):
             self.raw = torch.empty(self.size + ALIGN_SLOT, device=dev, dtype=torch.uint8)
         shift = (-self.raw.data_ptr()) % ALIGN_SLOT
         self.base = self.raw[shift:shift + self.size]
@@ -113,6 +134,7 @@ class Ring:
         self.slots: List[Slot] = []
         self.want = 0                                             # bytes the largest call so far asked for
         self.last_lookup = 0
+        self.pool = _new_pool(dev)                                # (dies with the ring: see USE_POOL)
 
     def acquire(self) -> Optional[Slot]:
         """A slot nothing refers to (regrown first if the last call did not fit), a new one, or None."""
@@ -120,14 +142,14 @@ class Ring:
             if not s.free():
                 continue
             if s.size < self.want:                                # the shape's demand grew (a larger capacity class)
-                self.slots[i] = s = Slot(self.dev, self._padded(self.want))
+                self.slots[i] = s = Slot(self.dev, self._padded(self.want), self.pool)
                 STATS["regrown"] += 1
             else:
                 STATS["slot_hits"] += 1
             s.begin()
             return s
         if self.want > 0 and len(self.slots) < MAX_SLOTS:
-            s = Slot(self.dev, self._padded(self.want))
+            s = Slot(self.dev, self._padded(self.want), self.pool)
             self.slots.append(s)
             STATS["slots_created"] += 1
             s.begin()
@@ -136,7 +158,14 @@ class Ring:
 
     @staticmethod
     def _padded(n: int) -> int:
-        return (int(n * 1.10) + ALIGN_SLOT - 1) // ALIGN_SLOT * ALIGN_SLOT   # head room: capacities drift by a few percent
+        """Slot size for a demand of ``n`` bytes: the next step of a geometric ladder (x 1.25 from 2 MiB) above n + 10 % -- a
+        slot regrown for a slightly larger capacity class then has the size of a block its pool already caches more often
+        than not, and a ring's memory stays within a constant factor of its demand."""
+        need = int(n * 1.10)
+        size = ALIGN_SLOT
+        while size < need:
+            size = (int(size * 1.25) + ALIGN_SLOT - 1) // ALIGN_SLOT * ALIGN_SLOT
+        return size
 
     def release(self, slot: Optional[Slot], demand: int) -> None:
         """What the call asked for in total (also when it had no slot): the next slot of this ring is sized for it."""
@@ -154,11 +183,14 @@ def ring(key: tuple, dev: torch.device) -> Optional[Ring]:
         return None
     global _LOOKUPS
     _LOOKUPS += 1
+    global _TRIM_PENDING
     r = _RINGS.get(key)
     if r is None:
+        trim()                                                    # (a new shape: the moment abandoned rings' memory is wanted)
         r = _RINGS[key] = Ring(dev)
         while len(_RINGS) > MAX_RINGS:
             _RINGS.popitem(last=False)                            # (its slots live on while views of them do)
+            _TRIM_PENDING = True
     else:
         _RINGS.move_to_end(key)
     r.last_lookup = _LOOKUPS
@@ -169,6 +201,10 @@ def ring(key: tuple, dev: torch.device) -> Optional[Ring]:
                 break
             del _RINGS[k0]
             STATS["rings_dropped_idle"] += 1
+            _TRIM_PENDING = True                                  # (returned to the device when the next new shape arrives: a
+                                                                  #  trim moves the caller's allocator blocks too, i.e. costs
+                                                                  #  the steady state a round of graph captures -- at a shape
+                                                                  #  change everything is new anyway)
     return r
 
 
@@ -202,7 +238,7 @@ class Carver:
             nbytes = count * _ESIZE[dtype]
             align = ALIGN_BIG if nbytes >= BIG else ALIGN_SMALL
             self.shadow = (self.shadow + align - 1) // align * align + nbytes
-            with pool_ctx(self.dev):                              # (a ring's first call: see USE_POOL)
+            with pool_ctx(self.dev, self.ring.pool):              # (a ring's first call: see USE_POOL)
                 return torch.empty(max(count, 0), device=self.dev, dtype=dtype)
         return torch.empty(max(count, 0), device=self.dev, dtype=dtype)
 
@@ -219,4 +255,9 @@ class Carver:
 
 
 def reset() -> None:
+    global _TRIM_PENDING
+    if _RINGS:
+        _TRIM_PENDING = True
     _RINGS.clear()
+    if torch.cuda.is_available():
+        trim()

@@ -66,6 +66,10 @@ class GraphedStep:
         if not ops.fused_node_ok():
             raise ops._lib.MisplatError("GraphedStep needs the default single-node path (MISPLAT_FUSED / MISPLAT_FUSED_NODE / "
                                         "atomic gradient mode)")
+        # the count of every replay lands in a pinned word of this graph's own (advisor, round 4: with one word per device a
+        # view's overflow was overwritten by the next view's replay before anybody looked)
+        self._count = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+        self._worst = 0
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         # An autograd graph kept alive across calls (returned by fn, or stashed anywhere else: a dict of "last outputs", a
@@ -78,7 +82,7 @@ class GraphedStep:
         warn_always = torch.is_warn_always_enabled()
         torch.set_warn_always(True)
         try:
-            with warnings.catch_warnings(record=True) as caught, torch.cuda.stream(side), ops.static_capacity(self.capacity):
+            with warnings.catch_warnings(record=True) as caught, torch.cuda.stream(side), ops.static_capacity(self.capacity, self._count):
                 warnings.simplefilter("always")
                 for _ in range(max(warmup, 1)):               # allocator warm-up, launch-order feedback, lazy initialisation
                     res = fn()
@@ -101,12 +105,12 @@ class GraphedStep:
                 "tensor with autograd history: outputs, a meta dict, a loss) -- PyTorch reported AccumulateGrad nodes on a "
                 "foreign stream during the warm-up, and capturing in that state crashes the process.  Drop or detach those "
                 "references before creating the GraphedStep")
-        ops.check_static_capacity(self.device)                # too small already: fail before capturing
+        self._check_count()                                   # too small already: fail before capturing
         self.graph = torch.cuda.CUDAGraph()
         self._keep: list = []
         ops._CAPTURE_KEEP = self._keep
         try:
-            with ops.static_capacity(self.capacity), torch.cuda.graph(self.graph):
+            with ops.static_capacity(self.capacity, self._count), torch.cuda.graph(self.graph):
                 self.result = fn()
         finally:
             ops._CAPTURE_KEEP = None
@@ -115,10 +119,17 @@ class GraphedStep:
         self.graph.replay()
         return self.result
 
+    def _check_count(self) -> int:
+        n = int(self._count[0])
+        if n > self.capacity:
+            raise ops._lib.MisplatError(f"{n} tile intersections exceed the fixed capacity {self.capacity}: rerun with a larger one")
+        return max(n, 0)
+
     def check(self) -> int:
-        """Synchronise and return the intersection count of the last replay; raises if it exceeded the capacity."""
+        """Synchronise and return the intersection count of this graph's last replay; raises if it exceeded the capacity
+        (the images and gradients of that replay are then incomplete)."""
         torch.cuda.synchronize(self.device)
-        return ops.check_static_capacity(self.device)
+        return self._check_count()
 
 
 class GraphedViews:
@@ -142,6 +153,9 @@ class GraphedViews:
     def replay(self, v: int):
         return self.steps[v].replay()
 
-    def check(self) -> int:
-        """Synchronise; the intersection count of the LAST replay (raises if it exceeded the capacity)."""
-        return self.steps[0].check()
+    def check(self, v: Optional[int] = None) -> int:
+        """Synchronise; the intersection count of view ``v``'s last replay, or (``v`` None) the largest among all views' last
+        replays -- raises if ANY of them exceeded the capacity: every graph has its own pinned count."""
+        torch.cuda.synchronize(self.steps[0].device)
+        worst = max(st._check_count() for st in self.steps)
+        return worst if v is None else self.steps[v]._check_count()

@@ -593,6 +593,8 @@ def _readback_slot(dev: torch.device, static: bool = False) -> Tensor:
     before it returns, so one slot per device serves all of them; fixed-capacity calls (``static_capacity``: nobody
     waits, a captured graph replays the copy) have a slot of their own, so that a replay queued in front of an eager
     forward can never be mistaken for that forward's count."""
+    if static and _STATIC_SLOT is not None:
+        return _STATIC_SLOT
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
     key = (idx, bool(static))
     if key not in _READBACK:
@@ -672,22 +674,28 @@ MERGE_PHASES = os.environ.get("MISPLAT_MERGE_PHASES", "1") == "1"
 # hipGraph (graphs.GraphedStep).  ``meta["n_isects"]`` is then a device tensor, the lists beyond it are unspecified, and
 # an overflow (count > capacity) is reported by ``check_static_capacity()`` after the fact.
 _STATIC_CAP: Optional[int] = None
+_STATIC_SLOT: Optional[Tensor] = None      # pinned int64[1] of the caller's own that receives the count (else: one per device)
 
 
 class static_capacity:
-    """``with ops.static_capacity(n): rasterization(...)`` -- see _STATIC_CAP."""
+    """``with ops.static_capacity(n): rasterization(...)`` -- see _STATIC_CAP.  ``slot``: a pinned int64[1] that receives the
+    intersection count of the calls inside (a captured graph keeps writing it on every replay): several graphs that are
+    replayed in turn each have their own, so that an overflow of any of them is seen (graphs.GraphedViews)."""
 
-    def __init__(self, n: Optional[int]):
+    def __init__(self, n: Optional[int], slot: Optional[Tensor] = None):
         self.n = None if n is None else int(n)
+        self.slot = slot
 
     def __enter__(self):
-        global _STATIC_CAP
+        global _STATIC_CAP, _STATIC_SLOT
         self.old, _STATIC_CAP = _STATIC_CAP, self.n
+        self.old_slot, _STATIC_SLOT = _STATIC_SLOT, self.slot
         return self
 
     def __exit__(self, *exc):
-        global _STATIC_CAP
+        global _STATIC_CAP, _STATIC_SLOT
         _STATIC_CAP = self.old
+        _STATIC_SLOT = self.old_slot
         return False
 
 

@@ -281,6 +281,23 @@ class RadegsModel(nn.Module):
             return 2 ** max(self.config.num_downscales - self.step // max(self.config.resolution_schedule, 1), 0)
         return 1
 
+    def _downscale_if_required(self, image: Tensor) -> Tensor:
+        """Splatfacto's ``_downscale_if_required`` [UNVERIFIED-UPSTREAM]: while the resolution schedule renders at 1 / d, the
+        ground truth is box-filtered by the same d (a d x d mean with stride d, nerfstudio's ``resize_image``), so that the
+        image loss compares like with like -- a data manager hands out full-resolution images whatever the schedule says."""
+        d = self._get_downscale_factor()
+        if d <= 1:
+            return image
+        x = image.to(torch.float32).permute(2, 0, 1)[:, None]
+        weight = torch.full((1, 1, d, d), 1.0 / (d * d), device=x.device, dtype=torch.float32)
+        return torch.nn.functional.conv2d(x, weight, stride=d).squeeze(1).permute(1, 2, 0)
+
+    def get_gt_img(self, image: Tensor) -> Tensor:
+        """Splatfacto's ``get_gt_img`` [UNVERIFIED-UPSTREAM]: uint8 -> 0..1 floats, then the schedule's downscale."""
+        if image.dtype == torch.uint8:
+            image = image.to(torch.float32) / 255.0
+        return self._downscale_if_required(image)
+
     def _prefilter_voxel(self, camera_params: Dict) -> Tensor:
         """rade_gs_model.py:348-399: visibility mask from projection radii."""
         from .wrapper import fully_fused_projection
@@ -499,12 +516,10 @@ class RadegsModel(nn.Module):
         SSIM and their backward are one autograd node (``ops.mean_losses``: a handful of launches instead of ~60)."""
         loss_dict: Dict[str, Tensor] = {}
         rgb = outputs["rgb"]
-        gt = batch["image"].to(rgb.device) if batch is not None and "image" in batch else None
-        # (Splatfacto takes whatever the data manager hands it -- a sliced, permuted, uint8 or float64 batch image: normalise
-        # first; uint8 images are 0..255 [UNVERIFIED-UPSTREAM: nerfstudio scales them to 0..1 in its data pipeline])
+        # (Splatfacto takes whatever the data manager hands it -- a full-resolution, sliced, permuted, uint8 or float64 batch
+        # image: get_gt_img brings it to the render's resolution and to 0..1 floats first)
+        gt = self.get_gt_img(batch["image"].to(rgb.device)) if batch is not None and "image" in batch else None
         if gt is not None and rgb.is_cuda:
-            if gt.dtype == torch.uint8:
-                gt = gt.to(torch.float32) / 255.0
             gt = gt.to(rgb.dtype).contiguous()
             rgb = rgb.contiguous()
         with_dn = self.config.use_depth_normal_loss and self.step >= self.config.regularization_from_iter

@@ -22,17 +22,63 @@ ENABLE_ND_ONE_PASS = True        # a8: 5..20 channels in one compositing pass (F
 
 
 class _Meta(dict):
-    """``meta`` dict; ``meta["isect_ids"]`` (gsplat's sorted 64-bit keys, which nothing on the
-    reference's path reads) is rebuilt from the tile ids and depths on first access."""
+    """``meta`` dict.  Two of gsplat's keys are produced on demand: ``isect_ids`` (the sorted 64-bit keys, which nothing on
+    the reference's path reads) is rebuilt from the tile ids and depths, and ``flatten_ids`` is absent after a front-only
+    forward (only the heads of the buckets are sorted) and completed by the regular per-tile sort.  EVERY way of asking for
+    them completes them -- ``meta[k]``, ``meta.get(k)``, ``k in meta``, ``keys()`` / ``items()`` / ``values()`` / iteration,
+    ``dict(meta)`` / ``copy()`` -- so code written against gsplat's contract (the keys are always there) sees them whatever its
+    access style (advisor, round 4).  ``_has(k)`` asks without completing.  NOTE: ``meta`` refers to arrays of the call's
+    arena slot (``meta["_bins"]``): the slot stays in use for as long as ``meta`` is held."""
+
+    _LAZY = ("isect_ids", "flatten_ids")
 
     def __missing__(self, key):
         if key == "isect_ids":
-            self[key] = ops.isect_ids(self["_bins"])
-            return self[key]
+            self[key] = ops.isect_ids(dict.__getitem__(self, "_bins"))
+            return dict.__getitem__(self, key)
         if key == "flatten_ids":                       # (absent after a front-only forward: only the heads are sorted)
-            self[key] = ops.complete_bins(self["_bins"])
-            return self[key]
+            self[key] = ops.complete_bins(dict.__getitem__(self, "_bins"))
+            return dict.__getitem__(self, key)
         raise KeyError(key)
+
+    def _has(self, key) -> bool:
+        """Is ``key`` materialised already?  (plain dict membership: does not complete anything)"""
+        return dict.__contains__(self, key)
+
+    def _complete(self) -> None:
+        if dict.__contains__(self, "_bins"):
+            for k in self._LAZY:
+                if not dict.__contains__(self, k):
+                    self[k]                              # (through __missing__)
+
+    def __contains__(self, key) -> bool:
+        return dict.__contains__(self, key) or (key in self._LAZY and dict.__contains__(self, "_bins"))
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+    def keys(self):
+        self._complete()
+        return dict.keys(self)
+
+    def items(self):
+        self._complete()
+        return dict.items(self)
+
+    def values(self):
+        self._complete()
+        return dict.values(self)
+
+    def __iter__(self):
+        self._complete()
+        return dict.__iter__(self)
+
+    def __len__(self) -> int:
+        return dict.__len__(self) + (sum(1 for k in self._LAZY if not dict.__contains__(self, k)) if dict.__contains__(self, "_bins") else 0)
+
+    def copy(self):
+        self._complete()
+        return _Meta(dict.items(self))
 
 
 def rasterization(

@@ -504,3 +504,33 @@ def test_key_trace_report_names_the_fields_that_moved(monkeypatch):
 def test_row_capacity_of_the_sparse_reduce():
     from collab_splats_amd import parallel
     assert parallel._row_capacity(0) == 1024 and parallel._row_capacity(100_000) == 150_000
+
+
+def test_meta_completes_its_lazy_keys_for_every_access_style(monkeypatch):
+    """``meta["flatten_ids"]`` / ``["isect_ids"]`` are produced on demand (after a front-only forward only the heads
+    of the buckets are sorted).  gsplat's contract is that the keys are THERE: ``get``, ``in``, ``keys`` / ``items`` /
+    ``values``, iteration, ``len``, ``dict(meta)`` and ``copy()`` complete them just like indexing does."""
+    from collab_splats_amd import ops, rendering
+    calls = []
+    monkeypatch.setattr(ops, "isect_ids", lambda bins: calls.append("isect") or "ISECT")
+    monkeypatch.setattr(ops, "complete_bins", lambda bins: calls.append("flat") or "FLAT")
+
+    def fresh():
+        calls.clear()
+        return rendering._Meta({"_bins": {"partial": object()}, "radii": 1, "width": 4})
+
+    m = fresh()
+    assert not m._has("flatten_ids") and "flatten_ids" in m and "isect_ids" in m and "nope" not in m and calls == []
+    assert len(m) == 5 and calls == []                            # (the two keys count before they exist)
+    assert m.get("flatten_ids") == "FLAT" and calls == ["flat"] and m.get("nope", 7) == 7
+    assert m["isect_ids"] == "ISECT" and calls == ["flat", "isect"] and len(m) == 5
+    for access in (lambda m: list(m.keys()), lambda m: [k for k, _ in m.items()], lambda m: list(m), lambda m: list(dict(m)),
+                   lambda m: list(m.copy().keys()), lambda m: list({**m})):
+        m = fresh()
+        assert {"flatten_ids", "isect_ids", "radii", "width", "_bins"} == set(access(m)) and sorted(calls) == ["flat", "isect"]
+    m = fresh()
+    assert "FLAT" in list(m.values())
+    plain = rendering._Meta({"radii": 1})                         # (no bins: nothing to complete, an ordinary dict)
+    assert "flatten_ids" not in plain and plain.get("flatten_ids") is None and list(plain) == ["radii"] and len(plain) == 1
+    with pytest.raises(KeyError):
+        plain["flatten_ids"]
