@@ -91,6 +91,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--parity-view", type=int, default=3, help="the rotated view the gradient check runs on besides view 0")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="Gaussians in the CPU-baseline sample")
+    ap.add_argument("--details", default=None, metavar="FILE",
+                    help="also write the line with everything behind it (per-view counts, per-tensor errors, graph / arena / path "
+                         "counters, live counters) as indented JSON: the printed line itself stays under 4 KB so that the driver's "
+                         "record carries it whole")
     return ap.parse_args()
 
 
@@ -163,7 +167,8 @@ def cpu_baseline(args, seed: int):
     v, reps, isects, threads, keep = _c_port_time(n, W, H, args, seed, None, 8.0)
     base = {"value": round(v, 4), "unit": "Msplats/s", "cores": threads, "kind": "port",
             "sample": f"{n} Gaussians (same generator, seed {seed}), {W}x{H}, {args.render_mode} fwd+bwd, "
-                      f"{reps} timed iteration(s) after 1 warm-up, {isects} intersections, C/OpenMP fp32"}
+                      f"{reps} timed iteration(s) after 1 warm-up, {isects} intersections, C/OpenMP fp32",
+            "sample_short": f"{n} Gaussians {W}x{H} {args.render_mode} fwd+bwd, {reps} iterations, C/OpenMP fp32"}
     n1 = min(10_000, n)
     vc, repsc, isectsc, tc, _ = _c_port_time(n1, 256, 256, args, seed, None, 3.0, max_reps=20)
     base["config1"] = {"value": round(vc, 4), "cores": tc,
@@ -385,6 +390,53 @@ def spawn_ranks(args) -> int:
 GUIDE_COPY_GBS = 6290.0     # MI355X_MICROARCH.md: measured float4 copy
 
 
+def unit_tensors(meta) -> dict:
+    """What the post-timing pass needs of a step's ``meta`` to count the units the step really visited -- plain tensors only
+    (a reference to ``meta`` itself would keep the step's autograd graph alive, which a whole-step capture cannot tolerate)."""
+    bins = meta["_bins"] if meta._has("_bins") else {}
+    part = bins.get("partial")
+    return {"last_ids": meta["last_ids"], "isect_offsets": meta["isect_offsets"], "touched": bins.get("touched"),
+            "grec": bins.get("grec"), "front_n": part["front_n"] if part else None}
+
+
+def visited_units(meta, W, H, N, I):
+    """The units one step actually visited (SURVEY.md section 8(d) prices every intersection and every Gaussian; front-only
+    ordering, early termination, on-demand colours and the flagged-row backward legitimately never touch most of them on a
+    dense scene):  I_trav -- list entries the compositing backward stages (per band: first entry .. deepest last_id);
+    I_sort -- entries the per-tile sort ordered (the heads, with front-only ordering; else all);  N_touched -- rows that
+    received a 2-D gradient (``misplat_params.touched``);  N_colour -- rows whose SH colour was evaluated (colour slot set)."""
+    u = {"I": int(I), "I_trav": traversed_entries(meta, W, H), "I_sort": int(I), "N_touched": int(N), "N_colour": int(N)}
+    if meta.get("touched") is not None:
+        u["N_touched"] = int((meta["touched"] != 0).sum().item())
+    if meta.get("grec") is not None:
+        g = meta["grec"]
+        u["N_colour"] = int((g[:, 12].view(torch.int32) != 0x7fc0dead).sum().item())      # (kColourUnset, csrc/blend.hip)
+    if meta.get("front_n") is not None:
+        fn = meta["front_n"].long()
+        offs = meta["isect_offsets"].reshape(-1).long()
+        cnt = torch.diff(torch.cat([offs, offs.new_tensor([I])]))
+        u["I_sort"] = int(torch.where(fn >= 0, torch.minimum(fn, cnt), cnt).sum().item())
+    if u["I_trav"] is None:
+        u["I_trav"] = int(I)
+    return u
+
+
+def visited_bytes(kernel: str, N: int, P: int, u: dict) -> float:
+    """SURVEY 8(d)'s per-unit figures times the units VISITED (see visited_units).  blend_bwd: 88 P + 64 I_trav + 60 N_touched.
+    step: projection reads 44 B and writes 60 B for every row; 192 + 12 B of SH coefficients / colour per row whose colour is
+    evaluated; 12 I binned; 24 B per sorted entry; 64 B per staged entry in the forward and again in the backward; 136 P of
+    images; 60 + 368 B per row that carries a gradient (2-D gradient written, then parameters + saved geometry / colour + the
+    2-D gradient read); 236 N of dense parameter gradients written."""
+    if kernel == "blend_bwd":
+        return 88.0 * P + 64.0 * u["I_trav"] + 60.0 * u["N_touched"]
+    if kernel == "blend_fwd":
+        return 64.0 * u["I_trav"] + 48.0 * P
+    if kernel == "step":
+        return (340.0 * N + 204.0 * u["N_colour"] + 428.0 * u["N_touched"] + 12.0 * u["I"] + 24.0 * u["I_sort"]
+                + 128.0 * u["I_trav"] + 136.0 * P)
+    raise KeyError(kernel)
+
+
 def traversed_entries(meta, W, H):
     """List entries the compositing BACKWARD stages: per band (16 x 8 pixels) everything from the tile's first entry to the
     band's deepest `last_ids` -- what `64 * I` of SURVEY 8(d) becomes once the early termination is counted."""
@@ -462,7 +514,7 @@ def main():
             if bucket is not None:
                 info["allreduce_ms"].append(bucket.allreduce())
             info["n_isects"], info["n_visible"] = model.info["n_isects"], model.info["radii"]
-            info["meta"] = {"last_ids": model.info["last_ids"], "isect_offsets": model.info["isect_offsets"]}
+            info["meta"] = unit_tensors(model.info)
             info["isects"].append(int(model.info["n_isects"]))
             info["it"] += 1
     else:
@@ -489,7 +541,7 @@ def main():
             # graph alive, which a whole-step capture -- --graphed -- cannot tolerate)
             m = out[5]
             info["n_isects"], info["n_visible"] = m["n_isects"], m["radii"]
-            info["meta"] = {"last_ids": m["last_ids"], "isect_offsets": m["isect_offsets"]}
+            info["meta"] = unit_tensors(m)
             if not torch.is_tensor(m["n_isects"]):
                 info["isects"].append(int(m["n_isects"]))
             info["it"] += 1
@@ -620,29 +672,40 @@ def main():
     ops.KERNEL_EVENTS = {}
     info["isects"].clear()
     n_inst = 10
-    trav = []
+    units = []
+    stats_i = dict(ops.PATH_STATS)
     for i in range(n_inst):
         step()
         if rank == 0 and i >= 2:
-            t = traversed_entries(info["meta"], W, H)
-            if t is not None:
-                trav.append(t)
+            units.append(visited_units(info["meta"], W, H, N, int(info["n_isects"])))
     torch.cuda.synchronize()
     events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    took_i = {k: ops.PATH_STATS[k] - stats_i.get(k, 0) for k in ops.PATH_STATS}
 
     if rank == 0:
         isects = info["isects"][2:] or [int(info["n_isects"])]
         I = int(sum(isects) / len(isects))         # mean over the instrumented launches (the views differ)
         n_vis = int((info["n_visible"] > 0).any(-1).sum().item())
+        P_px = W * H
         ktimes = {}
         for k, v in events.items():                # ms; the first two instrumented steps are warm-up; MEAN duration per launch
             ts = [a.elapsed_time(b) for a, b in v[2:]] or [0.0]
             ktimes[k] = sum(ts) / len(ts)
         dom = max((k for k in ktimes if k in ("blend_bwd", "blend_fwd", "slab_reduce")), key=ktimes.get)
-        abytes = algorithmic_bytes(dom, N, I, W * H, args.features, cd)
+        u = {k: int(sum(x[k] for x in units) / len(units)) for k in units[0]} if units else {"I": I, "I_trav": I, "I_sort": I, "N_touched": N, "N_colour": N}
+        # SURVEY 8(d) prices every intersection and every Gaussian ("nominal"); a dense scene's step legitimately never visits
+        # most of them (front-only ordering, early termination, on-demand colours, the flagged-row backward): when any of those
+        # paths ran, `achieved` / `frac` / `step_frac` are computed from the units the step VISITED and the nominal figures are
+        # kept beside them -- a fraction above the box's own copy roof can only come from counting work that was not done
+        sparse_paths = bool(took_i.get("forward_lazy_colour") or took_i.get("forward_front_only") or took_i.get("backward_background_fill"))
+        plain_rgb = args.features == 0 and dom in ("blend_bwd", "blend_fwd")
+        nominal = algorithmic_bytes(dom, N, I, P_px, args.features, cd)
+        visited = visited_bytes(dom, N, P_px, u) if plain_rgb else nominal
+        abytes = visited if (sparse_paths and plain_rgb) else nominal
         achieved = abytes / (ktimes[dom] * 1e-3) / 1e9
-        I_trav = int(sum(trav) / len(trav)) if trav else None
-        step_bytes = algorithmic_bytes("step", N, I, W * H, args.features, cd)
+        step_nominal = algorithmic_bytes("step", N, I, P_px, args.features, cd)
+        step_visited = visited_bytes("step", N, P_px, u) if args.features == 0 else step_nominal
+        step_bytes = step_visited if (sparse_paths and args.features == 0) else step_nominal
         step_gbs = step_bytes / (dev_med * 1e-3) / 1e9
         pmc = {}
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -652,114 +715,79 @@ def main():
             except Exception:
                 pmc = {}
         vif = pmc.get("valu_issue_frac")
-        # class-weighted issue budget of the dominant kernel (scripts/valu_budget.py on the same PMC file: plain 2.5 cycles,
-        # DPP 4.5, packed 4.9, transcendental 8.5 ... per wave instruction, and the measured busy share of the vector ALU)
-        valu_budget = None
-        try:
-            vb = json.load(open(os.path.join(ROOT, "profiles", "r04_valu_budget.json")))["kernels"]
-            valu_budget = (vb.get(dom) or {}).get("issue_frac") if pmc else None
-        except Exception:
-            valu_budget = None
-        view_txt = ("one fixed view" if headline_mode["fixed"] else "8 cycling views (configs[3]'s cameras, one per step)")
+        view_txt = "1 fixed view" if headline_mode["fixed"] else "8 cycling views"
         if args.dn_loss:
-            img_loss = "L1 (no SSIM: --no-ssim)" if args.no_ssim else "main_loss = 0.8 L1 + 0.2 (1 - SSIM) (Splatfacto's, restated)"
-            wl = (f"{N} shared Gaussians, {view_txt} {W}x{H} per GPU, model mirror get_outputs -> {img_loss} + depth-normal "
-                  f"consistency loss -> backward (BASELINE configs[4] per GPU); activations inside the projection kernels")
+            wl = (f"{N} shared Gaussians, {view_txt} {W}x{H}, model step: get_outputs -> "
+                  f"{'L1' if args.no_ssim else 'L1+SSIM'} + depth-normal loss -> backward (configs[4] per GPU)")
+        elif args.features > 0:
+            wl = (f"features model call: {N} Gaussians, {view_txt} {W}x{H}, SH3 + {args.features} feature channels = {cd} channels "
+                  f"({args.render_mode}), fwd+bwd, one entry")
         else:
-            wl = (f"{N} random Gaussians, {view_txt} {W}x{H} per GPU, SH degree 3, {args.render_mode} "
-                  f"({args.rasterize_mode}), colour+alpha+expected/median depth+normal, fwd+bwd to all six parameter tensors; "
-                  + ("exp(log_scales) / sigmoid(opacity_logits) inside the projection kernels (scales_are_log / opacities_are_logit extension)"
-                     if headline_mode["ext"] else "torch activations (torch.exp / torch.sigmoid in front, the reference's call)"))
+            wl = (f"{N} random Gaussians, {view_txt} {W}x{H}, SH3, {args.render_mode} {args.rasterize_mode}, 5 outputs, fwd+bwd to 6 "
+                  f"parameter tensors, " + ("activations in the kernels" if headline_mode["ext"] else "torch activations (the reference's call)"))
+        forced = dist.is_initialized() and world == 1
         if not shared and bucket is None:
             par = "independent views, no collective"
-        elif world == 1:
-            par = "one GPU, no collective" + ("; gradients written into a GradientBuckets flat buffer (--buckets)" if bucket is not None else "")
+        elif world == 1 and not forced:
+            par = "one GPU, no collective" + ("; GradientBuckets sink" if bucket is not None else "")
         else:
             be = dist.get_backend() if dist.is_initialized() else "none"
-            par = (f"shared Gaussians, {'RCCL' if be == 'nccl' else be + ' (a rehearsal: not RCCL)'} reduce of 236 B/Gaussian grads (colour + geometry "
-                   f"bucket, zero-copy flat buffer; sparse rows where the flags allow: {dict(parallel.STATS)})")
+            par = (f"shared Gaussians, {'RCCL' if be == 'nccl' else be + ' (rehearsal, not RCCL)'} reduce of 236 B/Gaussian"
+                   + (" (a group of ONE rank with forced collectives)" if forced else ""))
+        def var(label):
+            return variants.get(label, {})
+        fixed_l = ("ext" if headline_mode["ext"] else "torch") + "_activations+fixed_view"
         line = {
             "metric": "Msplats/s fwd+bwd @1080p (1M Gaussians); grad max-rel-err vs reference",
             "value": round(world * N / (dt / args.steps) / 1e6, 3), "unit": "Msplats/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_head, 4),
             "device_ms_median": round(dev_med, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "value_ext": variants.get("ext_activations+cycling_views", {}).get("value"),
-            "variants": variants,
-            "config": {"workload": wl, "views": 1 if headline_mode["fixed"] else 8, "n_isects": I, "n_isects_per_view": isects[:8],
-                       "n_visible": n_vis, "parallelism": par,
-                       "git_rev": git_rev(), "graph_cache": ops.graph_cache_stats(), "graph_cache_timed": graph_timed,
-                       "graph_cache_headline": graph_all,
-                       # (the model step rebuilds its camera tensors every step: its blocks recur with the allocator's period,
-                       # not per view -- the raw share of the timed region is the figure there)
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            # the literal configs[2] figure (ONE view) beside the headline's eight cycling views, and the activations-in-kernel extension
+            "value_fixed_view": var(fixed_l).get("value"), "ms_fixed_view": var(fixed_l).get("ms_per_step"),
+            "value_ext": var("ext_activations+cycling_views").get("value"),
+            "variants": {k: [v["ms_per_step"], v["value"]] for k, v in variants.items()},
+            "config": {"workload": wl, "views": 1 if headline_mode["fixed"] else 8, "n_isects": I, "n_visible": n_vis,
+                       "parallelism": par, "git_rev": git_rev(),
                        "graph_hit_rate": graph_timed["hit_rate"] if args.dn_loss else graph_all["hit_rate_of_replayable"],
-                       "graph_hit_rate_note": "replays / calls that could replay (a view's third visit onwards: the cache captures on "
-                                              "the second sighting of an argument block) over the headline's warm-up + timed steps; "
-                                              "graph_cache_timed = the raw counts of the timed region", "arena": dict(__import__("collab_splats_amd.arena", fromlist=["STATS"]).STATS),
-                       "path": {k: took.get(k, 0) for k in ("forward", "forward_lazy_colour", "forward_merged_phases",
-                                                           "forward_view_order", "forward_prev_order", "capacity_redo", "backward_one_call",
-                                                           "backward_background_fill", "backward_staged", "backward_sink",
-                                                           "forward_rows_on_touch", "backward_rows_refilled", "forward_front_only",
-                                                           "forward_arena_slot", "forward_probe")},
-                       "path_note": f"counts over the {args.steps + args.warmup} headline steps: on-demand colours, merged "
-                                    "phases, view-keyed launch order, capacity misses, one-call backward, background fill, gradient rows cleared on touch",
-                       "host": ((f"whole step replayed as one hipGraph ({len(graphed_all)} graph(s): one per resident camera, replayed in "
-                                 f"turn; graphs.GraphedStep, fixed capacity ") +
-                                f"{graphed.capacity} intersections, no host synchronisation)" if graphed is not None
-                                else "eager PyTorch step (the reference's training loop is eager)")},
+                       "graph_timed": [graph_timed["hits"], graph_timed["captures"], graph_timed["calls"]],
+                       "path": {k: took.get(k, 0) for k in ("forward", "forward_lazy_colour", "forward_view_order", "capacity_redo",
+                                                           "backward_one_call", "backward_background_fill", "forward_front_only",
+                                                           "forward_probe")},
+                       "host": "whole-step hipGraphs" if graphed is not None else "eager"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "frac_of_guide_copy_6290": round(achieved / GUIDE_COPY_GBS, 5),
-                         "traffic": pmc.get(dom), "traffic_git_rev": pmc.get("git_rev"),
-                         "valu_issue_frac": vif.get(dom) if isinstance(vif, dict) else None,
-                         "valu_issue_budget": valu_budget,
+                         "traffic": pmc.get(dom), "traffic_source": "file",
+                         "algorithmic_bytes": abytes, "bytes_basis": "visited" if abytes is visited and sparse_paths else "nominal",
+                         "achieved_nominal": round(nominal / (ktimes[dom] * 1e-3) / 1e9, 2),
+                         "frac_nominal": round(nominal / (ktimes[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "units": u,
                          "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
-                         "kernel_ms_note": "mean per launch: HIP events recorded by the C entries directly around the compositing "
-                                           "kernels of the headline path, in a separate pass of plain launches after the timed region",
-                         "algorithmic_bytes": abytes,
-                         "algorithmic_bytes_note": "SURVEY 8(d): 88 P + 64 I + 60 N with I = all intersections (mean over the views)",
-                         "traversed_entries": I_trav,
-                         "achieved_traversed": (round(algorithmic_bytes("blend_bwd", N, I_trav, W * H, args.features, cd) / (ktimes[dom] * 1e-3) / 1e9, 2)
-                                                if (I_trav is not None and dom == "blend_bwd") else None),
-                         "traversed_note": "64 I replaced by 64 x the list entries the backward really stages (early termination: "
-                                           "per band, first entry .. deepest last_id); the dense-scene figure to read next to `achieved`",
-                         "copy_roof_GBs": round(roof, 1), "copy_roof_variants_GBs": roof_variants,
-                         "frac_of_copy_roof": round(achieved / max(roof, 1e-9), 5),
-                         "step_algorithmic_bytes": step_bytes, "step_GBs": round(step_gbs, 1),
-                         "step_frac": round(step_gbs / HBM_PEAK_GBS, 5),
-                         "step_frac_of_guide_copy_6290": round(step_gbs / GUIDE_COPY_GBS, 5),
-                         "step_frac_of_copy_roof": round(step_gbs / max(roof, 1e-9), 5),
-                         "note": "the compositing kernels are VALU (v_exp/FMA) issue bound, not HBM bound: "
-                                 "valu_issue_frac = instructions x 4 cycles / SIMD cycles (PMC, profiles/); valu_issue_budget: the same count priced "
-                                 "per instruction class, and the measured busy share of the vector ALU (DESIGN.md section 6)"},
+                         "valu_busy": vif.get(dom) if isinstance(vif, dict) else None,
+                         "copy_roof_GBs": round(roof, 1),
+                         "step_GBs": round(step_gbs, 1), "step_frac": round(step_gbs / HBM_PEAK_GBS, 5),
+                         "step_frac_nominal": round(step_nominal / (dev_med * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
         }
+        details = {"variants": variants, "graph_cache": ops.graph_cache_stats(), "graph_cache_timed": graph_timed,
+                   "graph_cache_headline": graph_all, "arena": dict(__import__("collab_splats_amd.arena", fromlist=["STATS"]).STATS),
+                   "path": dict(took), "n_isects_per_view": isects[:8], "copy_roof_variants_GBs": roof_variants,
+                   "units_per_step": units, "parallel_stats": dict(parallel.STATS)}
         if allreduce_ms:
             line["allreduce_ms"] = round(allreduce_ms[len(allreduce_ms) // 2], 4)
-        if args.features > 0:
-            line["config"]["workload"] = (f"the features model's call (rade_features_model.py:427-476): {N} random Gaussians, {view_txt} "
-                                          f"{W}x{H}, SH degree 3 -> clamp_min(c + 0.5, 0) fused with {args.features} feature channels "
-                                          f"-> {cd} composited channels ({args.render_mode}), fwd+bwd to means / quats / scales / "
-                                          f"opacities / SH coefficients AND features; one entry (rasterization(..., features=...))")
-            line["roofline"]["algorithmic_bytes_note"] = ("SURVEY 8(d) with 4 D' substituted in the colour terms (D' = "
-                                                          f"{cd}): see bench.algorithmic_bytes")
-            line["cpu_baseline_note"] = "not timed for this leg (the default run carries cpu_baseline and the gradient check)"
         if world == 1 and not args.no_cpu_baseline and not args.no_live_pmc and not args.dn_loss and args.features == 0 and graphed is None:
             live = live_pmc(args)
             if live and dom in live:
                 rf = line["roofline"]
-                rf["traffic"], rf["valu_issue_frac"] = live[dom]["traffic"], live[dom]["valu_issue_frac"]
-                rf["traffic_source"] = ("measured in this run: counters-only rocprofv3 passes (FETCH_SIZE, WRITE_SIZE, SQ) over a "
-                                        "short child run of the same workload, after the timed region")
-                rf["traffic_git_rev"] = git_rev()
-                rf["valu_busy_measured"] = live[dom]["valu_busy"]
-                rf["pmc_live"] = live
-            else:
-                line["roofline"]["traffic_source"] = "profiles/pmc_traffic.json (no live measurement: rocprofv3 missing, nested, or failed)"
+                rf["traffic"], rf["valu_busy"], rf["traffic_source"] = live[dom]["traffic"], live[dom]["valu_busy"], "live"
+                details["pmc_live"] = live
         if world == 1 and not args.no_cpu_baseline and not args.dn_loss and args.features == 0:
             import numpy as np
             from oracle.craster import CRaster
-            line["cpu_baseline"], keep = cpu_baseline(args, seed)
+            base, keep = cpu_baseline(args, seed)
+            details["cpu_baseline"] = base
+            line["cpu_baseline"] = {"value": base["value"], "unit": base["unit"], "cores": base["cores"], "kind": base["kind"],
+                                    "sample": base["sample_short"], "config1_value": base["config1"]["value"],
+                                    "threads1_value": base["threads1"]["value"]}
             cr = CRaster(np.float32)
             full = (os.cpu_count() or 1) >= 32 and args.cpu_sample < N <= 1_000_000
             mode.update(headline_mode)
@@ -777,31 +805,33 @@ def main():
                    torch.sigmoid(params_p["opacity_logits"]).detach().cpu().numpy())
             gcpu = torch.Generator().manual_seed(7)
             ups_np = [torch.rand(s, generator=gcpu) for s in ((1, H, W, cd), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3))]
-            ups_d = [u.to(dev) for u in ups_np]
+            ups_d = [u_.to(dev) for u_ in ups_np]
             # view 0 (the generator's identity view) AND the heaviest of the rotated views the headline cycles through
-            # (seven of its eight views are rotated; view 3 stages ~40 % more entries per band than view 0)
             per_view = {}
             for v in (0, args.parity_view):
                 sc_v = dict(sc_p, viewmats=view_matrix(v))
-                st, gr = _c_port_run(cr, sc_v, act[0], act[1], W, H, args, [u[0].numpy() for u in ups_np])
+                st, gr = _c_port_run(cr, sc_v, act[0], act[1], W, H, args, [u_[0].numpy() for u_ in ups_np])
                 per_view[f"view{v}"] = parity(args, params_p, views[v], Ks, W, H, headline_mode["ext"], ups_d, st, gr, act,
                                               what.replace("view 0", f"view {v}"), cr)
-                if v == 0:
-                    # what the largest figure (means) is made of: the same call with the bitwise-reproducible backward (slab +
-                    # fixed-order reduce) -- if the error stays, it is not the order of the atomic sums
-                    det = parity(args, params_p, views[v], Ks, W, H, headline_mode["ext"], ups_d, st, gr, act, what, cr, deterministic=True)
-                    per_view["view0_deterministic"] = {k: det[k] for k in ("value", "per_tensor", "gradient_mode")}
-            head = per_view["view0"]
-            timed_views = [pv for k, pv in per_view.items() if not k.endswith("deterministic")]
-            line["grad_max_rel_err"] = dict(
-                head, views=per_view, value=float(f"{max(pv['value'] for pv in timed_views):.3e}"),
-                value_clean=float(f"{max(pv['value_clean'] for pv in timed_views):.3e}"),
-                rows_over_unexplained=sum(pv["rows_over_unexplained"] for pv in timed_views),
-                reading="value: all rows of both views; value_clean: the rows whose screen box covers no pixel where the two "
-                        "implementations took different sides of a threshold (alpha 1/255, T' 1e-4, T 0.5); every row above "
-                        "the target is counted in rows_over and must be covered by such a pixel (rows_flip) -- "
-                        "rows_over_unexplained must be 0")
+            timed_views = list(per_view.values())
+            details["grad_max_rel_err"] = per_view
+            # value: all rows of both views; value_clean: the rows whose screen box covers no pixel where the two implementations
+            # took different sides of a threshold (alpha 1/255, T' 1e-4, T 0.5); every row above the target is counted and must be
+            # covered by such a pixel -- rows_over_unexplained must be 0
+            line["grad_max_rel_err"] = {
+                "value": float(f"{max(pv['value'] for pv in timed_views):.3e}"),
+                "value_clean": float(f"{max(pv['value_clean'] for pv in timed_views):.3e}"),
+                "rows_over_unexplained": sum(pv["rows_over_unexplained"] for pv in timed_views),
+                "pixels_unexplained": sum(pv["pixels_unexplained"] for pv in timed_views),
+                "target": 1e-4, "on": ("full workload" if full else "cpu sample") + f", views 0 and {args.parity_view}",
+                "against": "oracle/craster.c (C port; parity unpinned)",
+                "views": {k: {"value": pv["value"], "value_clean": pv["value_clean"], "flip_pixels": pv["flip_pixels"],
+                              "rows_over": sum(t["rows_over"] for t in pv["per_tensor"].values())} for k, pv in per_view.items()}}
         print(json.dumps(line), flush=True)
+        if args.details:
+            os.makedirs(os.path.dirname(os.path.abspath(args.details)), exist_ok=True)
+            with open(args.details, "w") as f:
+                json.dump(dict(line, details=details), f, indent=1)
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -1035,6 +1035,7 @@ class _RasterFused(torch.autograd.Function):
         imgs, bins, sched = _raster_phase_b(P, state, cd)
         render, alpha, exp_depth, med_depth, normal, last_ids, median_ids = imgs
         extra["bins"] = bins
+        bins["grec"] = grec                                              # (the packed records: bench.py counts the colours that were set)
         ctx.P, ctx.bins, ctx.sched, ctx.cd, ctx.absgrad = P, bins, sched, cd, absgrad
         ctx.color_args = (deg, kd, n_color, per_cam)
         ctx.depth_slot = 12 + n_color if (depth_channel and nxq == 0) else -1
