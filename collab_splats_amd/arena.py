@@ -51,7 +51,10 @@ STATS: "collections.Counter" = collections.Counter()             # slots_created
 # (torch.cuda.empty_cache(): a synchronisation, paid once per refinement step of a densifying run, at the moment every
 # address changes anyway; at most two generations of rings are held).
 USE_POOL = os.environ.get("MISPLAT_ARENA_POOL", "1") == "1"
-_TRIM_PENDING = False
+# ... and only once the dropped rings add up to this much (a trim also moves the blocks the CALLER's temporaries come from --
+# one round of graph captures for a steady loop that happens to see it: not worth it for a few megabytes of small scenes)
+TRIM_BYTES = int(float(os.environ.get("MISPLAT_ARENA_TRIM_MB", "256")) * (1 << 20))
+_TRIM_PENDING = 0                                                 # bytes of the slots of dropped rings not yet returned
 
 
 def _new_pool(dev: torch.device):
@@ -75,8 +78,8 @@ def pool_ctx(dev: torch.device, pool=None):
 def trim() -> None:
     """Give the memory of dropped rings back to the device (their pools are gone: their cached blocks are free to go)."""
     global _TRIM_PENDING
-    if _TRIM_PENDING and not torch.cuda.is_current_stream_capturing():
-        _TRIM_PENDING = False
+    if _TRIM_PENDING >= max(TRIM_BYTES, 1) and not torch.cuda.is_current_stream_capturing():
+        _TRIM_PENDING = 0
         torch.cuda.empty_cache()
         STATS["trims"] += 1
 
@@ -167,6 +170,9 @@ class Ring:
             size = (int(size * 1.25) + ALIGN_SLOT - 1) // ALIGN_SLOT * ALIGN_SLOT
         return size
 
+    def nbytes(self) -> int:
+        return sum(s.size for s in self.slots)
+
     def release(self, slot: Optional[Slot], demand: int) -> None:
         """What the call asked for in total (also when it had no slot): the next slot of this ring is sized for it."""
         self.want = max(self.want, int(demand))
@@ -189,8 +195,7 @@ def ring(key: tuple, dev: torch.device) -> Optional[Ring]:
         trim()                                                    # (a new shape: the moment abandoned rings' memory is wanted)
         r = _RINGS[key] = Ring(dev)
         while len(_RINGS) > MAX_RINGS:
-            _RINGS.popitem(last=False)                            # (its slots live on while views of them do)
-            _TRIM_PENDING = True
+            _TRIM_PENDING += _RINGS.popitem(last=False)[1].nbytes()   # (its slots live on while views of them do)
     else:
         _RINGS.move_to_end(key)
     r.last_lookup = _LOOKUPS
@@ -199,9 +204,9 @@ def ring(key: tuple, dev: torch.device) -> Optional[Ring]:
             k0 = next(iter(_RINGS))
             if _LOOKUPS - _RINGS[k0].last_lookup <= IDLE_LOOKUPS:
                 break
-            del _RINGS[k0]
+            _TRIM_PENDING += _RINGS.pop(k0).nbytes()
             STATS["rings_dropped_idle"] += 1
-            _TRIM_PENDING = True                                  # (returned to the device when the next new shape arrives: a
+                                                                  # (returned to the device when the next new shape arrives: a
                                                                   #  trim moves the caller's allocator blocks too, i.e. costs
                                                                   #  the steady state a round of graph captures -- at a shape
                                                                   #  change everything is new anyway)
@@ -256,8 +261,7 @@ class Carver:
 
 def reset() -> None:
     global _TRIM_PENDING
-    if _RINGS:
-        _TRIM_PENDING = True
+    _TRIM_PENDING += sum(r.nbytes() for r in _RINGS.values())
     _RINGS.clear()
     if torch.cuda.is_available():
         trim()

@@ -31,3 +31,17 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(200): step()
 torch.cuda.synchronize(); pr.disable()
 st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+st.sort_stats("cumtime").print_stats(45)
+# the backward runs on the autograd engine's device thread, which cProfile does not see: time it by hand
+import collab_splats_amd.ops as ops
+orig = ops._RasterFused.backward
+acc = [0.0, 0]
+def timed_bwd(ctx, *a):
+    t = time.perf_counter()
+    r = orig(ctx, *a)
+    acc[0] += time.perf_counter() - t; acc[1] += 1
+    return r
+ops._RasterFused.backward = staticmethod(timed_bwd)
+for _ in range(200): step()
+torch.cuda.synchronize()
+print("python time inside _RasterFused.backward: %.1f us per call (%d calls)" % (acc[0] / max(acc[1], 1) * 1e6, acc[1]))

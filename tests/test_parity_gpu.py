@@ -2536,7 +2536,7 @@ def test_arena_memory_stays_bounded_while_the_scene_grows(dev):
         del leaves
         n = int(n * 1.2)
     took = {k: arena.STATS[k] - before.get(k, 0) for k in arena.STATS}
-    assert took.get("rings_dropped_idle", 0) >= 8 and took.get("trims", 0) >= 4, took
+    assert took.get("rings_dropped_idle", 0) >= 8 and took.get("trims", 0) >= 2, took   # (a trim per >= 256 MB of dropped slots)
     assert len(arena._RINGS) <= 4
     # what the first shape cost, scaled by the growth of N (x 4.3 over the run), bounds the last one -- the sum over all nine
     # shapes would be ~ 4.8 x that
