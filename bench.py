@@ -89,6 +89,11 @@ def parse():
                          "`variants` then also times the reference's own composition (spherical_harmonics, clamp_min, cat, "
                          "rasterization(sh_degree=None)) through the same library")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--key-trace", action="store_true",
+                    help="print (stderr) the argument-block fields that differ between two visits of a view: why a graph did not replay")
+    ap.add_argument("--rehearse-sparse", action="store_true",
+                    help="with --buckets on one GPU: run every step of the sparse shared-Gaussian reduce except the collective itself")
+    ap.add_argument("--oversubscribe", action="store_true", help="--gpus N on fewer than N devices (a rehearsal of the plumbing)")
     ap.add_argument("--parity-view", type=int, default=3, help="the rotated view the gradient check runs on besides view 0")
     ap.add_argument("--cpu-sample", type=int, default=100_000, help="Gaussians in the CPU-baseline sample")
     ap.add_argument("--details", default=None, metavar="FILE",
@@ -376,9 +381,9 @@ def spawn_ranks(args) -> int:
     """``python bench.py --gpus N`` without a torchrun environment: start the N ranks as CHILD processes (nothing in
     this process has touched the GPU yet) and relay their output; rank 0 of the children prints the JSON line."""
     n_dev = torch.cuda.device_count()               # does not initialise the GPU
-    if n_dev < args.gpus and os.environ.get("MISPLAT_OVERSUBSCRIBE", "0") != "1":
+    if n_dev < args.gpus and not args.oversubscribe:
         print(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible "
-              f"(MISPLAT_OVERSUBSCRIBE=1 rehearses N ranks on fewer devices)", file=sys.stderr)
+              f"(--oversubscribe rehearses N ranks on fewer devices)", file=sys.stderr)
         return 2
     port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
@@ -465,6 +470,10 @@ def main():
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     from collab_splats_amd import ops, radegs
+    if args.key_trace:
+        ops.KEY_TRACE = []
+    if args.rehearse_sparse:
+        parallel.REHEARSE = True
     from collab_splats_amd.synthetic import random_scene, view_matrix
 
     N, W, H = args.gaussians, args.width, args.height

@@ -23,20 +23,19 @@ import torch
 from torch import Tensor
 
 ENABLED = os.environ.get("MISPLAT_ARENA", "1") == "1"
-MAX_SLOTS = int(os.environ.get("MISPLAT_ARENA_SLOTS", "4"))
-MAX_RINGS = int(os.environ.get("MISPLAT_ARENA_RINGS", "12"))      # distinct (stream, shape, role) keys kept; LRU beyond
+MAX_SLOTS = 4
+MAX_RINGS = 12      # distinct (stream, shape, role) keys kept; LRU beyond
 # A ring nobody has asked for in this many lookups is dropped: densification changes the number of Gaussians every few hundred
 # steps and never comes back to the old one (scripts/soak.py: +0.7 GB of reserved memory per change at 1 M without this).
-IDLE_LOOKUPS = int(os.environ.get("MISPLAT_ARENA_IDLE", "64"))
+IDLE_LOOKUPS = 64
 # Placement inside a slot.  Measured (5 M Gaussians / 1080p, one box): with every array of >= 1 MiB on a 2 MiB boundary
 # the kernels that write several arrays at the same element offset (bucket_rows: order / rect_sorted / depth_sorted at
 # [pos]) ran 2 x slower (74 -> 182 us; their streams then map to the same memory channels) and the step lost 0.1 ms; the
 # 1 M step lost 4 %.  So arrays are packed at 256-byte granularity, as a one-allocation carve always was -- what the arena
-# contributes is that the addresses REPEAT (graph replay), not where they are.  MISPLAT_ARENA_ALIGN_MB > 0 restores the
-# aligned placement of big arrays for an A/B.
+# contributes is that the addresses REPEAT (graph replay), not where they are.
 BIG = 1 << 20
 ALIGN_SLOT = 2 << 20              # the slot itself starts on a 2 MiB boundary
-ALIGN_BIG = int(float(os.environ.get("MISPLAT_ARENA_ALIGN_MB", "0")) * (1 << 20)) or 256
+ALIGN_BIG = 256
 ALIGN_SMALL = 256
 STATS: "collections.Counter" = collections.Counter()             # slots_created / slot_hits / fallbacks / regrown
 # The slots (and the allocator memory a ring's FIRST call runs from) come from a memory pool of their own
@@ -50,7 +49,7 @@ STATS: "collections.Counter" = collections.Counter()             # slots_created
 # -- called from ``ring()`` when the next NEW shape arrives with a dropped ring on record -- returns them to the device
 # (torch.cuda.empty_cache(): a synchronisation, paid once per refinement step of a densifying run, at the moment every
 # address changes anyway; at most two generations of rings are held).
-USE_POOL = os.environ.get("MISPLAT_ARENA_POOL", "1") == "1"
+USE_POOL = True
 # ... and only once the dropped rings add up to this much (a trim also moves the blocks the CALLER's temporaries come from --
 # one round of graph captures for a steady loop that happens to see it: not worth it for a few megabytes of small scenes)
 TRIM_BYTES = int(float(os.environ.get("MISPLAT_ARENA_TRIM_MB", "256")) * (1 << 20))

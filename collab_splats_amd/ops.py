@@ -37,8 +37,7 @@ def set_deterministic(flag: bool) -> None:
 # strip, which the BACKWARD of the same step uses (always valid: same lists, same early termination) and which is
 # remembered per image shape for the NEXT FORWARD (pays when consecutive calls look at similar views -- evaluation
 # sweeps, repeated benchmark steps; harmless otherwise: a stale order is just another arbitrary order).
-UNIT_ORDER = os.environ.get("MISPLAT_UNIT_ORDER", "1") == "1"
-UNIT_ORDER_FWD = os.environ.get("MISPLAT_UNIT_ORDER_FWD", "1") == "1"
+UNIT_ORDER = True
 # keyed by (device, STREAM, shape): the buffer is written by misplat_unit_order on the stream of the call that produced it,
 # so only a later call on the same stream is ordered behind that write (a forward on another stream -- an evaluation
 # render, a second thread -- starts from the default order instead of reading a half-written permutation)
@@ -63,10 +62,9 @@ BANDS = 2                              # MISPLAT_BANDS: wavefronts (16 x 8 pixel
 # (include/misplat.h: misplat_params.unit_sel) -- a training loop revisits its cameras every epoch, so every view finds
 # the order of its own last visit, where a single "previous call" order belongs to some other view (measured on the
 # bench's 8 cycling views: as good as no order).  16 336 words per record at 1080p: 16.7 MB for 256 slots.
-ORDER_BY_VIEW = os.environ.get("MISPLAT_ORDER_BY_VIEW", "1") == "1"
-ORDER_SLOTS = int(os.environ.get("MISPLAT_ORDER_SLOTS", "256"))
+ORDER_SLOTS = 256
 ORDER_HEADER = 16                     # MISPLAT_ORDER_HEADER
-ORDER_TABLES_MAX = int(os.environ.get("MISPLAT_ORDER_TABLES", "8"))     # (device, stream, shape) keys kept, least recently used beyond
+ORDER_TABLES_MAX = 8     # (device, stream, shape) keys kept, least recently used beyond
 _ORDER_TABLES: "collections.OrderedDict[tuple, tuple]" = collections.OrderedDict()
 
 
@@ -76,7 +74,7 @@ def _order_slots(table: Tensor, stride: int) -> int:
 
 def _order_table(P: Params, dev: torch.device):
     """(table, sel, stride) of this device / stream / shape, or None when view-keyed orders are off."""
-    if not (UNIT_ORDER and UNIT_ORDER_FWD and ORDER_BY_VIEW and ORDER_SLOTS > 0):
+    if not (UNIT_ORDER and ORDER_SLOTS > 0):
         return None
     units = P.tile_w * P.tile_h * P.n_cams * BANDS
     key = (dev.index, _stream_id(), P.n_cams, P.tile_w, P.tile_h, ORDER_SLOTS)
@@ -126,7 +124,7 @@ class _UnitSchedule:
     def before_forward(self, P: Params) -> None:
         if not self.on:
             return
-        last = _LAST_ORDER.get(self.key) if UNIT_ORDER_FWD else None
+        last = _LAST_ORDER.get(self.key)
         P.unit_perm = last.data_ptr() if last is not None else None
         P.unit_work = self.work.data_ptr()
         self._keep = last                                      # stays alive until the launch has been enqueued
@@ -200,7 +198,6 @@ def _kernel_event_pair():
 
 
 # SH colours: the forward keeps the Jacobian d rgb / d dir for the backward (see misplat_color_fwd)
-SH_AUX = os.environ.get("MISPLAT_SH_AUX", "1") == "1"
 def _c(t: Optional[Tensor]) -> Optional[Tensor]:
     return None if t is None else t.contiguous()
 
@@ -212,105 +209,6 @@ def _f32(t: Tensor, name: str) -> Tensor:
     return t.contiguous()
 
 
-# ----------------------------------------------------------------------------- projection
-
-class _Project(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, means, quats, scales, opacities, viewmats, Ks, P: Params):
-        lib = _lib.load()
-        require_gpu(means, quats, scales, viewmats, Ks)
-        N, Cn = P.n_gauss, P.n_cams
-        dev = means.device
-        f = dict(device=dev, dtype=torch.float32)
-        radii = torch.empty(Cn, N, 2, device=dev, dtype=torch.int32)
-        means2d = torch.empty(Cn, N, 2, **f)
-        depths = torch.empty(Cn, N, **f)
-        conics = torch.empty(Cn, N, 3, **f)
-        comps = torch.empty(Cn, N, **f)
-        ray_ts = torch.empty(Cn, N, **f)
-        ray_planes = torch.empty(Cn, N, 2, **f)
-        normals = torch.empty(Cn, N, 3, **f)
-        check(lib.misplat_project_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
-                                      ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
-                                      ptr(conics), ptr(comps), ptr(ray_ts), ptr(ray_planes), ptr(normals),
-                                      stream_ptr()), "misplat_project_fwd")
-        ctx.P = P
-        ctx.save_for_backward(means, quats, scales, viewmats, Ks, radii)
-        ctx.mark_non_differentiable(radii)
-        return radii, means2d, depths, conics, comps, ray_ts, ray_planes, normals
-
-    @staticmethod
-    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comps, v_ray_ts, v_ray_planes, v_normals):
-        lib = _lib.load()
-        means, quats, scales, viewmats, Ks, radii = ctx.saved_tensors
-        P = ctx.P
-        v_means = torch.empty_like(means)
-        v_quats = torch.empty_like(quats)
-        v_scales = torch.empty_like(scales)
-        g = [_c(t) for t in (v_means2d, v_depths, v_conics, v_comps, v_ray_ts, v_ray_planes, v_normals)]
-        check(lib.misplat_project_bwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(viewmats), ptr(Ks),
-                                      ptr(radii), *[ptr(t) for t in g], ptr(v_means), ptr(v_quats),
-                                      ptr(v_scales), stream_ptr()), "misplat_project_bwd")
-        return v_means, v_quats, v_scales, None, None, None, None
-
-
-def project(means: Tensor, quats: Tensor, scales: Tensor, opacities: Optional[Tensor], viewmats: Tensor,
-            Ks: Tensor, P: Params):
-    """8-tuple (radii, means2d, depths, conics, compensations, ray_ts, ray_planes, normals)."""
-    means, quats, scales = _f32(means, "means"), _f32(quats, "quats"), _f32(scales, "scales")
-    viewmats, Ks = _f32(viewmats, "viewmats"), _f32(Ks, "Ks")
-    op = None if opacities is None else _f32(opacities.detach(), "opacities")
-    return _Project.apply(means, quats, scales, op, viewmats, Ks, P)
-
-
-# ----------------------------------------------------------------------------- SH
-
-class _SphericalHarmonics(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, dirs, coeffs, degree: int, radii):
-        lib = _lib.load()
-        require_gpu(dirs, coeffs)
-        N, K = coeffs.shape[0], coeffs.shape[1]
-        Cn = dirs.numel() // (3 * N) if N > 0 else 1
-        colors = torch.empty(dirs.shape[:-1] + (3,), device=dirs.device, dtype=torch.float32)
-        check(lib.misplat_sh_fwd(C.c_int32(N), C.c_int32(Cn), C.c_int32(K), C.c_int32(degree), ptr(dirs),
-                                 ptr(coeffs), ptr(radii), ptr(colors), stream_ptr()), "misplat_sh_fwd")
-        ctx.save_for_backward(dirs, coeffs, radii)
-        ctx.degree, ctx.Cn = degree, Cn
-        return colors
-
-    @staticmethod
-    def backward(ctx, v_colors):
-        lib = _lib.load()
-        dirs, coeffs, radii = ctx.saved_tensors
-        N, K = coeffs.shape[0], coeffs.shape[1]
-        v_coeffs = torch.empty_like(coeffs)
-        v_dirs = torch.empty_like(dirs)
-        check(lib.misplat_sh_bwd(C.c_int32(N), C.c_int32(ctx.Cn), C.c_int32(K), C.c_int32(ctx.degree),
-                                 ptr(dirs), ptr(coeffs), ptr(radii), ptr(_c(v_colors)), ptr(v_coeffs),
-                                 ptr(v_dirs), stream_ptr()), "misplat_sh_bwd")
-        return v_dirs, v_coeffs, None, None
-
-
-def spherical_harmonics_raw(degree: int, dirs: Tensor, coeffs: Tensor, radii: Optional[Tensor] = None) -> Tensor:
-    """dirs [..., N, 3] (C leading cameras allowed), coeffs [N, K, 3] -> [..., N, 3]; raw SH."""
-    if coeffs.dim() != 3 or coeffs.shape[-1] != 3:
-        raise ValueError(f"coeffs must be [N, K, 3], got {tuple(coeffs.shape)}")
-    if dirs.shape[-2:] != (coeffs.shape[0], 3):
-        raise ValueError(f"dirs {tuple(dirs.shape)} does not match coeffs {tuple(coeffs.shape)}")
-    if not 0 <= degree <= 3 or (degree + 1) ** 2 > coeffs.shape[1]:
-        raise ValueError(f"degree {degree} needs {(degree + 1) ** 2} <= K={coeffs.shape[1]} and degree <= 3")
-    r = None if radii is None else radii.contiguous()
-    return _SphericalHarmonics.apply(_f32(dirs, "dirs"), _f32(coeffs, "coeffs"), int(degree), r)
-
-
-# ----------------------------------------------------------------------------- binning
-
-# Ordering (csrc/bucket.hip + csrc/binning.hip; gives exactly the (tile, depth, Gaussian id) order of a one-shot 64-bit key
-# sort): rows are put into coarse screen-cell order, a workgroup of 1024 neighbouring rows counts / fills its intersections
-# per tile through an LDS window with one global atomic per (workgroup, tile): every intersection is written once (its row,
-# 4 bytes) and no tile-id array exists; one workgroup per tile then sorts its bucket by (depth, row).  All sizes live on
-# the device.
 _PLAN_CACHE: Dict[tuple, Tuple[int, int]] = {}
 
 
@@ -343,201 +241,6 @@ def bucket_plan(P: Params) -> Tuple[int, int]:
     return _PLAN_CACHE[key]
 
 
-def _read_back(n_dev: Tensor) -> Dict:
-    """Asynchronous read-back of a device int64 (pinned buffer + event)."""
-    host = torch.empty(1, dtype=torch.int64, pin_memory=True)
-    host.copy_(n_dev, non_blocking=True)
-    event = torch.cuda.Event()
-    event.record()
-    return dict(host=host, event=event)
-
-
-@torch.no_grad()
-def start_binning(P: Params, means2d: Tensor, radii: Tensor) -> Dict[str, Tensor]:
-    """First half of ``bin_tiles``: everything that does not need the number of intersections on the host (tile
-    counts, the cell ordering of the rows), and an ASYNCHRONOUS read-back of that number.  Called right
-    after the projection kernel, before the colour kernel is launched, so that the host's wait for n_isects -- the one
-    sync of the step -- and the launches that follow it are hidden behind the colour kernel instead of idling the GPU."""
-    lib = _lib.load()
-    dev = means2d.device
-    total = P.n_gauss * P.n_cams
-    n_tiles = P.tile_w * P.tile_h * P.n_cams
-    n_cells, n_blocks = bucket_plan(P)
-    tiles_per_gauss, rect2, cellhist, cell_count, cell_cursor, cell_offs, order, rect_sorted, counters, tile_count = _carve(
-        dev, (total, 2 * total, n_blocks * n_cells, n_cells, n_cells, n_cells + 1, total, 2 * total, 4, n_tiles + 1))
-    counters = counters.view(torch.int64)
-    check(lib.misplat_bucket_count(C.byref(P), ptr(means2d), ptr(radii), ptr(tiles_per_gauss), ptr(rect2),
-                                   ptr(cellhist), ptr(cell_count), ptr(counters), C.c_int32(0), stream_ptr()),
-          "misplat_bucket_count")
-    pend = _read_back(counters[0:1])
-    check(lib.misplat_bucket_rows(C.byref(P), ptr(tiles_per_gauss), ptr(rect2), ptr(cellhist), ptr(cell_count),
-                                  ptr(cell_cursor), ptr(cell_offs), ptr(order), ptr(rect_sorted), ptr(counters),
-                                  ptr(tile_count), ptr(None), C.c_int32(0), stream_ptr()), "misplat_bucket_rows")
-    pend.update(tiles_per_gauss=tiles_per_gauss, rect2=rect_sorted, order=order, counters=counters, tile_count=tile_count)
-    return pend
-
-
-@torch.no_grad()
-def bin_tiles(P: Params, means2d: Tensor, radii: Tensor, depths: Tensor,
-              pending: Optional[Dict[str, Tensor]] = None) -> Dict[str, Tensor]:
-    """Tile intersection + ordering + offsets.  One host read-back: n_isects.
-
-    Result: ``flatten_ids[n_isects]`` (Gaussian rows in (tile, depth, id) order), ``isect_offsets[n_tiles + 1]`` (the
-    last entry is n_isects), ``tiles_per_gauss``; in deterministic mode also ``slots`` (the emission slot of every
-    sorted intersection: the row of the gradient slab)."""
-    lib = _lib.load()
-    dev = means2d.device
-    total = P.n_gauss * P.n_cams
-    n_tiles = P.tile_w * P.tile_h * P.n_cams
-    deterministic = DETERMINISTIC_BACKWARD
-    pend = pending if pending is not None else start_binning(P, means2d, radii)
-    tiles_per_gauss = pend["tiles_per_gauss"]
-    pend["event"].synchronize()                                   # the one sync of the step (usually long past)
-    n_isects = int(pend["host"][0])
-    if n_isects >= 2 ** 31:
-        raise _lib.MisplatError(f"{n_isects} tile intersections exceed int32 indexing")
-    depths = depths.contiguous()
-    out = dict(tiles_per_gauss=tiles_per_gauss, n_isects=n_isects, depths=depths, tile_ids=None, n_tiles=n_tiles)
-    offsets, payload, flatten_ids, scratch, isect_gid = _carve(
-        dev, (n_tiles + 2, n_isects, n_isects, 2 * n_isects, n_isects if deterministic else 0))
-    cum = None
-    if deterministic:                                         # emission slots index the gradient slab
-        cum = (torch.cumsum(tiles_per_gauss, dim=0, dtype=torch.int64) - tiles_per_gauss).contiguous()
-        out["cum"] = cum
-    else:
-        isect_gid = None
-    check(lib.misplat_bucket_tiles(C.byref(P), ptr(pend["order"]), ptr(pend["rect2"]), ptr(pend["counters"]),
-                                   ptr(pend["tile_count"]), ptr(offsets), ptr(cum), C.c_int64(n_isects), ptr(payload),
-                                   ptr(isect_gid), stream_ptr()), "misplat_bucket_tiles")
-    if n_isects > 0:
-        check(lib.misplat_tile_sort(ptr(offsets), C.c_int32(n_tiles), C.c_int64(n_isects), ptr(depths), ptr(isect_gid),
-                                    ptr(payload), ptr(flatten_ids), ptr(scratch), C.c_int32(3), stream_ptr()),
-              "misplat_tile_sort")
-    out.update(slots=payload if deterministic else None, flatten_ids=flatten_ids, isect_offsets=offsets[:n_tiles + 1])
-    return out
-
-
-@torch.no_grad()
-def complete_bins(bins: Dict[str, Tensor]) -> Tensor:
-    """``flatten_ids`` with every tile's list sorted to its end.  After a front-only forward only the head of each list
-    is there (the part the compositing and the backward read); this sorts every bucket in full from ``payload``, which is
-    still a permutation of it -- the heads come out as they were (they are the first entries of the sorted lists), so it may
-    run before or after the backward."""
-    part = bins.get("partial")
-    if part is not None:
-        n_tiles = bins["n_tiles"]
-        if part["cap"] > 0:
-            # (the bucket entries are positions in the cell-ordered row list: flags bit 2)
-            check(_lib.load().misplat_tile_sort(ptr(part["offsets"]), C.c_int32(n_tiles), C.c_int64(part["cap"]),
-                                                ptr(part["depth_sorted"]), ptr(part["row_map"]), ptr(part["payload"]),
-                                                ptr(part["flatten_ids"]), ptr(part["scratch"]), C.c_int32(7), stream_ptr()),
-                  "misplat_tile_sort")
-        bins["partial"] = None
-        PATH_STATS["bins_completed"] += 1
-    return bins["flatten_ids"]
-
-
-@torch.no_grad()
-def isect_ids(bins: Dict[str, Tensor]) -> Tensor:
-    """gsplat's ``meta["isect_ids"]``: the sorted 64-bit keys (tile << 32 | depth bits), on demand."""
-    lib = _lib.load()
-    complete_bins(bins)
-    n = bins["n_isects"]
-    out = torch.empty(n, device=bins["flatten_ids"].device, dtype=torch.int64)
-    if bins["tile_ids"] is None:                       # no sorted tile-id array exists: rebuild it from the offsets
-        cnt = torch.diff(bins["isect_offsets"].long())
-        bins["tile_ids"] = torch.repeat_interleave(torch.arange(cnt.numel(), device=cnt.device, dtype=torch.int32), cnt)
-    check(lib.misplat_isect_ids(ptr(bins["tile_ids"]), ptr(bins["flatten_ids"]), ptr(bins["depths"]),
-                                C.c_int64(n), ptr(out), stream_ptr()), "misplat_isect_ids")
-    return out
-
-
-def _cum_by_row(bins: Dict[str, Tensor]) -> Tensor:
-    """First emission slot of every Gaussian row (deterministic backward only; built lazily)."""
-    if "cum" not in bins:
-        tpg = bins["tiles_per_gauss"]
-        bins["cum"] = (torch.cumsum(tpg, dim=0, dtype=torch.int64) - tpg).contiguous()
-    return bins["cum"]
-
-
-# ----------------------------------------------------------------------------- blending
-
-class _Blend(torch.autograd.Function):
-    """Compositing of <= 4 colour channels + alpha + expected/median depth + normal."""
-
-    @staticmethod
-    def forward(ctx, means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Params,
-                bins: Dict[str, Tensor], absgrad: bool, pass_index: int = 0):
-        lib = _lib.load()
-        ctx.pass_index = pass_index
-        require_gpu(means2d)
-        Cn, N, H, W = P.n_cams, P.n_gauss, P.height, P.width
-        cd = colors.shape[-1]
-        dev = means2d.device
-        rows = Cn * N
-        grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
-        check(lib.misplat_pack(C.c_int64(rows), C.c_int32(cd), ptr(means2d), ptr(conics), ptr(opac),
-                               ptr(ray_ts), ptr(ray_planes), ptr(normals), ptr(colors), ptr(grec),
-                               stream_ptr()), "misplat_pack")
-        f = dict(device=dev, dtype=torch.float32)
-        render = torch.empty(Cn, H, W, cd, **f)
-        alpha = torch.empty(Cn, H, W, 1, **f)
-        exp_depth = torch.empty(Cn, H, W, 1, **f)
-        med_depth = torch.empty(Cn, H, W, 1, **f)
-        normal = torch.empty(Cn, H, W, 3, **f)
-        last_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
-        median_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
-        sched = _UnitSchedule(P, dev)
-        with _timed("blend_fwd"):
-            sched.before_forward(P)
-            check(lib.misplat_blend_fwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
-                                        ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(render),
-                                        ptr(alpha), ptr(exp_depth), ptr(med_depth), ptr(normal), ptr(last_ids),
-                                        ptr(median_ids), stream_ptr()), "misplat_blend_fwd")
-        sched.after_forward(P)
-        ctx.sched = sched
-        ctx.P, ctx.bins, ctx.absgrad, ctx.cd = P, bins, absgrad, cd
-        ctx.means2d_ref = means2d if absgrad else None
-        ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids, render)
-        ctx.mark_non_differentiable(last_ids, median_ids)
-        ctx.set_materialize_grads(False)               # absent upstream gradients arrive as None
-        return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
-
-    @staticmethod
-    def backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, _l, _m):
-        ctx.sched.before_backward(ctx.P)
-        v_grec, v_abs = _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
-        _UnitSchedule.done(ctx.P)
-        P, cd = ctx.P, ctx.cd
-        Cn, N = P.n_cams, P.n_gauss
-        g = v_grec.view(Cn, N, MISPLAT_REC)
-        if ctx.absgrad:
-            # gsplat convention: the 2-D |gradient| rides on the means2d tensor for the strategy; the 4-channel
-            # passes of one render (rendering.py generic path) each add their channels' share
-            # (|.| is taken per pass, so with more than one pass the sum is an upper bound of the one-pass value)
-            parts = ctx.means2d_ref.__dict__.setdefault("_absgrad_parts", {})
-            parts[ctx.pass_index] = v_abs.view(Cn, N, 2)
-            ctx.means2d_ref.absgrad = parts[0] if len(parts) == 1 and 0 in parts else sum(parts.values())
-        return (g[..., 0:2], g[..., 2:5], g[..., 5], g[..., 12:12 + cd], g[..., 6], g[..., 7:9],
-                g[..., 9:12], None, None, None, None, None)
-
-
-def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Params, bins, absgrad=False,
-          pass_index: int = 0):
-    """``pass_index``: which 4-channel pass of one render this is (rendering.py generic path); every pass adds its
-    channels' share to ``means2d.absgrad``."""
-    if colors.shape[-1] < 1 or colors.shape[-1] > 4:
-        raise ValueError("blend() takes 1..4 colour channels per pass")
-    if pass_index == 0:
-        means2d.__dict__.pop("_absgrad_parts", None)
-    args = [_f32(t, n) for t, n in ((means2d, "means2d"), (conics, "conics"), (opac, "opacities"),
-                                    (colors, "colors"), (ray_ts, "ray_ts"), (ray_planes, "ray_planes"),
-                                    (normals, "normals"), (Ks, "Ks"))]
-    if args[0] is not means2d:
-        raise ValueError("means2d must be contiguous float32 so that its .grad/.absgrad can be retained")
-    return _Blend.apply(*args, P, bins, bool(absgrad), int(pass_index))
-
-
 # ----------------------------------------------------------------------------- one host entry per phase
 
 # The reference's path (RGB / RGB+ED with SH or pass-through colours, atomic gradient mode, "cells" ordering) goes
@@ -545,19 +248,18 @@ def blend(means2d, conics, opac, colors, ray_ts, ray_planes, normals, Ks, P: Par
 # and three allocations per forward instead of ~15 calls and ~30 allocations.  SPECULATE: phase B is enqueued with a
 # capacity guessed from the previous call of the same shape BEFORE the host has seen the intersection count; the
 # count is checked afterwards (exact results always: an overflow re-runs phase B with the exact size).
-FUSED_ENTRY = os.environ.get("MISPLAT_FUSED", "1") == "1"
-SPECULATE = os.environ.get("MISPLAT_SPECULATE", "1") == "1"
-CAP_MARGIN = float(os.environ.get("MISPLAT_CAP_MARGIN", "1.1"))        # re-chosen when the count comes within this of it
+FUSED_ENTRY = True
+SPECULATE = True
+CAP_MARGIN = 1.1        # re-chosen when the count comes within this of it
 # A capacity, once chosen, STAYS: it is part of every phase-B argument block (a change re-captures every graph of the shape)
 # and it sizes the per-tile lists inside the arena slot.  The first choice (and every later increase) is generous -- the views
 # of one scene differ by tens of percent in their counts (the bench's eight: 3.8 - 6.4 M) --, address space is what it costs.
-CAP_FIRST_MARGIN = float(os.environ.get("MISPLAT_CAP_FIRST_MARGIN", "2.0"))
+CAP_FIRST_MARGIN = 2.0
 _CAP_CHOSEN: Dict[tuple, int] = {}
 # (measurement aid: a list here collects (entry, byte image of the argument blocks) per call -- the graph cache's keys;
 # key_trace_report() names the fields that differ between a call and the one `period` calls earlier)
-KEY_TRACE: Optional[list] = [] if os.environ.get("MISPLAT_KEY_TRACE") else None
+KEY_TRACE: Optional[list] = None          # bench.py --key-trace sets it to a list
 # (the first call of a shape learns its intersection count from a counting pass and then runs in the steady form)
-PROBE_FIRST = os.environ.get("MISPLAT_PROBE_FIRST", "1") == "1"
 
 
 def key_trace_report(period: int, start: int = 0) -> list:
@@ -676,7 +378,7 @@ def _dp(t: Optional[Tensor]):
 
 # One call for BOTH phases when the capacity of the intersection buffers is known before phase A runs (a hint from the
 # previous call of this shape, or a capacity fixed by the caller): one hipGraphLaunch and no Python between the phases.
-MERGE_PHASES = os.environ.get("MISPLAT_MERGE_PHASES", "1") == "1"
+MERGE_PHASES = True
 # Fixed capacity (``static_capacity``): the intersection buffers get exactly this size and NOTHING on the host waits for
 # the count -- the call contains no host synchronisation at all, so a whole training step can be captured into one
 # hipGraph (graphs.GraphedStep).  ``meta["n_isects"]`` is then a device tensor, the lists beyond it are unspecified, and
@@ -731,21 +433,19 @@ def _cap_key(P: Params, dev: torch.device):
 # a record when it first stages it.  Pays when most visible Gaussians are never composited (dense scenes: 1 M random
 # Gaussians at 1080p stage a third of the visible ones); "auto" switches it on from the typical bucket length.
 SPARSE_BWD_MIN_ROWS = 262144        # raster.hip: background_fill_ok
-ROWS_ON_TOUCH = os.environ.get("MISPLAT_ROWS_ON_TOUCH", "1") != "0"
+ROWS_ON_TOUCH = True
 LAZY_SH = os.environ.get("MISPLAT_LAZY_SH", "auto")
-LAZY_ND = os.environ.get("MISPLAT_LAZY_ND", "1")                       # on-demand N-D records (features model) where LAZY_SH allows
-LAZY_SH_MIN_BUCKET = int(os.environ.get("MISPLAT_LAZY_SH_MIN_BUCKET", "450"))   # measured crossover at 1080p: 391 even, 549 ahead
+LAZY_ND = "1"                       # on-demand N-D records (features model) where LAZY_SH allows
+LAZY_SH_MIN_BUCKET = 450   # measured crossover at 1080p: 391 even, 549 ahead
 # Front-only ordering (csrc/binning.hip, tile_sort_front_kernel): in a dense scene the compositing stops long before the end of
 # a tile's list, so only the part of every bucket in front of the depth the view's LAST visit reached (x a margin; the
 # pivots live in the view-keyed launch-order records) is sorted; a tile whose pixels outlive its sorted part is sorted in
 # full and composited again (exact images either way), and meta["flatten_ids"] / ["isect_ids"] are completed on access.
 # "auto": from a typical bucket of FRONT_MIN_AVG entries (the hint of the previous call of the shape); "1": always; "0": off.
-INDEXED_BUCKETS = os.environ.get("MISPLAT_INDEXED_BUCKETS", "1")          # "force": also without front-only ordering (measurements)
-INDEXED_BUCKETS = INDEXED_BUCKETS if INDEXED_BUCKETS == "force" else INDEXED_BUCKETS == "1"   # (one-entry path: see misplat_raster_args.depth_sorted)
 FRONT_ONLY = os.environ.get("MISPLAT_FRONT_ONLY", "auto")
-FRONT_MIN_AVG = int(os.environ.get("MISPLAT_FRONT_MIN_AVG", "1024"))
-FRONT_MIN_BUCKET = int(os.environ.get("MISPLAT_FRONT_MIN_BUCKET", "256"))
-FRONT_MARGIN = float(os.environ.get("MISPLAT_FRONT_MARGIN", "1.05"))
+FRONT_MIN_AVG = 1024
+FRONT_MIN_BUCKET = 256
+FRONT_MARGIN = 1.05
 
 
 def _lazy_colour_ok(P: Params, dev, deg: int, kd: int, n_color: int, want_grad: bool, cd: int, nxq: int = 0,
@@ -765,8 +465,8 @@ def _lazy_colour_ok(P: Params, dev, deg: int, kd: int, n_color: int, want_grad: 
 
 def _front_only_wanted(P: Params, dev) -> bool:
     """Front-only ordering for this call?  Needs the view-keyed records (pivots), a capacity hint (the typical bucket) and
-    an eager, non-static call; decided before phase A, which then also lays the buckets out for it (INDEXED_BUCKETS)."""
-    if FRONT_ONLY == "0" or _STATIC_CAP is not None or not (SPECULATE and UNIT_ORDER and UNIT_ORDER_FWD and ORDER_BY_VIEW):
+    an eager, non-static call; decided before phase A, which then also lays the buckets out for it (entries = positions in the cell-ordered row list)."""
+    if FRONT_ONLY == "0" or _STATIC_CAP is not None or not (SPECULATE and UNIT_ORDER):
         return False
     hint = _CAP_HINT.get(_cap_key(P, dev))
     return hint is not None and (FRONT_ONLY == "1" or hint >= FRONT_MIN_AVG * P.tile_w * P.tile_h * P.n_cams)
@@ -789,7 +489,7 @@ def _raster_phase_a(P: Params, means, quats, scales, opacities, colors, colors_r
     # (records, lists) start on 2 MiB boundaries.  A slot is handed out again only when nothing refers to its storage.
     # (bucket entries as positions in the cell-ordered row list: pays where the per-tile sort's depth gather misses the L2 --
     # dense scenes, i.e. together with front-only ordering; at 1 M Gaussians it costs the sort a second gather: 55 -> 86 us)
-    indexed = INDEXED_BUCKETS and (INDEXED_BUCKETS == "force" or _front_only_wanted(P, dev)) and rows < (1 << 23)     # (23 index bits + 9 bits of depth code)
+    indexed = _front_only_wanted(P, dev) and rows < (1 << 23)          # (23 index bits + 9 bits of depth code)
     cv = arena.Carver(None if probe else ("fwd", dev.index, _stream_id(), N, Cn, P.width, P.height, kd, int(want_grad), int(want_aux),
                                           int(absgrad), int(depth_channel), int(indexed), int(nxq)), dev)
     if defer and not probe and _STATIC_CAP is None and _CAP_HINT.get(_cap_key(P, dev)) is not None:
@@ -918,7 +618,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
         a.unit_perm_in, a.unit_work, a.unit_perm_out = None, _dp(sched.work), None
     elif sched.on:
         a.order_table, a.order_sel = None, None
-        last = _LAST_ORDER.get(sched.key) if UNIT_ORDER_FWD else None
+        last = _LAST_ORDER.get(sched.key)
         if last is not None and _CAPTURE_KEEP is not None:
             _CAPTURE_KEEP.append(last)                                # a captured graph keeps reading this buffer
         if last is not None:
@@ -995,7 +695,7 @@ def _raster_phase_b(P: Params, state: dict, cd: int):
 # after ``backward()`` (rade_gs_model.py:191-198) -- is kept by assigning both from inside the backward.  The other
 # per-Gaussian intermediates in ``meta`` (conics, ray planes, ...) are not differentiable in this form; set
 # MISPLAT_FUSED_NODE=0 (the two-node form) to differentiate through them.
-FUSED_NODE = os.environ.get("MISPLAT_FUSED_NODE", "1") == "1"
+FUSED_NODE = True
 
 
 def fused_node_ok() -> bool:
@@ -1018,8 +718,8 @@ class _RasterFused(torch.autograd.Function):
         # N-D colours in one pass (a8, rade_features_model.py:427-476): cd = D' composited channels, 4 in the record + 4 nxq
         nxq = (cd - 4 + 3) // 4 if cd > 4 else 0
         lazy = _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd, nxq, features)
-        want_aux = SH_AUX and deg >= 0 and want_grad and not lazy
-        if (PROBE_FIRST and MERGE_PHASES and SPECULATE and _STATIC_CAP is None and _cap_key(P, means.device) not in _CAP_HINT
+        want_aux = deg >= 0 and want_grad and not lazy
+        if (MERGE_PHASES and SPECULATE and _STATIC_CAP is None and _cap_key(P, means.device) not in _CAP_HINT
                 and not torch.cuda.is_current_stream_capturing()):
             # First call of a shape: a counting pass (projection + bucketing, results dropped) learns the intersection count,
             # so that THIS call already runs in the steady form -- one merged entry with a speculative capacity, the argument
@@ -1031,7 +731,7 @@ class _RasterFused(torch.autograd.Function):
             del st
             PATH_STATS["forward_probe"] += 1
             lazy = _lazy_colour_ok(P, means.device, deg, kd, n_color, want_grad, cd, nxq, features)
-            want_aux = SH_AUX and deg >= 0 and want_grad and not lazy
+            want_aux = deg >= 0 and want_grad and not lazy
         defer = _STATIC_CAP is not None or (MERGE_PHASES and SPECULATE and _cap_key(P, means.device) in _CAP_HINT)
         PATH_STATS["forward"] += 1
         PATH_STATS["forward_lazy_colour"] += int(lazy)
@@ -1232,196 +932,6 @@ def raster_fused(means, quats, scales, opacities, colors, viewmats, Ks, P: Param
     return out, extra["bins"]
 
 
-# ----------------------------------------------------------------------------- fused path
-
-def _grads_of_pack(P: Params, v_means2d, v_grec):
-    """Incoming gradients of (means2d, grec).  When the mean gradient is exactly the view of columns 0:2 of
-    the packed rows that _BlendPacked returned (nothing else was accumulated into means2d), the kernel
-    reads it from the rows and the strided copy is skipped (v_means2d -> None)."""
-    rows = P.n_cams * P.n_gauss
-    if v_grec is None:
-        ref = v_means2d
-        v_grec = torch.zeros(rows, MISPLAT_REC, device=ref.device, dtype=torch.float32)
-    v_grec = _c(v_grec)
-    if v_means2d is None:
-        v_means2d = torch.zeros(rows, 2, device=v_grec.device, dtype=torch.float32)
-    elif (v_means2d.data_ptr() == v_grec.data_ptr() and v_means2d.dtype == torch.float32
-          and v_means2d.stride() == (P.n_gauss * MISPLAT_REC, MISPLAT_REC, 1)):
-        v_means2d = None
-    else:
-        v_means2d = _c(v_means2d)
-    return v_means2d, v_grec
-
-
-class _ProjectPack(torch.autograd.Function):
-    """projection + colour (SH or pass-through) -> packed blend records, one autograd node.
-
-    Outputs (radii, means2d, depths, compensations, grec).  ``means2d`` is a separate
-    differentiable output so that ``meta["means2d"].retain_grad()`` works (rade_gs_model.py:191-198);
-    every other gradient travels in the packed rows ``v_grec`` (columns 0:2 of which are ignored
-    here -- the mean2d gradient arrives through ``v_means2d``)."""
-
-    @staticmethod
-    def forward(ctx, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, P: Params, sh_degree,
-                depth_channel: bool, prebin: Optional[dict] = None):
-        lib = _lib.load()
-        require_gpu(means, quats, scales, opacities, colors, viewmats, Ks)
-        N, Cn = P.n_gauss, P.n_cams
-        dev = means.device
-        if sh_degree is not None:
-            kd = colors.shape[1] if colors_rest is None else 1 + colors_rest.shape[1]
-            deg, n_color, per_cam = int(sh_degree), 3, 0
-        else:
-            deg, kd, per_cam = -1, colors.shape[-1], int(colors.dim() == 3)
-            n_color = kd
-        if prebin is not None and fused_entry_ok() and N > 0:
-            # one host entry: projection, row bucketing, asynchronous n_isects read-back, colours
-            want_grad = any(ctx.needs_input_grad[:6])
-            want_aux = SH_AUX and deg >= 0 and want_grad
-            radii, means2d, depths, comps, grec, sh_aux, state = _raster_phase_a(
-                P, means, quats, scales, opacities, colors, colors_rest, viewmats, Ks, deg, kd, n_color, per_cam,
-                depth_channel, want_aux, want_grad)
-            prebin["fused"] = state
-            ctx.P, ctx.color_args = P, (deg, kd, n_color, per_cam)
-            ctx.depth_slot = 12 + n_color if depth_channel else -1
-            ctx.has_rest = colors_rest is not None
-            ctx.has_aux = sh_aux is not None
-            ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps,
-                                  colors_rest if colors_rest is not None else colors,
-                                  sh_aux if sh_aux is not None else comps)
-            ctx.mark_non_differentiable(radii, depths, comps)
-            ctx.set_materialize_grads(False)
-            return radii, means2d, depths, comps, grec
-        radii = torch.empty(Cn, N, 2, device=dev, dtype=torch.int32)
-        means2d = torch.empty(Cn, N, 2, device=dev, dtype=torch.float32)
-        depths = torch.empty(Cn, N, device=dev, dtype=torch.float32)
-        comps = torch.empty(Cn, N, device=dev, dtype=torch.float32)
-        grec = torch.empty(Cn * N, MISPLAT_REC, device=dev, dtype=torch.float32)
-        check(lib.misplat_project_pack_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
-                                           ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
-                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), ptr(None), ptr(None), stream_ptr()),
-              "misplat_project_pack_fwd")
-        if prebin is not None:                         # count tiles + start the n_isects read-back before the colours
-            prebin["pending"] = start_binning(P, means2d, radii)
-        # SH + a backward to come: keep d rgb / d dir (48 B per (camera, Gaussian)) so that the backward does not
-        # read the coefficients (192 B at degree 3) again
-        sh_aux = None
-        if SH_AUX and deg >= 0 and any(ctx.needs_input_grad[:6]):
-            sh_aux = torch.empty(Cn * N, 12, device=dev, dtype=torch.float32)
-        check(lib.misplat_color_fwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
-                                    C.c_int32(per_cam), C.c_int32(int(depth_channel)), ptr(means), ptr(viewmats),
-                                    ptr(colors), ptr(colors_rest), ptr(radii), ptr(depths), ptr(grec), ptr(sh_aux),
-                                    ptr(None), stream_ptr()), "misplat_color_fwd")
-        ctx.P, ctx.color_args = P, (deg, kd, n_color, per_cam)
-        ctx.depth_slot = 12 + n_color if depth_channel else -1
-        ctx.has_rest = colors_rest is not None
-        ctx.has_aux = sh_aux is not None
-        ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps,
-                              colors_rest if colors_rest is not None else colors,
-                              sh_aux if sh_aux is not None else comps)
-        ctx.mark_non_differentiable(radii, depths, comps)
-        ctx.set_materialize_grads(False)               # no zero tensors for the non-differentiable outputs
-        return radii, means2d, depths, comps, grec
-
-    @staticmethod
-    def backward(ctx, _v_radii, v_means2d, _v_depths, _v_comps, v_grec):
-        lib = _lib.load()
-        means, quats, scales, opacities, colors, viewmats, Ks, radii, comps, colors_rest, sh_aux = ctx.saved_tensors
-        if not ctx.has_rest:
-            colors_rest = None
-        if not ctx.has_aux:
-            sh_aux = None
-        P = ctx.P
-        deg, kd, n_color, per_cam = ctx.color_args
-        v_means2d, v_grec = _grads_of_pack(P, v_means2d, v_grec)
-        v_colors = _grad_out(colors)
-        v_colors_rest = _grad_out(colors_rest) if colors_rest is not None else None
-        v_means_dir = torch.empty_like(means) if deg >= 0 else None
-        check(lib.misplat_color_bwd(C.byref(P), C.c_int32(deg), C.c_int32(kd), C.c_int32(n_color),
-                                    C.c_int32(per_cam), ptr(means), ptr(viewmats), ptr(colors), ptr(colors_rest),
-                                    ptr(radii), ptr(v_grec), ptr(v_colors), ptr(v_colors_rest), ptr(v_means_dir),
-                                    ptr(sh_aux), stream_ptr()), "misplat_color_bwd")
-        if GRAD_SINK is not None:
-            GRAD_SINK.colour_ready()                   # the colour bucket's all-reduce starts now, overlapped with the rest
-        v_means, v_quats = _grad_out(means), _grad_out(quats)
-        v_scales, v_opac = _grad_out(scales), _grad_out(opacities)
-        check(lib.misplat_project_pack_bwd(C.byref(P), C.c_int32(ctx.depth_slot), ptr(means), ptr(quats),
-                                           ptr(scales), ptr(opacities), ptr(viewmats), ptr(Ks), ptr(radii),
-                                           ptr(comps), ptr(v_means2d), ptr(v_grec), ptr(v_means_dir), ptr(v_means),
-                                           ptr(v_quats), ptr(v_scales), ptr(v_opac), None, C.c_int32(0), stream_ptr()),
-              "misplat_project_pack_bwd")
-        return v_means, v_quats, v_scales, v_opac, v_colors, v_colors_rest, None, None, None, None, None, None
-
-
-def project_pack(means, quats, scales, opacities, colors, viewmats, Ks, P: Params, sh_degree, depth_channel,
-                 prebin: Optional[dict] = None):
-    """``colors`` may be a pair (features_dc [N,3], features_rest [N,K-1,3]) when ``sh_degree`` is given.
-    ``prebin``: a dict that receives ``["pending"]`` = ``start_binning(...)`` for ``bin_tiles(pending=...)``."""
-    rest = None
-    if isinstance(colors, (tuple, list)):
-        colors, rest = colors
-        rest = _f32(rest, "features_rest")
-    args = [_f32(t, n) for t, n in ((means, "means"), (quats, "quats"), (scales, "scales"),
-                                    (opacities, "opacities"), (colors, "colors"))]
-    return _ProjectPack.apply(*args, rest, _f32(viewmats, "viewmats"), _f32(Ks, "Ks"), P, sh_degree,
-                              bool(depth_channel), prebin)
-
-
-class _BlendPacked(torch.autograd.Function):
-    """Compositing straight from the packed records (<= 4 colour slots)."""
-
-    @staticmethod
-    def forward(ctx, means2d, grec, Ks, P: Params, bins: Dict[str, Tensor], absgrad: bool, cd: int):
-        lib = _lib.load()
-        Cn, H, W = P.n_cams, P.height, P.width
-        dev = grec.device
-        if "args" in bins:                             # phase-A state of the one-entry path: buckets, sort, compositing
-            imgs, done, sched = _raster_phase_b(P, bins, cd)
-            bins.clear()
-            bins.update(done)                          # the caller's dict becomes the finished bins (meta reads it)
-            render, alpha, exp_depth, med_depth, normal, last_ids, median_ids = imgs
-            ctx.sched = sched
-            ctx.P, ctx.bins, ctx.absgrad, ctx.cd = P, bins, absgrad, cd
-            ctx.means2d_ref = means2d if absgrad else None
-            ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids, render)
-            ctx.mark_non_differentiable(last_ids, median_ids)
-            ctx.set_materialize_grads(False)
-            return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
-        f = dict(device=dev, dtype=torch.float32)
-        render = torch.empty(Cn, H, W, cd, **f)
-        alpha = torch.empty(Cn, H, W, 1, **f)
-        exp_depth = torch.empty(Cn, H, W, 1, **f)
-        med_depth = torch.empty(Cn, H, W, 1, **f)
-        normal = torch.empty(Cn, H, W, 3, **f)
-        last_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
-        median_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
-        sched = _UnitSchedule(P, dev)
-        with _timed("blend_fwd"):
-            sched.before_forward(P)
-            check(lib.misplat_blend_fwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
-                                        ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(render),
-                                        ptr(alpha), ptr(exp_depth), ptr(med_depth), ptr(normal), ptr(last_ids),
-                                        ptr(median_ids), stream_ptr()), "misplat_blend_fwd")
-        sched.after_forward(P)
-        ctx.sched = sched
-        ctx.P, ctx.bins, ctx.absgrad, ctx.cd = P, bins, absgrad, cd
-        ctx.means2d_ref = means2d if absgrad else None
-        ctx.save_for_backward(grec, Ks, alpha, last_ids, median_ids, render)
-        ctx.mark_non_differentiable(last_ids, median_ids)
-        ctx.set_materialize_grads(False)               # absent upstream gradients arrive as None
-        return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
-
-    @staticmethod
-    def backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, _l, _m):
-        ctx.sched.before_backward(ctx.P)
-        v_grec, v_abs = _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
-        _UnitSchedule.done(ctx.P)
-        P = ctx.P
-        if ctx.absgrad:
-            ctx.means2d_ref.absgrad = v_abs.view(P.n_cams, P.n_gauss, 2)
-        return v_grec.view(P.n_cams, P.n_gauss, MISPLAT_REC)[..., 0:2], v_grec, None, None, None, None, None
-
-
 def _upstream(P: Params, cd: int, dev, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
     """Contiguous upstream gradients of the five images; an output that took no part in the loss (None: the
     nodes do not materialise gradients) contributes zeros."""
@@ -1429,436 +939,14 @@ def _upstream(P: Params, cd: int, dev, v_render, v_alpha, v_exp_depth, v_med_dep
     return [_c(t) if t is not None else torch.zeros(P.n_cams, P.height, P.width, w, device=dev, dtype=torch.float32)
             for t, w in zip((v_render, v_alpha, v_exp_depth, v_med_depth, v_normal), widths)]
 
-
-def _blend_backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal):
-    """blend_bwd -> per-intersection rows -> fixed-order per-Gaussian sum.  Returns (v_grec, v_abs)."""
-    lib = _lib.load()
-    grec, Ks, alpha, last_ids, median_ids, render = ctx.saved_tensors
-    P, bins, cd = ctx.P, ctx.bins, ctx.cd
-    n_isects = bins["n_isects"]
-    rows = P.n_cams * P.n_gauss
-    dev = grec.device
-    ups = _upstream(P, cd, dev, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
-    if bins["slots"] is None:                      # binned in atomic mode (ops.DETERMINISTIC_BACKWARD was False)
-        # the one-entry forward left a cleared gradient buffer behind (written by the colour kernel): first backward only
-        v_grec = bins.pop("v_grec_zero", None)
-        prezeroed = v_grec is not None and not bins.get("rows_on_touch")
-        if v_grec is None:
-            v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
-        v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
-        with _timed("blend_bwd"):
-            check(lib.misplat_blend_bwd_atomic(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
-                                               ptr(bins["isect_offsets"]), C.c_int64(n_isects), ptr(alpha),
-                                               ptr(last_ids), ptr(median_ids), ptr(render), *[ptr(t) for t in ups],
-                                               ptr(v_grec), ptr(v_abs), C.c_int32(int(prezeroed)), stream_ptr()),
-                  "misplat_blend_bwd_atomic")
-        return v_grec, v_abs
-    planes = int(lib.misplat_blend_planes(C.byref(P)))
-    rows_s = max(n_isects, 1) * planes
-    slab = torch.empty(rows_s, MISPLAT_REC, device=dev, dtype=torch.float32)
-    slab_abs = torch.empty(rows_s, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
-    slab_valid = torch.empty(rows_s, device=dev, dtype=torch.uint8)
-    with _timed("blend_bwd"):
-        check(lib.misplat_blend_bwd(C.byref(P), C.c_int32(cd), ptr(Ks), ptr(grec), ptr(bins["flatten_ids"]),
-                                    ptr(bins["slots"]), ptr(bins["isect_offsets"]), C.c_int64(n_isects),
-                                    ptr(alpha), ptr(last_ids), ptr(median_ids), ptr(render), *[ptr(t) for t in ups],
-                                    ptr(slab), ptr(slab_abs), ptr(slab_valid), stream_ptr()), "misplat_blend_bwd")
-    v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
-    v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
-    with _timed("slab_reduce"):
-        check(lib.misplat_slab_reduce(C.byref(P), C.c_int64(rows), C.c_int64(n_isects), ptr(_cum_by_row(bins)),
-                                      ptr(bins["tiles_per_gauss"]), ptr(slab), ptr(slab_abs), ptr(slab_valid),
-                                      ptr(v_grec), ptr(v_abs), stream_ptr()), "misplat_slab_reduce")
-    return v_grec, v_abs
-
-
-def blend_packed(means2d, grec, Ks, P: Params, bins, absgrad: bool, cd: int):
-    if not 1 <= cd <= 4:
-        raise ValueError("blend_packed() takes 1..4 colour channels")
-    return _BlendPacked.apply(means2d, grec, _f32(Ks, "Ks"), P, bins, bool(absgrad), int(cd))
-
-
-# ----------------------------------------------------------------------------- N-D colours (a8)
-
-class _ProjectPackX(torch.autograd.Function):
-    """projection + pass-through colours with D' = D (+ depth) in 5..20 channels: channels 0..3 go to the record,
-    the rest to ``featx[C*N, 4*nxq]`` (rade_features_model.py:441-476 renders 16 fused channels, 17 with ED)."""
-
-    @staticmethod
-    def forward(ctx, means, quats, scales, opacities, colors, viewmats, Ks, P: Params, depth_channel: bool, nxq: int):
-        lib = _lib.load()
-        require_gpu(means, quats, scales, opacities, colors, viewmats, Ks)
-        N, Cn = P.n_gauss, P.n_cams
-        dev = means.device
-        radii = torch.empty(Cn, N, 2, device=dev, dtype=torch.int32)
-        means2d = torch.empty(Cn, N, 2, device=dev, dtype=torch.float32)
-        depths = torch.empty(Cn, N, device=dev, dtype=torch.float32)
-        comps = torch.empty(Cn, N, device=dev, dtype=torch.float32)
-        grec = torch.empty(Cn * N, MISPLAT_REC, device=dev, dtype=torch.float32)
-        featx = torch.empty(Cn * N, 4 * nxq, device=dev, dtype=torch.float32)
-        check(lib.misplat_project_pack_fwd(C.byref(P), ptr(means), ptr(quats), ptr(scales), ptr(opacities),
-                                           ptr(viewmats), ptr(Ks), ptr(radii), ptr(means2d), ptr(depths),
-                                           ptr(comps), ptr(grec), ptr(None), C.c_int32(0), ptr(None), ptr(None), stream_ptr()),
-              "misplat_project_pack_fwd")
-        D, per_cam = colors.shape[-1], int(colors.dim() == 3)
-        check(lib.misplat_color_fwd_x(C.byref(P), C.c_int32(D), C.c_int32(per_cam), C.c_int32(int(depth_channel)),
-                                      C.c_int32(nxq), ptr(colors), ptr(radii), ptr(depths), ptr(grec), ptr(featx),
-                                      stream_ptr()), "misplat_color_fwd_x")
-        ctx.P, ctx.D, ctx.per_cam, ctx.nxq, ctx.depth_channel = P, D, per_cam, nxq, depth_channel
-        ctx.save_for_backward(means, quats, scales, opacities, colors, viewmats, Ks, radii, comps)
-        ctx.mark_non_differentiable(radii, depths, comps)
-        ctx.set_materialize_grads(False)
-        return radii, means2d, depths, comps, grec, featx
-
-    @staticmethod
-    def backward(ctx, _v_radii, v_means2d, _v_depths, _v_comps, v_grec, v_featx):
-        lib = _lib.load()
-        means, quats, scales, opacities, colors, viewmats, Ks, radii, comps = ctx.saved_tensors
-        P, D, nxq = ctx.P, ctx.D, ctx.nxq
-        v_means2d, v_grec = _grads_of_pack(P, v_means2d, v_grec)
-        v_featx = _c(v_featx) if v_featx is not None else torch.zeros(v_grec.shape[0], 4 * nxq, device=v_grec.device)
-        v_colors = torch.empty_like(colors)
-        check(lib.misplat_color_bwd_x(C.byref(P), C.c_int32(D), C.c_int32(ctx.per_cam), C.c_int32(nxq), ptr(radii),
-                                      ptr(v_grec), ptr(v_featx), ptr(v_colors), stream_ptr()), "misplat_color_bwd_x")
-        depth_slot, v_depth_rows, v_depth_stride = -1, None, 0
-        if ctx.depth_channel:                       # channel D carries the depth
-            if D < 4:
-                depth_slot = 12 + D
-            else:                                   # it lives in featx: the projection backward reads it from there (float D - 4
-                #                                     of every v_featx row) -- no copy of the 64-byte gradient rows to park it in
-                v_depth_rows = C.c_void_p(v_featx.data_ptr() + 4 * (D - 4))
-                v_depth_stride = 4 * nxq
-        v_means, v_quats = torch.empty_like(means), torch.empty_like(quats)
-        v_scales, v_opac = torch.empty_like(scales), torch.empty_like(opacities)
-        check(lib.misplat_project_pack_bwd(C.byref(P), C.c_int32(depth_slot), ptr(means), ptr(quats), ptr(scales),
-                                           ptr(opacities), ptr(viewmats), ptr(Ks), ptr(radii), ptr(comps),
-                                           ptr(v_means2d), ptr(v_grec), ptr(None), ptr(v_means), ptr(v_quats),
-                                           ptr(v_scales), ptr(v_opac), v_depth_rows, C.c_int32(v_depth_stride), stream_ptr()),
-              "misplat_project_pack_bwd")
-        return v_means, v_quats, v_scales, v_opac, v_colors, None, None, None, None, None
-
-
-def project_pack_x(means, quats, scales, opacities, colors, viewmats, Ks, P: Params, depth_channel: bool, nxq: int):
-    args = [_f32(t, n) for t, n in ((means, "means"), (quats, "quats"), (scales, "scales"),
-                                    (opacities, "opacities"), (colors, "colors"), (viewmats, "viewmats"), (Ks, "Ks"))]
-    return _ProjectPackX.apply(*args, P, bool(depth_channel), int(nxq))
-
-
-class _BlendPackedX(torch.autograd.Function):
-    """One-pass compositing of 5..20 colour channels (atomic gradient mode)."""
-
-    @staticmethod
-    def forward(ctx, means2d, grec, featx, Ks, P: Params, bins: Dict[str, Tensor], absgrad: bool, n_channels: int,
-                nxq: int):
-        lib = _lib.load()
-        Cn, H, W = P.n_cams, P.height, P.width
-        dev = grec.device
-        f = dict(device=dev, dtype=torch.float32)
-        render = torch.empty(Cn, H, W, n_channels, **f)
-        alpha = torch.empty(Cn, H, W, 1, **f)
-        exp_depth = torch.empty(Cn, H, W, 1, **f)
-        med_depth = torch.empty(Cn, H, W, 1, **f)
-        normal = torch.empty(Cn, H, W, 3, **f)
-        last_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
-        median_ids = torch.empty(Cn, H, W, device=dev, dtype=torch.int32)
-        sched = _UnitSchedule(P, dev)
-        ctx.sched = sched
-        with _timed("blend_fwd"):
-            sched.before_forward(P)
-            check(lib.misplat_blend_fwd_x(C.byref(P), C.c_int32(n_channels), C.c_int32(nxq), ptr(Ks), ptr(grec),
-                                          ptr(featx), ptr(bins["flatten_ids"]), ptr(bins["isect_offsets"]),
-                                          C.c_int64(bins["n_isects"]), ptr(render), ptr(alpha), ptr(exp_depth),
-                                          ptr(med_depth), ptr(normal), ptr(last_ids), ptr(median_ids), stream_ptr()),
-                  "misplat_blend_fwd_x")
-        sched.after_forward(P)
-        ctx.P, ctx.bins, ctx.absgrad, ctx.n_channels, ctx.nxq = P, bins, absgrad, n_channels, nxq
-        ctx.means2d_ref = means2d if absgrad else None
-        ctx.save_for_backward(grec, featx, Ks, alpha, last_ids, median_ids, render)
-        ctx.mark_non_differentiable(last_ids, median_ids)
-        ctx.set_materialize_grads(False)               # absent upstream gradients arrive as None
-        return render, alpha, exp_depth, med_depth, normal, last_ids, median_ids
-
-    @staticmethod
-    def backward(ctx, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, _l, _m):
-        lib = _lib.load()
-        grec, featx, Ks, alpha, last_ids, median_ids, render = ctx.saved_tensors
-        P, bins = ctx.P, ctx.bins
-        rows = P.n_cams * P.n_gauss
-        dev = grec.device
-        v_grec = torch.empty(rows, MISPLAT_REC, device=dev, dtype=torch.float32)
-        v_featx = torch.empty(rows, 4 * ctx.nxq, device=dev, dtype=torch.float32)
-        v_abs = torch.empty(rows, 2, device=dev, dtype=torch.float32) if ctx.absgrad else None
-        ups = _upstream(P, ctx.n_channels, dev, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal)
-        ctx.sched.before_backward(P)
-        with _timed("blend_bwd"):
-            check(lib.misplat_blend_bwd_x_atomic(C.byref(P), C.c_int32(ctx.n_channels), C.c_int32(ctx.nxq), ptr(Ks),
-                                                 ptr(grec), ptr(featx), ptr(bins["flatten_ids"]),
-                                                 ptr(bins["isect_offsets"]), C.c_int64(bins["n_isects"]), ptr(alpha),
-                                                 ptr(last_ids), ptr(median_ids), ptr(render), *[ptr(t) for t in ups],
-                                                 ptr(v_grec), ptr(v_featx), ptr(v_abs), stream_ptr()),
-                  "misplat_blend_bwd_x_atomic")
-        _UnitSchedule.done(P)
-        if ctx.absgrad:
-            ctx.means2d_ref.absgrad = v_abs.view(P.n_cams, P.n_gauss, 2)
-        return (v_grec.view(P.n_cams, P.n_gauss, MISPLAT_REC)[..., 0:2], v_grec, v_featx, None, None, None, None, None,
-                None)
-
-
-def blend_packed_x(means2d, grec, featx, Ks, P: Params, bins, absgrad: bool, n_channels: int, nxq: int):
-    return _BlendPackedX.apply(means2d, grec, featx, _f32(Ks, "Ks"), P, bins, bool(absgrad), int(n_channels), int(nxq))
-
-
-# ----------------------------------------------------------------------------- depth -> normal
-
-class _DepthNormal(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, exp_depth, med_depth, n_render, fx: float, fy: float):
-        lib = _lib.load()
-        require_gpu(exp_depth, med_depth, n_render)
-        H, W = exp_depth.shape[-2], exp_depth.shape[-1]
-        dev = exp_depth.device
-        normals2 = torch.empty(2, H, W, 3, device=dev, dtype=torch.float32)
-        err = torch.empty(2, H, W, device=dev, dtype=torch.float32)
-        check(lib.misplat_depth_normal_fwd(C.c_int32(W), C.c_int32(H), C.c_float(fx), C.c_float(fy),
-                                           ptr(exp_depth), ptr(med_depth), ptr(n_render), ptr(normals2),
-                                           ptr(err), stream_ptr()), "misplat_depth_normal_fwd")
-        ctx.save_for_backward(exp_depth, med_depth, n_render)
-        ctx.fx, ctx.fy = fx, fy
-        return normals2, err
-
-    @staticmethod
-    def backward(ctx, v_normals2, v_err):
-        lib = _lib.load()
-        ed, md, nr = ctx.saved_tensors
-        H, W = ed.shape[-2], ed.shape[-1]
-        v_ed, v_md, v_nr = torch.empty_like(ed), torch.empty_like(md), torch.empty_like(nr)
-        check(lib.misplat_depth_normal_bwd(C.c_int32(W), C.c_int32(H), C.c_float(ctx.fx), C.c_float(ctx.fy),
-                                           ptr(ed), ptr(md), ptr(nr), ptr(_c(v_normals2)), ptr(_c(v_err)),
-                                           ptr(v_ed), ptr(v_md), ptr(v_nr), C.c_int32(0), stream_ptr()),
-              "misplat_depth_normal_bwd")
-        return v_ed, v_md, v_nr, None, None
-
-
-def depth_normal(exp_depth: Tensor, med_depth: Tensor, n_render: Tensor, fx: float, fy: float):
-    """Fused camera_utils.depth_double_to_normal + error map.  exp/med_depth [H,W], n_render [H,W,3]
-    -> (normals2 [2,H,W,3], err [2,H,W])."""
-    return _DepthNormal.apply(_f32(exp_depth, "exp_depth"), _f32(med_depth, "med_depth"),
-                              _f32(n_render, "n_render"), float(fx), float(fy))
-
-
-# ----------------------------------------------------------------------------- get_outputs epilogue (a3)
-
-class _Outputs(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, render, alpha, exp_depth, med_depth, exp_normal, bg, want_depth_im: bool):
-        lib = _lib.load()
-        require_gpu(render, alpha, exp_depth, med_depth, exp_normal)
-        cd = render.shape[-1]
-        n_pix = alpha.numel()
-        dev = render.device
-        f = dict(device=dev, dtype=torch.float32)
-        rgb = torch.empty(alpha.shape[:-1] + (3,), **f)
-        depth, median = torch.empty_like(alpha), torch.empty_like(alpha)
-        normals = torch.empty_like(exp_normal)
-        depth_im = torch.empty_like(alpha) if want_depth_im else None
-        maxes = torch.empty(4, **f)
-        bg_c = (C.c_float * 3)(*[float(b) for b in bg])
-        check(lib.misplat_outputs_fwd(C.c_int64(n_pix), C.c_int32(cd), bg_c, ptr(render), ptr(alpha), ptr(exp_depth),
-                                      ptr(med_depth), ptr(exp_normal), ptr(maxes), ptr(rgb), ptr(depth), ptr(median),
-                                      ptr(normals), ptr(depth_im), stream_ptr()), "misplat_outputs_fwd")
-        ctx.save_for_backward(render, alpha)
-        ctx.bg, ctx.cd, ctx.want_depth_im = bg_c, cd, want_depth_im
-        if want_depth_im:
-            return rgb, depth, median, normals, depth_im
-        return rgb, depth, median, normals
-
-    @staticmethod
-    def backward(ctx, v_rgb, v_depth, v_median, v_normals, v_depth_im=None):
-        lib = _lib.load()
-        render, alpha = ctx.saved_tensors
-        v_render = torch.empty_like(render)
-        v_alpha, v_ed, v_md = torch.empty_like(alpha), torch.empty_like(alpha), torch.empty_like(alpha)
-        v_nr = torch.empty_like(v_normals)
-        ups = [_c(t) for t in (v_rgb, v_depth, v_median, v_normals)]
-        vdi = _c(v_depth_im) if ctx.want_depth_im else None
-        check(lib.misplat_outputs_bwd(C.c_int64(alpha.numel()), C.c_int32(ctx.cd), ctx.bg, ptr(render), ptr(alpha),
-                                      *[ptr(t) for t in ups], ptr(vdi), ptr(v_render), ptr(v_alpha), ptr(v_ed),
-                                      ptr(v_md), ptr(v_nr), stream_ptr()), "misplat_outputs_bwd")
-        return v_render, v_alpha, v_ed, v_md, v_nr, None, None
-
-
-def outputs_epilogue(render, alpha, exp_depth, med_depth, exp_normal, background, want_depth_im: bool):
-    """rade_gs_model.py:221-254 in three kernels.  ``background``: 3 Python floats."""
-    if render.shape[-1] not in (3, 4) or (want_depth_im and render.shape[-1] != 4):
-        raise ValueError("outputs_epilogue needs render[..., 3] (RGB) or [..., 4] (RGB+ED)")
-    args = [_f32(t, n) for t, n in ((render, "render"), (alpha, "alpha"), (exp_depth, "expected_depths"),
-                                    (med_depth, "median_depths"), (exp_normal, "expected_normals"))]
-    return _Outputs.apply(*args, tuple(float(b) for b in background), bool(want_depth_im))
-
-
-class _GetOutputs(torch.autograd.Function):
-    """a3 + a4 in ONE autograd node: the depth->normal error maps
-    (rade_gs_model.py:206-214) and the output post-processing (:221-254) share their inputs, so the backward is
-    outputs_bwd followed by depth_normal_bwd ACCUMULATING into the same five gradient buffers -- no autograd
-    add kernels, and upstream gradients of outputs that took no part in the loss stay NULL instead of being
-    materialised as zero tensors."""
-
-    @staticmethod
-    def forward(ctx, render, alpha, exp_depth, med_depth, exp_normal, bg, want_depth_im: bool, fx: float, fy: float):
-        lib = _lib.load()
-        require_gpu(render, alpha, exp_depth, med_depth, exp_normal)
-        if alpha.shape[0] != 1:
-            raise ValueError("get_outputs epilogue: one camera per call (rade_gs_model.py:94-95)")
-        cd = render.shape[-1]
-        H, W = alpha.shape[1], alpha.shape[2]
-        f = dict(device=render.device, dtype=torch.float32)
-        rgb = torch.empty(1, H, W, 3, **f)
-        depth, median = torch.empty_like(alpha), torch.empty_like(alpha)
-        normals = torch.empty_like(exp_normal)
-        depth_im = torch.empty_like(alpha) if want_depth_im else None
-        maxes = torch.empty(4, **f)
-        err = torch.empty(2, H, W, **f)
-        normals2 = torch.empty(2, H, W, 3, **f)
-        bg_c = (C.c_float * 3)(*[float(b) for b in bg])
-        check(lib.misplat_depth_normal_fwd(C.c_int32(W), C.c_int32(H), C.c_float(fx), C.c_float(fy), ptr(exp_depth),
-                                           ptr(med_depth), ptr(exp_normal), ptr(normals2), ptr(err), stream_ptr()),
-              "misplat_depth_normal_fwd")
-        check(lib.misplat_outputs_fwd(C.c_int64(H * W), C.c_int32(cd), bg_c, ptr(render), ptr(alpha), ptr(exp_depth),
-                                      ptr(med_depth), ptr(exp_normal), ptr(maxes), ptr(rgb), ptr(depth), ptr(median),
-                                      ptr(normals), ptr(depth_im), stream_ptr()), "misplat_outputs_fwd")
-        ctx.save_for_backward(render, alpha, exp_depth, med_depth, exp_normal)
-        ctx.bg, ctx.cd, ctx.want_depth_im, ctx.fx, ctx.fy = bg_c, cd, want_depth_im, fx, fy
-        ctx.set_materialize_grads(False)
-        if want_depth_im:
-            return rgb, depth, median, normals, err, depth_im
-        return rgb, depth, median, normals, err
-
-    @staticmethod
-    def backward(ctx, v_rgb, v_depth, v_median, v_normals, v_err, v_depth_im=None):
-        lib = _lib.load()
-        render, alpha, ed, md, nr = ctx.saved_tensors
-        H, W = alpha.shape[1], alpha.shape[2]
-        v_render = torch.empty_like(render)
-        v_alpha, v_ed, v_md = torch.empty_like(alpha), torch.empty_like(alpha), torch.empty_like(alpha)
-        v_nr = torch.empty_like(nr)
-        check(lib.misplat_outputs_bwd(C.c_int64(H * W), C.c_int32(ctx.cd), ctx.bg, ptr(render), ptr(alpha),
-                                      ptr(_c(v_rgb)), ptr(_c(v_depth)), ptr(_c(v_median)), ptr(_c(v_normals)),
-                                      ptr(_c(v_depth_im) if ctx.want_depth_im else None), ptr(v_render), ptr(v_alpha),
-                                      ptr(v_ed), ptr(v_md), ptr(v_nr), stream_ptr()), "misplat_outputs_bwd")
-        if v_err is not None:
-            check(lib.misplat_depth_normal_bwd(C.c_int32(W), C.c_int32(H), C.c_float(ctx.fx), C.c_float(ctx.fy),
-                                               ptr(ed), ptr(md), ptr(nr), ptr(None), ptr(_c(v_err)), ptr(v_ed),
-                                               ptr(v_md), ptr(v_nr), C.c_int32(1), stream_ptr()),
-                  "misplat_depth_normal_bwd")
-        return v_render, v_alpha, v_ed, v_md, v_nr, None, None, None, None
-
-
-def get_outputs_epilogue(render, alpha, exp_depth, med_depth, exp_normal, background, want_depth_im: bool, fx: float,
-                         fy: float):
-    """(rgb, depth, median_depth, normals, err[2,H,W] (, depth_im)) -- rade_gs_model.py:206-254 as one node."""
-    if render.shape[-1] not in (3, 4) or (want_depth_im and render.shape[-1] != 4):
-        raise ValueError("get_outputs_epilogue needs render[..., 3] (RGB) or [..., 4] (RGB+ED)")
-    args = [_f32(t, n) for t, n in ((render, "render"), (alpha, "alpha"), (exp_depth, "expected_depths"),
-                                    (med_depth, "median_depths"), (exp_normal, "expected_normals"))]
-    return _GetOutputs.apply(*args, tuple(float(b) for b in background), bool(want_depth_im), float(fx), float(fy))
-
-
-LOSS_PARTIALS = 3 * 512      # MISPLAT_LOSS_PARTIALS
-
-
-class _MeanLosses(torch.autograd.Function):
-    """a5 (rade_gs_model.py:289-307 + the base model's L1 term) as ONE autograd node: forward = two launches
-    (misplat_loss_fwd), backward = one (misplat_loss_bwd) that writes the gradient images the a3 + a4 node consumes --
-    instead of ~30 elementwise / reduction launches of a few microseconds each.  ``err``: the [2,H,W] tensor whose halves
-    are the two error maps (then e1 / e2 are ignored), or None with e1 / e2 given separately."""
-
-    @staticmethod
-    def forward(ctx, rgb, gt, err, e1, e2, depth_ratio: float, lam: float, ssim_lambda: float = 0.0):
-        lib = _lib.load()
-        with_rgb = rgb is not None and gt is not None
-        if err is not None:
-            e1, e2 = err[0], err[1]
-        with_dn = e1 is not None and e2 is not None
-        require_gpu(*[t for t in (rgb, gt, e1, e2) if t is not None])
-        n_pix = rgb.numel() // 3 if with_rgb else e1.numel()
-        if with_rgb and with_dn and e1.numel() != n_pix:
-            raise ValueError("get_loss_dict: the error maps and the image differ in size")
-        dev = rgb.device if with_rgb else e1.device
-        with_ssim = with_rgb and ssim_lambda > 0.0               # (the SSIM forward then sums the L1 term too: its tiles hold both images)
-        l1_here = with_rgb and not with_ssim
-        rgb_loss = torch.empty((), device=dev, dtype=torch.float32) if l1_here else None
-        dn_loss = torch.empty((), device=dev, dtype=torch.float32) if with_dn else None
-        if l1_here or with_dn:
-            partials = torch.empty(LOSS_PARTIALS, device=dev, dtype=torch.float32)
-            check(lib.misplat_loss_fwd(C.c_int64(n_pix), ptr(rgb if l1_here else None), ptr(gt if l1_here else None),
-                                       ptr(e1 if with_dn else None), ptr(e2 if with_dn else None), C.c_float(depth_ratio),
-                                       C.c_float(lam), ptr(partials), ptr(rgb_loss), ptr(dn_loss), stream_ptr()), "misplat_loss_fwd")
-        # the base model's image loss (Splatfacto: (1 - l) L1 + l (1 - SSIM)): two launches that sum both terms tile by tile
-        # and leave the derivative maps of the SSIM for the backward
-        ctx.ssim = None
-        if with_ssim:
-            H, W = int(rgb.shape[-3]), int(rgb.shape[-2])
-            if rgb.shape[-1] != 3 or rgb.numel() != 3 * H * W:
-                raise ValueError("mean_losses: the SSIM term takes one [H,W,3] image")
-            n_scratch = int(lib.misplat_ssim_scratch_floats(C.c_int32(H), C.c_int32(W)))
-            if n_scratch < 0:
-                raise ValueError(f"mean_losses: the SSIM window needs an image of at least 11 x 11 pixels (got {H} x {W})")
-            scratch = torch.empty(n_scratch, device=dev, dtype=torch.float32)
-            main = torch.empty((), device=dev, dtype=torch.float32)
-            check(lib.misplat_ssim_fwd(C.c_int32(H), C.c_int32(W), ptr(rgb), ptr(gt), ptr(scratch), None,
-                                       C.c_float(ssim_lambda), None, ptr(main), stream_ptr()), "misplat_ssim_fwd")
-            ctx.ssim = (H, W, scratch, float(ssim_lambda))
-            rgb_loss = main
-        ctx.save_for_backward(*(t for t in (rgb, gt) if with_rgb))
-        ctx.with_rgb, ctx.with_dn, ctx.packed, ctx.n_pix = with_rgb, with_dn, err is not None, n_pix
-        ctx.err_shape = tuple(err.shape) if err is not None else (tuple(e1.shape) if with_dn else None)
-        ctx.k = (float(depth_ratio), float(lam))
-        ctx.dev = dev
-        ctx.set_materialize_grads(False)
-        return rgb_loss, dn_loss
-
-    @staticmethod
-    def backward(ctx, g_rgb, g_dn):
-        lib = _lib.load()
-        rgb, gt = ctx.saved_tensors if ctx.with_rgb else (None, None)
-        want_rgb = ctx.with_rgb and ctx.needs_input_grad[0] and g_rgb is not None
-        want_dn = ctx.with_dn and g_dn is not None and (ctx.needs_input_grad[2] if ctx.packed
-                                                       else (ctx.needs_input_grad[3] or ctx.needs_input_grad[4]))
-        v_rgb = torch.empty_like(rgb) if want_rgb else None
-        v_err = v_e1 = v_e2 = None
-        if want_dn:
-            if ctx.packed:
-                v_err = torch.empty(ctx.err_shape, device=ctx.dev, dtype=torch.float32)
-                v_e1, v_e2 = v_err[0], v_err[1]
-            else:
-                v_e1 = torch.empty(ctx.err_shape, device=ctx.dev, dtype=torch.float32)
-                v_e2 = torch.empty(ctx.err_shape, device=ctx.dev, dtype=torch.float32)
-        g1 = g_rgb.to(torch.float32).contiguous() if want_rgb else None
-        g2 = g_dn.to(torch.float32).contiguous() if want_dn else None
-        l1_here = want_rgb and ctx.ssim is None
-        if want_rgb and ctx.ssim is not None:                         # both halves of the image term in one launch
-            H, W, scratch, ssim_lambda = ctx.ssim
-            check(lib.misplat_ssim_bwd(C.c_int32(H), C.c_int32(W), ptr(rgb), ptr(gt), ptr(scratch), ptr(g1),
-                                       C.c_float(ssim_lambda), ptr(v_rgb), stream_ptr()), "misplat_ssim_bwd")
-        if l1_here or want_dn:
-            check(lib.misplat_loss_bwd(C.c_int64(ctx.n_pix), ptr(rgb if l1_here else None), ptr(gt if l1_here else None),
-                                       ptr(g1 if l1_here else None), ptr(g2), C.c_float(ctx.k[0]), C.c_float(ctx.k[1]),
-                                       ptr(v_rgb if l1_here else None), ptr(v_e1), ptr(v_e2), stream_ptr()), "misplat_loss_bwd")
-        if ctx.packed:
-            return v_rgb, None, v_err, None, None, None, None, None
-        return v_rgb, None, None, v_e1, v_e2, None, None, None
-
-
-def mean_losses(rgb, gt, err=None, e1=None, e2=None, depth_ratio: float = 0.0, depth_normal_lambda: float = 0.0,
-                ssim_lambda: float = 0.0):
-    """(rgb_loss or None, depth_normal_loss or None): mean |gt - rgb| and lambda * ((1 - r) * mean(e1) + r * mean(e2)).
-    Contiguous float32 GPU tensors; ``err`` [2,...] packs e1 / e2 (its gradient then arrives as one tensor).
-    ``ssim_lambda`` > 0: the first value is the base model's ``main_loss`` = (1 - l) mean |gt - rgb| + l (1 - SSIM(gt, rgb))
-    of one [H,W,3] image (misplat_ssim_fwd / misplat_ssim_bwd)."""
-    def ok(t):
-        return t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous())
-    if not all(ok(t) for t in (rgb, gt, err, e1, e2)):
-        raise ValueError("mean_losses: contiguous float32 GPU tensors only")
-    if rgb is not None and gt is not None and rgb.shape != gt.shape:
-        raise ValueError("mean_losses: image and ground truth differ in shape")
-    return _MeanLosses.apply(rgb, gt, err, e1, e2, float(depth_ratio), float(depth_normal_lambda), float(ssim_lambda))
+# ----------------------------------------------------------------------------- the other nodes
+# The stage-by-stage nodes live in ops_stages.py, the model-level ones in ops_epilogue.py; ``ops.X`` resolves there on first use
+# (lazily: ops_stages reads this module's switches, so neither can import the other's names at import time).
+def __getattr__(name: str):
+    if name.startswith("__"):
+        raise AttributeError(name)
+    from . import ops_epilogue, ops_stages
+    for m in (ops_stages, ops_epilogue):
+        if name in m.__dict__:
+            return m.__dict__[name]
+    raise AttributeError(f"module 'collab_splats_amd.ops' has no attribute {name!r}")

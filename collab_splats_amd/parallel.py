@@ -50,11 +50,11 @@ def shard_views(n_views: int, rank: int, world: int) -> List[int]:
 #                          buffer with every peer at once, the pattern that uses all 7 xGMI links of a GPU (~1.9 ms for
 #                          1.18 GB where a per-link-bound ring takes ~13.5 ms) -- for the case RCCL picks a ring.
 SPARSE = os.environ.get("MISPLAT_SPARSE_REDUCE", "auto")
-SPARSE_MAX_FRACTION = float(os.environ.get("MISPLAT_SPARSE_MAX_FRACTION", "0.35"))
+SPARSE_MAX_FRACTION = 0.35
 ALLREDUCE = os.environ.get("MISPLAT_ALLREDUCE", "auto")
-# One-GPU rehearsal (bench.py --buckets): run the flags -> bitmap -> union -> pack -> [no collective] -> unpack path with a
+# One-GPU rehearsal (bench.py --buckets --rehearse-sparse): run the flags -> bitmap -> union -> pack -> [no collective] -> unpack path with a
 # world of one, to measure what the sparse reduce costs on the device besides the bytes it saves on the links.
-REHEARSE = os.environ.get("MISPLAT_SPARSE_REHEARSE", "0") == "1"
+REHEARSE = False                                  # bench.py --rehearse-sparse sets it
 # A process group of ONE rank normally short-cuts every collective (there is nothing to sum).  With this switch the calls are
 # issued all the same -- uint8 all_gather_into_tensor, the packed all_reduce, reduce_scatter_tensor + all_gather_into_tensor,
 # the dense all_reduce, the early colour launch -- so that one GPU can put the whole sequence through RCCL (dtype, size,
