@@ -31,7 +31,8 @@ timeline() { # $1 = name, rest = bench flags
 }
 for part in $PARTS; do case $part in
 bench)
-  python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || tail -5 $OUT/bench.err
+  python3 bench.py --details $OUT/bench_details.json > $OUT/bench.json 2> $OUT/bench.err || tail -5 $OUT/bench.err
+  python3 bench.py --steps 20 --warmup 5 --details $OUT/bench_driver_protocol_details.json > $OUT/bench_driver_protocol.json 2> /dev/null
   say "bench: $(python3 scripts/bench_brief.py $OUT/bench.json 2>&1 | head -3 | tr '\n' ' ')";;
 stats)
   ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-variants > $OUT/stats_bench.log 2>&1 )
@@ -63,7 +64,9 @@ models)
   done; done
   MISPLAT_FRONT_ONLY=0 python3 bench.py --no-cpu-baseline --no-variants --dn-loss --gaussians 5000000 --fixed-view > $OUT/bench_5M_dnloss_fixed_full_sort.json 2> /dev/null
   python3 bench.py --no-cpu-baseline --no-variants --dn-loss --gaussians 5000000 --fixed-view --buckets > $OUT/bench_5M_dnloss_fixed_buckets.json 2> /dev/null
-  MISPLAT_SPARSE_REHEARSE=1 python3 bench.py --no-cpu-baseline --no-variants --dn-loss --gaussians 5000000 --fixed-view --buckets > $OUT/bench_5M_dnloss_fixed_buckets_sparse_rehearsal.json 2> /dev/null
+  python3 bench.py --no-cpu-baseline --no-variants --dn-loss --gaussians 5000000 --fixed-view --buckets --rehearse-sparse > $OUT/bench_5M_dnloss_fixed_buckets_sparse_rehearsal.json 2> /dev/null
+  # the configs[4] step with every collective of the N > 1 path issued through RCCL by a group of ONE rank (no scaling figure: a smoke)
+  MISPLAT_FORCE_COLLECTIVES=1 python3 bench.py --no-cpu-baseline --no-variants --shared-grads --dn-loss --gaussians 5000000 --buckets > $OUT/bench_5M_shared_rccl_world1.json 2> $OUT/bench_5M_shared_rccl_world1.err
   say "5M full sort / buckets / sparse rehearsal: $(for f in full_sort buckets buckets_sparse_rehearsal; do python3 -c "import json; d=json.load(open('$OUT/bench_5M_dnloss_fixed_$f.json')); print(d['ms_per_step'], end=' ')"; done 2>&1)";;
 small)
   python3 bench.py --no-cpu-baseline --gaussians 10000 --width 256 --height 256 > $OUT/bench_10k.json 2> /dev/null
@@ -71,12 +74,10 @@ small)
   python3 bench.py --no-cpu-baseline --gaussians 10000 --width 256 --height 256 --graphed --fixed-view > $OUT/bench_10k_graphed.json 2> /dev/null
   python3 bench.py --no-cpu-baseline --gaussians 10000 --width 256 --height 256 --graphed > $OUT/bench_10k_graphed_cycling.json 2> /dev/null
   python3 bench.py --no-cpu-baseline --gaussians 100000 --graphed > $OUT/bench_100k_graphed_cycling.json 2> /dev/null
-  say "10k / 100k / 10k graphed: $(for f in 10k 100k 10k_graphed; do python3 -c "import json; d=json.load(open('$OUT/bench_$f.json')); print(d['ms_per_step'], {k: v['ms_per_step'] for k, v in d['variants'].items()}, d['config'].get('graph_hit_rate'), end=' | ')"; done 2>&1)";;
+  say "10k / 100k / 10k graphed: $(for f in 10k 100k 10k_graphed; do python3 -c "import json; d=json.load(open('$OUT/bench_$f.json')); print(d['ms_per_step'], {k: v[0] for k, v in d['variants'].items()}, d['config'].get('graph_hit_rate'), end=' | ')"; done 2>&1)";;
 features)
   python3 bench.py --features 13 --fixed-view --no-cpu-baseline > $OUT/bench_features.json 2> $OUT/bench_features.err
   timeline 1M_features_fixed --features 13 --fixed-view
-  MISPLAT_LAZY_ND=0 python3 bench.py --features 13 --fixed-view --no-cpu-baseline --no-variants > $OUT/bench_features_dense.json 2> /dev/null
-  MISPLAT_LAZY_ND=0 timeline 1M_features_fixed_dense --features 13 --fixed-view
-  say "features: $(python3 -c "import json; d=json.load(open('$OUT/bench_features.json')); print(d['ms_per_step'], {k: v['ms_per_step'] for k, v in d['variants'].items()})" 2>&1)";;
+  say "features: $(python3 -c "import json; d=json.load(open('$OUT/bench_features.json')); print(d['ms_per_step'], {k: v[0] for k, v in d['variants'].items()})" 2>&1)";;
 esac; done
 cat $OUT/progress.txt

@@ -61,6 +61,6 @@ for p in params.values():
     assert torch.isfinite(p).all()
 print(json.dumps({"steps": STEPS, "step_size": STEP, "marks": marks, "front_only_samples": front[-12:],
                   "front_only_flagged_mean": (sum(f[1] for f in front[4:]) / max(len(front[4:]), 1)) if front else None}))
-if ops.KEY_TRACE:                                                    # MISPLAT_KEY_TRACE=1: what moved between two visits of a view
+if ops.KEY_TRACE:                                                    # (ops.KEY_TRACE = [] before the run: what moved between two visits of a view)
     for line in ops.key_trace_report(16, start=64)[:12]:
         print("key-trace", line, file=sys.stderr)

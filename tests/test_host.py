@@ -534,3 +534,39 @@ def test_meta_completes_its_lazy_keys_for_every_access_style(monkeypatch):
     assert "flatten_ids" not in plain and plain.get("flatten_ids") is None and list(plain) == ["radii"] and len(plain) == 1
     with pytest.raises(KeyError):
         plain["flatten_ids"]
+
+
+def test_every_environment_switch_reaches_its_module_variable():
+    """INTEGRATION.md section 5 documents twelve MISPLAT_* switches (round 4 had forty); each is read once, at import, into a
+    module variable -- checked here in a child process with every one of them set to a non-default value.  Whatever else
+    was a variable in round 4 is a module constant now: nothing in the package reads another MISPLAT_* name."""
+    import json
+    import re
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MISPLAT_DETERMINISTIC="1", MISPLAT_GRAPH="0", MISPLAT_GRAPH_ENTRIES="17", MISPLAT_LAZY_SH="0",
+               MISPLAT_FRONT_ONLY="1", MISPLAT_ARENA="0", MISPLAT_ARENA_TRIM_MB="3", MISPLAT_SPARSE_REDUCE="0",
+               MISPLAT_ALLREDUCE="rs_ag", MISPLAT_FORCE_COLLECTIVES="1", MISPLAT_LIB="/nonexistent/libmisplat.so")
+    code = ("import json, sys; sys.path.insert(0, %r); from collab_splats_amd import ops, arena, parallel, _lib\n"
+            "try:\n    _lib.load(); lib = 'loaded'\nexcept _lib.MisplatError as e:\n    lib = str(e)\n"
+            "print(json.dumps(dict(det=ops.DETERMINISTIC_BACKWARD, graph=ops.GRAPHS, entries=ops.GRAPH_CACHE_ENTRIES, lazy=ops.LAZY_SH,"
+            " front=ops.FRONT_ONLY, arena=arena.ENABLED, trim=arena.TRIM_BYTES, sparse=parallel.SPARSE, allreduce=parallel.ALLREDUCE,"
+            " force=parallel.FORCE_COLLECTIVES, lib=lib)))") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["det"] is True and got["graph"] is False and got["entries"] == 17 and got["lazy"] == "0" and got["front"] == "1"
+    assert got["arena"] is False and got["trim"] == 3 << 20 and got["sparse"] == "0" and got["allreduce"] == "rs_ag" and got["force"] is True
+    assert "/nonexistent/libmisplat.so" in got["lib"] and "no CPU fallback" in got["lib"]
+    documented = {"MISPLAT_DETERMINISTIC", "MISPLAT_GRAPH", "MISPLAT_GRAPH_ENTRIES", "MISPLAT_LAZY_SH", "MISPLAT_FRONT_ONLY", "MISPLAT_ARENA",
+                  "MISPLAT_ARENA_TRIM_MB", "MISPLAT_SPARSE_REDUCE", "MISPLAT_ALLREDUCE", "MISPLAT_DIST_BACKEND", "MISPLAT_FORCE_COLLECTIVES",
+                  "MISPLAT_LIB"}
+    read = set()
+    pkg = os.path.join(ROOT, "collab_splats_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            read |= set(re.findall(r"environ(?:\.get)?\(\s*\"(MISPLAT_[A-Z_]+)\"", open(os.path.join(pkg, f)).read()))
+    assert read == documented, (read - documented, documented - read)
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert all(f"`{name}`" in text for name in documented)
