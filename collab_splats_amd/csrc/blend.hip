@@ -808,7 +808,10 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
                 const float dy = q0.y - py;
                 const float bdy = q0.w * dy, ecc = (q1.x * dy) * dy;
                 const float tpy = q1.z - q2.x * dy;
-                if (sub == 3) {
+                // (N-D records, NXQ > 0: every trip takes the two-pixel body -- 17 more accumulations and a second butterfly per
+                //  trip leave no registers for a second body: with one, the NXQ = 4 kernel spilled 160 bytes inside the loop and
+                //  the features model's backward went from 0.83 to 1.73 ms)
+                if (NXQ > 0 || sub == 3) {
                     // ---- both halves: the lane's two pixels in packed instructions (v_pk_{fma,mul,add}_f32); the per-pixel
                     // decisions are lane masks in scalar registers (one ballot per vector compare, combined with scalar ANDs,
                     // turned back into select conditions with inverse_ballot): see blend_fwd_kernel
@@ -878,7 +881,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
 #pragma unroll
                     for (int ch = 0; ch < 16; ch++) accx[ch] = (NXQ > 0 && ch < NX) ? dot2(w, vcolx2[ch < NX ? ch : 0]) : 0.f;
                     if (ABS) { ab0 = fabsf(vmx.x) + fabsf(vmx.y); ab1 = fabsf(vmy.x) + fabsf(vmy.y); }
-                } else {
+                } else if (NXQ == 0) {
                     // ---- one half: the same operations on component k alone
                     auto half = [&](auto kc) {
                         constexpr int k = decltype(kc)::value;
