@@ -762,7 +762,7 @@ def main():
                        "graph_timed": [graph_timed["hits"], graph_timed["captures"], graph_timed["calls"]],
                        "path": {k: took.get(k, 0) for k in ("forward", "forward_lazy_colour", "forward_view_order", "capacity_redo",
                                                            "backward_one_call", "backward_background_fill", "forward_front_only",
-                                                           "forward_probe")},
+                                                           "forward_probe", "forward_plan_hit", "backward_plan_hit")},
                        "host": "whole-step hipGraphs" if graphed is not None else "eager"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),

@@ -25,6 +25,7 @@ from torch import Tensor
 ENABLED = os.environ.get("MISPLAT_ARENA", "1") == "1"
 MAX_SLOTS = 4
 MAX_RINGS = 12      # distinct (stream, shape, role) keys kept; LRU beyond
+MAX_PLANS = 32      # cached call plans per slot (ops._FwdPlan / _BwdPlan: one per resident camera of a training loop)
 # A ring nobody has asked for in this many lookups is dropped: densification changes the number of Gaussians every few hundred
 # steps and never comes back to the old one (scripts/soak.py: +0.7 GB of reserved memory per change at 1 M without this).
 IDLE_LOOKUPS = 64
@@ -104,12 +105,42 @@ class Slot:
         self.floor = self._count()                                # raw + base + the typed views + the storage wrapper
         self.off = 0
         self.demand = 0
+        # A steady-state call may leave its carved views and filled argument blocks here for its next visit (ops._FwdPlan /
+        # _BwdPlan): `plan_refs` = how many tensors of the plan refer to this storage -- they are the library's own and do not
+        # make the slot busy.
+        self.plans: "collections.OrderedDict" = collections.OrderedDict()     # key -> plan (a plan has `.refs`); LRU of MAX_PLANS
+        self.plan_refs = 0
 
     def _count(self) -> int:
         return int(_use_count(self.storage._cdata))
 
     def free(self) -> bool:
-        return self._count() <= self.floor
+        return self._count() <= self.floor + self.plan_refs
+
+    def get_plan(self, key):
+        p = self.plans.get(key)
+        if p is not None:
+            self.plans.move_to_end(key)
+        return p
+
+    def put_plan(self, key, plan, refs: int) -> None:
+        """``refs`` = how many tensors of ``plan`` refer to this slot's storage (measured by the caller around the build)."""
+        self.drop_plan(key)
+        plan.refs = int(refs)
+        self.plans[key] = plan
+        self.plan_refs += plan.refs
+        while len(self.plans) > MAX_PLANS:                        # (a trainer's resident cameras: one plan per view)
+            _, old = self.plans.popitem(last=False)
+            self.plan_refs -= old.refs
+
+    def drop_plan(self, key=None) -> None:
+        if key is None:
+            self.plans.clear()
+            self.plan_refs = 0
+        else:
+            old = self.plans.pop(key, None)
+            if old is not None:
+                self.plan_refs -= old.refs
 
     def begin(self) -> None:
         self.off = 0

@@ -2501,6 +2501,70 @@ def test_arena_slots_are_not_recycled_under_tensors_that_are_still_held(dev):
     assert arena.STATS["slots_created"] - before.get("slots_created", 0) <= 3
 
 
+def test_plan_cache_changes_nothing_and_keeps_held_tensors_intact(dev, monkeypatch):
+    """A steady-state call finds its carved views and its filled argument blocks on its arena slot (``ops._FwdPlan`` /
+    ``_BwdPlan``: what a small scene's eager step spent most of its host time rebuilding).  The plan is pure plumbing: the same
+    images bit for bit and the same gradients as a loop that rebuilds everything, plan hits from the third step on; and the
+    plan's own references to the slot are counted EXACTLY -- a caller that keeps a single tensor of a call (here ``radii`` alone)
+    keeps that slot out of circulation, its values stay what they were while other calls run."""
+    from collab_splats_amd import arena, ops, rasterization
+    from collab_splats_amd.synthetic import random_scene, view_matrix
+    N, W, H = 20_000, 320, 192
+    sc = random_scene(N, W, H, seed=13)
+    leaves = [sc[k].to(dev).requires_grad_(True) for k in ("means", "quats", "log_scales", "opacity_logits", "sh")]
+    views = [view_matrix(v).to(dev) for v in range(2)]
+    K = sc["Ks"].to(dev)
+    kw = dict(sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased", return_depth_normal=True, scales_are_log=True,
+              opacities_are_logit=True, absgrad=True)
+    ups = [u.to(dev) for u in upstream([(1, H, W, 4), (1, H, W, 1), (1, H, W, 1), (1, H, W, 1), (1, H, W, 3)], dtype=torch.float32)]
+
+    def loop(n_steps):
+        res = []
+        for it in range(n_steps):
+            for l in leaves:
+                l.grad = None
+            out = rasterization(*leaves, views[it % 2], K, W, H, **kw)
+            m2d = out[5]["means2d"]
+            m2d.retain_grad()
+            torch.autograd.backward(list(out[:5]), ups)
+            res.append(([t.detach().clone() for t in out[:5]], [l.grad.clone() for l in leaves], m2d.grad.clone(), m2d.absgrad.clone(),
+                        out[5]["flatten_ids"].clone()))
+            del out, m2d
+        torch.cuda.synchronize()
+        return res
+
+    arena.reset()
+    monkeypatch.setattr(ops, "PLAN_CACHE", False)
+    ref = loop(6)
+    arena.reset()
+    monkeypatch.setattr(ops, "PLAN_CACHE", True)
+    before = dict(ops.PATH_STATS)
+    got = loop(10)
+    took = {k: ops.PATH_STATS[k] - before.get(k, 0) for k in ops.PATH_STATS}
+    assert took.get("forward_plan_hit", 0) >= 6 and took.get("backward_plan_hit", 0) >= 6, took
+    for it in (4, 5, 8, 9):
+        r = ref[4 + it % 2]
+        for a, b in zip(got[it][0], r[0]):
+            assert torch.equal(a, b), it
+        for a, b in zip(got[it][1], r[1]):
+            assert rel_err(a, b) < 2e-5, it
+        assert rel_err(got[it][2], r[2]) < 2e-5 and rel_err(got[it][3], r[3]) < 2e-5 and torch.equal(got[it][4], r[4])
+    # ---- one tensor of a call held across later calls: the slot it lives in is not handed out again
+    for l in leaves:
+        l.grad = None
+    out = rasterization(*leaves, views[0], K, W, H, **kw)
+    held = out[5]["radii"]
+    snap = held.clone()
+    del out
+    with torch.no_grad():
+        leaves[0].add_(0.3)                                          # another scene: a recycled slot would show other radii
+    later = loop(4)
+    assert not torch.equal(later[-2][4], got[8][4])                  # (the scene did change)
+    assert torch.equal(held, snap)
+    del held
+    loop(2)
+
+
 def test_arena_memory_stays_bounded_while_the_scene_grows(dev):
     """densification only ever grows N, so every arena ring becomes obsolete sooner or later.  Each ring has a
     memory pool of its own that dies with it, and the memory of dropped rings goes back to the device (``arena.trim``): after
