@@ -826,6 +826,8 @@ class _RasterFused(torch.autograd.Function):
                 cv=cv)
             cv = state["carver"]
             prep = _phase_b_prepare(P, state, cd)
+            state["carver"] = None            # (a plan that kept its carver would close a cycle slot -> plan -> carver -> ring -> slot:
+                                              #  a dropped ring's memory would then wait for the cyclic collector)
             if pkey is not None and prep["sched"].by_view is not None and cv.slot is not None:
                 plan = _FwdPlan()
                 plan.key, plan.state, plan.prep, plan.outs = pkey, state, prep, (r0, m0, d0, c0, g0, s0)
