@@ -113,7 +113,7 @@ SYMBOLS = {
     "misplat_bucket_tiles": (C.c_int, 11),
     "misplat_unit_order": (C.c_int, 4), "misplat_raster_fwd": (C.c_int, 5), "misplat_raster_bwd": (C.c_int, 4), "misplat_raster_bwd_plan": (C.c_int, 2), "misplat_graph_cache_create": (C.c_void_p, 1),
     "misplat_graph_cache_destroy": (None, 1), "misplat_graph_cache_stats": (C.c_int, 3), "misplat_wait_count": (C.c_int64, 2), "misplat_zero_bytes": (C.c_int, 3), "misplat_stream_copy": (C.c_int, 5),
-    "misplat_touched_bits": (C.c_int, 4), "misplat_union_count": (C.c_int, 5), "misplat_union_ids": (C.c_int, 7),
+    "misplat_touched_bits": (C.c_int, 4), "misplat_union_count": (C.c_int, 5), "misplat_union_scan": (C.c_int, 5), "misplat_union_ids": (C.c_int, 7),
     "misplat_rows_pack": (C.c_int, 8), "misplat_rows_unpack": (C.c_int, 8),
     "misplat_debug_memset_replay": (C.c_int, 5),
     "misplat_version": (C.c_char_p, 0),

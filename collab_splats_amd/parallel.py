@@ -192,6 +192,8 @@ class GradientBuckets:
         # the collectives have been waited for -- a union that outgrew the capacity leaves the dense buffer untouched and is
         # reduced densely then.  (The host read in the middle of the backward cost the 5 M step 0.6 ms on one GPU.)
         self._row_cap = None
+        self._ws = None                                  # device work arrays of the sparse path (bitmaps, counts, offsets, ids)
+        self._packed: dict = {}                          # packed row buffers per bucket span, sized by the row capacity
         self._pin = None
         self._pending = None                             # (event, the capacity the step ran with) of the count copy in flight
 
@@ -217,7 +219,9 @@ class GradientBuckets:
         handed out since ``attach()`` (else None: the caller allocates, autograd accumulates).  A FRESH view object
         every time: autograd adopts an incoming gradient without a copy only if nobody else holds it."""
         i = self._by_ptr.get(inp.data_ptr())
-        if i is None or self.views[i].shape != inp.shape:
+        # (the parameter itself, or a reshaped view of ALL of it -- the model passes ``opacities.squeeze(-1)``,
+        # rade_gs_model.py:444: the gradient of the view, written into the slice, reaches ``p.grad`` as a view of the same memory)
+        if i is None or self.views[i].numel() != inp.numel() or not inp.is_contiguous():
             return None
         if i in self._handed:
             if self._reduced:
@@ -324,19 +328,26 @@ class GradientBuckets:
             import ctypes as C
             from . import _lib
             lib = _lib.load()
-            bits = torch.empty(nbytes, device=t.device, dtype=torch.uint8)
-            _lib.check(lib.misplat_touched_bits(_lib.ptr(t), C.c_int64(n), _lib.ptr(bits), _lib.stream_ptr()), "misplat_touched_bits")
-            gathered = torch.empty(world * nbytes, device=t.device, dtype=torch.uint8)
-            _gather_bits(gathered, bits)
             n_blocks = (nbytes + 255) // 256
-            counts = torch.empty(n_blocks, device=t.device, dtype=torch.int32)
+            # (the small work arrays of this path live with the sink: no allocator call and no library scan per step -- the
+            # first torch op behind the backward's launch used to block the autograd thread for 0.9 ms a step at 5 M)
+            ws = self._ws
+            if ws is None or ws["key"] != (n, world, t.device):
+                ws = self._ws = dict(key=(n, world, t.device), bits=torch.empty(nbytes, device=t.device, dtype=torch.uint8),
+                                     gathered=torch.empty(world * nbytes, device=t.device, dtype=torch.uint8),
+                                     counts=torch.empty(n_blocks, device=t.device, dtype=torch.int32),
+                                     offs=torch.empty(n_blocks, device=t.device, dtype=torch.int64),
+                                     total=torch.empty(1, device=t.device, dtype=torch.int64), ids=None)
+            bits, gathered, counts, offs, total_dev = ws["bits"], ws["gathered"], ws["counts"], ws["offs"], ws["total"]
+            _lib.check(lib.misplat_touched_bits(_lib.ptr(t), C.c_int64(n), _lib.ptr(bits), _lib.stream_ptr()), "misplat_touched_bits")
+            _gather_bits(gathered, bits)
             _lib.check(lib.misplat_union_count(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr(counts),
                                                _lib.stream_ptr()), "misplat_union_count")
-            incl = torch.cumsum(counts, dim=0, dtype=torch.int64)
-            offs = (incl - counts).contiguous()
+            _lib.check(lib.misplat_union_scan(_lib.ptr(counts), C.c_int64(n_blocks), _lib.ptr(offs), _lib.ptr(total_dev),
+                                              _lib.stream_ptr()), "misplat_union_scan")
             cap = self._row_cap
             if cap is None:                                                # first sparse step of this sink: one host read
-                total = int(incl[-1].item())
+                total = int(total_dev.item())
                 STATS["host_reads_in_step"] += 1
                 self._row_cap = _row_capacity(total)
                 if SPARSE != "1" and total > SPARSE_MAX_FRACTION * n:
@@ -349,14 +360,16 @@ class GradientBuckets:
                 # the size goes to a pinned slot behind everything else of the step; allreduce() reads it at the end
                 if self._pin is None:
                     self._pin = torch.empty(1, dtype=torch.int64).pin_memory()
-                self._count_dev = incl[-1:]
+                self._count_dev = total_dev
                 self._pin.copy_(self._count_dev, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 self._pending = (ev, cap)
                 if SPARSE != "1" and cap > SPARSE_MAX_FRACTION * n:
                     return None                                            # (dense; the count is still tracked: the union may shrink)
-                ids = torch.empty(cap, device=t.device, dtype=torch.int32)
+                if ws["ids"] is None or ws["ids"].numel() != cap:
+                    ws["ids"] = torch.empty(cap, device=t.device, dtype=torch.int32)
+                ids = ws["ids"]
                 _lib.check(lib.misplat_union_ids(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr(offs), _lib.ptr(ids),
                                                  C.c_int64(cap), _lib.stream_ptr()), "misplat_union_ids")
                 self._union = ids
@@ -402,8 +415,12 @@ class GradientBuckets:
         n_pack = int(ids.numel()) * W
         n_pad = (n_pack + world - 1) // world * world                      # (rs_ag wants a multiple of the world size)
         dev = self.flat.device
-        packed = torch.zeros(n_pad, device=dev, dtype=torch.float32) if n_pad != n_pack else torch.empty(n_pad, device=dev, dtype=torch.float32)
         counted = bool(getattr(self, "_union_counted", False))
+        packed = self._packed.get((a, b)) if (counted and dev.type == "cuda") else None
+        if packed is None or packed.numel() != n_pad:
+            packed = torch.zeros(n_pad, device=dev, dtype=torch.float32) if n_pad != n_pack else torch.empty(n_pad, device=dev, dtype=torch.float32)
+            if counted and dev.type == "cuda":
+                self._packed[(a, b)] = packed            # (the padding floats stay zero: pack only writes n_pack of them)
         self._rows_move(True, members, widths, ids, packed, counted)
         if _backend() == "gloo" and packed.is_cuda:
             host = packed.cpu()

@@ -596,7 +596,9 @@ int misplat_adam_step(int32_t n_tensors, float* const* params, const float* cons
  *   touched_bits  bits[ceil(n_rows / 8)]: bit (r & 7) of byte r >> 3 = flags[r] != 0 (flags: misplat_params.touched, 8-byte
  *                 aligned) -- the bitmap a rank contributes to the all-gather;
  *   union_count   gathered[world][nbytes] = the ranks' bitmaps; block_counts[ceil(nbytes / 256)] = rows set in the OR of
- *                 them, per block of 2 048 rows (the caller scans them: block_offsets, and reads the total);
+ *                 them, per block of 2 048 rows;
+ *   union_scan    block_offsets[b] = sum of block_counts[0 .. b) (int64), *total = the union's size (one workgroup: the counts
+ *                 are a few thousand; the caller reads the total when -- and if -- it needs it on the host);
  *   union_ids     ids[block_offsets[b] ...] = the set rows of block b, ascending: the same list on every rank;
  *   rows_pack     packed[u][W] = the rows ids[u] of n_tensors (<= 8) row-major tensors of `widths` floats per row, side by
  *                 side (W = sum of the widths); rows_unpack: the inverse (rows outside `ids` are not touched). */
@@ -604,6 +606,8 @@ int misplat_adam_step(int32_t n_tensors, float* const* params, const float* cons
 int misplat_touched_bits(const uint8_t* flags, int64_t n_rows, uint8_t* bits, misplat_stream_t stream);
 int misplat_union_count(const uint8_t* gathered, int32_t world, int64_t nbytes, int32_t* block_counts,
                         misplat_stream_t stream);
+int misplat_union_scan(const int32_t* block_counts, int64_t n_blocks, int64_t* block_offsets, int64_t* total,
+                       misplat_stream_t stream);
 int misplat_union_ids(const uint8_t* gathered, int32_t world, int64_t nbytes, const int64_t* block_offsets, int32_t* ids,
                       int64_t ids_cap, misplat_stream_t stream);
 /* count_dev (device, or NULL = n_ids): how many of the n_ids slots hold a row, for a caller that sized ids / packed from the

@@ -1889,6 +1889,56 @@ def test_rccl_world_of_one_runs_every_collective_of_the_gradient_buckets(dev):
     assert all(c["stats"]["collectives"] > 0 for c in res["cases"].values())
 
 
+def test_model_step_into_the_gradient_sink_goes_sparse_for_both_buckets(dev, monkeypatch):
+    """configs[4] per rank: the model mirror's step (``get_outputs`` -> ``get_loss_dict`` -> backward) with its six parameters
+    in a ``GradientBuckets`` sink.  The model hands the rasterizer ``opacities.squeeze(-1)`` (rade_gs_model.py:444) -- a view
+    of the whole parameter: its gradient is written into the parameter's slice all the same, so EVERY slice is written in
+    place and both buckets can travel as touched rows only (round 4 copied that one gradient in, which silently sent the
+    geometry bucket densely: 220 MB instead of a few at 5 M).  Gradients equal those of a step without a sink."""
+    from collab_splats_amd import ops, parallel, radegs
+    from collab_splats_amd.synthetic import random_scene
+    monkeypatch.setattr(parallel, "REHEARSE", True)
+    monkeypatch.setattr(parallel, "SPARSE", "1")
+    N, W, H = 300_000, 640, 360
+    sc = random_scene(N, W, H, seed=23)
+    cfg = radegs.RadegsModelConfig(rasterize_mode="antialiased", regularization_from_iter=0, ssim_lambda=0.2)
+    model = radegs.RadegsModel(cfg, sc["means"], sc["log_scales"] + 0.405, sc["quats"], sc["opacity_logits"], sc["sh"][:, 0],
+                               sc["sh"][:, 1:]).to(dev)
+    model.train()
+    model.step = 20000
+    c2w = torch.tensor([[1.0, 0, 0, 0], [0, -1.0, 0, 0], [0, 0, -1.0, 0]])
+    cam = radegs.PinholeCamera.make(c2w, 0.9 * W, 0.9 * W, W, H)
+    target = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    leaves = [model.gauss_params[k] for k in parallel.GRAD_KEYS]
+
+    def step(bucket):
+        if bucket is None:
+            for p in leaves:
+                p.grad = None
+        else:
+            bucket.attach()
+        try:
+            loss = model.get_loss_dict(model.get_outputs(cam), {"image": target})
+            sum(loss.values()).backward()
+        finally:
+            if bucket is not None:
+                bucket.allreduce()
+        return [p.grad.clone() for p in leaves]
+
+    ref = step(None)
+    bucket = parallel.GradientBuckets(leaves)
+    before = dict(parallel.STATS)
+    for it in range(3):
+        got = step(bucket)
+        for name, a, b in zip(parallel.GRAD_KEYS, got, ref):
+            assert torch.isfinite(a).all() and rel_err(a, b) < 2e-5, (it, name, rel_err(a, b))
+        for p, v in zip(leaves, bucket.views):
+            assert p.grad.data_ptr() == v.data_ptr()
+    took = {k: parallel.STATS[k] - before.get(k, 0) for k in parallel.STATS}
+    assert took["sparse"] == 6 and took["dense"] == 0 and took["geometry_touched_late"] == 0, took
+    assert ops.GRAD_SINK is None
+
+
 def test_large_scene_entirely_out_of_view_gives_zero_gradients(dev):
     """No intersection at all in a scene large enough for the background-fill path (>= 262 144 Gaussians): the compositing
     backward has no grid to carry the fill, the zeros are then written by plain fill launches -- every gradient is
@@ -2630,6 +2680,10 @@ def test_sparse_reduce_kernels_bitmaps_union_pack_unpack(dev):
         rows = np.flatnonzero((flags != 0).any(0))
         incl = torch.cumsum(counts, 0, dtype=torch.int64)
         assert int(incl[-1]) == rows.size
+        offs_k = torch.full((n_blocks,), -1, dtype=torch.int64, device=dev)          # the library's own one-workgroup scan
+        total_k = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        _lib.check(lib.misplat_union_scan(_lib.ptr(counts), C.c_int64(n_blocks), _lib.ptr(offs_k), _lib.ptr(total_k), _lib.stream_ptr()), "scan")
+        assert torch.equal(offs_k, incl - counts) and int(total_k) == rows.size
         ids = torch.empty(max(rows.size, 1), dtype=torch.int32, device=dev)
         _lib.check(lib.misplat_union_ids(_lib.ptr(gathered), C.c_int32(world), C.c_int64(nbytes), _lib.ptr((incl - counts).contiguous()),
                                          _lib.ptr(ids), C.c_int64(ids.numel()), _lib.stream_ptr()), "ids")
