@@ -35,6 +35,7 @@ from __future__ import annotations
 
 import argparse
 import functools
+import gc
 import json
 import os
 import subprocess
@@ -566,6 +567,7 @@ def main():
             run()
         info["allreduce_ms"].clear()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
+        gc.collect()                               # (a full collection that is due lands here, not as a 30 - 50 ms pause in one of K short steps)
         fence()
         info["graph0"] = ops.graph_cache_stats()                 # (host-side counters: no device work)
         t0 = time.perf_counter()
