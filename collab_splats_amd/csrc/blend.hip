@@ -158,11 +158,27 @@ __device__ __forceinline__ float4 lazy_colour(const LazyColour& lz, int g) {
     const float* row = split ? lz.coeffs_rest + (size_t)gg * 45 - 3 : lz.coeffs + (size_t)gg * 48;
     const float* dc = split ? lz.coeffs + (size_t)gg * 3 : row;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    // The coefficients arrive in TWO round trips (terms 0 - 8, the degrees <= 2, then 9 - 15), each requested as a block before
+    // the first of its terms is used: the wave that evaluates sits in the compositing loop's staging step and every round trip
+    // is a stall of all its pixels (term by term, as the walk's scheduling groups would have it, there were eight).  27
+    // registers at a point where the trip's temporaries are dead.
+    float cf[48];
+    const int n1 = lz.deg > 1 ? 9 : (lz.deg > 0 ? 4 : 1);
+    cf[0] = dc[0]; cf[1] = dc[1]; cf[2] = dc[2];
+#pragma unroll
+    for (int k = 1; k < 9; k++)
+        if (k < n1) { cf[3 * k] = row[3 * k]; cf[3 * k + 1] = row[3 * k + 1]; cf[3 * k + 2] = row[3 * k + 2]; }
+    __builtin_amdgcn_sched_barrier(0);
 #define LZ_TERM(k, B, BX, BY, BZ)                                                       \
     {                                                                                   \
-        const float* f_ = (k) == 0 ? dc : row + 3 * (k);                                \
+        if ((k) == 9) {                                                                 \
+            _Pragma("unroll") for (int k2 = 9; k2 < 16; k2++) {                         \
+                cf[3 * k2] = row[3 * k2]; cf[3 * k2 + 1] = row[3 * k2 + 1]; cf[3 * k2 + 2] = row[3 * k2 + 2]; \
+            }                                                                           \
+            __builtin_amdgcn_sched_barrier(0);                                          \
+        }                                                                               \
         const float b_ = (B);                                                           \
-        c0 = fmaf(b_, f_[0], c0); c1 = fmaf(b_, f_[1], c1); c2 = fmaf(b_, f_[2], c2);   \
+        c0 = fmaf(b_, cf[3 * (k)], c0); c1 = fmaf(b_, cf[3 * (k) + 1], c1); c2 = fmaf(b_, cf[3 * (k) + 2], c2); \
     }
     MISPLAT_SH_WALK(lz.deg, x, y, z, LZ_TERM)
 #undef LZ_TERM
