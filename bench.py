@@ -568,6 +568,17 @@ def main():
         info["allreduce_ms"].clear()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(k)]
         gc.collect()                               # (a full collection that is due lands here, not as a 30 - 50 ms pause in one of K short steps)
+        # what the host did between the fences, for the details file: the enqueue time of every step and the interpreter's
+        # collections (generation, seconds) -- a multi-millisecond pause in one of K short steps shows up here, not in the kernels
+        stamps, pauses, began = [], [], [0.0]
+
+        def on_gc(phase, gc_info):
+            if phase == "start":
+                began[0] = time.perf_counter()
+            else:
+                pauses.append((gc_info["generation"], time.perf_counter() - began[0]))
+
+        gc.callbacks.append(on_gc)
         fence()
         info["graph0"] = ops.graph_cache_stats()                 # (host-side counters: no device work)
         t0 = time.perf_counter()
@@ -575,10 +586,17 @@ def main():
             e0.record()
             run()
             e1.record()
+            stamps.append(time.perf_counter())
         fence()
         dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+        gc.callbacks.remove(on_gc)
         info["graph1"] = ops.graph_cache_stats()
         dev_ms = sorted(a.elapsed_time(b) for a, b in evs)
+        host = sorted((b - a) * 1e3 for a, b in zip([t0] + stamps[:-1], stamps))
+        info["host_trace"] = {"enqueue_ms_median": round(host[len(host) // 2], 4), "enqueue_ms_max": round(host[-1], 4),
+                              "device_ms_max": round(dev_ms[-1], 4),
+                              "gc": {str(g): [sum(1 for x in pauses if x[0] == g), round(sum(x[1] for x in pauses if x[0] == g) * 1e3, 3)]
+                                     for g in sorted({x[0] for x in pauses})}}
         return dt, dev_ms[len(dev_ms) // 2]
 
     roof, roof_variants = copy_roof(dev) if rank == 0 else (0.0, [])
@@ -620,6 +638,7 @@ def main():
     stats0 = dict(ops.PATH_STATS)
     g_start = ops.graph_cache_stats()
     dt, dev_med = timed(step, args.steps, args.warmup)
+    host_trace_head = info.pop("host_trace", None)
     took = {k: ops.PATH_STATS[k] - stats0.get(k, 0) for k in ops.PATH_STATS}
     if ops.KEY_TRACE and rank == 0:                # MISPLAT_KEY_TRACE=1: which argument fields moved between two visits of a view
         for line in ops.key_trace_report(2 * (1 if mode["fixed"] else 8)):
@@ -782,7 +801,9 @@ def main():
         details = {"variants": variants, "graph_cache": ops.graph_cache_stats(), "graph_cache_timed": graph_timed,
                    "graph_cache_headline": graph_all, "arena": dict(__import__("collab_splats_amd.arena", fromlist=["STATS"]).STATS),
                    "path": dict(took), "n_isects_per_view": isects[:8], "copy_roof_variants_GBs": roof_variants,
-                   "units_per_step": units, "parallel_stats": dict(parallel.STATS)}
+                   "units_per_step": units, "parallel_stats": dict(parallel.STATS), "host_trace": host_trace_head}
+        # (compact: the slowest step's enqueue time on the host -- a pause of the interpreter or the OS in one of K short steps)
+        line["config"]["host_enqueue_ms"] = [host_trace_head["enqueue_ms_median"], host_trace_head["enqueue_ms_max"]] if host_trace_head else None
         if allreduce_ms:
             line["allreduce_ms"] = round(allreduce_ms[len(allreduce_ms) // 2], 4)
         if world == 1 and not args.no_cpu_baseline and not args.no_live_pmc and not args.dn_loss and args.features == 0 and graphed is None:

@@ -503,7 +503,8 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
                     w.x = MISPLAT_LANE(stop0) ? 0.f : w.x; w.y = MISPLAT_LANE(stop1) ? 0.f : w.y;
                     alive[k0] &= ~stop0; alive[k1] &= ~stop1;
                     any_alive |= alive[k0] | alive[k1];
-                    const v2f zp = ((q1z - q2.x * dy) - q1w * dx) * il2[kp];     // (q2 is consumed late: its LDS read hides behind alpha)
+                    // (depth times |ray| = rt - rp . d: the 1 / |ray| of the pixel multiplies the finished sums, below)
+                    const v2f zp = (q1z - q2.x * dy) - q1w * dx;                 // (q2 is consumed late: its LDS read hides behind alpha)
                     col2[kp][0] += w * q3.x;
                     if (CD > 1) col2[kp][CD > 1 ? 1 : 0] += w * q3.y;
                     if (CD > 2) col2[kp][CD > 2 ? 2 : 0] += w * q3.z;
@@ -559,7 +560,8 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
                 const int k = 2 * kp + h;
                 const float Ts = h ? T2[kp].y : T2[kp].x;               // negative: terminated, magnitude = T at termination
                 T[k] = Ts > 0.f ? Ts : 0.f; Tfin[k] = fabsf(Ts);
-                dep[k] = h ? dep2[kp].y : dep2[kp].x; med[k] = h ? med2[kp].y : med2[kp].x;
+                const float ilk = h ? il2[kp].y : il2[kp].x;
+                dep[k] = (h ? dep2[kp].y : dep2[kp].x) * ilk; med[k] = (h ? med2[kp].y : med2[kp].x) * ilk;
 #pragma unroll
                 for (int ch = 0; ch < CD; ch++) col[k][ch] = h ? col2[kp][ch].y : col2[kp][ch].x;
 #pragma unroll
@@ -685,7 +687,13 @@ __device__ __forceinline__ int wave_max(int v) {
 // Measured (1 M / 1080p, PPL 2): 4 waves/SIMD (111 VGPRs) 0.663 ms, 5 waves (96 VGPRs + 48 B
 // scratch) 0.616 ms, 6 waves (80 VGPRs + 88 B scratch) 0.711 ms.
 // PPL 4: 2 waves (172 VGPRs) 0.73 ms, 3 waves 0.655 ms, 4 waves (spills) 1.28 ms.
-template <int CD, int PPL, bool ABS, bool ATOMIC, int NXQ = 0>
+// MSUM (the one-call backward's flagged-row form, where the per-Gaussian kernel of the same call is the only reader of the rows):
+// row slots 0 - 1 carry  sum dx dL/dsigma,  sum dy dL/dsigma  instead of the mean2d gradient -- which is linear in them,
+//   v_mean2d = (a s0 + b s1 - rp_x v_rt,  b s0 + c s1 - rp_y v_rt)     (conic a b c, ray plane rp, v_rt = slot 6),
+// and slot 5 carries  sum o vis dL/dalpha = o times the opacity gradient (the sum of -dL/dsigma, which the trip has anyway).
+// Both are finished once per ROW by the per-Gaussian kernel (project.hip: project_bwd_one, pp_bwd_row) where this kernel
+// finished them once per PIXEL: seven packed + eight plain instructions of a two-pixel trip, ten of a one-pixel trip.
+template <int CD, int PPL, bool ABS, bool ATOMIC, int NXQ = 0, bool MSUM = false>
 #ifndef MISPLAT_BWD_WAVES
 #define MISPLAT_BWD_WAVES 5
 #endif
@@ -700,6 +708,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
     uint8_t* __restrict__ valid, const float4* __restrict__ featx = nullptr, float* __restrict__ v_featx = nullptr,
     int n_channels = CD, misplat_internal::FillList F = {}, FeatSrc fsrc = FeatSrc()) {
     static_assert(NXQ == 0 || ATOMIC, "N-D colours: atomic gradient mode only");
+    static_assert(!MSUM || (ATOMIC && !ABS && NXQ == 0), "sums for the mean2d gradient: the flagged-row backward without absgrad");
     static_assert(PPL == 2, "a band is two 8 x 8 halves, one pixel of each per lane");
     // Background role (F.blocks > 0): the last workgroups of the grid -- dispatched when the machine starts to drain --
     // or (at_head: fills too large for the tail) the first ones clear the tensors the per-Gaussian backward kernels write
@@ -768,8 +777,9 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
             }
             D2[k] = Tf * va;
             vn2[0][k] = v_normal[pid * 3]; vn2[1][k] = v_normal[pid * 3 + 1]; vn2[2][k] = v_normal[pid * 3 + 2];
-            vd2[k] = v_exp_depth[pid];
-            vm2[k] = v_med_depth[pid];
+            vd2[k] = v_exp_depth[pid] * il2[k];         // (the depth gradients ride pre-multiplied by 1 / |ray|: the pixel's
+                                                          //  depth is (rt - rp . d) / |ray|, and only these two see the factor)
+            vm2[k] = v_med_depth[pid] * il2[k];
         }
         // (wave-uniform, and in a SCALAR register: the deepest entry any pixel of half k composited)
         sublast[k] = __builtin_amdgcn_readfirstlane(wave_max(last[k]));
@@ -779,7 +789,8 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
     const int comp = butterfly_comp(lane);
     const bool writer = (lane & 3) == 0;          // one lane per quad holds (and writes) component `comp`
     // per-lane scale undoing the conic pre-multiplication (component = record layout index)
-    const float out_scale = (comp == 2 || comp == 4) ? -0.5f * kLog2e : (comp == 3 ? -kLog2e : 1.0f);
+    const float out_scale = MSUM ? ((comp == 2 || comp == 4) ? -0.5f : ((comp < 2 || comp == 3) ? -1.0f : 1.0f))
+                                 : ((comp == 2 || comp == 4) ? -0.5f * kLog2e : (comp == 3 ? -kLog2e : 1.0f));
     const float amax = P.alpha_max, amin = P.alpha_min;
     const uint32_t amax_bits = __float_as_uint(amax);
     const uint32_t comp_off = 4u * (uint32_t)comp;           // byte offset of this lane's component inside a 64-byte row
@@ -831,8 +842,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
                     // ---- both halves: the lane's two pixels in packed instructions (v_pk_{fma,mul,add}_f32); the per-pixel
                     // decisions are lane masks in scalar registers (one ballot per vector compare, combined with scalar ANDs,
                     // turned back into select conditions with inverse_ballot): see blend_fwd_kernel
-                    const float dyy = dy * dy, ndy = -dy;
-                    const float c1y = 2.0f * q1.x * dy;
+                    const float ndy = -dy;
                     const v2f dx = q0.x - px2;
                     const v2f e = fma2(fma2(q0.z, dx, bdy), dx, ecc);
                     v2f vis;
@@ -853,7 +863,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
                     T2 *= ra;
                     const v2f Tk = T2;
                     const v2f w = a * Tk;
-                    const v2f zp = (tpy - q1.w * dx) * il2;
+                    const v2f zp = tpy - q1.w * dx;                       // (depth times |ray|: vd2 carries the 1 / |ray|)
                     v2f dot = q3.x * vcol2[0];
                     if (CD > 1) dot += q3.y * vcol2[CD > 1 ? 1 : 0];
                     if (CD > 2) dot += q3.z * vcol2[CD > 2 ? 2 : 0];
@@ -864,30 +874,37 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
                     dot += q2.y * vn2[0] + q2.z * vn2[1] + q2.w * vn2[2] + zp * vd2;
                     const v2f v_a = D2 * ra + Tk * dot;                   // (only used through vam below: masked there)
                     D2 -= w * dot;
-                    v2f vz = w * vd2;
+                    v2f vzl = w * vd2;                                    // gradient of (rt - rp . d): depth gradient / |ray|
                     if (batch_has_median) {          // wave-uniform: most batches hold no pixel's median Gaussian
                         asm volatile("; median gradient" ::);               // (a real branch, not a speculated select)
                         v2f vmed;
                         vmed.x = (ok0 && i == medi[0]) ? vm2.x : 0.f; vmed.y = (ok1 && i == medi[1]) ? vm2.y : 0.f;
-                        vz += vmed;
+                        vzl += vmed;
                     }
-                    const v2f vzl = vz * il2;
                     // d alpha / d (o vis) is 1 below the clamp, 0 at it; and nothing flows through a pixel that skipped
                     const bool un0 = __builtin_amdgcn_inverse_ballot_w64(okm0 & __ballot(ov.x <= amax));
                     const bool un1 = __builtin_amdgcn_inverse_ballot_w64(okm1 & __ballot(ov.y <= amax));
                     v2f vam;
                     vam.x = un0 ? v_a.x : 0.f; vam.y = un1 ? v_a.y : 0.f;
-                    const v2f v_e = (kLn2 * ov) * vam;
+                    const v2f v_e = MSUM ? ov * vam : (kLn2 * ov) * vam;    // (MSUM: -dL/dsigma, the row scales carry no log2 e)
                     const v2f dxve = dx * v_e;
-                    const v2f vmx = (2.0f * q0.z * dx + bdy) * v_e - vzl * q1.w;
-                    const v2f vmy = (c1y + q0.w * dx) * v_e - vzl * q2.x;
                     // Per-Gaussian sums over the lane's two pixels.  A packed multiply costs two plain issue slots on gfx950
                     // (scripts/ubench/valu_rates.hip), so forming 16 packed products and then adding their halves (48 slots)
                     // loses against scalar mul + fma on the halves (<= 2 per component) with shared factors pulled out: 28.
                     const float s_ve = v_e.x + v_e.y, s_dxve = dxve.x + dxve.y, s_vzl = vzl.x + vzl.y;
-                    acc[0] = vmx.x + vmx.y; acc[1] = vmy.x + vmy.y;
-                    acc[2] = dot2(dx, dxve); acc[3] = dy * s_dxve; acc[4] = dyy * s_ve;
-                    acc[5] = dot2(vis, vam);
+                    v2f vmx, vmy;
+                    if (MSUM) {
+                        acc[0] = s_dxve; acc[1] = dy * s_ve;
+                        acc[4] = dy * acc[1];
+                    } else {
+                        const float c1y = 2.0f * q1.x * dy;
+                        vmx = (2.0f * q0.z * dx + bdy) * v_e - vzl * q1.w;
+                        vmy = (c1y + q0.w * dx) * v_e - vzl * q2.x;
+                        acc[0] = vmx.x + vmx.y; acc[1] = vmy.x + vmy.y;
+                        acc[4] = (dy * dy) * s_ve;
+                    }
+                    acc[2] = dot2(dx, dxve); acc[3] = dy * s_dxve;
+                    acc[5] = MSUM ? s_ve : dot2(vis, vam);                  // (MSUM: o times the opacity gradient)
                     acc[6] = s_vzl; acc[7] = dot2(-vzl, dx); acc[8] = ndy * s_vzl;
                     acc[9] = dot2(w, vn2[0]); acc[10] = dot2(w, vn2[1]); acc[11] = dot2(w, vn2[2]);
                     acc[12] = dot2(w, vcol2[0]);
@@ -917,7 +934,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
                         T2 *= k == 0 ? mk2(ra, 1.0f) : mk2(1.0f, ra);
                         const float Tk = T2[k];
                         const float w = a * Tk;
-                        const float zp = (tpy - q1.w * dx) * il2[k];
+                        const float zp = tpy - q1.w * dx;
                         float dot = q3.x * vcol2[0][k];
                         if (CD > 1) dot += q3.y * vcol2[CD > 1 ? 1 : 0][k];
                         if (CD > 2) dot += q3.z * vcol2[CD > 2 ? 2 : 0][k];
@@ -929,20 +946,25 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
                         dot += q2.y * vn2[0][k] + q2.z * vn2[1][k] + q2.w * vn2[2][k] + zp * vd2[k];
                         const float v_a = D2[k] * ra + Tk * dot;
                         D2 -= (k == 0 ? mk2(w, 0.f) : mk2(0.f, w)) * dot;
-                        float vz = w * vd2[k];
+                        float vzl = w * vd2[k];
                         if (batch_has_median) {
                             asm volatile("; median gradient" ::);
-                            vz += (ok && i == medi[k]) ? vm2[k] : 0.f;
+                            vzl += (ok && i == medi[k]) ? vm2[k] : 0.f;
                         }
-                        const float vzl = vz * il2[k];
                         const bool un = __builtin_amdgcn_inverse_ballot_w64(okm & __ballot(ov <= amax));
                         const float vam = un ? v_a : 0.f;
-                        const float v_e = (kLn2 * ov) * vam;
+                        const float v_e = MSUM ? ov * vam : (kLn2 * ov) * vam;
                         const float dxve = dx * v_e;
-                        acc[0] = (2.0f * q0.z * dx + bdy) * v_e - vzl * q1.w;
-                        acc[1] = (2.0f * q1.x * dy + q0.w * dx) * v_e - vzl * q2.x;
-                        acc[2] = dx * dxve; acc[3] = dy * dxve; acc[4] = (dy * dy) * v_e;
-                        acc[5] = vis * vam;
+                        if (MSUM) {
+                            acc[0] = dxve; acc[1] = dy * v_e;
+                            acc[4] = dy * acc[1];
+                        } else {
+                            acc[0] = (2.0f * q0.z * dx + bdy) * v_e - vzl * q1.w;
+                            acc[1] = (2.0f * q1.x * dy + q0.w * dx) * v_e - vzl * q2.x;
+                            acc[4] = (dy * dy) * v_e;
+                        }
+                        acc[2] = dx * dxve; acc[3] = dy * dxve;
+                        acc[5] = MSUM ? v_e : vis * vam;
                         acc[6] = vzl; acc[7] = -vzl * dx; acc[8] = -dy * vzl;
                         acc[9] = w * vn2[0][k]; acc[10] = w * vn2[1][k]; acc[11] = w * vn2[2][k];
                         acc[12] = w * vcol2[0][k];
@@ -1453,8 +1475,8 @@ int misplat_internal::blend_bwd_atomic(const misplat_params* p, int32_t color_di
                                        const float* render, const float* v_render, const float* v_alpha,
                                        const float* v_exp_depth, const float* v_med_depth, const float* v_normal,
                                        float* v_grec, float* v_abs, int32_t v_grec_is_zero, const FillList* fills,
-                                       hipStream_t s) {
-    if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !v_grec) return MISPLAT_EINVAL;
+                                       hipStream_t s, bool mean_sums) {
+    if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || !v_grec || (mean_sums && v_abs)) return MISPLAT_EINVAL;
     const size_t rows = (size_t)p->n_gauss * p->n_cams;
     if (rows == 0) return MISPLAT_OK;
     if (rows >= ((size_t)1 << 26)) return MISPLAT_EINVAL;   // the kernels address gradient rows with 32-bit byte offsets (64 B each)
@@ -1486,13 +1508,19 @@ int misplat_internal::blend_bwd_atomic(const misplat_params* p, int32_t color_di
                        (const float4*)grec, flatten_ids, (const int32_t*)nullptr, offsets, n_isects, alpha,    \
                        last_ids, median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal,    \
                        v_grec, v_abs, (uint8_t*)nullptr, (const float4*)nullptr, (float*)nullptr, CD_, F)
-#define DISPATCH_BWDA(CD_) do { if (v_abs) LAUNCH_BWDA(CD_, true); else LAUNCH_BWDA(CD_, false); } while (0)
+#define LAUNCH_BWDA_MSUM(CD_)                                                                                \
+    hipLaunchKernelGGL((blend_bwd_kernel<CD_, kPpl, false, true, 0, true>), dim3(grid), dim3(64), 0, s, *p, Ks, \
+                       (const float4*)grec, flatten_ids, (const int32_t*)nullptr, offsets, n_isects, alpha,    \
+                       last_ids, median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal,    \
+                       v_grec, v_abs, (uint8_t*)nullptr, (const float4*)nullptr, (float*)nullptr, CD_, F)
+#define DISPATCH_BWDA(CD_) do { if (v_abs) LAUNCH_BWDA(CD_, true); else if (mean_sums) LAUNCH_BWDA_MSUM(CD_); else LAUNCH_BWDA(CD_, false); } while (0)
     if (color_dim == 1) DISPATCH_BWDA(1);
     else if (color_dim == 2) DISPATCH_BWDA(2);
     else if (color_dim == 3) DISPATCH_BWDA(3);
     else if (color_dim == 4) DISPATCH_BWDA(4);
     else return MISPLAT_EINVAL;
 #undef DISPATCH_BWDA
+#undef LAUNCH_BWDA_MSUM
 #undef LAUNCH_BWDA
     return check_launch();
 }
@@ -1510,7 +1538,7 @@ extern "C" int misplat_blend_bwd_atomic(const misplat_params* p, int32_t color_d
                                         int32_t v_grec_is_zero, misplat_stream_t stream) {
     return misplat_internal::blend_bwd_atomic(p, color_dim, Ks, grec, flatten_ids, offsets, n_isects, alpha, last_ids,
                                               median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal,
-                                              v_grec, v_abs, v_grec_is_zero, nullptr, (hipStream_t)stream);
+                                              v_grec, v_abs, v_grec_is_zero, nullptr, (hipStream_t)stream, false);
 }
 
 // ---- N-D colours: D' = n_channels in 5..20 composited in ONE pass.

@@ -33,7 +33,9 @@ int blend_bwd_atomic(const misplat_params* p, int32_t color_dim, const float* Ks
                      const int32_t* offsets, int64_t n_isects, const float* alpha, const int32_t* last_ids,
                      const int32_t* median_ids, const float* render, const float* v_render, const float* v_alpha,
                      const float* v_exp_depth, const float* v_med_depth, const float* v_normal, float* v_grec, float* v_abs,
-                     int32_t v_grec_is_zero, const FillList* fills, hipStream_t s);
+                     int32_t v_grec_is_zero, const FillList* fills, hipStream_t s,
+                     bool mean_sums = false /* row slots 0 - 1 = sums the mean2d gradient is linear in (blend_bwd_kernel, MSUM): for
+                                               gauss_bwd_sparse with the same flag; v_abs must be NULL */);
 
 // misplat_project_pack_fwd whose on-demand-colour mode (lazy_rows != NULL: colour slots start UNSET) clears the gradient
 // rows only when clear_lazy_rows is set -- otherwise blend_fwd_lazy clears the rows it reaches (below).  order_table /
@@ -74,7 +76,8 @@ int gauss_bwd_sparse(const misplat_params* p, int32_t sh_degree, int32_t depth_s
                      float* v_means2d_out /* or NULL: [N,2] (cleared like the others), columns 0:2 of the flagged rows */,
                      hipStream_t s, const float* v_featx = nullptr, int32_t nxq = 0,
                      float* v_features = nullptr /* N-D records: [N, n_feat] (cleared like the others), the flagged rows */,
-                     int32_t n_feat = 0, int32_t depth_in_featx = 0);
+                     int32_t n_feat = 0, int32_t depth_in_featx = 0,
+                     bool mean_sums = false /* the rows' slots 0 - 1 are blend_bwd_atomic(mean_sums)'s sums */);
 
 // Bucket entries in index mode (bucket_tiles(indexed)): position in the cell-ordered row list in the low 23 bits, a 9-bit
 // MONOTONE code of the row's depth above them (6 bits of the float's exponent from 2^-7 up, 3 bits of mantissa: buckets 9 %

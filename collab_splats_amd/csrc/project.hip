@@ -222,16 +222,30 @@ __global__ __launch_bounds__(256) void project_fwd_kernel(
 
 struct ProjGrads {
     float v_m2d[2], v_depth, v_conic[3], v_comp, v_rt, v_rp[2], v_nr[3];
+    // m2d_sums: v_m2d holds (sum dx dL/dsigma, sum dy dL/dsigma) of the compositing backward's MSUM form (blend.hip): the mean2d
+    // gradient is formed here from the recomputed conic and ray plane -- and left in v_m2d for the caller
+    bool m2d_sums = false;
 };
 
 // Backward of project_one + rade_extras for ONE (camera, Gaussian); ACCUMULATES into o_m/o_q/o_s.
 __device__ __forceinline__ void project_bwd_one(const float* mean, const float* quat, const float* sc,
-                                                const Cam& cam, const misplat_params& P, const ProjGrads& G,
+                                                const Cam& cam, const misplat_params& P, ProjGrads& G,
                                                 float* o_m, float* o_q, float* o_s) {
     ProjState S;
-    if (!project_one(mean, quat, sc, cam, P, S)) return;
+    if (!project_one(mean, quat, sc, cam, P, S)) {
+        if (G.m2d_sums) { G.v_m2d[0] = 0.f; G.v_m2d[1] = 0.f; }
+        return;
+    }
     float rt, rp[2], nr[3];
     rade_extras(sc, cam, P, S, rt, rp, nr);
+    if (G.m2d_sums) {
+        // sigma = (a dx^2 + c dy^2) / 2 + b dx dy with the conic the forward packed (project_pack: c/det, -b/det, a/det), and the
+        // pixel's depth  (rt - rp . d) / |ray|  falls with d: v_mean2d = conic (s0, s1) - rp v_rt
+        const float ca = S.c / S.det, cb = -S.b / S.det, cc = S.a / S.det;
+        const float s0 = G.v_m2d[0], s1 = G.v_m2d[1];
+        G.v_m2d[0] = ca * s0 + cb * s1 - rp[0] * G.v_rt;
+        G.v_m2d[1] = cb * s0 + cc * s1 - rp[1] * G.v_rt;
+    }
     const float* Rw = cam.Rw;
     float z = S.mu[2], rz = 1.0f / z, rz2 = rz * rz;
     float v_mu[3] = {0.f, 0.f, 0.f}, v_u = 0.f, v_v = 0.f, v_s[3] = {0.f, 0.f, 0.f};
@@ -1349,7 +1363,7 @@ __device__ __forceinline__ void pp_bwd_row(const misplat_params& P, const Cam& c
                                            const float* __restrict__ v_grec, const float (&dir)[3], float* __restrict__ v_means,
                                            float* __restrict__ v_quats, float* __restrict__ v_scales,
                                            float* __restrict__ v_opacities, const float* __restrict__ v_depth_rows = nullptr,
-                                           int v_depth_stride = 0) {
+                                           int v_depth_stride = 0, bool mean_sums = false, float2* __restrict__ m2d_out = nullptr) {
     float mean[3] = {means[3 * g], means[3 * g + 1], means[3 * g + 2]};
     float quat[4] = {quats[4 * g], quats[4 * g + 1], quats[4 * g + 2], quats[4 * g + 3]};
     float sc[3] = {scales[3 * g], scales[3 * g + 1], scales[3 * g + 2]};
@@ -1362,8 +1376,13 @@ __device__ __forceinline__ void pp_bwd_row(const misplat_params& P, const Cam& c
     ProjGrads G;
     G.v_m2d[0] = v_means2d ? v_means2d[2 * g] : g0.x;
     G.v_m2d[1] = v_means2d ? v_means2d[2 * g + 1] : g0.y;
+    G.m2d_sums = mean_sums;
     G.v_conic[0] = g0.z; G.v_conic[1] = g0.w; G.v_conic[2] = g1.x;
-    const float v_oeff = g1.y;
+    float v_oeff = g1.y;
+    if (mean_sums) {                       // (slot 5 = o_eff times the gradient: blend.hip, MSUM; a flagged row has o_eff >= 1/255)
+        const float oe = P.antialiased ? opac * comps[g] : opac;
+        v_oeff = oe > 0.f ? v_oeff / oe : 0.f;
+    }
     G.v_rt = g1.z; G.v_rp[0] = g1.w; G.v_rp[1] = g2.x;
     G.v_nr[0] = g2.y; G.v_nr[1] = g2.z; G.v_nr[2] = g2.w;
     G.v_depth = depth_slot == 12 ? g3.x : (depth_slot == 13 ? g3.y : (depth_slot == 14 ? g3.z : (depth_slot == 15 ? g3.w : 0.f)));
@@ -1371,6 +1390,7 @@ __device__ __forceinline__ void pp_bwd_row(const misplat_params& P, const Cam& c
     if (P.antialiased) { o_op += v_oeff * comps[g]; G.v_comp = v_oeff * opac; }
     else { o_op += v_oeff; G.v_comp = 0.f; }
     project_bwd_one(mean, quat, sc, cam, P, G, o_m, o_q, o_s);
+    if (m2d_out) m2d_out[g] = make_float2(G.v_m2d[0], G.v_m2d[1]);       // (meta["means2d"].grad of the row)
     if (P.activations & 1) { o_s[0] *= sc[0]; o_s[1] *= sc[1]; o_s[2] *= sc[2]; }       // d exp(x) = exp(x) dx
     if (P.activations & 2) o_op *= opac * (1.0f - opac);                                 // d sigmoid(x) = s (1 - s) dx
 #pragma unroll
@@ -1550,7 +1570,7 @@ __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
     const float* __restrict__ comps, const float* __restrict__ v_grec, float* __restrict__ v_coeffs,
     float* __restrict__ v_coeffs_rest, float* __restrict__ v_means, float* __restrict__ v_quats, float* __restrict__ v_scales,
     float* __restrict__ v_opacities, float2* __restrict__ v_m2d, const float* __restrict__ v_featx, int nx,
-    float* __restrict__ v_features, int n_feat, int depth_in_featx) {
+    float* __restrict__ v_features, int n_feat, int depth_in_featx, int mean_sums) {
     // (N-D records, v_features != NULL: the flagged rows' feature gradients are picked from the record row's slot 15 and the
     // featx row -- color_copy_x_bwd's job for these rows --, the depth gradient rides behind the last feature in featx)
     __shared__ int queue[128];
@@ -1570,8 +1590,8 @@ __global__ __launch_bounds__(64) void gauss_bwd_sparse_kernel(
                            stage, rows, dir);
         if (active) {
             pp_bwd_row(P, cam, depth_slot, g, means, quats, scales, opacities, comps, nullptr, v_grec, dir, v_means, v_quats,
-                       v_scales, v_opacities, depth_in_featx ? v_featx + (n_feat - 1) : nullptr, depth_in_featx ? nx : 0);
-            if (v_m2d) v_m2d[g] = *reinterpret_cast<const float2*>(v_grec + (size_t)g * MISPLAT_REC);
+                       v_scales, v_opacities, depth_in_featx ? v_featx + (n_feat - 1) : nullptr, depth_in_featx ? nx : 0,
+                       mean_sums != 0, v_m2d);
             if (v_features) {
                 const float* gx = v_featx + (size_t)g * nx;
                 float* o = v_features + (size_t)g * n_feat;
@@ -1833,7 +1853,7 @@ int misplat_internal::gauss_bwd_sparse(const misplat_params* p, int32_t sh_degre
                                        const float* v_grec, float* v_coeffs, float* v_coeffs_rest, float* v_means, float* v_quats,
                                        float* v_scales, float* v_opacities, float* v_means2d_out, hipStream_t s,
                                        const float* v_featx, int32_t nxq, float* v_features, int32_t n_feat,
-                                       int32_t depth_in_featx) {
+                                       int32_t depth_in_featx, bool mean_sums) {
     if (!p || p->n_gauss < 1 || p->n_cams != 1 || !p->touched || sh_degree < 0 || sh_degree > 3) return MISPLAT_EINVAL;
     if (v_features && (!v_featx || nxq < 1 || nxq > 4 || n_feat < 1 || n_feat - 1 + (depth_in_featx ? 1 : 0) > 4 * nxq ||
                        (depth_in_featx && depth_slot != -1)))
@@ -1856,7 +1876,7 @@ int misplat_internal::gauss_bwd_sparse(const misplat_params* p, int32_t sh_degre
     hipLaunchKernelGGL((gauss_bwd_sparse_kernel<SPLIT_, FPL_>), dim3((unsigned)waves), dim3(64), 0, s, *p, sh_degree, depth_slot, \
                        means, quats, scales, opacities, viewmats, Ks, coeffs, coeffs_rest, compensations, v_grec, v_coeffs,  \
                        v_coeffs_rest, v_means, v_quats, v_scales, v_opacities, (float2*)v_means2d_out, v_featx, 4 * (int)nxq, \
-                       v_features, (int)n_feat, (int)depth_in_featx)
+                       v_features, (int)n_feat, (int)depth_in_featx, mean_sums ? 1 : 0)
     if (coeffs_rest) { if (fine) LAUNCH_SPARSE(true, 4); else LAUNCH_SPARSE(true, 8); }
     else { if (fine) LAUNCH_SPARSE(false, 4); else LAUNCH_SPARSE(false, 8); }
 #undef LAUNCH_SPARSE

@@ -448,18 +448,25 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
                                         b->compensations, b->v_means2d, b->v_grec, b->sh_degree >= 0 ? b->v_means_dir : nullptr,
                                         b->v_means, b->v_quats, b->v_scales, b->v_opacities, v_depth_rows, stride, (misplat_stream_t)s);
     }
+    // the flagged-row form without absgrad: the rows are read by gauss_bwd_sparse alone, and their mean2d slots carry the two sums
+    // that gradient is linear in (blend.hip, MSUM) -- formed per row there instead of per pixel here
+#if defined(MISPLAT_DIAG_NO_MEAN_SUMS)          // (diagnostic build, scripts/build_variant.sh: the per-pixel form everywhere)
+    const bool mean_sums = false;
+#else
+    const bool mean_sums = background && !b->v_abs;
+#endif
     if (b->ev_blend_begin && hipEventRecord((hipEvent_t)b->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
     int rc = misplat_internal::blend_bwd_atomic(&q, b->color_dim, b->Ks, b->grec, b->flatten_ids, b->offsets, b->n_isects,
                                                 b->alpha, b->last_ids, b->median_ids, b->render, b->v_render, b->v_alpha,
                                                 b->v_exp_depth, b->v_med_depth, b->v_normal, b->v_grec, b->v_abs, b->zero_flags,
-                                                background ? &F : nullptr, s);
+                                                background ? &F : nullptr, s, mean_sums);
     if (rc != MISPLAT_OK) return rc;
     if (b->ev_blend_end && hipEventRecord((hipEvent_t)b->ev_blend_end, s) != hipSuccess) return MISPLAT_ELAUNCH;
     if (background)        // flagged rows only, both per-Gaussian stages in one launch
         return misplat_internal::gauss_bwd_sparse(p, b->sh_degree, b->depth_slot, b->means, b->quats, b->scales, b->opacities,
                                                   b->viewmats, b->Ks, b->colors, b->colors_rest, b->compensations, b->v_grec,
                                                   b->v_colors, b->v_colors_rest, b->v_means, b->v_quats, b->v_scales,
-                                                  b->v_opacities, b->v_means2d_out, s);
+                                                  b->v_opacities, b->v_means2d_out, s, nullptr, 0, nullptr, 0, 0, mean_sums);
     rc = misplat_color_bwd(p, b->sh_degree, b->K_or_D, b->n_color, b->per_cam, b->means, b->viewmats, b->colors, b->colors_rest,
                            b->radii, b->v_grec, b->v_colors, b->v_colors_rest, b->v_means_dir, b->sh_aux, (misplat_stream_t)s);
     if (rc != MISPLAT_OK) return rc;
