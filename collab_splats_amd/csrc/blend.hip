@@ -708,7 +708,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
     uint8_t* __restrict__ valid, const float4* __restrict__ featx = nullptr, float* __restrict__ v_featx = nullptr,
     int n_channels = CD, misplat_internal::FillList F = {}, FeatSrc fsrc = FeatSrc()) {
     static_assert(NXQ == 0 || ATOMIC, "N-D colours: atomic gradient mode only");
-    static_assert(!MSUM || (ATOMIC && !ABS && NXQ == 0), "sums for the mean2d gradient: the flagged-row backward without absgrad");
+    static_assert(!MSUM || (ATOMIC && !ABS), "sums for the mean2d gradient: the flagged-row backward without absgrad");
     static_assert(PPL == 2, "a band is two 8 x 8 halves, one pixel of each per lane");
     // Background role (F.blocks > 0): the last workgroups of the grid -- dispatched when the machine starts to drain --
     // or (at_head: fills too large for the tail) the first ones clear the tensors the per-Gaussian backward kernels write
@@ -1608,7 +1608,7 @@ extern "C" int misplat_blend_bwd_x_atomic(const misplat_params* p, int32_t n_cha
                                           float* v_featx, float* v_abs, misplat_stream_t stream) {
     return misplat_internal::blend_bwd_x_atomic(p, n_channels, nxq, Ks, grec, featx, flatten_ids, offsets, n_isects, alpha, last_ids,
                                                 median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal, v_grec,
-                                                v_featx, v_abs, 0, nullptr, (hipStream_t)stream, nullptr, 0, 0, nullptr);
+                                                v_featx, v_abs, 0, nullptr, (hipStream_t)stream, nullptr, 0, 0, nullptr, false);
 }
 
 int misplat_internal::blend_bwd_x_atomic(const misplat_params* p, int32_t n_channels, int32_t nxq, const float* Ks,
@@ -1619,10 +1619,10 @@ int misplat_internal::blend_bwd_x_atomic(const misplat_params* p, int32_t n_chan
                                          const float* v_med_depth, const float* v_normal, float* v_grec,
                                          float* v_featx, float* v_abs, int32_t zero_flags, const FillList* fills,
                                          hipStream_t stream, const float* features, int32_t n_feat, int32_t depth_channel,
-                                         const float* depths) {
+                                         const float* depths, bool mean_sums) {
     // featx == NULL: channels 4.. straight from features [N, n_feat] (+ depths): the forward ran with on-demand records
     if (!params_ok(p) || n_isects < 0 || n_isects > 0x7fffffffLL || nxq < 1 || nxq > 4 || n_channels < 5 ||
-        n_channels > 4 + 4 * nxq || !v_grec || !v_featx)
+        n_channels > 4 + 4 * nxq || !v_grec || !v_featx || (mean_sums && v_abs))
         return MISPLAT_EINVAL;
     if (!featx && (!features || n_feat < 1 || 3 + n_feat + (depth_channel ? 1 : 0) != n_channels || (depth_channel && !depths) ||
                    p->n_cams != 1))
@@ -1656,15 +1656,16 @@ int misplat_internal::blend_bwd_x_atomic(const misplat_params* p, int32_t n_chan
     if (n_isects == 0) return MISPLAT_OK;
     const int total = p->tile_w * p->tile_h * p->n_cams * kBands;
     const int grid = ((total + 7) / 8) * 8 + F.blocks;
-#define LAUNCH_BWDX(NXQ_, ABS_)                                                                              \
-    hipLaunchKernelGGL((blend_bwd_kernel<4, 2, ABS_, true, NXQ_>), dim3(grid), dim3(64), 0, s, *p, Ks,          \
+#define LAUNCH_BWDX(NXQ_, ABS_, MSUM_)                                                                       \
+    hipLaunchKernelGGL((blend_bwd_kernel<4, 2, ABS_, true, NXQ_, MSUM_>), dim3(grid), dim3(64), 0, s, *p, Ks,   \
                        (const float4*)grec, flatten_ids, (const int32_t*)nullptr, offsets, n_isects, alpha,    \
                        last_ids, median_ids, render, v_render, v_alpha, v_exp_depth, v_med_depth, v_normal,    \
                        v_grec, v_abs, (uint8_t*)nullptr, (const float4*)featx, v_featx, n_channels, F, fsrc)
 #define DISPATCH_BWDX(NXQ_)                     \
     do {                                        \
-        if (v_abs) LAUNCH_BWDX(NXQ_, true);     \
-        else LAUNCH_BWDX(NXQ_, false);          \
+        if (v_abs) LAUNCH_BWDX(NXQ_, true, false);     \
+        else if (mean_sums) LAUNCH_BWDX(NXQ_, false, true); \
+        else LAUNCH_BWDX(NXQ_, false, false);          \
     } while (0)
     if (nxq == 1) DISPATCH_BWDX(1);
     else if (nxq == 2) DISPATCH_BWDX(2);

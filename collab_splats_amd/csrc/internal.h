@@ -150,6 +150,7 @@ int blend_bwd_x_atomic(const misplat_params* p, int32_t n_channels, int32_t nxq,
                        const float* v_normal, float* v_grec, float* v_featx, float* v_abs, int32_t zero_flags,
                        const FillList* fills /* or NULL: as blend_bwd_atomic */, hipStream_t s,
                        const float* features = nullptr /* featx == NULL: channels 4.. from features [N, n_feat] (+ depths) */,
-                       int32_t n_feat = 0, int32_t depth_channel = 0, const float* depths = nullptr);
+                       int32_t n_feat = 0, int32_t depth_channel = 0, const float* depths = nullptr,
+                       bool mean_sums = false /* as blend_bwd_atomic */);
 
 }  // namespace misplat_internal

@@ -410,6 +410,13 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
         if (b->v_means2d_out) add(b->v_means2d_out, n * 2);
         if (b->nxq > 0) add(b->v_features, n * b->n_feat);
     }
+    // the flagged-row form without absgrad: the rows are read by gauss_bwd_sparse alone, and their mean2d slots carry the two sums
+    // that gradient is linear in (blend.hip, MSUM) -- formed per row there instead of per pixel here
+#if defined(MISPLAT_DIAG_NO_MEAN_SUMS)          // (diagnostic build, scripts/build_variant.sh: the per-pixel form everywhere)
+    const bool mean_sums = false;
+#else
+    const bool mean_sums = background && !b->v_abs;
+#endif
     if (b->nxq > 0) {
         // N-D channels: compositing backward over record + featx rows, then the colour stage's backward, then the projection's
         if (!b->v_featx || b->nxq > 4 || (!b->featx && !(b->features && b->sh_degree >= 0))) return MISPLAT_EINVAL;
@@ -418,7 +425,7 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
                                                       b->n_isects, b->alpha, b->last_ids, b->median_ids, b->render, b->v_render,
                                                       b->v_alpha, b->v_exp_depth, b->v_med_depth, b->v_normal, b->v_grec,
                                                       b->v_featx, b->v_abs, b->zero_flags, background ? &F : nullptr, s,
-                                                      b->features, b->n_feat, b->depth_channel, b->depths);
+                                                      b->features, b->n_feat, b->depth_channel, b->depths, mean_sums);
         if (rx != MISPLAT_OK) return rx;
         if (b->ev_blend_end && hipEventRecord((hipEvent_t)b->ev_blend_end, s) != hipSuccess) return MISPLAT_ELAUNCH;
         if (background)    // flagged rows only: SH backward, feature gradients and the projection backward in one launch
@@ -426,7 +433,7 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
                                                       b->Ks, b->colors, b->colors_rest, b->compensations, b->v_grec, b->v_colors,
                                                       b->v_colors_rest, b->v_means, b->v_quats, b->v_scales, b->v_opacities,
                                                       b->v_means2d_out, s, b->v_featx, b->nxq, b->v_features, b->n_feat,
-                                                      b->depth_channel ? 1 : 0);
+                                                      b->depth_channel ? 1 : 0, mean_sums);
         const int n_pre = b->sh_degree >= 0 ? 3 : 0, d_src = b->sh_degree >= 0 ? b->n_feat : b->K_or_D;
         if (b->sh_degree >= 0) {
             if (!b->v_features || !b->v_means_dir) return MISPLAT_EINVAL;
@@ -448,13 +455,6 @@ static int enqueue_backward(const misplat_params* p, const misplat_raster_bwd_ar
                                         b->compensations, b->v_means2d, b->v_grec, b->sh_degree >= 0 ? b->v_means_dir : nullptr,
                                         b->v_means, b->v_quats, b->v_scales, b->v_opacities, v_depth_rows, stride, (misplat_stream_t)s);
     }
-    // the flagged-row form without absgrad: the rows are read by gauss_bwd_sparse alone, and their mean2d slots carry the two sums
-    // that gradient is linear in (blend.hip, MSUM) -- formed per row there instead of per pixel here
-#if defined(MISPLAT_DIAG_NO_MEAN_SUMS)          // (diagnostic build, scripts/build_variant.sh: the per-pixel form everywhere)
-    const bool mean_sums = false;
-#else
-    const bool mean_sums = background && !b->v_abs;
-#endif
     if (b->ev_blend_begin && hipEventRecord((hipEvent_t)b->ev_blend_begin, s) != hipSuccess) return MISPLAT_ELAUNCH;
     int rc = misplat_internal::blend_bwd_atomic(&q, b->color_dim, b->Ks, b->grec, b->flatten_ids, b->offsets, b->n_isects,
                                                 b->alpha, b->last_ids, b->median_ids, b->render, b->v_render, b->v_alpha,
