@@ -218,7 +218,7 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
                                              const float4* grec,
                                              const int32_t* __restrict__ flatten_ids,
                                              const int32_t* __restrict__ slots, float xlo, float xhi,
-                                             float ylo, float yhi, float alpha_min,
+                                             float ylo, float yhi, float alpha_min, float alpha_max,
                                              float4* smx = nullptr, const float4* __restrict__ featx = nullptr,
                                              const LazyColour* lz = nullptr, const FeatSrc* fs = nullptr, int* n_both = nullptr) {
     float4 q0, q1, q2, q3;
@@ -240,6 +240,9 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
             sub = (bound * __builtin_amdgcn_exp2f(-s0 * kLog2e) >= alpha_min ? 1 : 0) |
                   (bound * __builtin_amdgcn_exp2f(-s1 * kLog2e) >= alpha_min ? 2 : 0);
             keep = sub != 0;
+            // bit 2: the opacity is above alpha_max, so alpha = min(alpha_max, o vis) CAN clamp for this Gaussian; for every other
+            // one (vis <= 1 where sigma >= 0) the backward's trips skip the clamp and its test
+            if (q1.y > alpha_max) sub |= 4;
         } else {
             const float smin = sigma_min_box(q0.z, q0.w, q1.x, -q0.w * __builtin_amdgcn_rcpf(q1.x), -q0.w * __builtin_amdgcn_rcpf(q0.z),
                                              q0.x - xhi, q0.x - xlo, q0.y - yhi, q0.y - ylo);
@@ -255,7 +258,7 @@ __device__ __forceinline__ int stage_records(float4* sm, int* sm_idx, int* sm_sl
             q3 = lazy_colour<NXQ>(*lz, g);
     }
     const unsigned long long mask = __ballot(keep);
-    if (HALVES && n_both) *n_both = __popcll(__ballot(sub == 3));
+    if (HALVES && n_both) *n_both = __popcll(__ballot((sub & 3) == 3));
     if (keep) {
         const int pos = __popcll(mask & ((1ull << lane) - 1ull));
         q0.z *= -0.5f * kLog2e; q0.w *= -kLog2e; q1.x *= -0.5f * kLog2e;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
         __syncthreads();
         int n_both = 0;
         const int n = stage_records<NXQ, LAZY, true>(sm, sm_idx, nullptr, nullptr, lane, bs + lane, bs + lane < c.end, grec, flatten_ids,
-                                                     nullptr, xlo, xhi, ylo, yhi, amin, smx, featx, &lz, (LAZY && NXQ > 0) ? &fsrc : nullptr, &n_both);
+                                                     nullptr, xlo, xhi, ylo, yhi, amin, amax, smx, featx, &lz, (LAZY && NXQ > 0) ? &fsrc : nullptr, &n_both);
         __syncthreads();
         reach_end = min(bs + 64, c.end);
         if (n == 0) continue;
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
         const int bs = c.beg + (b << 6);
         __syncthreads();
         const int n = stage_records<NXQ, false, true>(sm, sm_idx, sm_slot, sm_sub, lane, bs + lane, bs + lane <= maxlast, grec, flatten_ids,
-                                         ATOMIC ? nullptr : slots, xlo, xhi, ylo, yhi, amin, smx, featx, nullptr,
+                                         ATOMIC ? nullptr : slots, xlo, xhi, ylo, yhi, amin, amax, smx, featx, nullptr,
                                          NXQ > 0 ? &fsrc : nullptr);
         __syncthreads();
         if (n == 0) continue;
@@ -822,7 +825,9 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
             // The halves this trip has to run: those the staged box test admits AND whose pixels reach this deep
             // (i <= the half's deepest last_id) -- all wave-uniform, so a real scalar branch per half.
             const int i = __builtin_amdgcn_readfirstlane(iv);
-            const int sub = __builtin_amdgcn_readfirstlane(subv) & ((i <= sublast[0] ? 1 : 0) | (i <= sublast[1] ? 2 : 0));
+            const int subr = __builtin_amdgcn_readfirstlane(subv);
+            const int sub = subr & ((i <= sublast[0] ? 1 : 0) | (i <= sublast[1] ? 2 : 0));
+            const bool can_clamp = (subr & 4) != 0;        // (wave-uniform, a scalar: see stage_records)
             float acc[16];
             float accx[16];
             float ab0 = 0.f, ab1 = 0.f;
@@ -849,8 +854,14 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
                     vis.x = __builtin_amdgcn_exp2f(e.x); vis.y = __builtin_amdgcn_exp2f(e.y);
                     const v2f ov = q1.y * vis;
                     // min(alpha_max, o vis) as an unsigned minimum of the bit patterns (non-negative floats; a NaN fails e <= 0)
-                    const float am0 = __uint_as_float(min(amax_bits, __float_as_uint(ov.x)));
-                    const float am1 = __uint_as_float(min(amax_bits, __float_as_uint(ov.y)));
+                    float am0 = ov.x, am1 = ov.y;
+                    lmask below0 = ~0ull, below1 = ~0ull;       // pixels whose alpha is NOT clamped (d alpha / d (o vis) = 1)
+                    if (can_clamp) {
+                        asm volatile("; alpha_max clamp" ::);   // (a real branch: few Gaussians have o > alpha_max)
+                        am0 = __uint_as_float(min(amax_bits, __float_as_uint(ov.x)));
+                        am1 = __uint_as_float(min(amax_bits, __float_as_uint(ov.y)));
+                        below0 = __ballot(ov.x <= amax); below1 = __ballot(ov.y <= amax);
+                    }
                     const lmask okm0 = __ballot(i <= last[0]) & __ballot(e.x <= 0.f) & __ballot(am0 >= amin);
                     const lmask okm1 = __ballot(i <= last[1]) & __ballot(e.y <= 0.f) & __ballot(am1 >= amin);
                     any_ok = okm0 | okm1;
@@ -882,8 +893,8 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
                         vzl += vmed;
                     }
                     // d alpha / d (o vis) is 1 below the clamp, 0 at it; and nothing flows through a pixel that skipped
-                    const bool un0 = __builtin_amdgcn_inverse_ballot_w64(okm0 & __ballot(ov.x <= amax));
-                    const bool un1 = __builtin_amdgcn_inverse_ballot_w64(okm1 & __ballot(ov.y <= amax));
+                    const bool un0 = __builtin_amdgcn_inverse_ballot_w64(okm0 & below0);
+                    const bool un1 = __builtin_amdgcn_inverse_ballot_w64(okm1 & below1);
                     v2f vam;
                     vam.x = un0 ? v_a.x : 0.f; vam.y = un1 ? v_a.y : 0.f;
                     const v2f v_e = MSUM ? ov * vam : (kLn2 * ov) * vam;    // (MSUM: -dL/dsigma, the row scales carry no log2 e)
@@ -922,7 +933,13 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
                         const float e = pair_exponent(q0.z, dx, bdy, ecc);
                         const float vis = __builtin_amdgcn_exp2f(e);
                         const float ov = q1.y * vis;
-                        const float am = __uint_as_float(min(amax_bits, __float_as_uint(ov)));
+                        float am = ov;
+                        lmask below = ~0ull;
+                        if (can_clamp) {
+                            asm volatile("; alpha_max clamp" ::);
+                            am = __uint_as_float(min(amax_bits, __float_as_uint(ov)));
+                            below = __ballot(ov <= amax);
+                        }
                         const lmask okm = __ballot(i <= last[k]) & __ballot(e <= 0.f) & __ballot(am >= amin);
                         any_ok = okm;
                         const bool ok = __builtin_amdgcn_inverse_ballot_w64(okm);
@@ -951,7 +968,7 @@ __global__ __launch_bounds__(64, (PPL == 2 && NXQ == 0) ? MISPLAT_BWD_WAVES : (N
                             asm volatile("; median gradient" ::);
                             vzl += (ok && i == medi[k]) ? vm2[k] : 0.f;
                         }
-                        const bool un = __builtin_amdgcn_inverse_ballot_w64(okm & __ballot(ov <= amax));
+                        const bool un = __builtin_amdgcn_inverse_ballot_w64(okm & below);
                         const float vam = un ? v_a : 0.f;
                         const float v_e = MSUM ? ov * vam : (kLn2 * ov) * vam;
                         const float dxve = dx * v_e;
