@@ -533,7 +533,9 @@ typedef struct misplat_raster_bwd_args {
     const float* render;
     /* upstream gradients of the five images (all given) */
     const float *v_render, *v_alpha, *v_exp_depth, *v_med_depth, *v_normal;
-    float *v_grec, *v_abs /* or NULL */;
+    float *v_grec, *v_abs /* or NULL */;   /* v_grec is WORKSPACE of this call: in the two-launch form without v_abs its rows hold sums
+                                            * the per-Gaussian kernel finishes (slots 0 - 1, 5: csrc/blend.hip MSUM), not the layout of
+                                            * misplat_blend_bwd_atomic -- take the mean2d gradient from v_means2d_out */
     const int32_t* unit_perm /* or NULL */;
     int32_t color_dim, zero_flags;
     /* per-Gaussian backward */
