@@ -158,29 +158,30 @@ __device__ __forceinline__ float4 lazy_colour(const LazyColour& lz, int g) {
     const float* row = split ? lz.coeffs_rest + (size_t)gg * 45 - 3 : lz.coeffs + (size_t)gg * 48;
     const float* dc = split ? lz.coeffs + (size_t)gg * 3 : row;
     float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-    // The coefficients arrive in TWO round trips (terms 0 - 8, the degrees <= 2, then 9 - 15), each requested as a block before
-    // the first of its terms is used: the wave that evaluates sits in the compositing loop's staging step and every round trip
-    // is a stall of all its pixels (term by term, as the walk's scheduling groups would have it, there were eight).  27
-    // registers at a point where the trip's temporaries are dead.
+    // The coefficients arrive in FOUR round trips (terms 0 - 3, 4 - 8, 9 - 11, 12 - 15: a block per degree, the third degree in two),
+    // each requested as a block before the first of its terms is used: the wave that evaluates sits in the compositing loop's
+    // staging step and every round trip is a stall of all its pixels (term by term, as the walk's scheduling groups would have
+    // it, there were eight).  At most 15 registers at a time: two round trips (27 registers) spilled inside this branch.
     float cf[48];
-    const int n1 = lz.deg > 1 ? 9 : (lz.deg > 0 ? 4 : 1);
-    cf[0] = dc[0]; cf[1] = dc[1]; cf[2] = dc[2];
-#pragma unroll
-    for (int k = 1; k < 9; k++)
-        if (k < n1) { cf[3 * k] = row[3 * k]; cf[3 * k + 1] = row[3 * k + 1]; cf[3 * k + 2] = row[3 * k + 2]; }
-    __builtin_amdgcn_sched_barrier(0);
+#define LZ_FETCH(k0, k1)                                                                \
+    {                                                                                   \
+        _Pragma("unroll") for (int k2 = (k0); k2 < (k1); k2++) {                        \
+            const float* f_ = k2 == 0 ? dc : row + 3 * k2;                              \
+            cf[3 * k2] = f_[0]; cf[3 * k2 + 1] = f_[1]; cf[3 * k2 + 2] = f_[2];         \
+        }                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    }
+    if (lz.deg > 0) LZ_FETCH(0, 4) else LZ_FETCH(0, 1)
 #define LZ_TERM(k, B, BX, BY, BZ)                                                       \
     {                                                                                   \
-        if ((k) == 9) {                                                                 \
-            _Pragma("unroll") for (int k2 = 9; k2 < 16; k2++) {                         \
-                cf[3 * k2] = row[3 * k2]; cf[3 * k2 + 1] = row[3 * k2 + 1]; cf[3 * k2 + 2] = row[3 * k2 + 2]; \
-            }                                                                           \
-            __builtin_amdgcn_sched_barrier(0);                                          \
-        }                                                                               \
+        if ((k) == 4) LZ_FETCH(4, 9)                                                    \
+        if ((k) == 9) LZ_FETCH(9, 12)                                                   \
+        if ((k) == 12) LZ_FETCH(12, 16)                                                 \
         const float b_ = (B);                                                           \
         c0 = fmaf(b_, cf[3 * (k)], c0); c1 = fmaf(b_, cf[3 * (k) + 1], c1); c2 = fmaf(b_, cf[3 * (k) + 2], c2); \
     }
     MISPLAT_SH_WALK(lz.deg, x, y, z, LZ_TERM)
+#undef LZ_FETCH
 #undef LZ_TERM
     float w3 = 0.f;
     if (NXQ > 0) {                                             // (compile time: the 4-channel kernel must not pay for it)
@@ -376,15 +377,12 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
     // pair is on the same side of every threshold in the forward and in the backward.
     const int y = c.y0 + (lane >> 3);
     const float py = (float)y + 0.5f;
-    const float ryn = (py - c.cy) / c.fy;
-    float px[PPL], inv_ell[PPL], T[PPL], Tfin[PPL], dep[PPL], med[PPL], col[PPL][CD], nrm[PPL][3];
+    float px[PPL], T[PPL], Tfin[PPL], dep[PPL], med[PPL], col[PPL][CD], nrm[PPL][3];
     int xk[PPL], last[PPL], medi[PPL];
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
         xk[k] = c.tx * MISPLAT_TILE + 8 * k + (lane & 7);
         px[k] = (float)xk[k] + 0.5f;
-        const float rxn = (px[k] - c.cx) / c.fx;
-        inv_ell[k] = 1.0f / sqrtf(rxn * rxn + ryn * ryn + 1.0f);
         const bool inside = xk[k] < P.width && y < P.height;
         T[k] = inside ? 1.0f : 0.0f;           // T == 0  <=>  pixel finished
         Tfin[k] = 1.0f; dep[k] = 0.f; med[k] = 0.f; last[k] = -1; medi[k] = -1;
@@ -401,12 +399,12 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
     static_assert(PPL % 2 == 0, "the compositing loops work on pixel pairs");
     constexpr int NP = PPL / 2;
     constexpr int NXF = NXQ > 0 ? 4 * NXQ : 1;
-    v2f px2[NP], il2[NP], T2[NP], dep2[NP], med2[NP], col2[NP][CD], nrm2[NP][3], colx2[NP][NXF];
+    v2f px2[NP], T2[NP], dep2[NP], med2[NP], col2[NP][CD], nrm2[NP][3], colx2[NP][NXF];
     {
 #pragma unroll
         for (int kp = 0; kp < NP; kp++) {
             const int k0 = 2 * kp, k1 = 2 * kp + 1;
-            px2[kp] = mk2(px[k0], px[k1]); il2[kp] = mk2(inv_ell[k0], inv_ell[k1]);
+            px2[kp] = mk2(px[k0], px[k1]);
             T2[kp] = mk2(T[k0], T[k1]);
             dep2[kp] = mk2(0.f, 0.f); med2[kp] = mk2(0.f, 0.f);
 #pragma unroll
@@ -563,7 +561,9 @@ __global__ __launch_bounds__(64, (MISPLAT_FWD_WAVES > 0 && PPL == 2 && NXQ == 0)
                 const int k = 2 * kp + h;
                 const float Ts = h ? T2[kp].y : T2[kp].x;               // negative: terminated, magnitude = T at termination
                 T[k] = Ts > 0.f ? Ts : 0.f; Tfin[k] = fabsf(Ts);
-                const float ilk = h ? il2[kp].y : il2[kp].x;
+                // 1 / |ray| of the pixel, formed here (nothing of it lives across the loop); the backward uses the same expression
+                const float rxn = ((h ? px2[kp].y : px2[kp].x) - c.cx) / c.fx, ryn = (py - c.cy) / c.fy;
+                const float ilk = 1.0f / sqrtf(rxn * rxn + ryn * ryn + 1.0f);
                 dep[k] = (h ? dep2[kp].y : dep2[kp].x) * ilk; med[k] = (h ? med2[kp].y : med2[kp].x) * ilk;
 #pragma unroll
                 for (int ch = 0; ch < CD; ch++) col[k][ch] = h ? col2[kp][ch].y : col2[kp][ch].x;
