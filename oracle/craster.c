@@ -751,7 +751,8 @@ void cr_quad_stats(const real* means2d, const real* conics, const real* opac,
 #pragma omp for schedule(dynamic, 1)
         for (int t = 0; t < nt; t++) {
             int ty = t / tw, tx = t % tw;
-            int64_t beg = offsets[t], end = (t + 1 < nt) ? offsets[t + 1] : I;
+            int64_t beg = offsets[t];
+            (void)I;
             for (int band = 0; band < 2; band++) {
                 int y0 = band * 8;
                 if (ty * ts + y0 >= P->height) continue;
