@@ -2164,6 +2164,9 @@ _FULL_SIZE = pytest.mark.skipif((os.cpu_count() or 1) < 32, reason="the C port a
     # finished per row by the per-Gaussian kernel) -- the bench's and the model's default; the second case shifts the opacity
     # logits up by 3 (a third of the Gaussians above alpha_max = 0.99): the trips that keep the clamp and its test
     (300_000, 640, 360, None, 1.5, False, 0.0), (300_000, 640, 360, 2, 1.5, False, 3.0),
+    # (a negative shift selects rasterize_mode="classic" for the same form: no compensation factor in the opacity the row's
+    #  sixth slot is divided by)
+    (300_000, 640, 360, 4, 1.5, False, -0.5),
     # BASELINE configs[2] / [3] at full size: the headline workload on its heaviest rotated view, every gradient (round 4 had
     # this comparison in bench.py's post-timing leg only)
     pytest.param(1_000_000, 1920, 1080, 3, 1.0, False, 0.0, marks=_FULL_SIZE),
@@ -2198,7 +2201,8 @@ def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H
         sc["viewmats"] = view_matrix(view)
     log_s = (sc["log_scales"] + math.log(scale_mul)).contiguous()
     sc["opacity_logits"] = (sc["opacity_logits"] + opac_shift).contiguous()
-    if opac_shift:
+    mode = "classic" if opac_shift < 0 else "antialiased"
+    if opac_shift > 0:
         assert 0.2 < float((torch.sigmoid(sc["opacity_logits"]) > 0.99).float().mean()) < 0.6
     leaves = [t.to(dev).requires_grad_(True) for t in (sc["means"], sc["quats"], log_s, sc["opacity_logits"], sc["sh"])]
     V, K = sc["viewmats"].to(dev), sc["Ks"].to(dev)
@@ -2214,7 +2218,7 @@ def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H
         for l in leaves:
             l.grad = None
         del out
-        out = rasterization(*leaves, V, K, W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased",
+        out = rasterization(*leaves, V, K, W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode=mode,
                             absgrad=absgrad, return_depth_normal=True, scales_are_log=True, opacities_are_logit=True)
         torch.autograd.backward(list(out[:5]), ups_dev)
     torch.cuda.synchronize()
@@ -2248,7 +2252,7 @@ def test_steady_state_training_path_vs_c_port(dev, craster, monkeypatch, N, W, H
     scales_np = torch.exp(leaves[2].detach()).cpu().numpy()
     op_np = torch.sigmoid(leaves[3].detach()).cpu().numpy()
     st = cr.forward(sc["means"].numpy(), sc["quats"].numpy(), scales_np, op_np, sc["sh"].numpy(), sc["viewmats"][0].numpy(),
-                    sc["Ks"][0].numpy(), W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode="antialiased")
+                    sc["Ks"][0].numpy(), W, H, sh_degree=3, render_mode="RGB+ED", rasterize_mode=mode)
     assert np.array_equal(st["proj"]["radii"], meta["radii"][0].cpu().numpy())
     assert np.array_equal(st["proj"]["depths"].view(np.uint32), meta["depths"][0].detach().cpu().numpy().view(np.uint32))
     assert np.array_equal(st["proj"]["means2d"].view(np.uint32), meta["means2d"][0].detach().cpu().numpy().view(np.uint32))
